@@ -1,0 +1,228 @@
+"""Pins the CPU oracle against the reference's own golden outputs.
+CPU-only; no GPU, no /root/reference access at run time (fixtures are committed)."""
+import numpy as np
+import pytest
+
+from golden_util import TextIndex, eval_filter, f32_of, load_goldens, materialize, tokenize
+from host_model import brute_force_part
+from oracle import oracle as o
+
+G = load_goldens()
+M = {"L2": o.METRIC_L2, "IP": o.METRIC_IP, "Cosine": o.METRIC_COSINE}
+
+
+def check(ids, dis, case, qi=0):
+    exp_ids = np.array(case["ids"][qi], np.int64)
+    exp = f32_of(case["dists"][qi])
+    n = len(exp_ids)
+    assert ids[:n].tolist() == exp_ids.tolist()
+    assert dis[:n].tolist() == exp.tolist(), (dis[:n], exp)  # bit-exact f32
+
+
+def test_arithmetic_is_mul_then_add_not_fma():
+    # 00001: [0.1]*3 vs [3,3,3] -> 25.230003 (an fma chain would give 25.230001)
+    assert o.l2sqr([0.1] * 3, [3.0] * 3) == np.float32("25.230003")
+    assert o.ip([0.1] * 3, [98.0] * 3) == np.float32("29.400002")
+
+
+def test_c_oracle_equals_numpy_restatement():
+    rng = np.random.default_rng(5)
+    for d in (1, 3, 4, 5, 63, 64, 65, 127, 128, 200, 768, 1536):
+        Y = rng.standard_normal((40, d), dtype=np.float32) * 3
+        x = rng.standard_normal(d, dtype=np.float32)
+        a = np.array([o.l2sqr(x, y) for y in Y])
+        b = np.array([o.ip(x, y) for y in Y])
+        assert (a == o.np_l2sqr(x, Y)).all()
+        assert (b == o.np_ip(x, Y)).all()
+        a64 = ((Y.astype(np.float64) - x) ** 2).sum(1)
+        assert np.allclose(a, a64, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["00001_flat_l2", "00003_prewhere", "00008_empty_vectors"])
+def test_flat_index_goldens(name):
+    c = G[name]
+    ids, vecs, empty = materialize(c["base"])
+    alive = eval_filter(c.get("filter"), ids) & ~empty  # empty rows are never indexed (VIPartReader.h:240-244)
+    for qi, q in enumerate(c["queries"]):
+        i, d = o.knn(q, vecs, c["k"], M[c["metric"]], labels=ids, alive=alive)
+        check(i[0], d[0], c, qi)
+
+
+@pytest.mark.parametrize("name", ["00002_batch_l2", "00002_batch_ip"])
+def test_batch_distance_two_parts(name):
+    c = G[name]
+    k = c["k"]
+    per_part = []
+    for segs in c["parts"]:
+        ids, vecs, _ = materialize(segs)
+        i, d = o.knn(np.array(c["queries"], np.float32), vecs, k, M[c["metric"]], labels=ids)
+        per_part.append((i, d))
+    for qi in range(len(c["queries"])):
+        # ORDER BY dist.1, dist.2 [DESC] LIMIT 10 BY dist.1 over the union of the parts' results
+        ids = np.concatenate([p[0][qi] for p in per_part])
+        dis = np.concatenate([p[1][qi] for p in per_part])
+        order = np.argsort(-dis if c["metric"] == "IP" else dis, kind="stable")[:k]
+        check(ids[order], dis[order], c, qi)
+
+
+@pytest.mark.parametrize("name", ["00012_brute_force", "00009_brute_force_filter", "00010_brute_force_filter",
+                                  "00011_brute_force_filter", "00014_cosine_bruteforce"])
+def test_brute_force_block_loop(name):
+    c = G[name]
+    ids, vecs, empty = materialize(c["base"])
+    filt = eval_filter(c["filter"], ids) if c.get("filter") else None
+    fid, fdist = brute_force_part(o.search_wrapper, vecs, empty, c.get("index_granularity", 8192),
+                                  c["queries"], c["k"], c["metric"], filt=filt)
+    valid = fid[0] > -1
+    got_ids = ids[fid[0][valid]]
+    assert len(got_ids) == len(c["ids"][0])
+    check(got_ids, fdist[0][valid], c)
+
+
+def test_cosine_d4_index_golden_exact_and_ivf():
+    c = G["00014_cosine_d4_index"]
+    ids, vecs, _ = materialize(c["base"])
+    i, d = o.search_without_index(np.array(c["queries"], np.float32), vecs, c["k"], o.METRIC_COSINE)
+    check(ids[i[0]], d[0], c)
+    # IVFFLAT (nprobe=32) over normalised rows reproduces the same rows: 16 lists, probing all
+    vn = o.normalize_rows(vecs)
+    cent = o.kmeans(vn, 16, 5)
+    off, lv, lids = o.build_ivf(vn, ids, cent)
+    qn = o.normalize_rows(np.array(c["queries"], np.float32))
+    ii, dd, _ = o.ivf_search(cent, off, lv, lids, qn, 32, c["k"], o.METRIC_IP)
+    check(ii[0], (np.float32(1) - dd[0]).astype(np.float32), c)
+
+
+@pytest.mark.parametrize("tag", ["l2", "cosine", "cosine_where", "cosine_lwd"])
+def test_768d_goldens(tag):
+    c = G["00028_768_" + tag]
+    ids, vecs, _ = materialize(c["base"])
+    alive = eval_filter(c.get("filter"), ids)
+    alive[np.isin(ids, c["deleted"])] = False
+    i, d = o.search_without_index(np.array(c["queries"], np.float32), vecs, c["k"], M[c["metric"]], alive=alive)
+    exp = f32_of(c["dists"][0])
+    assert i[0].tolist() == c["ids"][0]
+    # accumulation order is not pinned at d=768: compare at the north-star tolerance
+    assert np.allclose(d[0], exp, rtol=1e-4, atol=0)
+    assert np.abs(d[0] / exp - 1).max() < 2e-6
+
+
+# ------------------------------------------------------------------ BM25 + fusion
+
+def text_search(docs, query, k, alive=None, stats=None):
+    idx = TextIndex([d["texts"] for d in docs], o.fieldnorm_id)
+    terms = [t for t in tokenize(query)]
+    qt = [idx.vocab[t] for t in terms if t in idx.vocab]
+    if stats is None:
+        df = [idx.doc_freq(t) for t in terms if t in idx.vocab]
+        n, tok = idx.num_docs, idx.total_tokens
+    else:
+        df = [stats["df"][t] for t in terms if t in idx.vocab]
+        n, tok = stats["N"], stats["tokens"]
+    rows, scores = o.bm25_search(idx.post_off, idx.doc_ids, idx.tfs, idx.fieldnorm_ids, qt, df, n, tok, k, alive=alive)
+    return rows, scores
+
+
+def test_bm25_goldens():
+    c = G["00040_hybrid"]
+    docs = c["docs"]
+    rows, scores = text_search(docs, c["text_query"], c["limit"])
+    assert [docs[r]["id"] for r in rows] == c["text_search"][0]
+    assert scores.tolist() == f32_of(c["text_search"][1]).tolist()
+    alive = np.array([d["id"] < 10 for d in docs])
+    rows, scores = text_search(docs, c["text_query"], c["limit"], alive=alive)
+    assert [docs[r]["id"] for r in rows] == c["text_search_where_id_lt_10"][0]
+    assert scores.tolist() == f32_of(c["text_search_where_id_lt_10"][1]).tolist()
+
+
+def test_bm25_array_column_golden():
+    c = G["00040_text_array"]
+    rows, scores = text_search(c["docs"], c["text_query"], c["limit"])
+    assert [c["docs"][r]["id"] for r in rows] == c["text_search"][0]
+    assert scores.tolist() == f32_of(c["text_search"][1]).tolist()
+
+
+def vec_topk(docs, q, k, alive=None):
+    vecs = np.array([d["vector"] for d in docs], np.float32)
+    i, d = o.knn(q, vecs, k, o.METRIC_L2, alive=alive)
+    keep = i[0] > -1
+    return i[0][keep], d[0][keep]
+
+
+def fuse(docs, c, kind, alive=None):
+    limit = c["limit"]
+    # The goldens of 00040/00041 are only reproduced with num_candidates == LIMIT (id 13 must NOT be among the
+    # vector candidates and the RSF max-distance is id 4's 27): the .reference files predate the
+    # hybrid_search_top_k_multiple_base = 3 default of ExpressionAnalyzer.cpp:1204-1222.  num_candidates is an input
+    # of the path (VSDescription.topk), so the fixture simply passes LIMIT.
+    num_candidates = limit
+    vi, vd = vec_topk(docs, c["vec_query"], num_candidates, alive)
+    tr, ts = text_search(docs, c["text_query"], num_candidates, alive=alive)
+    z = lambda n: np.zeros(n, np.uint64)
+    s, p, l = o.hybrid_fusion(kind, (vd, z(len(vi)), vi), (ts, z(len(tr)), tr), limit)
+    return [docs[int(x)]["id"] for x in l], s
+
+
+def order_by_score_desc_id(ids, scores, limit):
+    o_ = sorted(range(len(ids)), key=lambda j: (-float(scores[j]), ids[j]))[:limit]
+    return [ids[j] for j in o_], [scores[j] for j in o_]
+
+
+def test_fusion_goldens():
+    c = G["00040_hybrid"]
+    docs = c["docs"]
+    for kind, key in (("rsf", "rsf"), ("rrf", "rrf")):
+        ids, s = fuse(docs, c, kind)
+        ids, s = order_by_score_desc_id(ids, s, c["limit"])  # outer ORDER BY score DESC, id LIMIT 5
+        assert ids == c[key][0]
+        assert np.array(s, np.float32).tolist() == f32_of(c[key][1]).tolist()
+    alive = np.array([d["id"] < 10 for d in docs])
+    ids, s = fuse(docs, c, "rsf", alive=alive)
+    ids, s = order_by_score_desc_id(ids, s, c["limit"])
+    assert ids == c["rsf_where_id_lt_10"][0]
+    assert np.array(s, np.float32).tolist() == f32_of(c["rsf_where_id_lt_10"][1]).tolist()
+
+
+def test_fusion_doc2_golden():
+    c = G["00040_hybrid_doc2"]
+    ids, s = fuse(c["docs"], c, "rsf")
+    ids, s = order_by_score_desc_id(ids, s, c["limit"])
+    assert ids == c["rsf"][0]
+    assert np.array(s, np.float32).tolist() == f32_of(c["rsf"][1]).tolist()
+
+
+def test_bm25_two_parts_global_statistics():
+    """00041: two parts scored with TABLE-level statistics give the one-part scores."""
+    c = G["00041_two_parts"]
+    docs = c["docs"]
+    whole = TextIndex([d["texts"] for d in docs], o.fieldnorm_id)
+    stats = {"N": whole.num_docs, "tokens": whole.total_tokens,
+             "df": {t: whole.doc_freq(t) for t in tokenize(c["text_query"])}}
+    res = []
+    lo = 0
+    for sz in c["part_sizes"]:
+        part = docs[lo:lo + sz]
+        rows, scores = text_search(part, c["text_query"], c["limit"], stats=stats)
+        res += [(float(s), part[int(r)]["id"]) for r, s in zip(rows, scores)]
+        lo += sz
+    res.sort(key=lambda t: -t[0])
+    assert [r[1] for r in res] == c["text_search_2parts"][0] == c["text_search_1part"][0]
+    assert [np.float32(r[0]) for r in res] == f32_of(c["text_search_2parts"][1]).tolist()
+
+
+def test_total_topk_multimap_order():
+    # ties: ascending keeps insertion order, descending reverses it (MergeTreeBaseSearchManager.cpp:207-299)
+    s = [1.0, 2.0, 2.0, 3.0]
+    parts = [0, 0, 1, 1]
+    labels = [10, 11, 12, 13]
+    a = o.total_topk(s, parts, labels, 3, desc=False)
+    assert a[2].tolist() == [10, 11, 12]
+    b = o.total_topk(s, parts, labels, 3, desc=True)
+    assert b[2].tolist() == [13, 12, 11]
+
+
+def test_fieldnorm_table():
+    # tantivy/src/fieldnorm/code.rs FIELD_NORMS_TABLE spot values
+    assert [o.fieldnorm_of_id(i) for i in (0, 1, 39, 40, 41, 48, 49, 56, 57, 255)] == \
+        [0, 1, 39, 40, 42, 56, 60, 88, 96, 2013265944]
+    assert o.fieldnorm_id(41) == 40 and o.fieldnorm_id(42) == 41 and o.fieldnorm_id(7) == 7
