@@ -1,0 +1,161 @@
+/*
+ * msvs.h -- C-ABI of libmsvs.so: the MI355X (gfx950) vector-scan / BM25 hot path for MyScaleDB.
+ *
+ * Plain pointers and sizes only.  Every entry point replaces one call the MyScaleDB host makes
+ * into its (absent) native libraries; the reference call site is cited at each declaration
+ * (paths relative to the MyScaleDB tree).  INTEGRATION.md shows the host-side shims.
+ *
+ * Conventions kept from the reference:
+ *   - ids are int64 row offsets local to the data part, -1 = "no result" (host tests `> -1`,
+ *     src/VectorIndex/Storages/MergeTreeVSManager.cpp:1507,1523); on the device they must fit u32
+ *     (the host stores labels in ColumnUInt32, MergeTreeVSManager.cpp:418-420);
+ *   - results are sorted best-first; L2 is the SQUARED distance; cosine is 1 - <x^,y^>;
+ *     IP is the raw dot product, larger is better;
+ *   - unfilled slots carry the heap's neutral value: +FLT_MAX (L2), -FLT_MAX (IP),
+ *     1 - (-FLT_MAX) (cosine, like VIWithDataPart.h:374-380);
+ *   - ties are broken by ascending id (the reference leaves this to Faiss' heap);
+ *   - filter bitmaps are LSB-first uint64 words, bit i of word i/64 <=> id i, 1 = candidate
+ *     (the shim converts Search::DenseBitmap through is_member()/to_vector()).
+ *
+ * Threading: every function may be called concurrently from many host threads (the reference
+ * allows 2 x cores concurrent searches, ScanThreadLimiter.h); index search is re-entrant on a
+ * shared immutable index.  Errors: return value != MSVS_OK and a thread-local message in
+ * msvs_last_error() -- the shim rethrows it as VIException (VICommon.h:75-104) so the host's
+ * existing fallback logic applies.  There is NO CPU fallback inside this library.
+ */
+#ifndef MSVS_H
+#define MSVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSVS_API __attribute__((visibility("default")))
+
+typedef enum msvs_status {
+    MSVS_OK = 0,
+    MSVS_ERR_INVALID_ARGUMENT = 1,
+    MSVS_ERR_NOT_IMPLEMENTED = 2, /* DB::ErrorCodes::NOT_IMPLEMENTED, BruteForceSearch.h:89-92 */
+    MSVS_ERR_DEVICE = 3,          /* HIP runtime error; message carries hipGetErrorString */
+    MSVS_ERR_OUT_OF_MEMORY = 4,
+    MSVS_ERR_NOT_READY = 5, /* index->ready() == false, VIWithDataPart.cpp:876-879 */
+    MSVS_ERR_UNSUPPORTED_K = 6,
+    MSVS_ERR_ID_RANGE = 7,
+    MSVS_ERR_IO = 8
+} msvs_status;
+
+enum msvs_metric { MSVS_METRIC_L2 = 0, MSVS_METRIC_IP = 1, MSVS_METRIC_COSINE = 2 };
+enum msvs_index_type { MSVS_INDEX_FLAT = 0, MSVS_INDEX_IVFFLAT = 1 };
+enum msvs_mem { MSVS_MEM_HOST = 0, MSVS_MEM_DEVICE = 1 };
+
+/* largest k (and nprobe) the device top-k supports */
+#define MSVS_MAX_K 256
+
+MSVS_API const char * msvs_last_error(void);
+MSVS_API const char * msvs_version(void);
+MSVS_API int msvs_device_count(int * count);
+MSVS_API int msvs_set_device(int ordinal);
+MSVS_API int msvs_device_synchronize(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Seam A2 -- brute force.  Replaces the body of
+ *   VectorIndex::tryBruteForceSearch<FloatVector>(x, y, d, k, nx, ny, result_id, distance, metric)
+ *   (src/VectorIndex/Common/BruteForceSearch.h:63-92) = faiss::knn_L2sqr / faiss::knn_inner_product.
+ * x: nx*d queries, y: ny*d base rows (row-major f32, HOST pointers); ids/dis: nx*k, caller-owned.
+ * metric: MSVS_METRIC_L2 or MSVS_METRIC_IP; anything else -> MSVS_ERR_NOT_IMPLEMENTED like the
+ * reference (cosine is composed above this call by searchWithoutIndex, VIWithDataPart.h:341-382).
+ */
+MSVS_API int msvs_knn_f32(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny, int metric,
+                          int64_t * ids, float * dis);
+
+/* VectorDataset<FloatVector>::normalize() (src/VectorIndex/Common/VectorDataset.h:98-117) on the device:
+ * sequential f32 sum of squares, rows with sum < FLT_EPSILON untouched, x /= sqrt(sum). In place, HOST pointer. */
+MSVS_API int msvs_normalize_f32(float * x, size_t n, size_t d);
+
+/* ---------------------------------------------------------------------------------------------
+ * Seam A1 -- vector index object.  Replaces Search::VectorIndex<...,FloatVector>:
+ *   createVectorIndex(name, type, metric, dim, total_vec, params, ...)   VIWithDataPart.cpp:415-446
+ *   build(reader, threads, cancel)  [train + chunked add]                VIWithDataPart.h:295-339, VIPartReader.h:170-304
+ *   search(DataSet{nq,dim}, k, params, first_stage_only, DenseBitmap*)   VIWithDataPart.cpp:922-926
+ *   ready(), numData(), getResourceUsage(), serialize()/load()           VIWithDataPart.cpp:368-385,472-479,698-700
+ * The index data lives in HBM; search never touches host copies of the vectors.
+ */
+typedef struct msvs_index msvs_index_t;
+
+/* params: "key=value" pairs separated by ',' or a flat JSON object, e.g. "ncentroids=1024" /
+ * {"ncentroids":"1024"}.  IVFFLAT build params: ncentroids (default 1024), kmeans_iters (10),
+ * train_sample (ncentroids*64), seed (1234).  Sharding for multi-GPU: shard_rank / shard_world
+ * (lists with list_id % shard_world == shard_rank are kept on this device). */
+MSVS_API int msvs_index_create(int index_type, int metric, size_t dim, const char * params, msvs_index_t ** out);
+MSVS_API void msvs_index_free(msvs_index_t * index);
+
+/* IVFFLAT: k-means over the training rows (ignored by FLAT).  mem = MSVS_MEM_HOST|MSVS_MEM_DEVICE. */
+MSVS_API int msvs_index_train(msvs_index_t * index, const float * x, size_t n, int mem);
+/* Alternative to train: adopt given coarse centroids (nlist*dim). */
+MSVS_API int msvs_index_set_centroids(msvs_index_t * index, const float * centroids, size_t nlist, int mem);
+/* One chunk of the build feed: n rows (n*dim f32) + their ids (nullable => consecutive from the current count).
+ * Mirrors Search::DataChunk{data, n, dim} + setDataID(ids) (VIPartReader.h:296-303). */
+MSVS_API int msvs_index_add(msvs_index_t * index, const float * x, const int64_t * ids, size_t n, int mem);
+/* Finalise: assign rows to lists, lay lists out contiguously (ascending id inside a list), drop staging. */
+MSVS_API int msvs_index_build(msvs_index_t * index);
+MSVS_API int msvs_index_ready(const msvs_index_t * index);
+MSVS_API size_t msvs_index_num_data(const msvs_index_t * index);
+MSVS_API size_t msvs_index_num_lists(const msvs_index_t * index);
+MSVS_API size_t msvs_index_memory_usage(const msvs_index_t * index);
+
+/* search(): queries nq*dim f32 (HOST); params e.g. "nprobe=32" (IVFFLAT search param, validated like
+ * parseVSParameters.cpp:43-222); alive_bits nullable, nbits = number of valid bits; ids/dis nq*k (HOST). */
+MSVS_API int msvs_index_search(const msvs_index_t * index, const float * queries, size_t nq, int k,
+                               const char * params, const uint64_t * alive_bits, size_t nbits, int64_t * ids,
+                               float * dis);
+/* Same with DEVICE pointers, enqueued on `hip_stream` (hipStream_t, NULL = default stream) without host
+ * synchronisation: the form a GPU-resident host pipeline (and bench.py) uses. */
+MSVS_API int msvs_index_search_device(const msvs_index_t * index, const float * d_queries, size_t nq, int k,
+                                      int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
+                                      float * d_dis, void * hip_stream);
+
+/* Export the index structure (for parity checks against the oracle and for serialisation):
+ * any output may be NULL; sizes: centroids nlist*dim, list_off nlist+1, vecs num_data*dim, ids num_data.
+ * Cosine indexes export the stored (normalised) rows. */
+MSVS_API int msvs_index_export(const msvs_index_t * index, float * centroids, int64_t * list_off, float * vecs,
+                               int64_t * ids);
+MSVS_API int msvs_index_serialize(const msvs_index_t * index, const char * path);
+MSVS_API int msvs_index_load(const char * path, msvs_index_t ** out);
+
+/* Multi-part / multi-GPU merge of partial top-k lists with the canonical total order -- the
+ * device-side analogue of MergeTreeBaseSearchManager::getTotalTopSearchResultImpl
+ * (src/VectorIndex/Storages/MergeTreeBaseSearchManager.cpp:207-299) for lists that share one id space.
+ * ids/dis: [nparts][nq][k] (HOST), out: [nq][k]. */
+MSVS_API int msvs_merge_topk(const int64_t * ids, const float * dis, size_t nparts, size_t nq, size_t k, int metric,
+                             int64_t * out_ids, float * out_dis);
+MSVS_API int msvs_merge_topk_device(const int64_t * d_ids, const float * d_dis, size_t nparts, size_t nq, size_t k,
+                                    int metric, int64_t * d_out_ids, float * d_out_dis, void * hip_stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Seam B -- BM25 posting-list scorer.  Replaces the scoring inside
+ *   TANTIVY::ffi_bm25_search(index_path, sentence, column_names, topk, alive_bitmap, use_filter, enable_nlq,
+ *                            operator_or, statistics)   src/Storages/MergeTree/TantivyIndexStore.cpp:908-917,939-948
+ * Tokenisation / query parsing stay on the host; the postings of a part are exported once into flat arrays:
+ * term t owns postings [post_off[t], post_off[t+1]) of (doc_ids ascending, tfs); fieldnorm_ids[doc] is
+ * tantivy's 1-byte quantised field length.
+ */
+typedef struct msvs_postings msvs_postings_t;
+MSVS_API int msvs_postings_create(const int64_t * post_off, size_t num_terms, const uint32_t * doc_ids,
+                                  const uint32_t * tfs, const uint8_t * fieldnorm_ids, size_t num_docs,
+                                  msvs_postings_t ** out);
+MSVS_API void msvs_postings_free(msvs_postings_t * postings);
+/* qterms/df: the query's term ids and their TABLE-level document frequencies (TANTIVY::Statistics.docs_freq,
+ * src/VectorIndex/Processors/ReadWithHybridSearch.cpp:89-209); total_docs / total_tokens likewise.
+ * Output: up to k (row id, score) best-first (score desc, row asc); *n_out = number written. */
+MSVS_API int msvs_bm25_search(const msvs_postings_t * postings, const uint32_t * qterms, const uint64_t * df,
+                              size_t num_qterms, uint64_t total_docs, uint64_t total_tokens,
+                              const uint64_t * alive_bits, size_t nbits, size_t k, uint64_t * row_ids, float * scores,
+                              size_t * n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSVS_H */

@@ -1,0 +1,274 @@
+"""ctypes binding of libmsvs.so (include/msvs.h).  Plumbing only -- no compute happens here.
+
+Fails loudly when the library is missing: there is deliberately no fallback path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsvs.so")
+
+METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
+INDEX_FLAT, INDEX_IVFFLAT = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+MAX_K = 256
+METRICS = {"L2": METRIC_L2, "IP": METRIC_IP, "Cosine": METRIC_COSINE, "COSINE": METRIC_COSINE, "cosine": METRIC_COSINE}
+
+OK, ERR_INVALID_ARGUMENT, ERR_NOT_IMPLEMENTED, ERR_DEVICE, ERR_OOM, ERR_NOT_READY, ERR_UNSUPPORTED_K, ERR_ID_RANGE, \
+    ERR_IO = range(9)
+
+SYMBOLS = [
+    "msvs_last_error", "msvs_version", "msvs_device_count", "msvs_set_device", "msvs_device_synchronize",
+    "msvs_knn_f32", "msvs_normalize_f32", "msvs_index_create", "msvs_index_free", "msvs_index_train",
+    "msvs_index_set_centroids", "msvs_index_add", "msvs_index_build", "msvs_index_ready", "msvs_index_num_data",
+    "msvs_index_num_lists", "msvs_index_memory_usage", "msvs_index_search", "msvs_index_search_device",
+    "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
+    "msvs_postings_create", "msvs_postings_free", "msvs_bm25_search",
+]
+
+
+class MsvsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("msvs error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmsvs.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "-- there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.msvs_last_error.restype = C.c_char_p
+        _lib.msvs_version.restype = C.c_char_p
+        for n in ("msvs_index_num_data", "msvs_index_num_lists", "msvs_index_memory_usage"):
+            getattr(_lib, n).restype = C.c_size_t
+            getattr(_lib, n).argtypes = [C.c_void_p]
+        _lib.msvs_index_free.argtypes = [C.c_void_p]
+        _lib.msvs_index_free.restype = None
+        _lib.msvs_postings_free.argtypes = [C.c_void_p]
+        _lib.msvs_postings_free.restype = None
+        _lib.msvs_index_ready.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MsvsError(rc, lib().msvs_last_error().decode())
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def pack_bits(mask):
+    mask = np.asarray(mask, dtype=bool)
+    n = mask.size
+    padded = np.zeros(((n + 63) // 64) * 64, dtype=bool)
+    padded[:n] = mask
+    return np.packbits(padded.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy()
+
+
+def version():
+    return lib().msvs_version().decode()
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().msvs_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(i):
+    _check(lib().msvs_set_device(int(i)))
+
+
+def synchronize():
+    _check(lib().msvs_device_synchronize())
+
+
+def knn(x, y, k, metric):
+    """msvs_knn_f32 (seam A2).  x [nx,d], y [ny,d] host arrays -> (ids int64 [nx,k], dis f32 [nx,k])."""
+    y = _f32(y)
+    d = y.shape[1]
+    x = _f32(x).reshape(-1, d)
+    nx = x.shape[0]
+    ids = np.empty((nx, k), np.int64)
+    dis = np.empty((nx, k), np.float32)
+    _check(lib().msvs_knn_f32(_p(x, C.c_float), _p(y, C.c_float), C.c_size_t(d), C.c_size_t(k), C.c_size_t(nx),
+                              C.c_size_t(y.shape[0]), int(metric), _p(ids, C.c_int64), _p(dis, C.c_float)))
+    return ids, dis
+
+
+def normalize(x):
+    x = _f32(x).copy()
+    x2 = x.reshape(-1, x.shape[-1])
+    _check(lib().msvs_normalize_f32(_p(x2, C.c_float), C.c_size_t(x2.shape[0]), C.c_size_t(x2.shape[1])))
+    return x
+
+
+def merge_topk(ids, dis, metric):
+    """ids/dis [nparts, nq, k] host arrays -> merged (ids [nq,k], dis [nq,k])."""
+    ids = np.ascontiguousarray(ids, np.int64)
+    dis = _f32(dis)
+    nparts, nq, k = ids.shape
+    oi, od = np.empty((nq, k), np.int64), np.empty((nq, k), np.float32)
+    _check(lib().msvs_merge_topk(_p(ids, C.c_int64), _p(dis, C.c_float), C.c_size_t(nparts), C.c_size_t(nq),
+                                 C.c_size_t(k), int(metric), _p(oi, C.c_int64), _p(od, C.c_float)))
+    return oi, od
+
+
+class Index:
+    """msvs_index_t (seam A1)."""
+
+    def __init__(self, index_type, metric, dim, params="", _handle=None):
+        self.dim = int(dim)
+        self.metric = metric
+        self.index_type = index_type
+        if _handle is not None:
+            self._h = _handle
+            return
+        h = C.c_void_p()
+        _check(lib().msvs_index_create(int(index_type), int(metric), C.c_size_t(dim), params.encode(), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().msvs_index_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def _ptr(x, mem):
+        if mem == MEM_DEVICE:
+            return C.c_void_p(int(x))
+        return x.ctypes.data_as(C.c_void_p)
+
+    def train(self, x, n=None, mem=MEM_HOST):
+        if mem == MEM_HOST:
+            x = _f32(x)
+            n = x.shape[0]
+        _check(lib().msvs_index_train(self._h, self._ptr(x, mem), C.c_size_t(n), mem))
+
+    def set_centroids(self, c):
+        c = _f32(c)
+        _check(lib().msvs_index_set_centroids(self._h, self._ptr(c, MEM_HOST), C.c_size_t(c.shape[0]), MEM_HOST))
+
+    def add(self, x, ids=None, n=None, mem=MEM_HOST):
+        if mem == MEM_HOST:
+            x = _f32(x)
+            n = x.shape[0]
+            idp = None
+            if ids is not None:
+                ids = np.ascontiguousarray(ids, np.int64)
+                idp = ids.ctypes.data_as(C.c_void_p)
+        else:
+            idp = None if ids is None else C.c_void_p(int(ids))
+        _check(lib().msvs_index_add(self._h, self._ptr(x, mem), idp, C.c_size_t(n), mem))
+
+    def build(self):
+        _check(lib().msvs_index_build(self._h))
+
+    @property
+    def ready(self):
+        return bool(lib().msvs_index_ready(self._h))
+
+    @property
+    def num_data(self):
+        return lib().msvs_index_num_data(self._h)
+
+    @property
+    def num_lists(self):
+        return lib().msvs_index_num_lists(self._h)
+
+    @property
+    def memory_usage(self):
+        return lib().msvs_index_memory_usage(self._h)
+
+    def search(self, queries, k, params="", alive=None):
+        q = _f32(queries).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), np.int64)
+        dis = np.empty((nq, k), np.float32)
+        bits, nbits = None, 0
+        if alive is not None:
+            nbits = len(alive)
+            bits = pack_bits(alive)
+        _check(lib().msvs_index_search(self._h, _p(q, C.c_float), C.c_size_t(nq), int(k), params.encode(),
+                                       _p(bits, C.c_uint64), C.c_size_t(nbits), _p(ids, C.c_int64), _p(dis, C.c_float)))
+        return ids, dis
+
+    def search_device(self, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0):
+        """All arguments are raw device addresses (ints); enqueues on `stream` and returns immediately."""
+        _check(lib().msvs_index_search_device(self._h, C.c_void_p(int(d_queries)), C.c_size_t(nq), int(k), int(nprobe),
+                                              C.c_void_p(int(d_alive)) if d_alive else None, C.c_size_t(nbits),
+                                              C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
+                                              C.c_void_p(int(stream)) if stream else None))
+
+    def export(self):
+        n, nl, d = self.num_data, self.num_lists, self.dim
+        cent = np.empty((nl, d), np.float32) if self.index_type == INDEX_IVFFLAT else None
+        off = np.empty(nl + 1, np.int64)
+        vecs = np.empty((n, d), np.float32)
+        ids = np.empty(n, np.int64)
+        _check(lib().msvs_index_export(self._h, _p(cent, C.c_float), _p(off, C.c_int64), _p(vecs, C.c_float),
+                                       _p(ids, C.c_int64)))
+        return cent, off, vecs, ids
+
+    def serialize(self, path):
+        _check(lib().msvs_index_serialize(self._h, path.encode()))
+
+    @classmethod
+    def load(cls, path, index_type, metric, dim):
+        h = C.c_void_p()
+        _check(lib().msvs_index_load(path.encode(), C.byref(h)))
+        return cls(index_type, metric, dim, _handle=h)
+
+
+class Postings:
+    """msvs_postings_t (seam B): flat-array export of one part's inverted index."""
+
+    def __init__(self, post_off, doc_ids, tfs, fieldnorm_ids):
+        post_off = np.ascontiguousarray(post_off, np.int64)
+        doc_ids = np.ascontiguousarray(doc_ids, np.uint32)
+        tfs = np.ascontiguousarray(tfs, np.uint32)
+        fieldnorm_ids = np.ascontiguousarray(fieldnorm_ids, np.uint8)
+        h = C.c_void_p()
+        _check(lib().msvs_postings_create(_p(post_off, C.c_int64), C.c_size_t(post_off.size - 1), _p(doc_ids, C.c_uint32),
+                                          _p(tfs, C.c_uint32), _p(fieldnorm_ids, C.c_uint8),
+                                          C.c_size_t(fieldnorm_ids.size), C.byref(h)))
+        self._h = h
+        self.num_docs = fieldnorm_ids.size
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().msvs_postings_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def bm25_search(self, qterms, df, total_docs, total_tokens, k, alive=None):
+        qterms = np.ascontiguousarray(qterms, np.uint32)
+        df = np.ascontiguousarray(df, np.uint64)
+        bits, nbits = None, 0
+        if alive is not None:
+            nbits = len(alive)
+            bits = pack_bits(alive)
+        rows, scores = np.empty(k, np.uint64), np.empty(k, np.float32)
+        n = C.c_size_t(0)
+        _check(lib().msvs_bm25_search(self._h, _p(qterms, C.c_uint32), _p(df, C.c_uint64), C.c_size_t(qterms.size),
+                                      C.c_uint64(int(total_docs)), C.c_uint64(int(total_tokens)), _p(bits, C.c_uint64),
+                                      C.c_size_t(nbits), C.c_size_t(k), _p(rows, C.c_uint64), _p(scores, C.c_float),
+                                      C.byref(n)))
+        return rows[:n.value], scores[:n.value]

@@ -1,0 +1,211 @@
+// device_ops.hip -- kernel instantiation + launch dispatch for the scan / merge kernels.
+#include "device_ops.hpp"
+
+#include <map>
+#include <mutex>
+
+namespace msvs
+{
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string & m) { g_last_error = m; }
+const char * last_error_cstr() { return g_last_error.c_str(); }
+
+void Scratch::reserve(size_t bytes, hipStream_t stream)
+{
+    used = 0;
+    bytes += 4096;
+    if (bytes <= buf.n)
+        return;
+    if (buf.p)
+        MSVS_HIP(hipStreamSynchronize(stream)); // earlier work on this stream may still read the old arena
+    size_t cap = bytes + bytes / 2;
+    buf.alloc(cap);
+}
+
+Scratch & scratch_for(hipStream_t stream)
+{
+    static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    return arenas[{dev, stream}];
+}
+
+FlatPlan plan_flat(size_t n_rows, size_t nq)
+{
+    FlatPlan p;
+    p.T = nq <= 1 ? 1 : (nq <= 2 ? 2 : (nq <= 4 ? 4 : 8));
+    p.n_qtiles = (uint32_t)ceil_div(nq ? nq : 1, p.T);
+    // enough blocks to fill 256 CUs a few times over, but at least 16 rows (one block iteration) each
+    size_t want = 2048 / p.n_qtiles;
+    if (want < 1)
+        want = 1;
+    size_t max_blocks = ceil_div(n_rows ? n_rows : 1, 16);
+    size_t nb = want < max_blocks ? want : max_blocks;
+    size_t rpb = round_up(ceil_div(n_rows ? n_rows : 1, nb), 16);
+    p.rows_per_block = (uint32_t)rpb;
+    p.n_blocks = (uint32_t)ceil_div(n_rows ? n_rows : 1, rpb);
+    return p;
+}
+
+template <int METRIC, int T>
+static void flat_dispatch_r(const FlatPlan & plan, const ScanParams & a, hipStream_t stream)
+{
+    dim3 grid(plan.n_blocks, plan.n_qtiles);
+    size_t lds = scan_lds_bytes(T, a.ld4, a.k);
+    switch (r_for_k(a.k))
+    {
+        case 1:
+            hipLaunchKernelGGL((flat_scan_kernel<METRIC, T, 1>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+        case 2:
+            hipLaunchKernelGGL((flat_scan_kernel<METRIC, T, 2>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((flat_scan_kernel<METRIC, T, 4>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+    }
+}
+
+template <int METRIC>
+static void flat_dispatch_t(const FlatPlan & plan, const ScanParams & a, hipStream_t stream)
+{
+    switch (plan.T)
+    {
+        case 1:
+            flat_dispatch_r<METRIC, 1>(plan, a, stream);
+            break;
+        case 2:
+            flat_dispatch_r<METRIC, 2>(plan, a, stream);
+            break;
+        case 4:
+            flat_dispatch_r<METRIC, 4>(plan, a, stream);
+            break;
+        default:
+            flat_dispatch_r<METRIC, 8>(plan, a, stream);
+            break;
+    }
+}
+
+void launch_flat_scan(int metric, const FlatPlan & plan, ScanParams a, hipStream_t stream)
+{
+    a.rows_per_block = plan.rows_per_block;
+    a.n_blocks = plan.n_blocks;
+    if (scan_lds_bytes(plan.T, a.ld4, a.k) > 160 * 1024)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large for the LDS query tile", a.ld4 * 4);
+    if (metric == M_IP)
+        flat_dispatch_t<M_IP>(plan, a, stream);
+    else
+        flat_dispatch_t<M_L2>(plan, a, stream);
+    MSVS_HIP(hipGetLastError());
+}
+
+template <int METRIC>
+static void merge_dispatch(const MergeParams & a, uint32_t nq, hipStream_t stream)
+{
+    size_t lds = (size_t)5 * a.k * 8;
+    switch (r_for_k(a.k))
+    {
+        case 1:
+            hipLaunchKernelGGL((merge_kernel<METRIC, 1>), dim3(nq), dim3(BLOCK), lds, stream, a);
+            break;
+        case 2:
+            hipLaunchKernelGGL((merge_kernel<METRIC, 2>), dim3(nq), dim3(BLOCK), lds, stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((merge_kernel<METRIC, 4>), dim3(nq), dim3(BLOCK), lds, stream, a);
+            break;
+    }
+}
+
+void launch_merge(int metric, MergeParams a, uint32_t nq, hipStream_t stream)
+{
+    if (nq == 0)
+        return;
+    if (metric == M_IP)
+        merge_dispatch<M_IP>(a, nq, stream);
+    else
+        merge_dispatch<M_L2>(a, nq, stream);
+    MSVS_HIP(hipGetLastError());
+}
+
+template <int METRIC>
+static void ivf_dispatch(const ScanParams & a, hipStream_t stream)
+{
+    dim3 grid(a.seg_max, a.nprobe, a.nq);
+    size_t lds = scan_lds_bytes(1, a.ld4, a.k);
+    switch (r_for_k(a.k))
+    {
+        case 1:
+            hipLaunchKernelGGL((ivf_scan_kernel<METRIC, 1>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+        case 2:
+            hipLaunchKernelGGL((ivf_scan_kernel<METRIC, 2>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((ivf_scan_kernel<METRIC, 4>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+    }
+}
+
+void launch_ivf_scan(int metric, ScanParams a, hipStream_t stream)
+{
+    if (a.nq == 0 || a.nprobe == 0 || a.seg_max == 0)
+        return;
+    if (metric == M_IP)
+        ivf_dispatch<M_IP>(a, stream);
+    else
+        ivf_dispatch<M_L2>(a, stream);
+    MSVS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ params
+
+std::map<std::string, std::string> parse_params(const char * s)
+{
+    std::map<std::string, std::string> m;
+    if (!s)
+        return m;
+    std::string cur_k, cur_v;
+    bool in_v = false;
+    auto flush = [&]() {
+        auto trim = [](std::string x) {
+            size_t a = x.find_first_not_of(" \t\r\n\"'{}");
+            size_t b = x.find_last_not_of(" \t\r\n\"'{}");
+            return a == std::string::npos ? std::string() : x.substr(a, b - a + 1);
+        };
+        std::string k = trim(cur_k), v = trim(cur_v);
+        if (!k.empty())
+            m[k] = v;
+        cur_k.clear();
+        cur_v.clear();
+        in_v = false;
+    };
+    for (const char * p = s; *p; ++p)
+    {
+        char c = *p;
+        if (c == ',' || c == ';')
+            flush();
+        else if ((c == '=' || c == ':') && !in_v)
+            in_v = true;
+        else
+            (in_v ? cur_v : cur_k).push_back(c);
+    }
+    flush();
+    return m;
+}
+
+long param_int(const std::map<std::string, std::string> & m, const char * key, long dflt)
+{
+    auto it = m.find(key);
+    if (it == m.end())
+        return dflt;
+    char * end = nullptr;
+    long v = strtol(it->second.c_str(), &end, 10);
+    if (end == it->second.c_str() || *end != '\0')
+        fail(MSVS_ERR_INVALID_ARGUMENT, "parameter `%s` value should be int, got `%s`", key, it->second.c_str());
+    return v;
+}
+
+}

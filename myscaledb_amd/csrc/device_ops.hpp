@@ -1,0 +1,54 @@
+// device_ops.hpp -- host-side launchers of the scan / merge kernels (all device pointers, stream-ordered).
+#pragma once
+
+#include "common.hpp"
+#include "scan_kernels.hpp"
+
+namespace msvs
+{
+
+/// Grow-only scratch arena, one per (host thread, stream): search calls are stream-ordered, so consecutive
+/// calls on one stream may reuse it without synchronisation; different host threads never share one.
+struct Scratch
+{
+    DevBuf<unsigned char> buf;
+    size_t used = 0;
+    void reset() { used = 0; }
+    /// Reserve must be called once per operation with the total need BEFORE any take() (it may reallocate).
+    void reserve(size_t bytes, hipStream_t stream);
+    template <typename T>
+    T * take(size_t count)
+    {
+        size_t off = round_up(used, 256);
+        size_t need = off + count * sizeof(T);
+        if (need > buf.n)
+            fail(MSVS_ERR_DEVICE, "internal: scratch overflow (%zu > %zu)", need, buf.n);
+        used = need;
+        return reinterpret_cast<T *>(buf.p + off);
+    }
+};
+
+Scratch & scratch_for(hipStream_t stream);
+
+inline int r_for_k(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
+
+struct FlatPlan
+{
+    uint32_t T, n_qtiles, rows_per_block, n_blocks;
+};
+
+FlatPlan plan_flat(size_t n_rows, size_t nq);
+
+/// bytes of partial keys a flat scan writes
+inline size_t flat_partial_keys(const FlatPlan & p, size_t nq, uint32_t k) { return nq * (size_t)p.n_blocks * k; }
+
+/// Exhaustive scan of `n_rows` rows for nq queries -> partial[nq][n_blocks][k] keys.
+void launch_flat_scan(int metric, const FlatPlan & plan, ScanParams a, hipStream_t stream);
+
+/// partial[nq][n_lists][k] -> final results.
+void launch_merge(int metric, MergeParams a, uint32_t nq, hipStream_t stream);
+
+/// IVF list scan, grid (seg_max, nprobe, nq).
+void launch_ivf_scan(int metric, ScanParams a, hipStream_t stream);
+
+}

@@ -1,0 +1,864 @@
+// msvs_capi.hip -- the C-ABI of libmsvs.so (include/msvs.h): seam A2 (brute force), seam A1 (index object),
+// top-k merge.  Everything computes on the GPU; there is no CPU fallback.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <numeric>
+#include <random>
+
+#include "device_ops.hpp"
+#include "ivf_build_kernels.hpp"
+
+namespace msvs
+{
+const char * last_error_cstr();
+
+static inline int scan_metric(int metric) { return metric == MSVS_METRIC_L2 ? M_L2 : M_IP; }
+
+static inline hipStream_t as_stream(void * s) { return reinterpret_cast<hipStream_t>(s); }
+
+/// Copy n rows of d floats (host or device) into a device buffer with row stride ld (zero padded).
+static void upload_rows(float * dst, const float * src, size_t n, uint32_t d, uint32_t ld, int mem, hipStream_t stream)
+{
+    if (n == 0)
+        return;
+    if (ld != d)
+        MSVS_HIP(hipMemsetAsync(dst, 0, n * ld * sizeof(float), stream));
+    MSVS_HIP(hipMemcpy2DAsync(dst, ld * sizeof(float), src, d * sizeof(float), d * sizeof(float), n,
+                              mem == MSVS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+}
+
+static inline uint32_t padded_dim(size_t d) { return (uint32_t)round_up(d, 4); }
+
+static void check_k(size_t k)
+{
+    if (k > MSVS_MAX_K)
+        fail(MSVS_ERR_UNSUPPORTED_K, "k = %zu exceeds the device top-k limit %d", k, MSVS_MAX_K);
+}
+
+/// Exhaustive top-k of device queries (nq x ld) against device rows (n x ld) -> device ids/dis.
+/// `scr` must have been reserved by the caller for flat_scratch_bytes().
+static size_t flat_scratch_bytes(size_t n, size_t nq, uint32_t k)
+{
+    FlatPlan p = plan_flat(n, nq);
+    return flat_partial_keys(p, nq, k) * 8 + 1024;
+}
+
+static void flat_search_device(Scratch & scr, int metric, const float * d_rows, const uint32_t * d_row_ids, size_t n,
+                               uint32_t ld, const float * d_q, size_t nq, uint32_t k, const uint64_t * d_alive,
+                               size_t nbits, MergeParams out, hipStream_t stream)
+{
+    FlatPlan p = plan_flat(n, nq);
+    uint64_t * partial = scr.take<uint64_t>(flat_partial_keys(p, nq, k));
+    ScanParams a{};
+    a.Y = reinterpret_cast<const float4 *>(d_rows);
+    a.ids = d_row_ids;
+    a.alive = d_alive;
+    a.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
+    a.Q = reinterpret_cast<const float4 *>(d_q);
+    a.partial = partial;
+    a.ld4 = ld / 4;
+    a.k = k;
+    a.nq = (uint32_t)nq;
+    a.n_rows = (uint32_t)n;
+    launch_flat_scan(scan_metric(metric), p, a, stream);
+    out.partial = partial;
+    out.n_lists = p.n_blocks;
+    out.k = k;
+    launch_merge(scan_metric(metric), out, (uint32_t)nq, stream);
+}
+
+}
+
+using namespace msvs;
+
+// =========================================================================================== basics
+
+extern "C" const char * msvs_last_error(void) { return last_error_cstr(); }
+extern "C" const char * msvs_version(void) { return "msvs 0.1 (gfx950)"; }
+
+extern "C" int msvs_device_count(int * count)
+{
+    return guarded([&] {
+        if (!count)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "count is null");
+        MSVS_HIP(hipGetDeviceCount(count));
+    });
+}
+
+extern "C" int msvs_set_device(int ordinal)
+{
+    return guarded([&] { MSVS_HIP(hipSetDevice(ordinal)); });
+}
+
+extern "C" int msvs_device_synchronize(void)
+{
+    return guarded([&] { MSVS_HIP(hipDeviceSynchronize()); });
+}
+
+// =========================================================================================== seam A2
+
+extern "C" int msvs_knn_f32(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny, int metric,
+                            int64_t * ids, float * dis)
+{
+    return guarded([&] {
+        if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
+            fail(MSVS_ERR_NOT_IMPLEMENTED, "Metric not implemented in brute force search for Float32 Vector");
+        if (nx == 0 || k == 0)
+            return;
+        if (!x || !ids || !dis || (ny && !y) || d == 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer or zero dimension");
+        check_k(k);
+        if (ny > 0xfffffff0ull)
+            fail(MSVS_ERR_ID_RANGE, "ny exceeds the u32 id range");
+        hipStream_t stream = nullptr;
+        const uint32_t ld = padded_dim(d);
+        Scratch & scr = scratch_for(stream);
+        size_t need = (nx + ny) * (size_t)ld * 4 + nx * k * 12 + flat_scratch_bytes(ny, nx, (uint32_t)k) + 8192;
+        scr.reserve(need, stream);
+        float * dq = scr.take<float>(nx * ld);
+        float * dy = scr.take<float>(std::max<size_t>(ny, 1) * ld);
+        int64_t * d_ids = scr.take<int64_t>(nx * k);
+        float * d_dis = scr.take<float>(nx * k);
+        upload_rows(dq, x, nx, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
+        upload_rows(dy, y, ny, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
+        MergeParams out{};
+        out.out_ids = d_ids;
+        out.out_dis = d_dis;
+        flat_search_device(scr, metric, dy, nullptr, ny, ld, dq, nx, (uint32_t)k, nullptr, 0, out, stream);
+        MSVS_HIP(hipMemcpyAsync(ids, d_ids, nx * k * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipMemcpyAsync(dis, d_dis, nx * k * sizeof(float), hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+    });
+}
+
+extern "C" int msvs_normalize_f32(float * x, size_t n, size_t d)
+{
+    return guarded([&] {
+        if (n == 0)
+            return;
+        if (!x || d == 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer or zero dimension");
+        hipStream_t stream = nullptr;
+        Scratch & scr = scratch_for(stream);
+        scr.reserve(n * d * 4 + 4096, stream);
+        float * dx = scr.take<float>(n * d);
+        MSVS_HIP(hipMemcpyAsync(dx, x, n * d * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, dx, n,
+                           (uint32_t)d, (uint32_t)d);
+        MSVS_HIP(hipGetLastError());
+        MSVS_HIP(hipMemcpyAsync(x, dx, n * d * 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+    });
+}
+
+// =========================================================================================== seam A1
+
+struct msvs_index
+{
+    int type = MSVS_INDEX_FLAT;
+    int metric = MSVS_METRIC_L2;
+    size_t dim = 0;
+    uint32_t ld = 0;
+    int device = 0;
+    // build parameters
+    size_t ncentroids = 1024;
+    int kmeans_iters = 10;
+    size_t train_sample = 0;
+    uint64_t seed = 1234;
+    int shard_rank = 0, shard_world = 1;
+    // coarse quantiser (IVFFLAT)
+    size_t nlist = 0;
+    DevBuf<float> centroids; // nlist x ld
+    // staging (between add and build)
+    struct Chunk
+    {
+        DevBuf<float> x; // n x ld (normalised for cosine)
+        std::vector<int64_t> ids;
+        std::vector<int32_t> assign;
+        size_t n = 0;
+    };
+    std::vector<Chunk> chunks;
+    size_t staged = 0;
+    // final storage
+    DevBuf<float> vecs;       // n x ld, list-major (IVF) / id order (FLAT)
+    DevBuf<uint32_t> row_ids; // n
+    DevBuf<int64_t> list_off; // nlist + 1
+    std::vector<int64_t> h_list_off;
+    size_t n = 0;
+    size_t max_list_len = 0;
+    bool ready = false;
+};
+
+static void index_assign(const msvs_index & ix, const float * d_x, size_t n, int32_t * d_assign, hipStream_t stream)
+{
+    DevBuf<float> cnorm(ix.nlist);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)ceil_div(ix.nlist, 256)), dim3(256), 0, stream,
+                       ix.centroids.p, cnorm.p, (uint32_t)ix.nlist, (uint32_t)ix.dim, ix.ld);
+    unsigned grid = (unsigned)ceil_div(n, AS_TN);
+    if (ix.metric == MSVS_METRIC_L2)
+        hipLaunchKernelGGL((assign_kernel<false>), dim3(grid), dim3(256), 0, stream, d_x, n, ix.centroids.p, cnorm.p,
+                           (uint32_t)ix.nlist, (uint32_t)ix.dim, ix.ld, d_assign, (float *)nullptr);
+    else
+        hipLaunchKernelGGL((assign_kernel<true>), dim3(grid), dim3(256), 0, stream, d_x, n, ix.centroids.p, cnorm.p,
+                           (uint32_t)ix.nlist, (uint32_t)ix.dim, ix.ld, d_assign, (float *)nullptr);
+    MSVS_HIP(hipGetLastError());
+    MSVS_HIP(hipStreamSynchronize(stream));
+}
+
+static void normalize_device_rows(float * d_x, size_t n, uint32_t d, uint32_t ld, hipStream_t stream)
+{
+    if (n == 0)
+        return;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, d_x, n, d, ld);
+    MSVS_HIP(hipGetLastError());
+}
+
+extern "C" int msvs_index_create(int index_type, int metric, size_t dim, const char * params, msvs_index_t ** out)
+{
+    return guarded([&] {
+        if (!out)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "out is null");
+        *out = nullptr;
+        if (index_type != MSVS_INDEX_FLAT && index_type != MSVS_INDEX_IVFFLAT)
+            fail(MSVS_ERR_NOT_IMPLEMENTED, "index type %d is not implemented", index_type);
+        if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP && metric != MSVS_METRIC_COSINE)
+            fail(MSVS_ERR_NOT_IMPLEMENTED, "metric %d is not implemented for Float32 vectors", metric);
+        if (dim == 0 || dim > 8192)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %zu out of range [1, 8192]", dim);
+        auto p = parse_params(params);
+        std::unique_ptr<msvs_index> ix(new msvs_index);
+        ix->type = index_type;
+        ix->metric = metric;
+        ix->dim = dim;
+        ix->ld = padded_dim(dim);
+        MSVS_HIP(hipGetDevice(&ix->device));
+        ix->ncentroids = (size_t)param_int(p, "ncentroids", 1024);
+        ix->kmeans_iters = (int)param_int(p, "kmeans_iters", 10);
+        ix->train_sample = (size_t)param_int(p, "train_sample", 0);
+        ix->seed = (uint64_t)param_int(p, "seed", 1234);
+        ix->shard_rank = (int)param_int(p, "shard_rank", 0);
+        ix->shard_world = (int)param_int(p, "shard_world", 1);
+        if (ix->ncentroids == 0 || ix->shard_world < 1 || ix->shard_rank < 0 || ix->shard_rank >= ix->shard_world)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "bad ncentroids / shard parameters");
+        *out = ix.release();
+    });
+}
+
+extern "C" void msvs_index_free(msvs_index_t * index) { delete index; }
+
+extern "C" int msvs_index_set_centroids(msvs_index_t * ix, const float * centroids, size_t nlist, int mem)
+{
+    return guarded([&] {
+        if (!ix || !centroids || nlist == 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/centroids");
+        if (ix->type != MSVS_INDEX_IVFFLAT)
+            return;
+        if (ix->staged || ix->ready)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "centroids must be set before data is added");
+        ix->nlist = nlist;
+        ix->centroids.alloc(nlist * ix->ld);
+        upload_rows(ix->centroids.p, centroids, nlist, (uint32_t)ix->dim, ix->ld, mem, nullptr);
+        MSVS_HIP(hipStreamSynchronize(nullptr));
+    });
+}
+
+extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, int mem)
+{
+    return guarded([&] {
+        if (!ix || (n && !x))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/data");
+        if (ix->type != MSVS_INDEX_IVFFLAT)
+            return;
+        if (ix->staged || ix->ready)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "train must precede add");
+        if (n == 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "no training data");
+        hipStream_t stream = nullptr;
+        const uint32_t d = (uint32_t)ix->dim, ld = ix->ld;
+        size_t nlist = std::min(ix->ncentroids, n);
+        size_t ns = ix->train_sample ? ix->train_sample : nlist * 64;
+        ns = std::min(ns, n);
+        // deterministic sample: a seeded partial Fisher-Yates over row indices
+        std::mt19937_64 rng(ix->seed);
+        std::vector<uint32_t> perm(n);
+        std::iota(perm.begin(), perm.end(), 0u);
+        for (size_t i = 0; i < ns; i++)
+        {
+            size_t j = i + (size_t)(rng() % (n - i));
+            std::swap(perm[i], perm[j]);
+        }
+        perm.resize(ns);
+        // stage the sample on the device (rows padded to ld)
+        DevBuf<float> xs(ns * ld);
+        {
+            DevBuf<uint32_t> d_idx(ns);
+            MSVS_HIP(hipMemcpyAsync(d_idx.p, perm.data(), ns * 4, hipMemcpyHostToDevice, stream));
+            if (mem == MSVS_MEM_DEVICE && ld == d)
+            {
+                size_t total = ns * (ld / 4);
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
+                                   reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(xs.p), d_idx.p, ns,
+                                   ld / 4);
+                MSVS_HIP(hipGetLastError());
+            }
+            else
+            {
+                // host data (or odd dimension): gather on the host, then upload
+                std::vector<float> hx;
+                const float * src = x;
+                if (mem == MSVS_MEM_DEVICE)
+                {
+                    hx.resize(n * d);
+                    MSVS_HIP(hipMemcpy(hx.data(), x, n * d * 4, hipMemcpyDeviceToHost));
+                    src = hx.data();
+                }
+                std::vector<float> g(ns * d);
+                for (size_t i = 0; i < ns; i++)
+                    memcpy(&g[i * d], src + (size_t)perm[i] * d, d * 4);
+                upload_rows(xs.p, g.data(), ns, d, ld, MSVS_MEM_HOST, stream);
+                MSVS_HIP(hipStreamSynchronize(stream));
+            }
+            MSVS_HIP(hipStreamSynchronize(stream));
+        }
+        if (ix->metric == MSVS_METRIC_COSINE)
+            normalize_device_rows(xs.p, ns, d, ld, stream);
+        // init: the first nlist sampled rows
+        ix->nlist = nlist;
+        ix->centroids.alloc(nlist * ld);
+        MSVS_HIP(hipMemcpyAsync(ix->centroids.p, xs.p, nlist * ld * 4, hipMemcpyDeviceToDevice, stream));
+        DevBuf<int32_t> d_assign(ns);
+        DevBuf<int64_t> d_off(nlist + 1);
+        DevBuf<uint32_t> d_members(ns);
+        std::vector<int32_t> h_assign(ns);
+        std::vector<int64_t> off(nlist + 1);
+        std::vector<uint32_t> members(ns);
+        for (int it = 0; it < ix->kmeans_iters; it++)
+        {
+            // Lloyd step: L2 assignment (IP/cosine indexes train on L2 too, like Faiss' default clustering)
+            msvs_index tmp_view;
+            (void)tmp_view;
+            int saved = ix->metric;
+            ix->metric = MSVS_METRIC_L2;
+            index_assign(*ix, xs.p, ns, d_assign.p, stream);
+            ix->metric = saved;
+            MSVS_HIP(hipMemcpy(h_assign.data(), d_assign.p, ns * 4, hipMemcpyDeviceToHost));
+            std::fill(off.begin(), off.end(), 0);
+            for (size_t i = 0; i < ns; i++)
+                off[h_assign[i] + 1]++;
+            for (size_t j = 0; j < nlist; j++)
+                off[j + 1] += off[j];
+            std::vector<int64_t> cur(off.begin(), off.end() - 1);
+            for (size_t i = 0; i < ns; i++)
+                members[cur[h_assign[i]]++] = (uint32_t)i;
+            MSVS_HIP(hipMemcpyAsync(d_off.p, off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, stream));
+            MSVS_HIP(hipMemcpyAsync(d_members.p, members.data(), ns * 4, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)nlist), dim3(256), 0, stream, xs.p, d, ld,
+                               d_off.p, d_members.p, ix->centroids.p);
+            MSVS_HIP(hipGetLastError());
+            MSVS_HIP(hipStreamSynchronize(stream));
+        }
+    });
+}
+
+extern "C" int msvs_index_add(msvs_index_t * ix, const float * x, const int64_t * ids, size_t n, int mem)
+{
+    return guarded([&] {
+        if (!ix || (n && !x))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/data");
+        if (ix->ready)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "index already built");
+        if (n == 0)
+            return;
+        if (ix->type == MSVS_INDEX_IVFFLAT && ix->nlist == 0)
+            fail(MSVS_ERR_NOT_READY, "IVFFLAT index must be trained (or given centroids) before add");
+        hipStream_t stream = nullptr;
+        const uint32_t d = (uint32_t)ix->dim, ld = ix->ld;
+        msvs_index::Chunk ch;
+        ch.n = n;
+        ch.x.alloc(n * ld);
+        upload_rows(ch.x.p, x, n, d, ld, mem, stream);
+        ch.ids.resize(n);
+        if (ids)
+        {
+            if (mem == MSVS_MEM_DEVICE)
+                MSVS_HIP(hipMemcpy(ch.ids.data(), ids, n * 8, hipMemcpyDeviceToHost));
+            else
+                memcpy(ch.ids.data(), ids, n * 8);
+        }
+        else
+            for (size_t i = 0; i < n; i++)
+                ch.ids[i] = (int64_t)(ix->staged + i);
+        for (size_t i = 0; i < n; i++)
+            if (ch.ids[i] < 0 || ch.ids[i] > 0xfffffff0ll)
+                fail(MSVS_ERR_ID_RANGE, "id %lld does not fit the u32 label range", (long long)ch.ids[i]);
+        if (ix->metric == MSVS_METRIC_COSINE)
+            normalize_device_rows(ch.x.p, n, d, ld, stream);
+        if (ix->type == MSVS_INDEX_IVFFLAT)
+        {
+            DevBuf<int32_t> d_assign(n);
+            index_assign(*ix, ch.x.p, n, d_assign.p, stream);
+            ch.assign.resize(n);
+            MSVS_HIP(hipMemcpy(ch.assign.data(), d_assign.p, n * 4, hipMemcpyDeviceToHost));
+        }
+        MSVS_HIP(hipStreamSynchronize(stream));
+        ix->staged += n;
+        ix->chunks.push_back(std::move(ch));
+    });
+}
+
+extern "C" int msvs_index_build(msvs_index_t * ix)
+{
+    return guarded([&] {
+        if (!ix)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
+        if (ix->ready)
+            return;
+        hipStream_t stream = nullptr;
+        const uint32_t ld = ix->ld;
+        const size_t nlist = ix->type == MSVS_INDEX_IVFFLAT ? ix->nlist : 1;
+        if (ix->type == MSVS_INDEX_IVFFLAT && nlist == 0)
+            fail(MSVS_ERR_NOT_READY, "IVFFLAT index has no centroids");
+        // rows kept on this shard, ordered by (list, id)
+        struct Ref
+        {
+            int32_t list;
+            uint32_t id;
+            uint32_t chunk;
+            uint32_t row;
+        };
+        std::vector<Ref> refs;
+        refs.reserve(ix->staged);
+        for (size_t c = 0; c < ix->chunks.size(); c++)
+        {
+            const auto & ch = ix->chunks[c];
+            for (size_t i = 0; i < ch.n; i++)
+            {
+                int32_t l = ix->type == MSVS_INDEX_IVFFLAT ? ch.assign[i] : 0;
+                if (ix->type == MSVS_INDEX_IVFFLAT && ix->shard_world > 1 && l % ix->shard_world != ix->shard_rank)
+                    continue;
+                if (ix->type == MSVS_INDEX_FLAT && ix->shard_world > 1)
+                {
+                    // FLAT shards by contiguous id ranges of the staged order
+                    size_t g = 0;
+                    for (size_t cc = 0; cc < c; cc++)
+                        g += ix->chunks[cc].n;
+                    g += i;
+                    size_t per = ceil_div(ix->staged, (size_t)ix->shard_world);
+                    if (g / per != (size_t)ix->shard_rank)
+                        continue;
+                }
+                refs.push_back({l, (uint32_t)ch.ids[i], (uint32_t)c, (uint32_t)i});
+            }
+        }
+        std::stable_sort(refs.begin(), refs.end(), [](const Ref & a, const Ref & b) {
+            return a.list != b.list ? a.list < b.list : a.id < b.id;
+        });
+        const size_t n = refs.size();
+        ix->n = n;
+        ix->h_list_off.assign(nlist + 1, 0);
+        for (const auto & r : refs)
+            ix->h_list_off[r.list + 1]++;
+        ix->max_list_len = 0;
+        for (size_t l = 0; l < nlist; l++)
+        {
+            ix->max_list_len = std::max<size_t>(ix->max_list_len, (size_t)ix->h_list_off[l + 1]);
+            ix->h_list_off[l + 1] += ix->h_list_off[l];
+        }
+        ix->vecs.alloc(std::max<size_t>(n, 1) * ld);
+        ix->row_ids.alloc(std::max<size_t>(n, 1));
+        ix->list_off.alloc(nlist + 1);
+        std::vector<uint32_t> h_ids(n);
+        std::vector<std::vector<uint32_t>> pos(ix->chunks.size());
+        std::vector<std::vector<uint32_t>> src(ix->chunks.size());
+        for (size_t p = 0; p < n; p++)
+        {
+            h_ids[p] = refs[p].id;
+            pos[refs[p].chunk].push_back((uint32_t)p);
+            src[refs[p].chunk].push_back(refs[p].row);
+        }
+        for (size_t c = 0; c < ix->chunks.size(); c++)
+        {
+            size_t m = pos[c].size();
+            if (m)
+            {
+                // gather the kept rows of the chunk, then scatter them to their list-major positions
+                DevBuf<uint32_t> d_src(m), d_pos(m);
+                DevBuf<float> tmp(m * ld);
+                MSVS_HIP(hipMemcpyAsync(d_src.p, src[c].data(), m * 4, hipMemcpyHostToDevice, stream));
+                MSVS_HIP(hipMemcpyAsync(d_pos.p, pos[c].data(), m * 4, hipMemcpyHostToDevice, stream));
+                size_t total = m * (ld / 4);
+                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
+                                   reinterpret_cast<const float4 *>(ix->chunks[c].x.p),
+                                   reinterpret_cast<float4 *>(tmp.p), d_src.p, m, ld / 4);
+                hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
+                                   reinterpret_cast<const float4 *>(tmp.p), reinterpret_cast<float4 *>(ix->vecs.p),
+                                   d_pos.p, m, ld / 4);
+                MSVS_HIP(hipGetLastError());
+                MSVS_HIP(hipStreamSynchronize(stream));
+            }
+            ix->chunks[c].x.release();
+        }
+        if (n)
+            MSVS_HIP(hipMemcpy(ix->row_ids.p, h_ids.data(), n * 4, hipMemcpyHostToDevice));
+        MSVS_HIP(hipMemcpy(ix->list_off.p, ix->h_list_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
+        ix->chunks.clear();
+        ix->ready = true;
+    });
+}
+
+extern "C" int msvs_index_ready(const msvs_index_t * ix) { return ix && ix->ready ? 1 : 0; }
+extern "C" size_t msvs_index_num_data(const msvs_index_t * ix) { return ix ? (ix->ready ? ix->n : ix->staged) : 0; }
+extern "C" size_t msvs_index_num_lists(const msvs_index_t * ix)
+{
+    return ix ? (ix->type == MSVS_INDEX_IVFFLAT ? ix->nlist : 1) : 0;
+}
+extern "C" size_t msvs_index_memory_usage(const msvs_index_t * ix)
+{
+    return ix ? ix->vecs.bytes() + ix->row_ids.bytes() + ix->centroids.bytes() + ix->list_off.bytes() : 0;
+}
+
+namespace msvs
+{
+
+static size_t ivf_rows_per_block(const msvs_index & ix, size_t nq, size_t nprobe)
+{
+    // aim for ~2048 blocks over the probed lists; at least one block iteration (16 rows), at most 1024 rows
+    size_t avg = std::max<size_t>(1, ix.n / std::max<size_t>(ix.nlist, 1));
+    size_t rpb = round_up(std::max<size_t>(16, avg * nq * nprobe / 2048), 16);
+    return std::min<size_t>(rpb, 256);
+}
+
+static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k, size_t nprobe)
+{
+    size_t b = nq * (size_t)ix.ld * 4 + 4096;
+    if (ix.type == MSVS_INDEX_FLAT)
+        return b + flat_scratch_bytes(ix.n, nq, k);
+    size_t rpb = ivf_rows_per_block(ix, nq, nprobe);
+    size_t seg_max = std::max<size_t>(1, ceil_div(ix.max_list_len, rpb));
+    return b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + nq * nprobe * 4 + nq * nprobe * seg_max * k * 8
+        + 16384;
+}
+
+/// The search proper: all pointers on the device, everything enqueued on `stream`.
+static void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
+                                uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
+                                float * d_dis, hipStream_t stream)
+{
+    if (!ix.ready)
+        fail(MSVS_ERR_NOT_READY, "index is not ready");
+    if (nq == 0 || k == 0)
+        return;
+    check_k(k);
+    if (ix.type == MSVS_INDEX_IVFFLAT)
+    {
+        if (nprobe == 0)
+            nprobe = 1;
+        nprobe = std::min(nprobe, ix.nlist);
+        check_k(nprobe);
+    }
+    const uint32_t d = (uint32_t)ix.dim, ld = ix.ld;
+    Scratch & scr = scratch_for(stream);
+    scr.reserve(index_search_scratch(ix, nq, k, nprobe), stream);
+    // queries: pad and/or normalise into scratch when needed
+    const float * dq = d_queries;
+    if (ld != d || ix.metric == MSVS_METRIC_COSINE)
+    {
+        float * q2 = scr.take<float>(nq * ld);
+        upload_rows(q2, d_queries, nq, d, ld, MSVS_MEM_DEVICE, stream);
+        if (ix.metric == MSVS_METRIC_COSINE)
+            normalize_device_rows(q2, nq, d, ld, stream);
+        dq = q2;
+    }
+    MergeParams out{};
+    out.out_ids = d_ids;
+    out.out_dis = d_dis;
+    out.cosine = ix.metric == MSVS_METRIC_COSINE;
+    const int m = ix.metric == MSVS_METRIC_L2 ? MSVS_METRIC_L2 : MSVS_METRIC_IP;
+    if (ix.type == MSVS_INDEX_FLAT)
+    {
+        flat_search_device(scr, m, ix.vecs.p, ix.row_ids.p, ix.n, ld, dq, nq, k, d_alive, nbits, out, stream);
+        return;
+    }
+    // 1. coarse quantiser: exact top-nprobe of the centroids (canonical arithmetic, so probes match the oracle)
+    int32_t * d_probes = scr.take<int32_t>(nq * nprobe);
+    MergeParams co{};
+    co.mode = 1;
+    co.out_probes = d_probes;
+    flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co, stream);
+    // 2. scan the probed lists
+    const size_t rpb = ivf_rows_per_block(ix, nq, nprobe);
+    const size_t seg_max = std::max<size_t>(1, ceil_div(ix.max_list_len, rpb));
+    uint64_t * partial = scr.take<uint64_t>(nq * nprobe * seg_max * k);
+    for (size_t q0 = 0; q0 < nq; q0 += 32768)
+    {
+        size_t nqc = std::min<size_t>(32768, nq - q0);
+        ScanParams a{};
+        a.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
+        a.ids = ix.row_ids.p;
+        a.alive = d_alive;
+        a.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
+        a.Q = reinterpret_cast<const float4 *>(dq + q0 * ld);
+        a.partial = partial + q0 * nprobe * seg_max * k;
+        a.ld4 = ld / 4;
+        a.k = k;
+        a.nq = (uint32_t)nqc;
+        a.rows_per_block = (uint32_t)rpb;
+        a.probes = d_probes + q0 * nprobe;
+        a.list_off = ix.list_off.p;
+        a.nprobe = (uint32_t)nprobe;
+        a.seg_max = (uint32_t)seg_max;
+        launch_ivf_scan(scan_metric(m), a, stream);
+    }
+    // 3. per-query top-k over all segments
+    out.partial = partial;
+    out.n_lists = (uint32_t)(nprobe * seg_max);
+    out.k = k;
+    launch_merge(scan_metric(m), out, (uint32_t)nq, stream);
+}
+
+}
+
+extern "C" int msvs_index_search_device(const msvs_index_t * ix, const float * d_queries, size_t nq, int k, int nprobe,
+                                        const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids, float * d_dis,
+                                        void * hip_stream)
+{
+    return guarded([&] {
+        if (!ix || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/buffer or negative k");
+        index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), d_alive_bits, nbits, d_ids,
+                            d_dis, as_stream(hip_stream));
+    });
+}
+
+extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
+                                 const uint64_t * alive_bits, size_t nbits, int64_t * ids, float * dis)
+{
+    return guarded([&] {
+        if (!ix || (nq && (!queries || !ids || !dis)) || k < 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/buffer or negative k");
+        if (!ix->ready)
+            fail(MSVS_ERR_NOT_READY, "index is not ready");
+        if (nq == 0 || k == 0)
+            return;
+        check_k((size_t)k);
+        auto p = parse_params(params);
+        for (const auto & kv : p)
+            if (kv.first != "nprobe")
+                fail(MSVS_ERR_INVALID_ARGUMENT, "unknown search parameter `%s`", kv.first.c_str());
+        long nprobe = param_int(p, "nprobe", 1);
+        if (nprobe < 1)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "nprobe must be >= 1");
+        hipStream_t stream = nullptr;
+        const size_t words = alive_bits ? ceil_div(nbits, 64) : 0;
+        // host staging lives in plain device allocations (the arena belongs to the device-level search)
+        DevBuf<float> dq(nq * ix->dim);
+        DevBuf<int64_t> d_ids(nq * (size_t)k);
+        DevBuf<float> d_dis(nq * (size_t)k);
+        DevBuf<uint64_t> d_alive(words);
+        MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
+        if (words)
+            MSVS_HIP(hipMemcpyAsync(d_alive.p, alive_bits, words * 8, hipMemcpyHostToDevice, stream));
+        index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, words ? d_alive.p : nullptr, nbits, d_ids.p,
+                            d_dis.p, stream);
+        MSVS_HIP(hipMemcpyAsync(ids, d_ids.p, nq * (size_t)k * 8, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipMemcpyAsync(dis, d_dis.p, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+    });
+}
+
+extern "C" int msvs_index_export(const msvs_index_t * ix, float * centroids, int64_t * list_off, float * vecs,
+                                 int64_t * ids)
+{
+    return guarded([&] {
+        if (!ix || !ix->ready)
+            fail(MSVS_ERR_NOT_READY, "index is not ready");
+        const size_t d = ix->dim, ld = ix->ld;
+        if (centroids && ix->type == MSVS_INDEX_IVFFLAT)
+            MSVS_HIP(hipMemcpy2D(centroids, d * 4, ix->centroids.p, ld * 4, d * 4, ix->nlist, hipMemcpyDeviceToHost));
+        if (list_off)
+            memcpy(list_off, ix->h_list_off.data(), ix->h_list_off.size() * 8);
+        if (vecs && ix->n)
+            MSVS_HIP(hipMemcpy2D(vecs, d * 4, ix->vecs.p, ld * 4, d * 4, ix->n, hipMemcpyDeviceToHost));
+        if (ids && ix->n)
+        {
+            std::vector<uint32_t> h(ix->n);
+            MSVS_HIP(hipMemcpy(h.data(), ix->row_ids.p, ix->n * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < ix->n; i++)
+                ids[i] = (int64_t)h[i];
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------- serialisation
+
+namespace
+{
+struct FileHeader
+{
+    char magic[8]; // "MSVSIDX1"
+    int32_t type, metric;
+    uint64_t dim, nlist, n;
+    int32_t shard_rank, shard_world;
+};
+}
+
+extern "C" int msvs_index_serialize(const msvs_index_t * ix, const char * path)
+{
+    return guarded([&] {
+        if (!ix || !ix->ready || !path)
+            fail(MSVS_ERR_NOT_READY, "index is not ready");
+        const size_t nlist = msvs_index_num_lists(ix);
+        std::vector<float> cent(ix->type == MSVS_INDEX_IVFFLAT ? nlist * ix->dim : 0), vecs(ix->n * ix->dim);
+        std::vector<int64_t> off(nlist + 1), ids(ix->n);
+        int rc = msvs_index_export(ix, cent.empty() ? nullptr : cent.data(), off.data(), vecs.data(), ids.data());
+        if (rc)
+            fail(rc, "%s", msvs_last_error());
+        FILE * f = fopen(path, "wb");
+        if (!f)
+            fail(MSVS_ERR_IO, "cannot open %s for writing", path);
+        FileHeader h{};
+        memcpy(h.magic, "MSVSIDX1", 8);
+        h.type = ix->type;
+        h.metric = ix->metric;
+        h.dim = ix->dim;
+        h.nlist = nlist;
+        h.n = ix->n;
+        h.shard_rank = ix->shard_rank;
+        h.shard_world = ix->shard_world;
+        bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+        ok = ok && (cent.empty() || fwrite(cent.data(), 4, cent.size(), f) == cent.size());
+        ok = ok && fwrite(off.data(), 8, off.size(), f) == off.size();
+        ok = ok && (vecs.empty() || fwrite(vecs.data(), 4, vecs.size(), f) == vecs.size());
+        ok = ok && (ids.empty() || fwrite(ids.data(), 8, ids.size(), f) == ids.size());
+        ok = (fclose(f) == 0) && ok;
+        if (!ok)
+            fail(MSVS_ERR_IO, "short write to %s", path);
+    });
+}
+
+extern "C" int msvs_index_load(const char * path, msvs_index_t ** out)
+{
+    return guarded([&] {
+        if (!path || !out)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null path/out");
+        *out = nullptr;
+        FILE * f = fopen(path, "rb");
+        if (!f)
+            fail(MSVS_ERR_IO, "cannot open %s", path);
+        std::unique_ptr<FILE, int (*)(FILE *)> guard(f, fclose);
+        FileHeader h{};
+        if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "MSVSIDX1", 8) != 0)
+            fail(MSVS_ERR_IO, "%s is not an msvs index file", path);
+        std::unique_ptr<msvs_index> ix(new msvs_index);
+        ix->type = h.type;
+        ix->metric = h.metric;
+        ix->dim = h.dim;
+        ix->ld = padded_dim(h.dim);
+        ix->shard_rank = h.shard_rank;
+        ix->shard_world = h.shard_world;
+        MSVS_HIP(hipGetDevice(&ix->device));
+        const size_t nlist = h.nlist, n = h.n, d = h.dim;
+        std::vector<float> cent(ix->type == MSVS_INDEX_IVFFLAT ? nlist * d : 0), vecs(n * d);
+        std::vector<int64_t> off(nlist + 1), ids(n);
+        bool ok = cent.empty() || fread(cent.data(), 4, cent.size(), f) == cent.size();
+        ok = ok && fread(off.data(), 8, off.size(), f) == off.size();
+        ok = ok && (vecs.empty() || fread(vecs.data(), 4, vecs.size(), f) == vecs.size());
+        ok = ok && (ids.empty() || fread(ids.data(), 8, ids.size(), f) == ids.size());
+        if (!ok)
+            fail(MSVS_ERR_IO, "%s is truncated", path);
+        if (ix->type == MSVS_INDEX_IVFFLAT)
+        {
+            ix->nlist = nlist;
+            ix->centroids.alloc(nlist * ix->ld);
+            upload_rows(ix->centroids.p, cent.data(), nlist, (uint32_t)d, ix->ld, MSVS_MEM_HOST, nullptr);
+        }
+        ix->n = n;
+        ix->h_list_off = off;
+        ix->max_list_len = 0;
+        for (size_t l = 0; l < nlist; l++)
+            ix->max_list_len = std::max<size_t>(ix->max_list_len, (size_t)(off[l + 1] - off[l]));
+        ix->vecs.alloc(std::max<size_t>(n, 1) * ix->ld);
+        ix->row_ids.alloc(std::max<size_t>(n, 1));
+        ix->list_off.alloc(nlist + 1);
+        upload_rows(ix->vecs.p, vecs.data(), n, (uint32_t)d, ix->ld, MSVS_MEM_HOST, nullptr);
+        std::vector<uint32_t> h_ids(n);
+        for (size_t i = 0; i < n; i++)
+            h_ids[i] = (uint32_t)ids[i];
+        if (n)
+            MSVS_HIP(hipMemcpy(ix->row_ids.p, h_ids.data(), n * 4, hipMemcpyHostToDevice));
+        MSVS_HIP(hipMemcpy(ix->list_off.p, off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
+        MSVS_HIP(hipStreamSynchronize(nullptr));
+        ix->ready = true;
+        *out = ix.release();
+    });
+}
+
+// =========================================================================================== merge
+
+namespace msvs
+{
+static void merge_topk_device(const int64_t * d_ids, const float * d_dis, size_t nparts, size_t nq, size_t k,
+                              int metric, int64_t * d_out_ids, float * d_out_dis, hipStream_t stream)
+{
+    if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
+        fail(MSVS_ERR_NOT_IMPLEMENTED, "merge supports L2 / IP ordering (cosine distances are ascending: use L2)");
+    if (nq == 0 || k == 0)
+        return;
+    check_k(k);
+    Scratch & scr = scratch_for(stream);
+    const size_t total = nparts * nq * k;
+    scr.reserve(total * 8 * 2 + 8192, stream);
+    uint64_t * keys = scr.take<uint64_t>(total);       // [nparts][nq][k]
+    uint64_t * keys_q = scr.take<uint64_t>(total);     // [nq][nparts][k]
+    if (metric == MSVS_METRIC_IP)
+        hipLaunchKernelGGL((pack_keys_kernel<M_IP>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, d_ids,
+                           d_dis, keys, total);
+    else
+        hipLaunchKernelGGL((pack_keys_kernel<M_L2>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, d_ids,
+                           d_dis, keys, total);
+    MSVS_HIP(hipGetLastError());
+    // transpose [nparts][nq][k] -> [nq][nparts][k] with strided copies
+    MSVS_HIP(hipMemcpy2DAsync(keys_q, nparts * k * 8, keys, k * 8, k * 8, nq, hipMemcpyDeviceToDevice, stream));
+    for (size_t p = 1; p < nparts; p++)
+        MSVS_HIP(hipMemcpy2DAsync(keys_q + p * k, nparts * k * 8, keys + p * nq * k, k * 8, k * 8, nq,
+                                  hipMemcpyDeviceToDevice, stream));
+    MergeParams m{};
+    m.partial = keys_q;
+    m.n_lists = (uint32_t)nparts;
+    m.k = (uint32_t)k;
+    m.out_ids = d_out_ids;
+    m.out_dis = d_out_dis;
+    launch_merge(scan_metric(metric), m, (uint32_t)nq, stream);
+}
+}
+
+extern "C" int msvs_merge_topk_device(const int64_t * d_ids, const float * d_dis, size_t nparts, size_t nq, size_t k,
+                                      int metric, int64_t * d_out_ids, float * d_out_dis, void * hip_stream)
+{
+    return guarded([&] {
+        if (nparts && nq && k && (!d_ids || !d_dis || !d_out_ids || !d_out_dis))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
+        merge_topk_device(d_ids, d_dis, nparts, nq, k, metric, d_out_ids, d_out_dis, as_stream(hip_stream));
+    });
+}
+
+extern "C" int msvs_merge_topk(const int64_t * ids, const float * dis, size_t nparts, size_t nq, size_t k, int metric,
+                               int64_t * out_ids, float * out_dis)
+{
+    return guarded([&] {
+        if (nparts == 0 || nq == 0 || k == 0)
+            return;
+        if (!ids || !dis || !out_ids || !out_dis)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
+        const size_t total = nparts * nq * k;
+        DevBuf<int64_t> d_ids(total), d_oi(nq * k);
+        DevBuf<float> d_dis(total), d_od(nq * k);
+        MSVS_HIP(hipMemcpy(d_ids.p, ids, total * 8, hipMemcpyHostToDevice));
+        MSVS_HIP(hipMemcpy(d_dis.p, dis, total * 4, hipMemcpyHostToDevice));
+        merge_topk_device(d_ids.p, d_dis.p, nparts, nq, k, metric, d_oi.p, d_od.p, nullptr);
+        MSVS_HIP(hipMemcpy(out_ids, d_oi.p, nq * k * 8, hipMemcpyDeviceToHost));
+        MSVS_HIP(hipMemcpy(out_dis, d_od.p, nq * k * 4, hipMemcpyDeviceToHost));
+    });
+}

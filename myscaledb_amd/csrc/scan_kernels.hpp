@@ -1,0 +1,492 @@
+// scan_kernels.hpp -- CDNA4 (gfx950) device code of the candidate scan: batched L2 / IP distances of a
+// query tile against row-major f32 rows streamed from HBM, wavefront top-k, block / grid merges.
+//
+// Numerics contract (must stay bit-identical to oracle/msvs_oracle.c "W64 tree"):
+//   a row is owned by a 16-lane DPP row; lane g owns float4 columns g, g+16, g+32, ... and keeps one f32
+//   accumulator per float4 component, i.e. accumulator index (k mod 64) for element k; products and sums are
+//   separately rounded (__fmul_rn/__fadd_rn, never fma); the 64 partial sums are folded by the adjacent
+//   pairwise tree: (c0+c1)+(c2+c3) inside the lane, then lane^1, lane^2, quad^1, half^1 through DPP.
+// Top-k contract: 64-bit keys (orderable(distance) << 32 | id) ascending == canonical best-first order with
+//   ascending-id tie break; key ~0 is the "no result" sentinel (id -1).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msvs
+{
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256; // 4 waves
+constexpr uint64_t KEY_NONE = ~0ull;
+
+enum : int
+{
+    M_L2 = 0,
+    M_IP = 1
+};
+
+// ------------------------------------------------------------------------------------------ keys
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+template <int METRIC>
+__device__ __forceinline__ uint64_t make_key(float v, uint32_t id)
+{
+    // admitted only if strictly better than the heap's neutral value (NaN never): Faiss CMax/CMin semantics
+    bool ok = METRIC == M_IP ? (v > -3.402823466e+38f) : (v < 3.402823466e+38f);
+    uint32_t hi = METRIC == M_IP ? ~f2ord(v) : f2ord(v);
+    return ok ? ((uint64_t)hi << 32 | id) : KEY_NONE;
+}
+
+template <int METRIC>
+__device__ __forceinline__ float key_value(uint64_t key)
+{
+    if (key == KEY_NONE)
+        return METRIC == M_IP ? -3.402823466e+38f : 3.402823466e+38f;
+    uint32_t hi = (uint32_t)(key >> 32);
+    return ord2f(METRIC == M_IP ? ~hi : hi);
+}
+
+// ------------------------------------------------------------------------------------------ cross-lane helpers
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
+{
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return (uint64_t)hi << 32 | lo;
+}
+
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v)
+{
+    uint32_t lo = __shfl_up((int)(uint32_t)v, 1, WAVE);
+    uint32_t hi = __shfl_up((int)(uint32_t)(v >> 32), 1, WAVE);
+    return (uint64_t)hi << 32 | lo;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+/// Sum of the 16 lanes of a DPP row in adjacent-pairwise-tree order; every lane of the row gets the result.
+__device__ __forceinline__ float row16_tree_sum(float s)
+{
+    s = __fadd_rn(s, dpp<0xB1>(s));  // quad_perm [1,0,3,2]  : lane ^ 1
+    s = __fadd_rn(s, dpp<0x4E>(s));  // quad_perm [2,3,0,1]  : lane ^ 2
+    s = __fadd_rn(s, dpp<0x141>(s)); // row_half_mirror      : other quad of the half (quads are uniform by now)
+    s = __fadd_rn(s, dpp<0x140>(s)); // row_mirror           : other half of the row
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------ wavefront top-k
+
+/// Sorted (ascending key) list of up to 64*R entries spread over the lanes of one wavefront:
+/// entry e lives in register v[e / 64] of lane e % 64.  `thr` is the current k-th best key (wave-uniform).
+template <int R>
+struct WaveTopK
+{
+    uint64_t v[R];
+    uint64_t thr;
+
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            v[r] = KEY_NONE;
+        thr = KEY_NONE;
+    }
+
+    __device__ __forceinline__ void insert(uint64_t ckey, uint32_t k, uint32_t lane)
+    {
+        uint32_t pos = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            pos += __popcll(__ballot(v[r] < ckey));
+#pragma unroll
+        for (int r = R - 1; r >= 0; r--)
+        {
+            uint64_t up = shfl_up64(v[r]);
+            if (r > 0)
+            {
+                uint64_t carry = readlane64(v[r - 1], 63);
+                if (lane == 0)
+                    up = carry;
+            }
+            uint32_t e = r * 64 + lane;
+            v[r] = e < pos ? v[r] : (e == pos ? ckey : up);
+        }
+        uint32_t kr = (k - 1) >> 6, kl = (k - 1) & 63;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (r == (int)kr)
+                thr = readlane64(v[r], kl);
+    }
+
+    /// Offer one candidate per lane (KEY_NONE = nothing).
+    __device__ __forceinline__ void offer(uint64_t key, uint32_t k, uint32_t lane)
+    {
+        uint64_t m = __ballot(key < thr);
+        while (m)
+        {
+            int b = __builtin_ctzll(m);
+            m &= m - 1;
+            uint64_t ck = readlane64(key, b);
+            if (ck < thr)
+                insert(ck, k, lane);
+        }
+    }
+
+    __device__ __forceinline__ void store(uint64_t * dst, uint32_t k, uint32_t lane) const
+    {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+        {
+            uint32_t e = r * 64 + lane;
+            if (e < k)
+                dst[e] = v[r];
+        }
+    }
+};
+
+/// Merge the 4 per-wave sorted lists lists[w][0..k) (LDS) into out[0..k) (LDS) by rank: keys are unique
+/// (distinct ids) except for the sentinel, so rank = own index + #smaller keys in the other lists.
+/// Must be called by all BLOCK threads; ends with a barrier.
+__device__ __forceinline__ void block_rank_merge(const uint64_t * lists, uint32_t stride, uint64_t * out, uint32_t k,
+                                                 uint32_t tid)
+{
+    for (uint32_t i = tid; i < k; i += BLOCK)
+        out[i] = KEY_NONE;
+    __syncthreads();
+    for (uint32_t i = tid; i < 4 * k; i += BLOCK)
+    {
+        uint32_t w = i / k, e = i - w * k;
+        uint64_t key = lists[w * stride + e];
+        if (key == KEY_NONE)
+            continue;
+        uint32_t pos = e;
+        for (uint32_t o = 0; o < 4; o++)
+        {
+            if (o == w)
+                continue;
+            const uint64_t * l = lists + o * stride;
+            uint32_t lo = 0, hi = k; // first index with l[idx] >= key
+            while (lo < hi)
+            {
+                uint32_t mid = (lo + hi) >> 1;
+                if (l[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            pos += lo;
+        }
+        if (pos < k)
+            out[pos] = key;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ the scan
+
+struct ScanParams
+{
+    const float4 * Y;       // base rows, ld4 float4 per row (zero padded to a multiple of 4 floats)
+    const uint32_t * ids;   // nullable: id of stored row r (else r + id_base)
+    const uint64_t * alive; // nullable filter bitmap indexed by id, LSB-first
+    const float4 * Q;       // queries, ld4 float4 per row
+    uint64_t * partial;     // output keys
+    uint32_t id_base;
+    uint32_t nbits;
+    uint32_t ld4;
+    uint32_t k;
+    uint32_t nq;
+    // FLAT front end
+    uint32_t n_rows;
+    uint32_t rows_per_block;
+    uint32_t n_blocks; // partial lists per query
+    // IVF front end
+    const int32_t * probes;   // [nq][nprobe] list ids (-1 = none)
+    const int64_t * list_off; // [nlist+1]
+    uint32_t nprobe;
+    uint32_t seg_max;
+};
+
+/// Scans rows [row_begin,row_end) for T queries already staged in LDS (qs[t*ld4 + c]) and leaves the block's
+/// merged top-k of query t in out[t][0..k) (global).  All BLOCK threads participate.
+template <int METRIC, int T, int R>
+__device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_begin, uint32_t row_end,
+                                          const float4 * qs, uint64_t * lds_merge, uint64_t * const * out)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, g = lane & 15;
+    const uint32_t ld4 = a.ld4, k = a.k;
+    const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
+
+    WaveTopK<R> top[T];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+        top[t].init();
+
+    for (uint32_t base = row_begin + wave * 4; base < row_end; base += 16)
+    {
+        const uint32_t r = base + grp;
+        const bool rv = r < row_end;
+        const float4 * yrow = a.Y + (size_t)(rv ? r : row_end - 1) * ld4 + g;
+        const float4 * qrow = qs + g;
+
+        float4 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+            acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        auto step = [&](const float4 y, const float4 * qp) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+            {
+                const float4 q = qp[t * ld4];
+                if (METRIC == M_L2)
+                {
+                    float dx = __fsub_rn(q.x, y.x), dy = __fsub_rn(q.y, y.y), dz = __fsub_rn(q.z, y.z),
+                          dw = __fsub_rn(q.w, y.w);
+                    acc[t].x = __fadd_rn(acc[t].x, __fmul_rn(dx, dx));
+                    acc[t].y = __fadd_rn(acc[t].y, __fmul_rn(dy, dy));
+                    acc[t].z = __fadd_rn(acc[t].z, __fmul_rn(dz, dz));
+                    acc[t].w = __fadd_rn(acc[t].w, __fmul_rn(dw, dw));
+                }
+                else
+                {
+                    acc[t].x = __fadd_rn(acc[t].x, __fmul_rn(q.x, y.x));
+                    acc[t].y = __fadd_rn(acc[t].y, __fmul_rn(q.y, y.y));
+                    acc[t].z = __fadd_rn(acc[t].z, __fmul_rn(q.z, y.z));
+                    acc[t].w = __fadd_rn(acc[t].w, __fmul_rn(q.w, y.w));
+                }
+            }
+        };
+
+        uint32_t j = 0;
+        for (; j + 4 <= jfull; j += 4)
+        {
+            // 4 independent 16-byte loads in flight per lane (4 KiB per wave) before the first use
+            const float4 y0 = yrow[(j + 0) * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16],
+                         y3 = yrow[(j + 3) * 16];
+            step(y0, qrow + (j + 0) * 16);
+            step(y1, qrow + (j + 1) * 16);
+            step(y2, qrow + (j + 2) * 16);
+            step(y3, qrow + (j + 3) * 16);
+        }
+        for (; j < jfull; j++)
+            step(yrow[j * 16], qrow + j * 16);
+        if (g < jtail)
+            step(yrow[jfull * 16], qrow + jfull * 16);
+
+        // id + filter of this row (same value in the 16 lanes of the row; only lane g == 0 offers it)
+        uint32_t id = 0;
+        bool ok = rv && g == 0;
+        if (ok)
+        {
+            id = a.ids ? a.ids[r] : r + a.id_base;
+            if (a.alive)
+                ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++)
+        {
+            float s = __fadd_rn(__fadd_rn(acc[t].x, acc[t].y), __fadd_rn(acc[t].z, acc[t].w));
+            s = row16_tree_sum(s);
+            uint64_t key = ok ? make_key<METRIC>(s, id) : KEY_NONE;
+            top[t].offer(key, k, lane);
+        }
+    }
+
+    // 4 wave lists -> 1 block list per query
+    for (int t = 0; t < T; t++)
+    {
+        __syncthreads();
+        top[t].store(lds_merge + wave * k, k, lane);
+        __syncthreads();
+        uint64_t * merged = lds_merge + 4 * k;
+        block_rank_merge(lds_merge, k, merged, k, tid);
+        for (uint32_t i = tid; i < k; i += BLOCK)
+            out[t][i] = merged[i];
+    }
+}
+
+/// Stage T query rows (zero padded) into LDS.  Queries beyond nq repeat the last valid one.
+template <int T>
+__device__ __forceinline__ void stage_queries(const ScanParams & a, const uint32_t * qidx, float4 * qs)
+{
+    for (uint32_t i = threadIdx.x; i < T * a.ld4; i += BLOCK)
+    {
+        uint32_t t = i / a.ld4, c = i - t * a.ld4;
+        qs[i] = a.Q[(size_t)qidx[t] * a.ld4 + c];
+    }
+    __syncthreads();
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char msvs_smem[];
+
+/// LDS bytes a scan block needs.
+inline size_t scan_lds_bytes(uint32_t T, uint32_t ld4, uint32_t k) { return (size_t)T * ld4 * 16 + (size_t)5 * k * 8; }
+
+/// FLAT: grid (n_blocks, ceil(nq/T)); block bx scans rows [bx*rows_per_block, ...) for queries by*T...
+/// partial layout: [nq][n_blocks][k].
+template <int METRIC, int T, int R>
+__global__ __launch_bounds__(BLOCK) void flat_scan_kernel(const ScanParams a)
+{
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)T * a.ld4 * 16);
+    const uint32_t q0 = blockIdx.y * T;
+    uint32_t qidx[T];
+    uint64_t * out[T];
+    uint64_t * dummy = lds_merge + 5 * 0; // never used: duplicates write to their own (valid) slot of the last query
+    (void)dummy;
+#pragma unroll
+    for (int t = 0; t < T; t++)
+    {
+        uint32_t q = q0 + t < a.nq ? q0 + t : a.nq - 1;
+        qidx[t] = q;
+        out[t] = a.partial + ((size_t)q * a.n_blocks + blockIdx.x) * a.k;
+    }
+    stage_queries<T>(a, qidx, qs);
+    const uint32_t row_begin = blockIdx.x * a.rows_per_block;
+    uint32_t row_end = row_begin + a.rows_per_block;
+    if (row_end > a.n_rows)
+        row_end = a.n_rows;
+    scan_rows<METRIC, T, R>(a, row_begin < row_end ? row_begin : row_end, row_end, qs, lds_merge, out);
+}
+
+/// IVF, one query per block: grid (seg_max, nprobe, nq).  Block (s, p, q) scans segment s of the p-th probed
+/// list of query q.  partial layout: [nq][nprobe*seg_max][k]; empty segments write sentinels.
+template <int METRIC, int R>
+__global__ __launch_bounds__(BLOCK) void ivf_scan_kernel(const ScanParams a)
+{
+    const uint32_t s = blockIdx.x, p = blockIdx.y, q = blockIdx.z;
+    uint64_t * out0 = a.partial + (((size_t)q * a.nprobe + p) * a.seg_max + s) * a.k;
+    const int32_t list = a.probes[(size_t)q * a.nprobe + p];
+    int64_t lb = 0, le = 0;
+    if (list >= 0)
+    {
+        lb = a.list_off[list] + (int64_t)s * a.rows_per_block;
+        le = a.list_off[list + 1];
+        if (le > lb + a.rows_per_block)
+            le = lb + a.rows_per_block;
+    }
+    if (lb >= le)
+    {
+        for (uint32_t i = threadIdx.x; i < a.k; i += BLOCK)
+            out0[i] = KEY_NONE;
+        return;
+    }
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16);
+    uint32_t qidx[1] = {q};
+    uint64_t * out[1] = {out0};
+    stage_queries<1>(a, qidx, qs);
+    scan_rows<METRIC, 1, R>(a, (uint32_t)lb, (uint32_t)le, qs, lds_merge, out);
+}
+
+// ------------------------------------------------------------------------------------------ final merge
+
+struct MergeParams
+{
+    const uint64_t * partial; // [nq][n_lists][k]
+    uint32_t n_lists;
+    uint32_t k;
+    int64_t * out_ids;    // [nq][k] (mode 0)
+    float * out_dis;      // [nq][k] (mode 0)
+    int32_t * out_probes; // [nq][k] (mode 1)
+    uint64_t * out_keys;  // [nq][k] (mode 2: keep keys, for multi-level merges)
+    int mode;
+    int cosine; // mode 0: report 1 - ip
+};
+
+/// One block per query: top-k of n_lists*k keys.
+template <int METRIC, int R>
+__global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams a)
+{
+    uint64_t * lds = reinterpret_cast<uint64_t *>(msvs_smem);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k, q = blockIdx.x;
+    const uint64_t * src = a.partial + (size_t)q * a.n_lists * k;
+    const uint64_t total = (uint64_t)a.n_lists * k;
+    WaveTopK<R> top;
+    top.init();
+    for (uint64_t base = 0; base < total; base += BLOCK)
+    {
+        uint64_t i = base + tid;
+        uint64_t key = i < total ? src[i] : KEY_NONE;
+        top.offer(key, k, lane);
+    }
+    top.store(lds + wave * k, k, lane);
+    __syncthreads();
+    uint64_t * merged = lds + 4 * k;
+    block_rank_merge(lds, k, merged, k, tid);
+    for (uint32_t i = tid; i < k; i += BLOCK)
+    {
+        uint64_t key = merged[i];
+        size_t o = (size_t)q * k + i;
+        if (a.mode == 1)
+            a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
+        else if (a.mode == 2)
+            a.out_keys[o] = key;
+        else
+        {
+            a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
+            float v = key_value<METRIC>(key);
+            a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+        }
+    }
+}
+
+/// (ids, dis) lists -> keys, for msvs_merge_topk: [n] entries.
+template <int METRIC>
+__global__ void pack_keys_kernel(const int64_t * ids, const float * dis, uint64_t * keys, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        keys[i] = ids[i] < 0 ? KEY_NONE : make_key<METRIC>(dis[i], (uint32_t)ids[i]);
+}
+
+// ------------------------------------------------------------------------------------------ normalisation
+
+/// VectorDataset::normalize(): one thread per row, strictly sequential f32 sum of squares (the reference's order),
+/// rows with sum < FLT_EPSILON untouched.  ld = row stride in floats (>= d).
+static __global__ void normalize_rows_kernel(float * x, size_t n, uint32_t d, uint32_t ld)
+{
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n)
+        return;
+    float * p = x + r * ld;
+    float sum = 0.f;
+    for (uint32_t j = 0; j < d; j++)
+        sum = __fadd_rn(sum, __fmul_rn(p[j], p[j]));
+    if (sum < 1.1920928955078125e-7f)
+        return;
+    float s = __fsqrt_rn(sum);
+    for (uint32_t j = 0; j < d; j++)
+        p[j] = __fdiv_rn(p[j], s);
+}
+
+/// Copies rows with stride conversion (d -> ld, zero padding) on the device.
+static __global__ void pad_rows_kernel(const float * src, float * dst, size_t n, uint32_t d, uint32_t ld)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = n * ld;
+    if (i >= total)
+        return;
+    size_t r = i / ld;
+    uint32_t c = (uint32_t)(i - r * ld);
+    dst[i] = c < d ? src[r * d + c] : 0.f;
+}
+
+}

@@ -1,0 +1,35 @@
+"""CPU-side checks of the drop-in boundary: libmsvs.so loads without a GPU and exports every entry point that
+include/msvs.h declares (no compute calls here)."""
+import os
+import re
+
+import myscaledb_amd.capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, "include", "msvs.h")) as f:
+        src = f.read()
+    return sorted(set(re.findall(r"MSVS_API\s+[\w\s\*]+?\b(msvs_\w+)\s*\(", src)))
+
+
+def test_header_declares_what_the_binding_lists():
+    assert declared_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = capi.lib()
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+    assert capi.version().startswith("msvs")
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no product source may import, include, link or dlopen it."""
+    bad = re.compile(r"(^\s*(from|import)\s+oracle)|(#include\s*[\"<][^\">]*oracle)|(libmsvs_oracle)|(dlopen)", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "myscaledb_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or fn == "Makefile":
+                with open(os.path.join(dirpath, fn)) as f:
+                    assert not bad.search(f.read()), fn

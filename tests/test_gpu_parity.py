@@ -1,0 +1,373 @@
+"""GPU parity tests proper: everything goes through the C-ABI of libmsvs.so (ctypes) and is compared with the
+CPU oracle on the same seeded inputs -- ids bit-exact, distances bit-exact (the oracle and the kernels share one
+canonical arithmetic), which is stricter than the north-star 1e-4 relative tolerance."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import myscaledb_amd.capi as capi
+from golden_util import TextIndex, eval_filter, f32_of, load_goldens, materialize, tokenize
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+G = load_goldens()
+OM = {capi.METRIC_L2: o.METRIC_L2, capi.METRIC_IP: o.METRIC_IP, capi.METRIC_COSINE: o.METRIC_COSINE}
+
+
+def same(a_ids, a_dis, b_ids, b_dis):
+    assert a_ids.shape == b_ids.shape
+    assert (a_ids == b_ids).all(), np.argwhere(a_ids != b_ids)[:5]
+    assert (a_dis.view(np.uint32) == b_dis.view(np.uint32)).all()
+
+
+# ---------------------------------------------------------------------------------------- seam A2
+
+@pytest.mark.parametrize("nx,ny,d,k", [(1, 100, 3, 10), (3, 1000, 128, 10), (8, 5000, 768, 10), (17, 3000, 100, 30),
+                                       (2, 777, 5, 7), (4, 2000, 64, 100), (1, 4000, 48, 200), (5, 1536, 1536, 10),
+                                       (9, 10000, 128, 10), (1, 50000, 128, 64), (33, 999, 36, 1)])
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP])
+def test_knn_matches_oracle(nx, ny, d, k, metric):
+    rng = np.random.default_rng(nx * 1000 + ny + d + k)
+    x = rng.standard_normal((nx, d), dtype=np.float32)
+    y = rng.standard_normal((ny, d), dtype=np.float32)
+    ids, dis = capi.knn(x, y, k, metric)
+    oi, od = o.knn(x, y, k, OM[metric])
+    same(ids, dis, oi, od)
+
+
+def test_knn_fewer_rows_than_k_pads_with_minus_one():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 16), dtype=np.float32)
+    y = rng.standard_normal((5, 16), dtype=np.float32)
+    for metric in (capi.METRIC_L2, capi.METRIC_IP):
+        ids, dis = capi.knn(x, y, 8, metric)
+        oi, od = o.knn(x, y, 8, OM[metric])
+        same(ids, dis, oi, od)
+        assert (ids[:, 5:] == -1).all()
+
+
+def test_knn_ties_break_by_ascending_id_and_nan_inf_rows_are_skipped():
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal((600, 32), dtype=np.float32)
+    y[100:300] = y[7]  # 201 identical rows
+    y[400, 3] = np.nan
+    y[401, 5] = np.inf
+    y[402] = np.finfo(np.float32).max  # FLT_MAX padding of empty rows (MergeTreeVSManager.cpp:1380)
+    x = y[[7, 8]].copy()
+    for metric in (capi.METRIC_L2, capi.METRIC_IP):
+        ids, dis = capi.knn(x, y, 50, metric)
+        oi, od = o.knn(x, y, 50, OM[metric])
+        same(ids, dis, oi, od)
+    ids, _ = capi.knn(x, y, 50, capi.METRIC_L2)
+    assert ids[0, :5].tolist() == [7, 100, 101, 102, 103]
+    assert not np.isin(ids, [400, 401, 402]).any()
+
+
+def test_knn_cosine_is_not_implemented_like_the_reference():
+    x = np.zeros((1, 4), np.float32)
+    with pytest.raises(capi.MsvsError) as e:
+        capi.knn(x, x, 1, capi.METRIC_COSINE)
+    assert e.value.code == capi.ERR_NOT_IMPLEMENTED
+
+
+def test_k_too_large_is_an_error_not_a_fallback():
+    x = np.zeros((1, 4), np.float32)
+    with pytest.raises(capi.MsvsError) as e:
+        capi.knn(x, np.zeros((1000, 4), np.float32), 257, capi.METRIC_L2)
+    assert e.value.code == capi.ERR_UNSUPPORTED_K
+
+
+def test_normalize_matches_reference_normalize():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((300, 77), dtype=np.float32) * 5
+    x[5] = 0  # below FLT_EPSILON: left untouched
+    x[6] = 1e-5
+    a = capi.normalize(x)
+    b = o.normalize_rows(x)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("name", ["00001_flat_l2", "00002_batch_l2", "00002_batch_ip"])
+def test_golden_via_knn(name):
+    c = G[name]
+    parts = c.get("parts") or [c["base"]]
+    k = c["k"]
+    q = np.array(c["queries"], np.float32)
+    m = capi.METRICS[c["metric"]]
+    res = []
+    for segs in parts:
+        ids, vecs, _ = materialize(segs)
+        i, d = capi.knn(q, vecs, k, m)
+        res.append((ids[i], d))
+    for qi in range(len(q)):
+        ids = np.concatenate([r[0][qi] for r in res])
+        dis = np.concatenate([r[1][qi] for r in res])
+        order = np.argsort(-dis if c["metric"] == "IP" else dis, kind="stable")[:k]
+        assert ids[order].tolist() == c["ids"][qi]
+        assert dis[order].tolist() == f32_of(c["dists"][qi]).tolist()
+
+
+# ---------------------------------------------------------------------------------------- seam A1: FLAT
+
+@pytest.mark.parametrize("name", ["00001_flat_l2", "00003_prewhere", "00008_empty_vectors", "00014_cosine_d4_index",
+                                  "00028_768_l2", "00028_768_cosine", "00028_768_cosine_where", "00028_768_cosine_lwd"])
+def test_golden_via_flat_index(name):
+    c = G[name]
+    ids, vecs, empty = materialize(c["base"])
+    metric = capi.METRICS[c["metric"]]
+    ix = capi.Index(capi.INDEX_FLAT, metric, vecs.shape[1])
+    ix.add(vecs[~empty], ids[~empty])  # empty rows are never fed to the index build (VIPartReader.h:240-244)
+    ix.build()
+    alive = None
+    if c.get("filter") or c.get("deleted"):
+        alive = np.zeros(int(ids.max()) + 1, bool)
+        alive[ids] = eval_filter(c.get("filter"), ids) & ~np.isin(ids, c.get("deleted", []))
+    i, d = ix.search(np.array(c["queries"], np.float32), c["k"], alive=alive)
+    exp = f32_of(c["dists"][0])
+    assert i[0].tolist() == c["ids"][0]
+    if name.startswith("00028"):
+        assert np.abs(d[0] / exp - 1).max() < 2e-6  # accumulation order not pinned at d=768, tolerance 1e-4
+    else:
+        assert d[0].tolist() == exp.tolist()
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("n,d,nq,k", [(5000, 128, 7, 10), (3000, 768, 64, 10), (1200, 40, 3, 100)])
+def test_flat_index_filter_and_labels(metric, n, d, nq, k):
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    labels = rng.permutation(n * 3)[:n].astype(np.int64)
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    alive = rng.random(n * 3) < 0.3
+    ix = capi.Index(capi.INDEX_FLAT, metric, d)
+    ix.add(x[: n // 2], labels[: n // 2])  # chunked feed
+    ix.add(x[n // 2:], labels[n // 2:])
+    ix.build()
+    assert ix.ready and ix.num_data == n
+    ids, dis = ix.search(q, k, alive=alive)
+    if metric == capi.METRIC_COSINE:
+        xn, qn = o.normalize_rows(x), o.normalize_rows(q)
+        oi, od = o.knn(qn, xn, k, o.METRIC_IP, labels=labels, alive=alive[labels])
+        od = (np.float32(1) - od).astype(np.float32)
+    else:
+        oi, od = o.knn(q, x, k, OM[metric], labels=labels, alive=alive[labels])
+    same(ids, dis, oi, od)
+
+
+# ---------------------------------------------------------------------------------------- seam A1: IVFFLAT
+
+def build_ivf(x, metric, nlist, ids=None, params=""):
+    ix = capi.Index(capi.INDEX_IVFFLAT, metric, x.shape[1], "ncentroids=%d,kmeans_iters=5%s" % (nlist, params))
+    ix.train(x)
+    half = x.shape[0] // 2
+    ix.add(x[:half], None if ids is None else ids[:half])
+    ix.add(x[half:], None if ids is None else ids[half:])
+    ix.build()
+    return ix
+
+
+def oracle_on_exported(ix, q, nprobe, k, metric, alive=None):
+    cent, off, vecs, lids = ix.export()
+    if metric == capi.METRIC_COSINE:
+        oi, od, pr = o.ivf_search(cent, off, vecs, lids, o.normalize_rows(q), nprobe, k, o.METRIC_IP, alive=alive)
+        return oi, (np.float32(1) - od).astype(np.float32), pr
+    return o.ivf_search(cent, off, vecs, lids, q, nprobe, k, OM[metric], alive=alive)
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(20000, 128, 64, 16, 8, 10), (30000, 768, 128, 5, 32, 10),
+                                                   (8000, 100, 32, 1, 4, 100), (6000, 36, 16, 70, 16, 30)])
+def test_ivfflat_matches_oracle_on_exported_structure(metric, n, d, nlist, nq, nprobe, k):
+    rng = np.random.default_rng(n + d + nlist)
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, metric, nlist)
+    assert ix.num_data == n and ix.num_lists == nlist
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+    same(ids, dis, oi, od)
+    # with a filter bitmap (PREWHERE / lightweight delete)
+    alive = rng.random(n) < 0.5
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=alive)
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric, alive=alive)
+    same(ids, dis, oi, od)
+
+
+def test_ivfflat_structure_invariants_and_full_probe_equals_flat():
+    rng = np.random.default_rng(11)
+    n, d, nlist = 12000, 64, 48
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    ids = (np.arange(n, dtype=np.int64) * 3 + 1)
+    ix = build_ivf(x, capi.METRIC_L2, nlist, ids=ids)
+    cent, off, vecs, lids = ix.export()
+    assert off[0] == 0 and off[-1] == n and (np.diff(off) >= 0).all()
+    assert sorted(lids.tolist()) == ids.tolist()  # a permutation of the fed ids
+    for l in range(nlist):
+        seg = lids[off[l]:off[l + 1]]
+        assert (np.diff(seg) > 0).all()  # ascending ids inside a list
+    back = {int(i): r for r, i in enumerate(lids)}
+    pick = rng.integers(0, n, 200)
+    assert all((vecs[back[int(ids[p])]] == x[p]).all() for p in pick)  # rows moved intact
+    # every row sits in (one of) its nearest list(s): compare against the oracle's canonical assignment
+    a = o.assign(x[pick], cent)
+    got = np.searchsorted(off, [back[int(ids[p])] for p in pick], side="right") - 1
+    assert (a == got).mean() > 0.97  # MFMA assignment may differ only on near-ties
+    # probing every list == exhaustive search
+    q = rng.standard_normal((9, d), dtype=np.float32)
+    i1, d1 = ix.search(q, 10, "nprobe=%d" % nlist)
+    oi, od = o.knn(q, x, 10, o.METRIC_L2, labels=ids)
+    same(i1, d1, oi, od)
+
+
+def test_ivfflat_recall_on_clustered_data():
+    rng = np.random.default_rng(12)
+    n, d, nlist = 50000, 64, 64
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 3
+    x = (centers[rng.integers(0, nlist, n)] + 0.5 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, 50)] + 0.5 * rng.standard_normal((50, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, capi.METRIC_L2, nlist)
+    ids, _ = ix.search(q, 10, "nprobe=8")
+    gt, _ = o.knn(q, x, 10, o.METRIC_L2, threads=8)
+    recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(ids.tolist(), gt.tolist())])
+    assert recall >= 0.95
+
+
+def test_index_errors_and_serialization_roundtrip():
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((4000, 32), dtype=np.float32)
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, 32, "ncentroids=16")
+    with pytest.raises(capi.MsvsError) as e:
+        ix.add(x)  # not trained
+    assert e.value.code == capi.ERR_NOT_READY
+    ix.train(x)
+    ix.add(x)
+    with pytest.raises(capi.MsvsError) as e:
+        ix.search(x[:1], 5, "nprobe=4")  # not built
+    assert e.value.code == capi.ERR_NOT_READY
+    ix.build()
+    with pytest.raises(capi.MsvsError) as e:
+        ix.search(x[:1], 5, "alpha=3")  # unknown search parameter -> BAD_ARGUMENTS (00040 golden, serverError)
+    assert e.value.code == capi.ERR_INVALID_ARGUMENT
+    a = ix.search(x[:20], 5, "nprobe=4")
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "v1-ivfflat.vidx3")
+        ix.serialize(p)
+        ix2 = capi.Index.load(p, capi.INDEX_IVFFLAT, capi.METRIC_L2, 32)
+    b = ix2.search(x[:20], 5, "nprobe=4")
+    same(a[0], a[1], b[0], b[1])
+    with pytest.raises(capi.MsvsError):
+        capi.Index(7, capi.METRIC_L2, 8)
+
+
+def test_sharded_lists_merge_equals_unsharded():
+    """lists sharded list_id % W across W index objects + canonical merge == the unsharded index."""
+    rng = np.random.default_rng(14)
+    n, d, nlist, W = 16000, 48, 32, 4
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((11, d), dtype=np.float32)
+    full = build_ivf(x, capi.METRIC_IP, nlist)
+    cent = full.export()[0]
+    parts = []
+    for r in range(W):
+        ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_IP, d, "shard_rank=%d,shard_world=%d" % (r, W))
+        ix.set_centroids(cent)
+        ix.add(x)
+        ix.build()
+        parts.append(ix.search(q, 10, "nprobe=8"))
+    assert sum(1 for _ in parts) == W
+    mi, md = capi.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), capi.METRIC_IP)
+    fi, fd = full.search(q, 10, "nprobe=8")
+    same(mi, md, fi, fd)
+
+
+# ---------------------------------------------------------------------------------------- seam B: BM25
+
+def bm25_both(docs_texts, query, k, alive=None):
+    idx = TextIndex(docs_texts, o.fieldnorm_id)
+    terms = [t for t in tokenize(query) if t in idx.vocab]
+    qt = [idx.vocab[t] for t in terms]
+    df = [idx.doc_freq(t) for t in terms]
+    ps = capi.Postings(idx.post_off, idx.doc_ids, idx.tfs, idx.fieldnorm_ids)
+    got = ps.bm25_search(qt, df, idx.num_docs, idx.total_tokens, k, alive=alive)
+    exp = o.bm25_search(idx.post_off, idx.doc_ids, idx.tfs, idx.fieldnorm_ids, qt, df, idx.num_docs,
+                        idx.total_tokens, k, alive=alive)
+    return got, exp
+
+
+def test_bm25_goldens_on_gpu():
+    c = G["00040_hybrid"]
+    got, exp = bm25_both([d["texts"] for d in c["docs"]], c["text_query"], 5)
+    assert got[0].tolist() == exp[0].tolist() == [13, 0]
+    assert got[1].tolist() == f32_of(c["text_search"][1]).tolist()
+    c = G["00040_text_array"]
+    got, exp = bm25_both([d["texts"] for d in c["docs"]], c["text_query"], 5)
+    assert [c["docs"][int(r)]["id"] for r in got[0]] == c["text_search"][0]
+    assert got[1].tolist() == f32_of(c["text_search"][1]).tolist()
+
+
+def test_bm25_synthetic_corpus_matches_oracle():
+    rng = np.random.default_rng(21)
+    vocab = ["w%d" % i for i in range(3000)]
+    p = 1.0 / np.arange(1, len(vocab) + 1) ** 1.1
+    p /= p.sum()
+    docs = []
+    for _ in range(40000):
+        n = max(1, rng.poisson(30))
+        docs.append([" ".join(vocab[j] for j in rng.choice(len(vocab), n, p=p))])
+    alive = rng.random(len(docs)) < 0.7
+    for query in ("w3 w17 w250", "w1", "w40 w41 w42 w43", "w2999 w5"):
+        for k in (10, 100):
+            got, exp = bm25_both(docs, query, k)
+            assert got[0].tolist() == exp[0].tolist()
+            assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
+        got, exp = bm25_both(docs, query, 10, alive=alive)
+        assert got[0].tolist() == exp[0].tolist()
+        assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
+
+
+# ---------------------------------------------------------------------------------------- BASELINE-size properties
+
+def test_full_size_1m_x_768_properties():
+    """BASELINE config 2 shape (1M x 768, nlist 1024, nprobe 32, top-10): the oracle cannot redo all of it in
+    seconds, so check size-independent properties + a handful of oracle-verified queries."""
+    import torch
+
+    n, d, nlist, nq, k, nprobe = 1_000_000, 768, 1024, 64, 10, 32
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x_dev = torch.randn((n, d), generator=g, device="cuda", dtype=torch.float32)
+    q_dev = torch.randn((nq, d), generator=g, device="cuda", dtype=torch.float32)
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=%d,kmeans_iters=4,train_sample=32768" % nlist)
+    ix.train(x_dev.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+    ix.add(x_dev.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+    ix.build()
+    assert ix.num_data == n
+    q = q_dev.cpu().numpy()
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    # (1) sortedness, uniqueness, valid ids
+    assert (np.diff(dis, axis=1) >= 0).all()
+    assert all(len(set(r)) == k for r in ids.tolist()) and ids.min() >= 0 and ids.max() < n
+    # (2) idempotence / batch independence: one query alone == the same query inside the batch
+    i1, d1 = ix.search(q[5:6], k, "nprobe=%d" % nprobe)
+    same(i1, d1, ids[5:6], dis[5:6])
+    # (3) the reported distance is the canonical distance of the reported row
+    x_rows = x_dev[torch.from_numpy(ids[:4].reshape(-1)).cuda()].cpu().numpy().reshape(4, k, d)
+    for qi in range(4):
+        for j in range(k):
+            assert o.l2sqr(q[qi], x_rows[qi, j]) == dis[qi, j]
+    # (4) oracle on the exported structure for a few queries
+    cent, off, vecs, lids = ix.export()
+    oi, od, _ = o.ivf_search(cent, off, vecs, lids, q[:6], nprobe, k, o.METRIC_L2, threads=8)
+    same(ids[:6], dis[:6], oi, od)
+    # (5) probing all lists == exhaustive FLAT scan of the resident rows (ids and distances)
+    flat = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
+    flat.add(x_dev.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+    flat.build()
+    fi, fd = flat.search(q[:8], k)
+    ai, ad = ix.search(q[:8], k, "nprobe=256")
+    oe, de = o.knn(q[:2], x_dev.cpu().numpy(), k, o.METRIC_L2, threads=8)
+    same(fi[:2], fd[:2], oe, de)
+    # nprobe=256 of 1024 lists on iid gaussians is not exhaustive; it can only be worse or equal, never better
+    assert (ad >= fd - 0).all()
