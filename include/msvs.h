@@ -125,6 +125,17 @@ MSVS_API int msvs_index_export(const msvs_index_t * index, float * centroids, in
 MSVS_API int msvs_index_serialize(const msvs_index_t * index, const char * path);
 MSVS_API int msvs_index_load(const char * path, msvs_index_t ** out);
 
+/* Measurement support (bench.py): number of stored rows the list scan of msvs_index_search(queries, nprobe)
+ * has to read, i.e. sum over (query, probed list) of the list length; FLAT: nq * num_data.  Queries are HOST. */
+MSVS_API int msvs_index_scanned_rows(const msvs_index_t * index, const float * queries, size_t nq, int nprobe,
+                                     uint64_t * rows);
+/* Kernel timing with HIP events recorded on the launch stream around every kernel of the scan path.
+ * enable(1) starts collecting, get() synchronises and returns call count and summed milliseconds of the kernel
+ * family `name` ("flat_scan", "ivf_scan", "merge", "bm25_score"), reset() drops the samples. */
+MSVS_API int msvs_profile_enable(int on);
+MSVS_API int msvs_profile_get(const char * name, uint64_t * calls, double * total_ms);
+MSVS_API int msvs_profile_reset(void);
+
 /* Multi-part / multi-GPU merge of partial top-k lists with the canonical total order -- the
  * device-side analogue of MergeTreeBaseSearchManager::getTotalTopSearchResultImpl
  * (src/VectorIndex/Storages/MergeTreeBaseSearchManager.cpp:207-299) for lists that share one id space.

@@ -25,7 +25,8 @@ SYMBOLS = [
     "msvs_index_set_centroids", "msvs_index_add", "msvs_index_build", "msvs_index_ready", "msvs_index_num_data",
     "msvs_index_num_lists", "msvs_index_memory_usage", "msvs_index_search", "msvs_index_search_device",
     "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
-    "msvs_postings_create", "msvs_postings_free", "msvs_bm25_search",
+    "msvs_postings_create", "msvs_postings_free", "msvs_bm25_search", "msvs_index_scanned_rows",
+    "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset",
 ]
 
 
@@ -97,6 +98,21 @@ def synchronize():
     _check(lib().msvs_device_synchronize())
 
 
+def profile_enable(on):
+    _check(lib().msvs_profile_enable(int(bool(on))))
+
+
+def profile_reset():
+    _check(lib().msvs_profile_reset())
+
+
+def profile_get(name):
+    """-> (calls, total_ms) of the kernel family `name` since the last reset (synchronises)."""
+    c, t = C.c_uint64(0), C.c_double(0)
+    _check(lib().msvs_profile_get(name.encode(), C.byref(c), C.byref(t)))
+    return c.value, t.value
+
+
 def knn(x, y, k, metric):
     """msvs_knn_f32 (seam A2).  x [nx,d], y [ny,d] host arrays -> (ids int64 [nx,k], dis f32 [nx,k])."""
     y = _f32(y)
@@ -143,8 +159,8 @@ class Index:
         self._h = h
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().msvs_index_free(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.msvs_index_free(self._h)
             self._h = None
 
     __del__ = close
@@ -216,6 +232,13 @@ class Index:
                                               C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
                                               C.c_void_p(int(stream)) if stream else None))
 
+    def scanned_rows(self, queries, nprobe):
+        q = _f32(queries).reshape(-1, self.dim)
+        rows = C.c_uint64(0)
+        _check(lib().msvs_index_scanned_rows(self._h, _p(q, C.c_float), C.c_size_t(q.shape[0]), int(nprobe),
+                                             C.byref(rows)))
+        return rows.value
+
     def export(self):
         n, nl, d = self.num_data, self.num_lists, self.dim
         cent = np.empty((nl, d), np.float32) if self.index_type == INDEX_IVFFLAT else None
@@ -252,8 +275,8 @@ class Postings:
         self.num_docs = fieldnorm_ids.size
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().msvs_postings_free(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.msvs_postings_free(self._h)
             self._h = None
 
     __del__ = close

@@ -128,6 +128,7 @@ extern "C" int msvs_bm25_search(const msvs_postings_t * ps, const uint32_t * qte
         }
         a.partial = partial;
         const size_t lds = (size_t)5 * k * 8;
+        ProfileScope prof("bm25_score", stream);
         switch (r_for_k((uint32_t)k))
         {
             case 1:

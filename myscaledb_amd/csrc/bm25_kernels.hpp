@@ -9,6 +9,8 @@
 
 #include "scan_kernels.hpp"
 
+#pragma clang fp contract(off)
+
 namespace msvs
 {
 

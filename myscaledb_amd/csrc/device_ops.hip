@@ -1,6 +1,7 @@
 // device_ops.hip -- kernel instantiation + launch dispatch for the scan / merge kernels.
 #include "device_ops.hpp"
 
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -30,6 +31,73 @@ Scratch & scratch_for(hipStream_t stream)
     int dev = 0;
     MSVS_HIP(hipGetDevice(&dev));
     return arenas[{dev, stream}];
+}
+
+// ------------------------------------------------------------------------------------------ profiling
+
+namespace
+{
+struct Sample
+{
+    const char * name;
+    hipEvent_t start, stop;
+};
+std::mutex g_prof_mu;
+std::vector<Sample> g_samples;
+std::atomic<bool> g_prof_on{false};
+}
+
+void profile_enable(bool on) { g_prof_on.store(on); }
+
+ProfileScope::ProfileScope(const char * n, hipStream_t s) : name(n), stream(s)
+{
+    if (!g_prof_on.load(std::memory_order_relaxed))
+        return;
+    MSVS_HIP(hipEventCreate(&start));
+    MSVS_HIP(hipEventRecord(start, stream));
+}
+
+ProfileScope::~ProfileScope()
+{
+    if (!start)
+        return;
+    hipEvent_t stop = nullptr;
+    if (hipEventCreate(&stop) != hipSuccess || hipEventRecord(stop, stream) != hipSuccess)
+        return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_samples.push_back({name, start, stop});
+}
+
+void profile_get(const char * name, uint64_t * calls, double * total_ms)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    uint64_t c = 0;
+    double t = 0;
+    for (auto & s : g_samples)
+    {
+        if (strcmp(s.name, name) != 0)
+            continue;
+        MSVS_HIP(hipEventSynchronize(s.stop));
+        float ms = 0;
+        MSVS_HIP(hipEventElapsedTime(&ms, s.start, s.stop));
+        c++;
+        t += ms;
+    }
+    if (calls)
+        *calls = c;
+    if (total_ms)
+        *total_ms = t;
+}
+
+void profile_reset()
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto & s : g_samples)
+    {
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    g_samples.clear();
 }
 
 FlatPlan plan_flat(size_t n_rows, size_t nq)
@@ -94,6 +162,7 @@ void launch_flat_scan(int metric, const FlatPlan & plan, ScanParams a, hipStream
     a.n_blocks = plan.n_blocks;
     if (scan_lds_bytes(plan.T, a.ld4, a.k) > 160 * 1024)
         fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large for the LDS query tile", a.ld4 * 4);
+    ProfileScope prof("flat_scan", stream);
     if (metric == M_IP)
         flat_dispatch_t<M_IP>(plan, a, stream);
     else
@@ -123,6 +192,7 @@ void launch_merge(int metric, MergeParams a, uint32_t nq, hipStream_t stream)
 {
     if (nq == 0)
         return;
+    ProfileScope prof("merge", stream);
     if (metric == M_IP)
         merge_dispatch<M_IP>(a, nq, stream);
     else
@@ -153,6 +223,7 @@ void launch_ivf_scan(int metric, ScanParams a, hipStream_t stream)
 {
     if (a.nq == 0 || a.nprobe == 0 || a.seg_max == 0)
         return;
+    ProfileScope prof("ivf_scan", stream);
     if (metric == M_IP)
         ivf_dispatch<M_IP>(a, stream);
     else

@@ -30,6 +30,19 @@ struct Scratch
 
 Scratch & scratch_for(hipStream_t stream);
 
+/// Optional HIP-event timing of kernel launches (msvs_profile_* in the C-ABI); a no-op unless enabled.
+struct ProfileScope
+{
+    ProfileScope(const char * name, hipStream_t stream);
+    ~ProfileScope();
+    const char * name;
+    hipStream_t stream;
+    hipEvent_t start = nullptr;
+};
+void profile_enable(bool on);
+void profile_get(const char * name, uint64_t * calls, double * total_ms);
+void profile_reset();
+
 inline int r_for_k(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : 4); }
 
 struct FlatPlan

@@ -668,6 +668,69 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
     });
 }
 
+extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * queries, size_t nq, int nprobe,
+                                       uint64_t * rows)
+{
+    return guarded([&] {
+        if (!ix || !rows || (nq && !queries))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
+        if (!ix->ready)
+            fail(MSVS_ERR_NOT_READY, "index is not ready");
+        *rows = 0;
+        if (nq == 0)
+            return;
+        if (ix->type == MSVS_INDEX_FLAT)
+        {
+            *rows = (uint64_t)nq * ix->n;
+            return;
+        }
+        size_t np = std::min<size_t>((size_t)std::max(nprobe, 1), ix->nlist);
+        check_k(np);
+        hipStream_t stream = nullptr;
+        const uint32_t d = (uint32_t)ix->dim, ld = ix->ld;
+        DevBuf<float> dq(nq * ld);
+        DevBuf<int32_t> d_probes(nq * np);
+        upload_rows(dq.p, queries, nq, d, ld, MSVS_MEM_HOST, stream);
+        if (ix->metric == MSVS_METRIC_COSINE)
+            normalize_device_rows(dq.p, nq, d, ld, stream);
+        Scratch & scr = scratch_for(stream);
+        scr.reserve(flat_scratch_bytes(ix->nlist, nq, (uint32_t)np) + 4096, stream);
+        MergeParams co{};
+        co.mode = 1;
+        co.out_probes = d_probes.p;
+        const int m = ix->metric == MSVS_METRIC_L2 ? MSVS_METRIC_L2 : MSVS_METRIC_IP;
+        flat_search_device(scr, m, ix->centroids.p, nullptr, ix->nlist, ld, dq.p, nq, (uint32_t)np, nullptr, 0, co,
+                           stream);
+        std::vector<int32_t> h(nq * np);
+        MSVS_HIP(hipMemcpyAsync(h.data(), d_probes.p, h.size() * 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+        uint64_t total = 0;
+        for (int32_t l : h)
+            if (l >= 0)
+                total += (uint64_t)(ix->h_list_off[l + 1] - ix->h_list_off[l]);
+        *rows = total;
+    });
+}
+
+extern "C" int msvs_profile_enable(int on)
+{
+    return guarded([&] { profile_enable(on != 0); });
+}
+
+extern "C" int msvs_profile_get(const char * name, uint64_t * calls, double * total_ms)
+{
+    return guarded([&] {
+        if (!name)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null name");
+        profile_get(name, calls, total_ms);
+    });
+}
+
+extern "C" int msvs_profile_reset(void)
+{
+    return guarded([&] { profile_reset(); });
+}
+
 extern "C" int msvs_index_export(const msvs_index_t * ix, float * centroids, int64_t * list_off, float * vecs,
                                  int64_t * ids)
 {

@@ -13,6 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// __fmul_rn/__fadd_rn/__fsub_rn are plain operators in this toolchain: keep the compiler from fusing them.
+#pragma clang fp contract(off)
+
 namespace msvs
 {
 
@@ -472,7 +475,9 @@ static __global__ void normalize_rows_kernel(float * x, size_t n, uint32_t d, ui
         sum = __fadd_rn(sum, __fmul_rn(p[j], p[j]));
     if (sum < 1.1920928955078125e-7f)
         return;
-    float s = __fsqrt_rn(sum);
+    // NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS that is v_sqrt_f32 (1 ulp); sqrtf() is IEEE-correct
+    // under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt, and so is operator/ behind __fdiv_rn.
+    float s = sqrtf(sum);
     for (uint32_t j = 0; j < d; j++)
         p[j] = __fdiv_rn(p[j], s);
 }
