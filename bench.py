@@ -180,11 +180,18 @@ def main():
     c_calls, c_ms = capi.profile_get("flat_scan")
     m_calls, m_ms = capi.profile_get("merge")
     capi.profile_reset()
-    rows = sum(ix.scanned_rows(q_all[(i % n_pool) * B:(i % n_pool + 1) * B].cpu().numpy(), nprobe)
-               for i in range(min(args.steps, n_pool)))
-    bytes_per_launch = rows * (4 * d + 4) / max(calls, 1)
+    sr = [ix.scanned_rows(q_all[(i % n_pool) * B:(i % n_pool + 1) * B].cpu().numpy(), nprobe)
+          for i in range(min(args.steps, n_pool))]
+    rows_model = sum(r[0] for r in sr)     # sum over (query, probed list) of list length: SURVEY 8d per-query model
+    rows_streamed = sum(r[1] for r in sr)  # rows the launch streams given its query tiles (<= rows_model)
+    bytes_per_launch = rows_streamed * (4 * d + 4) / max(calls, 1)
+    model_bytes_per_launch = rows_model * (4 * d + 4) / max(calls, 1)
     scan_ms = total_ms / max(calls, 1)
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    model_gbs = model_bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # f32 VALU work of the same launch: 3 ops (sub, mul, add) per (query, row, element), vs the 78.6 T lane-op/s
+    # non-packed VALU issue peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
+    valu_frac = (rows_model * d * 3 / max(calls, 1)) / (scan_ms * 1e-3) / 78.6e12 if scan_ms > 0 else 0.0
     if world > 1:
         # report the slowest rank's kernel (bytes are this rank's local lists)
         t = torch.tensor([achieved], device=dev, dtype=torch.float64)
@@ -254,8 +261,13 @@ def main():
             "p99_ms_batch1": round(float(np.percentile(lat, 99)), 4) if lat else None,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "ivf_scan_kernel", "launch_ms": round(scan_ms, 4),
+                         "kernel": "ivf_batched_scan_kernel (T-query tiles per list pass)" if B * nprobe >= nlist
+                         else "ivf_scan_kernel", "launch_ms": round(scan_ms, 4),
                          "bytes_per_launch": int(bytes_per_launch),
+                         "note": "achieved = bytes the launch streams (sum over (list, query tile) of list bytes) / "
+                                 "kernel time; per_query_model_gbs = SURVEY 8d per-query bytes x queries / time "
+                                 "(exceeds HBM speed when a list pass is shared by a tile of queries)",
+                         "per_query_model_gbs": round(model_gbs, 1), "valu_issue_frac": round(valu_frac, 4),
                          "other_kernels_ms": {"coarse_flat_scan": round(c_ms / max(c_calls, 1), 4),
                                               "merge(avg of 2)": round(m_ms / max(m_calls, 1), 4)}},
             "cpu_baseline": cpu,

@@ -231,6 +231,97 @@ void launch_ivf_scan(int metric, ScanParams a, hipStream_t stream)
     MSVS_HIP(hipGetLastError());
 }
 
+void launch_ivf_plan(const IvfPlanParams & p, hipStream_t stream)
+{
+    if (p.n_pairs == 0)
+        return;
+    ProfileScope prof("ivf_plan", stream);
+    unsigned g = (unsigned)ceil_div(p.n_pairs, 256);
+    hipLaunchKernelGGL(ivf_hist_kernel, dim3(g), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(ivf_scatter_kernel, dim3(g), dim3(256), 0, stream, p);
+    MSVS_HIP(hipGetLastError());
+}
+
+template <int METRIC, int T>
+static void ivf_batched_dispatch_r(uint32_t grid, const ScanParams & a, hipStream_t stream)
+{
+    size_t lds = scan_lds_bytes(T, a.ld4, a.k);
+    switch (r_for_k(a.k))
+    {
+        case 1:
+            hipLaunchKernelGGL((ivf_batched_scan_kernel<METRIC, T, 1>), dim3(grid), dim3(BLOCK), lds, stream, a);
+            break;
+        case 2:
+            hipLaunchKernelGGL((ivf_batched_scan_kernel<METRIC, T, 2>), dim3(grid), dim3(BLOCK), lds, stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((ivf_batched_scan_kernel<METRIC, T, 4>), dim3(grid), dim3(BLOCK), lds, stream, a);
+            break;
+    }
+}
+
+template <int METRIC>
+static void ivf_batched_dispatch_t(uint32_t T, uint32_t grid, const ScanParams & a, hipStream_t stream)
+{
+    switch (T)
+    {
+        case 2:
+            ivf_batched_dispatch_r<METRIC, 2>(grid, a, stream);
+            break;
+        case 4:
+            ivf_batched_dispatch_r<METRIC, 4>(grid, a, stream);
+            break;
+        default:
+            ivf_batched_dispatch_r<METRIC, 8>(grid, a, stream);
+            break;
+    }
+}
+
+void launch_ivf_batched_scan(int metric, uint32_t T, uint32_t grid, ScanParams a, hipStream_t stream)
+{
+    if (grid == 0)
+        return;
+    if (scan_lds_bytes(T, a.ld4, a.k) > 160 * 1024)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large for the LDS query tile", a.ld4 * 4);
+    ProfileScope prof("ivf_scan", stream);
+    if (metric == M_IP)
+        ivf_batched_dispatch_t<M_IP>(T, grid, a, stream);
+    else
+        ivf_batched_dispatch_t<M_L2>(T, grid, a, stream);
+    MSVS_HIP(hipGetLastError());
+}
+
+template <int METRIC>
+static void ivf_merge_dispatch(const IvfMergeParams & a, uint32_t nq, hipStream_t stream)
+{
+    size_t lds = (size_t)5 * a.k * 8;
+    switch (r_for_k(a.k))
+    {
+        case 1:
+            hipLaunchKernelGGL((ivf_merge_kernel<METRIC, 1>), dim3(nq), dim3(BLOCK), lds, stream, a);
+            break;
+        case 2:
+            hipLaunchKernelGGL((ivf_merge_kernel<METRIC, 2>), dim3(nq), dim3(BLOCK), lds, stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((ivf_merge_kernel<METRIC, 4>), dim3(nq), dim3(BLOCK), lds, stream, a);
+            break;
+    }
+}
+
+void launch_ivf_merge(int metric, IvfMergeParams a, uint32_t nq, hipStream_t stream)
+{
+    if (nq == 0)
+        return;
+    ProfileScope prof("merge", stream);
+    if (metric == M_IP)
+        ivf_merge_dispatch<M_IP>(a, nq, stream);
+    else
+        ivf_merge_dispatch<M_L2>(a, nq, stream);
+    MSVS_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ params
 
 std::map<std::string, std::string> parse_params(const char * s)

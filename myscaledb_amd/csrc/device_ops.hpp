@@ -61,7 +61,16 @@ void launch_flat_scan(int metric, const FlatPlan & plan, ScanParams a, hipStream
 /// partial[nq][n_lists][k] -> final results.
 void launch_merge(int metric, MergeParams a, uint32_t nq, hipStream_t stream);
 
-/// IVF list scan, grid (seg_max, nprobe, nq).
+/// IVF list scan, one query per block, grid (seg_max, nprobe, nq).
 void launch_ivf_scan(int metric, ScanParams a, hipStream_t stream);
+
+/// Group the (query, probed list) pairs by list: histogram, scans, scatter (p.cnt / p.fill must be zeroed).
+void launch_ivf_plan(const IvfPlanParams & p, hipStream_t stream);
+
+/// List-batched IVF scan over the plan's work items; T in {2, 4, 8}; fixed grid of `grid` blocks.
+void launch_ivf_batched_scan(int metric, uint32_t T, uint32_t grid, ScanParams a, hipStream_t stream);
+
+/// Per-query top-k over the valid segments of its probed lists.
+void launch_ivf_merge(int metric, IvfMergeParams a, uint32_t nq, hipStream_t stream);
 
 }

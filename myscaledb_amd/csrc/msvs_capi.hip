@@ -522,12 +522,61 @@ extern "C" size_t msvs_index_memory_usage(const msvs_index_t * ix)
 namespace msvs
 {
 
-static size_t ivf_rows_per_block(const msvs_index & ix, size_t nq, size_t nprobe)
+/// How an IVF search of nq queries is decomposed.
+struct IvfSearchPlan
 {
-    // aim for ~2048 blocks over the probed lists; at least one block iteration (16 rows), at most 1024 rows
-    size_t avg = std::max<size_t>(1, ix.n / std::max<size_t>(ix.nlist, 1));
-    size_t rpb = round_up(std::max<size_t>(16, avg * nq * nprobe / 2048), 16);
-    return std::min<size_t>(rpb, 256);
+    uint32_t T;       // 1 = one query per block (ivf_scan_kernel); 2/4/8 = list-batched query tiles
+    uint32_t rpb;     // rows per work item
+    uint32_t seg_max; // segments of the longest list
+    uint32_t grid;    // batched: fixed grid size
+};
+
+static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe)
+{
+    IvfSearchPlan p{};
+    const size_t pairs = nq * nprobe;
+    const size_t nlist = std::max<size_t>(ix.nlist, 1);
+    const size_t avg = std::max<size_t>(1, ix.n / nlist);
+    // Query tiles only pay when several queries of the batch probe the same list.
+    // (measured on MI355X, 1M x 768, nlist 1024, nprobe 32: T=4 beats T=8 up to ~8 pairs per list because its 128
+    // VGPRs allow 4 waves/SIMD against 2; see profiles/r01_ivf_tuning_sweep.txt)
+    p.T = pairs >= 16 * nlist ? 8 : (pairs >= 2 * nlist ? 4 : (pairs >= nlist ? 2 : 1));
+    const size_t tiles = std::max<size_t>(1, pairs / p.T);
+    if (p.T == 1)
+    {
+        // one (query, list, segment) per block: many small blocks, ~8192 of them
+        size_t rpb = round_up(std::max<size_t>(16, avg * pairs / 8192), 16);
+        p.rpb = (uint32_t)std::min<size_t>(std::max<size_t>(rpb, 64), 256);
+    }
+    else
+    {
+        // work items of up to 512 rows walked by a fixed grid of 4096 blocks (4 rounds at 4 blocks/CU)
+        size_t rpb = round_up(std::max<size_t>(64, avg * tiles / 4096), 16);
+        p.rpb = (uint32_t)std::min<size_t>(rpb, p.T == 8 ? 1024 : 512);
+    }
+    p.grid = 4096;
+    // tuning knobs for experiments (never needed in production): MSVS_IVF_T / MSVS_IVF_RPB / MSVS_IVF_GRID
+    if (const char * e = getenv("MSVS_IVF_T"))
+    {
+        int t = atoi(e);
+        if (t == 1 || t == 2 || t == 4 || t == 8)
+            p.T = (uint32_t)t;
+    }
+    if (const char * e = getenv("MSVS_IVF_RPB"))
+    {
+        int r = atoi(e);
+        if (r >= 16)
+            p.rpb = (uint32_t)round_up((size_t)r, 16);
+    }
+    if (const char * e = getenv("MSVS_IVF_GRID"))
+    {
+        int g = atoi(e);
+        if (g >= 1)
+            p.grid = (uint32_t)g;
+    }
+    p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, p.rpb));
+    p.grid = (uint32_t)std::min<size_t>(p.grid, std::max<size_t>(1, tiles * ceil_div(avg, p.rpb) * 2));
+    return p;
 }
 
 static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k, size_t nprobe)
@@ -535,10 +584,9 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     size_t b = nq * (size_t)ix.ld * 4 + 4096;
     if (ix.type == MSVS_INDEX_FLAT)
         return b + flat_scratch_bytes(ix.n, nq, k);
-    size_t rpb = ivf_rows_per_block(ix, nq, nprobe);
-    size_t seg_max = std::max<size_t>(1, ceil_div(ix.max_list_len, rpb));
-    return b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + nq * nprobe * 4 + nq * nprobe * seg_max * k * 8
-        + 16384;
+    IvfSearchPlan p = plan_ivf(ix, nq, nprobe);
+    return b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + nq * nprobe * 4
+        + nq * nprobe * (size_t)p.seg_max * k * 8 + (4 * ix.nlist + 8 + nq * nprobe) * 4 + 32768;
 }
 
 /// The search proper: all pointers on the device, everything enqueued on `stream`.
@@ -588,34 +636,75 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     co.out_probes = d_probes;
     flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co, stream);
     // 2. scan the probed lists
-    const size_t rpb = ivf_rows_per_block(ix, nq, nprobe);
-    const size_t seg_max = std::max<size_t>(1, ceil_div(ix.max_list_len, rpb));
-    uint64_t * partial = scr.take<uint64_t>(nq * nprobe * seg_max * k);
-    for (size_t q0 = 0; q0 < nq; q0 += 32768)
+    if (nq * nprobe > 0x7fffffffull)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");
+    const IvfSearchPlan pl = plan_ivf(ix, nq, nprobe);
+    uint64_t * partial = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max * k);
+    ScanParams a{};
+    a.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
+    a.ids = ix.row_ids.p;
+    a.alive = d_alive;
+    a.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
+    a.Q = reinterpret_cast<const float4 *>(dq);
+    a.partial = partial;
+    a.ld4 = ld / 4;
+    a.k = k;
+    a.nq = (uint32_t)nq;
+    a.rows_per_block = pl.rpb;
+    a.probes = d_probes;
+    a.list_off = ix.list_off.p;
+    a.nprobe = (uint32_t)nprobe;
+    a.seg_max = pl.seg_max;
+    a.nlist = (uint32_t)ix.nlist;
+    if (pl.T == 1)
     {
-        size_t nqc = std::min<size_t>(32768, nq - q0);
-        ScanParams a{};
-        a.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
-        a.ids = ix.row_ids.p;
-        a.alive = d_alive;
-        a.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
-        a.Q = reinterpret_cast<const float4 *>(dq + q0 * ld);
-        a.partial = partial + q0 * nprobe * seg_max * k;
-        a.ld4 = ld / 4;
-        a.k = k;
-        a.nq = (uint32_t)nqc;
-        a.rows_per_block = (uint32_t)rpb;
-        a.probes = d_probes + q0 * nprobe;
-        a.list_off = ix.list_off.p;
-        a.nprobe = (uint32_t)nprobe;
-        a.seg_max = (uint32_t)seg_max;
-        launch_ivf_scan(scan_metric(m), a, stream);
+        // few queries: one (query, list, segment) per block, no grouping pass
+        for (size_t q0 = 0; q0 < nq; q0 += 32768)
+        {
+            ScanParams c = a;
+            c.nq = (uint32_t)std::min<size_t>(32768, nq - q0);
+            c.Q = reinterpret_cast<const float4 *>(dq + q0 * ld);
+            c.partial = partial + q0 * nprobe * (size_t)pl.seg_max * k;
+            c.probes = d_probes + q0 * nprobe;
+            launch_ivf_scan(scan_metric(m), c, stream);
+        }
     }
-    // 3. per-query top-k over all segments
-    out.partial = partial;
-    out.n_lists = (uint32_t)(nprobe * seg_max);
-    out.k = k;
-    launch_merge(scan_metric(m), out, (uint32_t)nq, stream);
+    else
+    {
+        // group the (query, list) pairs by list, then one pass over each list segment per tile of T queries
+        IvfPlanParams pp{};
+        pp.probes = d_probes;
+        pp.list_off = ix.list_off.p;
+        pp.n_pairs = (uint32_t)(nq * nprobe);
+        pp.nlist = (uint32_t)ix.nlist;
+        pp.rows_per_block = pl.rpb;
+        pp.T = pl.T;
+        uint32_t * counters = scr.take<uint32_t>(2 * ix.nlist);
+        pp.cnt = counters;
+        pp.fill = counters + ix.nlist;
+        pp.pair_off = scr.take<uint32_t>(ix.nlist + 1);
+        pp.work_off = scr.take<uint32_t>(ix.nlist + 1);
+        pp.pairs = scr.take<uint32_t>(nq * nprobe);
+        MSVS_HIP(hipMemsetAsync(counters, 0, 2 * ix.nlist * sizeof(uint32_t), stream));
+        launch_ivf_plan(pp, stream);
+        a.pairs = pp.pairs;
+        a.pair_off = pp.pair_off;
+        a.work_off = pp.work_off;
+        launch_ivf_batched_scan(scan_metric(m), pl.T, pl.grid, a, stream);
+    }
+    // 3. per-query top-k over the valid segments of its probed lists
+    IvfMergeParams im{};
+    im.partial = partial;
+    im.probes = d_probes;
+    im.list_off = ix.list_off.p;
+    im.nprobe = (uint32_t)nprobe;
+    im.seg_max = pl.seg_max;
+    im.rows_per_block = pl.rpb;
+    im.k = k;
+    im.out_ids = d_ids;
+    im.out_dis = d_dis;
+    im.cosine = ix.metric == MSVS_METRIC_COSINE;
+    launch_ivf_merge(scan_metric(m), im, (uint32_t)nq, stream);
 }
 
 }
@@ -669,7 +758,7 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
 }
 
 extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * queries, size_t nq, int nprobe,
-                                       uint64_t * rows)
+                                       uint64_t * rows, uint64_t * rows_streamed)
 {
     return guarded([&] {
         if (!ix || !rows || (nq && !queries))
@@ -677,11 +766,15 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
         if (!ix->ready)
             fail(MSVS_ERR_NOT_READY, "index is not ready");
         *rows = 0;
+        if (rows_streamed)
+            *rows_streamed = 0;
         if (nq == 0)
             return;
         if (ix->type == MSVS_INDEX_FLAT)
         {
             *rows = (uint64_t)nq * ix->n;
+            if (rows_streamed)
+                *rows_streamed = (uint64_t)plan_flat(ix->n, nq).n_qtiles * ix->n;
             return;
         }
         size_t np = std::min<size_t>((size_t)std::max(nprobe, 1), ix->nlist);
@@ -705,10 +798,22 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
         MSVS_HIP(hipMemcpyAsync(h.data(), d_probes.p, h.size() * 4, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipStreamSynchronize(stream));
         uint64_t total = 0;
+        std::vector<uint32_t> cnt(ix->nlist, 0);
         for (int32_t l : h)
             if (l >= 0)
+            {
                 total += (uint64_t)(ix->h_list_off[l + 1] - ix->h_list_off[l]);
+                cnt[l]++;
+            }
         *rows = total;
+        if (rows_streamed)
+        {
+            const uint32_t T = plan_ivf(*ix, nq, np).T;
+            uint64_t st = 0;
+            for (size_t l = 0; l < ix->nlist; l++)
+                st += (uint64_t)ceil_div(cnt[l], T) * (uint64_t)(ix->h_list_off[l + 1] - ix->h_list_off[l]);
+            *rows_streamed = st;
+        }
     });
 }
 

@@ -224,6 +224,11 @@ struct ScanParams
     const int64_t * list_off; // [nlist+1]
     uint32_t nprobe;
     uint32_t seg_max;
+    // list-batched IVF front end (see IvfPlanParams)
+    const uint32_t * pairs;
+    const uint32_t * pair_off;
+    const uint32_t * work_off;
+    uint32_t nlist;
 };
 
 /// Scans rows [row_begin,row_end) for T queries already staged in LDS (qs[t*ld4 + c]) and leaves the block's
@@ -312,27 +317,60 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
         }
     }
 
-    // 4 wave lists -> 1 block list per query
+    // 4 wave lists -> 1 block list per query, all T queries in one pass (3 barriers per work item):
+    // lists at lds_merge[(t*4 + wave)*k + e], merged lists at lds_merge[T*4*k + t*k + e]
+    uint64_t * merged = lds_merge + (size_t)T * 4 * k;
+    __syncthreads();
+#pragma unroll
     for (int t = 0; t < T; t++)
+        top[t].store(lds_merge + (t * 4 + wave) * k, k, lane);
+    for (uint32_t i = tid; i < T * k; i += BLOCK)
+        merged[i] = KEY_NONE;
+    __syncthreads();
+    for (uint32_t i = tid; i < T * 4 * k; i += BLOCK)
     {
-        __syncthreads();
-        top[t].store(lds_merge + wave * k, k, lane);
-        __syncthreads();
-        uint64_t * merged = lds_merge + 4 * k;
-        block_rank_merge(lds_merge, k, merged, k, tid);
-        for (uint32_t i = tid; i < k; i += BLOCK)
-            out[t][i] = merged[i];
+        const uint32_t t = i / (4 * k), rem = i - t * 4 * k, w = rem / k, e = rem - w * k;
+        const uint64_t * lists = lds_merge + (size_t)t * 4 * k;
+        const uint64_t key = lists[w * k + e];
+        if (key == KEY_NONE)
+            continue;
+        uint32_t pos = e; // rank = own index + #smaller keys in the other three lists (keys are unique)
+        for (uint32_t o = 0; o < 4; o++)
+        {
+            if (o == w)
+                continue;
+            const uint64_t * l = lists + o * k;
+            uint32_t lo = 0, hi = k;
+            while (lo < hi)
+            {
+                uint32_t mid = (lo + hi) >> 1;
+                if (l[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            pos += lo;
+        }
+        if (pos < k)
+            merged[t * k + pos] = key;
     }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; t++)
+        for (uint32_t e = tid; e < k; e += BLOCK)
+            out[t][e] = merged[t * k + e];
 }
 
 /// Stage T query rows (zero padded) into LDS.  Queries beyond nq repeat the last valid one.
 template <int T>
 __device__ __forceinline__ void stage_queries(const ScanParams & a, const uint32_t * qidx, float4 * qs)
 {
-    for (uint32_t i = threadIdx.x; i < T * a.ld4; i += BLOCK)
+#pragma unroll
+    for (int t = 0; t < T; t++) // static index into qidx: keeps it in registers
     {
-        uint32_t t = i / a.ld4, c = i - t * a.ld4;
-        qs[i] = a.Q[(size_t)qidx[t] * a.ld4 + c];
+        const float4 * src = a.Q + (size_t)qidx[t] * a.ld4;
+        for (uint32_t c = threadIdx.x; c < a.ld4; c += BLOCK)
+            qs[t * a.ld4 + c] = src[c];
     }
     __syncthreads();
 }
@@ -340,7 +378,10 @@ __device__ __forceinline__ void stage_queries(const ScanParams & a, const uint32
 extern __shared__ __attribute__((aligned(16))) unsigned char msvs_smem[];
 
 /// LDS bytes a scan block needs.
-inline size_t scan_lds_bytes(uint32_t T, uint32_t ld4, uint32_t k) { return (size_t)T * ld4 * 16 + (size_t)5 * k * 8; }
+inline size_t scan_lds_bytes(uint32_t T, uint32_t ld4, uint32_t k)
+{
+    return (size_t)T * ld4 * 16 + (size_t)T * 5 * k * 8;
+}
 
 /// FLAT: grid (n_blocks, ceil(nq/T)); block bx scans rows [bx*rows_per_block, ...) for queries by*T...
 /// partial layout: [nq][n_blocks][k].
@@ -369,8 +410,10 @@ __global__ __launch_bounds__(BLOCK) void flat_scan_kernel(const ScanParams a)
     scan_rows<METRIC, T, R>(a, row_begin < row_end ? row_begin : row_end, row_end, qs, lds_merge, out);
 }
 
-/// IVF, one query per block: grid (seg_max, nprobe, nq).  Block (s, p, q) scans segment s of the p-th probed
-/// list of query q.  partial layout: [nq][nprobe*seg_max][k]; empty segments write sentinels.
+/// IVF, one query per block (the low-latency form used for very small batches): grid (seg_max, nprobe, nq).
+/// Block (s, p, q) scans segment s of the p-th probed list of query q and writes its top-k to
+/// partial[((q*nprobe + p)*seg_max + s)*k ...]; blocks past the end of the list exit without writing (the merge
+/// kernel derives the number of valid segments from the list length).
 template <int METRIC, int R>
 __global__ __launch_bounds__(BLOCK) void ivf_scan_kernel(const ScanParams a)
 {
@@ -386,17 +429,212 @@ __global__ __launch_bounds__(BLOCK) void ivf_scan_kernel(const ScanParams a)
             le = lb + a.rows_per_block;
     }
     if (lb >= le)
-    {
-        for (uint32_t i = threadIdx.x; i < a.k; i += BLOCK)
-            out0[i] = KEY_NONE;
         return;
-    }
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
     uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16);
     uint32_t qidx[1] = {q};
     uint64_t * out[1] = {out0};
     stage_queries<1>(a, qidx, qs);
     scan_rows<METRIC, 1, R>(a, (uint32_t)lb, (uint32_t)le, qs, lds_merge, out);
+}
+
+// ------------------------------------------------------------------------------------------ list-batched IVF scan
+//
+// For a batch of queries the (query, probed list) pairs are grouped BY LIST on the device, so that one pass over a
+// list's rows serves a tile of up to T queries that probe it (the rows are streamed from HBM once per tile instead
+// of once per query).  Work item = (list, query tile, row segment); a fixed-size grid walks the work items.
+
+struct IvfPlanParams
+{
+    const int32_t * probes;   // [n_pairs] list id of pair i = q*nprobe + p (-1 = none)
+    const int64_t * list_off; // [nlist+1]
+    uint32_t n_pairs;
+    uint32_t nlist;
+    uint32_t rows_per_block;
+    uint32_t T;
+    uint32_t * cnt;      // [nlist] pairs per list            (zeroed by the caller)
+    uint32_t * fill;     // [nlist] scatter cursors            (zeroed by the caller)
+    uint32_t * pair_off; // [nlist+1] exclusive scan of cnt
+    uint32_t * work_off; // [nlist+1] exclusive scan of ceil(cnt/T) * ceil(len/rows_per_block)
+    uint32_t * pairs;    // [n_pairs] pair indices grouped by list
+};
+
+static __global__ void ivf_hist_kernel(const IvfPlanParams p)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.n_pairs)
+    {
+        int32_t l = p.probes[i];
+        if (l >= 0)
+            atomicAdd(&p.cnt[l], 1u);
+    }
+}
+
+/// One block of 1024 threads: the two exclusive scans over the lists.
+static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPlanParams p)
+{
+    __shared__ uint32_t sp[2][1024];
+    __shared__ uint32_t sw[2][1024];
+    __shared__ uint32_t carry[2];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 2)
+        carry[tid] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < p.nlist; base += 1024)
+    {
+        const uint32_t l = base + tid;
+        uint32_t c = 0, w = 0;
+        if (l < p.nlist)
+        {
+            c = p.cnt[l];
+            uint32_t len = (uint32_t)(p.list_off[l + 1] - p.list_off[l]);
+            w = ((c + p.T - 1) / p.T) * ((len + p.rows_per_block - 1) / p.rows_per_block);
+        }
+        int cur = 0;
+        sp[0][tid] = c;
+        sw[0][tid] = w;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1)
+        {
+            uint32_t vp = sp[cur][tid], vw = sw[cur][tid];
+            if (tid >= d)
+            {
+                vp += sp[cur][tid - d];
+                vw += sw[cur][tid - d];
+            }
+            sp[cur ^ 1][tid] = vp;
+            sw[cur ^ 1][tid] = vw;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const uint32_t cp = carry[0], cw = carry[1];
+        if (l < p.nlist)
+        {
+            p.pair_off[l] = cp + sp[cur][tid] - c;
+            p.work_off[l] = cw + sw[cur][tid] - w;
+        }
+        __syncthreads();
+        if (tid == 1023)
+        {
+            carry[0] = cp + sp[cur][1023];
+            carry[1] = cw + sw[cur][1023];
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+    {
+        p.pair_off[p.nlist] = carry[0];
+        p.work_off[p.nlist] = carry[1];
+    }
+}
+
+static __global__ void ivf_scatter_kernel(const IvfPlanParams p)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.n_pairs)
+    {
+        int32_t l = p.probes[i];
+        if (l >= 0)
+            p.pairs[p.pair_off[l] + atomicAdd(&p.fill[l], 1u)] = i;
+    }
+}
+
+/// grid: any size; block b handles work items b, b + gridDim.x, ...
+template <int METRIC, int T, int R>
+__global__ __launch_bounds__(BLOCK) void ivf_batched_scan_kernel(const ScanParams a)
+{
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)T * a.ld4 * 16);
+    const uint32_t total = a.work_off[a.nlist];
+    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x)
+    {
+        // the list owning work item w: work_off[l] <= w < work_off[l+1]
+        uint32_t lo = 0, hi = a.nlist;
+        while (hi - lo > 1)
+        {
+            uint32_t mid = (lo + hi) >> 1;
+            if (a.work_off[mid] <= w)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t l = lo;
+        const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
+        const uint32_t nseg = ((uint32_t)(lend - lbeg) + a.rows_per_block - 1) / a.rows_per_block;
+        const uint32_t local = w - a.work_off[l];
+        const uint32_t tile = local / nseg, seg = local - tile * nseg;
+        const uint32_t pb = a.pair_off[l] + tile * T, pe = a.pair_off[l + 1];
+        uint32_t qidx[T];
+        uint64_t * out[T];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+        {
+            uint32_t pi = pb + t < pe ? pb + t : pe - 1; // short tiles repeat their last pair (same slot, same values)
+            uint32_t qp = a.pairs[pi];
+            qidx[t] = qp / a.nprobe;
+            out[t] = a.partial + ((size_t)qp * a.seg_max + seg) * a.k;
+        }
+        __syncthreads();
+        stage_queries<T>(a, qidx, qs);
+        const int64_t rb = lbeg + (int64_t)seg * a.rows_per_block;
+        const int64_t re = rb + a.rows_per_block < lend ? rb + a.rows_per_block : lend;
+        scan_rows<METRIC, T, R>(a, (uint32_t)rb, (uint32_t)re, qs, lds_merge, out);
+    }
+}
+
+struct IvfMergeParams
+{
+    const uint64_t * partial; // [(q*nprobe + p)*seg_max + s][k]
+    const int32_t * probes;   // [nq][nprobe]
+    const int64_t * list_off;
+    uint32_t nprobe, seg_max, rows_per_block, k;
+    int64_t * out_ids;
+    float * out_dis;
+    int cosine;
+};
+
+/// One block per query: top-k over the valid segments of its probed lists.
+template <int METRIC, int R>
+__global__ __launch_bounds__(BLOCK) void ivf_merge_kernel(const IvfMergeParams a)
+{
+    uint64_t * lds = reinterpret_cast<uint64_t *>(msvs_smem);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k, q = blockIdx.x;
+    WaveTopK<R> top;
+    top.init();
+    for (uint32_t p = wave; p < a.nprobe; p += 4)
+    {
+        const int32_t l = __builtin_amdgcn_readfirstlane(a.probes[(size_t)q * a.nprobe + p]);
+        if (l < 0)
+            continue;
+        const uint32_t len = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
+        const uint32_t n = ((len + a.rows_per_block - 1) / a.rows_per_block) * k;
+        const uint64_t * src = a.partial + ((size_t)q * a.nprobe + p) * a.seg_max * k;
+        for (uint32_t base = 0; base < n; base += 4 * WAVE)
+        {
+            uint64_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                uint32_t i = base + u * WAVE + lane;
+                key[u] = i < n ? src[i] : KEY_NONE;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                top.offer(key[u], k, lane);
+        }
+    }
+    top.store(lds + wave * k, k, lane);
+    __syncthreads();
+    uint64_t * merged = lds + 4 * k;
+    block_rank_merge(lds, k, merged, k, tid);
+    for (uint32_t i = tid; i < k; i += BLOCK)
+    {
+        uint64_t key = merged[i];
+        size_t o = (size_t)q * k + i;
+        a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
+        float v = key_value<METRIC>(key);
+        a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ final merge
@@ -424,11 +662,18 @@ __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams a)
     const uint64_t total = (uint64_t)a.n_lists * k;
     WaveTopK<R> top;
     top.init();
-    for (uint64_t base = 0; base < total; base += BLOCK)
+    for (uint64_t base = 0; base < total; base += 4 * BLOCK)
     {
-        uint64_t i = base + tid;
-        uint64_t key = i < total ? src[i] : KEY_NONE;
-        top.offer(key, k, lane);
+        uint64_t key[4]; // 4 independent loads in flight before the first (serialising) offer
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            uint64_t i = base + u * BLOCK + tid;
+            key[u] = i < total ? src[i] : KEY_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            top.offer(key[u], k, lane);
     }
     top.store(lds + wave * k, k, lane);
     __syncthreads();

@@ -178,7 +178,8 @@ def oracle_on_exported(ix, q, nprobe, k, metric, alive=None):
 
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
 @pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(20000, 128, 64, 16, 8, 10), (30000, 768, 128, 5, 32, 10),
-                                                   (8000, 100, 32, 1, 4, 100), (6000, 36, 16, 70, 16, 30)])
+                                                   (8000, 100, 32, 1, 4, 100), (6000, 36, 16, 70, 16, 30),
+                                                   (10000, 64, 64, 12, 16, 10), (9000, 32, 40, 300, 8, 5)])
 def test_ivfflat_matches_oracle_on_exported_structure(metric, n, d, nlist, nq, nprobe, k):
     rng = np.random.default_rng(n + d + nlist)
     centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
