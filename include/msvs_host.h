@@ -1,0 +1,62 @@
+/*
+ * msvs_host.h -- C-ABI of libmsvs_host.so: the HOST side of the hot path, i.e. the parts the reference keeps in
+ * clickhouse-server C++ above the native-library boundary, rebuilt on top of
+ * libmsvs.so.  The C++ classes live in myscaledb_amd/host/msvs_host.hpp with the reference's names; these C entry
+ * points exist so that tests (ctypes) and other hosts can drive them.  Pure host code: no HIP calls here except
+ * through libmsvs.so's C-ABI.
+ */
+#ifndef MSVS_HOST_H
+#define MSVS_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSVS_HOST_API __attribute__((visibility("default")))
+
+/* VIWithColumnInPart::searchWithoutIndex<FloatVector> (src/VectorIndex/Common/VIWithDataPart.h:341-382):
+ * cosine => normalise query and base IN PLACE (device kernel), IP search, d = 1 - d.  metric: msvs_metric. */
+MSVS_HOST_API int msvs_host_search_without_index(float * query, float * base, size_t dim, size_t k, size_t nq,
+                                                 size_t nbase, int metric, int64_t * labels, float * distances);
+
+/* MergeTreeVSManager::searchWrapper<FloatVector> (src/VectorIndex/Storages/MergeTreeVSManager.cpp:1537-1679):
+ * one brute-force block merged into the running (final_id, final_distance)[nq*k].
+ * row_exists: LSB-first bitmap over the block's rows (nullable when delete_id_num == 0);
+ * actual_id_in_range: nullable unless prewhere != 0. */
+MSVS_HOST_API int msvs_host_search_wrapper(int prewhere, float * query, float * base, size_t nbase, int k, int dim,
+                                           int nq, int num_rows_read, int64_t * final_id, float * final_distance,
+                                           const uint64_t * actual_id_in_range, int metric,
+                                           const uint64_t * row_exists, int delete_id_num);
+
+/* MergeTreeBaseSearchManager::getTotalTopSearchResultImpl (MergeTreeBaseSearchManager.cpp:207-299): cross-part
+ * top-k through a multimap keyed by score; returns the number of results. */
+MSVS_HOST_API size_t msvs_host_total_topk(const float * scores, const uint64_t * part_index, const uint64_t * labels,
+                                          size_t n, size_t top_k, int desc_direction, float * out_scores,
+                                          uint64_t * out_part_index, uint64_t * out_labels);
+
+/* MergeTreeHybridSearchManager::hybridSearch + RankFusion / RelativeScoreFusion
+ * (MergeTreeHybridSearchManager.cpp:108-171, src/VectorIndex/Utils/HybridSearchUtils.cpp:164-314).
+ * fusion_type: 0 = RRF, 1 = RSF.  Inputs are the already ordered (best first) vector and text result lists. */
+MSVS_HOST_API size_t msvs_host_hybrid_search(int fusion_type, const float * vec_scores, const uint64_t * vec_parts,
+                                             const uint64_t * vec_labels, size_t nvec, const float * txt_scores,
+                                             const uint64_t * txt_parts, const uint64_t * txt_labels, size_t ntxt,
+                                             uint64_t fusion_k, float fusion_weight, int vector_scan_direction,
+                                             size_t topk, float * out_scores, uint64_t * out_parts,
+                                             uint64_t * out_labels);
+
+/* Canonical merge of per-shard top-k lists that share one id space (the multi-GPU exchange step when the merge is
+ * done on the host): ids/dis [nparts][nq][k] -> [nq][k]; order (dist asc | desc for IP, id asc), -1 ids ignored. */
+MSVS_HOST_API int msvs_host_merge_topk(const int64_t * ids, const float * dis, size_t nparts, size_t nq, size_t k,
+                                       int metric, int64_t * out_ids, float * out_dis);
+
+/* BM25InfoInDataParts-style statistics reduction (src/VectorIndex/Common/BM25InfoInDataParts.cpp:40-93):
+ * element-wise sums of per-part (total_docs, total_tokens, df[n_terms]) vectors laid out [nparts][2 + n_terms]. */
+MSVS_HOST_API void msvs_host_sum_bm25_stats(const uint64_t * per_part, size_t nparts, size_t n_terms, uint64_t * out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes binding of libmsvs_host.so (include/msvs_host.h): the host-side mirror of the reference's operator
+interface (searchWithoutIndex, searchWrapper, getTotalTopSearchResultImpl, hybridSearch, ...).  Plumbing only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsvs_host.so")
+
+SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_host_total_topk",
+           "msvs_host_hybrid_search", "msvs_host_merge_topk", "msvs_host_sum_bm25_stats"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmsvs_host.so is not built (%s)" % LIB_PATH)
+        capi.lib()  # libmsvs.so first (the host library links against it)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.msvs_host_total_topk.restype = C.c_size_t
+        _lib.msvs_host_hybrid_search.restype = C.c_size_t
+        _lib.msvs_host_sum_bm25_stats.restype = None
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def search_without_index(x, y, k, metric):
+    """VIWithColumnInPart::searchWithoutIndex; works on copies (the reference normalises in place)."""
+    y = _f32(y).copy()
+    x = _f32(x).reshape(-1, y.shape[1]).copy()
+    nq, d = x.shape
+    ids = np.empty((nq, k), np.int64)
+    dis = np.empty((nq, k), np.float32)
+    capi._check(lib().msvs_host_search_without_index(_p(x, C.c_float), _p(y, C.c_float), C.c_size_t(d), C.c_size_t(k),
+                                                     C.c_size_t(nq), C.c_size_t(y.shape[0]), int(metric),
+                                                     _p(ids, C.c_int64), _p(dis, C.c_float)))
+    return ids, dis
+
+
+def search_wrapper(query, base, k, metric, final_id, final_distance, num_rows_read=0, actual_id_in_range=None,
+                   row_exists=None, delete_id_num=0):
+    """MergeTreeVSManager::searchWrapper: merges one block into (final_id, final_distance) in place."""
+    base = _f32(base).copy()
+    d = base.shape[1]
+    query = _f32(query).reshape(-1, d).copy()
+    nq = query.shape[0]
+    act = None if actual_id_in_range is None else _u64(actual_id_in_range)
+    bits = None if row_exists is None else capi.pack_bits(row_exists)
+    capi._check(lib().msvs_host_search_wrapper(int(act is not None), _p(query, C.c_float), _p(base, C.c_float),
+                                               C.c_size_t(base.shape[0]), int(k), int(d), int(nq), int(num_rows_read),
+                                               _p(final_id, C.c_int64), _p(final_distance, C.c_float),
+                                               _p(act, C.c_uint64), int(metric), _p(bits, C.c_uint64),
+                                               int(delete_id_num)))
+
+
+def total_topk(scores, parts, labels, top_k, desc):
+    scores, parts, labels = _f32(scores), _u64(parts), _u64(labels)
+    os_, op, ol = np.empty(top_k, np.float32), np.empty(top_k, np.uint64), np.empty(top_k, np.uint64)
+    n = lib().msvs_host_total_topk(_p(scores, C.c_float), _p(parts, C.c_uint64), _p(labels, C.c_uint64),
+                                   C.c_size_t(scores.size), C.c_size_t(top_k), int(desc), _p(os_, C.c_float),
+                                   _p(op, C.c_uint64), _p(ol, C.c_uint64))
+    return os_[:n], op[:n], ol[:n]
+
+
+def hybrid_search(fusion_type, vec, txt, topk, fusion_k=60, fusion_weight=0.5, vector_scan_direction=1):
+    vs, vp, vl = _f32(vec[0]), _u64(vec[1]), _u64(vec[2])
+    ts, tp, tl = _f32(txt[0]), _u64(txt[1]), _u64(txt[2])
+    os_, op, ol = np.empty(topk, np.float32), np.empty(topk, np.uint64), np.empty(topk, np.uint64)
+    n = lib().msvs_host_hybrid_search(1 if fusion_type == "rsf" else 0, _p(vs, C.c_float), _p(vp, C.c_uint64),
+                                      _p(vl, C.c_uint64), C.c_size_t(vs.size), _p(ts, C.c_float), _p(tp, C.c_uint64),
+                                      _p(tl, C.c_uint64), C.c_size_t(ts.size), C.c_uint64(int(fusion_k)),
+                                      C.c_float(fusion_weight), int(vector_scan_direction), C.c_size_t(topk),
+                                      _p(os_, C.c_float), _p(op, C.c_uint64), _p(ol, C.c_uint64))
+    return os_[:n], op[:n], ol[:n]
+
+
+def merge_topk(ids, dis, metric):
+    ids = np.ascontiguousarray(ids, np.int64)
+    dis = _f32(dis)
+    nparts, nq, k = ids.shape
+    oi, od = np.empty((nq, k), np.int64), np.empty((nq, k), np.float32)
+    capi._check(lib().msvs_host_merge_topk(_p(ids, C.c_int64), _p(dis, C.c_float), C.c_size_t(nparts), C.c_size_t(nq),
+                                           C.c_size_t(k), int(metric), _p(oi, C.c_int64), _p(od, C.c_float)))
+    return oi, od
+
+
+def sum_bm25_stats(per_part):
+    a = _u64(per_part)
+    out = np.empty(a.shape[1], np.uint64)
+    lib().msvs_host_sum_bm25_stats(_p(a, C.c_uint64), C.c_size_t(a.shape[0]), C.c_size_t(a.shape[1] - 2),
+                                   _p(out, C.c_uint64))
+    return out

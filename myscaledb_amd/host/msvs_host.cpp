@@ -1,0 +1,370 @@
+// msvs_host.cpp -- implementation of the host mirror (see msvs_host.hpp) + its C entry points (include/msvs_host.h).
+#include "msvs_host.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+
+#include "../../include/msvs_host.h"
+
+namespace VectorIndex
+{
+
+void VIWithColumnInPart::searchWithoutIndex(VectorDataset & query_data, VectorDataset & base_data, int32_t k,
+                                            float * distances, int64_t * labels, const VIMetric & metric)
+{
+    VIMetric new_metric = metric;
+    if (metric == VIMetric::Cosine)
+    {
+        // cosine = normalise both sides, search by inner product, report 1 - ip
+        new_metric = VIMetric::IP;
+        query_data.normalize();
+        base_data.normalize();
+    }
+    tryBruteForceSearch(query_data.data, base_data.data, static_cast<size_t>(query_data.dimension), static_cast<size_t>(k),
+                        static_cast<size_t>(query_data.total_vectors), static_cast<size_t>(base_data.total_vectors), labels,
+                        distances, new_metric);
+    if (metric == VIMetric::Cosine)
+        for (int64_t i = 0; i < static_cast<int64_t>(k) * query_data.total_vectors; i++)
+            distances[i] = 1 - distances[i];
+}
+
+}
+
+namespace DB
+{
+
+void MergeTreeVSManager::searchWrapper(bool prewhere, VectorIndex::VectorDataset & query_vector,
+                                       VectorIndex::VectorDataset & base_data, int k, int /*dim*/, int nq,
+                                       int num_rows_read, std::vector<int64_t> & final_id,
+                                       std::vector<float> & final_distance,
+                                       const std::vector<size_t> & actual_id_in_range, const VIMetric & metric,
+                                       const VIBitmapView & row_exists, int delete_id_num)
+{
+    // "worst" sentinels of the block result.  IP deliberately uses numeric_limits<float>::min() (smallest positive
+    // normal), reproducing the reference: inner products <= 1.18e-38 never displace an empty slot in the merge.
+    const float worst = metric == VIMetric::IP ? std::numeric_limits<float>::min() : std::numeric_limits<float>::max();
+    const size_t slots = static_cast<size_t>(k) * nq;
+    std::vector<float> per_distance(slots, worst);
+    std::vector<int64_t> per_id(slots, -1);
+
+    if (delete_id_num > 0)
+    {
+        // over-fetch by the number of lightweight-deleted rows of the block, then drop the deleted ones
+        const size_t kk = static_cast<size_t>(k) + delete_id_num;
+        std::vector<float> wide_distance(kk * nq, worst);
+        std::vector<int64_t> wide_id(kk * nq, -1);
+        VectorIndex::VIWithColumnInPart::searchWithoutIndex(query_vector, base_data, static_cast<int32_t>(kk),
+                                                            wide_distance.data(), wide_id.data(), metric);
+        for (int q = 0; q < nq; q++)
+        {
+            size_t kept = 0;
+            for (size_t j = 0; j < kk && kept < static_cast<size_t>(k); j++)
+            {
+                const int64_t id = wide_id[q * kk + j];
+                if (id >= 0 && row_exists.is_member(static_cast<size_t>(id)))
+                {
+                    per_id[q * k + kept] = id;
+                    per_distance[q * k + kept] = wide_distance[q * kk + j];
+                    kept++;
+                }
+            }
+        }
+    }
+    else
+    {
+        VectorIndex::VIWithColumnInPart::searchWithoutIndex(query_vector, base_data, k, per_distance.data(), per_id.data(),
+                                                            metric);
+    }
+
+    if (prewhere)
+        for (auto & id : per_id)
+            if (id > -1)
+                id = static_cast<int64_t>(actual_id_in_range[static_cast<size_t>(id)]);
+
+    // two-way merge of the sorted block result into the sorted running result; strict comparison, so on equal
+    // distances the running (earlier block) entry is kept first
+    std::vector<float> merged_distance(slots);
+    std::vector<int64_t> merged_id(slots);
+    const bool larger_is_better = metric == VIMetric::IP;
+    for (int q = 0; q < nq; q++)
+    {
+        size_t run = static_cast<size_t>(q) * k, blk = run, dst = run;
+        for (int i = 0; i < k; i++, dst++)
+        {
+            const bool take_block = larger_is_better ? final_distance[run] < per_distance[blk]
+                                                     : final_distance[run] > per_distance[blk];
+            if (take_block)
+            {
+                merged_distance[dst] = per_distance[blk];
+                merged_id[dst] = per_id[blk] + num_rows_read;
+                blk++;
+            }
+            else
+            {
+                merged_distance[dst] = final_distance[run];
+                merged_id[dst] = final_id[run];
+                run++;
+            }
+        }
+    }
+    final_distance.swap(merged_distance);
+    final_id.swap(merged_id);
+}
+
+ScoreWithPartIndexAndLabels MergeTreeBaseSearchManager::getTotalTopSearchResultImpl(
+    const ScoreWithPartIndexAndLabels & all, uint64_t top_k, bool desc_direction)
+{
+    // a multimap keeps equal scores in insertion order; reverse iteration (descending) reverses that order too
+    std::multimap<float, ScoreWithPartIndexAndLabel> sorted;
+    for (const auto & e : all)
+        sorted.emplace(e.score, e);
+    ScoreWithPartIndexAndLabels result;
+    result.reserve(top_k);
+    if (desc_direction)
+    {
+        for (auto it = sorted.rbegin(); it != sorted.rend() && result.size() < top_k; ++it)
+            result.push_back(it->second);
+    }
+    else
+    {
+        for (auto it = sorted.begin(); it != sorted.end() && result.size() < top_k; ++it)
+            result.push_back(it->second);
+    }
+    return result;
+}
+
+void RankFusion(std::map<std::tuple<uint32_t, uint64_t, uint64_t>, float> & fusion_id_with_score,
+                const ScoreWithPartIndexAndLabels & vec_scan_result_dataset,
+                const ScoreWithPartIndexAndLabels & text_search_result_dataset, uint64_t fusion_k)
+{
+    // RRF: score += 1 / (fusion_k + rank), rank 1-based inside each list
+    for (const auto * list : {&vec_scan_result_dataset, &text_search_result_dataset})
+    {
+        size_t rank = 1;
+        for (const auto & e : *list)
+        {
+            fusion_id_with_score[std::make_tuple(e.shard_num, e.part_index, e.label_id)] += 1.0f / (fusion_k + rank);
+            rank++;
+        }
+    }
+}
+
+void computeNormalizedScore(const ScoreWithPartIndexAndLabels & search_result_dataset, std::vector<float> & norm_score)
+{
+    const size_t n = search_result_dataset.size();
+    if (n == 0)
+        return;
+    norm_score.reserve(n);
+    float min_score = search_result_dataset[n - 1].score, max_score = search_result_dataset[0].score;
+    if (min_score == max_score)
+    {
+        norm_score.assign(n, 1.0f);
+        return;
+    }
+    if (min_score > max_score)
+        std::swap(min_score, max_score);
+    const float scale = max_score - min_score;
+    for (const auto & e : search_result_dataset)
+        norm_score.push_back((e.score - min_score) / scale);
+}
+
+void RelativeScoreFusion(std::map<std::tuple<uint32_t, uint64_t, uint64_t>, float> & fusion_id_with_score,
+                         const ScoreWithPartIndexAndLabels & vec_scan_result_dataset,
+                         const ScoreWithPartIndexAndLabels & text_search_result_dataset, float fusion_weight,
+                         int8_t vector_scan_direction)
+{
+    std::vector<float> norm;
+    computeNormalizedScore(text_search_result_dataset, norm);
+    for (size_t i = 0; i < text_search_result_dataset.size(); i++)
+    {
+        const auto & e = text_search_result_dataset[i];
+        fusion_id_with_score[std::make_tuple(e.shard_num, e.part_index, e.label_id)] = norm[i] * fusion_weight;
+    }
+    norm.clear();
+    computeNormalizedScore(vec_scan_result_dataset, norm);
+    for (size_t i = 0; i < vec_scan_result_dataset.size(); i++)
+    {
+        const auto & e = vec_scan_result_dataset[i];
+        // direction -1 (IP): larger is better; otherwise a smaller distance is better
+        const float s = vector_scan_direction == -1 ? norm[i] * (1 - fusion_weight) : (1 - norm[i]) * (1 - fusion_weight);
+        fusion_id_with_score[std::make_tuple(e.shard_num, e.part_index, e.label_id)] += s;
+    }
+}
+
+ScoreWithPartIndexAndLabels MergeTreeHybridSearchManager::hybridSearch(
+    const ScoreWithPartIndexAndLabels & vec_scan_result_with_part_index,
+    const ScoreWithPartIndexAndLabels & text_search_result_with_part_index, const HybridSearchInfo & hybrid_info)
+{
+    std::map<std::tuple<uint32_t, uint64_t, uint64_t>, float> fused;
+    if (hybrid_info.fusion_type == "rsf" || hybrid_info.fusion_type == "RSF")
+        RelativeScoreFusion(fused, vec_scan_result_with_part_index, text_search_result_with_part_index,
+                            hybrid_info.fusion_weight, static_cast<int8_t>(hybrid_info.vector_scan_direction));
+    else
+        RankFusion(fused, vec_scan_result_with_part_index, text_search_result_with_part_index,
+                   hybrid_info.fusion_k <= 0 ? 60 : static_cast<uint64_t>(hybrid_info.fusion_k));
+    std::multimap<float, std::pair<uint64_t, uint64_t>, std::greater<float>> by_score;
+    for (const auto & [id, score] : fused)
+        by_score.emplace(score, std::make_pair(std::get<1>(id), std::get<2>(id)));
+    ScoreWithPartIndexAndLabels result;
+    for (const auto & [score, id] : by_score)
+    {
+        if (static_cast<int>(result.size()) == hybrid_info.topk)
+            break;
+        ScoreWithPartIndexAndLabel e;
+        e.score = score;
+        e.part_index = id.first;
+        e.label_id = id.second;
+        result.push_back(e);
+    }
+    return result;
+}
+
+}
+
+// ================================================================================================ C entry points
+
+namespace
+{
+template <typename F>
+int guarded(F && f)
+{
+    try
+    {
+        f();
+        return MSVS_OK;
+    }
+    catch (const VectorIndex::VIException & e)
+    {
+        return e.code;
+    }
+    catch (...)
+    {
+        return MSVS_ERR_DEVICE;
+    }
+}
+
+DB::ScoreWithPartIndexAndLabels make_list(const float * s, const uint64_t * p, const uint64_t * l, size_t n)
+{
+    DB::ScoreWithPartIndexAndLabels v(n);
+    for (size_t i = 0; i < n; i++)
+    {
+        v[i].score = s[i];
+        v[i].part_index = p[i];
+        v[i].label_id = l[i];
+    }
+    return v;
+}
+}
+
+extern "C" int msvs_host_search_without_index(float * query, float * base, size_t dim, size_t k, size_t nq, size_t nbase,
+                                              int metric, int64_t * labels, float * distances)
+{
+    return guarded([&] {
+        VectorIndex::VectorDataset q{query, static_cast<int64_t>(nq), static_cast<int64_t>(dim)};
+        VectorIndex::VectorDataset b{base, static_cast<int64_t>(nbase), static_cast<int64_t>(dim)};
+        VectorIndex::VIWithColumnInPart::searchWithoutIndex(q, b, static_cast<int32_t>(k), distances, labels,
+                                                            static_cast<VectorIndex::VIMetric>(metric));
+    });
+}
+
+extern "C" int msvs_host_search_wrapper(int prewhere, float * query, float * base, size_t nbase, int k, int dim, int nq,
+                                        int num_rows_read, int64_t * final_id, float * final_distance,
+                                        const uint64_t * actual_id_in_range, int metric, const uint64_t * row_exists,
+                                        int delete_id_num)
+{
+    return guarded([&] {
+        VectorIndex::VectorDataset q{query, nq, dim};
+        VectorIndex::VectorDataset b{base, static_cast<int64_t>(nbase), dim};
+        std::vector<int64_t> fid(final_id, final_id + static_cast<size_t>(k) * nq);
+        std::vector<float> fdist(final_distance, final_distance + static_cast<size_t>(k) * nq);
+        std::vector<size_t> actual;
+        if (prewhere)
+            actual.assign(actual_id_in_range, actual_id_in_range + nbase);
+        DB::VIBitmapView bits{row_exists};
+        DB::MergeTreeVSManager::searchWrapper(prewhere != 0, q, b, k, dim, nq, num_rows_read, fid, fdist, actual,
+                                              static_cast<VectorIndex::VIMetric>(metric), bits, delete_id_num);
+        std::memcpy(final_id, fid.data(), fid.size() * sizeof(int64_t));
+        std::memcpy(final_distance, fdist.data(), fdist.size() * sizeof(float));
+    });
+}
+
+extern "C" size_t msvs_host_total_topk(const float * scores, const uint64_t * part_index, const uint64_t * labels,
+                                       size_t n, size_t top_k, int desc_direction, float * out_scores,
+                                       uint64_t * out_part_index, uint64_t * out_labels)
+{
+    auto r = DB::MergeTreeBaseSearchManager::getTotalTopSearchResultImpl(make_list(scores, part_index, labels, n), top_k,
+                                                                         desc_direction != 0);
+    for (size_t i = 0; i < r.size(); i++)
+    {
+        out_scores[i] = r[i].score;
+        out_part_index[i] = r[i].part_index;
+        out_labels[i] = r[i].label_id;
+    }
+    return r.size();
+}
+
+extern "C" size_t msvs_host_hybrid_search(int fusion_type, const float * vec_scores, const uint64_t * vec_parts,
+                                          const uint64_t * vec_labels, size_t nvec, const float * txt_scores,
+                                          const uint64_t * txt_parts, const uint64_t * txt_labels, size_t ntxt,
+                                          uint64_t fusion_k, float fusion_weight, int vector_scan_direction, size_t topk,
+                                          float * out_scores, uint64_t * out_parts, uint64_t * out_labels)
+{
+    DB::HybridSearchInfo info;
+    info.fusion_type = fusion_type == 1 ? "rsf" : "rrf";
+    info.fusion_k = static_cast<int>(fusion_k);
+    info.fusion_weight = fusion_weight;
+    info.topk = static_cast<int>(topk);
+    info.vector_scan_direction = vector_scan_direction;
+    auto r = DB::MergeTreeHybridSearchManager::hybridSearch(make_list(vec_scores, vec_parts, vec_labels, nvec),
+                                                            make_list(txt_scores, txt_parts, txt_labels, ntxt), info);
+    for (size_t i = 0; i < r.size(); i++)
+    {
+        out_scores[i] = r[i].score;
+        out_parts[i] = r[i].part_index;
+        out_labels[i] = r[i].label_id;
+    }
+    return r.size();
+}
+
+extern "C" int msvs_host_merge_topk(const int64_t * ids, const float * dis, size_t nparts, size_t nq, size_t k, int metric,
+                                    int64_t * out_ids, float * out_dis)
+{
+    if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
+        return MSVS_ERR_NOT_IMPLEMENTED;
+    const bool desc = metric == MSVS_METRIC_IP;
+    std::vector<std::pair<float, int64_t>> all;
+    for (size_t q = 0; q < nq; q++)
+    {
+        all.clear();
+        for (size_t p = 0; p < nparts; p++)
+            for (size_t j = 0; j < k; j++)
+            {
+                const size_t o = (p * nq + q) * k + j;
+                if (ids[o] >= 0)
+                    all.emplace_back(dis[o], ids[o]);
+            }
+        std::sort(all.begin(), all.end(), [desc](const auto & a, const auto & b) {
+            if (a.first != b.first)
+                return desc ? a.first > b.first : a.first < b.first;
+            return a.second < b.second;
+        });
+        for (size_t j = 0; j < k; j++)
+        {
+            out_ids[q * k + j] = j < all.size() ? all[j].second : -1;
+            out_dis[q * k + j] = j < all.size() ? all[j].first
+                                                : (desc ? -std::numeric_limits<float>::max() : std::numeric_limits<float>::max());
+        }
+    }
+    return MSVS_OK;
+}
+
+extern "C" void msvs_host_sum_bm25_stats(const uint64_t * per_part, size_t nparts, size_t n_terms, uint64_t * out)
+{
+    const size_t w = 2 + n_terms;
+    for (size_t j = 0; j < w; j++)
+        out[j] = 0;
+    for (size_t p = 0; p < nparts; p++)
+        for (size_t j = 0; j < w; j++)
+            out[j] += per_part[p * w + j];
+}

@@ -1,0 +1,136 @@
+// msvs_host.hpp -- host-side mirror of the reference's operator interface for the hot path, written against
+// libmsvs.so.  Names, argument meaning and error behaviour follow the reference so that a maintainer can map each
+// piece onto the file it replaces (citations are paths in the MyScaleDB tree); the implementation is new.
+//
+//   VectorIndex::tryBruteForceSearch<FloatVector>   src/VectorIndex/Common/BruteForceSearch.h:63-92
+//   VIWithColumnInPart::searchWithoutIndex          src/VectorIndex/Common/VIWithDataPart.h:341-382
+//   MergeTreeVSManager::searchWrapper               src/VectorIndex/Storages/MergeTreeVSManager.cpp:1537-1679
+//   MergeTreeBaseSearchManager::getTotalTopSearchResultImpl   ...MergeTreeBaseSearchManager.cpp:207-299
+//   RankFusion / RelativeScoreFusion / hybridSearch src/VectorIndex/Utils/HybridSearchUtils.cpp:164-314,
+//                                                   src/VectorIndex/Storages/MergeTreeHybridSearchManager.cpp:108-171
+#pragma once
+
+#include <cstdint>
+#include <limits>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/msvs.h"
+
+namespace VectorIndex
+{
+
+enum class VIMetric
+{
+    L2 = MSVS_METRIC_L2,
+    IP = MSVS_METRIC_IP,
+    Cosine = MSVS_METRIC_COSINE
+};
+
+/// DB::Exception stand-in: carries the msvs status code (NOT_IMPLEMENTED, ...) and message.
+struct VIException : std::runtime_error
+{
+    int code;
+    VIException(int c, const std::string & m) : std::runtime_error(m), code(c) {}
+};
+
+inline void throwIfError(int rc)
+{
+    if (rc != MSVS_OK)
+        throw VIException(rc, msvs_last_error());
+}
+
+/// Same signature as the reference (raw caller-owned buffers of nx*k results, -1 = unfilled).
+inline void tryBruteForceSearch(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny,
+                                int64_t * result_id, float * distance, const VIMetric & metric_type)
+{
+    if (metric_type != VIMetric::IP && metric_type != VIMetric::L2)
+        throw VIException(MSVS_ERR_NOT_IMPLEMENTED, "Metric not implemented in brute force search for Float32 Vector");
+    throwIfError(msvs_knn_f32(x, y, d, k, nx, ny, static_cast<int>(metric_type), result_id, distance));
+}
+
+/// Owning/non-owning row-major float dataset with the reference's normalize() semantics executed on the GPU.
+struct VectorDataset
+{
+    float * data;
+    int64_t total_vectors;
+    int64_t dimension;
+    void normalize() { throwIfError(msvs_normalize_f32(data, static_cast<size_t>(total_vectors), static_cast<size_t>(dimension))); }
+};
+
+struct VIWithColumnInPart
+{
+    static void searchWithoutIndex(VectorDataset & query_data, VectorDataset & base_data, int32_t k, float * distances,
+                                   int64_t * labels, const VIMetric & metric);
+};
+
+}
+
+namespace DB
+{
+
+using VIMetric = VectorIndex::VIMetric;
+
+/// LSB-first bitmap view (1 = row exists / passes the filter).
+struct VIBitmapView
+{
+    const uint64_t * words = nullptr;
+    bool is_member(size_t i) const { return !words || ((words[i >> 6] >> (i & 63)) & 1); }
+};
+
+struct MergeTreeVSManager
+{
+    static void searchWrapper(bool prewhere, VectorIndex::VectorDataset & query_vector,
+                              VectorIndex::VectorDataset & base_data, int k, int dim, int nq, int num_rows_read,
+                              std::vector<int64_t> & final_id, std::vector<float> & final_distance,
+                              const std::vector<size_t> & actual_id_in_range, const VIMetric & metric,
+                              const VIBitmapView & row_exists, int delete_id_num);
+};
+
+struct ScoreWithPartIndexAndLabel
+{
+    float score = 0;
+    uint64_t part_index = 0;
+    uint64_t label_id = 0;
+    uint32_t shard_num = 0;
+};
+using ScoreWithPartIndexAndLabels = std::vector<ScoreWithPartIndexAndLabel>;
+
+struct MergeTreeBaseSearchManager
+{
+    /// `all` = every part's (score, part_index, label) in part order then rank order.
+    static ScoreWithPartIndexAndLabels getTotalTopSearchResultImpl(const ScoreWithPartIndexAndLabels & all,
+                                                                   uint64_t top_k, bool desc_direction);
+};
+
+void RankFusion(std::map<std::tuple<uint32_t, uint64_t, uint64_t>, float> & fusion_id_with_score,
+                const ScoreWithPartIndexAndLabels & vec_scan_result_dataset,
+                const ScoreWithPartIndexAndLabels & text_search_result_dataset, uint64_t fusion_k);
+
+void RelativeScoreFusion(std::map<std::tuple<uint32_t, uint64_t, uint64_t>, float> & fusion_id_with_score,
+                         const ScoreWithPartIndexAndLabels & vec_scan_result_dataset,
+                         const ScoreWithPartIndexAndLabels & text_search_result_dataset, float fusion_weight,
+                         int8_t vector_scan_direction);
+
+void computeNormalizedScore(const ScoreWithPartIndexAndLabels & search_result_dataset, std::vector<float> & norm_score);
+
+struct HybridSearchInfo
+{
+    std::string fusion_type = "rsf"; // "rsf" | "rrf"
+    int fusion_k = 60;
+    float fusion_weight = 0.5f;
+    int topk = 0;
+    int vector_scan_direction = 1;
+};
+
+struct MergeTreeHybridSearchManager
+{
+    static ScoreWithPartIndexAndLabels hybridSearch(const ScoreWithPartIndexAndLabels & vec_scan_result_with_part_index,
+                                                    const ScoreWithPartIndexAndLabels & text_search_result_with_part_index,
+                                                    const HybridSearchInfo & hybrid_info);
+};
+
+}

@@ -1,0 +1,83 @@
+"""Multi-GPU driver of the hot path: IVF lists (or FLAT row ranges) are sharded one shard per GPU / process, every
+rank scans its local shard for the whole query batch, then ONE all-gather of the per-rank partial top-k
+(ids i64 + distances f32, nq*k*12 B per rank) and the canonical merge.  This is the GPU analogue of the reference's
+per-part search + MergeTreeBaseSearchManager::getTotalTopSearchResultImpl
+(src/VectorIndex/Storages/MergeTreeBaseSearchManager.cpp:207-299) and of its Distributed-table scatter/gather.
+BM25 adds one all-reduce(sum) of (N, total tokens, df per term) before scoring, mirroring
+src/VectorIndex/Common/BM25InfoInDataParts.cpp:40-93.
+
+torch.distributed is only the transport (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests);
+the merge runs in libmsvs.so (device tensors) or libmsvs_host.so (host tensors)."""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+def exchange_and_merge(local_ids, local_dis, metric, group=None, stream=None):
+    """local_ids int64 [nq,k], local_dis float32 [nq,k] (same device on every rank) -> merged (ids, dis) on all ranks.
+    metric: capi.METRIC_L2 (ascending; also for cosine distances) or capi.METRIC_IP (descending)."""
+    world = dist.get_world_size(group)
+    nq, k = local_ids.shape
+    g_ids = torch.empty((world, nq, k), dtype=torch.int64, device=local_ids.device)
+    g_dis = torch.empty((world, nq, k), dtype=torch.float32, device=local_dis.device)
+    if local_ids.is_cuda:
+        dist.all_gather_into_tensor(g_ids, local_ids.contiguous(), group=group)
+        dist.all_gather_into_tensor(g_dis, local_dis.contiguous(), group=group)
+        out_ids = torch.empty((nq, k), dtype=torch.int64, device=local_ids.device)
+        out_dis = torch.empty((nq, k), dtype=torch.float32, device=local_ids.device)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        capi._check(capi.lib().msvs_merge_topk_device(
+            C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_dis.data_ptr()), C.c_size_t(world), C.c_size_t(nq),
+            C.c_size_t(k), int(metric), C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_dis.data_ptr()),
+            C.c_void_p(s) if s else None))
+        return out_ids, out_dis
+    # host tensors (gloo): all_gather into lists, merge with the host mirror
+    from . import host
+    il = [torch.empty_like(local_ids) for _ in range(world)]
+    dl = [torch.empty_like(local_dis) for _ in range(world)]
+    dist.all_gather(il, local_ids.contiguous(), group=group)
+    dist.all_gather(dl, local_dis.contiguous(), group=group)
+    oi, od = host.merge_topk(torch.stack(il).numpy(), torch.stack(dl).numpy(), metric)
+    return torch.from_numpy(oi), torch.from_numpy(od)
+
+
+def all_reduce_bm25_stats(total_docs, total_tokens, df, group=None, device="cpu"):
+    """Sum (N, total tokens, df[terms]) over the ranks: the one exchange step of sharded BM25."""
+    t = torch.tensor([int(total_docs), int(total_tokens)] + [int(x) for x in df], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    v = t.cpu().tolist()
+    return v[0], v[1], v[2:]
+
+
+class ShardedIndex:
+    """An IVFFLAT / FLAT index whose lists live on `world` GPUs (list_id % world == rank stays local)."""
+
+    def __init__(self, index_type, metric, dim, params="", group=None):
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.group = group
+        self.metric = metric
+        p = (params + "," if params else "") + "shard_rank=%d,shard_world=%d" % (self.rank, self.world)
+        self.index = capi.Index(index_type, metric, dim, p)
+
+    def set_centroids(self, centroids):
+        self.index.set_centroids(centroids)
+
+    def add(self, x, ids=None, n=None, mem=capi.MEM_HOST):
+        self.index.add(x, ids, n=n, mem=mem)
+
+    def build(self):
+        self.index.build()
+
+    def search_device(self, q, k, nprobe):
+        """q: CUDA float32 tensor [nq, dim].  Returns merged (ids, dis) CUDA tensors, identical on every rank."""
+        nq = q.shape[0]
+        ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        dis = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        self.index.search_device(q.data_ptr(), nq, k, nprobe, ids.data_ptr(), dis.data_ptr(), stream)
+        order = capi.METRIC_IP if self.metric == capi.METRIC_IP else capi.METRIC_L2
+        return exchange_and_merge(ids, dis, order, self.group, stream)

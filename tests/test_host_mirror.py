@@ -1,0 +1,103 @@
+"""Host mirror (libmsvs_host.so): the pure-host pieces are checked on CPU against the oracle and the goldens; the
+pieces that launch device work (searchWithoutIndex / searchWrapper) replay the brute-force goldens on the GPU."""
+import numpy as np
+import pytest
+
+import myscaledb_amd.capi as capi
+import myscaledb_amd.host as host
+from golden_util import eval_filter, f32_of, load_goldens, materialize
+from host_model import brute_force_part
+from oracle import oracle as o
+
+G = load_goldens()
+
+
+def test_host_library_exports_every_declared_symbol():
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "include", "msvs_host.h")) as f:
+        decl = sorted(set(re.findall(r"MSVS_HOST_API\s+[\w\s\*]+?\b(msvs_host_\w+)\s*\(", f.read())))
+    assert decl == sorted(host.SYMBOLS)
+    for s in decl:
+        assert hasattr(host.lib(), s)
+
+
+def test_total_topk_matches_oracle_and_multimap_tie_order():
+    rng = np.random.default_rng(4)
+    s = rng.integers(0, 20, 200).astype(np.float32)  # many ties
+    parts = np.repeat(np.arange(4), 50)
+    labels = np.tile(np.arange(50), 4)
+    for desc in (False, True):
+        a = host.total_topk(s, parts, labels, 30, desc)
+        b = o.total_topk(s, parts, labels, 30, desc)
+        assert all((x == y).all() for x, y in zip(a, b))
+
+
+def test_merge_topk_host_matches_canonical_order():
+    rng = np.random.default_rng(5)
+    ids = rng.permutation(3 * 4 * 10).reshape(3, 4, 10).astype(np.int64)
+    dis = rng.integers(0, 6, (3, 4, 10)).astype(np.float32)
+    ids[2, :, 7:] = -1
+    for metric in (capi.METRIC_L2, capi.METRIC_IP):
+        order = np.argsort(dis if metric == capi.METRIC_L2 else -dis, axis=2, kind="stable")
+        si, sd = np.take_along_axis(ids, order, 2), np.take_along_axis(dis, order, 2)
+        mi, md = host.merge_topk(si, sd, metric)
+        for q in range(4):
+            cand = [(d if metric == capi.METRIC_L2 else -d, i) for p in range(3) for i, d in zip(si[p, q], sd[p, q]) if i >= 0]
+            cand.sort()
+            assert mi[q].tolist() == [c[1] for c in cand[:10]]
+
+
+def test_fusion_goldens_through_host_mirror():
+    from test_oracle_golden import order_by_score_desc_id, text_search, vec_topk
+    c = G["00040_hybrid"]
+    docs = c["docs"]
+    limit = c["limit"]
+    vi, vd = vec_topk(docs, c["vec_query"], limit)
+    tr, ts = text_search(docs, c["text_query"], limit)
+    z = lambda n: np.zeros(n, np.uint64)
+    for kind in ("rsf", "rrf"):
+        s, p, l = host.hybrid_search(kind, (vd, z(len(vi)), vi), (ts, z(len(tr)), tr), limit)
+        so, po, lo = o.hybrid_fusion(kind, (vd, z(len(vi)), vi), (ts, z(len(tr)), tr), limit)
+        assert (s == so).all() and (l == lo).all()
+        ids, sc = order_by_score_desc_id([docs[int(x)]["id"] for x in l], s, limit)
+        assert ids == c[kind][0]
+        assert np.array(sc, np.float32).tolist() == f32_of(c[kind][1]).tolist()
+
+
+def test_sum_bm25_stats():
+    per_part = np.array([[10, 73, 1, 0], [10, 70, 1, 2]], np.uint64)
+    assert host.sum_bm25_stats(per_part).tolist() == [20, 143, 2, 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["00012_brute_force", "00009_brute_force_filter", "00010_brute_force_filter",
+                                  "00011_brute_force_filter", "00014_cosine_bruteforce"])
+def test_brute_force_goldens_through_host_search_wrapper(name):
+    c = G[name]
+    ids, vecs, empty = materialize(c["base"])
+    filt = eval_filter(c["filter"], ids) if c.get("filter") else None
+    fid, fdist = brute_force_part(host.search_wrapper, vecs, empty, c.get("index_granularity", 8192), c["queries"],
+                                  c["k"], c["metric"], filt=filt)
+    valid = fid[0] > -1
+    assert ids[fid[0][valid]].tolist() == c["ids"][0]
+    assert fdist[0][valid].tolist() == f32_of(c["dists"][0]).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["L2", "IP", "Cosine"])
+def test_search_wrapper_with_lightweight_deletes_matches_oracle(metric):
+    rng = np.random.default_rng(8)
+    n, d, nq, k, gran = 3000, 48, 3, 7, 512
+    vecs = rng.standard_normal((n, d), dtype=np.float32)
+    empty = np.zeros(n, bool)
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    row_exists = rng.random(n) > 0.2
+    a = brute_force_part(host.search_wrapper, vecs, empty, gran, q, k, metric, row_exists=row_exists)
+    b = brute_force_part(o.search_wrapper, vecs, empty, gran, q, k, metric, row_exists=row_exists)
+    assert (a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all()
+    filt = rng.random(n) < 0.3
+    a = brute_force_part(host.search_wrapper, vecs, empty, gran, q, k, metric, filt=filt)
+    b = brute_force_part(o.search_wrapper, vecs, empty, gran, q, k, metric, filt=filt)
+    assert (a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all()
