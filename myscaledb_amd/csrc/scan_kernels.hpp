@@ -258,45 +258,77 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
         for (int t = 0; t < T; t++)
             acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-        auto step = [&](const float4 y, const float4 * qp) {
-#pragma unroll
-            for (int t = 0; t < T; t++)
+        // one (query, float4 column) update; the accumulator of component c of query t only ever sees its own
+        // columns in ascending order, whatever the loop nest around it looks like
+        auto fma4 = [&](float4 & s, const float4 q, const float4 y) {
+            if (METRIC == M_L2)
             {
-                const float4 q = qp[t * ld4];
-                if (METRIC == M_L2)
-                {
-                    float dx = __fsub_rn(q.x, y.x), dy = __fsub_rn(q.y, y.y), dz = __fsub_rn(q.z, y.z),
-                          dw = __fsub_rn(q.w, y.w);
-                    acc[t].x = __fadd_rn(acc[t].x, __fmul_rn(dx, dx));
-                    acc[t].y = __fadd_rn(acc[t].y, __fmul_rn(dy, dy));
-                    acc[t].z = __fadd_rn(acc[t].z, __fmul_rn(dz, dz));
-                    acc[t].w = __fadd_rn(acc[t].w, __fmul_rn(dw, dw));
-                }
-                else
-                {
-                    acc[t].x = __fadd_rn(acc[t].x, __fmul_rn(q.x, y.x));
-                    acc[t].y = __fadd_rn(acc[t].y, __fmul_rn(q.y, y.y));
-                    acc[t].z = __fadd_rn(acc[t].z, __fmul_rn(q.z, y.z));
-                    acc[t].w = __fadd_rn(acc[t].w, __fmul_rn(q.w, y.w));
-                }
+                float dx = __fsub_rn(q.x, y.x), dy = __fsub_rn(q.y, y.y), dz = __fsub_rn(q.z, y.z),
+                      dw = __fsub_rn(q.w, y.w);
+                s.x = __fadd_rn(s.x, __fmul_rn(dx, dx));
+                s.y = __fadd_rn(s.y, __fmul_rn(dy, dy));
+                s.z = __fadd_rn(s.z, __fmul_rn(dz, dz));
+                s.w = __fadd_rn(s.w, __fmul_rn(dw, dw));
+            }
+            else
+            {
+                s.x = __fadd_rn(s.x, __fmul_rn(q.x, y.x));
+                s.y = __fadd_rn(s.y, __fmul_rn(q.y, y.y));
+                s.z = __fadd_rn(s.z, __fmul_rn(q.z, y.z));
+                s.w = __fadd_rn(s.w, __fmul_rn(q.w, y.w));
             }
         };
 
+        // The row is consumed in chunks of JC float4 columns per lane: all JC 16-byte loads are issued first
+        // (JC KiB in flight per wave), then the queries are walked OUTSIDE the columns, so only one query's
+        // LDS operands are live at a time (keeps T = 8 near 128 VGPRs instead of 245).
+        constexpr int JC = 6;
         uint32_t j = 0;
-        for (; j + 4 <= jfull; j += 4)
+        for (; j + JC <= jfull; j += JC)
         {
-            // 4 independent 16-byte loads in flight per lane (4 KiB per wave) before the first use
-            const float4 y0 = yrow[(j + 0) * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16],
-                         y3 = yrow[(j + 3) * 16];
-            step(y0, qrow + (j + 0) * 16);
-            step(y1, qrow + (j + 1) * 16);
-            step(y2, qrow + (j + 2) * 16);
-            step(y3, qrow + (j + 3) * 16);
+            float4 y[JC];
+#pragma unroll
+            for (int u = 0; u < JC; u++)
+                y[u] = yrow[(j + u) * 16];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+            {
+                const float4 * qp = qrow + t * ld4 + j * 16;
+                float4 q[JC];
+#pragma unroll
+                for (int u = 0; u < JC; u++)
+                    q[u] = qp[u * 16];
+#pragma unroll
+                for (int u = 0; u < JC; u++)
+                    fma4(acc[t], q[u], y[u]);
+                // do not let the scheduler hoist the next query's LDS reads above this one's arithmetic
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        for (; j + 2 <= jfull; j += 2)
+        {
+            const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+            {
+                fma4(acc[t], qrow[t * ld4 + j * 16], y0);
+                fma4(acc[t], qrow[t * ld4 + (j + 1) * 16], y1);
+            }
         }
         for (; j < jfull; j++)
-            step(yrow[j * 16], qrow + j * 16);
+        {
+            const float4 y1 = yrow[j * 16];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+                fma4(acc[t], qrow[t * ld4 + j * 16], y1);
+        }
         if (g < jtail)
-            step(yrow[jfull * 16], qrow + jfull * 16);
+        {
+            const float4 y1 = yrow[jfull * 16];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+                fma4(acc[t], qrow[t * ld4 + jfull * 16], y1);
+        }
 
         // id + filter of this row (same value in the 16 lanes of the row; only lane g == 0 offers it)
         uint32_t id = 0;
