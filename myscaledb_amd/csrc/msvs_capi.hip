@@ -690,6 +690,8 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         a.pairs = pp.pairs;
         a.pair_off = pp.pair_off;
         a.work_off = pp.work_off;
+        const char * xo = getenv("MSVS_IVF_XCD"); // experiment knob; default on
+        a.xcd_order = xo ? (uint32_t)atoi(xo) : 1u;
         launch_ivf_batched_scan(scan_metric(m), pl.T, pl.grid, a, stream);
     }
     // 3. per-query top-k over the valid segments of its probed lists

@@ -229,6 +229,7 @@ struct ScanParams
     const uint32_t * pair_off;
     const uint32_t * work_off;
     uint32_t nlist;
+    uint32_t xcd_order; // 1: XCD-contiguous work ranges (see ivf_batched_scan_kernel)
 };
 
 /// Scans rows [row_begin,row_end) for T queries already staged in LDS (qs[t*ld4 + c]) and leaves the block's
@@ -578,8 +579,16 @@ __global__ __launch_bounds__(BLOCK) void ivf_batched_scan_kernel(const ScanParam
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
     uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)T * a.ld4 * 16);
     const uint32_t total = a.work_off[a.nlist];
-    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x)
+    // Work order inside a list is [segment][query tile] (tile fastest): consecutive work items read the SAME rows
+    // for different query tiles.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, a speed
+    // assumption only), so slot s = b + i*gridDim.x is mapped to work item (s % 8) * per_xcd + s / 8: every XCD
+    // walks one contiguous range, and the tiles sharing a row segment run back to back on ONE XCD's L2.
+    const uint32_t per_xcd = (total + 7) / 8;
+    for (uint32_t s = blockIdx.x; s < 8 * per_xcd; s += gridDim.x)
     {
+        const uint32_t w = a.xcd_order ? (s & 7) * per_xcd + (s >> 3) : s;
+        if (w >= total || (a.xcd_order && (s >> 3) >= per_xcd))
+            continue;
         // the list owning work item w: work_off[l] <= w < work_off[l+1]
         uint32_t lo = 0, hi = a.nlist;
         while (hi - lo > 1)
@@ -594,8 +603,11 @@ __global__ __launch_bounds__(BLOCK) void ivf_batched_scan_kernel(const ScanParam
         const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
         const uint32_t nseg = ((uint32_t)(lend - lbeg) + a.rows_per_block - 1) / a.rows_per_block;
         const uint32_t local = w - a.work_off[l];
-        const uint32_t tile = local / nseg, seg = local - tile * nseg;
-        const uint32_t pb = a.pair_off[l] + tile * T, pe = a.pair_off[l + 1];
+        const uint32_t pe = a.pair_off[l + 1];
+        const uint32_t ntile = (pe - a.pair_off[l] + T - 1) / T;
+        const uint32_t seg = local / ntile, tile = local - seg * ntile;
+        (void)nseg;
+        const uint32_t pb = a.pair_off[l] + tile * T;
         uint32_t qidx[T];
         uint64_t * out[T];
 #pragma unroll
