@@ -183,12 +183,25 @@ def main():
     sr = [ix.scanned_rows(q_all[(i % n_pool) * B:(i % n_pool + 1) * B].cpu().numpy(), nprobe)
           for i in range(min(args.steps, n_pool))]
     rows_model = sum(r[0] for r in sr)     # sum over (query, probed list) of list length: SURVEY 8d per-query model
-    rows_streamed = sum(r[1] for r in sr)  # rows the launch streams given its query tiles (<= rows_model)
-    bytes_per_launch = rows_streamed * (4 * d + 4) / max(calls, 1)
+    rows_streamed = sum(r[1] for r in sr)  # rows streamed if every (list, query tile) pass went to HBM
+    rows_unique = sum(r[2] for r in sr)    # rows probed by >= 1 query of the batch: must come from HBM once
+    # Algorithmic bytes of ONE LAUNCH (a batch): the union of the probed rows (SURVEY 8d's batch definition
+    # "card(U probed rows) x row bytes"); everything above it is re-reads the kernel design is responsible for.
+    bytes_per_launch = rows_unique * (4 * d + 4) / max(calls, 1)
     model_bytes_per_launch = rows_model * (4 * d + 4) / max(calls, 1)
+    streamed_bytes_per_launch = rows_streamed * (4 * d + 4) / max(calls, 1)
     scan_ms = total_ms / max(calls, 1)
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     model_gbs = model_bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    streamed_gbs = streamed_bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # measured HBM traffic of this kernel from the committed rocprofv3 --pmc passes (same workload, same batch)
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if world == 1 and os.path.exists(tp):
+        with open(tp) as f:
+            tj = json.load(f)
+        if tj.get("batch") == B and tj.get("rows") == n and tj.get("dim") == d:
+            traffic = tj.get("hbm_bytes_per_launch")
     # f32 VALU work of the same launch: 3 ops (sub, mul, add) per (query, row, element), vs the 78.6 T lane-op/s
     # non-packed VALU issue peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
     valu_frac = (rows_model * d * 3 / max(calls, 1)) / (scan_ms * 1e-3) / 78.6e12 if scan_ms > 0 else 0.0
@@ -260,14 +273,18 @@ def main():
             "p50_ms_batch1": round(float(np.percentile(lat, 50)), 4) if lat else None,
             "p99_ms_batch1": round(float(np.percentile(lat, 99)), 4) if lat else None,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "ivf_batched_scan_kernel (T-query tiles per list pass)" if B * nprobe >= nlist
                          else "ivf_scan_kernel", "launch_ms": round(scan_ms, 4),
                          "bytes_per_launch": int(bytes_per_launch),
-                         "note": "achieved = bytes the launch streams (sum over (list, query tile) of list bytes) / "
-                                 "kernel time; per_query_model_gbs = SURVEY 8d per-query bytes x queries / time "
-                                 "(exceeds HBM speed when a list pass is shared by a tile of queries)",
-                         "per_query_model_gbs": round(model_gbs, 1), "valu_issue_frac": round(valu_frac, 4),
+                         "note": "achieved = union of the batch's probed rows x (4d+4) B / kernel time (each probed row "
+                                 "must leave HBM at least once per launch); traffic = FETCH_SIZE x2 + WRITE_SIZE from "
+                                 "rocprofv3 --pmc (profiles/); per_query_model_gbs = SURVEY 8d per-query bytes x "
+                                 "queries / time and streamed_model_gbs = bytes if every (list, query tile) pass "
+                                 "went to HBM -- both exceed HBM speed because a list pass is shared by a tile of "
+                                 "queries and tiles of one list share an XCD's L2",
+                         "per_query_model_gbs": round(model_gbs, 1), "streamed_model_gbs": round(streamed_gbs, 1),
+                         "valu_lane_op_frac": round(valu_frac, 4),
                          "other_kernels_ms": {"coarse_flat_scan": round(c_ms / max(c_calls, 1), 4),
                                               "merge(avg of 2)": round(m_ms / max(m_calls, 1), 4)}},
             "cpu_baseline": cpu,

@@ -129,9 +129,11 @@ MSVS_API int msvs_index_load(const char * path, msvs_index_t ** out);
  *   *rows          = sum over (query, probed list) of the list length (the per-query model of SURVEY.md 8d);
  *   *rows_streamed = rows the launch actually streams from HBM given its work decomposition: with query tiles
  *                    of T queries per list pass this is sum over lists of ceil(pairs_on_list / T) * list length
- *                    (== *rows when T == 1).  FLAT: nq * num_data / ceil(nq / T) * num_data.  Queries are HOST. */
+ *                    (== *rows when T == 1).  FLAT: nq * num_data / ceil(nq / T) * num_data;
+ *   *rows_unique   = rows probed by at least one query of the batch (the union): what MUST come from HBM at least
+ *                    once for this batch, i.e. the batch-level algorithmic bytes / (4d + 4).  Queries are HOST. */
 MSVS_API int msvs_index_scanned_rows(const msvs_index_t * index, const float * queries, size_t nq, int nprobe,
-                                     uint64_t * rows, uint64_t * rows_streamed);
+                                     uint64_t * rows, uint64_t * rows_streamed, uint64_t * rows_unique);
 /* Kernel timing with HIP events recorded on the launch stream around every kernel of the scan path.
  * enable(1) starts collecting, get() synchronises and returns call count and summed milliseconds of the kernel
  * family `name` ("flat_scan", "ivf_scan", "merge", "bm25_score"), reset() drops the samples. */

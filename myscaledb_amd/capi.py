@@ -234,10 +234,10 @@ class Index:
 
     def scanned_rows(self, queries, nprobe):
         q = _f32(queries).reshape(-1, self.dim)
-        rows, streamed = C.c_uint64(0), C.c_uint64(0)
+        rows, streamed, unique = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         _check(lib().msvs_index_scanned_rows(self._h, _p(q, C.c_float), C.c_size_t(q.shape[0]), int(nprobe),
-                                             C.byref(rows), C.byref(streamed)))
-        return rows.value, streamed.value
+                                             C.byref(rows), C.byref(streamed), C.byref(unique)))
+        return rows.value, streamed.value, unique.value
 
     def export(self):
         n, nl, d = self.num_data, self.num_lists, self.dim

@@ -760,7 +760,7 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
 }
 
 extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * queries, size_t nq, int nprobe,
-                                       uint64_t * rows, uint64_t * rows_streamed)
+                                       uint64_t * rows, uint64_t * rows_streamed, uint64_t * rows_unique)
 {
     return guarded([&] {
         if (!ix || !rows || (nq && !queries))
@@ -770,6 +770,8 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
         *rows = 0;
         if (rows_streamed)
             *rows_streamed = 0;
+        if (rows_unique)
+            *rows_unique = 0;
         if (nq == 0)
             return;
         if (ix->type == MSVS_INDEX_FLAT)
@@ -777,6 +779,8 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
             *rows = (uint64_t)nq * ix->n;
             if (rows_streamed)
                 *rows_streamed = (uint64_t)plan_flat(ix->n, nq).n_qtiles * ix->n;
+            if (rows_unique)
+                *rows_unique = ix->n;
             return;
         }
         size_t np = std::min<size_t>((size_t)std::max(nprobe, 1), ix->nlist);
@@ -815,6 +819,14 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
             for (size_t l = 0; l < ix->nlist; l++)
                 st += (uint64_t)ceil_div(cnt[l], T) * (uint64_t)(ix->h_list_off[l + 1] - ix->h_list_off[l]);
             *rows_streamed = st;
+        }
+        if (rows_unique)
+        {
+            uint64_t u = 0;
+            for (size_t l = 0; l < ix->nlist; l++)
+                if (cnt[l])
+                    u += (uint64_t)(ix->h_list_off[l + 1] - ix->h_list_off[l]);
+            *rows_unique = u;
         }
     });
 }

@@ -372,3 +372,57 @@ def test_full_size_1m_x_768_properties():
     same(fi[:2], fd[:2], oe, de)
     # nprobe=256 of 1024 lists on iid gaussians is not exhaustive; it can only be worse or equal, never better
     assert (ad >= fd - 0).all()
+
+
+# ---------------------------------------------------------------------------------------- hybrid (config 5 shape)
+
+def test_hybrid_goldens_end_to_end_on_gpu():
+    """00040: vector top-k (FLAT index on the GPU) + BM25 (GPU) + RRF / RSF (host mirror) == the reference's output."""
+    import myscaledb_amd.host as host
+    c = G["00040_hybrid"]
+    docs, limit = c["docs"], c["limit"]
+    vecs = np.array([d["vector"] for d in docs], np.float32)
+    ix = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, 3)
+    ix.add(vecs)
+    ix.build()
+    vi, vd = ix.search(np.array([c["vec_query"]], np.float32), limit)
+    (tr, ts), _ = bm25_both([d["texts"] for d in docs], c["text_query"], limit)
+    z = lambda n: np.zeros(n, np.uint64)
+    for kind in ("rsf", "rrf"):
+        s, _, l = host.hybrid_search(kind, (vd[0], z(limit), vi[0]), (ts, z(len(tr)), tr), limit)
+        order = sorted(range(len(l)), key=lambda j: (-float(s[j]), docs[int(l[j])]["id"]))
+        assert [docs[int(l[j])]["id"] for j in order] == c[kind][0]
+        assert [np.float32(s[j]) for j in order] == f32_of(c[kind][1]).tolist()
+
+
+def test_hybrid_pipeline_synthetic_matches_oracle_pipeline():
+    """vector top-100 (IVFFLAT, cosine) + BM25 top-100 + RRF(k=60) -> top-10, GPU pipeline vs oracle pipeline."""
+    import myscaledb_amd.host as host
+    rng = np.random.default_rng(31)
+    n, d, nlist = 20000, 64, 32
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    vocab = ["t%d" % i for i in range(800)]
+    p = 1.0 / np.arange(1, 801) ** 1.1
+    p /= p.sum()
+    docs = [[" ".join(vocab[j] for j in rng.choice(800, max(1, rng.poisson(20)), p=p))] for _ in range(n)]
+    ix = build_ivf(x, capi.METRIC_COSINE, nlist)
+    idx = TextIndex(docs, o.fieldnorm_id)
+    ps = capi.Postings(idx.post_off, idx.doc_ids, idx.tfs, idx.fieldnorm_ids)
+    cent, off, vecs, lids = ix.export()
+    for qi in range(5):
+        q = rng.standard_normal((1, d), dtype=np.float32)
+        terms = ["t%d" % t for t in rng.integers(5, 200, 3)]
+        qt = [idx.vocab[t] for t in terms if t in idx.vocab]
+        df = [idx.doc_freq(t) for t in terms if t in idx.vocab]
+        gi, gd = ix.search(q, 100, "nprobe=8")
+        gr, gs = ps.bm25_search(qt, df, idx.num_docs, idx.total_tokens, 100)
+        oi, od, _ = o.ivf_search(cent, off, vecs, lids, o.normalize_rows(q), 8, 100, o.METRIC_IP)
+        od = (np.float32(1) - od).astype(np.float32)
+        orr, osc = o.bm25_search(idx.post_off, idx.doc_ids, idx.tfs, idx.fieldnorm_ids, qt, df, idx.num_docs,
+                                 idx.total_tokens, 100)
+        same(gi, gd, oi, od)
+        assert gr.tolist() == orr.tolist() and (gs.view(np.uint32) == osc.view(np.uint32)).all()
+        z = lambda m: np.zeros(m, np.uint64)
+        a = host.hybrid_search("rrf", (gd[0], z(100), gi[0]), (gs, z(len(gr)), gr), 10, fusion_k=60)
+        b = o.hybrid_fusion("rrf", (od[0], z(100), oi[0]), (osc, z(len(orr)), orr), 10, fusion_k=60)
+        assert a[2].tolist() == b[2].tolist() and (a[0] == b[0]).all()  # integer ranks / row ids bit-exact
