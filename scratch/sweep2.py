@@ -26,7 +26,7 @@ ref = {}
 for c in sys.argv[1:]:
     kv = dict(p.split('=') for p in c.split(','))
     B = int(kv.pop('B'))
-    for kk in ("MSVS_IVF_T", "MSVS_IVF_RPB", "MSVS_IVF_GRID", "MSVS_IVF_XCD"):
+    for kk in ("MSVS_IVF_T", "MSVS_IVF_RPB", "MSVS_IVF_GRID", "MSVS_IVF_XCD", "MSVS_IVF_WT"):
         os.environ.pop(kk, None)
     for a, b in kv.items():
         os.environ["MSVS_IVF_" + a] = b
