@@ -242,7 +242,14 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as o
         cent, off, vecs, lids = ix.export()
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:  # a cgroup CPU quota smaller than the visible core count is what the threads really get
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                quota, period = f.read().split()
+            if quota != "max":
+                cores = max(1, min(cores, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
         qh = q_all[:4096].cpu().numpy()
         t1 = time.perf_counter()
         o.ivf_search(cent, off, vecs, lids, qh[:cores], nprobe, k, o.METRIC_L2, threads=cores)

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Secondary measurements of the other BASELINE.json configs (not the headline bench.py line): device-resident,
+HIP-event-free wall timing with stream sync, printed as plain text for profiles/.
+
+  C1  FLAT brute force 10k x 128 L2 top-10 (resident FLAT index; the A2 host-pointer call is PCIe-bound by design)
+  C2' FLAT exhaustive 1M x 768 L2 (the exact scan the IVF recall is measured against)
+  C3  partition scan ("MSTG-style"): IVFFLAT cosine, 10M x 768 (or --rows), nlist 4096, batch 64, nprobe 32
+  C5  BM25 over 10M documents (Zipf(1.1) vocabulary of 200k terms, Poisson(30) lengths), 3-term queries
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import myscaledb_amd.capi as capi  # noqa: E402
+from bench import make_data, make_queries  # noqa: E402
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps
+
+
+def flat_case(name, n, d, nqs, k, dev):
+    model, x = make_data(n, d, 1234, dev)
+    ix = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
+    ix.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+    ix.build()
+    stream = torch.cuda.current_stream().cuda_stream
+    for nq in nqs:
+        q = make_queries(model, nq, 4321, dev)
+        oi = torch.empty((nq, k), device=dev, dtype=torch.int64)
+        od = torch.empty((nq, k), device=dev, dtype=torch.float32)
+        dt = timed(lambda: ix.search_device(q.data_ptr(), nq, k, 0, oi.data_ptr(), od.data_ptr(), stream), 20)
+        passes = -(-nq // 8) if nq > 4 else 1
+        print("%s FLAT %dx%d nq=%d k=%d : %.3f ms/call  %.0f QPS  streamed %.2f GB -> %.0f GB/s  (per-query model %.0f GB/s)"
+              % (name, n, d, nq, k, dt * 1e3, nq / dt, passes * n * d * 4 / 1e9, passes * n * d * 4 / dt / 1e9,
+                 nq * n * d * 4 / dt / 1e9), flush=True)
+    ix.close()
+    del x
+
+
+def ivf_cosine_case(n, d, nlist, batch, nprobe, k, dev):
+    model, x = make_data(n, d, 1234, dev)
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_COSINE, d, "ncentroids=%d,kmeans_iters=8,train_sample=%d" % (nlist, nlist * 48))
+    t0 = time.time()
+    ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+    step = 2_000_000
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        ix.add(x[lo:hi].data_ptr(), n=hi - lo, mem=capi.MEM_DEVICE)
+    ix.build()
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    del x
+    q = make_queries(model, batch * 8, 4321, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    oi = torch.empty((batch, k), device=dev, dtype=torch.int64)
+    od = torch.empty((batch, k), device=dev, dtype=torch.float32)
+    it = [0]
+
+    def run():
+        b = it[0] % 8
+        it[0] += 1
+        ix.search_device(q[b * batch:(b + 1) * batch].data_ptr(), batch, k, nprobe, oi.data_ptr(), od.data_ptr(), stream)
+    dt = timed(run, 20)
+    rows, streamed, uniq = ix.scanned_rows(q[:batch].cpu().numpy(), nprobe)
+    rb = 4 * d + 4
+    print("C3 IVFFLAT cosine %dx%d nlist=%d batch=%d nprobe=%d k=%d : build %.1f s, %.3f ms/batch  %.0f QPS ; rows/query %.0f ; "
+          "union %.2f GB -> %.0f GB/s, streamed-model %.2f GB, per-query model %.2f GB"
+          % (n, d, nlist, batch, nprobe, k, build_s, dt * 1e3, batch / dt, rows / batch, uniq * rb / 1e9,
+             uniq * rb / dt / 1e9, streamed * rb / 1e9, rows * rb / 1e9), flush=True)
+    ix.close()
+
+
+def bm25_case(n_docs, vocab, k):
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    p = 1.0 / torch.arange(1, vocab + 1, device=dev, dtype=torch.float64) ** 1.1
+    lens_t = torch.clamp(torch.poisson(torch.full((n_docs,), 30.0, device=dev), generator=g), min=1).to(torch.int64)
+    total = int(lens_t.sum().item())
+    # corpus generation on the GPU (torch is plumbing here): Zipf tokens, then (term, doc) pairs sorted by term, doc
+    toks = torch.multinomial((p / p.sum()).to(torch.float32), total, replacement=True, generator=g)
+    doc_of = torch.repeat_interleave(torch.arange(n_docs, device=dev, dtype=torch.int64), lens_t)
+    key, _ = torch.sort(toks * n_docs + doc_of)
+    uk_t, tf_t = torch.unique_consecutive(key, return_counts=True)
+    uk, tf = uk_t.cpu().numpy(), tf_t.cpu().numpy()
+    lens = lens_t.cpu().numpy()
+    del toks, doc_of, key, uk_t, tf_t
+    term, doc = uk // n_docs, (uk % n_docs).astype(np.uint32)
+    post_off = np.zeros(vocab + 1, np.int64)
+    np.cumsum(np.bincount(term, minlength=vocab), out=post_off[1:])
+    table = [b if b < 24 else 24 + (((b - 24) & 7) if ((b - 24) >> 3) == 0 else (((b - 24) & 7) | 8) << (((b - 24) >> 3) - 1))
+             for b in range(256)]
+    fn_ids = (np.searchsorted(np.array(table, np.int64), lens, side="right") - 1).astype(np.uint8)
+    ps = capi.Postings(post_off, doc, tf.astype(np.uint32), fn_ids)
+    df_all = np.diff(post_off)
+    mids = np.argsort(-df_all)[50:2000]
+    times, bytes_ = [], []
+    for i in range(30):
+        q = rng.choice(mids, 3, replace=False)
+        df = df_all[q]
+        t = time.perf_counter()
+        rows, scores = ps.bm25_search(q, df, n_docs, total, k)
+        times.append(time.perf_counter() - t)
+        bytes_.append(int(df.sum()) * 8 + min(int(df.sum()), n_docs))
+    times, bytes_ = np.array(times[5:]), np.array(bytes_[5:])
+    print("C5 BM25 %d docs, %d postings, 3-term queries, k=%d : p50 %.3f ms/query (host call incl. D2H), "
+          "postings+fieldnorm bytes/query %.1f MB -> %.0f GB/s"
+          % (n_docs, len(doc), k, np.median(times) * 1e3, bytes_.mean() / 1e6, (bytes_ / times).mean() / 1e9), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--skip", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    capi.set_device(0)
+    if "c1" not in a.skip:
+        flat_case("C1", 10_000, 128, [1, 8, 64, 1000], 10, dev)
+    if "c2" not in a.skip:
+        flat_case("C2'", 1_000_000, 768, [1, 8, 64], 10, dev)
+    if "c3" not in a.skip:
+        ivf_cosine_case(a.rows, 768, 4096, 64, 32, 10, dev)
+    if "c5" not in a.skip:
+        bm25_case(a.docs, 200_000, 100)
+
+
+if __name__ == "__main__":
+    main()
