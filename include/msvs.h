@@ -149,6 +149,11 @@ MSVS_API int msvs_merge_topk(const int64_t * ids, const float * dis, size_t npar
                              int64_t * out_ids, float * out_dis);
 MSVS_API int msvs_merge_topk_device(const int64_t * d_ids, const float * d_dis, size_t nparts, size_t nq, size_t k,
                                     int metric, int64_t * d_out_ids, float * d_out_dis, void * hip_stream);
+/* Same, but shard p's [nq][k] lists start at d_ids + p * ids_part_stride / d_dis + p * dis_part_stride (strides in
+ * ELEMENTS): lets each rank all-gather ONE packed buffer {ids[nq*k] i64 | dis[nq*k] f32} and merge it in place. */
+MSVS_API int msvs_merge_topk_device_strided(const int64_t * d_ids, size_t ids_part_stride, const float * d_dis,
+                                            size_t dis_part_stride, size_t nparts, size_t nq, size_t k, int metric,
+                                            int64_t * d_out_ids, float * d_out_dis, void * hip_stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Seam B -- BM25 posting-list scorer.  Replaces the scoring inside

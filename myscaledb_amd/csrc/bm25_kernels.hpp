@@ -40,7 +40,7 @@ __global__ __launch_bounds__(BLOCK) void bm25_score_kernel(const Bm25Params a)
     __shared__ float score[BM25_DOCS];
     __shared__ uint8_t hit[BM25_DOCS];
     __shared__ float cache[256];
-    __shared__ int64_t range[2];
+    __shared__ int64_t range[BM25_MAX_TERMS][2];
     uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,27 +52,28 @@ __global__ __launch_bounds__(BLOCK) void bm25_score_kernel(const Bm25Params a)
         hit[i] = 0;
     }
     cache[tid] = a.norm_cache[tid];
+    if (tid < 2 * a.n_terms)
+    {
+        // all the posting-range searches of the block run side by side (one dependent-load chain of ~log2(df)
+        // steps in total instead of one per term): first posting of term t with doc >= base (side 0) / end (side 1)
+        const uint32_t t = tid >> 1, side = tid & 1;
+        const uint32_t target = side == 0 ? base : end;
+        int64_t lo = a.post_off[a.qterms[t]], hi = a.post_off[a.qterms[t] + 1];
+        while (lo < hi)
+        {
+            int64_t mid = (lo + hi) >> 1;
+            if (a.doc_ids[mid] < target)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        range[t][side] = lo;
+    }
     for (uint32_t t = 0; t < a.n_terms; t++)
     {
-        __syncthreads();
-        if (tid < 2)
-        {
-            // first posting with doc >= (tid == 0 ? base : end)
-            const uint32_t target = tid == 0 ? base : end;
-            int64_t lo = a.post_off[a.qterms[t]], hi = a.post_off[a.qterms[t] + 1];
-            while (lo < hi)
-            {
-                int64_t mid = (lo + hi) >> 1;
-                if (a.doc_ids[mid] < target)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            range[tid] = lo;
-        }
-        __syncthreads();
+        __syncthreads(); // orders term t after term t-1 (and after the range searches): f32 sums in query-term order
         const float w = a.weight[t];
-        for (int64_t p = range[0] + tid; p < range[1]; p += BLOCK)
+        for (int64_t p = range[t][0] + tid; p < range[t][1]; p += BLOCK)
         {
             const uint32_t doc = a.doc_ids[p];
             const float tf = (float)a.tfs[p];

@@ -173,7 +173,7 @@ void launch_flat_scan(int metric, const FlatPlan & plan, ScanParams a, hipStream
 template <int METRIC>
 static void merge_dispatch(const MergeParams & a, uint32_t nq, hipStream_t stream)
 {
-    size_t lds = (size_t)5 * a.k * 8;
+    size_t lds = merge_lds_bytes(a.k, 0);
     switch (r_for_k(a.k))
     {
         case 1:
@@ -295,7 +295,7 @@ void launch_ivf_batched_scan(int metric, uint32_t T, uint32_t grid, ScanParams a
 template <int METRIC>
 static void ivf_merge_dispatch(const IvfMergeParams & a, uint32_t nq, hipStream_t stream)
 {
-    size_t lds = (size_t)5 * a.k * 8;
+    size_t lds = merge_lds_bytes(a.k, a.nprobe);
     switch (r_for_k(a.k))
     {
         case 1:

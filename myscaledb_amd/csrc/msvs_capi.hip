@@ -546,7 +546,9 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe)
     {
         // one (query, list, segment) per block: many small blocks, ~8192 of them
         size_t rpb = round_up(std::max<size_t>(16, avg * pairs / 8192), 16);
-        p.rpb = (uint32_t)std::min<size_t>(std::max<size_t>(rpb, 64), 256);
+        // keep a query's partial lists (~1.5 * nprobe * avg / rpb of them) within the LDS budget of the merge block
+        size_t rpb_min = round_up(std::max<size_t>(64, nprobe * avg * 3 / 2 / 400), 16);
+        p.rpb = (uint32_t)std::min<size_t>(std::max<size_t>(rpb, rpb_min), 256);
     }
     else
     {
@@ -981,8 +983,9 @@ extern "C" int msvs_index_load(const char * path, msvs_index_t ** out)
 
 namespace msvs
 {
-static void merge_topk_device(const int64_t * d_ids, const float * d_dis, size_t nparts, size_t nq, size_t k,
-                              int metric, int64_t * d_out_ids, float * d_out_dis, hipStream_t stream)
+static void merge_topk_device(const int64_t * d_ids, size_t ids_stride, const float * d_dis, size_t dis_stride,
+                              size_t nparts, size_t nq, size_t k, int metric, int64_t * d_out_ids, float * d_out_dis,
+                              hipStream_t stream)
 {
     if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
         fail(MSVS_ERR_NOT_IMPLEMENTED, "merge supports L2 / IP ordering (cosine distances are ascending: use L2)");
@@ -991,21 +994,15 @@ static void merge_topk_device(const int64_t * d_ids, const float * d_dis, size_t
     check_k(k);
     Scratch & scr = scratch_for(stream);
     const size_t total = nparts * nq * k;
-    scr.reserve(total * 8 * 2 + 8192, stream);
-    uint64_t * keys = scr.take<uint64_t>(total);       // [nparts][nq][k]
-    uint64_t * keys_q = scr.take<uint64_t>(total);     // [nq][nparts][k]
+    scr.reserve(total * 8 + 8192, stream);
+    uint64_t * keys_q = scr.take<uint64_t>(total); // [nq][nparts][k]
     if (metric == MSVS_METRIC_IP)
         hipLaunchKernelGGL((pack_keys_kernel<M_IP>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, d_ids,
-                           d_dis, keys, total);
+                           ids_stride, d_dis, dis_stride, keys_q, (uint32_t)nparts, (uint32_t)nq, (uint32_t)k);
     else
         hipLaunchKernelGGL((pack_keys_kernel<M_L2>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, d_ids,
-                           d_dis, keys, total);
+                           ids_stride, d_dis, dis_stride, keys_q, (uint32_t)nparts, (uint32_t)nq, (uint32_t)k);
     MSVS_HIP(hipGetLastError());
-    // transpose [nparts][nq][k] -> [nq][nparts][k] with strided copies
-    MSVS_HIP(hipMemcpy2DAsync(keys_q, nparts * k * 8, keys, k * 8, k * 8, nq, hipMemcpyDeviceToDevice, stream));
-    for (size_t p = 1; p < nparts; p++)
-        MSVS_HIP(hipMemcpy2DAsync(keys_q + p * k, nparts * k * 8, keys + p * nq * k, k * 8, k * 8, nq,
-                                  hipMemcpyDeviceToDevice, stream));
     MergeParams m{};
     m.partial = keys_q;
     m.n_lists = (uint32_t)nparts;
@@ -1022,7 +1019,22 @@ extern "C" int msvs_merge_topk_device(const int64_t * d_ids, const float * d_dis
     return guarded([&] {
         if (nparts && nq && k && (!d_ids || !d_dis || !d_out_ids || !d_out_dis))
             fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
-        merge_topk_device(d_ids, d_dis, nparts, nq, k, metric, d_out_ids, d_out_dis, as_stream(hip_stream));
+        merge_topk_device(d_ids, nq * k, d_dis, nq * k, nparts, nq, k, metric, d_out_ids, d_out_dis,
+                          as_stream(hip_stream));
+    });
+}
+
+extern "C" int msvs_merge_topk_device_strided(const int64_t * d_ids, size_t ids_part_stride, const float * d_dis,
+                                              size_t dis_part_stride, size_t nparts, size_t nq, size_t k, int metric,
+                                              int64_t * d_out_ids, float * d_out_dis, void * hip_stream)
+{
+    return guarded([&] {
+        if (nparts && nq && k && (!d_ids || !d_dis || !d_out_ids || !d_out_dis))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
+        if (ids_part_stride < nq * k || dis_part_stride < nq * k)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "part stride smaller than nq * k");
+        merge_topk_device(d_ids, ids_part_stride, d_dis, dis_part_stride, nparts, nq, k, metric, d_out_ids, d_out_dis,
+                          as_stream(hip_stream));
     });
 }
 
@@ -1039,7 +1051,7 @@ extern "C" int msvs_merge_topk(const int64_t * ids, const float * dis, size_t np
         DevBuf<float> d_dis(total), d_od(nq * k);
         MSVS_HIP(hipMemcpy(d_ids.p, ids, total * 8, hipMemcpyHostToDevice));
         MSVS_HIP(hipMemcpy(d_dis.p, dis, total * 4, hipMemcpyHostToDevice));
-        merge_topk_device(d_ids.p, d_dis.p, nparts, nq, k, metric, d_oi.p, d_od.p, nullptr);
+        merge_topk_device(d_ids.p, nq * k, d_dis.p, nq * k, nparts, nq, k, metric, d_oi.p, d_od.p, nullptr);
         MSVS_HIP(hipMemcpy(out_ids, d_oi.p, nq * k * 8, hipMemcpyDeviceToHost));
         MSVS_HIP(hipMemcpy(out_dis, d_od.p, nq * k * 4, hipMemcpyDeviceToHost));
     });

@@ -626,6 +626,85 @@ __global__ __launch_bounds__(BLOCK) void ivf_batched_scan_kernel(const ScanParam
     }
 }
 
+// ------------------------------------------------------------------------------------------ merges of sorted lists
+
+constexpr uint32_t HEADS_CAP = 6144; // keys a merge block stages in LDS (48 KiB; the block stays below 64 KiB)
+
+/// LDS bytes of a merge block: staged keys + output + per-list cursors + per-probe list prefix (the 5*k key slots of
+/// the threshold-method fallback alias the staged-key region).
+inline size_t merge_lds_bytes(uint32_t k, uint32_t nprobe)
+{
+    size_t heads = (size_t)HEADS_CAP * 8 + (size_t)k * 8 + (size_t)HEADS_CAP * 2 + ((size_t)nprobe + 1) * 4 + 64;
+    size_t fallback = (size_t)5 * k * 8;
+    return heads > fallback ? heads : fallback;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+    return (uint64_t)hi << 32 | lo;
+}
+
+/// Wave-wide minimum of a u64, result uniform: 4 DPP steps inside each 16-lane row (a few cycles each, unlike the
+/// ~100-cycle ds_bpermute behind __shfl_xor), then 4 readlanes + scalar mins across the rows.
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+    uint64_t o;
+    o = dpp64<0xB1>(v);  // lane ^ 1
+    v = o < v ? o : v;
+    o = dpp64<0x4E>(v);  // lane ^ 2
+    v = o < v ? o : v;
+    o = dpp64<0x141>(v); // row_half_mirror
+    v = o < v ? o : v;
+    o = dpp64<0x140>(v); // row_mirror
+    v = o < v ? o : v;
+    uint64_t r0 = readlane64(v, 0), r1 = readlane64(v, 16), r2 = readlane64(v, 32), r3 = readlane64(v, 48);
+    r0 = r1 < r0 ? r1 : r0;
+    r2 = r3 < r2 ? r3 : r2;
+    return r2 < r0 ? r2 : r0;
+}
+
+/// P sorted lists of length L staged in LDS (list i at keys[i*L ...]) -> the k smallest keys in out[0..k) (LDS), by
+/// ONE wavefront: lane l owns lists l, l+64, ... and keeps the smallest unconsumed head among them; each of the k
+/// rounds is a wave-wide minimum + a rescan by the winning lane only.  Cost ~ k * (P/64 + log 64) LDS reads, against
+/// ~ P*L*ln(...) serialised insertions for the threshold method when most partial lists are short.
+/// idx: u16[P] LDS scratch.  Keys are unique except KEY_NONE.
+__device__ __forceinline__ void wave_heads_merge(const uint64_t * keys, uint32_t P, uint32_t L, uint16_t * idx,
+                                                 uint64_t * out, uint32_t k, uint32_t lane)
+{
+    for (uint32_t i = lane; i < P; i += WAVE)
+        idx[i] = 0;
+    uint64_t best = KEY_NONE;
+    uint32_t bl = 0;
+    auto rescan = [&]() {
+        best = KEY_NONE;
+        for (uint32_t i = lane; i < P; i += WAVE)
+        {
+            const uint32_t h = idx[i];
+            const uint64_t key = h < L ? keys[i * L + h] : KEY_NONE;
+            if (key < best)
+            {
+                best = key;
+                bl = i;
+            }
+        }
+    };
+    rescan();
+    for (uint32_t r = 0; r < k; r++)
+    {
+        const uint64_t m = wave_min_u64(best);
+        if (lane == 0)
+            out[r] = m;
+        if (m != KEY_NONE && best == m)
+        {
+            idx[bl] = (uint16_t)(idx[bl] + 1);
+            rescan();
+        }
+    }
+}
+
 struct IvfMergeParams
 {
     const uint64_t * partial; // [(q*nprobe + p)*seg_max + s][k]
@@ -643,6 +722,67 @@ __global__ __launch_bounds__(BLOCK) void ivf_merge_kernel(const IvfMergeParams a
 {
     uint64_t * lds = reinterpret_cast<uint64_t *>(msvs_smem);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k, q = blockIdx.x;
+
+    // Fast path: all valid partial lists of the query fit in LDS -> compact them and run the heads merge.
+    {
+        uint64_t * keys = lds;                                                  // [HEADS_CAP]
+        uint64_t * outk = lds + HEADS_CAP;                                      // [k]
+        uint16_t * idx = reinterpret_cast<uint16_t *>(outk + k);                // [HEADS_CAP]
+        uint32_t * lbase = reinterpret_cast<uint32_t *>(idx + HEADS_CAP);       // [nprobe + 1] list index prefix
+        for (uint32_t p = tid; p < a.nprobe; p += BLOCK) // segment counts: independent global loads, all in flight
+        {
+            const int32_t l = a.probes[(size_t)q * a.nprobe + p];
+            uint32_t ns = 0;
+            if (l >= 0)
+            {
+                const uint32_t len = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
+                ns = (len + a.rows_per_block - 1) / a.rows_per_block;
+            }
+            lbase[p + 1] = ns;
+        }
+        __syncthreads();
+        if (tid == 0) // exclusive prefix over <= 256 LDS values
+        {
+            uint32_t acc = 0;
+            for (uint32_t p = 0; p < a.nprobe; p++)
+            {
+                const uint32_t ns = lbase[p + 1];
+                lbase[p] = acc;
+                acc += ns;
+            }
+            lbase[a.nprobe] = acc;
+        }
+        __syncthreads();
+        const uint32_t P = lbase[a.nprobe];
+        if ((uint64_t)P * k <= HEADS_CAP)
+        {
+            // one flat loop over the padded (probe, segment-slot, rank) space: every load is independent, so the
+            // copy costs one memory latency instead of one per probe
+            const uint32_t slots = a.seg_max * k, padded = a.nprobe * slots;
+            const uint64_t * src = a.partial + (size_t)q * padded;
+            for (uint32_t i = tid; i < padded; i += BLOCK)
+            {
+                const uint32_t p = i / slots, r = i - p * slots;
+                if (r < (lbase[p + 1] - lbase[p]) * k)
+                    keys[(size_t)lbase[p] * k + r] = src[i];
+            }
+            __syncthreads();
+            if (wave == 0)
+                wave_heads_merge(keys, P, k, idx, outk, k, lane);
+            __syncthreads();
+            for (uint32_t i = tid; i < k; i += BLOCK)
+            {
+                uint64_t key = outk[i];
+                size_t o = (size_t)q * k + i;
+                a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
+                float v = key_value<METRIC>(key);
+                a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+            }
+            return;
+        }
+        __syncthreads();
+    }
+
     WaveTopK<R> top;
     top.init();
     for (uint32_t p = wave; p < a.nprobe; p += 4)
@@ -704,6 +844,37 @@ __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams a)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k, q = blockIdx.x;
     const uint64_t * src = a.partial + (size_t)q * a.n_lists * k;
     const uint64_t total = (uint64_t)a.n_lists * k;
+
+    if (total <= HEADS_CAP)
+    {
+        // Fast path: stage all lists in LDS and run the heads merge (see wave_heads_merge)
+        uint64_t * keys = lds;
+        uint64_t * outk = lds + HEADS_CAP;
+        uint16_t * idx = reinterpret_cast<uint16_t *>(outk + k);
+        for (uint32_t i = tid; i < (uint32_t)total; i += BLOCK)
+            keys[i] = src[i];
+        __syncthreads();
+        if (wave == 0)
+            wave_heads_merge(keys, a.n_lists, k, idx, outk, k, lane);
+        __syncthreads();
+        for (uint32_t i = tid; i < k; i += BLOCK)
+        {
+            uint64_t key = outk[i];
+            size_t o = (size_t)q * k + i;
+            if (a.mode == 1)
+                a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
+            else if (a.mode == 2)
+                a.out_keys[o] = key;
+            else
+            {
+                a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
+                float v = key_value<METRIC>(key);
+                a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+            }
+        }
+        return;
+    }
+
     WaveTopK<R> top;
     top.init();
     for (uint64_t base = 0; base < total; base += 4 * BLOCK)
@@ -740,13 +911,22 @@ __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams a)
     }
 }
 
-/// (ids, dis) lists -> keys, for msvs_merge_topk: [n] entries.
+/// (ids, dis) lists of `nparts` shards -> keys in the merge kernel's layout [nq][nparts][k].
+/// Shard p's lists start at ids + p * ids_stride / dis + p * dis_stride (element strides), each [nq][k].
 template <int METRIC>
-__global__ void pack_keys_kernel(const int64_t * ids, const float * dis, uint64_t * keys, size_t n)
+__global__ void pack_keys_kernel(const int64_t * ids, size_t ids_stride, const float * dis, size_t dis_stride,
+                                 uint64_t * keys, uint32_t nparts, uint32_t nq, uint32_t k)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        keys[i] = ids[i] < 0 ? KEY_NONE : make_key<METRIC>(dis[i], (uint32_t)ids[i]);
+    const size_t per_part = (size_t)nq * k;
+    if (i >= per_part * nparts)
+        return;
+    const uint32_t p = (uint32_t)(i / per_part);
+    const size_t rem = i - (size_t)p * per_part;
+    const uint32_t q = (uint32_t)(rem / k), j = (uint32_t)(rem - (size_t)q * k);
+    const int64_t id = ids[p * ids_stride + rem];
+    const float d = dis[p * dis_stride + rem];
+    keys[((size_t)q * nparts + p) * k + j] = id < 0 ? KEY_NONE : make_key<METRIC>(d, (uint32_t)id);
 }
 
 // ------------------------------------------------------------------------------------------ normalisation

@@ -44,6 +44,35 @@ def exchange_and_merge(local_ids, local_dis, metric, group=None, stream=None):
     return torch.from_numpy(oi), torch.from_numpy(od)
 
 
+class PackedExchange:
+    """Pre-allocated buffers for the steady-state exchange on the GPU: the search writes its partial ids / distances
+    into ONE packed buffer {ids[nq*k] i64 | dis[nq*k] f32}, a single RCCL all-gather moves it, and
+    msvs_merge_topk_device_strided merges the gathered buffer in place (no repacking kernels, no second collective)."""
+
+    def __init__(self, nq, k, device, group=None):
+        self.nq, self.k, self.group = nq, k, group
+        self.world = dist.get_world_size(group)
+        self.part_bytes = (nq * k * 12 + 7) // 8 * 8
+        self.local = torch.zeros(self.part_bytes, dtype=torch.uint8, device=device)
+        self.ids = self.local[:nq * k * 8].view(torch.int64).view(nq, k)
+        self.dis = self.local[nq * k * 8:nq * k * 12].view(torch.float32).view(nq, k)
+        self.gathered = torch.empty(self.world * self.part_bytes, dtype=torch.uint8, device=device)
+        self.out_ids = torch.empty((nq, k), dtype=torch.int64, device=device)
+        self.out_dis = torch.empty((nq, k), dtype=torch.float32, device=device)
+
+    def run(self, metric, stream=None):
+        """all-gather self.local (filled by the search) and merge -> (out_ids, out_dis)."""
+        dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        base = self.gathered.data_ptr()
+        capi._check(capi.lib().msvs_merge_topk_device_strided(
+            C.c_void_p(base), C.c_size_t(self.part_bytes // 8), C.c_void_p(base + self.nq * self.k * 8),
+            C.c_size_t(self.part_bytes // 4), C.c_size_t(self.world), C.c_size_t(self.nq), C.c_size_t(self.k),
+            int(metric), C.c_void_p(self.out_ids.data_ptr()), C.c_void_p(self.out_dis.data_ptr()),
+            C.c_void_p(s) if s else None))
+        return self.out_ids, self.out_dis
+
+
 def all_reduce_bm25_stats(total_docs, total_tokens, df, group=None, device="cpu"):
     """Sum (N, total tokens, df[terms]) over the ranks: the one exchange step of sharded BM25."""
     t = torch.tensor([int(total_docs), int(total_tokens)] + [int(x) for x in df], dtype=torch.int64, device=device)

@@ -426,3 +426,34 @@ def test_hybrid_pipeline_synthetic_matches_oracle_pipeline():
         a = host.hybrid_search("rrf", (gd[0], z(100), gi[0]), (gs, z(len(gr)), gr), 10, fusion_k=60)
         b = o.hybrid_fusion("rrf", (od[0], z(100), oi[0]), (osc, z(len(orr)), orr), 10, fusion_k=60)
         assert a[2].tolist() == b[2].tolist() and (a[0] == b[0]).all()  # integer ranks / row ids bit-exact
+
+
+def test_strided_device_merge_of_packed_exchange_buffers():
+    """The multi-GPU exchange layout: every rank's {ids[nq*k] i64 | dis[nq*k] f32} packed back to back (what ONE
+    all-gather delivers), merged in place by msvs_merge_topk_device_strided == the host-pointer merge."""
+    import ctypes as C
+
+    import torch
+    rng = np.random.default_rng(41)
+    W, nq, k = 5, 37, 10
+    ids = rng.permutation(W * nq * k).reshape(W, nq, k).astype(np.int64)
+    dis = rng.integers(0, 50, (W, nq, k)).astype(np.float32)
+    ids[3, :, 6:] = -1  # a shard with fewer than k local hits
+    for metric in (capi.METRIC_L2, capi.METRIC_IP):
+        order = np.argsort(dis if metric == capi.METRIC_L2 else -dis, axis=2, kind="stable")
+        si, sd = np.take_along_axis(ids, order, 2), np.take_along_axis(dis, order, 2)
+        part = (nq * k * 12 + 7) // 8 * 8
+        buf = np.zeros(W * part, np.uint8)
+        for p in range(W):
+            buf[p * part:p * part + nq * k * 8] = si[p].reshape(-1).view(np.uint8)
+            buf[p * part + nq * k * 8:p * part + nq * k * 12] = sd[p].reshape(-1).view(np.uint8)
+        g = torch.from_numpy(buf).cuda()
+        oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        od = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        capi._check(capi.lib().msvs_merge_topk_device_strided(
+            C.c_void_p(g.data_ptr()), C.c_size_t(part // 8), C.c_void_p(g.data_ptr() + nq * k * 8),
+            C.c_size_t(part // 4), C.c_size_t(W), C.c_size_t(nq), C.c_size_t(k), metric,
+            C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
+        torch.cuda.synchronize()
+        ri, rd = capi.merge_topk(si, sd, metric)
+        same(oi.cpu().numpy(), od.cpu().numpy(), ri, rd)
