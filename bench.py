@@ -203,11 +203,27 @@ def main():
     # f32 VALU work of the same launch: 3 ops (sub, mul, add) per (query, row, element), vs the 78.6 T lane-op/s
     # non-packed VALU issue peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
     valu_frac = (rows_model * d * 3 / max(calls, 1)) / (scan_ms * 1e-3) / 78.6e12 if scan_ms > 0 else 0.0
+    # f32 compute roofline of the same launch: 3 flop (sub, mul, add; fma is forbidden by the parity contract) per
+    # (query, row, element) against the 157.3 TFLOP/s f32 peak (vector == f32-MFMA rate on gfx950)
+    F32_PEAK_TF = 157.3
+    flops_per_launch = rows_model * d * 3 / max(calls, 1)
+    compute_tf = flops_per_launch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     if world > 1:
-        # report the slowest rank's kernel (bytes are this rank's local lists)
-        t = torch.tensor([achieved], device=dev, dtype=torch.float64)
+        # report the slowest rank's kernel (bytes / flops are this rank's local lists)
+        t = torch.tensor([achieved, compute_tf], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        achieved = float(t.item())
+        achieved, compute_tf = float(t[0].item()), float(t[1].item())
+    hbm_frac, compute_frac = achieved / HBM_PEAK_GBS, compute_tf / F32_PEAK_TF
+    # the roofline that binds this launch is the resource driven closest to its peak: small batches are HBM-bound,
+    # at >= ~16 queries per list pass the f32 arithmetic takes over
+    if compute_frac > hbm_frac:
+        roof = {"bound": "mfma", "achieved": round(compute_tf, 2), "peak": F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(compute_frac, 4), "hbm_frac_union_bytes": round(hbm_frac, 4),
+                "hbm_union_gbs": round(achieved, 1)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(hbm_frac, 4), "f32_compute_frac": round(compute_frac, 4),
+                "f32_compute_tflops": round(compute_tf, 2)}
 
     # ---- single-query latency (batch 1, synchronous, through the same C-ABI)
     lat = []
@@ -277,21 +293,23 @@ def main():
             "recall_at_10": None if recall is None else round(recall, 4),
             "p50_ms_batch1": round(float(np.percentile(lat, 50)), 4) if lat else None,
             "p99_ms_batch1": round(float(np.percentile(lat, 99)), 4) if lat else None,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "ivf_batched_scan_kernel (T-query tiles per list pass)" if B * nprobe >= nlist
-                         else "ivf_scan_kernel", "launch_ms": round(scan_ms, 4),
-                         "bytes_per_launch": int(bytes_per_launch),
-                         "note": "achieved = union of the batch's probed rows x (4d+4) B / kernel time (each probed row "
-                                 "must leave HBM at least once per launch); traffic = FETCH_SIZE x2 + WRITE_SIZE from "
-                                 "rocprofv3 --pmc (profiles/); per_query_model_gbs = SURVEY 8d per-query bytes x "
-                                 "queries / time and streamed_model_gbs = bytes if every (list, query tile) pass "
-                                 "went to HBM -- both exceed HBM speed because a list pass is shared by a tile of "
-                                 "queries and tiles of one list share an XCD's L2",
-                         "per_query_model_gbs": round(model_gbs, 1), "streamed_model_gbs": round(streamed_gbs, 1),
-                         "valu_lane_op_frac": round(valu_frac, 4),
-                         "other_kernels_ms": {"coarse_flat_scan": round(c_ms / max(c_calls, 1), 4),
-                                              "merge(avg of 2)": round(m_ms / max(m_calls, 1), 4)}},
+            "roofline": dict(roof, **{
+                "traffic": traffic,
+                "kernel": "ivf_batched_scan_kernel (T-query tiles per list pass)" if B * nprobe >= nlist
+                else "ivf_scan_kernel", "launch_ms": round(scan_ms, 4),
+                "bytes_per_launch": int(bytes_per_launch), "flops_per_launch": int(flops_per_launch),
+                "note": "hbm: achieved = union of the batch's probed rows x (4d+4) B / kernel time (each probed row "
+                        "must leave HBM at least once per launch); mfma: 3 flop per (query,row,element) / kernel time "
+                        "vs the 157.3 TFLOP/s f32 peak (f32 VALU == f32 MFMA rate; fma/MFMA are excluded by the parity "
+                        "contract) -- the larger fraction is the binding roofline; traffic = FETCH_SIZE x2 + WRITE_SIZE "
+                        "per launch from rocprofv3 --pmc (profiles/); per_query_model_gbs = SURVEY 8d per-query bytes x "
+                        "queries / time and streamed_model_gbs = bytes if every (list, query tile) pass went to HBM: "
+                        "both exceed HBM speed because a list pass is shared by a tile of queries and the tiles of one "
+                        "list share an XCD's L2",
+                "per_query_model_gbs": round(model_gbs, 1), "streamed_model_gbs": round(streamed_gbs, 1),
+                "valu_lane_op_frac": round(valu_frac, 4),
+                "other_kernels_ms": {"coarse_flat_scan": round(c_ms / max(c_calls, 1), 4),
+                                     "merge(avg of 2)": round(m_ms / max(m_calls, 1), 4)}}),
             "cpu_baseline": cpu,
             "setup_s": round(setup_s, 1),
         }

@@ -283,7 +283,10 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
         // The row is consumed in chunks of JC float4 columns per lane: all JC 16-byte loads are issued first
         // (JC KiB in flight per wave), then the queries are walked OUTSIDE the columns, so only one query's
         // LDS operands are live at a time (keeps T = 8 near 128 VGPRs instead of 245).
-        constexpr int JC = 6;
+#ifndef MSVS_JC8
+#define MSVS_JC8 6
+#endif
+        constexpr int JC = T >= 8 ? MSVS_JC8 : 6;
         uint32_t j = 0;
         for (; j + JC <= jfull; j += JC)
         {
