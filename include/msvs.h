@@ -51,8 +51,11 @@ enum msvs_metric { MSVS_METRIC_L2 = 0, MSVS_METRIC_IP = 1, MSVS_METRIC_COSINE = 
 enum msvs_index_type { MSVS_INDEX_FLAT = 0, MSVS_INDEX_IVFFLAT = 1 };
 enum msvs_mem { MSVS_MEM_HOST = 0, MSVS_MEM_DEVICE = 1 };
 
-/* largest k (and nprobe) the device top-k supports */
+/* largest k (and nprobe) one device top-k pass supports (what msvs_index_search_device accepts) */
 #define MSVS_MAX_K 256
+/* largest k of the host-pointer entry points: beyond MSVS_MAX_K they run exact rounds of MSVS_MAX_K per query,
+ * each excluding the rows already returned (covers the reference's k + deleted-rows over-fetch and LIMIT 1000) */
+#define MSVS_MAX_K_ROUNDS 4096
 
 MSVS_API const char * msvs_last_error(void);
 MSVS_API const char * msvs_version(void);
@@ -70,6 +73,11 @@ MSVS_API int msvs_device_synchronize(void);
  */
 MSVS_API int msvs_knn_f32(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny, int metric,
                           int64_t * ids, float * dis);
+/* Same with a row filter (LSB-first bitmap over the ny base rows, 1 = candidate): lets the host's searchWrapper
+ * (src/VectorIndex/Storages/MergeTreeVSManager.cpp:1612-1633) drop lightweight-deleted rows inside the scan instead of
+ * over-fetching k + delete_id_num and filtering afterwards -- the two are equivalent (top-k of the alive rows). */
+MSVS_API int msvs_knn_f32_filtered(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny,
+                                   int metric, const uint64_t * alive_bits, int64_t * ids, float * dis);
 
 /* VectorDataset<FloatVector>::normalize() (src/VectorIndex/Common/VectorDataset.h:98-117) on the device:
  * sequential f32 sum of squares, rows with sum < FLT_EPSILON untouched, x /= sqrt(sum). In place, HOST pointer. */

@@ -27,6 +27,7 @@ SYMBOLS = [
     "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
     "msvs_postings_create", "msvs_postings_free", "msvs_bm25_search", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
+    "msvs_knn_f32_filtered",
 ]
 
 
@@ -113,16 +114,23 @@ def profile_get(name):
     return c.value, t.value
 
 
-def knn(x, y, k, metric):
-    """msvs_knn_f32 (seam A2).  x [nx,d], y [ny,d] host arrays -> (ids int64 [nx,k], dis f32 [nx,k])."""
+def knn(x, y, k, metric, alive=None):
+    """msvs_knn_f32 / msvs_knn_f32_filtered (seam A2).  x [nx,d], y [ny,d] host arrays, alive bool[ny] or None
+    -> (ids int64 [nx,k], dis f32 [nx,k])."""
     y = _f32(y)
     d = y.shape[1]
     x = _f32(x).reshape(-1, d)
     nx = x.shape[0]
     ids = np.empty((nx, k), np.int64)
     dis = np.empty((nx, k), np.float32)
-    _check(lib().msvs_knn_f32(_p(x, C.c_float), _p(y, C.c_float), C.c_size_t(d), C.c_size_t(k), C.c_size_t(nx),
-                              C.c_size_t(y.shape[0]), int(metric), _p(ids, C.c_int64), _p(dis, C.c_float)))
+    if alive is None:
+        _check(lib().msvs_knn_f32(_p(x, C.c_float), _p(y, C.c_float), C.c_size_t(d), C.c_size_t(k), C.c_size_t(nx),
+                                  C.c_size_t(y.shape[0]), int(metric), _p(ids, C.c_int64), _p(dis, C.c_float)))
+    else:
+        bits = pack_bits(alive)
+        _check(lib().msvs_knn_f32_filtered(_p(x, C.c_float), _p(y, C.c_float), C.c_size_t(d), C.c_size_t(k),
+                                           C.c_size_t(nx), C.c_size_t(y.shape[0]), int(metric), _p(bits, C.c_uint64),
+                                           _p(ids, C.c_int64), _p(dis, C.c_float)))
     return ids, dis
 
 

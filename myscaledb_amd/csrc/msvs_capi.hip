@@ -31,6 +31,17 @@ static void upload_rows(float * dst, const float * src, size_t n, uint32_t d, ui
 
 static inline uint32_t padded_dim(size_t d) { return (uint32_t)round_up(d, 4); }
 
+/// Clear the filter bits of the (non-negative) ids just returned, so the next round of a large-k search skips them.
+static __global__ void clear_bits_kernel(uint64_t * bits, const int64_t * ids, uint32_t n)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+    {
+        const int64_t id = ids[i];
+        if (id >= 0)
+            atomicAnd(reinterpret_cast<unsigned long long *>(bits + (id >> 6)), ~(1ull << (id & 63)));
+    }
+}
+
 static void check_k(size_t k)
 {
     if (k > MSVS_MAX_K)
@@ -99,38 +110,87 @@ extern "C" int msvs_device_synchronize(void)
 
 // =========================================================================================== seam A2
 
+namespace msvs
+{
+/// Shared body of msvs_knn_f32 / msvs_knn_f32_filtered: host buffers in, host buffers out.
+static void knn_host(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny, int metric,
+                     const uint64_t * alive_bits, int64_t * ids, float * dis)
+{
+    if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
+        fail(MSVS_ERR_NOT_IMPLEMENTED, "Metric not implemented in brute force search for Float32 Vector");
+    if (nx == 0 || k == 0)
+        return;
+    if (!x || !ids || !dis || (ny && !y) || d == 0)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer or zero dimension");
+    if (k > MSVS_MAX_K_ROUNDS)
+        fail(MSVS_ERR_UNSUPPORTED_K, "k = %zu exceeds the limit %d", k, MSVS_MAX_K_ROUNDS);
+    if (ny > 0xfffffff0ull)
+        fail(MSVS_ERR_ID_RANGE, "ny exceeds the u32 id range");
+    hipStream_t stream = nullptr;
+    const uint32_t ld = padded_dim(d);
+    const uint32_t kpass = (uint32_t)std::min<size_t>(k, MSVS_MAX_K);
+    const size_t bw = ceil_div(std::max<size_t>(ny, 1), 64);
+    const bool rounds = k > MSVS_MAX_K;
+    Scratch & scr = scratch_for(stream);
+    size_t need = (nx + ny) * (size_t)ld * 4 + nx * k * 12 + bw * 8
+        + flat_scratch_bytes(ny, rounds ? 1 : nx, kpass) + 16384;
+    scr.reserve(need, stream);
+    float * dq = scr.take<float>(nx * ld);
+    float * dy = scr.take<float>(std::max<size_t>(ny, 1) * ld);
+    int64_t * d_ids = scr.take<int64_t>(nx * k);
+    float * d_dis = scr.take<float>(nx * k);
+    uint64_t * bm = (alive_bits || rounds) ? scr.take<uint64_t>(bw) : nullptr;
+    const size_t mark = scr.used; // everything taken after this point is per-pass scratch
+    upload_rows(dq, x, nx, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
+    upload_rows(dy, y, ny, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
+    auto load_filter = [&]() {
+        if (alive_bits)
+            MSVS_HIP(hipMemcpyAsync(bm, alive_bits, bw * 8, hipMemcpyHostToDevice, stream));
+        else if (bm)
+            MSVS_HIP(hipMemsetAsync(bm, 0xFF, bw * 8, stream));
+    };
+    MergeParams out{};
+    if (!rounds)
+    {
+        load_filter();
+        out.out_ids = d_ids;
+        out.out_dis = d_dis;
+        flat_search_device(scr, metric, dy, nullptr, ny, ld, dq, nx, (uint32_t)k, bm, ny, out, stream);
+    }
+    else
+    {
+        // rounds of MSVS_MAX_K per query, excluding what was already returned (see msvs_index_search)
+        for (size_t q = 0; q < nx; q++)
+        {
+            load_filter();
+            for (size_t done = 0; done < k; done += MSVS_MAX_K)
+            {
+                const uint32_t kr = (uint32_t)std::min<size_t>(MSVS_MAX_K, k - done);
+                scr.used = mark;
+                out.out_ids = d_ids + q * k + done;
+                out.out_dis = d_dis + q * k + done;
+                flat_search_device(scr, metric, dy, nullptr, ny, ld, dq + q * ld, 1, kr, bm, ny, out, stream);
+                hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(256), 0, stream, bm, out.out_ids, kr);
+                MSVS_HIP(hipGetLastError());
+            }
+        }
+    }
+    MSVS_HIP(hipMemcpyAsync(ids, d_ids, nx * k * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    MSVS_HIP(hipMemcpyAsync(dis, d_dis, nx * k * sizeof(float), hipMemcpyDeviceToHost, stream));
+    MSVS_HIP(hipStreamSynchronize(stream));
+}
+}
+
 extern "C" int msvs_knn_f32(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny, int metric,
                             int64_t * ids, float * dis)
 {
-    return guarded([&] {
-        if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
-            fail(MSVS_ERR_NOT_IMPLEMENTED, "Metric not implemented in brute force search for Float32 Vector");
-        if (nx == 0 || k == 0)
-            return;
-        if (!x || !ids || !dis || (ny && !y) || d == 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer or zero dimension");
-        check_k(k);
-        if (ny > 0xfffffff0ull)
-            fail(MSVS_ERR_ID_RANGE, "ny exceeds the u32 id range");
-        hipStream_t stream = nullptr;
-        const uint32_t ld = padded_dim(d);
-        Scratch & scr = scratch_for(stream);
-        size_t need = (nx + ny) * (size_t)ld * 4 + nx * k * 12 + flat_scratch_bytes(ny, nx, (uint32_t)k) + 8192;
-        scr.reserve(need, stream);
-        float * dq = scr.take<float>(nx * ld);
-        float * dy = scr.take<float>(std::max<size_t>(ny, 1) * ld);
-        int64_t * d_ids = scr.take<int64_t>(nx * k);
-        float * d_dis = scr.take<float>(nx * k);
-        upload_rows(dq, x, nx, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
-        upload_rows(dy, y, ny, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
-        MergeParams out{};
-        out.out_ids = d_ids;
-        out.out_dis = d_dis;
-        flat_search_device(scr, metric, dy, nullptr, ny, ld, dq, nx, (uint32_t)k, nullptr, 0, out, stream);
-        MSVS_HIP(hipMemcpyAsync(ids, d_ids, nx * k * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipMemcpyAsync(dis, d_dis, nx * k * sizeof(float), hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipStreamSynchronize(stream));
-    });
+    return guarded([&] { knn_host(x, y, d, k, nx, ny, metric, nullptr, ids, dis); });
+}
+
+extern "C" int msvs_knn_f32_filtered(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny,
+                                     int metric, const uint64_t * alive_bits, int64_t * ids, float * dis)
+{
+    return guarded([&] { knn_host(x, y, d, k, nx, ny, metric, alive_bits, ids, dis); });
 }
 
 extern "C" int msvs_normalize_f32(float * x, size_t n, size_t d)
@@ -188,6 +248,7 @@ struct msvs_index
     std::vector<int64_t> h_list_off;
     size_t n = 0;
     size_t max_list_len = 0;
+    uint64_t max_id = 0; // largest stored row id (size of the id space the filter bitmaps range over)
     bool ready = false;
 };
 
@@ -458,8 +519,12 @@ extern "C" int msvs_index_build(msvs_index_t * ix)
         const size_t n = refs.size();
         ix->n = n;
         ix->h_list_off.assign(nlist + 1, 0);
+        ix->max_id = 0;
         for (const auto & r : refs)
+        {
             ix->h_list_off[r.list + 1]++;
+            ix->max_id = std::max<uint64_t>(ix->max_id, r.id);
+        }
         ix->max_list_len = 0;
         for (size_t l = 0; l < nlist; l++)
         {
@@ -735,7 +800,8 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
             fail(MSVS_ERR_NOT_READY, "index is not ready");
         if (nq == 0 || k == 0)
             return;
-        check_k((size_t)k);
+        if ((size_t)k > MSVS_MAX_K_ROUNDS)
+            fail(MSVS_ERR_UNSUPPORTED_K, "k = %d exceeds the limit %d", k, MSVS_MAX_K_ROUNDS);
         auto p = parse_params(params);
         for (const auto & kv : p)
             if (kv.first != "nprobe")
@@ -753,8 +819,36 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
         if (words)
             MSVS_HIP(hipMemcpyAsync(d_alive.p, alive_bits, words * 8, hipMemcpyHostToDevice, stream));
-        index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, words ? d_alive.p : nullptr, nbits, d_ids.p,
-                            d_dis.p, stream);
+        if ((size_t)k <= MSVS_MAX_K)
+            index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, words ? d_alive.p : nullptr, nbits,
+                                d_ids.p, d_dis.p, stream);
+        else
+        {
+            // k beyond one wavefront top-k pass: rounds of MSVS_MAX_K per query, each round excluding the rows already
+            // returned through a private copy of the filter bitmap (exact: round r returns ranks 256r .. 256r+255)
+            const size_t idspace = std::max<size_t>(words ? nbits : 0, (size_t)ix->max_id + 1);
+            const size_t bw = ceil_div(idspace, 64);
+            DevBuf<uint64_t> bm(bw);
+            for (size_t q = 0; q < nq; q++)
+            {
+                if (words)
+                {
+                    MSVS_HIP(hipMemsetAsync(bm.p, 0, bw * 8, stream));
+                    MSVS_HIP(hipMemcpyAsync(bm.p, d_alive.p, words * 8, hipMemcpyDeviceToDevice, stream));
+                }
+                else
+                    MSVS_HIP(hipMemsetAsync(bm.p, 0xFF, bw * 8, stream));
+                for (size_t done = 0; done < (size_t)k; done += MSVS_MAX_K)
+                {
+                    const uint32_t kr = (uint32_t)std::min<size_t>(MSVS_MAX_K, (size_t)k - done);
+                    int64_t * oi = d_ids.p + q * (size_t)k + done;
+                    index_search_device(*ix, dq.p + q * ix->dim, 1, kr, (size_t)nprobe, bm.p, words ? nbits : idspace,
+                                        oi, d_dis.p + q * (size_t)k + done, stream);
+                    hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(256), 0, stream, bm.p, oi, kr);
+                    MSVS_HIP(hipGetLastError());
+                }
+            }
+        }
         MSVS_HIP(hipMemcpyAsync(ids, d_ids.p, nq * (size_t)k * 8, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipMemcpyAsync(dis, d_dis.p, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipStreamSynchronize(stream));
@@ -963,6 +1057,9 @@ extern "C" int msvs_index_load(const char * path, msvs_index_t ** out)
         ix->max_list_len = 0;
         for (size_t l = 0; l < nlist; l++)
             ix->max_list_len = std::max<size_t>(ix->max_list_len, (size_t)(off[l + 1] - off[l]));
+        ix->max_id = 0;
+        for (size_t i = 0; i < n; i++)
+            ix->max_id = std::max<uint64_t>(ix->max_id, (uint64_t)ids[i]);
         ix->vecs.alloc(std::max<size_t>(n, 1) * ix->ld);
         ix->row_ids.alloc(std::max<size_t>(n, 1));
         ix->list_off.alloc(nlist + 1);

@@ -48,7 +48,31 @@ void MergeTreeVSManager::searchWrapper(bool prewhere, VectorIndex::VectorDataset
     std::vector<float> per_distance(slots, worst);
     std::vector<int64_t> per_id(slots, -1);
 
-    if (delete_id_num > 0)
+    if (delete_id_num > 0 && static_cast<size_t>(k) + delete_id_num > MSVS_MAX_K && row_exists.words)
+    {
+        // Many deleted rows in the block: instead of over-fetching k + delete_id_num results and dropping the dead
+        // ones afterwards, let the scan skip them (msvs_knn_f32_filtered) -- the same top-k of the alive rows,
+        // without a top-(k + thousands) selection.
+        VIMetric m = metric;
+        if (metric == VIMetric::Cosine)
+        {
+            m = VIMetric::IP;
+            query_vector.normalize();
+            base_data.normalize();
+        }
+        VectorIndex::throwIfError(msvs_knn_f32_filtered(
+            query_vector.data, base_data.data, static_cast<size_t>(base_data.dimension), static_cast<size_t>(k),
+            static_cast<size_t>(nq), static_cast<size_t>(base_data.total_vectors), static_cast<int>(m), row_exists.words,
+            per_id.data(), per_distance.data()));
+        for (size_t i = 0; i < slots; i++)
+        {
+            if (metric == VIMetric::Cosine)
+                per_distance[i] = 1 - per_distance[i];
+            if (per_id[i] < 0)
+                per_distance[i] = worst; // unfilled slots keep the wrapper's own sentinel, like the reference
+        }
+    }
+    else if (delete_id_num > 0)
     {
         // over-fetch by the number of lightweight-deleted rows of the block, then drop the deleted ones
         const size_t kk = static_cast<size_t>(k) + delete_id_num;

@@ -75,8 +75,40 @@ def test_knn_cosine_is_not_implemented_like_the_reference():
 def test_k_too_large_is_an_error_not_a_fallback():
     x = np.zeros((1, 4), np.float32)
     with pytest.raises(capi.MsvsError) as e:
-        capi.knn(x, np.zeros((1000, 4), np.float32), 257, capi.METRIC_L2)
+        capi.knn(x, np.zeros((1000, 4), np.float32), 4097, capi.METRIC_L2)
     assert e.value.code == capi.ERR_UNSUPPORTED_K
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP])
+def test_large_k_runs_exact_rounds(metric):
+    """k beyond one top-k pass (256): the reference's k + deleted-rows over-fetch and LIMIT 1000 style queries."""
+    rng = np.random.default_rng(51)
+    y = rng.standard_normal((3000, 24), dtype=np.float32)
+    y[500:560] = y[3]  # ties across a round boundary
+    x = np.concatenate([rng.standard_normal((2, 24), dtype=np.float32), y[3:4]])
+    for k in (257, 700, 3000):
+        ids, dis = capi.knn(x, y, k, metric)
+        oi, od = o.knn(x, y, k, OM[metric])
+        same(ids, dis, oi, od)
+    alive = rng.random(3000) < 0.4
+    ids, dis = capi.knn(x, y, 1500, metric, alive=alive)  # fewer alive rows than k: -1 padded tail
+    oi, od = o.knn(x, y, 1500, OM[metric], alive=alive)
+    same(ids, dis, oi, od)
+    ix = build_ivf(y, metric, 16)
+    i1, d1 = ix.search(x, 600, "nprobe=16", alive=alive)
+    oi, od, _ = oracle_on_exported(ix, x, 16, 600, metric, alive=alive)
+    same(i1, d1, oi, od)
+
+
+def test_filtered_knn_matches_oracle():
+    rng = np.random.default_rng(52)
+    y = rng.standard_normal((5000, 96), dtype=np.float32)
+    x = rng.standard_normal((9, 96), dtype=np.float32)
+    alive = rng.random(5000) < 0.25
+    for metric in (capi.METRIC_L2, capi.METRIC_IP):
+        ids, dis = capi.knn(x, y, 20, metric, alive=alive)
+        oi, od = o.knn(x, y, 20, OM[metric], alive=alive)
+        same(ids, dis, oi, od)
 
 
 def test_normalize_matches_reference_normalize():
