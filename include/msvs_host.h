@@ -31,6 +31,22 @@ MSVS_HOST_API int msvs_host_search_wrapper(int prewhere, float * query, float * 
                                            const uint64_t * actual_id_in_range, int metric,
                                            const uint64_t * row_exists, int delete_id_num);
 
+/* MergeTreeVSManager::vectorScanWithoutIndex<FloatVector> (MergeTreeVSManager.cpp:959-1535): brute-force scan of one
+ * data part, mark by mark, straight from the ColumnArray(Float32) layout (offsets[i] = end of row i in `data`).
+ * filter_bits / row_exists_bits: nullable LSB-first bitmaps over the part's rows.  Outputs are sized nq*k by the
+ * caller; *n_out = number of result rows (slots with id > -1); out_query_ids only written when is_batch != 0. */
+MSVS_HOST_API int msvs_host_vector_scan_without_index(const uint64_t * offsets, const float * data, size_t rows,
+                                                      size_t dim, size_t index_granularity, const float * queries,
+                                                      size_t nq, int k, int metric, int is_batch,
+                                                      const uint64_t * filter_bits, const uint64_t * row_exists_bits,
+                                                      uint32_t * out_labels, uint32_t * out_query_ids,
+                                                      float * out_distances, size_t * n_out);
+
+/* Join of mergeSearchResultImpl (MergeTreeBaseSearchManager.cpp:23-164): out_pos[r] = index of part_offsets[r] in
+ * labels, or -1 when the read row is not among the part's search results. */
+MSVS_HOST_API void msvs_host_merge_search_result(const uint64_t * part_offsets, size_t n_rows, const uint32_t * labels,
+                                                 size_t n_labels, int64_t * out_pos);
+
 /* MergeTreeBaseSearchManager::getTotalTopSearchResultImpl (MergeTreeBaseSearchManager.cpp:207-299): cross-part
  * top-k through a multimap keyed by score; returns the number of results. */
 MSVS_HOST_API size_t msvs_host_total_topk(const float * scores, const uint64_t * part_index, const uint64_t * labels,

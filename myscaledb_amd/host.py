@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsvs_host.so")
 
 SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_host_total_topk",
-           "msvs_host_hybrid_search", "msvs_host_merge_topk", "msvs_host_sum_bm25_stats"]
+           "msvs_host_hybrid_search", "msvs_host_merge_topk", "msvs_host_sum_bm25_stats",
+           "msvs_host_vector_scan_without_index", "msvs_host_merge_search_result"]
 
 _lib = None
 
@@ -68,6 +69,45 @@ def search_wrapper(query, base, k, metric, final_id, final_distance, num_rows_re
                                                _p(final_id, C.c_int64), _p(final_distance, C.c_float),
                                                _p(act, C.c_uint64), int(metric), _p(bits, C.c_uint64),
                                                int(delete_id_num)))
+
+
+def vector_scan_without_index(rows, dim, index_granularity, queries, k, metric, is_batch=False, filt=None,
+                              row_exists=None):
+    """MergeTreeVSManager::vectorScanWithoutIndex over one part given as a list of per-row vectors (an empty list /
+    None = a row without a vector), converted to the ColumnArray layout (offsets + flat data).
+    -> (labels uint32[n], query_ids uint32[n] or None, distances f32[n])"""
+    offsets = np.zeros(len(rows), np.uint64)
+    flat = []
+    end = 0
+    for i, r in enumerate(rows):
+        if r is not None and len(r):
+            flat.extend(r)
+            end += len(r)
+        offsets[i] = end
+    data = np.asarray(flat, np.float64).astype(np.float32) if flat else np.zeros(1, np.float32)
+    q = _f32(queries).reshape(-1, dim)
+    nq = q.shape[0]
+    fb = None if filt is None else capi.pack_bits(filt)
+    eb = None if row_exists is None else capi.pack_bits(row_exists)
+    labels = np.empty(nq * k, np.uint32)
+    qids = np.empty(nq * k, np.uint32)
+    dist = np.empty(nq * k, np.float32)
+    n = C.c_size_t(0)
+    capi._check(lib().msvs_host_vector_scan_without_index(
+        _p(offsets, C.c_uint64), _p(data, C.c_float), C.c_size_t(len(rows)), C.c_size_t(dim),
+        C.c_size_t(index_granularity), _p(q, C.c_float), C.c_size_t(nq), int(k), int(metric), int(is_batch),
+        _p(fb, C.c_uint64), _p(eb, C.c_uint64), _p(labels, C.c_uint32), _p(qids, C.c_uint32), _p(dist, C.c_float),
+        C.byref(n)))
+    return labels[:n.value], (qids[:n.value] if is_batch else None), dist[:n.value]
+
+
+def merge_search_result(part_offsets, labels):
+    po = _u64(part_offsets)
+    lb = np.ascontiguousarray(labels, np.uint32)
+    out = np.empty(po.size, np.int64)
+    lib().msvs_host_merge_search_result(_p(po, C.c_uint64), C.c_size_t(po.size), _p(lb, C.c_uint32),
+                                        C.c_size_t(lb.size), _p(out, C.c_int64))
+    return out
 
 
 def total_topk(scores, parts, labels, top_k, desc):

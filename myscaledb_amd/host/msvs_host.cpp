@@ -136,6 +136,131 @@ void MergeTreeVSManager::searchWrapper(bool prewhere, VectorIndex::VectorDataset
     final_id.swap(merged_id);
 }
 
+std::vector<float> MergeTreeVSManager::generateVectorDataset(const void * values, bool is_float64,
+                                                             const uint64_t * offsets, size_t nq, size_t dim)
+{
+    std::vector<float> out(nq * dim);
+    uint64_t begin = 0;
+    for (size_t q = 0; q < nq; q++)
+    {
+        const uint64_t end = offsets ? offsets[q] : (q + 1) * dim;
+        if (end - begin != dim)
+            throw VectorIndex::VIException(MSVS_ERR_INVALID_ARGUMENT,
+                                           "Dimension is not equal: query: " + std::to_string(end - begin) + " vs search column: "
+                                               + std::to_string(dim));
+        for (size_t j = 0; j < dim; j++)
+            out[q * dim + j] = is_float64 ? static_cast<float>(static_cast<const double *>(values)[begin + j])
+                                          : static_cast<const float *>(values)[begin + j];
+        begin = end;
+    }
+    return out;
+}
+
+VectorScanResult MergeTreeVSManager::vectorScanWithoutIndex(const ColumnArrayView & column, size_t dim,
+                                                            size_t index_granularity, const std::vector<float> & queries,
+                                                            size_t nq, int k, const VIMetric & metric, bool is_batch,
+                                                            const VIBitmapView * filter, const VIBitmapView * row_exists)
+{
+    const float worst = metric == VIMetric::IP ? std::numeric_limits<float>::min() : std::numeric_limits<float>::max();
+    std::vector<float> final_distance(static_cast<size_t>(k) * nq, worst);
+    std::vector<int64_t> final_id(static_cast<size_t>(k) * nq, -1);
+    std::vector<float> query_copy;   // searchWithoutIndex normalises its inputs in place (cosine)
+    std::vector<float> block;
+    std::vector<size_t> actual_id_in_range;
+    const size_t total_rows = column.rows;
+
+    auto row_begin = [&](size_t r) { return r == 0 ? 0 : column.offsets[r - 1]; };
+
+    for (size_t mark_start = 0; mark_start < total_rows; mark_start += index_granularity)
+    {
+        const size_t mark_end = std::min(total_rows, mark_start + index_granularity);
+        block.clear();
+        actual_id_in_range.clear();
+        std::vector<uint64_t> exists_words;
+        int deleted_row_num = 0;
+        size_t block_rows = 0;
+        if (filter)
+        {
+            // only rows that pass the filter AND carry a vector are searched; their part offsets are remembered
+            for (size_t r = mark_start; r < mark_end; r++)
+            {
+                if (!filter->is_member(r))
+                    continue;
+                const uint64_t b = row_begin(r), e = column.offsets[r];
+                if (b == e)
+                    continue;
+                block.insert(block.end(), column.data + b, column.data + e);
+                actual_id_in_range.push_back(r);
+                block_rows++;
+            }
+        }
+        else
+        {
+            // dense block: a row without a vector is padded with FLT_MAX (its distance overflows and never wins)
+            block.assign((mark_end - mark_start) * dim, std::numeric_limits<float>::max());
+            block_rows = mark_end - mark_start;
+            exists_words.assign((block_rows + 63) / 64, ~0ull);
+            for (size_t r = mark_start; r < mark_end; r++)
+            {
+                const uint64_t b = row_begin(r), e = column.offsets[r];
+                if (e - b == dim)
+                    std::copy(column.data + b, column.data + e, block.begin() + (r - mark_start) * dim);
+                if (row_exists && !row_exists->is_member(r))
+                {
+                    exists_words[(r - mark_start) >> 6] &= ~(1ull << ((r - mark_start) & 63));
+                    deleted_row_num++;
+                }
+            }
+        }
+        query_copy = queries;
+        VectorIndex::VectorDataset q{query_copy.data(), static_cast<int64_t>(nq), static_cast<int64_t>(dim)};
+        VectorIndex::VectorDataset base{block.data(), static_cast<int64_t>(block_rows), static_cast<int64_t>(dim)};
+        VIBitmapView exists_view{exists_words.empty() ? nullptr : exists_words.data()};
+        searchWrapper(filter != nullptr, q, base, k, static_cast<int>(dim), static_cast<int>(nq),
+                      filter ? 0 : static_cast<int>(mark_start), final_id, final_distance, actual_id_in_range, metric,
+                      exists_view, deleted_row_num);
+    }
+
+    // result columns: only filled slots (id > -1); batch_distance adds the query id = slot / k
+    VectorScanResult res;
+    for (size_t slot = 0; slot < static_cast<size_t>(k) * nq; slot++)
+    {
+        if (final_id[slot] <= -1)
+            continue;
+        res.labels.push_back(static_cast<uint32_t>(final_id[slot]));
+        if (is_batch)
+            res.query_ids.push_back(static_cast<uint32_t>(slot / static_cast<size_t>(k)));
+        res.distances.push_back(final_distance[slot]);
+    }
+    res.computed = true;
+    return res;
+}
+
+std::vector<int64_t> mergeSearchResult(const std::vector<uint64_t> & part_offsets, const std::vector<uint32_t> & labels)
+{
+    // labels sorted together with their original positions, then one binary search per read row
+    std::vector<std::pair<uint32_t, int64_t>> sorted(labels.size());
+    for (size_t i = 0; i < labels.size(); i++)
+        sorted[i] = {labels[i], static_cast<int64_t>(i)};
+    std::sort(sorted.begin(), sorted.end());
+    std::vector<int64_t> pos(part_offsets.size(), -1);
+    for (size_t r = 0; r < part_offsets.size(); r++)
+    {
+        auto it = std::lower_bound(sorted.begin(), sorted.end(), std::make_pair(static_cast<uint32_t>(part_offsets[r]), int64_t(-1)));
+        if (it != sorted.end() && it->first == part_offsets[r])
+            pos[r] = it->second;
+    }
+    return pos;
+}
+
+std::vector<uint64_t> intersectDenseBitmaps(const std::vector<uint64_t> & a, const std::vector<uint64_t> & b)
+{
+    std::vector<uint64_t> out(std::min(a.size(), b.size()));
+    for (size_t i = 0; i < out.size(); i++)
+        out[i] = a[i] & b[i];
+    return out;
+}
+
 ScoreWithPartIndexAndLabels MergeTreeBaseSearchManager::getTotalTopSearchResultImpl(
     const ScoreWithPartIndexAndLabels & all, uint64_t top_k, bool desc_direction)
 {
@@ -311,6 +436,38 @@ extern "C" int msvs_host_search_wrapper(int prewhere, float * query, float * bas
         std::memcpy(final_id, fid.data(), fid.size() * sizeof(int64_t));
         std::memcpy(final_distance, fdist.data(), fdist.size() * sizeof(float));
     });
+}
+
+extern "C" int msvs_host_vector_scan_without_index(const uint64_t * offsets, const float * data, size_t rows, size_t dim,
+                                                   size_t index_granularity, const float * queries, size_t nq, int k,
+                                                   int metric, int is_batch, const uint64_t * filter_bits,
+                                                   const uint64_t * row_exists_bits, uint32_t * out_labels,
+                                                   uint32_t * out_query_ids, float * out_distances, size_t * n_out)
+{
+    return guarded([&] {
+        DB::ColumnArrayView col{offsets, data, rows};
+        std::vector<float> q(queries, queries + nq * dim);
+        DB::VIBitmapView f{filter_bits}, e{row_exists_bits};
+        auto res = DB::MergeTreeVSManager::vectorScanWithoutIndex(col, dim, index_granularity, q, nq, k,
+                                                                  static_cast<VectorIndex::VIMetric>(metric), is_batch != 0,
+                                                                  filter_bits ? &f : nullptr, row_exists_bits ? &e : nullptr);
+        for (size_t i = 0; i < res.labels.size(); i++)
+        {
+            out_labels[i] = res.labels[i];
+            out_distances[i] = res.distances[i];
+            if (is_batch)
+                out_query_ids[i] = res.query_ids[i];
+        }
+        *n_out = res.labels.size();
+    });
+}
+
+extern "C" void msvs_host_merge_search_result(const uint64_t * part_offsets, size_t n_rows, const uint32_t * labels,
+                                              size_t n_labels, int64_t * out_pos)
+{
+    auto pos = DB::mergeSearchResult(std::vector<uint64_t>(part_offsets, part_offsets + n_rows),
+                                     std::vector<uint32_t>(labels, labels + n_labels));
+    std::copy(pos.begin(), pos.end(), out_pos);
 }
 
 extern "C" size_t msvs_host_total_topk(const float * scores, const uint64_t * part_index, const uint64_t * labels,

@@ -81,6 +81,25 @@ struct VIBitmapView
     bool is_member(size_t i) const { return !words || ((words[i >> 6] >> (i & 63)) & 1); }
 };
 
+/// ColumnArray(Float32) of one data part as the MergeTree reader hands it over: offsets[i] = end of row i in `data`
+/// (ClickHouse ColumnArray layout; an empty Array has offsets[i] == offsets[i-1]).
+struct ColumnArrayView
+{
+    const uint64_t * offsets = nullptr;
+    const float * data = nullptr;
+    size_t rows = 0;
+};
+
+/// (label, [query id,] distance) result columns of one part: CommonSearchResult::result_columns
+/// (ColumnUInt32 label, ColumnUInt32 vector_id for batch_distance, ColumnFloat32 distance).
+struct VectorScanResult
+{
+    std::vector<uint32_t> labels;
+    std::vector<uint32_t> query_ids; // only for batch_distance
+    std::vector<float> distances;
+    bool computed = false;
+};
+
 struct MergeTreeVSManager
 {
     static void searchWrapper(bool prewhere, VectorIndex::VectorDataset & query_vector,
@@ -88,7 +107,28 @@ struct MergeTreeVSManager
                               std::vector<int64_t> & final_id, std::vector<float> & final_distance,
                               const std::vector<size_t> & actual_id_in_range, const VIMetric & metric,
                               const VIBitmapView & row_exists, int delete_id_num);
+
+    /// getQueryVector / getFloatQueryVectorInBatch (MergeTreeVSManager.cpp:59-181): Array(Float32|Float64) query
+    /// constants -> row-major f32; a row whose length differs from `dim` is an error like in the reference.
+    static std::vector<float> generateVectorDataset(const void * values, bool is_float64, const uint64_t * offsets,
+                                                    size_t nq, size_t dim);
+
+    /// vectorScanWithoutIndex<FloatVector> (MergeTreeVSManager.cpp:959-1535): brute force over one part, mark by
+    /// mark.  filter == nullptr: dense blocks (empty rows padded with FLT_MAX), lightweight-deleted rows handled by
+    /// row_exists; filter != nullptr: only the passing, non-empty rows of each mark are compacted and searched
+    /// (the filter already includes the lightweight deletes).  Returns the part's result columns.
+    static VectorScanResult vectorScanWithoutIndex(const ColumnArrayView & column, size_t dim, size_t index_granularity,
+                                                   const std::vector<float> & queries, size_t nq, int k,
+                                                   const VIMetric & metric, bool is_batch, const VIBitmapView * filter,
+                                                   const VIBitmapView * row_exists);
 };
+
+/// MergeTreeBaseSearchManager::mergeSearchResultImpl (MergeTreeBaseSearchManager.cpp:23-164), reduced to its join:
+/// for every read row (identified by its _part_offset) the position of its label in the part's result, or -1.
+std::vector<int64_t> mergeSearchResult(const std::vector<uint64_t> & part_offsets, const std::vector<uint32_t> & labels);
+
+/// Search::intersectDenseBitmaps as used in VIWithDataPart.cpp:903-908: filter AND delete bitmap (word-wise).
+std::vector<uint64_t> intersectDenseBitmaps(const std::vector<uint64_t> & a, const std::vector<uint64_t> & b);
 
 struct ScoreWithPartIndexAndLabel
 {

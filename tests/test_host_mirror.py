@@ -66,6 +66,48 @@ def test_fusion_goldens_through_host_mirror():
         assert np.array(sc, np.float32).tolist() == f32_of(c[kind][1]).tolist()
 
 
+def test_merge_search_result_join():
+    labels = np.array([40, 7, 19, 3], np.uint32)           # the part's search result, best first
+    part_offsets = np.array([2, 3, 4, 19, 40, 41], np.uint64)  # rows the reader materialised
+    assert host.merge_search_result(part_offsets, labels).tolist() == [-1, 3, -1, 2, 0, -1]
+
+
+def _rows(vecs, empty):
+    return [None if e else v.tolist() for v, e in zip(vecs, empty)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["00012_brute_force", "00009_brute_force_filter", "00010_brute_force_filter",
+                                  "00011_brute_force_filter", "00014_cosine_bruteforce"])
+def test_brute_force_goldens_through_vector_scan_without_index(name):
+    """The C++ per-mark loop (ColumnArray in, result columns out) against the reference's .reference files."""
+    c = G[name]
+    ids, vecs, empty = materialize(c["base"])
+    filt = eval_filter(c["filter"], ids) if c.get("filter") else None
+    labels, _, dist = host.vector_scan_without_index(_rows(vecs, empty), vecs.shape[1], c.get("index_granularity", 8192),
+                                                     c["queries"], c["k"], capi.METRICS[c["metric"]], filt=filt)
+    assert ids[labels].tolist() == c["ids"][0]
+    assert dist.tolist() == f32_of(c["dists"][0]).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["00002_batch_l2", "00002_batch_ip"])
+def test_batch_distance_golden_through_vector_scan_without_index(name):
+    c = G[name]
+    k, nq = c["k"], len(c["queries"])
+    per_query = [[] for _ in range(nq)]
+    for segs in c["parts"]:
+        ids, vecs, empty = materialize(segs)
+        labels, qids, dist = host.vector_scan_without_index(_rows(vecs, empty), 3, 8192, c["queries"], k,
+                                                            capi.METRICS[c["metric"]], is_batch=True)
+        for l, q, d in zip(labels, qids, dist):
+            per_query[int(q)].append((float(d), int(ids[l])))
+    for qi in range(nq):  # ORDER BY dist.1, dist.2 [DESC] LIMIT 10 BY dist.1
+        rows = sorted(per_query[qi], key=lambda t: -t[0] if c["metric"] == "IP" else t[0])[:k]
+        assert [r[1] for r in rows] == c["ids"][qi]
+        assert [np.float32(r[0]) for r in rows] == f32_of(c["dists"][qi]).tolist()
+
+
 def test_sum_bm25_stats():
     per_part = np.array([[10, 73, 1, 0], [10, 70, 1, 2]], np.uint64)
     assert host.sum_bm25_stats(per_part).tolist() == [20, 143, 2, 2]

@@ -1,5 +1,6 @@
+"""Tuning sweep of the IVF scan decomposition (MSVS_IVF_T / _RPB / _GRID / _XCD knobs), e.g.\n    python tools/ivf_sweep.py B=256 B=256,T=8,RPB=1024 B=1024\nResults of round 1: profiles/r01_ivf_tuning_sweep.txt."""
 import sys, os, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import myscaledb_amd.capi as capi
 from bench import make_data, make_queries
 dev = torch.device('cuda', 0)

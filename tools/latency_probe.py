@@ -1,3 +1,4 @@
+"""Single-query (batch 1) latency of msvs_index_search_device and its per-kernel split (HIP events)."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import myscaledb_amd.capi as capi
