@@ -148,6 +148,11 @@ MSVS_API int msvs_index_scanned_rows(const msvs_index_t * index, const float * q
 MSVS_API int msvs_profile_enable(int on);
 MSVS_API int msvs_profile_get(const char * name, uint64_t * calls, double * total_ms);
 MSVS_API int msvs_profile_reset(void);
+/* Counters of the matrix-core candidate pass of batched IVFFLAT searches (many queries per list): `queries` that
+ * went through it on the current device since process start and how many of them had no exactness certificate and
+ * were re-run through the canonical scan (`fallbacks`).  Results are identical either way; this is a speed metric.
+ * Synchronises the device. */
+MSVS_API int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks);
 
 /* Multi-part / multi-GPU merge of partial top-k lists with the canonical total order -- the
  * device-side analogue of MergeTreeBaseSearchManager::getTotalTopSearchResultImpl

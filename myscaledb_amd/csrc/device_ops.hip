@@ -322,6 +322,107 @@ void launch_ivf_merge(int metric, IvfMergeParams a, uint32_t nq, hipStream_t str
     MSVS_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------ matrix-core pass
+
+void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uint32_t * max_bits, hipStream_t stream)
+{
+    if (n == 0)
+        return;
+    hipLaunchKernelGGL(row_sqnorm16_kernel, dim3((unsigned)ceil_div(n, 16)), dim3(BLOCK), 0, stream,
+                       reinterpret_cast<const float4 *>(X), out, n, ld4, max_bits);
+    MSVS_HIP(hipGetLastError());
+}
+
+void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t stream)
+{
+    if (grid == 0)
+        return;
+    if (a.k > 64)
+        fail(MSVS_ERR_DEVICE, "internal: candidate count %u > 64", a.k);
+    ProfileScope prof("ivf_scan", stream);
+    if (metric == M_IP)
+        hipLaunchKernelGGL((ivf_mfma_scan_kernel<M_IP>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else
+        hipLaunchKernelGGL((ivf_mfma_scan_kernel<M_L2>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    MSVS_HIP(hipGetLastError());
+}
+
+void launch_ivf_rerank(int metric, RerankParams a, uint32_t nq, hipStream_t stream)
+{
+    if (nq == 0)
+        return;
+    const size_t lds = (size_t)a.ld4 * 16 + 64 * 8;
+    if (lds > 64 * 1024)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large for the re-rank block", a.ld4 * 4);
+    ProfileScope prof("rerank", stream);
+    if (metric == M_IP)
+        hipLaunchKernelGGL((ivf_rerank_kernel<M_IP>), dim3(nq), dim3(BLOCK), lds, stream, a);
+    else
+        hipLaunchKernelGGL((ivf_rerank_kernel<M_L2>), dim3(nq), dim3(BLOCK), lds, stream, a);
+    MSVS_HIP(hipGetLastError());
+}
+
+template <int METRIC>
+static void ivf_subset_dispatch(const ScanParams & a, uint32_t z, hipStream_t stream)
+{
+    dim3 grid(a.seg_max, a.nprobe, z);
+    size_t lds = scan_lds_bytes(1, a.ld4, a.k);
+    switch (r_for_k(a.k))
+    {
+        case 1:
+            hipLaunchKernelGGL((ivf_scan_subset_kernel<METRIC, 1>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+        case 2:
+            hipLaunchKernelGGL((ivf_scan_subset_kernel<METRIC, 2>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((ivf_scan_subset_kernel<METRIC, 4>), grid, dim3(BLOCK), lds, stream, a);
+            break;
+    }
+}
+
+void launch_ivf_scan_subset(int metric, ScanParams a, uint32_t z, hipStream_t stream)
+{
+    if (z == 0 || a.nprobe == 0 || a.seg_max == 0)
+        return;
+    ProfileScope prof("fallback_scan", stream);
+    if (metric == M_IP)
+        ivf_subset_dispatch<M_IP>(a, z, stream);
+    else
+        ivf_subset_dispatch<M_L2>(a, z, stream);
+    MSVS_HIP(hipGetLastError());
+}
+
+template <int METRIC>
+static void ivf_merge_subset_dispatch(const IvfMergeParams & a, uint32_t blocks, hipStream_t stream)
+{
+    size_t lds = merge_lds_bytes(a.k, a.nprobe);
+    switch (r_for_k(a.k))
+    {
+        case 1:
+            hipLaunchKernelGGL((ivf_merge_subset_kernel<METRIC, 1>), dim3(blocks), dim3(BLOCK), lds, stream, a);
+            break;
+        case 2:
+            hipLaunchKernelGGL((ivf_merge_subset_kernel<METRIC, 2>), dim3(blocks), dim3(BLOCK), lds, stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((ivf_merge_subset_kernel<METRIC, 4>), dim3(blocks), dim3(BLOCK), lds, stream, a);
+            break;
+    }
+}
+
+void launch_ivf_merge_subset(int metric, IvfMergeParams a, uint32_t blocks, hipStream_t stream)
+{
+    if (blocks == 0)
+        return;
+    ProfileScope prof("fallback_merge", stream);
+    if (metric == M_IP)
+        ivf_merge_subset_dispatch<M_IP>(a, blocks, stream);
+    else
+        ivf_merge_subset_dispatch<M_L2>(a, blocks, stream);
+    MSVS_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ params
 
 std::map<std::string, std::string> parse_params(const char * s)

@@ -3,6 +3,7 @@
 
 #include "common.hpp"
 #include "scan_kernels.hpp"
+#include "mfma_scan_kernels.hpp"
 
 namespace msvs
 {
@@ -72,5 +73,20 @@ void launch_ivf_batched_scan(int metric, uint32_t T, uint32_t grid, ScanParams a
 
 /// Per-query top-k over the valid segments of its probed lists.
 void launch_ivf_merge(int metric, IvfMergeParams a, uint32_t nq, hipStream_t stream);
+
+// ---- matrix-core candidate pass (mfma_scan_kernels.hpp)
+
+/// out[r] = |X[r]|^2 for n rows of ld4 float4; max_bits: nullable running maximum of the float bit patterns.
+void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uint32_t * max_bits, hipStream_t stream);
+
+/// Approximate (MFMA) scan over the plan's work items (plan built with T = MF_TQ); a.k = candidates kept (<= 64).
+void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t stream);
+
+/// Canonical re-rank of the candidates + certificate; failing queries are appended to a.failq.
+void launch_ivf_rerank(int metric, RerankParams a, uint32_t nq, hipStream_t stream);
+
+/// Canonical scan / merge of the queries listed in (a.qmap, *a.qcount) with `z` block slots per (segment, probe).
+void launch_ivf_scan_subset(int metric, ScanParams a, uint32_t z, hipStream_t stream);
+void launch_ivf_merge_subset(int metric, IvfMergeParams a, uint32_t blocks, hipStream_t stream);
 
 }

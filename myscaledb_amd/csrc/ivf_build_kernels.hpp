@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void assign_kernel(const float * __restrict__ 
         float v0 = red_v[0][tid], v1 = red_v[1][tid];
         int i0 = red_i[0][tid], i1 = red_i[1][tid];
         bool take1 = v1 < v0 || (v1 == v0 && i1 < i0);
-        assign[row0 + tid] = take1 ? i1 : i0;
+        const int best = take1 ? i1 : i0;
+        assign[row0 + tid] = best == 0x7fffffff ? 0 : best; // rows with NaN / overflowing scores go to list 0
         if (best_score)
             best_score[row0 + tid] = take1 ? v1 : v0;
     }

@@ -1,0 +1,441 @@
+// mfma_scan_kernels.hpp -- matrix-core candidate pass of the list-batched IVF scan + exact re-rank.
+//
+// When many queries of a batch probe the same list (>= 16 on average) the canonical scan of scan_kernels.hpp is
+// VALU-bound: the parity contract forbids fma, so every (query, row, element) costs three separately rounded VALU
+// ops.  The query-tile x row-tile inner products are a GEMM, so this path runs them on the FP32 matrix cores
+// (v_mfma_f32_32x32x2_f32) as a PRE-FILTER and keeps the returned numbers canonical:
+//
+//   1. ivf_mfma_scan_kernel : approximate distance a(q,x) = |x|^2 - 2<q,x> + |q|^2 (L2) or <q,x> (IP) for every
+//      (query, probed row); per (query, list segment) the KC best rows by a() are kept (KC = 32 or 64 >= k).
+//   2. ivf_merge_kernel     : per query, the KC best candidates over all its segments (keys carry row POSITIONS).
+//   3. ivf_rerank_kernel    : canonical (bit-exact, scan_kernels.hpp arithmetic) distance of the KC candidates, exact
+//      top-k among them, and a CERTIFICATE: every row that is not a candidate has a() >= a_KC (the worst kept
+//      candidate), and |a - canonical| <= eps for a rigorous rounding-error bound eps, so if a_KC - eps > e_k (the
+//      exact k-th distance found) no excluded row can enter the top-k and the result equals the exhaustive one.
+//   4. queries whose certificate fails (near-ties wider than KC, huge norms, NaN) are re-run through the canonical
+//      one-query-per-block scan (ivf_scan_subset_kernel / ivf_merge_subset_kernel), stream-ordered, no host sync.
+//
+// The result is therefore ALWAYS identical to the canonical scan; eps only decides how often step 4 has work.
+// Error bound (u = 2^-24): the MFMA dot product of d terms, whatever its internal order and rounding mode, is within
+// 2d * 2^-23 * |x||q| of the true one; the f32 norms within d*u; the canonical sum of d separately rounded terms in
+// depth <= 18 within 21u of the true distance; so |a - canonical| <= c * (|x| + |q|)^2 (L2), c * |x||q| (IP) with
+// c = 1.05 * (2d * 2^-23 + 64u), and |x| <= sqrt(max row norm) of the index.
+#pragma once
+
+#include "scan_kernels.hpp"
+
+namespace msvs
+{
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MF_ROWS = 128; // rows per sub-tile: 32 per wavefront
+constexpr int MF_TQ = 32;    // queries per tile (the N of the 32x32 MFMA)
+constexpr int MF_KC = 32;    // floats of the reduction dimension staged per step
+constexpr int MF_LDX = MF_KC + 4;   // LDS row stride of the staged operands (floats): 16-lane b128 reads conflict-free
+constexpr int MF_LDS = MF_ROWS + 4; // LDS row stride of the per-query distance tile
+
+/// out[r] = |X[r]|^2 (fma, 16 lanes per row; NOT the canonical order: only feeds the approximate pass and its error
+/// bound).  max_bits (nullable): running maximum of the float bit patterns (norms are >= 0; NaN compares largest).
+static __global__ __launch_bounds__(BLOCK) void row_sqnorm16_kernel(const float4 * X, float * out, size_t n,
+                                                                     uint32_t ld4, uint32_t * max_bits)
+{
+    const size_t r = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const uint32_t g = threadIdx.x & 15;
+    float s = 0.f;
+    if (r < n)
+        for (uint32_t c = g; c < ld4; c += 16)
+        {
+            const float4 v = X[r * ld4 + c];
+            s = fmaf(v.x, v.x, s);
+            s = fmaf(v.y, v.y, s);
+            s = fmaf(v.z, v.z, s);
+            s = fmaf(v.w, v.w, s);
+        }
+    s = row16_tree_sum(s);
+    if (r < n && g == 0)
+    {
+        out[r] = s;
+        if (max_bits)
+            atomicMax(max_bits, __float_as_uint(s));
+    }
+}
+
+/// One (query, float4 column) update of the canonical accumulators (same arithmetic as scan_rows).
+template <int METRIC>
+__device__ __forceinline__ void canonical_update(float4 & s, const float4 q, const float4 y)
+{
+    if (METRIC == M_L2)
+    {
+        float dx = __fsub_rn(q.x, y.x), dy = __fsub_rn(q.y, y.y), dz = __fsub_rn(q.z, y.z), dw = __fsub_rn(q.w, y.w);
+        s.x = __fadd_rn(s.x, __fmul_rn(dx, dx));
+        s.y = __fadd_rn(s.y, __fmul_rn(dy, dy));
+        s.z = __fadd_rn(s.z, __fmul_rn(dz, dz));
+        s.w = __fadd_rn(s.w, __fmul_rn(dw, dw));
+    }
+    else
+    {
+        s.x = __fadd_rn(s.x, __fmul_rn(q.x, y.x));
+        s.y = __fadd_rn(s.y, __fmul_rn(q.y, y.y));
+        s.z = __fadd_rn(s.z, __fmul_rn(q.z, y.z));
+        s.w = __fadd_rn(s.w, __fmul_rn(q.w, y.w));
+    }
+}
+
+/// Work item = (list, tile of <= 32 probing queries, row segment), walked by a fixed grid exactly like
+/// ivf_batched_scan_kernel (plan built with T = 32).  a.k = KC (<= 64); a.partial[(pair*seg_max + seg)*KC ...] receives
+/// the KC best (approximate key, row position) of the segment for each query of the tile.
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) void ivf_mfma_scan_kernel(const ScanParams a)
+{
+    __shared__ __attribute__((aligned(16))) float Xs[2][MF_ROWS * MF_LDX];
+    __shared__ __attribute__((aligned(16))) float Qs[2][MF_TQ * MF_LDX];
+    __shared__ float xn_s[MF_ROWS];
+    __shared__ float qn_s[MF_TQ];
+    __shared__ uint32_t qrow_s[MF_TQ];
+    __shared__ uint32_t qpair_s[MF_TQ];
+    float * const Ss = &Xs[0][0]; // the per-query distance tile reuses the operand stage between two reductions
+    static_assert(MF_TQ * MF_LDS <= 2 * MF_ROWS * MF_LDX, "distance tile must fit the operand stage");
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const uint32_t ld4 = a.ld4, kc = a.k;
+    const uint32_t nk = (ld4 + 7) / 8;          // reduction steps of 32 floats
+    const uint32_t lc = tid & 7, lr = tid >> 3; // loader role: float4 column lc of rows lr, lr+32, lr+64, lr+96
+    const uint32_t total = a.work_off[a.nlist];
+    const uint32_t per_xcd = (total + 7) / 8;
+    for (uint32_t s = blockIdx.x; s < 8 * per_xcd; s += gridDim.x)
+    {
+        const uint32_t w = a.xcd_order ? (s & 7) * per_xcd + (s >> 3) : s;
+        if (w >= total || (a.xcd_order && (s >> 3) >= per_xcd))
+            continue;
+        uint32_t lo = 0, hi = a.nlist;
+        while (hi - lo > 1)
+        {
+            uint32_t mid = (lo + hi) >> 1;
+            if (a.work_off[mid] <= w)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t l = lo;
+        const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
+        const uint32_t local = w - a.work_off[l];
+        const uint32_t pe = a.pair_off[l + 1];
+        const uint32_t ntile = (pe - a.pair_off[l] + MF_TQ - 1) / MF_TQ;
+        const uint32_t seg = local / ntile, tile = local - seg * ntile;
+        const uint32_t pb = a.pair_off[l] + tile * MF_TQ;
+        const uint32_t nvalid = pe - pb < (uint32_t)MF_TQ ? pe - pb : (uint32_t)MF_TQ;
+        const int64_t rb = lbeg + (int64_t)seg * a.rows_per_block;
+        const int64_t re = rb + a.rows_per_block < lend ? rb + a.rows_per_block : lend;
+
+        __syncthreads(); // the previous work item is done with the tile tables and the stage
+        if (tid < MF_TQ)
+        {
+            const uint32_t pi = pb + tid < pe ? pb + tid : pe - 1; // short tiles repeat their last pair (never selected)
+            const uint32_t qp = a.pairs[pi];
+            const uint32_t q = qp / a.nprobe;
+            qrow_s[tid] = q;
+            qpair_s[tid] = qp;
+            qn_s[tid] = METRIC == M_L2 ? a.qnorm[q] : 0.f;
+        }
+        if (METRIC == M_L2 && tid < MF_ROWS)
+            xn_s[tid] = a.xnorm[rb + tid < re ? rb + tid : re - 1];
+        __syncthreads();
+
+        WaveTopK<1> top[8]; // this wavefront selects for queries 8*wave .. 8*wave+7 of the tile
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            top[t].init();
+        const float4 * qsrc = a.Q + (size_t)qrow_s[lr] * ld4;
+        const float qn = qn_s[r32];
+
+        // The (sub-tile, reduction step) space is walked as ONE software pipeline: the operands of step i+1 are in
+        // flight (registers px/pq) while step i multiplies, across sub-tile borders too, so the first step of a
+        // sub-tile travels during the previous sub-tile's selection.
+        int64_t pf_sub = rb; // prefetch position
+        uint32_t pf_ki = 0;
+        const float4 * xsrc[4];
+        float4 px[4], pq;
+        auto set_rows = [&](int64_t sub) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                int64_t row = sub + lr + 32 * i;
+                if (row >= re)
+                    row = re - 1; // rows past the segment repeat its last row; they are never offered
+                xsrc[i] = a.Y + (size_t)row * ld4;
+            }
+        };
+        auto gload = [&]() {
+            const uint32_t c = pf_ki * 8 + lc;
+            const bool in = c < ld4;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                px[i] = in ? xsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pq = in ? qsrc[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto advance = [&]() {
+            if (++pf_ki == nk)
+            {
+                pf_ki = 0;
+                pf_sub += MF_ROWS;
+                if (pf_sub < re)
+                    set_rows(pf_sub);
+            }
+        };
+        auto sstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                *reinterpret_cast<float4 *>(&Xs[buf][(lr + 32 * i) * MF_LDX + 4 * lc]) = px[i];
+            *reinterpret_cast<float4 *>(&Qs[buf][lr * MF_LDX + 4 * lc]) = pq;
+        };
+        set_rows(rb);
+        gload();
+        advance();
+        sstore(0);
+        __syncthreads();
+        int cur = 0;
+
+        for (int64_t sub = rb; sub < re; sub += MF_ROWS)
+        {
+            // side data of this sub-tile's selection and of the next sub-tile's epilogue: requested now, used late
+            const bool has_next = sub + MF_ROWS < re;
+            float xn_next = 0.f;
+            if (METRIC == M_L2 && has_next && tid < MF_ROWS)
+                xn_next = a.xnorm[sub + MF_ROWS + tid < re ? sub + MF_ROWS + tid : re - 1];
+            bool okrow[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+            {
+                const int64_t row = sub + lane + 64 * u;
+                bool ok = row < re;
+                if (ok && a.alive)
+                {
+                    const uint32_t id = a.ids ? a.ids[row] : (uint32_t)row + a.id_base;
+                    ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
+                }
+                okrow[u] = ok;
+            }
+
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                acc[r] = 0.f;
+            for (uint32_t ki = 0; ki < nk; ki++)
+            {
+                const bool more = pf_sub < re;
+                if (more)
+                    gload();
+                // lane (r32, h) feeds row/query r32 at reduction index h of each 32x32x2 product: the 32 floats of the
+                // step are consumed as k = 8i + 4h + c, the same permutation on both operands
+                const float * xa = &Xs[cur][(32 * wave + r32) * MF_LDX + 4 * h];
+                const float * qb = &Qs[cur][r32 * MF_LDX + 4 * h];
+                float4 av[4], bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    av[i] = *reinterpret_cast<const float4 *>(xa + 8 * i);
+                    bv[i] = *reinterpret_cast<const float4 *>(qb + 8 * i);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+                }
+                if (ki + 1 < nk)
+                {
+                    sstore(cur ^ 1);
+                    __syncthreads();
+                    cur ^= 1;
+                }
+                if (more)
+                    advance();
+            }
+            __syncthreads(); // every wavefront is done reading the operand stage: it becomes the distance tile
+            // D[m = row][n = query]: this lane holds query r32, rows (r & 3) + 8 * (r >> 2) + 4 * h of the wave's 32
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++)
+            {
+                const uint32_t m0 = 32 * wave + 8 * g4 + 4 * h;
+                float4 o;
+                if (METRIC == M_L2)
+                {
+                    o.x = fmaf(-2.f, acc[4 * g4 + 0], xn_s[m0 + 0]) + qn;
+                    o.y = fmaf(-2.f, acc[4 * g4 + 1], xn_s[m0 + 1]) + qn;
+                    o.z = fmaf(-2.f, acc[4 * g4 + 2], xn_s[m0 + 2]) + qn;
+                    o.w = fmaf(-2.f, acc[4 * g4 + 3], xn_s[m0 + 3]) + qn;
+                }
+                else
+                    o = make_float4(acc[4 * g4 + 0], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+                *reinterpret_cast<float4 *>(&Ss[r32 * MF_LDS + m0]) = o;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+            {
+                const uint32_t n = 8 * wave + t;
+                if (n < nvalid)
+                {
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                    {
+                        const float v = Ss[n * MF_LDS + lane + 64 * u];
+                        const uint64_t key
+                            = okrow[u] ? make_key<METRIC>(v, (uint32_t)(sub + lane + 64 * u)) : KEY_NONE;
+                        top[t].offer(key, kc, lane);
+                    }
+                }
+            }
+            if (has_next)
+            {
+                __syncthreads(); // distance tile consumed: restage the first step of the next sub-tile
+                sstore(0);
+                if (METRIC == M_L2 && tid < MF_ROWS)
+                    xn_s[tid] = xn_next;
+                __syncthreads();
+                cur = 0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+        {
+            const uint32_t n = 8 * wave + t;
+            if (n < nvalid)
+                top[t].store(a.partial + ((size_t)qpair_s[n] * a.seg_max + seg) * kc, kc, lane);
+        }
+    }
+}
+
+struct RerankParams
+{
+    const float4 * Y;      // rows, ld4 float4 each
+    const uint32_t * ids;  // id of stored row r
+    const float4 * Q;      // queries
+    const float * qnorm;   // |q|^2 (approximate)
+    const uint64_t * cand; // [nq][kc] ascending approximate keys, low word = row position
+    uint32_t kc, k, ld4;
+    int64_t * out_ids; // [nq][k]
+    float * out_dis;
+    int cosine;
+    double eps_coef; // c of the header comment (times the experiment knob MSVS_IVF_EPS_SCALE)
+    float xmax;      // max |x|^2 over the index rows
+    uint32_t * failq; // queries whose certificate failed ...
+    uint32_t * nfail; // ... and their count (zeroed by the caller)
+    unsigned long long * stat_fail; // nullable: process-wide running total
+};
+
+/// One block per query.  dynamic LDS: ld4*16 + 64*8 bytes.
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) void ivf_rerank_kernel(const RerankParams a)
+{
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * keys = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, g = tid & 15;
+    const uint32_t q = blockIdx.x, ld4 = a.ld4, kc = a.kc;
+    for (uint32_t c = tid; c < ld4; c += BLOCK)
+        qs[c] = a.Q[(size_t)q * ld4 + c];
+    if (tid < 64)
+        keys[tid] = KEY_NONE;
+    __syncthreads();
+    const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
+    for (uint32_t c = grp; c < kc; c += 16)
+    {
+        const uint64_t ck = a.cand[(size_t)q * kc + c]; // uniform over the 16 lanes that own candidate c
+        if (ck == KEY_NONE)
+            continue;
+        const uint32_t pos = (uint32_t)ck;
+        const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
+        const float4 * qrow = qs + g;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t j = 0;
+        for (; j + 4 <= jfull; j += 4)
+        {
+            const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16], y3 = yrow[(j + 3) * 16];
+            canonical_update<METRIC>(acc, qrow[j * 16], y0);
+            canonical_update<METRIC>(acc, qrow[(j + 1) * 16], y1);
+            canonical_update<METRIC>(acc, qrow[(j + 2) * 16], y2);
+            canonical_update<METRIC>(acc, qrow[(j + 3) * 16], y3);
+        }
+        for (; j < jfull; j++)
+            canonical_update<METRIC>(acc, qrow[j * 16], yrow[j * 16]);
+        if (g < jtail)
+            canonical_update<METRIC>(acc, qrow[jfull * 16], yrow[jfull * 16]);
+        float s = __fadd_rn(__fadd_rn(acc.x, acc.y), __fadd_rn(acc.z, acc.w));
+        s = row16_tree_sum(s);
+        if (g == 0)
+            keys[c] = make_key<METRIC>(s, a.ids ? a.ids[pos] : pos);
+    }
+    __syncthreads();
+    if (wave != 0)
+        return;
+    WaveTopK<1> top;
+    top.init();
+    top.offer(lane < kc ? keys[lane] : KEY_NONE, a.k, lane);
+    if (lane < a.k)
+    {
+        const uint64_t key = top.v[0];
+        const size_t o = (size_t)q * a.k + lane;
+        a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
+        const float v = key_value<METRIC>(key);
+        a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+    }
+    // certificate (see the header comment); a candidate list that is not full holds every probed row
+    const uint64_t last = a.cand[(size_t)q * kc + kc - 1];
+    bool ok = true;
+    if (last != KEY_NONE)
+    {
+        const uint64_t ek = top.thr;
+        const float qn = a.qnorm[q];
+        if (ek == KEY_NONE || !(qn < 1e30f) || !(a.xmax < 1e30f))
+            ok = false;
+        else
+        {
+            const double al = (double)key_value<METRIC>(last), e = (double)key_value<METRIC>(ek);
+            const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
+            const double eps = (METRIC == M_L2 ? a.eps_coef * (sx + sq) * (sx + sq) : a.eps_coef * sx * sq) + 1e-30;
+            ok = METRIC == M_L2 ? (al - eps > e) : (al + eps < e);
+        }
+    }
+    if (!ok && lane == 0)
+    {
+        a.failq[atomicAdd(a.nfail, 1u)] = q;
+        if (a.stat_fail)
+            atomicAdd(a.stat_fail, 1ull);
+    }
+}
+
+/// ivf_scan_kernel over a device-side list of queries: grid (seg_max, nprobe, Z); block z handles
+/// a.qmap[z], a.qmap[z + Z], ... up to *a.qcount (which is usually 0: then every block exits at once).
+template <int METRIC, int R>
+__global__ __launch_bounds__(BLOCK) void ivf_scan_subset_kernel(const ScanParams a)
+{
+    const uint32_t s = blockIdx.x, p = blockIdx.y;
+    const uint32_t nf = *a.qcount;
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16);
+    for (uint32_t f = blockIdx.z; f < nf; f += gridDim.z)
+    {
+        const uint32_t q = a.qmap[f];
+        const int32_t list = a.probes[(size_t)q * a.nprobe + p];
+        int64_t lb = 0, le = 0;
+        if (list >= 0)
+        {
+            lb = a.list_off[list] + (int64_t)s * a.rows_per_block;
+            le = a.list_off[list + 1];
+            if (le > lb + a.rows_per_block)
+                le = lb + a.rows_per_block;
+        }
+        if (lb >= le)
+            continue;
+        uint32_t qidx[1] = {q};
+        uint64_t * out[1] = {a.partial + (((size_t)q * a.nprobe + p) * a.seg_max + s) * a.k};
+        __syncthreads();
+        stage_queries<1>(a, qidx, qs);
+        scan_rows<METRIC, 1, R>(a, (uint32_t)lb, (uint32_t)le, qs, lds_merge, out);
+    }
+}
+
+}

@@ -1,7 +1,9 @@
 // msvs_capi.hip -- the C-ABI of libmsvs.so (include/msvs.h): seam A2 (brute force), seam A1 (index object),
 // top-k merge.  Everything computes on the GPU; there is no CPU fallback.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <mutex>
 #include <cstdio>
 #include <memory>
 #include <numeric>
@@ -249,8 +251,46 @@ struct msvs_index
     size_t n = 0;
     size_t max_list_len = 0;
     uint64_t max_id = 0; // largest stored row id (size of the id space the filter bitmaps range over)
+    // matrix-core candidate pass (mfma_scan_kernels.hpp): |x|^2 of every stored row and their maximum
+    DevBuf<float> xnorm;
+    float xnorm_max = 0.f;
     bool ready = false;
 };
+
+/// Row norms for the approximate pass and its error bound; called once the final storage is in place.
+static void index_finalize_norms(msvs_index & ix, hipStream_t stream)
+{
+    ix.xnorm.alloc(std::max<size_t>(ix.n, 1));
+    ix.xnorm_max = 0.f;
+    if (ix.n == 0)
+        return;
+    DevBuf<uint32_t> mx(1);
+    MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
+    launch_row_sqnorm(ix.vecs.p, ix.xnorm.p, ix.n, ix.ld / 4, mx.p, stream);
+    uint32_t bits = 0;
+    MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
+    MSVS_HIP(hipStreamSynchronize(stream));
+    memcpy(&ix.xnorm_max, &bits, 4); // NaN / inf / huge values switch the candidate pass off (see plan_ivf)
+}
+
+/// Process-wide counters of the candidate pass: [0] = queries whose certificate failed (device side).
+static unsigned long long * prefilter_fail_counter()
+{
+    static std::map<int, unsigned long long *> per_device;
+    static std::mutex mu;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_device.find(dev);
+    if (it != per_device.end())
+        return it->second;
+    unsigned long long * p = nullptr;
+    MSVS_HIP(hipMalloc(&p, 8));
+    MSVS_HIP(hipMemset(p, 0, 8));
+    per_device[dev] = p;
+    return p;
+}
+static std::atomic<unsigned long long> g_prefilter_queries{0};
 
 static void index_assign(const msvs_index & ix, const float * d_x, size_t n, int32_t * d_assign, hipStream_t stream)
 {
@@ -569,6 +609,7 @@ extern "C" int msvs_index_build(msvs_index_t * ix)
             MSVS_HIP(hipMemcpy(ix->row_ids.p, h_ids.data(), n * 4, hipMemcpyHostToDevice));
         MSVS_HIP(hipMemcpy(ix->list_off.p, ix->h_list_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
         ix->chunks.clear();
+        index_finalize_norms(*ix, stream);
         ix->ready = true;
     });
 }
@@ -581,7 +622,9 @@ extern "C" size_t msvs_index_num_lists(const msvs_index_t * ix)
 }
 extern "C" size_t msvs_index_memory_usage(const msvs_index_t * ix)
 {
-    return ix ? ix->vecs.bytes() + ix->row_ids.bytes() + ix->centroids.bytes() + ix->list_off.bytes() : 0;
+    return ix ? ix->vecs.bytes() + ix->row_ids.bytes() + ix->centroids.bytes() + ix->list_off.bytes()
+            + ix->xnorm.bytes()
+              : 0;
 }
 
 namespace msvs
@@ -590,18 +633,55 @@ namespace msvs
 /// How an IVF search of nq queries is decomposed.
 struct IvfSearchPlan
 {
-    uint32_t T;       // 1 = one query per block (ivf_scan_kernel); 2/4/8 = list-batched query tiles
+    uint32_t T;       // 1 = one query per block (ivf_scan_kernel); 2/4/8 = list-batched query tiles;
+                      // 32 (MF_TQ) = matrix-core candidate pass + canonical re-rank (mfma_scan_kernels.hpp)
     uint32_t rpb;     // rows per work item
     uint32_t seg_max; // segments of the longest list
     uint32_t grid;    // batched: fixed grid size
+    // T == 32 only
+    uint32_t kc;       // candidates kept per query
+    uint32_t rpb1;     // rows per block / segments of the canonical fallback scan (one query per block)
+    uint32_t seg_max1;
+    uint32_t fb_slots; // block slots (grid z) of the fallback
 };
 
-static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe)
+static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, uint32_t k)
 {
     IvfSearchPlan p{};
     const size_t pairs = nq * nprobe;
     const size_t nlist = std::max<size_t>(ix.nlist, 1);
     const size_t avg = std::max<size_t>(1, ix.n / nlist);
+    // Matrix-core candidate pass: pays once ~16 queries share a list pass (the canonical scan is VALU-bound there);
+    // needs finite, sane row norms for its error bound and k small enough for a 64-entry candidate list.
+    {
+        const char * e = getenv("MSVS_IVF_MFMA"); // experiment knob: 0 = never, 2 = whenever eligible
+        const int mode = e ? atoi(e) : 1;
+        const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f; // false for NaN
+        if (mode != 0 && eligible && (pairs >= 16 * nlist || mode == 2))
+        {
+            p.T = MF_TQ;
+            p.kc = k <= 12 ? 32 : 64;
+            const size_t tiles = std::max<size_t>(1, pairs / MF_TQ);
+            // a query's partial candidate lists (~1.3 * nprobe * avg / rpb of them, kc keys each) should fit the merge
+            // block's LDS stage (HEADS_CAP keys)
+            const size_t rpb_min = nprobe * avg * 13 / 10 * p.kc / 5000;
+            size_t rpb = round_up(std::max<size_t>(std::max<size_t>(avg * tiles / 2048, rpb_min), MF_ROWS), MF_ROWS);
+            p.rpb = (uint32_t)std::min<size_t>(rpb, 1024);
+            if (const char * r = getenv("MSVS_IVF_RPB"))
+                if (atoi(r) >= MF_ROWS)
+                    p.rpb = (uint32_t)round_up((size_t)atoi(r), MF_ROWS);
+            p.grid = 4096;
+            if (const char * g = getenv("MSVS_IVF_GRID"))
+                if (atoi(g) >= 1)
+                    p.grid = (uint32_t)atoi(g);
+            p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, p.rpb));
+            size_t rpb1 = round_up(std::max<size_t>(64, nprobe * avg * 3 / 2 / 400), 16);
+            p.rpb1 = (uint32_t)std::min<size_t>(rpb1, 256);
+            p.seg_max1 = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, p.rpb1));
+            p.fb_slots = (uint32_t)std::min<size_t>(nq, 8);
+            return p;
+        }
+    }
     // Query tiles only pay when several queries of the batch probe the same list.
     // (measured on MI355X, 1M x 768, nlist 1024, nprobe 32: T=4 beats T=8 up to ~8 pairs per list because its 128
     // VGPRs allow 4 waves/SIMD against 2; see profiles/r01_ivf_tuning_sweep.txt)
@@ -651,9 +731,15 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     size_t b = nq * (size_t)ix.ld * 4 + 4096;
     if (ix.type == MSVS_INDEX_FLAT)
         return b + flat_scratch_bytes(ix.n, nq, k);
-    IvfSearchPlan p = plan_ivf(ix, nq, nprobe);
-    return b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + nq * nprobe * 4
-        + nq * nprobe * (size_t)p.seg_max * k * 8 + (4 * ix.nlist + 8 + nq * nprobe) * 4 + 32768;
+    IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k);
+    size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + nq * nprobe * 4
+        + (4 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
+    if (p.T == MF_TQ)
+        need += nq * nprobe * (size_t)p.seg_max * p.kc * 8 + nq * (size_t)p.kc * 8 + nq * 8 + 4096
+            + nq * nprobe * (size_t)p.seg_max1 * k * 8;
+    else
+        need += nq * nprobe * (size_t)p.seg_max * k * 8;
+    return need;
 }
 
 /// The search proper: all pointers on the device, everything enqueued on `stream`.
@@ -705,8 +791,8 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     // 2. scan the probed lists
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");
-    const IvfSearchPlan pl = plan_ivf(ix, nq, nprobe);
-    uint64_t * partial = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max * k);
+    const IvfSearchPlan pl = plan_ivf(ix, nq, nprobe, k);
+    uint64_t * partial = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max * (pl.T == MF_TQ ? pl.kc : k));
     ScanParams a{};
     a.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
     a.ids = ix.row_ids.p;
@@ -723,6 +809,94 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     a.nprobe = (uint32_t)nprobe;
     a.seg_max = pl.seg_max;
     a.nlist = (uint32_t)ix.nlist;
+    if (pl.T == MF_TQ)
+    {
+        // many queries per list: matrix-core candidate pass, canonical re-rank, certified (mfma_scan_kernels.hpp)
+        IvfPlanParams pp{};
+        pp.probes = d_probes;
+        pp.list_off = ix.list_off.p;
+        pp.n_pairs = (uint32_t)(nq * nprobe);
+        pp.nlist = (uint32_t)ix.nlist;
+        pp.rows_per_block = pl.rpb;
+        pp.T = MF_TQ;
+        uint32_t * counters = scr.take<uint32_t>(2 * ix.nlist + 1);
+        pp.cnt = counters;
+        pp.fill = counters + ix.nlist;
+        uint32_t * nfail = counters + 2 * ix.nlist;
+        pp.pair_off = scr.take<uint32_t>(ix.nlist + 1);
+        pp.work_off = scr.take<uint32_t>(ix.nlist + 1);
+        pp.pairs = scr.take<uint32_t>(nq * nprobe);
+        MSVS_HIP(hipMemsetAsync(counters, 0, (2 * ix.nlist + 1) * sizeof(uint32_t), stream));
+        launch_ivf_plan(pp, stream);
+        float * qnorm = scr.take<float>(nq);
+        launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
+        a.pairs = pp.pairs;
+        a.pair_off = pp.pair_off;
+        a.work_off = pp.work_off;
+        const char * xo = getenv("MSVS_IVF_XCD");
+        a.xcd_order = xo ? (uint32_t)atoi(xo) : 1u;
+        a.k = pl.kc;
+        a.qnorm = qnorm;
+        a.xnorm = ix.xnorm.p;
+        launch_ivf_mfma_scan(scan_metric(m), pl.grid, a, stream);
+        uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
+        IvfMergeParams cm{};
+        cm.partial = partial;
+        cm.probes = d_probes;
+        cm.list_off = ix.list_off.p;
+        cm.nprobe = (uint32_t)nprobe;
+        cm.seg_max = pl.seg_max;
+        cm.rows_per_block = pl.rpb;
+        cm.k = pl.kc;
+        cm.out_keys = cand;
+        launch_ivf_merge(scan_metric(m), cm, (uint32_t)nq, stream);
+        uint32_t * failq = scr.take<uint32_t>(nq);
+        RerankParams rp{};
+        rp.Y = a.Y;
+        rp.ids = ix.row_ids.p;
+        rp.Q = a.Q;
+        rp.qnorm = qnorm;
+        rp.cand = cand;
+        rp.kc = pl.kc;
+        rp.k = k;
+        rp.ld4 = ld / 4;
+        rp.out_ids = d_ids;
+        rp.out_dis = d_dis;
+        rp.cosine = ix.metric == MSVS_METRIC_COSINE;
+        const char * es = getenv("MSVS_IVF_EPS_SCALE"); // experiment / test knob: inflate eps to force the fallback
+        rp.eps_coef = 1.05 * (2.0 * (double)ix.dim * ldexp(1.0, -23) + 64.0 * ldexp(1.0, -24)) * (es ? atof(es) : 1.0);
+        rp.xmax = ix.xnorm_max;
+        rp.failq = failq;
+        rp.nfail = nfail;
+        rp.stat_fail = prefilter_fail_counter();
+        launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
+        g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
+        // queries without a certificate: canonical scan, one query per block (normally zero of them)
+        uint64_t * partial1 = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max1 * k);
+        ScanParams c = a;
+        c.k = k;
+        c.partial = partial1;
+        c.rows_per_block = pl.rpb1;
+        c.seg_max = pl.seg_max1;
+        c.qmap = failq;
+        c.qcount = nfail;
+        launch_ivf_scan_subset(scan_metric(m), c, pl.fb_slots, stream);
+        IvfMergeParams fm{};
+        fm.partial = partial1;
+        fm.probes = d_probes;
+        fm.list_off = ix.list_off.p;
+        fm.nprobe = (uint32_t)nprobe;
+        fm.seg_max = pl.seg_max1;
+        fm.rows_per_block = pl.rpb1;
+        fm.k = k;
+        fm.out_ids = d_ids;
+        fm.out_dis = d_dis;
+        fm.cosine = ix.metric == MSVS_METRIC_COSINE;
+        fm.qmap = failq;
+        fm.qcount = nfail;
+        launch_ivf_merge_subset(scan_metric(m), fm, pl.fb_slots, stream);
+        return;
+    }
     if (pl.T == 1)
     {
         // few queries: one (query, list, segment) per block, no grouping pass
@@ -910,7 +1084,7 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
         *rows = total;
         if (rows_streamed)
         {
-            const uint32_t T = plan_ivf(*ix, nq, np).T;
+            const uint32_t T = plan_ivf(*ix, nq, np, 10).T;
             uint64_t st = 0;
             for (size_t l = 0; l < ix->nlist; l++)
                 st += (uint64_t)ceil_div(cnt[l], T) * (uint64_t)(ix->h_list_off[l + 1] - ix->h_list_off[l]);
@@ -938,6 +1112,20 @@ extern "C" int msvs_profile_get(const char * name, uint64_t * calls, double * to
         if (!name)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null name");
         profile_get(name, calls, total_ms);
+    });
+}
+
+extern "C" int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks)
+{
+    return guarded([&] {
+        unsigned long long f = 0;
+        unsigned long long * p = prefilter_fail_counter();
+        MSVS_HIP(hipDeviceSynchronize());
+        MSVS_HIP(hipMemcpy(&f, p, 8, hipMemcpyDeviceToHost));
+        if (queries)
+            *queries = g_prefilter_queries.load();
+        if (fallbacks)
+            *fallbacks = f;
     });
 }
 
@@ -1071,6 +1259,7 @@ extern "C" int msvs_index_load(const char * path, msvs_index_t ** out)
             MSVS_HIP(hipMemcpy(ix->row_ids.p, h_ids.data(), n * 4, hipMemcpyHostToDevice));
         MSVS_HIP(hipMemcpy(ix->list_off.p, off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
         MSVS_HIP(hipStreamSynchronize(nullptr));
+        index_finalize_norms(*ix, nullptr);
         ix->ready = true;
         *out = ix.release();
     });

@@ -70,10 +70,12 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane)
     return (uint64_t)hi << 32 | lo;
 }
 
+/// Lane i gets lane i-1's value (lane 0: unspecified).  DPP wave_shr:1 -- a register move, against the ds_bpermute
+/// round trip through the LDS crossbar that __shfl_up costs; this sits on the serial path of every top-k insertion.
 __device__ __forceinline__ uint64_t shfl_up64(uint64_t v)
 {
-    uint32_t lo = __shfl_up((int)(uint32_t)v, 1, WAVE);
-    uint32_t hi = __shfl_up((int)(uint32_t)(v >> 32), 1, WAVE);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
     return (uint64_t)hi << 32 | lo;
 }
 
@@ -230,6 +232,11 @@ struct ScanParams
     const uint32_t * work_off;
     uint32_t nlist;
     uint32_t xcd_order; // 1: XCD-contiguous work ranges (see ivf_batched_scan_kernel)
+    // matrix-core candidate pass and its fallback (mfma_scan_kernels.hpp)
+    const float * qnorm;     // [nq] |q|^2
+    const float * xnorm;     // [n_rows] |x|^2
+    const uint32_t * qmap;   // subset kernels: the queries to process ...
+    const uint32_t * qcount; // ... and how many of them (device side)
 };
 
 /// Scans rows [row_begin,row_end) for T queries already staged in LDS (qs[t*ld4 + c]) and leaves the block's
@@ -717,14 +724,28 @@ struct IvfMergeParams
     int64_t * out_ids;
     float * out_dis;
     int cosine;
+    uint64_t * out_keys;     // non-null: write the merged keys [nq][k] instead of (ids, distances)
+    const uint32_t * qmap;   // subset kernel: the queries to merge ...
+    const uint32_t * qcount; // ... and how many of them (device side)
 };
 
-/// One block per query: top-k over the valid segments of its probed lists.
+/// Top-k of query q over the valid segments of its probed lists.  All BLOCK threads; uniform control flow.
 template <int METRIC, int R>
-__global__ __launch_bounds__(BLOCK) void ivf_merge_kernel(const IvfMergeParams a)
+__device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const uint32_t q)
 {
     uint64_t * lds = reinterpret_cast<uint64_t *>(msvs_smem);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k, q = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k;
+    auto emit = [&](uint32_t i, uint64_t key) {
+        const size_t o = (size_t)q * k + i;
+        if (a.out_keys)
+            a.out_keys[o] = key;
+        else
+        {
+            a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
+            const float v = key_value<METRIC>(key);
+            a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+        }
+    };
 
     // Fast path: all valid partial lists of the query fit in LDS -> compact them and run the heads merge.
     {
@@ -774,13 +795,7 @@ __global__ __launch_bounds__(BLOCK) void ivf_merge_kernel(const IvfMergeParams a
                 wave_heads_merge(keys, P, k, idx, outk, k, lane);
             __syncthreads();
             for (uint32_t i = tid; i < k; i += BLOCK)
-            {
-                uint64_t key = outk[i];
-                size_t o = (size_t)q * k + i;
-                a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
-                float v = key_value<METRIC>(key);
-                a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
-            }
+                emit(i, outk[i]);
             return;
         }
         __syncthreads();
@@ -815,12 +830,25 @@ __global__ __launch_bounds__(BLOCK) void ivf_merge_kernel(const IvfMergeParams a
     uint64_t * merged = lds + 4 * k;
     block_rank_merge(lds, k, merged, k, tid);
     for (uint32_t i = tid; i < k; i += BLOCK)
+        emit(i, merged[i]);
+}
+
+/// One block per query.
+template <int METRIC, int R>
+__global__ __launch_bounds__(BLOCK) void ivf_merge_kernel(const IvfMergeParams a)
+{
+    ivf_merge_query<METRIC, R>(a, blockIdx.x);
+}
+
+/// Block b merges queries a.qmap[b], a.qmap[b + gridDim.x], ... up to *a.qcount (usually 0).
+template <int METRIC, int R>
+__global__ __launch_bounds__(BLOCK) void ivf_merge_subset_kernel(const IvfMergeParams a)
+{
+    const uint32_t nf = *a.qcount;
+    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x)
     {
-        uint64_t key = merged[i];
-        size_t o = (size_t)q * k + i;
-        a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
-        float v = key_value<METRIC>(key);
-        a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+        ivf_merge_query<METRIC, R>(a, a.qmap[f]);
+        __syncthreads();
     }
 }
 

@@ -229,6 +229,69 @@ def test_ivfflat_matches_oracle_on_exported_structure(metric, n, d, nlist, nq, n
     same(ids, dis, oi, od)
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(40000, 768, 16, 200, 4, 10), (30000, 100, 8, 256, 8, 40),
+                                                   (20000, 20, 8, 129, 3, 1), (3000, 64, 4, 100, 4, 12)])
+def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, nq, nprobe, k, monkeypatch):
+    """>= 16 queries per list: MFMA candidate pass + canonical re-rank + certificate (mfma_scan_kernels.hpp).  The
+    result must be the canonical one bit for bit, with and without certificates."""
+    rng = np.random.default_rng(n + d + nlist + 5)
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, metric, nlist)
+    q0, f0 = capi.prefilter_stats()
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+    same(ids, dis, oi, od)
+    alive = rng.random(n) < 0.5
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=alive)
+    oa, oda, _ = oracle_on_exported(ix, q, nprobe, k, metric, alive=alive)
+    same(ids, dis, oa, oda)
+    q1, f1 = capi.prefilter_stats()
+    assert q1 - q0 == 2 * nq  # the matrix-core pass is the one that ran
+    assert f1 - f0 <= nq // 4  # and it certified (almost) every query
+    # no certificate for anybody: every query takes the canonical fallback, same answer
+    monkeypatch.setenv("MSVS_IVF_EPS_SCALE", "1e12")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    q2, f2 = capi.prefilter_stats()
+    assert f2 - f1 == nq
+    monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
+    # the pass switched off: the list-batched canonical scan, same answer
+    monkeypatch.setenv("MSVS_IVF_MFMA", "0")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    assert capi.prefilter_stats()[0] == q2
+
+
+def test_matrix_core_pass_with_massive_ties_and_unusable_norms():
+    rng = np.random.default_rng(77)
+    n, d, nlist, nq = 6000, 48, 4, 128
+    base = rng.standard_normal((40, d), dtype=np.float32)
+    x = base[rng.integers(0, 40, n)].copy()  # 40 distinct vectors: every top-10 is one big tie broken by id
+    q = (base[rng.integers(0, 40, nq)] + 0.01 * rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    for metric in (capi.METRIC_L2, capi.METRIC_IP):
+        ix = build_ivf(x, metric, nlist)
+        q0, f0 = capi.prefilter_stats()
+        ids, dis = ix.search(q, 10, "nprobe=2")
+        oi, od, _ = oracle_on_exported(ix, q, 2, 10, metric)
+        same(ids, dis, oi, od)
+        q1, f1 = capi.prefilter_stats()
+        assert q1 - q0 == nq and f1 - f0 > 0  # ties cannot be certified: they went through the fallback
+    # a NaN / huge row makes the error bound meaningless: the pass must switch itself off
+    for bad in (np.nan, 3e19):
+        y = rng.standard_normal((n, d), dtype=np.float32)
+        y[123, 5] = bad
+        ix = build_ivf(y, capi.METRIC_L2, nlist)
+        q0, _ = capi.prefilter_stats()
+        qq = rng.standard_normal((nq, d), dtype=np.float32)
+        ids, dis = ix.search(qq, 10, "nprobe=2")
+        oi, od, _ = oracle_on_exported(ix, qq, 2, 10, capi.METRIC_L2)
+        same(ids, dis, oi, od)
+        assert capi.prefilter_stats()[0] == q0
+
+
 def test_ivfflat_structure_invariants_and_full_probe_equals_flat():
     rng = np.random.default_rng(11)
     n, d, nlist = 12000, 64, 48

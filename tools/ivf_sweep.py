@@ -27,10 +27,22 @@ ref = {}
 for c in sys.argv[1:]:
     kv = dict(p.split('=') for p in c.split(','))
     B = int(kv.pop('B'))
-    for kk in ("MSVS_IVF_T", "MSVS_IVF_RPB", "MSVS_IVF_GRID", "MSVS_IVF_XCD", "MSVS_IVF_WT"):
+    for kk in ("MSVS_IVF_T", "MSVS_IVF_RPB", "MSVS_IVF_GRID", "MSVS_IVF_XCD", "MSVS_IVF_WT", "MSVS_IVF_MFMA",
+               "MSVS_IVF_EPS_SCALE"):
         os.environ.pop(kk, None)
     for a, b in kv.items():
         os.environ["MSVS_IVF_" + a] = b
+    f0 = capi.prefilter_stats()
     dt, ids = run(B)
+    f1 = capi.prefilter_stats()
     same = (ref.setdefault(B, ids) == ids).all()
-    print("B=%d %s : %.3f ms/step  %.0f QPS  same_ids=%s" % (B, kv, dt * 1e3, B / dt, same), flush=True)
+    capi.profile_reset(); capi.profile_enable(True)
+    run(B, steps=5)
+    capi.profile_enable(False)
+    fam = {}
+    for name in ("flat_scan", "merge", "ivf_plan", "ivf_scan", "rerank", "fallback_scan", "fallback_merge"):
+        c, ms = capi.profile_get(name)
+        if c:
+            fam[name] = round(ms / 8, 4)  # 3 warmup + 5 steps
+    print("B=%d %s : %.3f ms/step  %.0f QPS  same_ids=%s  prefilter(q,fallback)=%s  kernels ms/step %s"
+          % (B, kv, dt * 1e3, B / dt, same, (f1[0] - f0[0], f1[1] - f0[1]), fam), flush=True)
