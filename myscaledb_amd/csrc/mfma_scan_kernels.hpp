@@ -309,6 +309,372 @@ __global__ __launch_bounds__(BLOCK) void ivf_mfma_scan_kernel(const ScanParams a
     }
 }
 
+// ------------------------------------------------------------------------------------------ big-tile variant
+//
+// The 128-row x 32-query kernel above re-reads a list once per 32 probing queries and re-reads the query tile once per
+// 128 rows (~2.9x the unique bytes at ~50 queries per list), and its per-query candidate lists cost a serial
+// insertion (~270 cycles) per accepted key.  This variant:
+//   * holds a 128-row x 128-query tile per workgroup: each of the 4 wavefronts owns 32 rows x 128 queries = 4 MFMA
+//     accumulators, so one LDS read of its rows feeds up to 4 products; 32-query column blocks without queries are
+//     skipped.  74 KB of LDS -> two workgroups per CU, one selecting while the other multiplies;
+//   * keeps no list: every (query, 128-row slice) emits its own 16 best rows (radix select over the wavefront's 128
+//     keys by ballots, then a 16-lane DPP bitonic sort) straight to global memory.  16 > k (<= 12 here), so a slice
+//     can only hide a row from the result if 16 better rows sit in the same slice; the merge reports
+//     bound = min(32nd merged key, 16th key of every FULL slice list) and the re-rank certifies against that bound;
+//   * shares ONE number per query across the whole grid: qthr[q] = the smallest 16th-key distance any full slice list
+//     of the query has emitted so far (atomicMin).  A row whose approximate distance is not below it can be dropped
+//     at once -- it is no better than a key the bound already accounts for -- so after the first few slices of a
+//     query almost every later slice has fewer than 16 survivors and skips the selection altogether.  Which rows get
+//     dropped depends on timing; the certified result does not.
+
+constexpr int BG_ROWS = 128;
+constexpr int BG_TQ = 128;
+constexpr int BG_SLICE_K = 16; // keys emitted per (query, slice)
+constexpr int BG_KC = 32;      // candidates per query after the merge
+
+/// The 16 smallest of the wavefront's 128 keys (k0 of every lane, then k1; KEY_NONE = absent) in ascending order in
+/// lanes 0..15 of the return value (KEY_NONE padded; other lanes KEY_NONE).  Keys are unique except KEY_NONE.
+/// scratch: 16 u64 of LDS private to the wavefront.
+__device__ __forceinline__ uint64_t wave_select16(const uint64_t k0, const uint64_t k1, volatile uint64_t * scratch,
+                                                  const uint32_t lane)
+{
+    uint64_t alive0 = __ballot(k0 != KEY_NONE), alive1 = __ballot(k1 != KEY_NONE);
+    uint64_t sel0 = 0, sel1 = 0;
+    uint32_t need = BG_SLICE_K;
+    uint32_t cnt = __popcll(alive0) + __popcll(alive1);
+    if (cnt <= need)
+    {
+        sel0 = alive0;
+        sel1 = alive1;
+    }
+    else
+    {
+        // MSB-first radix select of the need-th smallest key: `alive` = keys still tied with it on the bits seen so far
+        const uint32_t h0 = (uint32_t)(k0 >> 32), l0 = (uint32_t)k0, h1 = (uint32_t)(k1 >> 32), l1 = (uint32_t)k1;
+        for (int bit = 63; bit >= 0; bit--)
+        {
+            const uint32_t sh = bit & 31;
+            const uint32_t w0 = bit >= 32 ? h0 : l0, w1 = bit >= 32 ? h1 : l1;
+            const uint64_t one0 = __ballot((w0 >> sh) & 1u), one1 = __ballot((w1 >> sh) & 1u);
+            const uint64_t z0 = alive0 & ~one0, z1 = alive1 & ~one1;
+            const uint32_t c = __popcll(z0) + __popcll(z1);
+            if (c >= need)
+            {
+                alive0 = z0;
+                alive1 = z1;
+                cnt = c;
+            }
+            else
+            {
+                need -= c; // every tied key with a 0 here is smaller: selected
+                sel0 |= z0;
+                sel1 |= z1;
+                alive0 &= one0;
+                alive1 &= one1;
+                cnt -= c;
+            }
+            if (cnt == need)
+            {
+                sel0 |= alive0;
+                sel1 |= alive1;
+                break;
+            }
+        }
+    }
+    // compact the selected keys into 16 LDS slots, reload one per lane
+    if (lane < (uint32_t)BG_SLICE_K)
+        scratch[lane] = KEY_NONE;
+    const uint32_t s0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel0, 0u));
+    const uint32_t s1 = __popcll(sel0)
+        + __builtin_amdgcn_mbcnt_hi((uint32_t)(sel1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel1, 0u));
+    if ((sel0 >> lane) & 1)
+        scratch[s0] = k0;
+    if ((sel1 >> lane) & 1)
+        scratch[s1] = k1;
+    __threadfence_block();
+    uint64_t v = lane < (uint32_t)BG_SLICE_K ? scratch[lane] : KEY_NONE;
+    // bitonic sort of the 16 lanes of DPP row 0 (flip + half-cleaner form; every exchange is a DPP move)
+    auto cx = [&](const uint64_t partner, const bool keep_min) {
+        const bool take = keep_min ? partner < v : partner > v;
+        v = take ? partner : v;
+    };
+    cx(dpp64<0xB1>(v), !(lane & 1));  // blocks of 2: lane ^ 1
+    cx(dpp64<0x1B>(v), !(lane & 2));  // blocks of 4: lane ^ 3 (quad reversed)
+    cx(dpp64<0xB1>(v), !(lane & 1));
+    cx(dpp64<0x141>(v), !(lane & 4)); // blocks of 8: lane ^ 7 (row_half_mirror)
+    cx(dpp64<0x4E>(v), !(lane & 2));  //              lane ^ 2
+    cx(dpp64<0xB1>(v), !(lane & 1));
+    cx(dpp64<0x140>(v), !(lane & 8)); // blocks of 16: lane ^ 15 (row_mirror)
+    {
+        const uint64_t up = dpp64<0x104>(v), dn = dpp64<0x114>(v); // row_shl:4 = lane + 4, row_shr:4 = lane - 4
+        cx((lane & 4) ? dn : up, !(lane & 4));                      //               lane ^ 4
+    }
+    cx(dpp64<0x4E>(v), !(lane & 2));
+    cx(dpp64<0xB1>(v), !(lane & 1));
+    return v;
+}
+
+/// Work item = (list, tile of <= 128 probing queries, segment of a.rows_per_block rows (a multiple of 128)); plan built
+/// with T = BG_TQ.  a.partial[(pair * a.seg_max + slice) * 16 ...] receives the 16 best (approximate key, row position)
+/// of 128-row slice `slice` of the pair's list; a.seg_max = slices of the longest list.
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void ivf_mfma_scan_big_kernel(
+    const ScanParams a)
+{
+    __shared__ __attribute__((aligned(16))) float stage[2 * (BG_ROWS + BG_TQ) * MF_LDX];
+    float(*const Xs)[BG_ROWS * MF_LDX] = reinterpret_cast<float(*)[BG_ROWS * MF_LDX]>(stage);
+    float(*const Qs)[BG_TQ * MF_LDX] = reinterpret_cast<float(*)[BG_TQ * MF_LDX]>(stage + 2 * BG_ROWS * MF_LDX);
+    __shared__ uint64_t sel_s[4][BG_SLICE_K];
+    __shared__ uint32_t thr_s[BG_TQ];
+    __shared__ float xn_s[BG_ROWS];
+    __shared__ float qn_s[BG_TQ];
+    __shared__ uint32_t qrow_s[BG_TQ];
+    __shared__ uint32_t qpair_s[BG_TQ];
+    float * const Ss = stage; // distance tile [128 queries][128 rows (+4)]: reuses the operand stages
+    static_assert(BG_TQ * MF_LDS <= 2 * (BG_ROWS + BG_TQ) * MF_LDX, "distance tile must fit the operand stages");
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const uint32_t ld4 = a.ld4;
+    const uint32_t nk = (ld4 + 7) / 8;
+    const uint32_t lc = tid & 7, lr = tid >> 3; // loader: float4 column lc of rows / queries lr + 32*i
+    const uint32_t total = a.work_off[a.nlist];
+    const uint32_t per_xcd = (total + 7) / 8;
+    for (uint32_t s = blockIdx.x; s < 8 * per_xcd; s += gridDim.x)
+    {
+        const uint32_t w = a.xcd_order ? (s & 7) * per_xcd + (s >> 3) : s;
+        if (w >= total || (a.xcd_order && (s >> 3) >= per_xcd))
+            continue;
+        uint32_t lo = 0, hi = a.nlist;
+        while (hi - lo > 1)
+        {
+            uint32_t mid = (lo + hi) >> 1;
+            if (a.work_off[mid] <= w)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t l = lo;
+        const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
+        const uint32_t local = w - a.work_off[l];
+        const uint32_t pe = a.pair_off[l + 1];
+        const uint32_t ntile = (pe - a.pair_off[l] + BG_TQ - 1) / BG_TQ;
+        const uint32_t seg = local / ntile, tile = local - seg * ntile;
+        const uint32_t pb = a.pair_off[l] + tile * BG_TQ;
+        const uint32_t nvalid = pe - pb < (uint32_t)BG_TQ ? pe - pb : (uint32_t)BG_TQ;
+        const uint32_t ncb = (nvalid + 31) >> 5; // 32-query column blocks in use
+        const int64_t rb = lbeg + (int64_t)seg * a.rows_per_block;
+        const int64_t re = rb + a.rows_per_block < lend ? rb + a.rows_per_block : lend;
+
+        __syncthreads(); // the previous work item is done with the tables and the stage
+        if (tid < BG_TQ)
+        {
+            const uint32_t pi = pb + tid < pe ? pb + tid : pe - 1; // short tiles repeat their last pair (never selected)
+            const uint32_t qp = a.pairs[pi];
+            const uint32_t q = qp / a.nprobe;
+            qrow_s[tid] = q;
+            qpair_s[tid] = qp;
+            qn_s[tid] = METRIC == M_L2 ? a.qnorm[q] : 0.f;
+        }
+        if (METRIC == M_L2 && tid < BG_ROWS)
+            xn_s[tid] = a.xnorm[rb + tid < re ? rb + tid : re - 1];
+        __syncthreads();
+
+        const float4 * qsrc[4];
+        bool qld[4];
+        float qn[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            qsrc[i] = a.Q + (size_t)qrow_s[lr + 32 * i] * ld4;
+            qld[i] = (uint32_t)i < ncb; // query row lr + 32*i lies in column block i
+            qn[i] = qn_s[32 * i + r32];
+        }
+
+        int64_t pf_sub = rb; // prefetch position of the software pipeline over (sub-tile, reduction step)
+        uint32_t pf_ki = 0;
+        const float4 * xsrc[4];
+        float4 px[4], pq[4];
+        auto set_rows = [&](int64_t sub) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                int64_t row = sub + lr + 32 * i;
+                if (row >= re)
+                    row = re - 1; // rows past the segment repeat its last row; they are never offered
+                xsrc[i] = a.Y + (size_t)row * ld4;
+            }
+        };
+        auto gload = [&]() {
+            const uint32_t c = pf_ki * 8 + lc;
+            const bool in = c < ld4;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                px[i] = in ? xsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                pq[i] = in && qld[i] ? qsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto advance = [&]() {
+            if (++pf_ki == nk)
+            {
+                pf_ki = 0;
+                pf_sub += BG_ROWS;
+                if (pf_sub < re)
+                    set_rows(pf_sub);
+            }
+        };
+        auto sstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                *reinterpret_cast<float4 *>(&Xs[buf][(lr + 32 * i) * MF_LDX + 4 * lc]) = px[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (qld[i])
+                    *reinterpret_cast<float4 *>(&Qs[buf][(lr + 32 * i) * MF_LDX + 4 * lc]) = pq[i];
+        };
+        set_rows(rb);
+        gload();
+        advance();
+        sstore(0);
+        __syncthreads();
+        int cur = 0;
+
+        for (int64_t sub = rb; sub < re; sub += BG_ROWS)
+        {
+            const bool has_next = sub + BG_ROWS < re;
+            float xn_next = 0.f;
+            if (METRIC == M_L2 && has_next && tid < BG_ROWS)
+                xn_next = a.xnorm[sub + BG_ROWS + tid < re ? sub + BG_ROWS + tid : re - 1];
+            if (tid < BG_TQ)
+                thr_s[tid] = a.qthr[qrow_s[tid]]; // read by the selection, at least one barrier from here
+            bool okrow[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+            {
+                const int64_t row = sub + lane + 64 * u;
+                bool ok = row < re;
+                if (ok && a.alive)
+                {
+                    const uint32_t id = a.ids ? a.ids[row] : (uint32_t)row + a.id_base;
+                    ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
+                }
+                okrow[u] = ok;
+            }
+
+            f32x16 acc0, acc1, acc2, acc3; // one per 32-query column block
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                acc0[r] = 0.f;
+                acc1[r] = 0.f;
+                acc2[r] = 0.f;
+                acc3[r] = 0.f;
+            }
+            for (uint32_t ki = 0; ki < nk; ki++)
+            {
+                const bool more = pf_sub < re;
+                if (more)
+                    gload();
+                {
+                    const float * xa = &Xs[cur][(32 * wave + r32) * MF_LDX + 4 * h];
+                    const float * qb = &Qs[cur][r32 * MF_LDX + 4 * h];
+                    float4 av[4], bv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        av[i] = *reinterpret_cast<const float4 *>(xa + 8 * i);
+                    auto block = [&](f32x16 & acc, const int cb) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            bv[i] = *reinterpret_cast<const float4 *>(qb + cb * 32 * MF_LDX + 8 * i);
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                        {
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+                        }
+                    };
+                    block(acc0, 0);
+                    if (ncb > 1)
+                        block(acc1, 1);
+                    if (ncb > 2)
+                        block(acc2, 2);
+                    if (ncb > 3)
+                        block(acc3, 3);
+                }
+                if (ki + 1 < nk)
+                {
+                    sstore(cur ^ 1);
+                    __syncthreads();
+                    cur ^= 1;
+                }
+                if (more)
+                    advance();
+            }
+
+            __syncthreads(); // every wavefront is done reading the operand stages: they become the distance tile
+            auto put = [&](const f32x16 & acc, const float qnv, const uint32_t n0) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++)
+                {
+                    const uint32_t m0 = 32 * wave + 8 * g4 + 4 * h;
+                    float4 o;
+                    if (METRIC == M_L2)
+                    {
+                        o.x = fmaf(-2.f, acc[4 * g4 + 0], xn_s[m0 + 0]) + qnv;
+                        o.y = fmaf(-2.f, acc[4 * g4 + 1], xn_s[m0 + 1]) + qnv;
+                        o.z = fmaf(-2.f, acc[4 * g4 + 2], xn_s[m0 + 2]) + qnv;
+                        o.w = fmaf(-2.f, acc[4 * g4 + 3], xn_s[m0 + 3]) + qnv;
+                    }
+                    else
+                        o = make_float4(acc[4 * g4 + 0], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+                    *reinterpret_cast<float4 *>(&Ss[(n0 + r32) * MF_LDS + m0]) = o;
+                }
+            };
+            put(acc0, qn[0], 0);
+            if (ncb > 1)
+                put(acc1, qn[1], 32);
+            if (ncb > 2)
+                put(acc2, qn[2], 64);
+            if (ncb > 3)
+                put(acc3, qn[3], 96);
+            __syncthreads();
+            const uint32_t slice = (uint32_t)((sub - lbeg) / BG_ROWS);
+            for (uint32_t n = wave; n < nvalid; n += 4)
+            {
+                const uint32_t cut = thr_s[n];
+                uint64_t key[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                {
+                    const float v = Ss[n * MF_LDS + lane + 64 * u];
+                    const uint64_t kk = okrow[u] ? make_key<METRIC>(v, (uint32_t)(sub + lane + 64 * u)) : KEY_NONE;
+                    key[u] = (uint32_t)(kk >> 32) < cut ? kk : KEY_NONE;
+                }
+                uint64_t best = KEY_NONE;
+                if (__ballot(key[0] != KEY_NONE) | __ballot(key[1] != KEY_NONE))
+                {
+                    best = wave_select16(key[0], key[1], sel_s[wave], lane);
+                    if (lane == (uint32_t)BG_SLICE_K - 1 && best != KEY_NONE) // a full list: its last key cuts
+                        atomicMin(&a.qthr[qrow_s[n]], (uint32_t)(best >> 32));
+                }
+                if (lane < (uint32_t)BG_SLICE_K)
+                    a.partial[((size_t)qpair_s[n] * a.seg_max + slice) * BG_SLICE_K + lane] = best;
+            }
+            if (has_next)
+            {
+                __syncthreads(); // distance tile consumed: restage the first step of the next sub-tile
+                sstore(0);
+                if (METRIC == M_L2 && tid < BG_ROWS)
+                    xn_s[tid] = xn_next;
+                __syncthreads();
+                cur = 0;
+            }
+        }
+    }
+}
+
 struct RerankParams
 {
     const float4 * Y;      // rows, ld4 float4 each
@@ -316,6 +682,7 @@ struct RerankParams
     const float4 * Q;      // queries
     const float * qnorm;   // |q|^2 (approximate)
     const uint64_t * cand; // [nq][kc] ascending approximate keys, low word = row position
+    const uint64_t * bound; // nullable [nq]: smallest key any earlier stage may have dropped (KEY_NONE = none dropped)
     uint32_t kc, k, ld4;
     int64_t * out_ids; // [nq][k]
     float * out_dis;
@@ -382,8 +749,11 @@ __global__ __launch_bounds__(BLOCK) void ivf_rerank_kernel(const RerankParams a)
         const float v = key_value<METRIC>(key);
         a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
     }
-    // certificate (see the header comment); a candidate list that is not full holds every probed row
-    const uint64_t last = a.cand[(size_t)q * kc + kc - 1];
+    // certificate (see the header comment): `last` = the smallest approximate key a non-candidate row can have; a
+    // candidate list that is not full (and no truncated slice) holds every probed row
+    uint64_t last = a.cand[(size_t)q * kc + kc - 1];
+    if (a.bound && a.bound[q] < last)
+        last = a.bound[q];
     bool ok = true;
     if (last != KEY_NONE)
     {

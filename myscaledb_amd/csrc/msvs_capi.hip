@@ -634,15 +634,16 @@ namespace msvs
 struct IvfSearchPlan
 {
     uint32_t T;       // 1 = one query per block (ivf_scan_kernel); 2/4/8 = list-batched query tiles;
-                      // 32 (MF_TQ) = matrix-core candidate pass + canonical re-rank (mfma_scan_kernels.hpp)
+                      // 32 (MF_TQ) / 128 (BG_TQ) = matrix-core candidate pass + canonical re-rank (mfma_scan_kernels.hpp)
     uint32_t rpb;     // rows per work item
     uint32_t seg_max; // segments of the longest list
     uint32_t grid;    // batched: fixed grid size
-    // T == 32 only
+    // matrix-core pass only
     uint32_t kc;       // candidates kept per query
     uint32_t rpb1;     // rows per block / segments of the canonical fallback scan (one query per block)
     uint32_t seg_max1;
     uint32_t fb_slots; // block slots (grid z) of the fallback
+    bool mfma() const { return T == (uint32_t)MF_TQ || T == (uint32_t)BG_TQ; }
 };
 
 static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, uint32_t k)
@@ -651,30 +652,35 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     const size_t pairs = nq * nprobe;
     const size_t nlist = std::max<size_t>(ix.nlist, 1);
     const size_t avg = std::max<size_t>(1, ix.n / nlist);
-    // Matrix-core candidate pass: pays once ~16 queries share a list pass (the canonical scan is VALU-bound there);
+    // Matrix-core candidate pass: pays once ~8 queries share a list pass (the canonical scan is VALU-bound there);
     // needs finite, sane row norms for its error bound and k small enough for a 64-entry candidate list.
     {
-        const char * e = getenv("MSVS_IVF_MFMA"); // experiment knob: 0 = never, 2 = whenever eligible
+        // experiment knob: 0 = never, 2 = whenever eligible, 3 = whenever eligible with the 32-query-tile kernel
+        const char * e = getenv("MSVS_IVF_MFMA");
         const int mode = e ? atoi(e) : 1;
         const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f; // false for NaN
-        if (mode != 0 && eligible && (pairs >= 16 * nlist || mode == 2))
+        if (mode != 0 && eligible && (pairs >= 8 * nlist || mode >= 2))
         {
-            p.T = MF_TQ;
             p.kc = k <= 12 ? 32 : 64;
-            const size_t tiles = std::max<size_t>(1, pairs / MF_TQ);
+            const bool big = p.kc == (uint32_t)BG_KC && mode != 3; // 256-row x 128-query tiles (lists of 32 keys in LDS)
+            p.T = big ? BG_TQ : MF_TQ;
+            const size_t rows = big ? BG_ROWS : MF_ROWS;
+            const size_t tiles = std::max<size_t>(1, pairs / p.T);
             // a query's partial candidate lists (~1.3 * nprobe * avg / rpb of them, kc keys each) should fit the merge
             // block's LDS stage (HEADS_CAP keys)
             const size_t rpb_min = nprobe * avg * 13 / 10 * p.kc / 5000;
-            size_t rpb = round_up(std::max<size_t>(std::max<size_t>(avg * tiles / 2048, rpb_min), MF_ROWS), MF_ROWS);
+            size_t rpb = big ? 512 : std::max<size_t>(avg * tiles / 1024, rpb_min);
+            rpb = round_up(std::max<size_t>(rpb, 2 * MF_ROWS), rows);
             p.rpb = (uint32_t)std::min<size_t>(rpb, 1024);
             if (const char * r = getenv("MSVS_IVF_RPB"))
                 if (atoi(r) >= MF_ROWS)
-                    p.rpb = (uint32_t)round_up((size_t)atoi(r), MF_ROWS);
-            p.grid = 4096;
+                    p.rpb = (uint32_t)round_up((size_t)atoi(r), rows);
+            p.grid = big ? 2048 : 4096;
             if (const char * g = getenv("MSVS_IVF_GRID"))
                 if (atoi(g) >= 1)
                     p.grid = (uint32_t)atoi(g);
-            p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, p.rpb));
+            // big: the partial lists are per 128-row SLICE (16 keys each), whatever the work-item size
+            p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, big ? (size_t)BG_ROWS : (size_t)p.rpb));
             size_t rpb1 = round_up(std::max<size_t>(64, nprobe * avg * 3 / 2 / 400), 16);
             p.rpb1 = (uint32_t)std::min<size_t>(rpb1, 256);
             p.seg_max1 = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, p.rpb1));
@@ -734,8 +740,9 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k);
     size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + nq * nprobe * 4
         + (4 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
-    if (p.T == MF_TQ)
-        need += nq * nprobe * (size_t)p.seg_max * p.kc * 8 + nq * (size_t)p.kc * 8 + nq * 8 + 4096
+    if (p.mfma())
+        need += nq * nprobe * (size_t)p.seg_max * (p.T == (uint32_t)BG_TQ ? (size_t)BG_SLICE_K : (size_t)p.kc) * 8
+            + nq * (size_t)p.kc * 8 + nq * 16 + 8192
             + nq * nprobe * (size_t)p.seg_max1 * k * 8;
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
@@ -792,7 +799,8 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");
     const IvfSearchPlan pl = plan_ivf(ix, nq, nprobe, k);
-    uint64_t * partial = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max * (pl.T == MF_TQ ? pl.kc : k));
+    uint64_t * partial = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max
+                                            * (pl.T == (uint32_t)BG_TQ ? (uint32_t)BG_SLICE_K : (pl.mfma() ? pl.kc : k)));
     ScanParams a{};
     a.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
     a.ids = ix.row_ids.p;
@@ -809,7 +817,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     a.nprobe = (uint32_t)nprobe;
     a.seg_max = pl.seg_max;
     a.nlist = (uint32_t)ix.nlist;
-    if (pl.T == MF_TQ)
+    if (pl.mfma())
     {
         // many queries per list: matrix-core candidate pass, canonical re-rank, certified (mfma_scan_kernels.hpp)
         IvfPlanParams pp{};
@@ -818,7 +826,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         pp.n_pairs = (uint32_t)(nq * nprobe);
         pp.nlist = (uint32_t)ix.nlist;
         pp.rows_per_block = pl.rpb;
-        pp.T = MF_TQ;
+        pp.T = pl.T;
         uint32_t * counters = scr.take<uint32_t>(2 * ix.nlist + 1);
         pp.cnt = counters;
         pp.fill = counters + ix.nlist;
@@ -838,17 +846,26 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         a.k = pl.kc;
         a.qnorm = qnorm;
         a.xnorm = ix.xnorm.p;
-        launch_ivf_mfma_scan(scan_metric(m), pl.grid, a, stream);
+        const bool big = pl.T == (uint32_t)BG_TQ;
+        if (big)
+        {
+            a.qthr = scr.take<uint32_t>(nq);
+            MSVS_HIP(hipMemsetAsync(a.qthr, 0xFF, nq * sizeof(uint32_t), stream));
+        }
+        launch_ivf_mfma_scan(scan_metric(m), big, pl.grid, a, stream);
         uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
         IvfMergeParams cm{};
         cm.partial = partial;
         cm.probes = d_probes;
         cm.list_off = ix.list_off.p;
         cm.nprobe = (uint32_t)nprobe;
+        uint64_t * bound = big ? scr.take<uint64_t>(nq) : nullptr;
         cm.seg_max = pl.seg_max;
-        cm.rows_per_block = pl.rpb;
+        cm.rows_per_block = big ? (uint32_t)BG_ROWS : pl.rpb;
         cm.k = pl.kc;
+        cm.list_len = big ? (uint32_t)BG_SLICE_K : 0;
         cm.out_keys = cand;
+        cm.out_bound = bound;
         launch_ivf_merge(scan_metric(m), cm, (uint32_t)nq, stream);
         uint32_t * failq = scr.take<uint32_t>(nq);
         RerankParams rp{};
@@ -857,6 +874,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         rp.Q = a.Q;
         rp.qnorm = qnorm;
         rp.cand = cand;
+        rp.bound = bound;
         rp.kc = pl.kc;
         rp.k = k;
         rp.ld4 = ld / 4;
