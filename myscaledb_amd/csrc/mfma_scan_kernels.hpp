@@ -16,10 +16,14 @@
 //      one-query-per-block scan (ivf_scan_subset_kernel / ivf_merge_subset_kernel), stream-ordered, no host sync.
 //
 // The result is therefore ALWAYS identical to the canonical scan; eps only decides how often step 4 has work.
-// Error bound (u = 2^-24): the MFMA dot product of d terms, whatever its internal order and rounding mode, is within
-// 2d * 2^-23 * |x||q| of the true one; the f32 norms within d*u; the canonical sum of d separately rounded terms in
-// depth <= 18 within 21u of the true distance; so |a - canonical| <= c * (|x| + |q|)^2 (L2), c * |x||q| (IP) with
-// c = 1.05 * (2d * 2^-23 + 64u), and |x| <= sqrt(max row norm) of the index.
+// Error bound (u = 2^-24), all relative to |x||q| <= (|x|+|q|)^2 / 4 with |x| <= sqrt(max row norm of the index):
+//   c_dot   the MFMA inner product of n accumulated terms, whatever its internal order and rounding mode, is within
+//           n * 2^-23 of the true one: n = 2d for the f32 kernel; the split-bf16 kernel adds 3.1 * 2^-16 for the terms
+//           it drops and accumulates n = 3d terms;
+//   c_norm  the fma-accumulated f32 norms: d * u;
+//   c_canon the canonical result itself (d separately rounded terms, depth <= 18, + the sub/mul of L2): 32u;
+//   L2:  eps = 2 c_dot |x||q| + c_norm (|x|^2 + |q|^2) + c_canon (|x|+|q|)^2 (+ 2 roundings of the final a);
+//   IP:  eps = (c_dot + c_canon) |x||q|;   everything times 1.05.
 #pragma once
 
 #include "scan_kernels.hpp"
@@ -316,7 +320,12 @@ __global__ __launch_bounds__(BLOCK) void ivf_mfma_scan_kernel(const ScanParams a
 // insertion (~270 cycles) per accepted key.  This variant:
 //   * holds a 128-row x 128-query tile per workgroup: each of the 4 wavefronts owns 32 rows x 128 queries = 4 MFMA
 //     accumulators, so one LDS read of its rows feeds up to 4 products; 32-query column blocks without queries are
-//     skipped.  74 KB of LDS -> two workgroups per CU, one selecting while the other multiplies;
+//     skipped.  71 KB of LDS -> two workgroups per CU, one selecting while the other multiplies;
+//   * multiplies in SPLIT BF16 ("bf16x3"): every f32 operand is staged in LDS as hi = bf16(v) and lo = bf16(v - hi)
+//     (v - hi is exact in f32), and <x,q> ~= <xh,qh> + <xh,ql> + <xl,qh> on v_mfma_f32_32x32x16_bf16 with f32
+//     accumulation: 6 bf16 MFMAs (32 cycles each) per 32 reduction elements instead of 16 f32 MFMAs (64 cycles each),
+//     i.e. 5.3x less matrix-core time, for a relative error of 3 * 2^-16 on the products (the dropped xl*ql term and
+//     the two second-order residues) -- the same order as the bound already budgeted for the accumulation;
 //   * keeps no list: every (query, 128-row slice) emits its own 16 best rows (radix select over the wavefront's 128
 //     keys by ballots, then a 16-lane DPP bitonic sort) straight to global memory.  16 > k (<= 12 here), so a slice
 //     can only hide a row from the result if 16 better rows sit in the same slice; the merge reports
@@ -326,6 +335,18 @@ __global__ __launch_bounds__(BLOCK) void ivf_mfma_scan_kernel(const ScanParams a
 //     at once -- it is no better than a key the bound already accounts for -- so after the first few slices of a
 //     query almost every later slice has fewer than 16 survivors and skips the selection altogether.  Which rows get
 //     dropped depends on timing; the certified result does not.
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+/// Two f32 -> two bf16 (round to nearest even) packed in one dword, `a` in the low half.
+__device__ __forceinline__ uint32_t pack_bf16(const float a, const float b)
+{
+    bf16x2 t;
+    t[0] = (__bf16)a;
+    t[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, t);
+}
 
 constexpr int BG_ROWS = 128;
 constexpr int BG_TQ = 128;
@@ -421,17 +442,20 @@ template <int METRIC>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void ivf_mfma_scan_big_kernel(
     const ScanParams a)
 {
-    __shared__ __attribute__((aligned(16))) float stage[2 * (BG_ROWS + BG_TQ) * MF_LDX];
-    float(*const Xs)[BG_ROWS * MF_LDX] = reinterpret_cast<float(*)[BG_ROWS * MF_LDX]>(stage);
-    float(*const Qs)[BG_TQ * MF_LDX] = reinterpret_cast<float(*)[BG_TQ * MF_LDX]>(stage + 2 * BG_ROWS * MF_LDX);
+    // Operand stage: 2 buffers x 4 planes (rows hi, rows lo, queries hi, queries lo) x 128 rows x 64 B (32 bf16 of the
+    // reduction step).  A row's four 16-byte chunks are XOR-swizzled by (row >> 2) & 3, which makes both the 8-byte
+    // staging writes and the 16-lane ds_read_b128 operand reads bank-conflict free without padding.
+    constexpr uint32_t PLANE = BG_ROWS * 64, BUF = 4 * PLANE;
+    constexpr uint32_t STAGE_BYTES = 2 * BUF > BG_TQ * MF_LDS * 4 ? 2 * BUF : BG_TQ * MF_LDS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[STAGE_BYTES];
     __shared__ uint64_t sel_s[4][BG_SLICE_K];
     __shared__ uint32_t thr_s[BG_TQ];
     __shared__ float xn_s[BG_ROWS];
     __shared__ float qn_s[BG_TQ];
     __shared__ uint32_t qrow_s[BG_TQ];
     __shared__ uint32_t qpair_s[BG_TQ];
-    float * const Ss = stage; // distance tile [128 queries][128 rows (+4)]: reuses the operand stages
-    static_assert(BG_TQ * MF_LDS <= 2 * (BG_ROWS + BG_TQ) * MF_LDX, "distance tile must fit the operand stages");
+    float * const Ss = reinterpret_cast<float *>(stage); // distance tile [128 queries][128 rows (+4)]: reuses the stage
+    static_assert(BG_ROWS == BG_TQ, "one plane size for rows and queries");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
     const uint32_t ld4 = a.ld4;
@@ -523,14 +547,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     set_rows(pf_sub);
             }
         };
+        // float4 -> 4 bf16 hi + 4 bf16 lo, written to the swizzled position of (row, float4 column lc)
+        auto split_store = [&](unsigned char * hi_plane, const uint32_t row, const float4 v) {
+            const uint32_t h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+            const float fx = __uint_as_float(h01 << 16), fy = __uint_as_float(h01 & 0xffff0000u);
+            const float fz = __uint_as_float(h23 << 16), fw = __uint_as_float(h23 & 0xffff0000u);
+            const uint32_t l01 = pack_bf16(v.x - fx, v.y - fy), l23 = pack_bf16(v.z - fz, v.w - fw);
+            const uint32_t off = row * 64 + ((((lc >> 1) ^ (row >> 2)) & 3) << 4) + ((lc & 1) << 3);
+            *reinterpret_cast<uint2 *>(hi_plane + off) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2 *>(hi_plane + PLANE + off) = make_uint2(l01, l23);
+        };
         auto sstore = [&](int buf) {
+            unsigned char * base = stage + buf * BUF;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                *reinterpret_cast<float4 *>(&Xs[buf][(lr + 32 * i) * MF_LDX + 4 * lc]) = px[i];
+                split_store(base, lr + 32 * i, px[i]);
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 if (qld[i])
-                    *reinterpret_cast<float4 *>(&Qs[buf][(lr + 32 * i) * MF_LDX + 4 * lc]) = pq[i];
+                    split_store(base + 2 * PLANE, lr + 32 * i, pq[i]);
         };
         set_rows(rb);
         gload();
@@ -576,24 +611,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 if (more)
                     gload();
                 {
-                    const float * xa = &Xs[cur][(32 * wave + r32) * MF_LDX + 4 * h];
-                    const float * qb = &Qs[cur][r32 * MF_LDX + 4 * h];
-                    float4 av[4], bv[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        av[i] = *reinterpret_cast<const float4 *>(xa + 8 * i);
+                    // lane (r32, h) feeds row / query r32 with reduction elements 16*j + 8*h .. +7 (chunk 2j + h) of
+                    // each 32x32x16 product; both operands use the same positions, so the element order inside the
+                    // instruction does not matter
+                    const unsigned char * base = stage + cur * BUF;
+                    const uint32_t sw = (r32 >> 2) & 3;
+                    const uint32_t o0 = ((h ^ sw) & 3) << 4, o1 = (((2 + h) ^ sw) & 3) << 4;
+                    const unsigned char * xa = base + (32 * wave + r32) * 64;
+                    const unsigned char * qb = base + 2 * PLANE + r32 * 64;
+                    const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(xa + o0);
+                    const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(xa + o1);
+                    const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(xa + PLANE + o0);
+                    const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(xa + PLANE + o1);
                     auto block = [&](f32x16 & acc, const int cb) {
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            bv[i] = *reinterpret_cast<const float4 *>(qb + cb * 32 * MF_LDX + 8 * i);
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                        {
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
-                        }
+                        const unsigned char * q = qb + cb * 32 * 64;
+                        const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(q + o0);
+                        const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(q + o1);
+                        const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(q + PLANE + o0);
+                        const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(q + PLANE + o1);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc, 0, 0, 0);
                     };
                     block(acc0, 0);
                     if (ncb > 1)
@@ -687,8 +728,11 @@ struct RerankParams
     int64_t * out_ids; // [nq][k]
     float * out_dis;
     int cosine;
-    double eps_coef; // c of the header comment (times the experiment knob MSVS_IVF_EPS_SCALE)
-    float xmax;      // max |x|^2 over the index rows
+    // error model of the approximate pass (each times the experiment knob MSVS_IVF_EPS_SCALE):
+    double c_dot;   // |approximate <x,q> - true| <= c_dot * |x||q|
+    double c_norm;  // |approximate |v|^2 - true| <= c_norm * |v|^2
+    double c_canon; // |canonical result - true| <= c_canon * (|x|+|q|)^2 (L2), * |x||q| (IP)
+    float xmax;     // max |x|^2 over the index rows
     uint32_t * failq; // queries whose certificate failed ...
     uint32_t * nfail; // ... and their count (zeroed by the caller)
     unsigned long long * stat_fail; // nullable: process-wide running total
@@ -765,7 +809,11 @@ __global__ __launch_bounds__(BLOCK) void ivf_rerank_kernel(const RerankParams a)
         {
             const double al = (double)key_value<METRIC>(last), e = (double)key_value<METRIC>(ek);
             const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
-            const double eps = (METRIC == M_L2 ? a.eps_coef * (sx + sq) * (sx + sq) : a.eps_coef * sx * sq) + 1e-30;
+            // L2: a = |x|^2 + |q|^2 - 2<x,q> with approximate norms and product; IP: a = <x,q>
+            const double eps = (METRIC == M_L2 ? 2.0 * a.c_dot * sx * sq + a.c_norm * (sx * sx + sq * sq)
+                                        + (a.c_canon + 4e-7) * (sx + sq) * (sx + sq)
+                                               : (a.c_dot + a.c_canon) * sx * sq)
+                + 1e-30;
             ok = METRIC == M_L2 ? (al - eps > e) : (al + eps < e);
         }
     }

@@ -652,14 +652,14 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     const size_t pairs = nq * nprobe;
     const size_t nlist = std::max<size_t>(ix.nlist, 1);
     const size_t avg = std::max<size_t>(1, ix.n / nlist);
-    // Matrix-core candidate pass: pays once ~8 queries share a list pass (the canonical scan is VALU-bound there);
+    // Matrix-core candidate pass: pays once ~4 queries share a list pass (the canonical scan is VALU-bound there);
     // needs finite, sane row norms for its error bound and k small enough for a 64-entry candidate list.
     {
         // experiment knob: 0 = never, 2 = whenever eligible, 3 = whenever eligible with the 32-query-tile kernel
         const char * e = getenv("MSVS_IVF_MFMA");
         const int mode = e ? atoi(e) : 1;
         const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f; // false for NaN
-        if (mode != 0 && eligible && (pairs >= 8 * nlist || mode >= 2))
+        if (mode != 0 && eligible && (pairs >= 4 * nlist || mode >= 2))
         {
             p.kc = k <= 12 ? 32 : 64;
             const bool big = p.kc == (uint32_t)BG_KC && mode != 3; // 256-row x 128-query tiles (lists of 32 keys in LDS)
@@ -669,7 +669,7 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
             // a query's partial candidate lists (~1.3 * nprobe * avg / rpb of them, kc keys each) should fit the merge
             // block's LDS stage (HEADS_CAP keys)
             const size_t rpb_min = nprobe * avg * 13 / 10 * p.kc / 5000;
-            size_t rpb = big ? 512 : std::max<size_t>(avg * tiles / 1024, rpb_min);
+            size_t rpb = big ? 256 : std::max<size_t>(avg * tiles / 1024, rpb_min);
             rpb = round_up(std::max<size_t>(rpb, 2 * MF_ROWS), rows);
             p.rpb = (uint32_t)std::min<size_t>(rpb, 1024);
             if (const char * r = getenv("MSVS_IVF_RPB"))
@@ -882,7 +882,10 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         rp.out_dis = d_dis;
         rp.cosine = ix.metric == MSVS_METRIC_COSINE;
         const char * es = getenv("MSVS_IVF_EPS_SCALE"); // experiment / test knob: inflate eps to force the fallback
-        rp.eps_coef = 1.05 * (2.0 * (double)ix.dim * ldexp(1.0, -23) + 64.0 * ldexp(1.0, -24)) * (es ? atof(es) : 1.0);
+        const double scale = 1.05 * (es ? atof(es) : 1.0), dd = (double)ix.dim;
+        rp.c_dot = scale * (big ? 3.1 * ldexp(1.0, -16) + 3.05 * dd * ldexp(1.0, -23) : 2.0 * dd * ldexp(1.0, -23));
+        rp.c_norm = scale * (dd + 8.0) * ldexp(1.0, -24);
+        rp.c_canon = scale * 32.0 * ldexp(1.0, -24);
         rp.xmax = ix.xnorm_max;
         rp.failq = failq;
         rp.nfail = nfail;
