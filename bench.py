@@ -170,14 +170,23 @@ def main():
     # ---- roofline of the dominant kernel (HIP events on the launch stream, separate pass)
     capi.profile_reset()
     capi.profile_enable(True)
+    pf0 = capi.prefilter_stats()
     for i in range(min(args.steps, n_pool)):
         step(i)
     torch.cuda.synchronize()
     capi.profile_enable(False)
+    pf1 = capi.prefilter_stats()
     calls, total_ms = capi.profile_get("ivf_scan")
     c_calls, c_ms = capi.profile_get("flat_scan")
     m_calls, m_ms = capi.profile_get("merge")
+    others = {}
+    for fam in ("ivf_plan", "rerank", "fallback_scan", "fallback_merge"):
+        fc, fms = capi.profile_get(fam)
+        if fc:
+            others[fam] = round(fms / fc, 4)
     capi.profile_reset()
+    # which scan ran: the matrix-core candidate pass (split-bf16 MFMA + canonical re-rank) or the canonical VALU scan
+    cand_pass = pf1[0] > pf0[0]
     sr = [ix.scanned_rows(q_all[(i % n_pool) * B:(i % n_pool + 1) * B].cpu().numpy(), nprobe)
           for i in range(min(args.steps, n_pool))]
     rows_model = sum(r[0] for r in sr)     # sum over (query, probed list) of list length: SURVEY 8d per-query model
@@ -203,10 +212,12 @@ def main():
     # f32 VALU work of the same launch: 3 ops (sub, mul, add) per (query, row, element), vs the 78.6 T lane-op/s
     # non-packed VALU issue peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
     valu_frac = (rows_model * d * 3 / max(calls, 1)) / (scan_ms * 1e-3) / 78.6e12 if scan_ms > 0 else 0.0
-    # f32 compute roofline of the same launch: 3 flop (sub, mul, add; fma is forbidden by the parity contract) per
-    # (query, row, element) against the 157.3 TFLOP/s f32 peak (vector == f32-MFMA rate on gfx950)
-    F32_PEAK_TF = 157.3
-    flops_per_launch = rows_model * d * 3 / max(calls, 1)
+    # compute roofline of the same launch.  Canonical scan: 3 flop (sub, mul, add; fma is forbidden by the parity
+    # contract) per (query, row, element) against the 157.3 TFLOP/s f32 peak (vector == f32-MFMA rate on gfx950).
+    # Candidate pass: 3 bf16 products (hi*hi, hi*lo, lo*hi) = 6 flop per (query, row, element) against the dense bf16
+    # MFMA peak.
+    F32_PEAK_TF = 2500.0 if cand_pass else 157.3
+    flops_per_launch = rows_model * d * (6 if cand_pass else 3) / max(calls, 1)
     compute_tf = flops_per_launch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     if world > 1:
         # report the slowest rank's kernel (bytes / flops are this rank's local lists)
@@ -295,21 +306,25 @@ def main():
             "p99_ms_batch1": round(float(np.percentile(lat, 99)), 4) if lat else None,
             "roofline": dict(roof, **{
                 "traffic": traffic,
-                "kernel": "ivf_batched_scan_kernel (T-query tiles per list pass)" if B * nprobe >= nlist
-                else "ivf_scan_kernel", "launch_ms": round(scan_ms, 4),
+                "kernel": ("ivf_mfma_scan_big_kernel (128x128 tiles, split-bf16 MFMA candidate pass; canonical re-rank "
+                           "+ certificate follow)") if cand_pass else (
+                    "ivf_batched_scan_kernel (T-query tiles per list pass)" if B * nprobe >= nlist
+                    else "ivf_scan_kernel"), "launch_ms": round(scan_ms, 4),
                 "bytes_per_launch": int(bytes_per_launch), "flops_per_launch": int(flops_per_launch),
                 "note": "hbm: achieved = union of the batch's probed rows x (4d+4) B / kernel time (each probed row "
-                        "must leave HBM at least once per launch); mfma: 3 flop per (query,row,element) / kernel time "
-                        "vs the 157.3 TFLOP/s f32 peak (f32 VALU == f32 MFMA rate; fma/MFMA are excluded by the parity "
-                        "contract) -- the larger fraction is the binding roofline; traffic = FETCH_SIZE x2 + WRITE_SIZE "
-                        "per launch from rocprofv3 --pmc (profiles/); per_query_model_gbs = SURVEY 8d per-query bytes x "
-                        "queries / time and streamed_model_gbs = bytes if every (list, query tile) pass went to HBM: "
-                        "both exceed HBM speed because a list pass is shared by a tile of queries and the tiles of one "
-                        "list share an XCD's L2",
+                        "must leave HBM at least once per launch); mfma: canonical scan = 3 flop per (query,row,element)"
+                        " vs the 157.3 TFLOP/s f32 peak (fma is excluded by the parity contract), candidate pass = 6 "
+                        "flop per (query,row,element) (three bf16 products) vs the 2500 TFLOP/s dense bf16 peak -- the "
+                        "larger fraction is the binding roofline; traffic = FETCH_SIZE x2 + WRITE_SIZE per launch from "
+                        "rocprofv3 --pmc (profiles/); per_query_model_gbs = SURVEY 8d per-query bytes x queries / time: "
+                        "it exceeds HBM speed because one pass over a list serves every query of the batch that probes "
+                        "it; prefilter = (queries through the candidate pass, queries that needed the canonical "
+                        "fallback) during the profiled steps",
                 "per_query_model_gbs": round(model_gbs, 1), "streamed_model_gbs": round(streamed_gbs, 1),
-                "valu_lane_op_frac": round(valu_frac, 4),
-                "other_kernels_ms": {"coarse_flat_scan": round(c_ms / max(c_calls, 1), 4),
-                                     "merge(avg of 2)": round(m_ms / max(m_calls, 1), 4)}}),
+                "valu_lane_op_frac": None if cand_pass else round(valu_frac, 4),
+                "prefilter": [pf1[0] - pf0[0], pf1[1] - pf0[1]],
+                "other_kernels_ms": dict(others, **{"coarse_flat_scan": round(c_ms / max(c_calls, 1), 4),
+                                                    "merge(avg of 2)": round(m_ms / max(m_calls, 1), 4)})}),
             "cpu_baseline": cpu,
             "setup_s": round(setup_s, 1),
         }

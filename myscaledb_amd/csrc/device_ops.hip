@@ -354,6 +354,17 @@ void launch_ivf_mfma_scan(int metric, bool big, uint32_t grid, ScanParams a, hip
     MSVS_HIP(hipGetLastError());
 }
 
+void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint32_t * qthr, uint32_t cap, uint32_t nq,
+                        uint32_t kc, uint64_t * out, uint64_t * bound, hipStream_t stream)
+{
+    if (nq == 0)
+        return;
+    ProfileScope prof("merge", stream);
+    hipLaunchKernelGGL(cand_select_kernel, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap,
+                       nq, kc, out, bound);
+    MSVS_HIP(hipGetLastError());
+}
+
 void launch_ivf_rerank(int metric, RerankParams a, uint32_t nq, hipStream_t stream)
 {
     if (nq == 0)

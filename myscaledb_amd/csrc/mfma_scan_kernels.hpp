@@ -326,10 +326,11 @@ __global__ __launch_bounds__(BLOCK) void ivf_mfma_scan_kernel(const ScanParams a
 //     accumulation: 6 bf16 MFMAs (32 cycles each) per 32 reduction elements instead of 16 f32 MFMAs (64 cycles each),
 //     i.e. 5.3x less matrix-core time, for a relative error of 3 * 2^-16 on the products (the dropped xl*ql term and
 //     the two second-order residues) -- the same order as the bound already budgeted for the accumulation;
-//   * keeps no list: every (query, 128-row slice) emits its own 16 best rows (radix select over the wavefront's 128
-//     keys by ballots, then a 16-lane DPP bitonic sort) straight to global memory.  16 > k (<= 12 here), so a slice
-//     can only hide a row from the result if 16 better rows sit in the same slice; the merge reports
-//     bound = min(32nd merged key, 16th key of every FULL slice list) and the re-rank certifies against that bound;
+//   * keeps no list: every (query, 128-row slice) appends its own 16 best rows (radix select over the wavefront's
+//     128 keys by ballots, then a 16-lane DPP bitonic sort) to the query's candidate buffer in global memory (atomic
+//     cursor).  16 > k (<= 12 here), so a slice can only hide a row from the result if 16 better rows sit in the same
+//     slice; cand_select_kernel then keeps the 32 best candidates of the query, and the re-rank certifies against
+//     bound = min(32nd candidate, 16th key of every FULL slice list) -- the second term is exactly qthr below;
 //   * shares ONE number per query across the whole grid: qthr[q] = the smallest 16th-key distance any full slice list
 //     of the query has emitted so far (atomicMin).  A row whose approximate distance is not below it can be dropped
 //     at once -- it is no better than a key the bound already accounts for -- so after the first few slices of a
@@ -436,8 +437,8 @@ __device__ __forceinline__ uint64_t wave_select16(const uint64_t k0, const uint6
 }
 
 /// Work item = (list, tile of <= 128 probing queries, segment of a.rows_per_block rows (a multiple of 128)); plan built
-/// with T = BG_TQ.  a.partial[(pair * a.seg_max + slice) * 16 ...] receives the 16 best (approximate key, row position)
-/// of 128-row slice `slice` of the pair's list; a.seg_max = slices of the longest list.
+/// with T = BG_TQ.  Every (query, 128-row slice) appends its <= 16 best (approximate key, row position) at
+/// a.partial[q * a.cand_cap + atomicAdd(a.qcnt[q], n)]; a.cand_cap >= 16 * (slices the query can meet).
 template <int METRIC>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void ivf_mfma_scan_big_kernel(
     const ScanParams a)
@@ -681,7 +682,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             if (ncb > 3)
                 put(acc3, qn[3], 96);
             __syncthreads();
-            const uint32_t slice = (uint32_t)((sub - lbeg) / BG_ROWS);
             for (uint32_t n = wave; n < nvalid; n += 4)
             {
                 const uint32_t cut = thr_s[n];
@@ -693,15 +693,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     const uint64_t kk = okrow[u] ? make_key<METRIC>(v, (uint32_t)(sub + lane + 64 * u)) : KEY_NONE;
                     key[u] = (uint32_t)(kk >> 32) < cut ? kk : KEY_NONE;
                 }
-                uint64_t best = KEY_NONE;
                 if (__ballot(key[0] != KEY_NONE) | __ballot(key[1] != KEY_NONE))
                 {
-                    best = wave_select16(key[0], key[1], sel_s[wave], lane);
+                    const uint64_t best = wave_select16(key[0], key[1], sel_s[wave], lane);
+                    const uint32_t q = qrow_s[n];
+                    const uint32_t nsel = __popcll(__ballot(best != KEY_NONE)); // lanes 0 .. nsel-1, ascending
+                    uint32_t pos = 0;
+                    if (lane == 0)
+                        pos = atomicAdd(&a.qcnt[q], nsel);
+                    pos = __builtin_amdgcn_readfirstlane(pos);
+                    if (lane < nsel)
+                        a.partial[(size_t)q * a.cand_cap + pos + lane] = best;
                     if (lane == (uint32_t)BG_SLICE_K - 1 && best != KEY_NONE) // a full list: its last key cuts
-                        atomicMin(&a.qthr[qrow_s[n]], (uint32_t)(best >> 32));
+                        atomicMin(&a.qthr[q], (uint32_t)(best >> 32));
                 }
-                if (lane < (uint32_t)BG_SLICE_K)
-                    a.partial[((size_t)qpair_s[n] * a.seg_max + slice) * BG_SLICE_K + lane] = best;
             }
             if (has_next)
             {
@@ -714,6 +719,42 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
         }
     }
+}
+
+/// The kc (<= 64) best of the keys a query's slices appended (unsorted runs), ascending, one block per query (the
+/// 4 wavefronts take interleaved 256-key chunks, then a rank merge): out[q][kc] (KEY_NONE padded);
+/// bound[q] = the smallest key any slice may have cut (from qthr; KEY_NONE if none).
+static __global__ __launch_bounds__(BLOCK) void cand_select_kernel(const uint64_t * buf, const uint32_t * qcnt,
+                                                                    const uint32_t * qthr, uint32_t cap, uint32_t nq,
+                                                                    uint32_t kc, uint64_t * out, uint64_t * bound)
+{
+    __shared__ uint64_t lds[5 * 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    const uint32_t n = qcnt[q] < cap ? qcnt[q] : cap;
+    const uint64_t * src = buf + (size_t)q * cap;
+    WaveTopK<1> top;
+    top.init();
+    for (uint32_t base = wave * 4 * WAVE; base < n; base += 4 * 4 * WAVE)
+    {
+        uint64_t key[4]; // 4 independent loads in flight before the first (serialising) offer
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const uint32_t i = base + u * WAVE + lane;
+            key[u] = i < n ? src[i] : KEY_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            top.offer(key[u], kc, lane);
+    }
+    top.store(lds + wave * kc, kc, lane);
+    __syncthreads();
+    uint64_t * merged = lds + 4 * kc;
+    block_rank_merge(lds, kc, merged, kc, tid);
+    if (tid < kc)
+        out[(size_t)q * kc + tid] = merged[tid];
+    if (tid == 0)
+        bound[q] = qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32;
 }
 
 struct RerankParams

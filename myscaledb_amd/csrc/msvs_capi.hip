@@ -742,7 +742,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + (4 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
     if (p.mfma())
         need += nq * nprobe * (size_t)p.seg_max * (p.T == (uint32_t)BG_TQ ? (size_t)BG_SLICE_K : (size_t)p.kc) * 8
-            + nq * (size_t)p.kc * 8 + nq * 16 + 8192
+            + nq * (size_t)p.kc * 8 + nq * 24 + 8192
             + nq * nprobe * (size_t)p.seg_max1 * k * 8;
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
@@ -847,26 +847,40 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         a.qnorm = qnorm;
         a.xnorm = ix.xnorm.p;
         const bool big = pl.T == (uint32_t)BG_TQ;
+        const size_t cand_cap = nprobe * (size_t)pl.seg_max * BG_SLICE_K; // big: appended keys per query, worst case
+        if (big && cand_cap > 0xffffffffull)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "candidate buffer too large");
         if (big)
         {
-            a.qthr = scr.take<uint32_t>(nq);
+            // per query: running cut (0xFFFFFFFF = none yet) and append cursor of its candidate buffer (= `partial`)
+            uint32_t * qstate = scr.take<uint32_t>(2 * nq);
+            a.qthr = qstate;
+            a.qcnt = qstate + nq;
+            a.cand_cap = (uint32_t)cand_cap;
             MSVS_HIP(hipMemsetAsync(a.qthr, 0xFF, nq * sizeof(uint32_t), stream));
+            MSVS_HIP(hipMemsetAsync(a.qcnt, 0, nq * sizeof(uint32_t), stream));
         }
         launch_ivf_mfma_scan(scan_metric(m), big, pl.grid, a, stream);
         uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
-        IvfMergeParams cm{};
-        cm.partial = partial;
-        cm.probes = d_probes;
-        cm.list_off = ix.list_off.p;
-        cm.nprobe = (uint32_t)nprobe;
-        uint64_t * bound = big ? scr.take<uint64_t>(nq) : nullptr;
-        cm.seg_max = pl.seg_max;
-        cm.rows_per_block = big ? (uint32_t)BG_ROWS : pl.rpb;
-        cm.k = pl.kc;
-        cm.list_len = big ? (uint32_t)BG_SLICE_K : 0;
-        cm.out_keys = cand;
-        cm.out_bound = bound;
-        launch_ivf_merge(scan_metric(m), cm, (uint32_t)nq, stream);
+        uint64_t * bound = nullptr;
+        if (big)
+        {
+            bound = scr.take<uint64_t>(nq);
+            launch_cand_select(partial, a.qcnt, a.qthr, a.cand_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
+        }
+        else
+        {
+            IvfMergeParams cm{};
+            cm.partial = partial;
+            cm.probes = d_probes;
+            cm.list_off = ix.list_off.p;
+            cm.nprobe = (uint32_t)nprobe;
+            cm.seg_max = pl.seg_max;
+            cm.rows_per_block = pl.rpb;
+            cm.k = pl.kc;
+            cm.out_keys = cand;
+            launch_ivf_merge(scan_metric(m), cm, (uint32_t)nq, stream);
+        }
         uint32_t * failq = scr.take<uint32_t>(nq);
         RerankParams rp{};
         rp.Y = a.Y;

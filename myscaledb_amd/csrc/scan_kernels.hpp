@@ -238,6 +238,8 @@ struct ScanParams
     const uint32_t * qmap;   // subset kernels: the queries to process ...
     const uint32_t * qcount; // ... and how many of them (device side)
     uint32_t * qthr;         // big-tile candidate pass: per-query running cut (ordered distance word), see there
+    uint32_t * qcnt;         // big-tile candidate pass: keys emitted so far per query (append cursor into `partial`)
+    uint32_t cand_cap;       // ... whose row for query q is partial[q * cand_cap ...]
 };
 
 /// Scans rows [row_begin,row_end) for T queries already staged in LDS (qs[t*ld4 + c]) and leaves the block's
