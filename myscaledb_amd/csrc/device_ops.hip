@@ -354,6 +354,15 @@ void launch_ivf_mfma_scan(int metric, bool big, uint32_t grid, ScanParams a, hip
     MSVS_HIP(hipGetLastError());
 }
 
+void launch_single_list_plan(uint32_t nq, uint32_t nrows, uint32_t rows_per_block, uint32_t tq, uint32_t * pairs,
+                             int32_t * probes0, int64_t * list_off, uint32_t * pair_off, uint32_t * work_off,
+                             hipStream_t stream)
+{
+    hipLaunchKernelGGL(single_list_plan_kernel, dim3((unsigned)ceil_div(std::max<uint32_t>(nq, 1), 256u)), dim3(256), 0,
+                       stream, nq, nrows, rows_per_block, tq, pairs, probes0, list_off, pair_off, work_off);
+    MSVS_HIP(hipGetLastError());
+}
+
 void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint32_t * qthr, uint32_t cap, uint32_t nq,
                         uint32_t kc, uint64_t * out, uint64_t * bound, hipStream_t stream)
 {

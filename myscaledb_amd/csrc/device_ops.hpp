@@ -83,6 +83,11 @@ void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uin
 /// tile kernel (plan built with T = BG_TQ, a.k == BG_KC), else 128 x 32 tiles (T = MF_TQ).
 void launch_ivf_mfma_scan(int metric, bool big, uint32_t grid, ScanParams a, hipStream_t stream);
 
+/// One-list plan over a plain row table (see single_list_plan_kernel).
+void launch_single_list_plan(uint32_t nq, uint32_t nrows, uint32_t rows_per_block, uint32_t tq, uint32_t * pairs,
+                             int32_t * probes0, int64_t * list_off, uint32_t * pair_off, uint32_t * work_off,
+                             hipStream_t stream);
+
 /// Big-tile pass only: the kc best of every query's appended candidates + the bound of what the slices cut.
 void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint32_t * qthr, uint32_t cap, uint32_t nq,
                         uint32_t kc, uint64_t * out, uint64_t * bound, hipStream_t stream);

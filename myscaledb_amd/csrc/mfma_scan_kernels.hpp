@@ -721,6 +721,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
 }
 
+/// The one-list "plan" that lets the candidate pass run over a plain row table (the coarse quantiser's centroids):
+/// every query probes list 0 = rows [0, nrows).
+static __global__ void single_list_plan_kernel(uint32_t nq, uint32_t nrows, uint32_t rows_per_block, uint32_t tq,
+                                               uint32_t * pairs, int32_t * probes0, int64_t * list_off,
+                                               uint32_t * pair_off, uint32_t * work_off)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq)
+    {
+        pairs[i] = i;
+        probes0[i] = 0;
+    }
+    if (i == 0)
+    {
+        list_off[0] = 0;
+        list_off[1] = nrows;
+        pair_off[0] = 0;
+        pair_off[1] = nq;
+        work_off[0] = 0;
+        work_off[1] = ((nq + tq - 1) / tq) * ((nrows + rows_per_block - 1) / rows_per_block);
+    }
+}
+
 /// The kc (<= 64) best of the keys a query's slices appended (unsorted runs), ascending, one block per query (the
 /// 4 wavefronts take interleaved 256-key chunks, then a rank merge): out[q][kc] (KEY_NONE padded);
 /// bound[q] = the smallest key any slice may have cut (from qthr; KEY_NONE if none).
@@ -768,6 +791,7 @@ struct RerankParams
     uint32_t kc, k, ld4;
     int64_t * out_ids; // [nq][k]
     float * out_dis;
+    int32_t * out_probes; // non-null: write [nq][k] int32 ids instead (the coarse quantiser's probe lists)
     int cosine;
     // error model of the approximate pass (each times the experiment knob MSVS_IVF_EPS_SCALE):
     double c_dot;   // |approximate <x,q> - true| <= c_dot * |x||q|
@@ -830,9 +854,14 @@ __global__ __launch_bounds__(BLOCK) void ivf_rerank_kernel(const RerankParams a)
     {
         const uint64_t key = top.v[0];
         const size_t o = (size_t)q * a.k + lane;
-        a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
-        const float v = key_value<METRIC>(key);
-        a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+        if (a.out_probes)
+            a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
+        else
+        {
+            a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
+            const float v = key_value<METRIC>(key);
+            a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+        }
     }
     // certificate (see the header comment): `last` = the smallest approximate key a non-candidate row can have; a
     // candidate list that is not full (and no truncated slice) holds every probed row

@@ -254,6 +254,8 @@ struct msvs_index
     // matrix-core candidate pass (mfma_scan_kernels.hpp): |x|^2 of every stored row and their maximum
     DevBuf<float> xnorm;
     float xnorm_max = 0.f;
+    DevBuf<float> cnorm; // same for the centroids (the coarse quantiser goes through the same pass)
+    float cnorm_max = 0.f;
     bool ready = false;
 };
 
@@ -262,9 +264,19 @@ static void index_finalize_norms(msvs_index & ix, hipStream_t stream)
 {
     ix.xnorm.alloc(std::max<size_t>(ix.n, 1));
     ix.xnorm_max = 0.f;
+    DevBuf<uint32_t> mx(1);
+    if (ix.type == MSVS_INDEX_IVFFLAT && ix.nlist)
+    {
+        ix.cnorm.alloc(ix.nlist);
+        MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
+        launch_row_sqnorm(ix.centroids.p, ix.cnorm.p, ix.nlist, ix.ld / 4, mx.p, stream);
+        uint32_t cb = 0;
+        MSVS_HIP(hipMemcpyAsync(&cb, mx.p, 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+        memcpy(&ix.cnorm_max, &cb, 4);
+    }
     if (ix.n == 0)
         return;
-    DevBuf<uint32_t> mx(1);
     MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
     launch_row_sqnorm(ix.vecs.p, ix.xnorm.p, ix.n, ix.ld / 4, mx.p, stream);
     uint32_t bits = 0;
@@ -623,7 +635,7 @@ extern "C" size_t msvs_index_num_lists(const msvs_index_t * ix)
 extern "C" size_t msvs_index_memory_usage(const msvs_index_t * ix)
 {
     return ix ? ix->vecs.bytes() + ix->row_ids.bytes() + ix->centroids.bytes() + ix->list_off.bytes()
-            + ix->xnorm.bytes()
+            + ix->xnorm.bytes() + ix->cnorm.bytes()
               : 0;
 }
 
@@ -732,13 +744,16 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     return p;
 }
 
+static size_t coarse_pass_scratch(const msvs_index & ix, size_t nq, size_t nprobe);
+
 static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k, size_t nprobe)
 {
     size_t b = nq * (size_t)ix.ld * 4 + 4096;
     if (ix.type == MSVS_INDEX_FLAT)
         return b + flat_scratch_bytes(ix.n, nq, k);
     IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k);
-    size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + nq * nprobe * 4
+    size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + coarse_pass_scratch(ix, nq, nprobe)
+        + nq * nprobe * 4
         + (4 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
     if (p.mfma())
         need += nq * nprobe * (size_t)p.seg_max * (p.T == (uint32_t)BG_TQ ? (size_t)BG_SLICE_K : (size_t)p.kc) * 8
@@ -747,6 +762,121 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
     return need;
+}
+
+static bool coarse_pass_eligible(const msvs_index & ix, size_t nq, size_t nprobe)
+{
+    const char * e = getenv("MSVS_COARSE_MFMA"); // experiment knob: 0 = never, 2 = whenever eligible
+    const int mode = e ? atoi(e) : 1;
+    // worth it once the (128-query tile) x (128-centroid slice) grid can occupy the chip: 64 work items measured no
+    // better than the canonical flat scan, 256 items 2x better (1M x 768 bench, profiles/)
+    const size_t items = ceil_div(nq, (size_t)BG_TQ) * ceil_div(ix.nlist, (size_t)BG_ROWS);
+    return mode != 0 && ix.cnorm.p && ix.cnorm_max < 1e30f && nprobe <= 40 && ix.nlist >= 256
+        && (items >= 128 || mode == 2);
+}
+
+static size_t coarse_pass_scratch(const msvs_index & ix, size_t nq, size_t nprobe)
+{
+    const size_t nslices = ceil_div(ix.nlist, (size_t)BG_ROWS);
+    return nq * (nslices * BG_SLICE_K * 8 + 64 * 8 + 96) + nq * ceil_div(ix.nlist, (size_t)256) * nprobe * 8 + 65536;
+}
+
+/// Coarse quantiser through the matrix-core candidate pass: the centroid table is one "list" every query probes;
+/// 16 candidates per (query, 128-centroid slice) -> 64 per query -> canonical re-rank -> exact top-nprobe with the
+/// same certificate / canonical fallback as the list scan (mfma_scan_kernels.hpp).  Probe SETS equal the exact scan's.
+static void coarse_by_candidate_pass(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq,
+                                     size_t nprobe, int32_t * d_probes, hipStream_t stream)
+{
+    const uint32_t ld = ix.ld, nrows = (uint32_t)ix.nlist, kc = 64;
+    const uint32_t nslices = (uint32_t)ceil_div(ix.nlist, (size_t)BG_ROWS);
+    const uint32_t cap = nslices * BG_SLICE_K;
+    uint32_t * pairs = scr.take<uint32_t>(nq);
+    int32_t * probes0 = scr.take<int32_t>(nq);
+    int64_t * list_off = scr.take<int64_t>(2);
+    uint32_t * small = scr.take<uint32_t>(5); // pair_off[2], work_off[2], nfail
+    uint32_t * qstate = scr.take<uint32_t>(2 * nq);
+    float * qnorm = scr.take<float>(nq);
+    uint64_t * candbuf = scr.take<uint64_t>(nq * (size_t)cap);
+    uint64_t * cand = scr.take<uint64_t>(nq * (size_t)kc);
+    uint64_t * bound = scr.take<uint64_t>(nq);
+    uint32_t * failq = scr.take<uint32_t>(nq);
+    const uint32_t rpb1 = 256, seg_max1 = (uint32_t)ceil_div(ix.nlist, (size_t)rpb1);
+    uint64_t * partial1 = scr.take<uint64_t>(nq * (size_t)seg_max1 * nprobe);
+    uint32_t * nfail = small + 4;
+    MSVS_HIP(hipMemsetAsync(small, 0, 5 * sizeof(uint32_t), stream));
+    MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
+    MSVS_HIP(hipMemsetAsync(qstate + nq, 0, nq * sizeof(uint32_t), stream));
+    launch_single_list_plan((uint32_t)nq, nrows, BG_ROWS, BG_TQ, pairs, probes0, list_off, small, small + 2, stream);
+    launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
+    ScanParams a{};
+    a.Y = reinterpret_cast<const float4 *>(ix.centroids.p);
+    a.Q = reinterpret_cast<const float4 *>(dq);
+    a.partial = candbuf;
+    a.ld4 = ld / 4;
+    a.k = BG_KC;
+    a.nq = (uint32_t)nq;
+    a.rows_per_block = BG_ROWS;
+    a.probes = probes0;
+    a.list_off = list_off;
+    a.nprobe = 1;
+    a.seg_max = nslices;
+    a.pairs = pairs;
+    a.pair_off = small;
+    a.work_off = small + 2;
+    a.nlist = 1;
+    a.xcd_order = 1;
+    a.qnorm = qnorm;
+    a.xnorm = ix.cnorm.p;
+    a.qthr = qstate;
+    a.qcnt = qstate + nq;
+    a.cand_cap = cap;
+    const size_t items = ceil_div(nq, (size_t)BG_TQ) * nslices;
+    {
+        ProfileScope prof("coarse_pass", stream);
+        launch_ivf_mfma_scan(scan_metric(m), true, (uint32_t)std::min<size_t>(items, 2048), a, stream);
+        launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
+        RerankParams rp{};
+        rp.Y = a.Y;
+        rp.Q = a.Q;
+        rp.qnorm = qnorm;
+        rp.cand = cand;
+        rp.bound = bound;
+        rp.kc = kc;
+        rp.k = (uint32_t)nprobe;
+        rp.ld4 = ld / 4;
+        rp.out_probes = d_probes;
+        const char * es = getenv("MSVS_IVF_EPS_SCALE");
+        const double scale = 1.05 * (es ? atof(es) : 1.0), dd = (double)ix.dim;
+        rp.c_dot = scale * (3.1 * ldexp(1.0, -16) + 3.05 * dd * ldexp(1.0, -23));
+        rp.c_norm = scale * (dd + 8.0) * ldexp(1.0, -24);
+        rp.c_canon = scale * 32.0 * ldexp(1.0, -24);
+        rp.xmax = ix.cnorm_max;
+        rp.failq = failq;
+        rp.nfail = nfail;
+        launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
+        // queries without a certificate: canonical scan of the centroid table
+        ScanParams c = a;
+        c.k = (uint32_t)nprobe;
+        c.partial = partial1;
+        c.rows_per_block = rpb1;
+        c.seg_max = seg_max1;
+        c.qmap = failq;
+        c.qcount = nfail;
+        const uint32_t slots = (uint32_t)std::min<size_t>(nq, 8);
+        launch_ivf_scan_subset(scan_metric(m), c, slots, stream);
+        IvfMergeParams fm{};
+        fm.partial = partial1;
+        fm.probes = probes0;
+        fm.list_off = list_off;
+        fm.nprobe = 1;
+        fm.seg_max = seg_max1;
+        fm.rows_per_block = rpb1;
+        fm.k = (uint32_t)nprobe;
+        fm.out_probes = d_probes;
+        fm.qmap = failq;
+        fm.qcount = nfail;
+        launch_ivf_merge_subset(scan_metric(m), fm, slots, stream);
+    }
 }
 
 /// The search proper: all pointers on the device, everything enqueued on `stream`.
@@ -791,10 +921,16 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     }
     // 1. coarse quantiser: exact top-nprobe of the centroids (canonical arithmetic, so probes match the oracle)
     int32_t * d_probes = scr.take<int32_t>(nq * nprobe);
-    MergeParams co{};
-    co.mode = 1;
-    co.out_probes = d_probes;
-    flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co, stream);
+    if (coarse_pass_eligible(ix, nq, nprobe))
+        coarse_by_candidate_pass(ix, scr, m, dq, nq, nprobe, d_probes, stream);
+    else
+    {
+        MergeParams co{};
+        co.mode = 1;
+        co.out_probes = d_probes;
+        flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co,
+                           stream);
+    }
     // 2. scan the probed lists
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");

@@ -728,6 +728,7 @@ struct IvfMergeParams
     float * out_dis;
     int cosine;
     uint64_t * out_keys;     // non-null: write the merged keys [nq][k] instead of (ids, distances)
+    int32_t * out_probes;    // non-null: write [nq][k] int32 ids instead (the coarse quantiser's probe lists)
     uint32_t list_len;       // length of a partial list (0: k); may be < k when the lists are per-slice pre-selections
     uint64_t * out_bound;    // nullable [nq]: min over the FULL partial lists of their last key (what they may have cut)
     const uint32_t * qmap;   // subset kernel: the queries to merge ...
@@ -744,6 +745,8 @@ __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const 
         const size_t o = (size_t)q * k + i;
         if (a.out_keys)
             a.out_keys[o] = key;
+        else if (a.out_probes)
+            a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
         else
         {
             a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;

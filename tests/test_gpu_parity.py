@@ -265,6 +265,34 @@ def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, 
     assert capi.prefilter_stats()[0] == q2
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+def test_coarse_quantiser_through_the_candidate_pass(metric, monkeypatch):
+    """nlist >= 256 and >= 512 queries: the top-nprobe centroids come from the matrix-core pass + canonical re-rank;
+    the probe SETS must equal the exact scan's, hence so must the final answer (with and without certificates)."""
+    rng = np.random.default_rng(2025)
+    n, d, nlist, nq, nprobe, k = 40000, 64, 320, 600, 12, 10
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, metric, nlist)
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+    monkeypatch.setenv("MSVS_COARSE_MFMA", "2")  # whenever eligible (by default only from ~128 tile x slice items on)
+    capi.profile_reset()
+    capi.profile_enable(True)
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    capi.profile_enable(False)
+    assert capi.profile_get("coarse_pass")[0] == 1  # the pass is the one that ran
+    capi.profile_reset()
+    same(ids, dis, oi, od)
+    monkeypatch.setenv("MSVS_IVF_EPS_SCALE", "1e12")  # every certificate fails: canonical fallbacks everywhere
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
+    monkeypatch.setenv("MSVS_COARSE_MFMA", "0")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+
+
 def test_matrix_core_pass_with_massive_ties_and_unusable_norms():
     rng = np.random.default_rng(77)
     n, d, nlist, nq = 6000, 48, 4, 128
