@@ -333,24 +333,15 @@ void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uin
     MSVS_HIP(hipGetLastError());
 }
 
-void launch_ivf_mfma_scan(int metric, bool big, uint32_t grid, ScanParams a, hipStream_t stream)
+void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t stream)
 {
     if (grid == 0)
         return;
-    if (a.k > 64 || (big && a.k != (uint32_t)BG_KC && a.k != (uint32_t)BG_SLICE_K))
-        fail(MSVS_ERR_DEVICE, "internal: candidate count %u not supported", a.k);
     ProfileScope prof("ivf_scan", stream);
-    if (big)
-    {
-        if (metric == M_IP)
-            hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_IP>), dim3(grid), dim3(BLOCK), 0, stream, a);
-        else
-            hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_L2>), dim3(grid), dim3(BLOCK), 0, stream, a);
-    }
-    else if (metric == M_IP)
-        hipLaunchKernelGGL((ivf_mfma_scan_kernel<M_IP>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    if (metric == M_IP)
+        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_IP>), dim3(grid), dim3(BLOCK), 0, stream, a);
     else
-        hipLaunchKernelGGL((ivf_mfma_scan_kernel<M_L2>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_L2>), dim3(grid), dim3(BLOCK), 0, stream, a);
     MSVS_HIP(hipGetLastError());
 }
 

@@ -79,9 +79,9 @@ void launch_ivf_merge(int metric, IvfMergeParams a, uint32_t nq, hipStream_t str
 /// out[r] = |X[r]|^2 for n rows of ld4 float4; max_bits: nullable running maximum of the float bit patterns.
 void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uint32_t * max_bits, hipStream_t stream);
 
-/// Approximate (MFMA) scan over the plan's work items; a.k = candidates kept (<= 64).  big: the 256-row x 128-query
-/// tile kernel (plan built with T = BG_TQ, a.k == BG_KC), else 128 x 32 tiles (T = MF_TQ).
-void launch_ivf_mfma_scan(int metric, bool big, uint32_t grid, ScanParams a, hipStream_t stream);
+/// Approximate (split-bf16 MFMA) scan over the plan's work items (plan built with T = BG_TQ); appends candidates to
+/// a.partial through a.qcnt / a.qthr (see mfma_scan_kernels.hpp).
+void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t stream);
 
 /// One-list plan over a plain row table (see single_list_plan_kernel).
 void launch_single_list_plan(uint32_t nq, uint32_t nrows, uint32_t rows_per_block, uint32_t tq, uint32_t * pairs,

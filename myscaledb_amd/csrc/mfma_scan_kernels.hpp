@@ -1,26 +1,32 @@
-// mfma_scan_kernels.hpp -- matrix-core candidate pass of the list-batched IVF scan + exact re-rank.
+// mfma_scan_kernels.hpp -- matrix-core candidate pass of batched searches + canonical re-rank.
 //
-// When many queries of a batch probe the same list (>= 16 on average) the canonical scan of scan_kernels.hpp is
-// VALU-bound: the parity contract forbids fma, so every (query, row, element) costs three separately rounded VALU
-// ops.  The query-tile x row-tile inner products are a GEMM, so this path runs them on the FP32 matrix cores
-// (v_mfma_f32_32x32x2_f32) as a PRE-FILTER and keeps the returned numbers canonical:
+// When many queries of a batch scan the same rows (>= ~4 per IVF list, or a batch against a whole table) the canonical
+// scan of scan_kernels.hpp is VALU-bound: the parity contract forbids fma, so every (query, row, element) costs three
+// separately rounded VALU ops.  The query-tile x row-tile inner products are a GEMM, so this path runs them on the
+// matrix cores as a PRE-FILTER and keeps the returned numbers canonical:
 //
-//   1. ivf_mfma_scan_kernel : approximate distance a(q,x) = |x|^2 - 2<q,x> + |q|^2 (L2) or <q,x> (IP) for every
-//      (query, probed row); per (query, list segment) the KC best rows by a() are kept (KC = 32 or 64 >= k).
-//   2. ivf_merge_kernel     : per query, the KC best candidates over all its segments (keys carry row POSITIONS).
-//   3. ivf_rerank_kernel    : canonical (bit-exact, scan_kernels.hpp arithmetic) distance of the KC candidates, exact
-//      top-k among them, and a CERTIFICATE: every row that is not a candidate has a() >= a_KC (the worst kept
-//      candidate), and |a - canonical| <= eps for a rigorous rounding-error bound eps, so if a_KC - eps > e_k (the
-//      exact k-th distance found) no excluded row can enter the top-k and the result equals the exhaustive one.
-//   4. queries whose certificate fails (near-ties wider than KC, huge norms, NaN) are re-run through the canonical
-//      one-query-per-block scan (ivf_scan_subset_kernel / ivf_merge_subset_kernel), stream-ordered, no host sync.
+//   1. ivf_mfma_scan_big_kernel : approximate distance a(q,x) = |x|^2 - 2<q,x> + |q|^2 (L2) or <q,x> (IP) for every
+//      (query, probed row), inner products in split bf16 on v_mfma_f32_32x32x16_bf16; every (query, 128-row slice)
+//      appends its <= 16 best rows by a() to the query's candidate buffer (keys carry row POSITIONS).
+//   2. cand_select_kernel : per query, the KC (32 for k <= 12, else 64) best candidates, ascending, and
+//      bound = the smallest key any slice may have cut.
+//   3. ivf_rerank_kernel  : canonical (bit-exact, scan_kernels.hpp arithmetic) distance of the KC candidates, exact
+//      top-k among them, and a CERTIFICATE: every row that is not a candidate has a() >= min(a_KC, bound), and
+//      |a - canonical| <= eps for a rigorous rounding-error bound eps, so if min(a_KC, bound) - eps > e_k (the exact
+//      k-th distance found) no excluded row can enter the top-k and the result equals the exhaustive one.
+//   4. queries whose certificate fails (near-ties wider than the candidate lists, huge norms, NaN, an overflowed
+//      buffer) are re-run through the canonical one-query-per-block scan (ivf_scan_subset_kernel /
+//      ivf_merge_subset_kernel), stream-ordered, no host sync.
 //
 // The result is therefore ALWAYS identical to the canonical scan; eps only decides how often step 4 has work.
-// Error bound (u = 2^-24), all relative to |x||q| <= (|x|+|q|)^2 / 4 with |x| <= sqrt(max row norm of the index):
-//   c_dot   the MFMA inner product of n accumulated terms, whatever its internal order and rounding mode, is within
-//           n * 2^-23 of the true one: n = 2d for the f32 kernel; the split-bf16 kernel adds 3.1 * 2^-16 for the terms
-//           it drops and accumulates n = 3d terms;
-//   c_norm  the fma-accumulated f32 norms: d * u;
+// The same four steps serve the IVF list scan, the coarse quantiser (centroid table = one list every query probes,
+// result = the probe lists) and FLAT indexes (single_list_plan_kernel).
+// Error bound (u = 2^-24), relative to |x||q| <= (|x|+|q|)^2 / 4 with |x| <= sqrt(max row norm of the table):
+//   c_dot   split bf16: x = xh + xl + rx with |xl| <= 2^-8 |x|, |rx| <= 2^-16 |x| (same for q); the products kept are
+//           xh*qh + xh*ql + xl*qh (each exact in f32), the dropped xl*ql, xh*rq, rx*q sum to <= 3.1 * 2^-16 |x||q|;
+//           the MFMA accumulation of n = 3d terms, whatever its internal order and rounding mode, stays within
+//           n * 2^-23 |x||q|;
+//   c_norm  the fma-accumulated f32 norms: (d + 8) u;
 //   c_canon the canonical result itself (d separately rounded terms, depth <= 18, + the sub/mul of L2): 32u;
 //   L2:  eps = 2 c_dot |x||q| + c_norm (|x|^2 + |q|^2) + c_canon (|x|+|q|)^2 (+ 2 roundings of the final a);
 //   IP:  eps = (c_dot + c_canon) |x||q|;   everything times 1.05.
@@ -33,11 +39,7 @@ namespace msvs
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MF_ROWS = 128; // rows per sub-tile: 32 per wavefront
-constexpr int MF_TQ = 32;    // queries per tile (the N of the 32x32 MFMA)
-constexpr int MF_KC = 32;    // floats of the reduction dimension staged per step
-constexpr int MF_LDX = MF_KC + 4;   // LDS row stride of the staged operands (floats): 16-lane b128 reads conflict-free
-constexpr int MF_LDS = MF_ROWS + 4; // LDS row stride of the per-query distance tile
+constexpr int MF_LDS = 128 + 4; // LDS row stride (floats) of the per-query distance tile
 
 /// out[r] = |X[r]|^2 (fma, 16 lanes per row; NOT the canonical order: only feeds the approximate pass and its error
 /// bound).  max_bits (nullable): running maximum of the float bit patterns (norms are >= 0; NaN compares largest).
@@ -86,252 +88,23 @@ __device__ __forceinline__ void canonical_update(float4 & s, const float4 q, con
     }
 }
 
-/// Work item = (list, tile of <= 32 probing queries, row segment), walked by a fixed grid exactly like
-/// ivf_batched_scan_kernel (plan built with T = 32).  a.k = KC (<= 64); a.partial[(pair*seg_max + seg)*KC ...] receives
-/// the KC best (approximate key, row position) of the segment for each query of the tile.
-template <int METRIC>
-__global__ __launch_bounds__(BLOCK) void ivf_mfma_scan_kernel(const ScanParams a)
-{
-    __shared__ __attribute__((aligned(16))) float Xs[2][MF_ROWS * MF_LDX];
-    __shared__ __attribute__((aligned(16))) float Qs[2][MF_TQ * MF_LDX];
-    __shared__ float xn_s[MF_ROWS];
-    __shared__ float qn_s[MF_TQ];
-    __shared__ uint32_t qrow_s[MF_TQ];
-    __shared__ uint32_t qpair_s[MF_TQ];
-    float * const Ss = &Xs[0][0]; // the per-query distance tile reuses the operand stage between two reductions
-    static_assert(MF_TQ * MF_LDS <= 2 * MF_ROWS * MF_LDX, "distance tile must fit the operand stage");
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
-    const uint32_t ld4 = a.ld4, kc = a.k;
-    const uint32_t nk = (ld4 + 7) / 8;          // reduction steps of 32 floats
-    const uint32_t lc = tid & 7, lr = tid >> 3; // loader role: float4 column lc of rows lr, lr+32, lr+64, lr+96
-    const uint32_t total = a.work_off[a.nlist];
-    const uint32_t per_xcd = (total + 7) / 8;
-    for (uint32_t s = blockIdx.x; s < 8 * per_xcd; s += gridDim.x)
-    {
-        const uint32_t w = a.xcd_order ? (s & 7) * per_xcd + (s >> 3) : s;
-        if (w >= total || (a.xcd_order && (s >> 3) >= per_xcd))
-            continue;
-        uint32_t lo = 0, hi = a.nlist;
-        while (hi - lo > 1)
-        {
-            uint32_t mid = (lo + hi) >> 1;
-            if (a.work_off[mid] <= w)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const uint32_t l = lo;
-        const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
-        const uint32_t local = w - a.work_off[l];
-        const uint32_t pe = a.pair_off[l + 1];
-        const uint32_t ntile = (pe - a.pair_off[l] + MF_TQ - 1) / MF_TQ;
-        const uint32_t seg = local / ntile, tile = local - seg * ntile;
-        const uint32_t pb = a.pair_off[l] + tile * MF_TQ;
-        const uint32_t nvalid = pe - pb < (uint32_t)MF_TQ ? pe - pb : (uint32_t)MF_TQ;
-        const int64_t rb = lbeg + (int64_t)seg * a.rows_per_block;
-        const int64_t re = rb + a.rows_per_block < lend ? rb + a.rows_per_block : lend;
-
-        __syncthreads(); // the previous work item is done with the tile tables and the stage
-        if (tid < MF_TQ)
-        {
-            const uint32_t pi = pb + tid < pe ? pb + tid : pe - 1; // short tiles repeat their last pair (never selected)
-            const uint32_t qp = a.pairs[pi];
-            const uint32_t q = qp / a.nprobe;
-            qrow_s[tid] = q;
-            qpair_s[tid] = qp;
-            qn_s[tid] = METRIC == M_L2 ? a.qnorm[q] : 0.f;
-        }
-        if (METRIC == M_L2 && tid < MF_ROWS)
-            xn_s[tid] = a.xnorm[rb + tid < re ? rb + tid : re - 1];
-        __syncthreads();
-
-        WaveTopK<1> top[8]; // this wavefront selects for queries 8*wave .. 8*wave+7 of the tile
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-            top[t].init();
-        const float4 * qsrc = a.Q + (size_t)qrow_s[lr] * ld4;
-        const float qn = qn_s[r32];
-
-        // The (sub-tile, reduction step) space is walked as ONE software pipeline: the operands of step i+1 are in
-        // flight (registers px/pq) while step i multiplies, across sub-tile borders too, so the first step of a
-        // sub-tile travels during the previous sub-tile's selection.
-        int64_t pf_sub = rb; // prefetch position
-        uint32_t pf_ki = 0;
-        const float4 * xsrc[4];
-        float4 px[4], pq;
-        auto set_rows = [&](int64_t sub) {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                int64_t row = sub + lr + 32 * i;
-                if (row >= re)
-                    row = re - 1; // rows past the segment repeat its last row; they are never offered
-                xsrc[i] = a.Y + (size_t)row * ld4;
-            }
-        };
-        auto gload = [&]() {
-            const uint32_t c = pf_ki * 8 + lc;
-            const bool in = c < ld4;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                px[i] = in ? xsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            pq = in ? qsrc[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        };
-        auto advance = [&]() {
-            if (++pf_ki == nk)
-            {
-                pf_ki = 0;
-                pf_sub += MF_ROWS;
-                if (pf_sub < re)
-                    set_rows(pf_sub);
-            }
-        };
-        auto sstore = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                *reinterpret_cast<float4 *>(&Xs[buf][(lr + 32 * i) * MF_LDX + 4 * lc]) = px[i];
-            *reinterpret_cast<float4 *>(&Qs[buf][lr * MF_LDX + 4 * lc]) = pq;
-        };
-        set_rows(rb);
-        gload();
-        advance();
-        sstore(0);
-        __syncthreads();
-        int cur = 0;
-
-        for (int64_t sub = rb; sub < re; sub += MF_ROWS)
-        {
-            // side data of this sub-tile's selection and of the next sub-tile's epilogue: requested now, used late
-            const bool has_next = sub + MF_ROWS < re;
-            float xn_next = 0.f;
-            if (METRIC == M_L2 && has_next && tid < MF_ROWS)
-                xn_next = a.xnorm[sub + MF_ROWS + tid < re ? sub + MF_ROWS + tid : re - 1];
-            bool okrow[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-            {
-                const int64_t row = sub + lane + 64 * u;
-                bool ok = row < re;
-                if (ok && a.alive)
-                {
-                    const uint32_t id = a.ids ? a.ids[row] : (uint32_t)row + a.id_base;
-                    ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
-                }
-                okrow[u] = ok;
-            }
-
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                acc[r] = 0.f;
-            for (uint32_t ki = 0; ki < nk; ki++)
-            {
-                const bool more = pf_sub < re;
-                if (more)
-                    gload();
-                // lane (r32, h) feeds row/query r32 at reduction index h of each 32x32x2 product: the 32 floats of the
-                // step are consumed as k = 8i + 4h + c, the same permutation on both operands
-                const float * xa = &Xs[cur][(32 * wave + r32) * MF_LDX + 4 * h];
-                const float * qb = &Qs[cur][r32 * MF_LDX + 4 * h];
-                float4 av[4], bv[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                {
-                    av[i] = *reinterpret_cast<const float4 *>(xa + 8 * i);
-                    bv[i] = *reinterpret_cast<const float4 *>(qb + 8 * i);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
-                }
-                if (ki + 1 < nk)
-                {
-                    sstore(cur ^ 1);
-                    __syncthreads();
-                    cur ^= 1;
-                }
-                if (more)
-                    advance();
-            }
-            __syncthreads(); // every wavefront is done reading the operand stage: it becomes the distance tile
-            // D[m = row][n = query]: this lane holds query r32, rows (r & 3) + 8 * (r >> 2) + 4 * h of the wave's 32
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++)
-            {
-                const uint32_t m0 = 32 * wave + 8 * g4 + 4 * h;
-                float4 o;
-                if (METRIC == M_L2)
-                {
-                    o.x = fmaf(-2.f, acc[4 * g4 + 0], xn_s[m0 + 0]) + qn;
-                    o.y = fmaf(-2.f, acc[4 * g4 + 1], xn_s[m0 + 1]) + qn;
-                    o.z = fmaf(-2.f, acc[4 * g4 + 2], xn_s[m0 + 2]) + qn;
-                    o.w = fmaf(-2.f, acc[4 * g4 + 3], xn_s[m0 + 3]) + qn;
-                }
-                else
-                    o = make_float4(acc[4 * g4 + 0], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
-                *reinterpret_cast<float4 *>(&Ss[r32 * MF_LDS + m0]) = o;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 8; t++)
-            {
-                const uint32_t n = 8 * wave + t;
-                if (n < nvalid)
-                {
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-                    {
-                        const float v = Ss[n * MF_LDS + lane + 64 * u];
-                        const uint64_t key
-                            = okrow[u] ? make_key<METRIC>(v, (uint32_t)(sub + lane + 64 * u)) : KEY_NONE;
-                        top[t].offer(key, kc, lane);
-                    }
-                }
-            }
-            if (has_next)
-            {
-                __syncthreads(); // distance tile consumed: restage the first step of the next sub-tile
-                sstore(0);
-                if (METRIC == M_L2 && tid < MF_ROWS)
-                    xn_s[tid] = xn_next;
-                __syncthreads();
-                cur = 0;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-        {
-            const uint32_t n = 8 * wave + t;
-            if (n < nvalid)
-                top[t].store(a.partial + ((size_t)qpair_s[n] * a.seg_max + seg) * kc, kc, lane);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------ big-tile variant
+// ------------------------------------------------------------------------------------------ the candidate pass
 //
-// The 128-row x 32-query kernel above re-reads a list once per 32 probing queries and re-reads the query tile once per
-// 128 rows (~2.9x the unique bytes at ~50 queries per list), and its per-query candidate lists cost a serial
-// insertion (~270 cycles) per accepted key.  This variant:
-//   * holds a 128-row x 128-query tile per workgroup: each of the 4 wavefronts owns 32 rows x 128 queries = 4 MFMA
+// Design of ivf_mfma_scan_big_kernel (measured alternatives: profiles/r01_candidate_pass_notes.txt):
+//   * a 128-row x 128-query tile per workgroup: each of the 4 wavefronts owns 32 rows x 128 queries = 4 MFMA
 //     accumulators, so one LDS read of its rows feeds up to 4 products; 32-query column blocks without queries are
-//     skipped.  71 KB of LDS -> two workgroups per CU, one selecting while the other multiplies;
-//   * multiplies in SPLIT BF16 ("bf16x3"): every f32 operand is staged in LDS as hi = bf16(v) and lo = bf16(v - hi)
-//     (v - hi is exact in f32), and <x,q> ~= <xh,qh> + <xh,ql> + <xl,qh> on v_mfma_f32_32x32x16_bf16 with f32
-//     accumulation: 6 bf16 MFMAs (32 cycles each) per 32 reduction elements instead of 16 f32 MFMAs (64 cycles each),
-//     i.e. 5.3x less matrix-core time, for a relative error of 3 * 2^-16 on the products (the dropped xl*ql term and
-//     the two second-order residues) -- the same order as the bound already budgeted for the accumulation;
-//   * keeps no list: every (query, 128-row slice) appends its own 16 best rows (radix select over the wavefront's
+//     skipped.  A list is read ONCE for up to 128 probing queries.  71 KB of LDS -> two workgroups per CU, one
+//     selecting while the other multiplies;
+//   * SPLIT BF16 ("bf16x3"): every f32 operand is staged in LDS as hi = bf16(v) and lo = bf16(v - hi) (v - hi is
+//     exact in f32), and <x,q> ~= <xh,qh> + <xh,ql> + <xl,qh> on v_mfma_f32_32x32x16_bf16 with f32 accumulation:
+//     6 bf16 MFMAs (32 cycles each) per 32 reduction elements where the f32 MFMA needs 16 x 64 cycles, i.e. 5.3x less
+//     matrix-core time, which turns the kernel from MFMA-bound into memory-bound;
+//   * no per-query list: every (query, 128-row slice) appends its own 16 best rows (radix select over the wavefront's
 //     128 keys by ballots, then a 16-lane DPP bitonic sort) to the query's candidate buffer in global memory (atomic
-//     cursor).  16 > k (<= 12 here), so a slice can only hide a row from the result if 16 better rows sit in the same
-//     slice; cand_select_kernel then keeps the 32 best candidates of the query, and the re-rank certifies against
-//     bound = min(32nd candidate, 16th key of every FULL slice list) -- the second term is exactly qthr below;
-//   * shares ONE number per query across the whole grid: qthr[q] = the smallest 16th-key distance any full slice list
+//     cursor).  A slice can only hide a row from the result if 16 better rows sit in the same slice; the re-rank
+//     certifies against bound = min(KC-th candidate, 16th key of every FULL slice list) -- the second term is
+//     exactly qthr below;
+//   * ONE number per query shared across the whole grid: qthr[q] = the smallest 16th-key distance any full slice list
 //     of the query has emitted so far (atomicMin).  A row whose approximate distance is not below it can be dropped
 //     at once -- it is no better than a key the bound already accounts for -- so after the first few slices of a
 //     query almost every later slice has fewer than 16 survivors and skips the selection altogether.  Which rows get
@@ -438,7 +211,9 @@ __device__ __forceinline__ uint64_t wave_select16(const uint64_t k0, const uint6
 
 /// Work item = (list, tile of <= 128 probing queries, segment of a.rows_per_block rows (a multiple of 128)); plan built
 /// with T = BG_TQ.  Every (query, 128-row slice) appends its <= 16 best (approximate key, row position) at
-/// a.partial[q * a.cand_cap + atomicAdd(a.qcnt[q], n)]; a.cand_cap >= 16 * (slices the query can meet).
+/// a.partial[q * a.cand_cap + atomicAdd(a.qcnt[q], n)].  a.cand_cap may be smaller than 16 * (slices the query can
+/// meet): keys past the capacity are dropped, qcnt keeps counting, and cand_select_kernel turns qcnt > cap into a
+/// failed certificate (canonical fallback) -- with the running cut at work a query appends a few hundred keys.
 template <int METRIC>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void ivf_mfma_scan_big_kernel(
     const ScanParams a)
@@ -702,7 +477,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     if (lane == 0)
                         pos = atomicAdd(&a.qcnt[q], nsel);
                     pos = __builtin_amdgcn_readfirstlane(pos);
-                    if (lane < nsel)
+                    if (lane < nsel && pos + lane < a.cand_cap)
                         a.partial[(size_t)q * a.cand_cap + pos + lane] = best;
                     if (lane == (uint32_t)BG_SLICE_K - 1 && best != KEY_NONE) // a full list: its last key cuts
                         atomicMin(&a.qthr[q], (uint32_t)(best >> 32));
@@ -776,8 +551,8 @@ static __global__ __launch_bounds__(BLOCK) void cand_select_kernel(const uint64_
     block_rank_merge(lds, kc, merged, kc, tid);
     if (tid < kc)
         out[(size_t)q * kc + tid] = merged[tid];
-    if (tid == 0)
-        bound[q] = qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32;
+    if (tid == 0) // an overflowed buffer dropped unknown keys: bound 0 = nothing can be certified
+        bound[q] = qcnt[q] > cap ? 0 : (qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32);
 }
 
 struct RerankParams

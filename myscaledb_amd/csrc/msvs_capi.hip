@@ -646,7 +646,7 @@ namespace msvs
 struct IvfSearchPlan
 {
     uint32_t T;       // 1 = one query per block (ivf_scan_kernel); 2/4/8 = list-batched query tiles;
-                      // 32 (MF_TQ) / 128 (BG_TQ) = matrix-core candidate pass + canonical re-rank (mfma_scan_kernels.hpp)
+                      // 128 (BG_TQ) = matrix-core candidate pass + canonical re-rank (mfma_scan_kernels.hpp)
     uint32_t rpb;     // rows per work item
     uint32_t seg_max; // segments of the longest list
     uint32_t grid;    // batched: fixed grid size
@@ -655,7 +655,7 @@ struct IvfSearchPlan
     uint32_t rpb1;     // rows per block / segments of the canonical fallback scan (one query per block)
     uint32_t seg_max1;
     uint32_t fb_slots; // block slots (grid z) of the fallback
-    bool mfma() const { return T == (uint32_t)MF_TQ || T == (uint32_t)BG_TQ; }
+    bool mfma() const { return T == (uint32_t)BG_TQ; }
 };
 
 static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, uint32_t k)
@@ -667,32 +667,23 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     // Matrix-core candidate pass: pays once ~4 queries share a list pass (the canonical scan is VALU-bound there);
     // needs finite, sane row norms for its error bound and k small enough for a 64-entry candidate list.
     {
-        // experiment knob: 0 = never, 2 = whenever eligible, 3 = whenever eligible with the 32-query-tile kernel
-        const char * e = getenv("MSVS_IVF_MFMA");
+        const char * e = getenv("MSVS_IVF_MFMA"); // experiment knob: 0 = never, 2 = whenever eligible
         const int mode = e ? atoi(e) : 1;
         const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f; // false for NaN
         if (mode != 0 && eligible && (pairs >= 4 * nlist || mode >= 2))
         {
+            p.T = BG_TQ;
             p.kc = k <= 12 ? 32 : 64;
-            const bool big = p.kc == (uint32_t)BG_KC && mode != 3; // 256-row x 128-query tiles (lists of 32 keys in LDS)
-            p.T = big ? BG_TQ : MF_TQ;
-            const size_t rows = big ? BG_ROWS : MF_ROWS;
-            const size_t tiles = std::max<size_t>(1, pairs / p.T);
-            // a query's partial candidate lists (~1.3 * nprobe * avg / rpb of them, kc keys each) should fit the merge
-            // block's LDS stage (HEADS_CAP keys)
-            const size_t rpb_min = nprobe * avg * 13 / 10 * p.kc / 5000;
-            size_t rpb = big ? 256 : std::max<size_t>(avg * tiles / 1024, rpb_min);
-            rpb = round_up(std::max<size_t>(rpb, 2 * MF_ROWS), rows);
-            p.rpb = (uint32_t)std::min<size_t>(rpb, 1024);
+            p.rpb = 2 * BG_ROWS; // work item = 2 slices of a list for a tile of <= 128 queries
             if (const char * r = getenv("MSVS_IVF_RPB"))
-                if (atoi(r) >= MF_ROWS)
-                    p.rpb = (uint32_t)round_up((size_t)atoi(r), rows);
-            p.grid = big ? 2048 : 4096;
+                if (atoi(r) >= BG_ROWS)
+                    p.rpb = (uint32_t)round_up((size_t)atoi(r), (size_t)BG_ROWS);
+            p.grid = 2048;
             if (const char * g = getenv("MSVS_IVF_GRID"))
                 if (atoi(g) >= 1)
                     p.grid = (uint32_t)atoi(g);
-            // big: the partial lists are per 128-row SLICE (16 keys each), whatever the work-item size
-            p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, big ? (size_t)BG_ROWS : (size_t)p.rpb));
+            // the candidate lists are per 128-row SLICE (<= 16 keys each), whatever the work-item size
+            p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, (size_t)BG_ROWS));
             size_t rpb1 = round_up(std::max<size_t>(64, nprobe * avg * 3 / 2 / 400), 16);
             p.rpb1 = (uint32_t)std::min<size_t>(rpb1, 256);
             p.seg_max1 = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, p.rpb1));
@@ -744,19 +735,28 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     return p;
 }
 
-static size_t coarse_pass_scratch(const msvs_index & ix, size_t nq, size_t nprobe);
+static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k);
+
+static size_t big_cand_cap(size_t nprobe, size_t slices_max)
+{
+    size_t limit = 16384;
+    if (const char * e = getenv("MSVS_CAND_CAP")) // experiment / test knob
+        limit = std::max<size_t>(64, (size_t)atol(e));
+    return std::min<size_t>(nprobe * slices_max * BG_SLICE_K, limit);
+}
 
 static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k, size_t nprobe)
 {
     size_t b = nq * (size_t)ix.ld * 4 + 4096;
     if (ix.type == MSVS_INDEX_FLAT)
-        return b + flat_scratch_bytes(ix.n, nq, k);
+        return b + flat_scratch_bytes(ix.n, nq, k) + table_pass_scratch(ix.n, nq, std::min<uint32_t>(k, 40));
     IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k);
-    size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe) + coarse_pass_scratch(ix, nq, nprobe)
+    size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe)
+        + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
         + nq * nprobe * 4
         + (4 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
     if (p.mfma())
-        need += nq * nprobe * (size_t)p.seg_max * (p.T == (uint32_t)BG_TQ ? (size_t)BG_SLICE_K : (size_t)p.kc) * 8
+        need += nq * big_cand_cap(nprobe, p.seg_max) * 8
             + nq * (size_t)p.kc * 8 + nq * 24 + 8192
             + nq * nprobe * (size_t)p.seg_max1 * k * 8;
     else
@@ -764,32 +764,64 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     return need;
 }
 
-static bool coarse_pass_eligible(const msvs_index & ix, size_t nq, size_t nprobe)
+/// Error model of the split-bf16 candidate pass (mfma_scan_kernels.hpp header), times the test knob MSVS_IVF_EPS_SCALE.
+static void set_error_model(RerankParams & rp, size_t dim)
 {
-    const char * e = getenv("MSVS_COARSE_MFMA"); // experiment knob: 0 = never, 2 = whenever eligible
+    const char * es = getenv("MSVS_IVF_EPS_SCALE"); // experiment / test knob: inflate eps to force the fallback
+    const double scale = 1.05 * (es ? atof(es) : 1.0), dd = (double)dim;
+    rp.c_dot = scale * (3.1 * ldexp(1.0, -16) + 3.05 * dd * ldexp(1.0, -23));
+    rp.c_norm = scale * (dd + 8.0) * ldexp(1.0, -24);
+    rp.c_canon = scale * 32.0 * ldexp(1.0, -24);
+}
+
+/// A plain row table searched through the matrix-core candidate pass: the table is one "list" every query probes
+/// (single_list_plan_kernel); 16 candidates per (query, 128-row slice) -> 32 / 64 per query -> canonical re-rank ->
+/// exact top-k with the same certificate / canonical fallback as the list scan (mfma_scan_kernels.hpp).
+/// Used for the coarse quantiser (table = centroids, result = probe lists) and for FLAT indexes (table = all rows).
+struct TablePass
+{
+    const float * rows;    // n x ld
+    const uint32_t * ids;  // nullable: id of row r (else r)
+    const float * norms;   // |row|^2
+    float norm_max;
+    size_t n;
+    const uint64_t * alive; // nullable filter bitmap over ids
+    size_t nbits;
+    uint32_t k;
+    int32_t * out_probes; // either the probe lists ...
+    int64_t * out_ids;    // ... or (ids, distances)
+    float * out_dis;
+    int cosine;
+    const char * prof_name;
+};
+
+static uint32_t table_fallback_rpb(size_t n) { return (uint32_t)round_up(std::max<size_t>(256, ceil_div(n, (size_t)256)), 16); }
+
+static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k)
+{
+    const size_t nslices = ceil_div(std::max<size_t>(n, 1), (size_t)BG_ROWS);
+    return nq * (big_cand_cap(1, nslices) * 8 + 64 * 8 + 96)
+        + nq * ceil_div(std::max<size_t>(n, 1), (size_t)table_fallback_rpb(n)) * k * 8 + 65536;
+}
+
+/// Worth it once the (128-query tile) x (128-row slice) grid can occupy the chip (64 work items measured no better
+/// than the canonical scan on the 1024-centroid table, 256 items 2x better) and enough queries share each pass over
+/// the rows for the canonical scan to be VALU-bound (>= 16).
+static bool table_pass_eligible(size_t n, const float * norms, float norm_max, size_t nq, uint32_t k, const char * knob)
+{
+    const char * e = getenv(knob); // experiment knob: 0 = never, 2 = whenever possible
     const int mode = e ? atoi(e) : 1;
-    // worth it once the (128-query tile) x (128-centroid slice) grid can occupy the chip: 64 work items measured no
-    // better than the canonical flat scan, 256 items 2x better (1M x 768 bench, profiles/)
-    const size_t items = ceil_div(nq, (size_t)BG_TQ) * ceil_div(ix.nlist, (size_t)BG_ROWS);
-    return mode != 0 && ix.cnorm.p && ix.cnorm_max < 1e30f && nprobe <= 40 && ix.nlist >= 256
-        && (items >= 128 || mode == 2);
+    const size_t items = ceil_div(nq, (size_t)BG_TQ) * ceil_div(n, (size_t)BG_ROWS);
+    return mode != 0 && norms && norm_max < 1e30f /* false for NaN */ && k <= 40 && n >= 256 && n <= 0xfffffff0ull
+        && ((items >= 128 && nq >= 16) || mode == 2);
 }
 
-static size_t coarse_pass_scratch(const msvs_index & ix, size_t nq, size_t nprobe)
+static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq,
+                                 const TablePass & t, hipStream_t stream)
 {
-    const size_t nslices = ceil_div(ix.nlist, (size_t)BG_ROWS);
-    return nq * (nslices * BG_SLICE_K * 8 + 64 * 8 + 96) + nq * ceil_div(ix.nlist, (size_t)256) * nprobe * 8 + 65536;
-}
-
-/// Coarse quantiser through the matrix-core candidate pass: the centroid table is one "list" every query probes;
-/// 16 candidates per (query, 128-centroid slice) -> 64 per query -> canonical re-rank -> exact top-nprobe with the
-/// same certificate / canonical fallback as the list scan (mfma_scan_kernels.hpp).  Probe SETS equal the exact scan's.
-static void coarse_by_candidate_pass(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq,
-                                     size_t nprobe, int32_t * d_probes, hipStream_t stream)
-{
-    const uint32_t ld = ix.ld, nrows = (uint32_t)ix.nlist, kc = 64;
-    const uint32_t nslices = (uint32_t)ceil_div(ix.nlist, (size_t)BG_ROWS);
-    const uint32_t cap = nslices * BG_SLICE_K;
+    const uint32_t ld = ix.ld, nrows = (uint32_t)t.n, kc = t.k <= 12 ? 32 : 64;
+    const uint32_t nslices = (uint32_t)ceil_div(t.n, (size_t)BG_ROWS);
+    const uint32_t cap = (uint32_t)big_cand_cap(1, nslices);
     uint32_t * pairs = scr.take<uint32_t>(nq);
     int32_t * probes0 = scr.take<int32_t>(nq);
     int64_t * list_off = scr.take<int64_t>(2);
@@ -800,22 +832,27 @@ static void coarse_by_candidate_pass(const msvs_index & ix, Scratch & scr, int m
     uint64_t * cand = scr.take<uint64_t>(nq * (size_t)kc);
     uint64_t * bound = scr.take<uint64_t>(nq);
     uint32_t * failq = scr.take<uint32_t>(nq);
-    const uint32_t rpb1 = 256, seg_max1 = (uint32_t)ceil_div(ix.nlist, (size_t)rpb1);
-    uint64_t * partial1 = scr.take<uint64_t>(nq * (size_t)seg_max1 * nprobe);
+    const uint32_t rpb1 = table_fallback_rpb(t.n), seg_max1 = (uint32_t)ceil_div(t.n, (size_t)rpb1);
+    uint64_t * partial1 = scr.take<uint64_t>(nq * (size_t)seg_max1 * t.k);
     uint32_t * nfail = small + 4;
     MSVS_HIP(hipMemsetAsync(small, 0, 5 * sizeof(uint32_t), stream));
     MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
     MSVS_HIP(hipMemsetAsync(qstate + nq, 0, nq * sizeof(uint32_t), stream));
-    launch_single_list_plan((uint32_t)nq, nrows, BG_ROWS, BG_TQ, pairs, probes0, list_off, small, small + 2, stream);
+    // work item = 2 slices, or 1 when that is what it takes to give the chip ~1000 items
+    const uint32_t rpb = ceil_div(nq, (size_t)BG_TQ) * ceil_div(t.n, (size_t)(2 * BG_ROWS)) < 1024 ? BG_ROWS : 2 * BG_ROWS;
+    launch_single_list_plan((uint32_t)nq, nrows, rpb, BG_TQ, pairs, probes0, list_off, small, small + 2, stream);
     launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
     ScanParams a{};
-    a.Y = reinterpret_cast<const float4 *>(ix.centroids.p);
+    a.Y = reinterpret_cast<const float4 *>(t.rows);
+    a.ids = t.ids;
+    a.alive = t.alive;
+    a.nbits = (uint32_t)std::min<size_t>(t.nbits, 0xffffffffu);
     a.Q = reinterpret_cast<const float4 *>(dq);
     a.partial = candbuf;
     a.ld4 = ld / 4;
-    a.k = BG_KC;
+    a.k = kc;
     a.nq = (uint32_t)nq;
-    a.rows_per_block = BG_ROWS;
+    a.rows_per_block = rpb;
     a.probes = probes0;
     a.list_off = list_off;
     a.nprobe = 1;
@@ -826,57 +863,58 @@ static void coarse_by_candidate_pass(const msvs_index & ix, Scratch & scr, int m
     a.nlist = 1;
     a.xcd_order = 1;
     a.qnorm = qnorm;
-    a.xnorm = ix.cnorm.p;
+    a.xnorm = t.norms;
     a.qthr = qstate;
     a.qcnt = qstate + nq;
     a.cand_cap = cap;
-    const size_t items = ceil_div(nq, (size_t)BG_TQ) * nslices;
-    {
-        ProfileScope prof("coarse_pass", stream);
-        launch_ivf_mfma_scan(scan_metric(m), true, (uint32_t)std::min<size_t>(items, 2048), a, stream);
-        launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
-        RerankParams rp{};
-        rp.Y = a.Y;
-        rp.Q = a.Q;
-        rp.qnorm = qnorm;
-        rp.cand = cand;
-        rp.bound = bound;
-        rp.kc = kc;
-        rp.k = (uint32_t)nprobe;
-        rp.ld4 = ld / 4;
-        rp.out_probes = d_probes;
-        const char * es = getenv("MSVS_IVF_EPS_SCALE");
-        const double scale = 1.05 * (es ? atof(es) : 1.0), dd = (double)ix.dim;
-        rp.c_dot = scale * (3.1 * ldexp(1.0, -16) + 3.05 * dd * ldexp(1.0, -23));
-        rp.c_norm = scale * (dd + 8.0) * ldexp(1.0, -24);
-        rp.c_canon = scale * 32.0 * ldexp(1.0, -24);
-        rp.xmax = ix.cnorm_max;
-        rp.failq = failq;
-        rp.nfail = nfail;
-        launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
-        // queries without a certificate: canonical scan of the centroid table
-        ScanParams c = a;
-        c.k = (uint32_t)nprobe;
-        c.partial = partial1;
-        c.rows_per_block = rpb1;
-        c.seg_max = seg_max1;
-        c.qmap = failq;
-        c.qcount = nfail;
-        const uint32_t slots = (uint32_t)std::min<size_t>(nq, 8);
-        launch_ivf_scan_subset(scan_metric(m), c, slots, stream);
-        IvfMergeParams fm{};
-        fm.partial = partial1;
-        fm.probes = probes0;
-        fm.list_off = list_off;
-        fm.nprobe = 1;
-        fm.seg_max = seg_max1;
-        fm.rows_per_block = rpb1;
-        fm.k = (uint32_t)nprobe;
-        fm.out_probes = d_probes;
-        fm.qmap = failq;
-        fm.qcount = nfail;
-        launch_ivf_merge_subset(scan_metric(m), fm, slots, stream);
-    }
+    const size_t items = ceil_div(nq, (size_t)BG_TQ) * ceil_div(t.n, (size_t)rpb);
+    ProfileScope prof(t.prof_name, stream);
+    launch_ivf_mfma_scan(scan_metric(m), (uint32_t)std::min<size_t>(items, 2048), a, stream);
+    launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
+    RerankParams rp{};
+    rp.Y = a.Y;
+    rp.ids = t.ids;
+    rp.Q = a.Q;
+    rp.qnorm = qnorm;
+    rp.cand = cand;
+    rp.bound = bound;
+    rp.kc = kc;
+    rp.k = t.k;
+    rp.ld4 = ld / 4;
+    rp.out_probes = t.out_probes;
+    rp.out_ids = t.out_ids;
+    rp.out_dis = t.out_dis;
+    rp.cosine = t.cosine;
+    set_error_model(rp, ix.dim);
+    rp.xmax = t.norm_max;
+    rp.failq = failq;
+    rp.nfail = nfail;
+    launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
+    // queries without a certificate: canonical scan of the table
+    ScanParams c = a;
+    c.k = t.k;
+    c.partial = partial1;
+    c.rows_per_block = rpb1;
+    c.seg_max = seg_max1;
+    c.qmap = failq;
+    c.qcount = nfail;
+    const uint32_t slots = (uint32_t)std::min<size_t>(nq, 8);
+    launch_ivf_scan_subset(scan_metric(m), c, slots, stream);
+    IvfMergeParams fm{};
+    fm.partial = partial1;
+    fm.probes = probes0;
+    fm.list_off = list_off;
+    fm.nprobe = 1;
+    fm.seg_max = seg_max1;
+    fm.rows_per_block = rpb1;
+    fm.k = t.k;
+    fm.out_probes = t.out_probes;
+    fm.out_ids = t.out_ids;
+    fm.out_dis = t.out_dis;
+    fm.cosine = t.cosine;
+    fm.qmap = failq;
+    fm.qcount = nfail;
+    launch_ivf_merge_subset(scan_metric(m), fm, slots, stream);
 }
 
 /// The search proper: all pointers on the device, everything enqueued on `stream`.
@@ -916,13 +954,43 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     const int m = ix.metric == MSVS_METRIC_L2 ? MSVS_METRIC_L2 : MSVS_METRIC_IP;
     if (ix.type == MSVS_INDEX_FLAT)
     {
+        if (table_pass_eligible(ix.n, ix.xnorm.p, ix.xnorm_max, nq, k, "MSVS_FLAT_MFMA"))
+        {
+            // a batch against the whole table: matrix-core candidate pass + canonical re-rank (exact, certified)
+            TablePass t{};
+            t.rows = ix.vecs.p;
+            t.ids = ix.row_ids.p;
+            t.norms = ix.xnorm.p;
+            t.norm_max = ix.xnorm_max;
+            t.n = ix.n;
+            t.alive = d_alive;
+            t.nbits = nbits;
+            t.k = k;
+            t.out_ids = d_ids;
+            t.out_dis = d_dis;
+            t.cosine = ix.metric == MSVS_METRIC_COSINE;
+            t.prof_name = "flat_pass";
+            table_candidate_pass(ix, scr, m, dq, nq, t, stream);
+            g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
+            return;
+        }
         flat_search_device(scr, m, ix.vecs.p, ix.row_ids.p, ix.n, ld, dq, nq, k, d_alive, nbits, out, stream);
         return;
     }
     // 1. coarse quantiser: exact top-nprobe of the centroids (canonical arithmetic, so probes match the oracle)
     int32_t * d_probes = scr.take<int32_t>(nq * nprobe);
-    if (coarse_pass_eligible(ix, nq, nprobe))
-        coarse_by_candidate_pass(ix, scr, m, dq, nq, nprobe, d_probes, stream);
+    if (table_pass_eligible(ix.nlist, ix.cnorm.p, ix.cnorm_max, nq, (uint32_t)nprobe, "MSVS_COARSE_MFMA"))
+    {
+        TablePass t{};
+        t.rows = ix.centroids.p;
+        t.norms = ix.cnorm.p;
+        t.norm_max = ix.cnorm_max;
+        t.n = ix.nlist;
+        t.k = (uint32_t)nprobe;
+        t.out_probes = d_probes;
+        t.prof_name = "coarse_pass";
+        table_candidate_pass(ix, scr, m, dq, nq, t, stream);
+    }
     else
     {
         MergeParams co{};
@@ -935,8 +1003,8 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");
     const IvfSearchPlan pl = plan_ivf(ix, nq, nprobe, k);
-    uint64_t * partial = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max
-                                            * (pl.T == (uint32_t)BG_TQ ? (uint32_t)BG_SLICE_K : (pl.mfma() ? pl.kc : k)));
+    uint64_t * partial = scr.take<uint64_t>(pl.mfma() ? nq * big_cand_cap(nprobe, pl.seg_max)
+                                                      : nq * nprobe * (size_t)pl.seg_max * k);
     ScanParams a{};
     a.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
     a.ids = ix.row_ids.p;
@@ -982,41 +1050,20 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         a.k = pl.kc;
         a.qnorm = qnorm;
         a.xnorm = ix.xnorm.p;
-        const bool big = pl.T == (uint32_t)BG_TQ;
-        const size_t cand_cap = nprobe * (size_t)pl.seg_max * BG_SLICE_K; // big: appended keys per query, worst case
-        if (big && cand_cap > 0xffffffffull)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "candidate buffer too large");
-        if (big)
-        {
-            // per query: running cut (0xFFFFFFFF = none yet) and append cursor of its candidate buffer (= `partial`)
-            uint32_t * qstate = scr.take<uint32_t>(2 * nq);
-            a.qthr = qstate;
-            a.qcnt = qstate + nq;
-            a.cand_cap = (uint32_t)cand_cap;
-            MSVS_HIP(hipMemsetAsync(a.qthr, 0xFF, nq * sizeof(uint32_t), stream));
-            MSVS_HIP(hipMemsetAsync(a.qcnt, 0, nq * sizeof(uint32_t), stream));
-        }
-        launch_ivf_mfma_scan(scan_metric(m), big, pl.grid, a, stream);
+        // capacity of a query's candidate buffer (= `partial`): the worst case (every slice full) up to MSVS_CAND_CAP
+        // keys; beyond that the buffer may overflow, which only costs the query its certificate
+        const size_t cand_cap = big_cand_cap(nprobe, pl.seg_max);
+        // per query: running cut (0xFFFFFFFF = none yet) and append cursor of its candidate buffer
+        uint32_t * qstate = scr.take<uint32_t>(2 * nq);
+        a.qthr = qstate;
+        a.qcnt = qstate + nq;
+        a.cand_cap = (uint32_t)cand_cap;
+        MSVS_HIP(hipMemsetAsync(a.qthr, 0xFF, nq * sizeof(uint32_t), stream));
+        MSVS_HIP(hipMemsetAsync(a.qcnt, 0, nq * sizeof(uint32_t), stream));
+        launch_ivf_mfma_scan(scan_metric(m), pl.grid, a, stream);
         uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
-        uint64_t * bound = nullptr;
-        if (big)
-        {
-            bound = scr.take<uint64_t>(nq);
-            launch_cand_select(partial, a.qcnt, a.qthr, a.cand_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
-        }
-        else
-        {
-            IvfMergeParams cm{};
-            cm.partial = partial;
-            cm.probes = d_probes;
-            cm.list_off = ix.list_off.p;
-            cm.nprobe = (uint32_t)nprobe;
-            cm.seg_max = pl.seg_max;
-            cm.rows_per_block = pl.rpb;
-            cm.k = pl.kc;
-            cm.out_keys = cand;
-            launch_ivf_merge(scan_metric(m), cm, (uint32_t)nq, stream);
-        }
+        uint64_t * bound = scr.take<uint64_t>(nq);
+        launch_cand_select(partial, a.qcnt, a.qthr, a.cand_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
         uint32_t * failq = scr.take<uint32_t>(nq);
         RerankParams rp{};
         rp.Y = a.Y;
@@ -1031,11 +1078,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         rp.out_ids = d_ids;
         rp.out_dis = d_dis;
         rp.cosine = ix.metric == MSVS_METRIC_COSINE;
-        const char * es = getenv("MSVS_IVF_EPS_SCALE"); // experiment / test knob: inflate eps to force the fallback
-        const double scale = 1.05 * (es ? atof(es) : 1.0), dd = (double)ix.dim;
-        rp.c_dot = scale * (big ? 3.1 * ldexp(1.0, -16) + 3.05 * dd * ldexp(1.0, -23) : 2.0 * dd * ldexp(1.0, -23));
-        rp.c_norm = scale * (dd + 8.0) * ldexp(1.0, -24);
-        rp.c_canon = scale * 32.0 * ldexp(1.0, -24);
+        set_error_model(rp, ix.dim);
         rp.xmax = ix.xnorm_max;
         rp.failq = failq;
         rp.nfail = nfail;

@@ -188,6 +188,41 @@ def test_flat_index_filter_and_labels(metric, n, d, nq, k):
     same(ids, dis, oi, od)
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("n,d,nq,k", [(40000, 96, 200, 10), (20000, 768, 48, 10), (33000, 100, 130, 40), (5000, 20, 17, 1)])
+def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, monkeypatch):
+    """A batch against the whole table: matrix-core candidate pass + canonical re-rank, exact and certified; the
+    answer (ids, distance bits) must be the canonical exhaustive one, with filters, labels and forced fallbacks."""
+    rng = np.random.default_rng(n + d + nq)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    labels = rng.permutation(n * 2)[:n].astype(np.int64)
+    q = (x[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    ix = capi.Index(capi.INDEX_FLAT, metric, d)
+    ix.add(x, labels)
+    ix.build()
+    monkeypatch.setenv("MSVS_FLAT_MFMA", "2")  # also for the shapes below the automatic threshold
+    xs, qs, om = (o.normalize_rows(x), o.normalize_rows(q), o.METRIC_IP) if metric == capi.METRIC_COSINE else (x, q, OM[metric])
+
+    def expect(alive=None):
+        oi, od = o.knn(qs, xs, k, om, labels=labels, alive=None if alive is None else alive[labels])
+        return oi, ((np.float32(1) - od).astype(np.float32) if metric == capi.METRIC_COSINE else od)
+
+    q0, _ = capi.prefilter_stats()
+    ids, dis = ix.search(q, k)
+    same(ids, dis, *expect())
+    assert capi.prefilter_stats()[0] - q0 == nq  # the pass is the one that ran
+    alive = rng.random(n * 2) < 0.4
+    ids, dis = ix.search(q, k, alive=alive)
+    same(ids, dis, *expect(alive))
+    monkeypatch.setenv("MSVS_IVF_EPS_SCALE", "1e12")  # no certificates: canonical fallback for every query
+    ids, dis = ix.search(q, k)
+    same(ids, dis, *expect())
+    monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
+    monkeypatch.setenv("MSVS_FLAT_MFMA", "0")
+    ids, dis = ix.search(q, k)
+    same(ids, dis, *expect())
+
+
 # ---------------------------------------------------------------------------------------- seam A1: IVFFLAT
 
 def build_ivf(x, metric, nlist, ids=None, params=""):
@@ -258,6 +293,12 @@ def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, 
     q2, f2 = capi.prefilter_stats()
     assert f2 - f1 == nq
     monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
+    # candidate buffers far too small: overflowing queries lose their certificate and take the fallback, same answer
+    monkeypatch.setenv("MSVS_CAND_CAP", "64")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    monkeypatch.delenv("MSVS_CAND_CAP")
+    q2 = capi.prefilter_stats()[0]
     # the pass switched off: the list-batched canonical scan, same answer
     monkeypatch.setenv("MSVS_IVF_MFMA", "0")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
