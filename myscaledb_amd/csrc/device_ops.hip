@@ -345,12 +345,21 @@ void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t s
     MSVS_HIP(hipGetLastError());
 }
 
-void launch_single_list_plan(uint32_t nq, uint32_t nrows, uint32_t rows_per_block, uint32_t tq, uint32_t * pairs,
-                             int32_t * probes0, int64_t * list_off, uint32_t * pair_off, uint32_t * work_off,
-                             hipStream_t stream)
+void launch_single_list_plan(uint32_t nq, uint32_t row_begin, uint32_t row_end, uint32_t rows_per_block, uint32_t tq,
+                             uint32_t * pairs, int32_t * probes0, int64_t * list_off, uint32_t * pair_off,
+                             uint32_t * work_off, hipStream_t stream)
 {
     hipLaunchKernelGGL(single_list_plan_kernel, dim3((unsigned)ceil_div(std::max<uint32_t>(nq, 1), 256u)), dim3(256), 0,
-                       stream, nq, nrows, rows_per_block, tq, pairs, probes0, list_off, pair_off, work_off);
+                       stream, nq, row_begin, row_end, rows_per_block, tq, pairs, probes0, list_off, pair_off, work_off);
+    MSVS_HIP(hipGetLastError());
+}
+
+void launch_sample_cut(const uint64_t * cand, uint32_t kc, uint32_t m, uint32_t nq, uint32_t * qthr, hipStream_t stream)
+{
+    if (nq == 0)
+        return;
+    hipLaunchKernelGGL(sample_cut_kernel, dim3((unsigned)ceil_div(nq, 256u)), dim3(256), 0, stream, cand, kc, m, nq,
+                       qthr);
     MSVS_HIP(hipGetLastError());
 }
 

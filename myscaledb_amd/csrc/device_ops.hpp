@@ -83,10 +83,13 @@ void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uin
 /// a.partial through a.qcnt / a.qthr (see mfma_scan_kernels.hpp).
 void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t stream);
 
-/// One-list plan over a plain row table (see single_list_plan_kernel).
-void launch_single_list_plan(uint32_t nq, uint32_t nrows, uint32_t rows_per_block, uint32_t tq, uint32_t * pairs,
-                             int32_t * probes0, int64_t * list_off, uint32_t * pair_off, uint32_t * work_off,
-                             hipStream_t stream);
+/// One-list plan over rows [row_begin, row_end) of a plain row table (see single_list_plan_kernel).
+void launch_single_list_plan(uint32_t nq, uint32_t row_begin, uint32_t row_end, uint32_t rows_per_block, uint32_t tq,
+                             uint32_t * pairs, int32_t * probes0, int64_t * list_off, uint32_t * pair_off,
+                             uint32_t * work_off, hipStream_t stream);
+
+/// qthr[q] = min(qthr[q], distance word of cand[q][m-1]) (see sample_cut_kernel).
+void launch_sample_cut(const uint64_t * cand, uint32_t kc, uint32_t m, uint32_t nq, uint32_t * qthr, hipStream_t stream);
 
 /// Big-tile pass only: the kc best of every query's appended candidates + the bound of what the slices cut.
 void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint32_t * qthr, uint32_t cap, uint32_t nq,

@@ -496,11 +496,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
 }
 
-/// The one-list "plan" that lets the candidate pass run over a plain row table (the coarse quantiser's centroids):
-/// every query probes list 0 = rows [0, nrows).
-static __global__ void single_list_plan_kernel(uint32_t nq, uint32_t nrows, uint32_t rows_per_block, uint32_t tq,
-                                               uint32_t * pairs, int32_t * probes0, int64_t * list_off,
-                                               uint32_t * pair_off, uint32_t * work_off)
+/// The one-list "plan" that lets the candidate pass run over a plain row table (the coarse quantiser's centroids, a
+/// FLAT index): every query probes list 0 = rows [row_begin, row_end).
+static __global__ void single_list_plan_kernel(uint32_t nq, uint32_t row_begin, uint32_t row_end,
+                                               uint32_t rows_per_block, uint32_t tq, uint32_t * pairs,
+                                               int32_t * probes0, int64_t * list_off, uint32_t * pair_off,
+                                               uint32_t * work_off)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq)
@@ -510,13 +511,27 @@ static __global__ void single_list_plan_kernel(uint32_t nq, uint32_t nrows, uint
     }
     if (i == 0)
     {
-        list_off[0] = 0;
-        list_off[1] = nrows;
+        list_off[0] = row_begin;
+        list_off[1] = row_end;
         pair_off[0] = 0;
         pair_off[1] = nq;
         work_off[0] = 0;
-        work_off[1] = ((nq + tq - 1) / tq) * ((nrows + rows_per_block - 1) / rows_per_block);
+        work_off[1] = ((nq + tq - 1) / tq) * ((row_end - row_begin + rows_per_block - 1) / rows_per_block);
     }
+}
+
+/// Long tables: after the candidate pass over a SAMPLE of the rows, the m-th best sample candidate of a query becomes
+/// its cut for the rest of the table (about m * n / sample rows of the whole table lie below it), so the main pass
+/// appends a few dozen keys per query instead of a fixed fraction of the table.  The cut is an ordinary qthr value:
+/// the certificate accounts for it, and a cut that turns out too tight only sends the query to the fallback.
+static __global__ void sample_cut_kernel(const uint64_t * cand, uint32_t kc, uint32_t m, uint32_t nq, uint32_t * qthr)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq)
+        return;
+    const uint64_t key = cand[(size_t)q * kc + (m - 1)];
+    if (key != KEY_NONE)
+        atomicMin(&qthr[q], (uint32_t)(key >> 32));
 }
 
 /// The kc (<= 64) best of the keys a query's slices appended (unsorted runs), ascending, one block per query (the

@@ -824,8 +824,8 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     const uint32_t cap = (uint32_t)big_cand_cap(1, nslices);
     uint32_t * pairs = scr.take<uint32_t>(nq);
     int32_t * probes0 = scr.take<int32_t>(nq);
-    int64_t * list_off = scr.take<int64_t>(2);
-    uint32_t * small = scr.take<uint32_t>(5); // pair_off[2], work_off[2], nfail
+    int64_t * list_off = scr.take<int64_t>(6);  // whole table, sample, rest
+    uint32_t * small = scr.take<uint32_t>(9);   // pair_off[2], nfail, work_off[2] x 3
     uint32_t * qstate = scr.take<uint32_t>(2 * nq);
     float * qnorm = scr.take<float>(nq);
     uint64_t * candbuf = scr.take<uint64_t>(nq * (size_t)cap);
@@ -834,14 +834,28 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     uint32_t * failq = scr.take<uint32_t>(nq);
     const uint32_t rpb1 = table_fallback_rpb(t.n), seg_max1 = (uint32_t)ceil_div(t.n, (size_t)rpb1);
     uint64_t * partial1 = scr.take<uint64_t>(nq * (size_t)seg_max1 * t.k);
-    uint32_t * nfail = small + 4;
-    MSVS_HIP(hipMemsetAsync(small, 0, 5 * sizeof(uint32_t), stream));
+    uint32_t * nfail = small + 2;
+    MSVS_HIP(hipMemsetAsync(small, 0, 9 * sizeof(uint32_t), stream));
     MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
     MSVS_HIP(hipMemsetAsync(qstate + nq, 0, nq * sizeof(uint32_t), stream));
     // work item = 2 slices, or 1 when that is what it takes to give the chip ~1000 items
     const uint32_t rpb = ceil_div(nq, (size_t)BG_TQ) * ceil_div(t.n, (size_t)(2 * BG_ROWS)) < 1024 ? BG_ROWS : 2 * BG_ROWS;
-    launch_single_list_plan((uint32_t)nq, nrows, rpb, BG_TQ, pairs, probes0, list_off, small, small + 2, stream);
+    // plan 0: the whole table (also what the fallback scans)
+    launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, BG_TQ, pairs, probes0, list_off, small, small + 3, stream);
     launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
+    // A table too long for "16 keys per slice" to fit the candidate buffers is searched in two phases: a sample first,
+    // whose m-th best candidate becomes the query's cut for the rest (sample_cut_kernel)
+    const bool two_phase = (size_t)nslices * BG_SLICE_K > cap;
+    const uint32_t sample = two_phase
+        ? (uint32_t)std::min<size_t>(t.n / 2, round_up(std::max<size_t>(32768, t.n / 32), (size_t)rpb))
+        : 0;
+    if (two_phase)
+    {
+        launch_single_list_plan((uint32_t)nq, 0, sample, rpb, BG_TQ, pairs, probes0, list_off + 2, small, small + 5,
+                                stream);
+        launch_single_list_plan((uint32_t)nq, sample, nrows, rpb, BG_TQ, pairs, probes0, list_off + 4, small, small + 7,
+                                stream);
+    }
     ScanParams a{};
     a.Y = reinterpret_cast<const float4 *>(t.rows);
     a.ids = t.ids;
@@ -859,7 +873,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     a.seg_max = nslices;
     a.pairs = pairs;
     a.pair_off = small;
-    a.work_off = small + 2;
+    a.work_off = small + 3;
     a.nlist = 1;
     a.xcd_order = 1;
     a.qnorm = qnorm;
@@ -867,9 +881,27 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     a.qthr = qstate;
     a.qcnt = qstate + nq;
     a.cand_cap = cap;
-    const size_t items = ceil_div(nq, (size_t)BG_TQ) * ceil_div(t.n, (size_t)rpb);
+    const size_t tiles = ceil_div(nq, (size_t)BG_TQ);
     ProfileScope prof(t.prof_name, stream);
-    launch_ivf_mfma_scan(scan_metric(m), (uint32_t)std::min<size_t>(items, 2048), a, stream);
+    if (two_phase)
+    {
+        ScanParams sa = a;
+        sa.list_off = list_off + 2;
+        sa.work_off = small + 5;
+        launch_ivf_mfma_scan(scan_metric(m), (uint32_t)std::min<size_t>(tiles * ceil_div((size_t)sample, (size_t)rpb), 2048),
+                             sa, stream);
+        launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
+        // about 4k rows of the whole table below the cut (k of them are the answer), at least the 2nd sample candidate
+        const uint32_t mth = (uint32_t)std::min<size_t>(kc, 1 + ceil_div((size_t)4 * t.k * sample, t.n));
+        launch_sample_cut(cand, kc, std::max<uint32_t>(mth, 2), (uint32_t)nq, a.qthr, stream);
+        sa.list_off = list_off + 4;
+        sa.work_off = small + 7;
+        launch_ivf_mfma_scan(scan_metric(m),
+                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n - sample, (size_t)rpb), 2048), sa, stream);
+    }
+    else
+        launch_ivf_mfma_scan(scan_metric(m), (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 2048), a,
+                             stream);
     launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
     RerankParams rp{};
     rp.Y = a.Y;

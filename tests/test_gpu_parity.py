@@ -218,6 +218,13 @@ def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, monk
     ids, dis = ix.search(q, k)
     same(ids, dis, *expect())
     monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
+    # small candidate buffers = what a long table looks like: sample first, its m-th candidate cuts the rest
+    monkeypatch.setenv("MSVS_CAND_CAP", "1024")
+    ids, dis = ix.search(q, k)
+    same(ids, dis, *expect())
+    ids, dis = ix.search(q, k, alive=alive)
+    same(ids, dis, *expect(alive))
+    monkeypatch.delenv("MSVS_CAND_CAP")
     monkeypatch.setenv("MSVS_FLAT_MFMA", "0")
     ids, dis = ix.search(q, k)
     same(ids, dis, *expect())
