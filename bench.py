@@ -77,9 +77,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    # 1024 queries per step: about 4 ms of arrivals at the measured rate -- what a batching front end in front of
+    # 4096 queries per step: about 2.5 ms of arrivals at the measured rate -- what a batching front end in front of
     # `ScanThreadLimiter`-many client threads accumulates; single-query latency is reported separately
-    ap.add_argument("--batch", type=int, default=1024)
+    # (profiles/r01_ivf_tuning_sweep.txt has the batch sweep 1 .. 16384)
+    ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--nlist", type=int, default=1024)
@@ -105,7 +106,7 @@ def main():
     n, d, nlist, nprobe, k, B = args.rows, args.dim, args.nlist, args.nprobe, args.k, args.batch
     t_setup = time.time()
     model, x = make_data(n, d, 1234, dev)
-    n_pool = 16
+    n_pool = 8
     q_all = make_queries(model, n_pool * B, 4321, dev)
     q_lat = make_queries(model, 256, 777, dev)
 

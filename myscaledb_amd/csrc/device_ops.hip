@@ -333,11 +333,11 @@ void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uin
     MSVS_HIP(hipGetLastError());
 }
 
-void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t stream)
+void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t stream, const char * profile_name)
 {
     if (grid == 0)
         return;
-    ProfileScope prof("ivf_scan", stream);
+    ProfileScope prof(profile_name, stream);
     if (metric == M_IP)
         hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_IP>), dim3(grid), dim3(BLOCK), 0, stream, a);
     else

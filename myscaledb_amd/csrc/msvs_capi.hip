@@ -889,19 +889,22 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         sa.list_off = list_off + 2;
         sa.work_off = small + 5;
         launch_ivf_mfma_scan(scan_metric(m), (uint32_t)std::min<size_t>(tiles * ceil_div((size_t)sample, (size_t)rpb), 2048),
-                             sa, stream);
+                             sa, stream, "table_scan");
         launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
-        // about 4k rows of the whole table below the cut (k of them are the answer), at least the 2nd sample candidate
-        const uint32_t mth = (uint32_t)std::min<size_t>(kc, 1 + ceil_div((size_t)4 * t.k * sample, t.n));
-        launch_sample_cut(cand, kc, std::max<uint32_t>(mth, 2), (uint32_t)nq, a.qthr, stream);
+        // the m-th best sample candidate leaves ~m * n / sample rows of the table below the cut; the query fails its
+        // certificate when fewer than k + 1 of them do, i.e. when >= m of the table's k + m best rows fell into the
+        // sample: m = 6 at a 1/32 sample makes that ~1e-5 for k = 10 (m = 3 measured 1.6 % fallbacks)
+        const uint32_t mth = (uint32_t)std::min<size_t>(kc, std::max<size_t>(6, 2 + ceil_div((size_t)8 * t.k * sample, t.n)));
+        launch_sample_cut(cand, kc, mth, (uint32_t)nq, a.qthr, stream);
         sa.list_off = list_off + 4;
         sa.work_off = small + 7;
         launch_ivf_mfma_scan(scan_metric(m),
-                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n - sample, (size_t)rpb), 2048), sa, stream);
+                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n - sample, (size_t)rpb), 2048), sa, stream,
+                             "table_scan");
     }
     else
         launch_ivf_mfma_scan(scan_metric(m), (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 2048), a,
-                             stream);
+                             stream, "table_scan");
     launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
     RerankParams rp{};
     rp.Y = a.Y;
@@ -921,6 +924,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     rp.xmax = t.norm_max;
     rp.failq = failq;
     rp.nfail = nfail;
+    rp.stat_fail = t.out_probes ? nullptr : prefilter_fail_counter(); // msvs_prefilter_stats counts result passes
     launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
     // queries without a certificate: canonical scan of the table
     ScanParams c = a;

@@ -41,14 +41,17 @@ def flat_case(name, n, d, nqs, k, dev):
         q = make_queries(model, nq, 4321, dev)
         oi = torch.empty((nq, k), device=dev, dtype=torch.int64)
         od = torch.empty((nq, k), device=dev, dtype=torch.float32)
+        f0 = capi.prefilter_stats()
         dt = timed(lambda: ix.search_device(q.data_ptr(), nq, k, 0, oi.data_ptr(), od.data_ptr(), stream), 20)
+        f1 = capi.prefilter_stats()
         # passes over the rows: one per 128-query tile through the candidate pass (nq >= 16 on a table of >= 128
         # tile x slice work items), else one per 8-query tile of the canonical scan
         cand = nq >= 16 and -(-nq // 128) * -(-n // 128) >= 128
         passes = -(-nq // 128) if cand else (-(-nq // 8) if nq > 4 else 1)
         print("%s FLAT %dx%d nq=%d k=%d : %.3f ms/call  %.0f QPS  streamed %.2f GB -> %.0f GB/s  (per-query model %.0f GB/s)"
+              "  candidate pass (queries, fallbacks) = (%d, %d)"
               % (name, n, d, nq, k, dt * 1e3, nq / dt, passes * n * d * 4 / 1e9, passes * n * d * 4 / dt / 1e9,
-                 nq * n * d * 4 / dt / 1e9), flush=True)
+                 nq * n * d * 4 / dt / 1e9, f1[0] - f0[0], f1[1] - f0[1]), flush=True)
     ix.close()
     del x
 

@@ -11,9 +11,13 @@ import sys
 
 
 def mean(db, counter, kern):
+    """Mean over the launches of `kern` with its LARGEST grid (the list scan; the same kernel also runs the much smaller
+    coarse-quantiser pass)."""
     c = sqlite3.connect(db)
+    g = list(c.execute("select max(grid_size) from counters_collection where counter_name = ? and kernel_name like ?",
+                       (counter, "%" + kern + "%")))[0][0]
     r = list(c.execute("select count(*), avg(value) from counters_collection where counter_name = ? and "
-                       "kernel_name like ?", (counter, "%" + kern + "%")))
+                       "kernel_name like ? and grid_size = ?", (counter, "%" + kern + "%", g)))
     return r[0][0], (r[0][1] or 0.0)
 
 
@@ -30,7 +34,7 @@ def main():
            "calibration": {"kernel": "gather_rows_kernel", "expected_bytes": int(rows) * int(dim) * 4,
                            "fetch_x2_bytes": int(cal * 2 * 1024)},
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (separate passes), "
-                     "tools/pmc_workload.py 4 256; FETCH_SIZE x2 (gfx950), KiB -> bytes"}
+                     "tools/pmc_workload.py 4 %s; FETCH_SIZE x2 (gfx950), KiB -> bytes" % batch}
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
