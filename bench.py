@@ -181,7 +181,7 @@ def main():
     c_calls, c_ms = capi.profile_get("flat_scan")
     m_calls, m_ms = capi.profile_get("merge")
     others = {}
-    for fam in ("coarse_pass", "ivf_plan", "rerank", "fallback_scan", "fallback_merge"):
+    for fam in ("coarse_pass", "ivf_plan", "ivf_sample_scan", "rerank", "fallback_scan", "fallback_merge"):
         fc, fms = capi.profile_get(fam)
         if fc:
             others[fam] = round(fms / fc, 4)

@@ -243,6 +243,14 @@ void launch_ivf_plan(const IvfPlanParams & p, hipStream_t stream)
     MSVS_HIP(hipGetLastError());
 }
 
+void launch_ivf_plan_rescan(const IvfPlanParams & p, hipStream_t stream)
+{
+    if (p.n_pairs == 0)
+        return;
+    hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+    MSVS_HIP(hipGetLastError());
+}
+
 template <int METRIC, int T>
 static void ivf_batched_dispatch_r(uint32_t grid, const ScanParams & a, hipStream_t stream)
 {

@@ -67,6 +67,8 @@ void launch_ivf_scan(int metric, ScanParams a, hipStream_t stream);
 
 /// Group the (query, probed list) pairs by list: histogram, scans, scatter (p.cnt / p.fill must be zeroed).
 void launch_ivf_plan(const IvfPlanParams & p, hipStream_t stream);
+/// Only the two exclusive scans again (pair_off, work_off) for another row range / work-item size of the same pairs.
+void launch_ivf_plan_rescan(const IvfPlanParams & p, hipStream_t stream);
 
 /// List-batched IVF scan over the plan's work items; T in {2, 4, 8}; fixed grid of `grid` blocks.
 void launch_ivf_batched_scan(int metric, uint32_t T, uint32_t grid, ScanParams a, hipStream_t stream);

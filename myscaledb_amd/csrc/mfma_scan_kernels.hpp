@@ -254,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 hi = mid;
         }
         const uint32_t l = lo;
-        const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
+        const int64_t lbeg = a.list_off[l], lend = a.list_end ? a.list_end[l] : a.list_off[l + 1];
         const uint32_t local = w - a.work_off[l];
         const uint32_t pe = a.pair_off[l + 1];
         const uint32_t ntile = (pe - a.pair_off[l] + BG_TQ - 1) / BG_TQ;

@@ -256,6 +256,7 @@ struct msvs_index
     float xnorm_max = 0.f;
     DevBuf<float> cnorm; // same for the centroids (the coarse quantiser goes through the same pass)
     float cnorm_max = 0.f;
+    DevBuf<int64_t> list_mid; // nlist: end of the SAMPLE slice of list l = min(list_off[l] + 128, list_off[l+1])
     bool ready = false;
 };
 
@@ -267,6 +268,12 @@ static void index_finalize_norms(msvs_index & ix, hipStream_t stream)
     DevBuf<uint32_t> mx(1);
     if (ix.type == MSVS_INDEX_IVFFLAT && ix.nlist)
     {
+        std::vector<int64_t> mid(ix.nlist);
+        for (size_t l = 0; l < ix.nlist; l++)
+            mid[l] = std::min<int64_t>(ix.h_list_off[l] + BG_ROWS, ix.h_list_off[l + 1]);
+        ix.list_mid.alloc(ix.nlist);
+        MSVS_HIP(hipMemcpyAsync(ix.list_mid.p, mid.data(), ix.nlist * 8, hipMemcpyHostToDevice, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
         ix.cnorm.alloc(ix.nlist);
         MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
         launch_row_sqnorm(ix.centroids.p, ix.cnorm.p, ix.nlist, ix.ld / 4, mx.p, stream);
@@ -635,7 +642,7 @@ extern "C" size_t msvs_index_num_lists(const msvs_index_t * ix)
 extern "C" size_t msvs_index_memory_usage(const msvs_index_t * ix)
 {
     return ix ? ix->vecs.bytes() + ix->row_ids.bytes() + ix->centroids.bytes() + ix->list_off.bytes()
-            + ix->xnorm.bytes() + ix->cnorm.bytes()
+            + ix->xnorm.bytes() + ix->cnorm.bytes() + ix->list_mid.bytes()
               : 0;
 }
 
@@ -754,7 +761,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe)
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
         + nq * nprobe * 4
-        + (4 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
+        + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
     if (p.mfma())
         need += nq * big_cand_cap(nprobe, p.seg_max) * 8
             + nq * (size_t)p.kc * 8 + nq * 24 + 8192
@@ -1059,10 +1066,14 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     a.nlist = (uint32_t)ix.nlist;
     if (pl.mfma())
     {
-        // many queries per list: matrix-core candidate pass, canonical re-rank, certified (mfma_scan_kernels.hpp)
+        // many queries per list: matrix-core candidate pass, canonical re-rank, certified (mfma_scan_kernels.hpp).
+        // Two phases: the first 128 rows of every probed list are a SAMPLE of the rows the query will see; its m-th
+        // best candidate becomes the query's cut for the rest (about m / sample-fraction rows of everything lie below
+        // it), which keeps the candidate buffers and the selection work small whatever the data looks like.
         IvfPlanParams pp{};
         pp.probes = d_probes;
-        pp.list_off = ix.list_off.p;
+        pp.list_off = ix.list_mid.p;       // phase B: rows [mid, end) of every list
+        pp.list_end = ix.list_off.p + 1;
         pp.n_pairs = (uint32_t)(nq * nprobe);
         pp.nlist = (uint32_t)ix.nlist;
         pp.rows_per_block = pl.rpb;
@@ -1076,11 +1087,16 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         pp.pairs = scr.take<uint32_t>(nq * nprobe);
         MSVS_HIP(hipMemsetAsync(counters, 0, (2 * ix.nlist + 1) * sizeof(uint32_t), stream));
         launch_ivf_plan(pp, stream);
+        IvfPlanParams pa = pp;             // phase A: rows [begin, mid), one 128-row work item per (list, query tile)
+        pa.list_off = ix.list_off.p;
+        pa.list_end = ix.list_mid.p;
+        pa.rows_per_block = BG_ROWS;
+        pa.work_off = scr.take<uint32_t>(ix.nlist + 1);
+        launch_ivf_plan_rescan(pa, stream);
         float * qnorm = scr.take<float>(nq);
         launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
         a.pairs = pp.pairs;
         a.pair_off = pp.pair_off;
-        a.work_off = pp.work_off;
         const char * xo = getenv("MSVS_IVF_XCD");
         a.xcd_order = xo ? (uint32_t)atoi(xo) : 1u;
         a.k = pl.kc;
@@ -1096,9 +1112,26 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         a.cand_cap = (uint32_t)cand_cap;
         MSVS_HIP(hipMemsetAsync(a.qthr, 0xFF, nq * sizeof(uint32_t), stream));
         MSVS_HIP(hipMemsetAsync(a.qcnt, 0, nq * sizeof(uint32_t), stream));
-        launch_ivf_mfma_scan(scan_metric(m), pl.grid, a, stream);
         uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
         uint64_t * bound = scr.take<uint64_t>(nq);
+        {
+            ScanParams sa = a;
+            sa.list_off = pa.list_off;
+            sa.list_end = pa.list_end;
+            sa.work_off = pa.work_off;
+            sa.rows_per_block = BG_ROWS;
+            launch_ivf_mfma_scan(scan_metric(m), pl.grid, sa, stream, "ivf_sample_scan");
+            launch_cand_select(partial, a.qcnt, a.qthr, a.cand_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
+            // m-th sample candidate: ~8k rows of everything below the cut (see sample_cut_kernel, table pass)
+            const size_t avg_len = std::max<size_t>(1, ix.n / std::max<size_t>(ix.nlist, 1));
+            const size_t mth = 2 + ceil_div((size_t)8 * k * std::min<size_t>(avg_len, BG_ROWS), avg_len);
+            launch_sample_cut(cand, pl.kc, (uint32_t)std::min<size_t>(pl.kc, std::max<size_t>(6, mth)), (uint32_t)nq,
+                              a.qthr, stream);
+        }
+        a.list_off = pp.list_off;
+        a.list_end = pp.list_end;
+        a.work_off = pp.work_off;
+        launch_ivf_mfma_scan(scan_metric(m), pl.grid, a, stream);
         launch_cand_select(partial, a.qcnt, a.qthr, a.cand_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
         uint32_t * failq = scr.take<uint32_t>(nq);
         RerankParams rp{};
@@ -1124,6 +1157,8 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         // queries without a certificate: canonical scan, one query per block (normally zero of them)
         uint64_t * partial1 = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max1 * k);
         ScanParams c = a;
+        c.list_off = ix.list_off.p; // the fallback scans whole lists
+        c.list_end = nullptr;
         c.k = k;
         c.partial = partial1;
         c.rows_per_block = pl.rpb1;

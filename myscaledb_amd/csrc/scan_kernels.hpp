@@ -224,6 +224,7 @@ struct ScanParams
     // IVF front end
     const int32_t * probes;   // [nq][nprobe] list ids (-1 = none)
     const int64_t * list_off; // [nlist+1]
+    const int64_t * list_end; // candidate pass only, nullable: rows of list l end here instead of at list_off[l+1]
     uint32_t nprobe;
     uint32_t seg_max;
     // list-batched IVF front end (see IvfPlanParams)
@@ -494,6 +495,7 @@ struct IvfPlanParams
 {
     const int32_t * probes;   // [n_pairs] list id of pair i = q*nprobe + p (-1 = none)
     const int64_t * list_off; // [nlist+1]
+    const int64_t * list_end; // nullable: end of list l (else list_off[l+1])
     uint32_t n_pairs;
     uint32_t nlist;
     uint32_t rows_per_block;
@@ -533,7 +535,7 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
         if (l < p.nlist)
         {
             c = p.cnt[l];
-            uint32_t len = (uint32_t)(p.list_off[l + 1] - p.list_off[l]);
+            uint32_t len = (uint32_t)((p.list_end ? p.list_end[l] : p.list_off[l + 1]) - p.list_off[l]);
             w = ((c + p.T - 1) / p.T) * ((len + p.rows_per_block - 1) / p.rows_per_block);
         }
         int cur = 0;

@@ -543,6 +543,27 @@ def test_full_size_1m_x_768_properties():
     same(fi[:2], fd[:2], oe, de)
     # nprobe=256 of 1024 lists on iid gaussians is not exhaustive; it can only be worse or equal, never better
     assert (ad >= fd - 0).all()
+    # (6) a 2048-query batch goes through the matrix-core candidate pass (coarse quantiser included); a query's answer
+    #     must not depend on the batch it travels in: compare with the same queries searched 16 at a time (canonical
+    #     kernels) and with the oracle
+    g2 = torch.Generator(device="cuda").manual_seed(99)
+    big = torch.randn((2048, d), generator=g2, device="cuda", dtype=torch.float32).cpu().numpy()
+    q0, f0 = capi.prefilter_stats()
+    bi, bd = ix.search(big, k, "nprobe=%d" % nprobe)
+    q1, f1 = capi.prefilter_stats()
+    assert q1 - q0 == 2048 and f1 - f0 <= 64
+    pick = np.arange(0, 2048, 64)
+    si, sd = ix.search(big[pick[:16]], k, "nprobe=%d" % nprobe)
+    same(bi[pick[:16]], bd[pick[:16]], si, sd)
+    si, sd = ix.search(big[pick[16:]], k, "nprobe=%d" % nprobe)
+    same(bi[pick[16:]], bd[pick[16:]], si, sd)
+    assert capi.prefilter_stats()[0] == q1  # those really were canonical runs
+    oi, od, _ = o.ivf_search(cent, off, vecs, lids, big[pick[:4]], nprobe, k, o.METRIC_L2, threads=8)
+    same(bi[pick[:4]], bd[pick[:4]], oi, od)
+    # (7) the exact FLAT scan of a batch (two-phase table pass) == the canonical exhaustive scan
+    fi2, fd2 = flat.search(big[:128], k)
+    fs, fds = flat.search(big[:8], k)
+    same(fi2[:8], fd2[:8], fs, fds)
 
 
 # ---------------------------------------------------------------------------------------- hybrid (config 5 shape)

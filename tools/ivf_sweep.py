@@ -40,7 +40,8 @@ for c in sys.argv[1:]:
     run(B, steps=5)
     capi.profile_enable(False)
     fam = {}
-    for name in ("flat_scan", "merge", "ivf_plan", "ivf_scan", "rerank", "fallback_scan", "fallback_merge"):
+    for name in ("flat_scan", "coarse_pass", "merge", "ivf_plan", "ivf_sample_scan", "ivf_scan", "rerank", "fallback_scan",
+                 "fallback_merge"):
         c, ms = capi.profile_get(name)
         if c:
             fam[name] = round(ms / 8, 4)  # 3 warmup + 5 steps
