@@ -650,7 +650,7 @@ constexpr uint32_t HEADS_CAP = 6144; // keys a merge block stages in LDS (48 KiB
 inline size_t merge_lds_bytes(uint32_t k, uint32_t nprobe)
 {
     size_t heads = (size_t)HEADS_CAP * 8 + (size_t)k * 8 + (size_t)HEADS_CAP * 2 + ((size_t)nprobe + 1) * 4 + 64;
-    size_t fallback = (size_t)5 * k * 8 + 4 * 8;
+    size_t fallback = (size_t)5 * k * 8;
     return heads > fallback ? heads : fallback;
 }
 
@@ -731,8 +731,6 @@ struct IvfMergeParams
     int cosine;
     uint64_t * out_keys;     // non-null: write the merged keys [nq][k] instead of (ids, distances)
     int32_t * out_probes;    // non-null: write [nq][k] int32 ids instead (the coarse quantiser's probe lists)
-    uint32_t list_len;       // length of a partial list (0: k); may be < k when the lists are per-slice pre-selections
-    uint64_t * out_bound;    // nullable [nq]: min over the FULL partial lists of their last key (what they may have cut)
     const uint32_t * qmap;   // subset kernel: the queries to merge ...
     const uint32_t * qcount; // ... and how many of them (device side)
 };
@@ -742,7 +740,7 @@ template <int METRIC, int R>
 __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const uint32_t q)
 {
     uint64_t * lds = reinterpret_cast<uint64_t *>(msvs_smem);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k, L = a.list_len ? a.list_len : a.k;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k;
     auto emit = [&](uint32_t i, uint64_t key) {
         const size_t o = (size_t)q * k + i;
         if (a.out_keys)
@@ -788,33 +786,21 @@ __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const 
         }
         __syncthreads();
         const uint32_t P = lbase[a.nprobe];
-        if ((uint64_t)P * L <= HEADS_CAP)
+        if ((uint64_t)P * k <= HEADS_CAP)
         {
             // one flat loop over the padded (probe, segment-slot, rank) space: every load is independent, so the
             // copy costs one memory latency instead of one per probe
-            const uint32_t slots = a.seg_max * L, padded = a.nprobe * slots;
+            const uint32_t slots = a.seg_max * k, padded = a.nprobe * slots;
             const uint64_t * src = a.partial + (size_t)q * padded;
             for (uint32_t i = tid; i < padded; i += BLOCK)
             {
                 const uint32_t p = i / slots, r = i - p * slots;
-                if (r < (lbase[p + 1] - lbase[p]) * L)
-                    keys[(size_t)lbase[p] * L + r] = src[i];
+                if (r < (lbase[p + 1] - lbase[p]) * k)
+                    keys[(size_t)lbase[p] * k + r] = src[i];
             }
             __syncthreads();
             if (wave == 0)
-                wave_heads_merge(keys, P, L, idx, outk, k, lane);
-            else if (wave == 1 && a.out_bound)
-            {
-                uint64_t b = KEY_NONE; // a list that is not full ends in KEY_NONE and drops out of the minimum
-                for (uint32_t i = lane; i < P; i += WAVE)
-                {
-                    const uint64_t t = keys[(size_t)i * L + L - 1];
-                    b = t < b ? t : b;
-                }
-                b = wave_min_u64(b);
-                if (lane == 0)
-                    a.out_bound[q] = b;
-            }
+                wave_heads_merge(keys, P, k, idx, outk, k, lane);
             __syncthreads();
             for (uint32_t i = tid; i < k; i += BLOCK)
                 emit(i, outk[i]);
@@ -825,15 +811,14 @@ __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const 
 
     WaveTopK<R> top;
     top.init();
-    uint64_t bnd = KEY_NONE;
     for (uint32_t p = wave; p < a.nprobe; p += 4)
     {
         const int32_t l = __builtin_amdgcn_readfirstlane(a.probes[(size_t)q * a.nprobe + p]);
         if (l < 0)
             continue;
         const uint32_t len = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
-        const uint32_t n = ((len + a.rows_per_block - 1) / a.rows_per_block) * L;
-        const uint64_t * src = a.partial + ((size_t)q * a.nprobe + p) * a.seg_max * L;
+        const uint32_t n = ((len + a.rows_per_block - 1) / a.rows_per_block) * k;
+        const uint64_t * src = a.partial + ((size_t)q * a.nprobe + p) * a.seg_max * k;
         for (uint32_t base = 0; base < n; base += 4 * WAVE)
         {
             uint64_t key[4];
@@ -842,8 +827,6 @@ __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const 
             {
                 uint32_t i = base + u * WAVE + lane;
                 key[u] = i < n ? src[i] : KEY_NONE;
-                if (i % L == L - 1 && key[u] < bnd)
-                    bnd = key[u];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++)
@@ -851,21 +834,11 @@ __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const 
         }
     }
     top.store(lds + wave * k, k, lane);
-    bnd = wave_min_u64(bnd);
-    if (lane == 0)
-        lds[5 * k + wave] = bnd;
     __syncthreads();
     uint64_t * merged = lds + 4 * k;
     block_rank_merge(lds, k, merged, k, tid);
     for (uint32_t i = tid; i < k; i += BLOCK)
         emit(i, merged[i]);
-    if (tid == 0 && a.out_bound)
-    {
-        uint64_t b = lds[5 * k];
-        for (int w2 = 1; w2 < 4; w2++)
-            b = lds[5 * k + w2] < b ? lds[5 * k + w2] : b;
-        a.out_bound[q] = b;
-    }
 }
 
 /// One block per query.
