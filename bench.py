@@ -178,10 +178,12 @@ def main():
     capi.profile_enable(False)
     pf1 = capi.prefilter_stats()
     calls, total_ms = capi.profile_get("ivf_scan")
+    s_calls, s_ms = capi.profile_get("ivf_sample_scan")  # the list scan's sample phase (candidate pass): same kernel,
+    total_ms += s_ms                                      # same step -- counted into the dominant kernel's time
     c_calls, c_ms = capi.profile_get("flat_scan")
     m_calls, m_ms = capi.profile_get("merge")
     others = {}
-    for fam in ("coarse_pass", "ivf_plan", "ivf_sample_scan", "rerank", "fallback_scan", "fallback_merge"):
+    for fam in ("coarse_pass", "ivf_plan", "rerank", "fallback_scan", "fallback_merge"):
         fc, fms = capi.profile_get(fam)
         if fc:
             others[fam] = round(fms / fc, 4)
@@ -311,6 +313,7 @@ def main():
                            "+ certificate follow)") if cand_pass else (
                     "ivf_batched_scan_kernel (T-query tiles per list pass)" if B * nprobe >= nlist
                     else "ivf_scan_kernel"), "launch_ms": round(scan_ms, 4),
+                "launches_per_step": 2 if s_calls else 1,
                 "bytes_per_launch": int(bytes_per_launch), "flops_per_launch": int(flops_per_launch),
                 "note": "hbm: achieved = union of the batch's probed rows x (4d+4) B / kernel time (each probed row "
                         "must leave HBM at least once per launch); mfma: canonical scan = 3 flop per (query,row,element)"

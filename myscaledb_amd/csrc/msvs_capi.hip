@@ -676,7 +676,8 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     {
         const char * e = getenv("MSVS_IVF_MFMA"); // experiment knob: 0 = never, 2 = whenever eligible
         const int mode = e ? atoi(e) : 1;
-        const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f; // false for NaN
+        // row positions travel in the low word of the candidate keys: < 2^32 rows; NaN norms compare false
+        const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f && ix.n <= 0xfffffff0ull;
         if (mode != 0 && eligible && (pairs >= 4 * nlist || mode >= 2))
         {
             p.T = BG_TQ;

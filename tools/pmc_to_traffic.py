@@ -11,14 +11,19 @@ import sys
 
 
 def mean(db, counter, kern):
-    """Mean over the launches of `kern` with its LARGEST grid (the list scan; the same kernel also runs the much smaller
-    coarse-quantiser pass)."""
+    """Per-step value of the list scan: the launches of `kern` with its LARGEST grid (the same kernel also runs the much
+    smaller coarse-quantiser pass) come in pairs -- a short sample phase and the main phase (value >= half the largest);
+    returns (main launches sampled, mean main + mean sample)."""
     c = sqlite3.connect(db)
     g = list(c.execute("select max(grid_size) from counters_collection where counter_name = ? and kernel_name like ?",
                        (counter, "%" + kern + "%")))[0][0]
-    r = list(c.execute("select count(*), avg(value) from counters_collection where counter_name = ? and "
-                       "kernel_name like ? and grid_size = ?", (counter, "%" + kern + "%", g)))
-    return r[0][0], (r[0][1] or 0.0)
+    mx = list(c.execute("select max(value) from counters_collection where counter_name = ? and kernel_name like ? "
+                        "and grid_size = ?", (counter, "%" + kern + "%", g)))[0][0] or 0.0
+    q = ("select count(*), avg(value) from counters_collection where counter_name = ? and kernel_name like ? "
+         "and grid_size = ? and value %s ?")
+    hi = list(c.execute(q % ">=", (counter, "%" + kern + "%", g, 0.5 * mx)))[0]
+    lo = list(c.execute(q % "<", (counter, "%" + kern + "%", g, 0.5 * mx)))[0]
+    return hi[0], (hi[1] or 0.0) + (lo[1] or 0.0)
 
 
 def main():
@@ -33,6 +38,7 @@ def main():
            "write_bytes_per_launch": int(w * 1024), "hbm_bytes_per_launch": int(f * 2 * 1024 + w * 1024),
            "calibration": {"kernel": "gather_rows_kernel", "expected_bytes": int(rows) * int(dim) * 4,
                            "fetch_x2_bytes": int(cal * 2 * 1024)},
+           "unit": "one search step = sample-phase launch + main-phase launch of the list scan",
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (separate passes), "
                      "tools/pmc_workload.py 4 %s; FETCH_SIZE x2 (gfx950), KiB -> bytes" % batch}
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
