@@ -341,15 +341,23 @@ void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uin
     MSVS_HIP(hipGetLastError());
 }
 
-void launch_ivf_mfma_scan(int metric, uint32_t grid, ScanParams a, hipStream_t stream, const char * profile_name)
+void launch_ivf_mfma_scan(int metric, uint32_t nqg, uint32_t grid, ScanParams a, hipStream_t stream,
+                          const char * profile_name)
 {
     if (grid == 0)
         return;
     ProfileScope prof(profile_name, stream);
-    if (metric == M_IP)
-        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_IP>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    if (nqg == 2)
+    {
+        if (metric == M_IP)
+            hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_IP, 2>), dim3(grid), dim3(2 * BLOCK), 0, stream, a);
+        else
+            hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_L2, 2>), dim3(grid), dim3(2 * BLOCK), 0, stream, a);
+    }
+    else if (metric == M_IP)
+        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_IP, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
     else
-        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_L2>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_L2, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
     MSVS_HIP(hipGetLastError());
 }
 

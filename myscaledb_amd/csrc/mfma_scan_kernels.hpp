@@ -209,34 +209,43 @@ __device__ __forceinline__ uint64_t wave_select16(const uint64_t k0, const uint6
     return v;
 }
 
-/// Work item = (list, tile of <= 128 probing queries, segment of a.rows_per_block rows (a multiple of 128)); plan built
-/// with T = BG_TQ.  Every (query, 128-row slice) appends its <= 16 best (approximate key, row position) at
+/// Work item = (list, tile of <= 128 * NQG probing queries, segment of a.rows_per_block rows (a multiple of 128)); plan
+/// built with T = BG_TQ * NQG.  Every (query, 128-row slice) appends its <= 16 best (approximate key, row position) at
 /// a.partial[q * a.cand_cap + atomicAdd(a.qcnt[q], n)].  a.cand_cap may be smaller than 16 * (slices the query can
 /// meet): keys past the capacity are dropped, qcnt keeps counting, and cand_select_kernel turns qcnt > cap into a
-/// failed certificate (canonical fallback) -- with the running cut at work a query appends a few hundred keys.
-template <int METRIC>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void ivf_mfma_scan_big_kernel(
+/// failed certificate (canonical fallback) -- with the cut at work a query appends a few hundred keys.
+///
+/// NQG = 1: 4 wavefronts, 128-query tiles, 71 KB of LDS, two workgroups per CU.
+/// NQG = 2: 8 wavefronts, 256-query tiles: wavefronts 0-3 and 4-7 multiply the SAME staged rows by the first / second
+///          128 queries, so a list probed by up to 256 queries of the batch is read once (at ~200 queries per list the
+///          128-query tiles read it 1.9 times); 102 KB of LDS, one workgroup per CU, same 8 wavefronts per CU.
+template <int METRIC, int NQG>
+__global__ __launch_bounds__(BLOCK * NQG) __attribute__((amdgpu_waves_per_eu(2, 2))) void ivf_mfma_scan_big_kernel(
     const ScanParams a)
 {
-    // Operand stage: 2 buffers x 4 planes (rows hi, rows lo, queries hi, queries lo) x 128 rows x 64 B (32 bf16 of the
-    // reduction step).  A row's four 16-byte chunks are XOR-swizzled by (row >> 2) & 3, which makes both the 8-byte
-    // staging writes and the 16-lane ds_read_b128 operand reads bank-conflict free without padding.
-    constexpr uint32_t PLANE = BG_ROWS * 64, BUF = 4 * PLANE;
+    constexpr uint32_t THREADS = BLOCK * NQG, NWAVE = 4 * NQG, TQ = BG_TQ * NQG;
+    constexpr uint32_t RS = THREADS / 8;       // rows covered by one pass of the loader (8 threads per 128-byte row)
+    constexpr int XPT = BG_ROWS / RS;          // row float4 per thread and step: 4 (NQG = 1) / 2 (NQG = 2)
+    constexpr int QPT = TQ / RS;               // query float4 per thread and step: 4
+    // Operand stage: 2 buffers x {rows hi, rows lo: 128 x 64 B; queries hi, queries lo: TQ x 64 B} (32 bf16 of the
+    // reduction step per row).  A row's four 16-byte chunks are XOR-swizzled by (row >> 2) & 3, which makes both the
+    // 8-byte staging writes and the 16-lane ds_read_b128 operand reads bank-conflict free without padding.
+    constexpr uint32_t XPLANE = BG_ROWS * 64, QPLANE = TQ * 64, BUF = 2 * XPLANE + 2 * QPLANE;
     constexpr uint32_t STAGE_BYTES = 2 * BUF > BG_TQ * MF_LDS * 4 ? 2 * BUF : BG_TQ * MF_LDS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char stage[STAGE_BYTES];
-    __shared__ uint64_t sel_s[4][BG_SLICE_K];
-    __shared__ uint32_t thr_s[BG_TQ];
+    __shared__ uint64_t sel_s[NWAVE][BG_SLICE_K];
+    __shared__ uint32_t thr_s[TQ];
     __shared__ float xn_s[BG_ROWS];
-    __shared__ float qn_s[BG_TQ];
-    __shared__ uint32_t qrow_s[BG_TQ];
-    __shared__ uint32_t qpair_s[BG_TQ];
+    __shared__ float qn_s[TQ];
+    __shared__ uint32_t qrow_s[TQ];
+    __shared__ uint32_t qpair_s[TQ];
     float * const Ss = reinterpret_cast<float *>(stage); // distance tile [128 queries][128 rows (+4)]: reuses the stage
-    static_assert(BG_ROWS == BG_TQ, "one plane size for rows and queries");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const uint32_t wr = wave & 3, qg = wave >> 2; // wavefront tile: rows 32*wr .. +31 x queries 128*qg .. +127
     const uint32_t ld4 = a.ld4;
     const uint32_t nk = (ld4 + 7) / 8;
-    const uint32_t lc = tid & 7, lr = tid >> 3; // loader: float4 column lc of rows / queries lr + 32*i
+    const uint32_t lc = tid & 7, lr = tid >> 3; // loader: float4 column lc of rows / queries lr + RS*i
     const uint32_t total = a.work_off[a.nlist];
     const uint32_t per_xcd = (total + 7) / 8;
     for (uint32_t s = blockIdx.x; s < 8 * per_xcd; s += gridDim.x)
@@ -257,16 +266,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         const int64_t lbeg = a.list_off[l], lend = a.list_end ? a.list_end[l] : a.list_off[l + 1];
         const uint32_t local = w - a.work_off[l];
         const uint32_t pe = a.pair_off[l + 1];
-        const uint32_t ntile = (pe - a.pair_off[l] + BG_TQ - 1) / BG_TQ;
+        const uint32_t ntile = (pe - a.pair_off[l] + TQ - 1) / TQ;
         const uint32_t seg = local / ntile, tile = local - seg * ntile;
-        const uint32_t pb = a.pair_off[l] + tile * BG_TQ;
-        const uint32_t nvalid = pe - pb < (uint32_t)BG_TQ ? pe - pb : (uint32_t)BG_TQ;
-        const uint32_t ncb = (nvalid + 31) >> 5; // 32-query column blocks in use
+        const uint32_t pb = a.pair_off[l] + tile * TQ;
+        const uint32_t nvalid = pe - pb < TQ ? pe - pb : TQ;
+        const uint32_t ncb = (nvalid + 31) >> 5; // 32-query column blocks in use (of 4 * NQG)
         const int64_t rb = lbeg + (int64_t)seg * a.rows_per_block;
         const int64_t re = rb + a.rows_per_block < lend ? rb + a.rows_per_block : lend;
 
         __syncthreads(); // the previous work item is done with the tables and the stage
-        if (tid < BG_TQ)
+        if (tid < TQ)
         {
             const uint32_t pi = pb + tid < pe ? pb + tid : pe - 1; // short tiles repeat their last pair (never selected)
             const uint32_t qp = a.pairs[pi];
@@ -279,26 +288,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             xn_s[tid] = a.xnorm[rb + tid < re ? rb + tid : re - 1];
         __syncthreads();
 
-        const float4 * qsrc[4];
-        bool qld[4];
+        const float4 * qsrc[QPT];
+        bool qld[QPT];
+#pragma unroll
+        for (int i = 0; i < QPT; i++)
+        {
+            qsrc[i] = a.Q + (size_t)qrow_s[lr + RS * i] * ld4;
+            qld[i] = (lr + RS * i) / 32 < ncb; // the column block of query row lr + RS*i is in use
+        }
         float qn[4];
 #pragma unroll
         for (int i = 0; i < 4; i++)
-        {
-            qsrc[i] = a.Q + (size_t)qrow_s[lr + 32 * i] * ld4;
-            qld[i] = (uint32_t)i < ncb; // query row lr + 32*i lies in column block i
-            qn[i] = qn_s[32 * i + r32];
-        }
+            qn[i] = qn_s[128 * qg + 32 * i + r32];
+        // this wavefront's column blocks (global index 4*qg + i) in use
+        const uint32_t mycb = ncb > 4 * qg ? (ncb - 4 * qg < 4 ? ncb - 4 * qg : 4) : 0;
 
         int64_t pf_sub = rb; // prefetch position of the software pipeline over (sub-tile, reduction step)
         uint32_t pf_ki = 0;
-        const float4 * xsrc[4];
-        float4 px[4], pq[4];
+        const float4 * xsrc[XPT];
+        float4 px[XPT], pq[QPT];
         auto set_rows = [&](int64_t sub) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < XPT; i++)
             {
-                int64_t row = sub + lr + 32 * i;
+                int64_t row = sub + lr + RS * i;
                 if (row >= re)
                     row = re - 1; // rows past the segment repeat its last row; they are never offered
                 xsrc[i] = a.Y + (size_t)row * ld4;
@@ -308,10 +321,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             const uint32_t c = pf_ki * 8 + lc;
             const bool in = c < ld4;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < XPT; i++)
                 px[i] = in ? xsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < QPT; i++)
                 pq[i] = in && qld[i] ? qsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f);
         };
         auto advance = [&]() {
@@ -323,25 +336,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     set_rows(pf_sub);
             }
         };
-        // float4 -> 4 bf16 hi + 4 bf16 lo, written to the swizzled position of (row, float4 column lc)
-        auto split_store = [&](unsigned char * hi_plane, const uint32_t row, const float4 v) {
+        // float4 -> 4 bf16 hi + 4 bf16 lo, written to the swizzled position of (row, float4 column lc); the lo plane
+        // follows the hi plane at `plane` bytes
+        auto split_store = [&](unsigned char * hi_plane, const uint32_t plane, const uint32_t row, const float4 v) {
             const uint32_t h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
             const float fx = __uint_as_float(h01 << 16), fy = __uint_as_float(h01 & 0xffff0000u);
             const float fz = __uint_as_float(h23 << 16), fw = __uint_as_float(h23 & 0xffff0000u);
             const uint32_t l01 = pack_bf16(v.x - fx, v.y - fy), l23 = pack_bf16(v.z - fz, v.w - fw);
             const uint32_t off = row * 64 + ((((lc >> 1) ^ (row >> 2)) & 3) << 4) + ((lc & 1) << 3);
             *reinterpret_cast<uint2 *>(hi_plane + off) = make_uint2(h01, h23);
-            *reinterpret_cast<uint2 *>(hi_plane + PLANE + off) = make_uint2(l01, l23);
+            *reinterpret_cast<uint2 *>(hi_plane + plane + off) = make_uint2(l01, l23);
         };
         auto sstore = [&](int buf) {
             unsigned char * base = stage + buf * BUF;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                split_store(base, lr + 32 * i, px[i]);
+            for (int i = 0; i < XPT; i++)
+                split_store(base, XPLANE, lr + RS * i, px[i]);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < QPT; i++)
                 if (qld[i])
-                    split_store(base + 2 * PLANE, lr + 32 * i, pq[i]);
+                    split_store(base + 2 * XPLANE, QPLANE, lr + RS * i, pq[i]);
         };
         set_rows(rb);
         gload();
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             float xn_next = 0.f;
             if (METRIC == M_L2 && has_next && tid < BG_ROWS)
                 xn_next = a.xnorm[sub + BG_ROWS + tid < re ? sub + BG_ROWS + tid : re - 1];
-            if (tid < BG_TQ)
+            if (tid < TQ)
                 thr_s[tid] = a.qthr[qrow_s[tid]]; // read by the selection, at least one barrier from here
             bool okrow[2];
 #pragma unroll
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 okrow[u] = ok;
             }
 
-            f32x16 acc0, acc1, acc2, acc3; // one per 32-query column block
+            f32x16 acc0, acc1, acc2, acc3; // one per 32-query column block of this wavefront's 128 queries
 #pragma unroll
             for (int r = 0; r < 16; r++)
             {
@@ -386,6 +400,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 const bool more = pf_sub < re;
                 if (more)
                     gload();
+                if (mycb)
                 {
                     // lane (r32, h) feeds row / query r32 with reduction elements 16*j + 8*h .. +7 (chunk 2j + h) of
                     // each 32x32x16 product; both operands use the same positions, so the element order inside the
@@ -393,18 +408,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     const unsigned char * base = stage + cur * BUF;
                     const uint32_t sw = (r32 >> 2) & 3;
                     const uint32_t o0 = ((h ^ sw) & 3) << 4, o1 = (((2 + h) ^ sw) & 3) << 4;
-                    const unsigned char * xa = base + (32 * wave + r32) * 64;
-                    const unsigned char * qb = base + 2 * PLANE + r32 * 64;
+                    const unsigned char * xa = base + (32 * wr + r32) * 64;
+                    const unsigned char * qb = base + 2 * XPLANE + (128 * qg + r32) * 64;
                     const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(xa + o0);
                     const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(xa + o1);
-                    const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(xa + PLANE + o0);
-                    const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(xa + PLANE + o1);
+                    const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(xa + XPLANE + o0);
+                    const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(xa + XPLANE + o1);
                     auto block = [&](f32x16 & acc, const int cb) {
                         const unsigned char * q = qb + cb * 32 * 64;
                         const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(q + o0);
                         const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(q + o1);
-                        const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(q + PLANE + o0);
-                        const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(q + PLANE + o1);
+                        const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(q + QPLANE + o0);
+                        const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(q + QPLANE + o1);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc, 0, 0, 0);
@@ -413,11 +428,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc, 0, 0, 0);
                     };
                     block(acc0, 0);
-                    if (ncb > 1)
+                    if (mycb > 1)
                         block(acc1, 1);
-                    if (ncb > 2)
+                    if (mycb > 2)
                         block(acc2, 2);
-                    if (ncb > 3)
+                    if (mycb > 3)
                         block(acc3, 3);
                 }
                 if (ki + 1 < nk)
@@ -430,12 +445,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     advance();
             }
 
-            __syncthreads(); // every wavefront is done reading the operand stages: they become the distance tile
+            // one selection round per 128-query group: its wavefronts publish their distances, ALL wavefronts select
             auto put = [&](const f32x16 & acc, const float qnv, const uint32_t n0) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; g4++)
                 {
-                    const uint32_t m0 = 32 * wave + 8 * g4 + 4 * h;
+                    const uint32_t m0 = 32 * wr + 8 * g4 + 4 * h;
                     float4 o;
                     if (METRIC == M_L2)
                     {
@@ -449,38 +464,51 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     *reinterpret_cast<float4 *>(&Ss[(n0 + r32) * MF_LDS + m0]) = o;
                 }
             };
-            put(acc0, qn[0], 0);
-            if (ncb > 1)
-                put(acc1, qn[1], 32);
-            if (ncb > 2)
-                put(acc2, qn[2], 64);
-            if (ncb > 3)
-                put(acc3, qn[3], 96);
-            __syncthreads();
-            for (uint32_t n = wave; n < nvalid; n += 4)
-            {
-                const uint32_t cut = thr_s[n];
-                uint64_t key[2];
 #pragma unroll
-                for (int u = 0; u < 2; u++)
+            for (uint32_t g = 0; g < (uint32_t)NQG; g++)
+            {
+                const uint32_t gvalid = nvalid > 128 * g ? (nvalid - 128 * g < 128 ? nvalid - 128 * g : 128) : 0;
+                if (gvalid == 0)
+                    break; // uniform over the workgroup
+                __syncthreads(); // operand stage (g = 0) / previous group's tile (g = 1) fully consumed
+                if (qg == g)
                 {
-                    const float v = Ss[n * MF_LDS + lane + 64 * u];
-                    const uint64_t kk = okrow[u] ? make_key<METRIC>(v, (uint32_t)(sub + lane + 64 * u)) : KEY_NONE;
-                    key[u] = (uint32_t)(kk >> 32) < cut ? kk : KEY_NONE;
+                    put(acc0, qn[0], 0);
+                    if (mycb > 1)
+                        put(acc1, qn[1], 32);
+                    if (mycb > 2)
+                        put(acc2, qn[2], 64);
+                    if (mycb > 3)
+                        put(acc3, qn[3], 96);
                 }
-                if (__ballot(key[0] != KEY_NONE) | __ballot(key[1] != KEY_NONE))
+                __syncthreads();
+                for (uint32_t n = wave; n < gvalid; n += NWAVE)
                 {
-                    const uint64_t best = wave_select16(key[0], key[1], sel_s[wave], lane);
-                    const uint32_t q = qrow_s[n];
-                    const uint32_t nsel = __popcll(__ballot(best != KEY_NONE)); // lanes 0 .. nsel-1, ascending
-                    uint32_t pos = 0;
-                    if (lane == 0)
-                        pos = atomicAdd(&a.qcnt[q], nsel);
-                    pos = __builtin_amdgcn_readfirstlane(pos);
-                    if (lane < nsel && pos + lane < a.cand_cap)
-                        a.partial[(size_t)q * a.cand_cap + pos + lane] = best;
-                    if (lane == (uint32_t)BG_SLICE_K - 1 && best != KEY_NONE) // a full list: its last key cuts
-                        atomicMin(&a.qthr[q], (uint32_t)(best >> 32));
+                    const uint32_t qi = 128 * g + n;
+                    const uint32_t cut = thr_s[qi];
+                    uint64_t key[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                    {
+                        const float v = Ss[n * MF_LDS + lane + 64 * u];
+                        const uint64_t kk
+                            = okrow[u] ? make_key<METRIC>(v, (uint32_t)(sub + lane + 64 * u)) : KEY_NONE;
+                        key[u] = (uint32_t)(kk >> 32) < cut ? kk : KEY_NONE;
+                    }
+                    if (__ballot(key[0] != KEY_NONE) | __ballot(key[1] != KEY_NONE))
+                    {
+                        const uint64_t best = wave_select16(key[0], key[1], sel_s[wave], lane);
+                        const uint32_t q = qrow_s[qi];
+                        const uint32_t nsel = __popcll(__ballot(best != KEY_NONE)); // lanes 0 .. nsel-1, ascending
+                        uint32_t pos = 0;
+                        if (lane == 0)
+                            pos = atomicAdd(&a.qcnt[q], nsel);
+                        pos = __builtin_amdgcn_readfirstlane(pos);
+                        if (lane < nsel && pos + lane < a.cand_cap)
+                            a.partial[(size_t)q * a.cand_cap + pos + lane] = best;
+                        if (lane == (uint32_t)BG_SLICE_K - 1 && best != KEY_NONE) // a full list: its last key cuts
+                            atomicMin(&a.qthr[q], (uint32_t)(best >> 32));
+                    }
                 }
             }
             if (has_next)

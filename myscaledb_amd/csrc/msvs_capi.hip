@@ -653,7 +653,7 @@ namespace msvs
 struct IvfSearchPlan
 {
     uint32_t T;       // 1 = one query per block (ivf_scan_kernel); 2/4/8 = list-batched query tiles;
-                      // 128 (BG_TQ) = matrix-core candidate pass + canonical re-rank (mfma_scan_kernels.hpp)
+                      // 128 / 256 (BG_TQ * nqg) = matrix-core candidate pass + canonical re-rank (mfma_scan_kernels.hpp)
     uint32_t rpb;     // rows per work item
     uint32_t seg_max; // segments of the longest list
     uint32_t grid;    // batched: fixed grid size
@@ -662,7 +662,8 @@ struct IvfSearchPlan
     uint32_t rpb1;     // rows per block / segments of the canonical fallback scan (one query per block)
     uint32_t seg_max1;
     uint32_t fb_slots; // block slots (grid z) of the fallback
-    bool mfma() const { return T == (uint32_t)BG_TQ; }
+    uint32_t nqg;      // 128-query groups per workgroup of the candidate pass (1 or 2)
+    bool mfma() const { return nqg != 0; }
 };
 
 static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, uint32_t k)
@@ -680,13 +681,20 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
         const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f && ix.n <= 0xfffffff0ull;
         if (mode != 0 && eligible && (pairs >= 4 * nlist || mode >= 2))
         {
-            p.T = BG_TQ;
+            // 256-query tiles (nqg = 2: one workgroup of 8 wavefronts per CU, the rows read once per 256 probing
+            // queries) measured SLOWER than two independent 128-query workgroups per CU at every batch size
+            // (4096 q/step: 1.92 vs 1.70 ms, 16384: 6.01 vs 5.89 ms): kept as a knob only
+            p.nqg = 1;
+            if (const char * g = getenv("MSVS_IVF_NQG"))
+                if (atoi(g) == 1 || atoi(g) == 2)
+                    p.nqg = (uint32_t)atoi(g);
+            p.T = BG_TQ * p.nqg;
             p.kc = k <= 12 ? 32 : 64;
             p.rpb = 2 * BG_ROWS; // work item = 2 slices of a list for a tile of <= 128 queries
             if (const char * r = getenv("MSVS_IVF_RPB"))
                 if (atoi(r) >= BG_ROWS)
                     p.rpb = (uint32_t)round_up((size_t)atoi(r), (size_t)BG_ROWS);
-            p.grid = 2048;
+            p.grid = 2048 / p.nqg;
             if (const char * g = getenv("MSVS_IVF_GRID"))
                 if (atoi(g) >= 1)
                     p.grid = (uint32_t)atoi(g);
@@ -828,6 +836,11 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
                                  const TablePass & t, hipStream_t stream)
 {
     const uint32_t ld = ix.ld, nrows = (uint32_t)t.n, kc = t.k <= 12 ? 32 : 64;
+    uint32_t nqg = 1; // 256-query tiles: see plan_ivf
+    if (const char * g = getenv("MSVS_IVF_NQG")) // experiment / test knob
+        if (atoi(g) == 1 || atoi(g) == 2)
+            nqg = (uint32_t)atoi(g);
+    const uint32_t tq = BG_TQ * nqg;
     const uint32_t nslices = (uint32_t)ceil_div(t.n, (size_t)BG_ROWS);
     const uint32_t cap = (uint32_t)big_cand_cap(1, nslices);
     uint32_t * pairs = scr.take<uint32_t>(nq);
@@ -847,9 +860,9 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
     MSVS_HIP(hipMemsetAsync(qstate + nq, 0, nq * sizeof(uint32_t), stream));
     // work item = 2 slices, or 1 when that is what it takes to give the chip ~1000 items
-    const uint32_t rpb = ceil_div(nq, (size_t)BG_TQ) * ceil_div(t.n, (size_t)(2 * BG_ROWS)) < 1024 ? BG_ROWS : 2 * BG_ROWS;
+    const uint32_t rpb = ceil_div(nq, (size_t)tq) * ceil_div(t.n, (size_t)(2 * BG_ROWS)) < 1024 ? BG_ROWS : 2 * BG_ROWS;
     // plan 0: the whole table (also what the fallback scans)
-    launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, BG_TQ, pairs, probes0, list_off, small, small + 3, stream);
+    launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, tq, pairs, probes0, list_off, small, small + 3, stream);
     launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
     // A table too long for "16 keys per slice" to fit the candidate buffers is searched in two phases: a sample first,
     // whose m-th best candidate becomes the query's cut for the rest (sample_cut_kernel)
@@ -859,9 +872,9 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         : 0;
     if (two_phase)
     {
-        launch_single_list_plan((uint32_t)nq, 0, sample, rpb, BG_TQ, pairs, probes0, list_off + 2, small, small + 5,
+        launch_single_list_plan((uint32_t)nq, 0, sample, rpb, tq, pairs, probes0, list_off + 2, small, small + 5,
                                 stream);
-        launch_single_list_plan((uint32_t)nq, sample, nrows, rpb, BG_TQ, pairs, probes0, list_off + 4, small, small + 7,
+        launch_single_list_plan((uint32_t)nq, sample, nrows, rpb, tq, pairs, probes0, list_off + 4, small, small + 7,
                                 stream);
     }
     ScanParams a{};
@@ -889,15 +902,16 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     a.qthr = qstate;
     a.qcnt = qstate + nq;
     a.cand_cap = cap;
-    const size_t tiles = ceil_div(nq, (size_t)BG_TQ);
+    const size_t tiles = ceil_div(nq, (size_t)tq);
     ProfileScope prof(t.prof_name, stream);
     if (two_phase)
     {
         ScanParams sa = a;
         sa.list_off = list_off + 2;
         sa.work_off = small + 5;
-        launch_ivf_mfma_scan(scan_metric(m), (uint32_t)std::min<size_t>(tiles * ceil_div((size_t)sample, (size_t)rpb), 2048),
-                             sa, stream, "table_scan");
+        launch_ivf_mfma_scan(scan_metric(m), nqg,
+                             (uint32_t)std::min<size_t>(tiles * ceil_div((size_t)sample, (size_t)rpb), 2048 / nqg), sa, stream,
+                             "table_scan");
         launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
         // the m-th best sample candidate leaves ~m * n / sample rows of the table below the cut; the query fails its
         // certificate when fewer than k + 1 of them do, i.e. when >= m of the table's k + m best rows fell into the
@@ -906,13 +920,14 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         launch_sample_cut(cand, kc, mth, (uint32_t)nq, a.qthr, stream);
         sa.list_off = list_off + 4;
         sa.work_off = small + 7;
-        launch_ivf_mfma_scan(scan_metric(m),
-                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n - sample, (size_t)rpb), 2048), sa, stream,
+        launch_ivf_mfma_scan(scan_metric(m), nqg,
+                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n - sample, (size_t)rpb), 2048 / nqg), sa, stream,
                              "table_scan");
     }
     else
-        launch_ivf_mfma_scan(scan_metric(m), (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 2048), a,
-                             stream, "table_scan");
+        launch_ivf_mfma_scan(scan_metric(m), nqg,
+                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 2048 / nqg), a, stream,
+                             "table_scan");
     launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
     RerankParams rp{};
     rp.Y = a.Y;
@@ -1121,7 +1136,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
             sa.list_end = pa.list_end;
             sa.work_off = pa.work_off;
             sa.rows_per_block = BG_ROWS;
-            launch_ivf_mfma_scan(scan_metric(m), pl.grid, sa, stream, "ivf_sample_scan");
+            launch_ivf_mfma_scan(scan_metric(m), pl.nqg, pl.grid, sa, stream, "ivf_sample_scan");
             launch_cand_select(partial, a.qcnt, a.qthr, a.cand_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
             // m-th sample candidate: ~8k rows of everything below the cut (see sample_cut_kernel, table pass)
             const size_t avg_len = std::max<size_t>(1, ix.n / std::max<size_t>(ix.nlist, 1));
@@ -1132,7 +1147,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         a.list_off = pp.list_off;
         a.list_end = pp.list_end;
         a.work_off = pp.work_off;
-        launch_ivf_mfma_scan(scan_metric(m), pl.grid, a, stream);
+        launch_ivf_mfma_scan(scan_metric(m), pl.nqg, pl.grid, a, stream);
         launch_cand_select(partial, a.qcnt, a.qthr, a.cand_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
         uint32_t * failq = scr.take<uint32_t>(nq);
         RerankParams rp{};

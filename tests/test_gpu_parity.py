@@ -218,6 +218,10 @@ def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, monk
     ids, dis = ix.search(q, k)
     same(ids, dis, *expect())
     monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
+    monkeypatch.setenv("MSVS_IVF_NQG", "2")  # 256-query tiles
+    ids, dis = ix.search(q, k)
+    same(ids, dis, *expect())
+    monkeypatch.delenv("MSVS_IVF_NQG")
     # small candidate buffers = what a long table looks like: sample first, its m-th candidate cuts the rest
     monkeypatch.setenv("MSVS_CAND_CAP", "1024")
     ids, dis = ix.search(q, k)
@@ -300,6 +304,13 @@ def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, 
     q2, f2 = capi.prefilter_stats()
     assert f2 - f1 == nq
     monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
+    # 256-query tiles (one 8-wavefront workgroup per CU; the default from ~96 queries per list on): same answer
+    monkeypatch.setenv("MSVS_IVF_NQG", "2")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=alive)
+    same(ids, dis, oa, oda)
+    monkeypatch.delenv("MSVS_IVF_NQG")
     # candidate buffers far too small: overflowing queries lose their certificate and take the fallback, same answer
     monkeypatch.setenv("MSVS_CAND_CAP", "64")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)

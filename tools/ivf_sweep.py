@@ -28,7 +28,7 @@ for c in sys.argv[1:]:
     kv = dict(p.split('=') for p in c.split(','))
     B = int(kv.pop('B'))
     for kk in ("MSVS_IVF_T", "MSVS_IVF_RPB", "MSVS_IVF_GRID", "MSVS_IVF_XCD", "MSVS_IVF_WT", "MSVS_IVF_MFMA",
-               "MSVS_IVF_EPS_SCALE"):
+               "MSVS_IVF_EPS_SCALE", "MSVS_IVF_NQG"):
         os.environ.pop(kk, None)
     for a, b in kv.items():
         os.environ["MSVS_IVF_" + a] = b
