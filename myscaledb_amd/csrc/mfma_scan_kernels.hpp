@@ -266,10 +266,11 @@ __global__ __launch_bounds__(BLOCK * NQG) __attribute__((amdgpu_waves_per_eu(2, 
         const int64_t lbeg = a.list_off[l], lend = a.list_end ? a.list_end[l] : a.list_off[l + 1];
         const uint32_t local = w - a.work_off[l];
         const uint32_t pe = a.pair_off[l + 1];
-        const uint32_t ntile = (pe - a.pair_off[l] + TQ - 1) / TQ;
+        const uint32_t tq = a.tile_q ? a.tile_q : TQ; // smaller tiles = more work items for small tables / batches
+        const uint32_t ntile = (pe - a.pair_off[l] + tq - 1) / tq;
         const uint32_t seg = local / ntile, tile = local - seg * ntile;
-        const uint32_t pb = a.pair_off[l] + tile * TQ;
-        const uint32_t nvalid = pe - pb < TQ ? pe - pb : TQ;
+        const uint32_t pb = a.pair_off[l] + tile * tq;
+        const uint32_t nvalid = pe - pb < tq ? pe - pb : tq;
         const uint32_t ncb = (nvalid + 31) >> 5; // 32-query column blocks in use (of 4 * NQG)
         const int64_t rb = lbeg + (int64_t)seg * a.rows_per_block;
         const int64_t re = rb + a.rows_per_block < lend ? rb + a.rows_per_block : lend;

@@ -820,16 +820,16 @@ static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k)
         + nq * ceil_div(std::max<size_t>(n, 1), (size_t)table_fallback_rpb(n)) * k * 8 + 65536;
 }
 
-/// Worth it once the (128-query tile) x (128-row slice) grid can occupy the chip (64 work items measured no better
-/// than the canonical scan on the 1024-centroid table, 256 items 2x better) and enough queries share each pass over
-/// the rows for the canonical scan to be VALU-bound (>= 16).
+/// Worth it once the (query tile) x (128-row slice) grid can occupy the chip (64 work items measured no better than
+/// the canonical scan on the 1024-centroid table, 256 items 2x better; the tiles shrink to 32 queries to get there)
+/// and enough queries share each pass over the rows for the canonical scan to be VALU-bound (>= 16).
 static bool table_pass_eligible(size_t n, const float * norms, float norm_max, size_t nq, uint32_t k, const char * knob)
 {
     const char * e = getenv(knob); // experiment knob: 0 = never, 2 = whenever possible
     const int mode = e ? atoi(e) : 1;
-    const size_t items = ceil_div(nq, (size_t)BG_TQ) * ceil_div(n, (size_t)BG_ROWS);
+    const size_t items = ceil_div(nq, (size_t)32) * ceil_div(n, (size_t)BG_ROWS); // at the smallest tile (32 queries)
     return mode != 0 && norms && norm_max < 1e30f /* false for NaN */ && k <= 40 && n >= 256 && n <= 0xfffffff0ull
-        && ((items >= 128 && nq >= 16) || mode == 2);
+        && ((items >= 256 && nq >= 16) || mode == 2);
 }
 
 static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq,
@@ -840,7 +840,11 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     if (const char * g = getenv("MSVS_IVF_NQG")) // experiment / test knob
         if (atoi(g) == 1 || atoi(g) == 2)
             nqg = (uint32_t)atoi(g);
-    const uint32_t tq = BG_TQ * nqg;
+    // queries per tile: the full 128 when that still gives the chip >= 512 work items, else 64 or 32 (the rows are then
+    // re-read by more tiles -- cheap for a table that lives in L2, like the centroids)
+    uint32_t tq = BG_TQ * nqg;
+    while (tq > 32 && ceil_div(nq, (size_t)tq) * ceil_div(t.n, (size_t)BG_ROWS) < 512)
+        tq /= 2;
     const uint32_t nslices = (uint32_t)ceil_div(t.n, (size_t)BG_ROWS);
     const uint32_t cap = (uint32_t)big_cand_cap(1, nslices);
     uint32_t * pairs = scr.take<uint32_t>(nq);
@@ -902,6 +906,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     a.qthr = qstate;
     a.qcnt = qstate + nq;
     a.cand_cap = cap;
+    a.tile_q = tq;
     const size_t tiles = ceil_div(nq, (size_t)tq);
     ProfileScope prof(t.prof_name, stream);
     if (two_phase)
