@@ -38,13 +38,13 @@ LATENT_DIM = 32
 N_BLOBS = 1024
 
 
-def _latent_model(d, seed, device):
+def _latent_model(d, seed, device, blobs=N_BLOBS):
     """Synthetic embedding model: a 1024-component gaussian mixture in a 32-d latent space (blob centres ~ 3 N(0,I),
     unit within-blob spread), embedded into R^d by a fixed random linear map, plus small isotropic noise.  Low
     intrinsic dimension + cluster structure is what real embedding sets look like to an IVF index; iid N(0,I) in 768-d
     has no neighbourhood structure at all (all points equidistant) and no index can reach recall 0.95 on it."""
     g = torch.Generator(device=device).manual_seed(seed)
-    centres = 3.0 * torch.randn((N_BLOBS, LATENT_DIM), generator=g, device=device, dtype=torch.float32)
+    centres = 3.0 * torch.randn((blobs, LATENT_DIM), generator=g, device=device, dtype=torch.float32)
     proj = torch.randn((LATENT_DIM, d), generator=g, device=device, dtype=torch.float32) / (LATENT_DIM ** 0.5)
     return centres, proj
 
@@ -55,14 +55,14 @@ def _sample(model, n, g, device, chunk=65536):
     x = torch.empty((n, d), device=device, dtype=torch.float32)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
-        z = torch.randint(0, N_BLOBS, (hi - lo,), generator=g, device=device)
+        z = torch.randint(0, centres.shape[0], (hi - lo,), generator=g, device=device)
         lat = centres[z] + torch.randn((hi - lo, LATENT_DIM), generator=g, device=device, dtype=torch.float32)
         x[lo:hi] = lat @ proj + 0.05 * torch.randn((hi - lo, d), generator=g, device=device, dtype=torch.float32)
     return x
 
 
-def make_data(n, d, seed, device):
-    model = _latent_model(d, 99, device)
+def make_data(n, d, seed, device, blobs=N_BLOBS):
+    model = _latent_model(d, 99, device, blobs)
     g = torch.Generator(device=device).manual_seed(seed)
     return model, _sample(model, n, g, device)
 

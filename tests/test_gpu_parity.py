@@ -277,7 +277,8 @@ def test_ivfflat_matches_oracle_on_exported_structure(metric, n, d, nlist, nq, n
 
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
 @pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(40000, 768, 16, 200, 4, 10), (30000, 100, 8, 256, 8, 40),
-                                                   (20000, 20, 8, 129, 3, 1), (3000, 64, 4, 100, 4, 12)])
+                                                   (20000, 20, 8, 129, 3, 1), (3000, 64, 4, 100, 4, 12),
+                                                   (6000, 1536, 4, 64, 2, 10)])
 def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, nq, nprobe, k, monkeypatch):
     """>= 16 queries per list: MFMA candidate pass + canonical re-rank + certificate (mfma_scan_kernels.hpp).  The
     result must be the canonical one bit for bit, with and without certificates."""

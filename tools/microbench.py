@@ -56,9 +56,9 @@ def flat_case(name, n, d, nqs, k, dev):
     del x
 
 
-def ivf_cosine_case(n, d, nlist, batch, nprobe, k, dev):
-    model, x = make_data(n, d, 1234, dev)
-    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_COSINE, d, "ncentroids=%d,kmeans_iters=8,train_sample=%d" % (nlist, nlist * 48))
+def ivf_cosine_case(n, d, nlist, batch, nprobe, k, dev, metric=capi.METRIC_COSINE, name="C3", blobs=1024):
+    model, x = make_data(n, d, 1234, dev, blobs=blobs)
+    ix = capi.Index(capi.INDEX_IVFFLAT, metric, d, "ncentroids=%d,kmeans_iters=8,train_sample=%d" % (nlist, nlist * 48))
     t0 = time.time()
     ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
     step = 2_000_000
@@ -82,10 +82,15 @@ def ivf_cosine_case(n, d, nlist, batch, nprobe, k, dev):
     dt = timed(run, 20)
     rows, streamed, uniq = ix.scanned_rows(q[:batch].cpu().numpy(), nprobe)
     rb = 4 * d + 4
-    print("C3 IVFFLAT cosine %dx%d nlist=%d batch=%d nprobe=%d k=%d : build %.1f s, %.3f ms/batch  %.0f QPS ; rows/query %.0f ; "
-          "union %.2f GB -> %.0f GB/s, streamed-model %.2f GB, per-query model %.2f GB"
-          % (n, d, nlist, batch, nprobe, k, build_s, dt * 1e3, batch / dt, rows / batch, uniq * rb / 1e9,
-             uniq * rb / dt / 1e9, streamed * rb / 1e9, rows * rb / 1e9), flush=True)
+    f0 = capi.prefilter_stats()
+    run()
+    torch.cuda.synchronize()
+    f1 = capi.prefilter_stats()
+    print("%s IVFFLAT %s %dx%d nlist=%d batch=%d nprobe=%d k=%d : build %.1f s, %.3f ms/batch  %.0f QPS ; rows/query %.0f ; "
+          "union %.2f GB -> %.0f GB/s, per-query model %.2f GB ; candidate pass (queries, fallbacks) per batch = (%d, %d)"
+          % (name, "cosine" if metric == capi.METRIC_COSINE else "L2", n, d, nlist, batch, nprobe, k, build_s, dt * 1e3,
+             batch / dt, rows / batch, uniq * rb / 1e9, uniq * rb / dt / 1e9, rows * rb / 1e9, f1[0] - f0[0],
+             f1[1] - f0[1]), flush=True)
     ix.close()
 
 
@@ -132,6 +137,9 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--docs", type=int, default=10_000_000)
     ap.add_argument("--skip", default="")
+    ap.add_argument("--big-rows", type=int, default=0,
+                    help="C4s: IVFFLAT L2 on this many rows x 768 (nlist = rows / 2048, nprobe 64, 4096 queries per batch); "
+                         "needs ~3 x rows x 3 KB of HBM during the build")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     capi.set_device(0)
@@ -141,6 +149,9 @@ def main():
         flat_case("C2'", 1_000_000, 768, [1, 8, 64, 1024], 10, dev)
     if "c3" not in a.skip:
         ivf_cosine_case(a.rows, 768, 4096, 64, 32, 10, dev)
+    if a.big_rows:
+        nl = max(1024, a.big_rows // 2048)
+        ivf_cosine_case(a.big_rows, 768, nl, 4096, 64, 10, dev, metric=capi.METRIC_L2, name="C4s", blobs=nl)
     if "c5" not in a.skip:
         bm25_case(a.docs, 200_000, 100)
 
