@@ -239,6 +239,42 @@ def main():
                 "frac": round(hbm_frac, 4), "f32_compute_frac": round(compute_frac, 4),
                 "f32_compute_tflops": round(compute_tf, 2)}
 
+    # ---- the same index at smaller steps (single GPU only; 20 timed steps each): where the list scan reads every
+    # probed row once it runs much closer to the HBM roofline than at the headline batch
+    other = {}
+    if world == 1:
+        for b2 in (256, 1024):
+            if b2 >= B:
+                continue
+            o_ids = torch.empty((b2, k), device=dev, dtype=torch.int64)
+            o_dis = torch.empty((b2, k), device=dev, dtype=torch.float32)
+
+            def step2(i):
+                lo = (i % (n_pool * B // b2)) * b2
+                ix.search_device(q_all[lo:lo + b2].data_ptr(), b2, k, nprobe, o_ids.data_ptr(), o_dis.data_ptr(), stream)
+            for i in range(3):
+                step2(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(20):
+                step2(i)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t1) / 20
+            capi.profile_reset()
+            capi.profile_enable(True)
+            for i in range(8):
+                step2(i)
+            torch.cuda.synchronize()
+            capi.profile_enable(False)
+            c2, ms2 = capi.profile_get("ivf_scan")
+            _, sms2 = capi.profile_get("ivf_sample_scan")
+            capi.profile_reset()
+            u2 = sum(ix.scanned_rows(q_all[i * b2:(i + 1) * b2].cpu().numpy(), nprobe)[2] for i in range(8))
+            scan2 = (ms2 + sms2) / max(c2, 1)
+            other[str(b2)] = {"qps": round(b2 / dt2, 1), "ms_per_step": round(dt2 * 1e3, 4),
+                              "list_scan_ms": round(scan2, 4),
+                              "hbm_frac_union_bytes": round(u2 / 8 * (4 * d + 4) / (scan2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
     # ---- single-query latency (batch 1, synchronous, through the same C-ABI)
     lat = []
     o1i = torch.empty((1, k), device=dev, dtype=torch.int64)
@@ -329,6 +365,7 @@ def main():
                 "prefilter": [pf1[0] - pf0[0], pf1[1] - pf0[1]],
                 "other_kernels_ms": dict(others, **{"coarse_flat_scan": round(c_ms / max(c_calls, 1), 4),
                                                     "merge(avg of 2)": round(m_ms / max(m_calls, 1), 4)})}),
+            "other_batches": other,
             "cpu_baseline": cpu,
             "setup_s": round(setup_s, 1),
         }
