@@ -114,9 +114,15 @@ extern "C" int msvs_bm25_search(const msvs_postings_t * ps, const uint32_t * qte
         a.k = (uint32_t)k;
         const uint32_t n_blocks = (uint32_t)ceil_div(ps->num_docs, BM25_DOCS);
         const size_t words = alive_bits ? ceil_div(nbits, 64) : 0;
+        // many doc blocks: their top-k lists are merged in two levels (32 groups, then the 32 group lists) -- one block
+        // walking 1221 lists (10M documents) took 153 us against 52 us for the scoring itself
+        const uint32_t groups = n_blocks > 64 ? 32 : 1;
+        const uint32_t n_pad = (uint32_t)round_up((size_t)n_blocks, (size_t)groups);
         Scratch & scr = scratch_for(stream);
-        scr.reserve((size_t)n_blocks * k * 8 + words * 8 + k * 12 + 8192, stream);
-        uint64_t * partial = scr.take<uint64_t>((size_t)n_blocks * k);
+        scr.reserve((size_t)(n_pad + groups) * k * 8 + words * 8 + k * 12 + 8192, stream);
+        uint64_t * partial = scr.take<uint64_t>((size_t)n_pad * k);
+        if (n_pad > n_blocks) // the padding lists are empty
+            MSVS_HIP(hipMemsetAsync(partial + (size_t)n_blocks * k, 0xFF, (size_t)(n_pad - n_blocks) * k * 8, stream));
         int64_t * d_ids = scr.take<int64_t>(k);
         float * d_sc = scr.take<float>(k);
         if (words)
@@ -146,6 +152,18 @@ extern "C" int msvs_bm25_search(const msvs_postings_t * ps, const uint32_t * qte
         m.partial = partial;
         m.n_lists = n_blocks;
         m.k = (uint32_t)k;
+        if (groups > 1)
+        {
+            uint64_t * level1 = scr.take<uint64_t>((size_t)groups * k);
+            m.n_lists = n_pad / groups; // group g merges lists [g * n_lists, (g + 1) * n_lists)
+            m.mode = 2;
+            m.out_keys = level1;
+            launch_merge(M_IP, m, groups, stream);
+            m.partial = level1;
+            m.n_lists = groups;
+            m.mode = 0;
+            m.out_keys = nullptr;
+        }
         m.out_ids = d_ids;
         m.out_dis = d_sc;
         launch_merge(M_IP, m, 1, stream);

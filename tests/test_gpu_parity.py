@@ -512,6 +512,32 @@ def test_bm25_synthetic_corpus_matches_oracle():
         assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
 
 
+def test_bm25_many_doc_blocks_two_level_merge():
+    """> 64 document blocks (here 700k documents = 86 blocks): the per-block top-k lists are merged in two levels."""
+    rng = np.random.default_rng(33)
+    n_docs, vocab = 700_000, 1500
+    p = 1.0 / np.arange(1, vocab + 1) ** 1.1
+    lens = np.maximum(1, rng.poisson(12, n_docs))
+    toks = rng.choice(vocab, int(lens.sum()), p=p / p.sum())
+    doc_of = np.repeat(np.arange(n_docs, dtype=np.int64), lens)
+    uk, tf = np.unique(toks.astype(np.int64) * n_docs + doc_of, return_counts=True)
+    term, doc = uk // n_docs, (uk % n_docs).astype(np.uint32)
+    post_off = np.zeros(vocab + 1, np.int64)
+    np.cumsum(np.bincount(term, minlength=vocab), out=post_off[1:])
+    fn_of_len = np.array([o.fieldnorm_id(int(n)) for n in range(int(lens.max()) + 1)], np.uint8)
+    fn_ids = fn_of_len[lens]
+    ps = capi.Postings(post_off, doc, tf.astype(np.uint32), fn_ids)
+    df_all = np.diff(post_off)
+    alive = rng.random(n_docs) < 0.5
+    for qt in ([3, 40, 700], [0], [1400, 1499, 5, 90]):
+        df = [int(df_all[t]) for t in qt]
+        for k, al in ((10, None), (100, None), (10, alive)):
+            got = ps.bm25_search(qt, df, n_docs, int(lens.sum()), k, alive=al)
+            exp = o.bm25_search(post_off, doc, tf.astype(np.uint32), fn_ids, qt, df, n_docs, int(lens.sum()), k, alive=al)
+            assert got[0].tolist() == exp[0].tolist()
+            assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
+
+
 # ---------------------------------------------------------------------------------------- BASELINE-size properties
 
 def test_full_size_1m_x_768_properties():
