@@ -71,6 +71,13 @@ inline int guarded(F && f)
     }
 }
 
+/// Non-owning device pointer with DevBuf's `.p` (arena slices used where a DevBuf used to be).
+template <typename T>
+struct DevView
+{
+    T * p;
+};
+
 /// Owning device allocation.
 template <typename T>
 struct DevBuf

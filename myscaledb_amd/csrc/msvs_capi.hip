@@ -1291,11 +1291,13 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
             fail(MSVS_ERR_INVALID_ARGUMENT, "nprobe must be >= 1");
         hipStream_t stream = nullptr;
         const size_t words = alive_bits ? ceil_div(nbits, 64) : 0;
-        // host staging lives in plain device allocations (the arena belongs to the device-level search)
-        DevBuf<float> dq(nq * ix->dim);
-        DevBuf<int64_t> d_ids(nq * (size_t)k);
-        DevBuf<float> d_dis(nq * (size_t)k);
-        DevBuf<uint64_t> d_alive(words);
+        // host staging lives in its own arena (scratch_for() belongs to the device-level search underneath)
+        Scratch & stg = staging_for(stream);
+        stg.reserve(nq * ix->dim * 4 + nq * (size_t)k * 12 + words * 8 + 4096, stream);
+        const DevView<float> dq{stg.take<float>(nq * ix->dim)};
+        const DevView<int64_t> d_ids{stg.take<int64_t>(nq * (size_t)k)};
+        const DevView<float> d_dis{stg.take<float>(nq * (size_t)k)};
+        const DevView<uint64_t> d_alive{words ? stg.take<uint64_t>(words) : nullptr};
         MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
         if (words)
             MSVS_HIP(hipMemcpyAsync(d_alive.p, alive_bits, words * 8, hipMemcpyHostToDevice, stream));

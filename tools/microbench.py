@@ -94,7 +94,8 @@ def ivf_cosine_case(n, d, nlist, batch, nprobe, k, dev, metric=capi.METRIC_COSIN
     ix.close()
 
 
-def bm25_case(n_docs, vocab, k):
+def build_postings(n_docs, vocab):
+    """Synthetic corpus on the GPU -> (capi.Postings, df per term, total tokens)."""
     rng = np.random.default_rng(5)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(5)
@@ -116,7 +117,12 @@ def bm25_case(n_docs, vocab, k):
              for b in range(256)]
     fn_ids = (np.searchsorted(np.array(table, np.int64), lens, side="right") - 1).astype(np.uint8)
     ps = capi.Postings(post_off, doc, tf.astype(np.uint32), fn_ids)
-    df_all = np.diff(post_off)
+    return ps, np.diff(post_off), total, len(doc)
+
+
+def bm25_case(n_docs, vocab, k):
+    rng = np.random.default_rng(5)
+    ps, df_all, total, n_post = build_postings(n_docs, vocab)
     mids = np.argsort(-df_all)[50:2000]
     times, bytes_ = [], []
     for i in range(30):
@@ -129,7 +135,42 @@ def bm25_case(n_docs, vocab, k):
     times, bytes_ = np.array(times[5:]), np.array(bytes_[5:])
     print("C5 BM25 %d docs, %d postings, 3-term queries, k=%d : p50 %.3f ms/query (host call incl. D2H), "
           "postings+fieldnorm bytes/query %.1f MB -> %.0f GB/s"
-          % (n_docs, len(doc), k, np.median(times) * 1e3, bytes_.mean() / 1e6, (bytes_ / times).mean() / 1e9), flush=True)
+          % (n_docs, n_post, k, np.median(times) * 1e3, bytes_.mean() / 1e6, (bytes_ / times).mean() / 1e9), flush=True)
+
+
+def hybrid_case(n, d, nlist, nprobe, vocab, dev):
+    """BASELINE config 5: per query, vector top-100 (IVFFLAT cosine, the partition scan) + BM25 top-100 over the same n
+    rows + reciprocal-rank fusion on the host (libmsvs_host.so) -> top-10; host-pointer calls, wall time per query."""
+    import myscaledb_amd.host as host
+    model, x = make_data(n, d, 1234, dev)
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_COSINE, d, "ncentroids=%d,kmeans_iters=8,train_sample=%d" % (nlist, nlist * 48))
+    ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+    for lo in range(0, n, 2_000_000):
+        hi = min(n, lo + 2_000_000)
+        ix.add(x[lo:hi].data_ptr(), n=hi - lo, mem=capi.MEM_DEVICE)
+    ix.build()
+    del x
+    ps, df_all, total, _ = build_postings(n, vocab)
+    rng = np.random.default_rng(6)
+    mids = np.argsort(-df_all)[50:2000]
+    qs = make_queries(model, 40, 4321, dev).cpu().numpy()
+    tv, tb, tf_, tt = [], [], [], []
+    z = lambda m: np.zeros(m, np.uint64)
+    for i in range(40):
+        qt = rng.choice(mids, 3, replace=False)
+        t0 = time.perf_counter()
+        vi, vd = ix.search(qs[i:i + 1], 100, "nprobe=%d" % nprobe)
+        t1 = time.perf_counter()
+        rows, scores = ps.bm25_search(qt, df_all[qt], n, total, 100)
+        t2 = time.perf_counter()
+        host.hybrid_search("rrf", (vd[0], z(100), vi[0].astype(np.uint64)), (scores, z(len(rows)), rows), 10, fusion_k=60)
+        t3 = time.perf_counter()
+        tv.append(t1 - t0), tb.append(t2 - t1), tf_.append(t3 - t2), tt.append(t3 - t0)
+    med = lambda a: float(np.median(a[8:])) * 1e3
+    print("C5h hybrid %d rows x %d (IVFFLAT cosine nlist=%d nprobe=%d top-100 + BM25 top-100 + RRF top-10), host calls per "
+          "query: p50 total %.3f ms = vector %.3f + bm25 %.3f + fusion %.3f" % (n, d, nlist, nprobe, med(tt), med(tv), med(tb), med(tf_)),
+          flush=True)
+    ix.close()
 
 
 def main():
@@ -152,6 +193,8 @@ def main():
     if a.big_rows:
         nl = max(1024, a.big_rows // 2048)
         ivf_cosine_case(a.big_rows, 768, nl, 4096, 64, 10, dev, metric=capi.METRIC_L2, name="C4s", blobs=nl)
+    if "c5h" not in a.skip and "c5" not in a.skip:
+        hybrid_case(a.rows, 768, 4096, 32, 200_000, dev)
     if "c5" not in a.skip:
         bm25_case(a.docs, 200_000, 100)
 
