@@ -465,6 +465,23 @@ def test_sharded_lists_merge_equals_unsharded():
     mi, md = capi.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), capi.METRIC_IP)
     fi, fd = full.search(q, 10, "nprobe=8")
     same(mi, md, fi, fd)
+    # a batch large enough for the matrix-core candidate pass on every shard (most lists of a shard are empty)
+    qb = rng.standard_normal((300, d), dtype=np.float32)
+    q0 = capi.prefilter_stats()[0]
+    shard_ix = []
+    for r in range(W):
+        ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_IP, d, "shard_rank=%d,shard_world=%d" % (r, W))
+        ix.set_centroids(cent)
+        ix.add(x)
+        ix.build()
+        shard_ix.append(ix)
+    parts = [ix.search(qb, 10, "nprobe=8") for ix in shard_ix]
+    assert capi.prefilter_stats()[0] - q0 == W * 300
+    mi, md = capi.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), capi.METRIC_IP)
+    fi, fd = full.search(qb, 10, "nprobe=8")
+    same(mi, md, fi, fd)
+    oi, od, _ = oracle_on_exported(full, qb, 8, 10, capi.METRIC_IP)
+    same(fi, fd, oi, od)
 
 
 # ---------------------------------------------------------------------------------------- seam B: BM25
