@@ -349,6 +349,17 @@ void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uin
     MSVS_HIP(hipGetLastError());
 }
 
+void launch_split_queries(const float * Q, uint32_t nq, uint32_t ld4, void * out, hipStream_t stream)
+{
+    if (nq == 0)
+        return;
+    const uint32_t nk = (ld4 + 7) / 8;
+    const size_t n = (size_t)nq * nk * 8;
+    hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4 *>(Q), nq, ld4, nk, reinterpret_cast<uint4 *>(out));
+    MSVS_HIP(hipGetLastError());
+}
+
 void launch_ivf_mfma_scan(int metric, uint32_t nqg, uint32_t grid, ScanParams a, hipStream_t stream,
                           const char * profile_name)
 {

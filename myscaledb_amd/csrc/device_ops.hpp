@@ -84,6 +84,9 @@ void launch_ivf_merge(int metric, IvfMergeParams a, uint32_t nq, hipStream_t str
 /// out[r] = |X[r]|^2 for n rows of ld4 float4; max_bits: nullable running maximum of the float bit patterns.
 void launch_row_sqnorm(const float * X, float * out, size_t n, uint32_t ld4, uint32_t * max_bits, hipStream_t stream);
 
+/// Queries (nq rows of ld4 float4) -> split-bf16 step layout, nq * ceil(ld4 / 8) * 128 bytes (split_queries_kernel).
+void launch_split_queries(const float * Q, uint32_t nq, uint32_t ld4, void * out, hipStream_t stream);
+
 /// Approximate (split-bf16 MFMA) scan over the plan's work items; nqg in {1, 2}: 128- or 256-query tiles (plan built
 /// with T = BG_TQ * nqg); appends candidates to a.partial through a.qcnt / a.qthr (see mfma_scan_kernels.hpp).
 void launch_ivf_mfma_scan(int metric, uint32_t nqg, uint32_t grid, ScanParams a, hipStream_t stream,

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BLOCK * NQG) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
         for (int i = 0; i < QPT; i++)
         {
-            qsrc[i] = a.Q + (size_t)qrow_s[lr + RS * i] * ld4;
+            qsrc[i] = a.Qsplit + (size_t)qrow_s[lr + RS * i] * nk * 8; // 8 x 16 B per query and reduction step
             qld[i] = (lr + RS * i) / 32 < ncb; // the column block of query row lr + RS*i is in use
         }
         float qn[4];
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(BLOCK * NQG) __attribute__((amdgpu_waves_per_eu(2, 
                 px[i] = in ? xsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < QPT; i++)
-                pq[i] = in && qld[i] ? qsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                pq[i] = qld[i] ? qsrc[i][c] : make_float4(0.f, 0.f, 0.f, 0.f); // already split and zero padded
         };
         auto advance = [&]() {
             if (++pf_ki == nk)
@@ -355,8 +355,13 @@ __global__ __launch_bounds__(BLOCK * NQG) __attribute__((amdgpu_waves_per_eu(2, 
                 split_store(base, XPLANE, lr + RS * i, px[i]);
 #pragma unroll
             for (int i = 0; i < QPT; i++)
-                if (qld[i])
-                    split_store(base + 2 * XPLANE, QPLANE, lr + RS * i, pq[i]);
+                if (qld[i]) // thread lc carries chunk lc & 3 of plane lc >> 2 (hi / lo): a plain 16-byte copy
+                {
+                    const uint32_t row = lr + RS * i;
+                    *reinterpret_cast<float4 *>(base + 2 * XPLANE + (lc >> 2) * QPLANE + row * 64
+                                                + ((((lc & 3) ^ (row >> 2)) & 3) << 4))
+                        = pq[i];
+                }
         };
         set_rows(rb);
         gload();
@@ -523,6 +528,32 @@ __global__ __launch_bounds__(BLOCK * NQG) __attribute__((amdgpu_waves_per_eu(2, 
             }
         }
     }
+}
+
+/// Queries -> the split-bf16 layout the candidate pass stages verbatim: per query and 32-element reduction step 128 B =
+/// {hi: 4 chunks of 8 bf16 | lo: 4 chunks of 8 bf16}, zero padded to whole steps (same bytes as the f32 rows; done once
+/// per search instead of once per (work item, sub-tile)).  One thread per 16-byte chunk.
+static __global__ void split_queries_kernel(const float4 * Q, uint32_t nq, uint32_t ld4, uint32_t nk, uint4 * out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nq * nk * 8)
+        return;
+    const uint32_t c = (uint32_t)(i & 7), ki = (uint32_t)((i >> 3) % nk), q = (uint32_t)((i >> 3) / nk);
+    const uint32_t col = ki * 8 + (c & 3) * 2; // float4 column of the chunk's first 4 elements
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v0 = col < ld4 ? Q[(size_t)q * ld4 + col] : zero, v1 = col + 1 < ld4 ? Q[(size_t)q * ld4 + col + 1] : zero;
+    uint32_t h0 = pack_bf16(v0.x, v0.y), h1 = pack_bf16(v0.z, v0.w), h2 = pack_bf16(v1.x, v1.y), h3 = pack_bf16(v1.z, v1.w);
+    if (c >> 2) // lo plane: bf16(v - hi), v - hi exact in f32
+    {
+        auto lo2 = [](const uint32_t h, const float a, const float b) {
+            return pack_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+        };
+        h0 = lo2(h0, v0.x, v0.y);
+        h1 = lo2(h1, v0.z, v0.w);
+        h2 = lo2(h2, v1.x, v1.y);
+        h3 = lo2(h3, v1.z, v1.w);
+    }
+    out[i] = make_uint4(h0, h1, h2, h3);
 }
 
 /// The one-list "plan" that lets the candidate pass run over a plain row table (the coarse quantiser's centroids, a

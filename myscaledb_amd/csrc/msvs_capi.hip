@@ -763,7 +763,7 @@ static size_t big_cand_cap(size_t nprobe, size_t slices_max)
 
 static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k, size_t nprobe)
 {
-    size_t b = nq * (size_t)ix.ld * 4 + 4096;
+    size_t b = nq * (size_t)ix.ld * 4 + 2 * (nq * (size_t)(ix.ld + 32) * 4 + 4096) + 4096; // queries (+ split copies)
     if (ix.type == MSVS_INDEX_FLAT)
         return b + flat_scratch_bytes(ix.n, nq, k) + table_pass_scratch(ix.n, nq, std::min<uint32_t>(k, 40));
     IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k);
@@ -868,6 +868,8 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     // plan 0: the whole table (also what the fallback scans)
     launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, tq, pairs, probes0, list_off, small, small + 3, stream);
     launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
+    float4 * qsplit = scr.take<float4>(nq * (size_t)ceil_div((size_t)ld / 4, (size_t)8) * 8);
+    launch_split_queries(dq, (uint32_t)nq, ld / 4, qsplit, stream);
     // A table too long for "16 keys per slice" to fit the candidate buffers is searched in two phases: a sample first,
     // whose m-th best candidate becomes the query's cut for the rest (sample_cut_kernel)
     const bool two_phase = (size_t)nslices * BG_SLICE_K > cap;
@@ -907,6 +909,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     a.qcnt = qstate + nq;
     a.cand_cap = cap;
     a.tile_q = tq;
+    a.Qsplit = qsplit;
     const size_t tiles = ceil_div(nq, (size_t)tq);
     ProfileScope prof(t.prof_name, stream);
     if (two_phase)
@@ -1116,6 +1119,9 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         launch_ivf_plan_rescan(pa, stream);
         float * qnorm = scr.take<float>(nq);
         launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
+        float4 * qsplit = scr.take<float4>(nq * (size_t)ceil_div((size_t)ld / 4, (size_t)8) * 8);
+        launch_split_queries(dq, (uint32_t)nq, ld / 4, qsplit, stream);
+        a.Qsplit = qsplit;
         a.pairs = pp.pairs;
         a.pair_off = pp.pair_off;
         const char * xo = getenv("MSVS_IVF_XCD");

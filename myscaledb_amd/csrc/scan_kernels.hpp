@@ -242,6 +242,7 @@ struct ScanParams
     uint32_t * qcnt;         // big-tile candidate pass: keys emitted so far per query (append cursor into `partial`)
     uint32_t cand_cap;       // ... whose row for query q is partial[q * cand_cap ...]
     uint32_t tile_q;         // candidate pass: queries per tile of the plan (0: the kernel's full tile); a multiple of 32
+    const float4 * Qsplit;   // candidate pass: the queries in split-bf16 step layout (split_queries_kernel)
 };
 
 /// Scans rows [row_begin,row_end) for T queries already staged in LDS (qs[t*ld4 + c]) and leaves the block's
