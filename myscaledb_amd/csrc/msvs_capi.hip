@@ -690,11 +690,13 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                     p.nqg = (uint32_t)atoi(g);
             p.T = BG_TQ * p.nqg;
             p.kc = k <= 12 ? 32 : 64;
-            p.rpb = 2 * BG_ROWS; // work item = 2 slices of a list for a tile of <= 128 queries
+            // work item = 1 slice of a list for a tile of <= 128 queries, a grid of 4096 blocks: with the selection cheap,
+            // the finest granularity balances best (2 slices / 2048 blocks: +5-8 % step time at 1024 .. 16384 q/step)
+            p.rpb = BG_ROWS;
             if (const char * r = getenv("MSVS_IVF_RPB"))
                 if (atoi(r) >= BG_ROWS)
                     p.rpb = (uint32_t)round_up((size_t)atoi(r), (size_t)BG_ROWS);
-            p.grid = 2048 / p.nqg;
+            p.grid = 4096 / p.nqg;
             if (const char * g = getenv("MSVS_IVF_GRID"))
                 if (atoi(g) >= 1)
                     p.grid = (uint32_t)atoi(g);
@@ -863,8 +865,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     MSVS_HIP(hipMemsetAsync(small, 0, 9 * sizeof(uint32_t), stream));
     MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
     MSVS_HIP(hipMemsetAsync(qstate + nq, 0, nq * sizeof(uint32_t), stream));
-    // work item = 2 slices, or 1 when that is what it takes to give the chip ~1000 items
-    const uint32_t rpb = ceil_div(nq, (size_t)tq) * ceil_div(t.n, (size_t)(2 * BG_ROWS)) < 1024 ? BG_ROWS : 2 * BG_ROWS;
+    const uint32_t rpb = BG_ROWS; // work item = 1 slice (see plan_ivf)
     // plan 0: the whole table (also what the fallback scans)
     launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, tq, pairs, probes0, list_off, small, small + 3, stream);
     launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
@@ -918,7 +919,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         sa.list_off = list_off + 2;
         sa.work_off = small + 5;
         launch_ivf_mfma_scan(scan_metric(m), nqg,
-                             (uint32_t)std::min<size_t>(tiles * ceil_div((size_t)sample, (size_t)rpb), 2048 / nqg), sa, stream,
+                             (uint32_t)std::min<size_t>(tiles * ceil_div((size_t)sample, (size_t)rpb), 4096 / nqg), sa, stream,
                              "table_scan");
         launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
         // the m-th best sample candidate leaves ~m * n / sample rows of the table below the cut; the query fails its
@@ -929,12 +930,12 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         sa.list_off = list_off + 4;
         sa.work_off = small + 7;
         launch_ivf_mfma_scan(scan_metric(m), nqg,
-                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n - sample, (size_t)rpb), 2048 / nqg), sa, stream,
+                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n - sample, (size_t)rpb), 4096 / nqg), sa, stream,
                              "table_scan");
     }
     else
         launch_ivf_mfma_scan(scan_metric(m), nqg,
-                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 2048 / nqg), a, stream,
+                             (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 4096 / nqg), a, stream,
                              "table_scan");
     launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
     RerankParams rp{};
