@@ -1099,6 +1099,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         pp.probes = d_probes;
         pp.list_off = ix.list_mid.p;       // phase B: rows [mid, end) of every list
         pp.list_end = ix.list_off.p + 1;
+        pp.whole_off = ix.list_off.p;
         pp.n_pairs = (uint32_t)(nq * nprobe);
         pp.nlist = (uint32_t)ix.nlist;
         pp.rows_per_block = pl.rpb;
@@ -1229,6 +1230,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         IvfPlanParams pp{};
         pp.probes = d_probes;
         pp.list_off = ix.list_off.p;
+        pp.whole_off = ix.list_off.p;
         pp.n_pairs = (uint32_t)(nq * nprobe);
         pp.nlist = (uint32_t)ix.nlist;
         pp.rows_per_block = pl.rpb;

@@ -498,6 +498,8 @@ struct IvfPlanParams
     const int32_t * probes;   // [n_pairs] list id of pair i = q*nprobe + p (-1 = none)
     const int64_t * list_off; // [nlist+1]
     const int64_t * list_end; // nullable: end of list l (else list_off[l+1])
+    const int64_t * whole_off; // nullable [nlist+1]: pairs whose list is EMPTY here are dropped from the plan (a shard of a
+                               // multi-GPU index holds 1/world of the lists; 7 of 8 probes point at lists it does not own)
     uint32_t n_pairs;
     uint32_t nlist;
     uint32_t rows_per_block;
@@ -515,7 +517,7 @@ static __global__ void ivf_hist_kernel(const IvfPlanParams p)
     if (i < p.n_pairs)
     {
         int32_t l = p.probes[i];
-        if (l >= 0)
+        if (l >= 0 && (!p.whole_off || p.whole_off[l + 1] > p.whole_off[l]))
             atomicAdd(&p.cnt[l], 1u);
     }
 }
@@ -584,7 +586,7 @@ static __global__ void ivf_scatter_kernel(const IvfPlanParams p)
     if (i < p.n_pairs)
     {
         int32_t l = p.probes[i];
-        if (l >= 0)
+        if (l >= 0 && (!p.whole_off || p.whole_off[l + 1] > p.whole_off[l]))
             p.pairs[p.pair_off[l] + atomicAdd(&p.fill[l], 1u)] = i;
     }
 }
