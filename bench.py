@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed steps + the roofline pass (for profiler runs: no other batches, latency, recall)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -242,7 +244,7 @@ def main():
     # ---- the same index at smaller steps (single GPU only; 20 timed steps each): where the list scan reads every
     # probed row once it runs much closer to the HBM roofline than at the headline batch
     other = {}
-    if world == 1:
+    if world == 1 and not args.headline_only:
         for b2 in (256, 1024):
             if b2 >= B:
                 continue
@@ -279,7 +281,7 @@ def main():
     lat = []
     o1i = torch.empty((1, k), device=dev, dtype=torch.int64)
     o1d = torch.empty((1, k), device=dev, dtype=torch.float32)
-    if world == 1:
+    if world == 1 and not args.headline_only:
         for i in range(20 + 200):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -291,7 +293,7 @@ def main():
     # the same single-query search captured once into a HIP graph and replayed (the C-ABI is stream-ordered and
     # allocation-free in steady state, so it captures): the latency without the per-kernel launch gaps
     lat_graph = []
-    if world == 1:
+    if world == 1 and not args.headline_only:
         try:
             qg = q_lat[:1].clone()
             cap_stream = torch.cuda.Stream()
@@ -321,7 +323,7 @@ def main():
 
     # ---- recall@10 against the exact scan of the same rows (rank 0, single GPU only: needs all lists)
     recall = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         flat = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
         flat.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
         flat.build()
@@ -334,7 +336,7 @@ def main():
 
     # ---- CPU baseline: the oracle's IVF search (same algorithm and arithmetic) on the host cores, bounded sample
     cpu = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not args.headline_only:
         from oracle import oracle as o
         cent, off, vecs, lids = ix.export()
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

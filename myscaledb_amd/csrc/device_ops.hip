@@ -360,8 +360,17 @@ void launch_split_queries(const float * Q, uint32_t nq, uint32_t ld4, void * out
     MSVS_HIP(hipGetLastError());
 }
 
+template <int METRIC, int NQG>
+static void mfma_scan_dispatch(bool main_phase, uint32_t grid, const ScanParams & a, hipStream_t stream)
+{
+    if (main_phase)
+        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<METRIC, NQG, 1>), dim3(grid), dim3(NQG * BLOCK), 0, stream, a);
+    else
+        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<METRIC, NQG, 0>), dim3(grid), dim3(NQG * BLOCK), 0, stream, a);
+}
+
 void launch_ivf_mfma_scan(int metric, uint32_t nqg, uint32_t grid, ScanParams a, hipStream_t stream,
-                          const char * profile_name)
+                          const char * profile_name, bool main_phase)
 {
     if (grid == 0)
         return;
@@ -369,14 +378,14 @@ void launch_ivf_mfma_scan(int metric, uint32_t nqg, uint32_t grid, ScanParams a,
     if (nqg == 2)
     {
         if (metric == M_IP)
-            hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_IP, 2>), dim3(grid), dim3(2 * BLOCK), 0, stream, a);
+            mfma_scan_dispatch<M_IP, 2>(main_phase, grid, a, stream);
         else
-            hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_L2, 2>), dim3(grid), dim3(2 * BLOCK), 0, stream, a);
+            mfma_scan_dispatch<M_L2, 2>(main_phase, grid, a, stream);
     }
     else if (metric == M_IP)
-        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_IP, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        mfma_scan_dispatch<M_IP, 1>(main_phase, grid, a, stream);
     else
-        hipLaunchKernelGGL((ivf_mfma_scan_big_kernel<M_L2, 1>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        mfma_scan_dispatch<M_L2, 1>(main_phase, grid, a, stream);
     MSVS_HIP(hipGetLastError());
 }
 

@@ -90,7 +90,7 @@ void launch_split_queries(const float * Q, uint32_t nq, uint32_t ld4, void * out
 /// Approximate (split-bf16 MFMA) scan over the plan's work items; nqg in {1, 2}: 128- or 256-query tiles (plan built
 /// with T = BG_TQ * nqg); appends candidates to a.partial through a.qcnt / a.qthr (see mfma_scan_kernels.hpp).
 void launch_ivf_mfma_scan(int metric, uint32_t nqg, uint32_t grid, ScanParams a, hipStream_t stream,
-                          const char * profile_name = "ivf_scan");
+                          const char * profile_name = "ivf_scan", bool main_phase = true);
 
 /// One-list plan over rows [row_begin, row_end) of a plain row table (see single_list_plan_kernel).
 void launch_single_list_plan(uint32_t nq, uint32_t row_begin, uint32_t row_end, uint32_t rows_per_block, uint32_t tq,

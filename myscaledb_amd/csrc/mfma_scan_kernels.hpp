@@ -219,7 +219,10 @@ __device__ __forceinline__ uint64_t wave_select16(const uint64_t k0, const uint6
 /// NQG = 2: 8 wavefronts, 256-query tiles: wavefronts 0-3 and 4-7 multiply the SAME staged rows by the first / second
 ///          128 queries, so a list probed by up to 256 queries of the batch is read once (at ~200 queries per list the
 ///          128-query tiles read it 1.9 times); 102 KB of LDS, one workgroup per CU, same 8 wavefronts per CU.
-template <int METRIC, int NQG>
+///
+/// PHASE only names the launch (0: sample phase / table passes, 1: main phase of the list scan) so that profilers list the
+/// two phases of a search step as two kernels; the code is the same.
+template <int METRIC, int NQG, int PHASE>
 __global__ __launch_bounds__(BLOCK * NQG) __attribute__((amdgpu_waves_per_eu(2, 2))) void ivf_mfma_scan_big_kernel(
     const ScanParams a)
 {

@@ -920,7 +920,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         sa.work_off = small + 5;
         launch_ivf_mfma_scan(scan_metric(m), nqg,
                              (uint32_t)std::min<size_t>(tiles * ceil_div((size_t)sample, (size_t)rpb), 4096 / nqg), sa, stream,
-                             "table_scan");
+                             "table_scan", false);
         launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
         // the m-th best sample candidate leaves ~m * n / sample rows of the table below the cut; the query fails its
         // certificate when fewer than k + 1 of them do, i.e. when >= m of the table's k + m best rows fell into the
@@ -931,12 +931,12 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         sa.work_off = small + 7;
         launch_ivf_mfma_scan(scan_metric(m), nqg,
                              (uint32_t)std::min<size_t>(tiles * ceil_div(t.n - sample, (size_t)rpb), 4096 / nqg), sa, stream,
-                             "table_scan");
+                             "table_scan", false);
     }
     else
         launch_ivf_mfma_scan(scan_metric(m), nqg,
                              (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 4096 / nqg), a, stream,
-                             "table_scan");
+                             "table_scan", false);
     launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
     RerankParams rp{};
     rp.Y = a.Y;
@@ -1149,7 +1149,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
             sa.list_end = pa.list_end;
             sa.work_off = pa.work_off;
             sa.rows_per_block = BG_ROWS;
-            launch_ivf_mfma_scan(scan_metric(m), pl.nqg, pl.grid, sa, stream, "ivf_sample_scan");
+            launch_ivf_mfma_scan(scan_metric(m), pl.nqg, pl.grid, sa, stream, "ivf_sample_scan", false);
             launch_cand_select(partial, a.qcnt, a.qthr, a.cand_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
             // m-th sample candidate: ~8k rows of everything below the cut (see sample_cut_kernel, table pass)
             const size_t avg_len = std::max<size_t>(1, ix.n / std::max<size_t>(ix.nlist, 1));
