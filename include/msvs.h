@@ -153,6 +153,11 @@ MSVS_API int msvs_profile_reset(void);
  * were re-run through the canonical scan (`fallbacks`).  Results are identical either way; this is a speed metric.
  * Synchronises the device. */
 MSVS_API int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks);
+/* Experiment / test knobs (DESIGN.md section 6b lists them; none is needed in production).  They are read ONCE per
+ * process from the MSVS_<NAME> environment variables; afterwards only this call changes them -- a search never calls
+ * getenv.  `name` without the MSVS_ prefix, any case; value NULL or "" restores the default.
+ * MSVS_ERR_INVALID_ARGUMENT for an unknown name. */
+MSVS_API int msvs_set_option(const char * name, const char * value);
 
 /* Multi-part / multi-GPU merge of partial top-k lists with the canonical total order -- the
  * device-side analogue of MergeTreeBaseSearchManager::getTotalTopSearchResultImpl

@@ -27,7 +27,7 @@ SYMBOLS = [
     "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
     "msvs_postings_create", "msvs_postings_free", "msvs_bm25_search", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
-    "msvs_knn_f32_filtered", "msvs_prefilter_stats",
+    "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option",
 ]
 
 
@@ -112,6 +112,11 @@ def profile_get(name):
     c, t = C.c_uint64(0), C.c_double(0)
     _check(lib().msvs_profile_get(name.encode(), C.byref(c), C.byref(t)))
     return c.value, t.value
+
+
+def set_option(name, value=None):
+    """Experiment / test knob (msvs_set_option): value None restores the default."""
+    _check(lib().msvs_set_option(name.encode(), None if value is None else str(value).encode()))
 
 
 def prefilter_stats():

@@ -131,4 +131,28 @@ inline size_t ceil_div(size_t x, size_t m) { return (x + m - 1) / m; }
 std::map<std::string, std::string> parse_params(const char * s);
 long param_int(const std::map<std::string, std::string> & m, const char * key, long dflt);
 
+/// Experiment / test knobs (never needed in production).  Read ONCE per process from the MSVS_<NAME> environment
+/// variables and changed afterwards only through msvs_set_option(): a search never calls getenv.
+struct Options
+{
+    double ivf_pass = 1;      // candidate pass of the list scan: 0 never, 1 from ~2 queries per list on, 2 whenever eligible
+    double ivf_h16 = 1;       // 1: over the fp16 shadow (h16_scan_kernels.hpp); 0: split-bf16 over the f32 rows
+    double coarse_mfma = 1;   // same switch for the coarse quantiser ...
+    double flat_mfma = 1;     // ... and for FLAT batches
+    double ivf_nqg = 1;       // split-bf16 pass: 128- (1) or 256-query (2) tiles
+    double ivf_rpb = 0;       // rows per work item (0 = planned)
+    double ivf_grid = 0;      // grid size (0 = planned)
+    double ivf_t = 0;         // canonical batched scan: query tile (0 = planned)
+    double ivf_xcd = 1;       // XCD-contiguous work ranges
+    double cand_cap = 0;      // candidate-buffer capacity per query (0 = planned; small values force overflow)
+    double ivf_eps_scale = 1; // multiplies the certificate's error bound (1e12: every query takes the fallback)
+    double h16_nt = 0;        // shadow pass: non-temporal row loads
+    double h16_grid = 0;      // shadow pass: grid size (0 = planned)
+    double h16_min_pairs = 0.25; // shadow pass from this many (query, list) pairs per list on
+    double h16_ncb = 0;       // shadow pass: column blocks (32 queries each) per tile, 0 = planned
+};
+const Options & options();
+/// name without the MSVS_ prefix, any case; value nullptr / "" restores the default.  false = unknown name.
+bool set_option(const char * name, const char * value);
+
 }

@@ -494,6 +494,69 @@ void launch_ivf_merge_subset(int metric, IvfMergeParams a, uint32_t blocks, hipS
     MSVS_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------ options
+
+namespace
+{
+struct OptionField
+{
+    const char * name;
+    double Options::*field;
+};
+const OptionField g_option_fields[] = {
+    {"ivf_pass", &Options::ivf_pass},       {"ivf_mfma", &Options::ivf_pass} /* round-1 name */,
+    {"ivf_h16", &Options::ivf_h16},         {"coarse_mfma", &Options::coarse_mfma},
+    {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
+    {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},
+    {"ivf_t", &Options::ivf_t},             {"ivf_xcd", &Options::ivf_xcd},
+    {"cand_cap", &Options::cand_cap},       {"ivf_eps_scale", &Options::ivf_eps_scale},
+    {"h16_nt", &Options::h16_nt},           {"h16_grid", &Options::h16_grid},
+    {"h16_min_pairs", &Options::h16_min_pairs}, {"h16_ncb", &Options::h16_ncb},
+};
+Options g_options;
+std::once_flag g_options_once;
+std::mutex g_options_mu;
+
+void options_from_env()
+{
+    for (const auto & f : g_option_fields)
+    {
+        std::string env = "MSVS_";
+        for (const char * c = f.name; *c; ++c)
+            env.push_back((char)toupper((unsigned char)*c));
+        if (const char * v = getenv(env.c_str()))
+            if (*v)
+                g_options.*(f.field) = atof(v);
+    }
+}
+}
+
+const Options & options()
+{
+    std::call_once(g_options_once, options_from_env);
+    return g_options;
+}
+
+bool set_option(const char * name, const char * value)
+{
+    (void)options();
+    if (!name)
+        return false;
+    std::string n;
+    for (const char * c = name; *c; ++c)
+        n.push_back((char)tolower((unsigned char)*c));
+    if (n.rfind("msvs_", 0) == 0)
+        n = n.substr(5);
+    std::lock_guard<std::mutex> lk(g_options_mu);
+    for (const auto & f : g_option_fields)
+        if (n == f.name)
+        {
+            g_options.*(f.field) = value && *value ? atof(value) : Options().*(f.field);
+            return true;
+        }
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------ params
 
 std::map<std::string, std::string> parse_params(const char * s)

@@ -1,0 +1,671 @@
+// h16_scan_kernels.hpp -- the list scan of batched IVF searches over the index's fp16 SHADOW.
+//
+// The candidate pass of mfma_scan_kernels.hpp reads the f32 rows and splits them into bf16 pairs on the fly: 4 B per
+// element from HBM, ~100 VALU ops per thread-step for the split, 3 MFMAs per product, a distance tile through LDS and
+// a radix select per (query, slice).  This file is the same idea with the work moved to where it is free:
+//
+//   * BUILD TIME: every IVF list is stored a second time as fp16 (x * s rounded to nearest, s = one power of two per
+//     index chosen from the largest |element|), in the register layout of the B operand of v_mfma_f32_32x32x16_f16:
+//     a shadow block = 32 rows, per 16-element reduction step 1 KiB = 64 lanes x 16 B, lane (r, h) holding elements
+//     16 s + 8 h .. + 7 of row r.  A wavefront streams its 32 rows with one fully coalesced global_load_dwordx4 per
+//     step straight into the MFMA operand registers: 2 B per element from HBM, no LDS round trip, no conversion.
+//     Lists are padded to whole blocks with zero rows (never offered).  +50 % index memory: 288 GB of HBM is what
+//     makes that the right trade (1M x 768: 3.07 GB f32 + 1.6 GB shadow).
+//   * PER SEARCH: the queries are rounded the same way once (h16_prep_queries_kernel: own power-of-two scale per
+//     query) into the LDS image of the A operand; the workgroup stages 64 reduction elements of its <= 128 queries per
+//     barrier, double buffered, XOR-swizzled so the ds_write_b128 of the stage and the ds_read_b128 of the operand
+//     reads are bank-conflict free.
+//   * ONE product per (row, query, step) instead of three: fp16 keeps 11 significant bits, so the single MFMA has
+//     error <= 2^-10 |x||q| where bf16 x 3 had 3.1 * 2^-16 -- larger, and still far below the spread of real
+//     distances (DESIGN.md section 4.3 has the numbers); the certificate of ivf_rerank_kernel takes the bound as a
+//     parameter, so the returned ids / distance bits stay those of the canonical scan in every case.
+//   * NO selection inside the scan.  A first launch (SAMPLE) computes the approximate distance of block 0 of every
+//     probed list (32 rows per list, ~3 % of the rows) and writes them out; h16_sample_thr_kernel turns the m-th best
+//     sample distance of a query into its cut `qthr` (about m * rows / sample rows of everything lie below it) and
+//     appends the sample rows below the cut.  The main launch scans the other blocks and appends every row whose
+//     approximate key is below the cut -- a compare + ballot per accumulator register, an atomic append for the few
+//     dozen survivors per query.  Every row that is not appended has key >= qthr, which is exactly the `bound` the
+//     certificate already knows (cand_select_kernel / ivf_rerank_kernel are reused unchanged).
+//
+// MFMA orientation: queries are the A operand (M, accumulator registers), rows the B operand (N, lanes), so a lane
+// owns ONE row and 16 queries per accumulator: the row's norm, id and filter bit are per-lane scalars and the
+// per-query constants come from LDS as broadcast float4 reads.
+#pragma once
+
+#include "mfma_scan_kernels.hpp"
+
+namespace msvs
+{
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H_ROWS = 32;  // rows per shadow block (one wavefront's B operand)
+constexpr int H_CHUNK = 64; // reduction elements per LDS stage = 4 MFMA steps = 128 B per query
+
+struct H16Params
+{
+    const uint4 * H;          // shadow blocks: [block][step][64 lanes] x 16 B
+    const uint32_t * hoff;    // [nlist + 1] first shadow block of list l
+    uint32_t nks;             // 16-element steps per stored row = 4 nch (rows are zero padded to whole chunks)
+    uint32_t nch;             // 64-element chunks per row / query = ceil(d / 64)
+    const uint4 * Qh;         // query image: [nq][nch][8 pieces] x 16 B (piece p of chunk c = elements 64 c + 8 p .. + 7)
+    const float2 * qinfo;     // [nq] {m2, qn}: L2 a = fma(m2, acc, |x|^2) + qn with m2 = -2 / (s_x s_q); IP a = m2 * acc
+    const float * xnorm;      // [n] |x|^2 (approximate)
+    const int64_t * list_off; // [nlist + 1] row range of list l in the f32 storage
+    const uint32_t * ids;     // id of stored row r
+    const uint64_t * alive;   // nullable filter bitmap over ids
+    uint32_t nbits;
+    const uint32_t * pairs;   // (query, probe) pairs grouped by list (IvfPlanParams)
+    const uint32_t * pair_off;
+    const uint32_t * work_off;
+    uint32_t nlist, nprobe, xcd_order;
+    // main launch
+    const uint32_t * qthr;    // [nq] cut (ordered distance word; 0xFFFFFFFF = none)
+    uint32_t * qcnt;          // [nq] append cursors
+    uint64_t * partial;       // [nq][cand_cap] appended keys (ordered distance word << 32 | row position)
+    uint32_t cand_cap;
+    // sample launch
+    uint32_t * sample_out;    // [nq * nprobe][32] ordered distance word of row r of block 0 (0xFFFFFFFF = no row)
+    uint32_t * sched;         // [8] work-queue cursors of this launch (zeroed by the caller)
+};
+
+/// Largest |element| of a table as float bits (NaN compares largest); max_bits zeroed by the caller.
+static __global__ void absmax_kernel(const float4 * x, size_t n4, uint32_t * max_bits)
+{
+    uint32_t m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const float4 v = x[i];
+        const uint32_t a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+        const uint32_t c = __float_as_uint(v.z) & 0x7fffffffu, e = __float_as_uint(v.w) & 0x7fffffffu;
+        m = max(max(m, a), max(b, max(c, e)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicMax(max_bits, m);
+}
+
+__device__ __forceinline__ uint32_t pack_h2(const float a, const float b)
+{
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v t;
+    t[0] = (_Float16)a; // round to nearest even, subnormals kept
+    t[1] = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, t);
+}
+
+/// f32 list-major rows -> shadow blocks; one thread per 16-byte piece.
+static __global__ void h16_build_kernel(const float * vecs, uint32_t ld, const int64_t * list_off,
+                                        const uint32_t * blk_list, const uint32_t * hoff, uint32_t nks, float scale,
+                                        uint4 * H, size_t piece0, size_t npieces)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npieces)
+        return;
+    i += piece0;
+    const uint32_t per_blk = nks * 64;
+    const uint32_t hb = (uint32_t)(i / per_blk), rem = (uint32_t)(i - (size_t)hb * per_blk);
+    const uint32_t s = rem >> 6, lane = rem & 63;
+    const uint32_t l = blk_list[hb];
+    const int64_t row = list_off[l] + (int64_t)(hb - hoff[l]) * H_ROWS + (lane & 31);
+    const uint32_t k0 = 16 * s + 8 * (lane >> 5);
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (row < list_off[l + 1])
+    {
+        const float * src = vecs + (size_t)row * ld;
+        if (k0 < ld)
+            v0 = *reinterpret_cast<const float4 *>(src + k0);
+        if (k0 + 4 < ld)
+            v1 = *reinterpret_cast<const float4 *>(src + k0 + 4);
+    }
+    H[i] = make_uint4(pack_h2(v0.x * scale, v0.y * scale), pack_h2(v0.z * scale, v0.w * scale),
+                      pack_h2(v1.x * scale, v1.y * scale), pack_h2(v1.z * scale, v1.w * scale));
+}
+
+/// Queries -> fp16 image + per-query constants; one wavefront per query.
+/// qnorm[q] (|q|^2, already computed) is overwritten with +inf when the query cannot be represented (NaN / inf /
+/// a scale outside 2^+-100): the certificate then fails and the canonical fallback serves the query.
+static __global__ void h16_prep_queries_kernel(const float * Q, uint32_t nq, uint32_t ld, uint32_t nch,
+                                               float inv_sx, int ip, uint4 * Qh, float2 * qinfo, float * qnorm)
+{
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq)
+        return;
+    const float * src = Q + (size_t)q * ld;
+    uint32_t m = 0;
+    for (uint32_t e = lane * 4; e < ld; e += 256)
+    {
+        const float4 v = *reinterpret_cast<const float4 *>(src + e);
+        m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
+                max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    const float maxabs = __uint_as_float(m);
+    bool bad = !(maxabs < 3.0e38f);
+    int ex = 0;
+    if (maxabs > 0.f && !bad)
+        (void)frexpf(maxabs, &ex); // maxabs = f * 2^ex, f in [0.5, 1): maxabs * 2^(14 - ex) < 2^14
+    int sh = 14 - ex;
+    if (sh > 100 || sh < -100)
+    {
+        bad = true;
+        sh = sh > 0 ? 100 : -100;
+    }
+    const float sq = ldexpf(1.f, sh), inv_sq = ldexpf(1.f, -sh);
+    for (uint32_t p = lane; p < nch * 8; p += 64)
+    {
+        const uint32_t k0 = p * 8;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (k0 < ld)
+            v0 = *reinterpret_cast<const float4 *>(src + k0);
+        if (k0 + 4 < ld)
+            v1 = *reinterpret_cast<const float4 *>(src + k0 + 4);
+        Qh[(size_t)q * nch * 8 + p] = make_uint4(pack_h2(v0.x * sq, v0.y * sq), pack_h2(v0.z * sq, v0.w * sq),
+                                                 pack_h2(v1.x * sq, v1.y * sq), pack_h2(v1.z * sq, v1.w * sq));
+    }
+    if (lane == 0)
+    {
+        const float unscale = inv_sx * inv_sq; // powers of two: exact
+        qinfo[q] = ip ? make_float2(unscale, 0.f) : make_float2(-2.f * unscale, qnorm[q]);
+        if (bad)
+            qnorm[q] = __uint_as_float(0x7f800000u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ the scan
+//
+// Work item = (list, tile of <= 32 NCB probing queries).  The workgroup (H_NW wavefronts, one per CU) first makes the
+// WHOLE query tile resident in LDS -- all d elements of its 32 NCB queries, 128 B per query and 64-element chunk,
+// XOR-swizzled -- and then its wavefronts stream the list's shadow blocks independently: block after block, no
+// barrier, no shared stage to wait for.  Per block a wavefront keeps H_RING - 1 chunks (4 KiB each) of rows in flight in a
+// register ring (plain global_load_dwordx4 that hipcc counts: the waits are vmcnt(N), never vmcnt(0)), reads the A
+// operands of the step from the resident tile and issues NCB MFMAs per 1 KiB of rows.
+//
+// How this shape was reached (profiles/r02_h16_notes.txt): a k-chunked tile staged per 128-row slice (every wavefront
+// loading rows AND queries) drains the row queue at every stage wait (vmcnt retires in order); a dedicated loader
+// wavefront fixes that but moves 16 KiB of queries per 16 KiB of rows through one wavefront's LDS-DMA stream
+// (~25 GB/s per CU) and a barrier per chunk: 0.6-0.8 ms of the step went to staging even with the row stream or the
+// matrix-core work removed.  With the tile resident the query bytes are read once per (list, tile) instead of once
+// per slice and the steady state has no barrier at all.
+// The price: a tile is at most what LDS holds (NCB <= 160 KiB / (d * 64 B): 3 column blocks = 96 queries at d = 768), so
+// a list probed by more queries is streamed once per tile; the tiles of a list are consecutive work items handed to
+// CUs of one XCD at the same time (per-XCD work queues), so the re-reads meet in that XCD's L2.
+//
+// SAMPLE launch: work item = (list, tile) as well, rows = block 0 only; wavefront w < ncb multiplies it by column
+// block w and writes the 32 x 32 ordered distance words to a.sample_out.
+
+constexpr int H_NW = 8;      // wavefronts per workgroup of the main launch
+constexpr int H_RING = 4;    // row chunks per wavefront in registers (H_RING - 1 in flight + the one being multiplied)
+constexpr int H_STAGE = 64;  // survivor records a wavefront stages in LDS before one round of atomics
+constexpr uint32_t H_NONE = 0xFFFFFFFFu;
+
+/// LDS bytes of the scan kernel for a tile of 32 * ncb queries.
+inline size_t h16_lds_bytes(uint32_t ncb, uint32_t nch)
+{
+    const size_t tq = 32 * (size_t)ncb;
+    return tq * nch * 128 + 5 * tq * 4 + (size_t)H_NW * H_STAGE * 12 + 16;
+}
+
+/// A wavefront's share of a work item: shadow blocks blk0, blk0 + stride, ... < nblk of the list (32 rows each) against
+/// NCBI column blocks of the resident tile.  The register ring runs THROUGH the block boundaries when nch is a
+/// multiple of H_RING (the chunks requested past the end of a block are the first chunks of the wavefront's next
+/// block), so in steady state every request is a useful one; otherwise, and after the last block, the requests past
+/// the end re-load the last chunk (harmless, L2 hits).
+template <int METRIC, int NCBI, bool SAMPLE, bool NT>
+__device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned char * qt /* tile + column-block offset */,
+                                           const uint32_t chunk_stride, const float * m2_s, const float * qn_s,
+                                           const uint32_t * thr_s, const uint32_t * qrow_s, const uint32_t * qpair_s,
+                                           uint32_t * stage, const uint32_t cb0, const uint32_t lane, const uint32_t nch,
+                                           const uint32_t hb_list /* first shadow block of the list */,
+                                           const uint32_t blk0, const uint32_t stride, const uint32_t nblk,
+                                           const int64_t lbeg, const int64_t lend, const uint32_t nvalid)
+{
+    if (blk0 >= nblk)
+        return;
+    const uint32_t r32 = lane & 31, h = lane >> 5;
+    // operand read offsets of this lane inside a 128-byte query row: piece (2 j + h) ^ swizzle
+    const uint32_t sw = (r32 >> 1) & 7;
+    uint32_t aoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        aoff[j] = r32 * 128 + (((2 * j + h) ^ sw) << 4);
+    const u32x4 * const hbase = reinterpret_cast<const u32x4 *>(a.H) + lane;
+    const size_t blk_pieces = (size_t)nch * 256; // 4 steps x 64 lanes per chunk
+    const uint32_t last = nch - 1;
+    const bool chain = nch % H_RING == 0;
+
+    u32x4 ring[H_RING][4];
+    auto load_chunk = [&](u32x4 (&b)[4], const u32x4 * p) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            b[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];
+    };
+    const u32x4 * hp = hbase + (size_t)(hb_list + blk0) * blk_pieces;
+#pragma unroll
+    for (int u = 0; u < H_RING - 1; u++)
+        load_chunk(ring[u], hp + (size_t)((uint32_t)u < last ? (uint32_t)u : last) * 256);
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (uint32_t blk = blk0; blk < nblk; blk += stride)
+    {
+        const bool has_next = chain && blk + stride < nblk;
+        const u32x4 * const hp_next = has_next ? hbase + (size_t)(hb_list + blk + stride) * blk_pieces : hp;
+        const int64_t row = lbeg + (int64_t)blk * H_ROWS + r32;
+        bool ok = row < lend;
+        float xn = 0.f;
+        if (ok)
+        {
+            if (METRIC == M_L2)
+                xn = a.xnorm[row];
+            if (a.alive)
+            {
+                const uint32_t id = a.ids[row];
+                ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
+            }
+        }
+        f32x16 acc[NCBI];
+#pragma unroll
+        for (int cb = 0; cb < NCBI; cb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                acc[cb][r] = 0.f;
+        auto step = [&](const u32x4 (&b)[4], const uint32_t c) {
+            const unsigned char * qb = qt + (size_t)c * chunk_stride;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const half8 bf = __builtin_bit_cast(half8, b[j]);
+                half8 af[NCBI];
+#pragma unroll
+                for (int cb = 0; cb < NCBI; cb++)
+                    af[cb] = *reinterpret_cast<const half8 *>(qb + cb * 4096 + aoff[j]);
+#pragma unroll
+                for (int cb = 0; cb < NCBI; cb++)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf, acc[cb], 0, 0, 0);
+            }
+        };
+        for (uint32_t c0 = 0; c0 < nch; c0 += H_RING)
+        {
+#pragma unroll
+            for (int u = 0; u < H_RING; u++)
+            {
+                const uint32_t c = c0 + u;
+                if (c >= nch)
+                    break;
+                // the chunk H_RING - 1 ahead: of this block, of the wavefront's next block, or a re-load of the last one.
+                // sched_barrier: without a fence hipcc sinks the prefetch loads down to their first use (register
+                // pressure heuristic) and the ring degenerates into load -> vmcnt(0) -> use
+                const uint32_t pc = c + H_RING - 1;
+                const u32x4 * src = pc < nch ? hp + (size_t)pc * 256
+                                             : (has_next ? hp_next + (size_t)(pc - nch) * 256 : hp + (size_t)last * 256);
+                load_chunk(ring[(u + H_RING - 1) % H_RING], src);
+                __builtin_amdgcn_sched_barrier(0);
+                step(ring[u], c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!chain && blk + stride < nblk)
+        {
+            // no chaining: restart the ring on the next block
+            const u32x4 * const nx = hbase + (size_t)(hb_list + blk + stride) * blk_pieces;
+#pragma unroll
+            for (int u = 0; u < H_RING - 1; u++)
+                load_chunk(ring[u], nx + (size_t)((uint32_t)u < last ? (uint32_t)u : last) * 256);
+            hp = nx;
+        }
+        else
+            hp = hp_next;
+
+        // ---- epilogue: accumulator register i of column block cb = query 32 cb + (i & 3) + 8 (i >> 2) + 4 h, row r32.
+        // Survivors are compacted per wavefront into an LDS stage (ballot + mbcnt) and appended to the queries'
+        // candidate buffers in ONE parallel round of global atomics per <= 64 records (a returning atomic per passing
+        // register serialises one L2 round trip each).
+        uint32_t cnt = 0; // records staged, wave-uniform
+        auto flush = [&]() {
+            if (lane < cnt)
+            {
+                const uint32_t q = stage[2 * H_STAGE + lane];
+                const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
+                if (pos < a.cand_cap)
+                    a.partial[(size_t)q * a.cand_cap + pos] = (uint64_t)stage[H_STAGE + lane] << 32 | stage[lane];
+            }
+            cnt = 0;
+        };
+#pragma unroll
+        for (int cbi = 0; cbi < NCBI; cbi++)
+        {
+            const uint32_t cb = cb0 + (uint32_t)cbi;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++)
+            {
+                const uint32_t q0 = 32 * cb + 8 * g4 + 4 * h;
+                const float4 m2 = *reinterpret_cast<const float4 *>(&m2_s[q0]);
+                const float4 qn = *reinterpret_cast<const float4 *>(&qn_s[q0]);
+                uint4 cut = make_uint4(0u, 0u, 0u, 0u);
+                if (!SAMPLE)
+                    cut = *reinterpret_cast<const uint4 *>(&thr_s[q0]);
+                const float m2v[4] = {m2.x, m2.y, m2.z, m2.w}, qnv[4] = {qn.x, qn.y, qn.z, qn.w};
+                const uint32_t cutv[4] = {cut.x, cut.y, cut.z, cut.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2v[e], acc[cbi][4 * g4 + e], xn), qnv[e])
+                                                   : __fmul_rn(m2v[e], acc[cbi][4 * g4 + e]);
+                    const uint64_t key = ok ? make_key<METRIC>(v, (uint32_t)row) : KEY_NONE;
+                    const uint32_t word = (uint32_t)(key >> 32);
+                    if (SAMPLE)
+                    {
+                        if (q0 + e < nvalid)
+                            a.sample_out[(size_t)qpair_s[q0 + e] * H_ROWS + r32] = word;
+                    }
+                    else
+                    {
+                        const bool pass = word < cutv[e]; // KEY_NONE has word 0xFFFFFFFF: never below a cut
+                        const uint64_t mask = __ballot(pass);
+                        if (mask)
+                        {
+                            const uint32_t np = __popcll(mask);
+                            if (cnt + np > (uint32_t)H_STAGE)
+                                flush();
+                            if (pass)
+                            {
+                                const uint32_t at = cnt
+                                    + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                                stage[at] = (uint32_t)key;
+                                stage[H_STAGE + at] = word;
+                                stage[2 * H_STAGE + at] = qrow_s[q0 + e];
+                            }
+                            cnt += np;
+                        }
+                    }
+                }
+            }
+        }
+        if (!SAMPLE)
+            flush();
+    }
+}
+
+/// Next work item of this workgroup: per-XCD queues (a.sched[x] = cursor of the x-th eighth of the items), own XCD
+/// first, then the others' leftovers.  Placement (block b on XCD b % 8) is a speed assumption only.
+__device__ __forceinline__ uint32_t h16_next_item(uint32_t * sched, const uint32_t total, const uint32_t xcd)
+{
+    const uint32_t per = (total + 7) / 8;
+    for (uint32_t t = 0; t < 8; t++)
+    {
+        const uint32_t x = (xcd + t) & 7;
+        if (x * per >= total)
+            continue;
+        const uint32_t i = atomicAdd(&sched[x], 1u);
+        if (i < per && x * per + i < total)
+            return x * per + i;
+    }
+    return H_NONE;
+}
+
+template <int METRIC, int NCB, bool NT>
+__global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
+{
+    constexpr uint32_t TQ = 32 * NCB;
+    constexpr uint32_t NW = H_NW;
+    constexpr bool SAMPLE = false;
+    const uint32_t nch = a.nch;
+    unsigned char * const tile = msvs_smem; // [chunk][query][8 x 16 B]
+    float * const m2_s = reinterpret_cast<float *>(tile + (size_t)TQ * nch * 128);
+    float * const qn_s = m2_s + TQ;
+    uint32_t * const thr_s = reinterpret_cast<uint32_t *>(qn_s + TQ);
+    uint32_t * const qrow_s = thr_s + TQ;
+    uint32_t * const qpair_s = qrow_s + TQ;
+    uint32_t * const stage_s = qpair_s + TQ; // [NW][3][H_STAGE]
+    uint32_t * const item_s = stage_s + NW * 3 * H_STAGE;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t total = a.work_off[a.nlist];
+    for (;;)
+    {
+        __syncthreads(); // the previous work item is done with the tile, the tables and item_s
+        if (tid == 0)
+            *item_s = h16_next_item(a.sched, total, blockIdx.x & 7);
+        __syncthreads();
+        const uint32_t w = *item_s;
+        if (w == H_NONE)
+            break;
+        uint32_t lo = 0, hi = a.nlist;
+        while (hi - lo > 1)
+        {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.work_off[mid] <= w)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t l = lo;
+        const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
+        const uint32_t tidx = w - a.work_off[l];
+        const uint32_t pe = a.pair_off[l + 1];
+        const uint32_t pb = a.pair_off[l] + tidx * TQ;
+        const uint32_t nvalid = pe - pb < TQ ? pe - pb : TQ;
+        const uint32_t nblk = a.hoff[l + 1] - a.hoff[l];
+
+        if (tid < TQ)
+        {
+            const bool v = tid < nvalid;
+            const uint32_t qp = a.pairs[v ? pb + tid : pe - 1];
+            const uint32_t q = qp / a.nprobe;
+            qrow_s[tid] = q;
+            qpair_s[tid] = qp;
+            const float2 qi = a.qinfo[q];
+            m2_s[tid] = qi.x;
+            qn_s[tid] = qi.y;
+            thr_s[tid] = (!SAMPLE && v) ? a.qthr[q] : 0u; // padding queries of a short tile never pass
+        }
+        __syncthreads();
+        // the tile: piece p = (chunk, query, slot) in LDS order holds piece slot ^ swizzle(query) of the query's chunk
+        {
+            const uint32_t npieces = TQ * nch * 8; // a multiple of 256
+            for (uint32_t p0 = tid; p0 < npieces; p0 += 4 * 64 * NW)
+            {
+                uint4 v0, v1, v2, v3; // 4 loads in flight per thread; pieces past the end re-load the last one
+                auto fetch = [&](const uint32_t pp) {
+                    const uint32_t p = pp < npieces ? pp : npieces - 1;
+                    const uint32_t slot = p & 7, qi = (p >> 3) % TQ, c = (p >> 3) / TQ;
+                    return a.Qh[((size_t)qrow_s[qi] * nch + c) * 8 + (slot ^ ((qi >> 1) & 7))];
+                };
+                v0 = fetch(p0);
+                v1 = fetch(p0 + 64 * NW);
+                v2 = fetch(p0 + 2 * 64 * NW);
+                v3 = fetch(p0 + 3 * 64 * NW);
+                *reinterpret_cast<uint4 *>(tile + (size_t)p0 * 16) = v0;
+                if (p0 + 64 * NW < npieces)
+                    *reinterpret_cast<uint4 *>(tile + (size_t)(p0 + 64 * NW) * 16) = v1;
+                if (p0 + 2 * 64 * NW < npieces)
+                    *reinterpret_cast<uint4 *>(tile + (size_t)(p0 + 2 * 64 * NW) * 16) = v2;
+                if (p0 + 3 * 64 * NW < npieces)
+                    *reinterpret_cast<uint4 *>(tile + (size_t)(p0 + 3 * 64 * NW) * 16) = v3;
+            }
+        }
+        __syncthreads();
+        uint32_t * const stage = stage_s + wave * 3 * H_STAGE;
+        h16_stream<METRIC, NCB, false, NT>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, qpair_s, stage, 0, lane, nch,
+                                               a.hoff[l], 1 + wave, NW, nblk, lbeg, lend, nvalid);
+    }
+}
+
+/// The sample launch: block 0 (<= 32 rows) of every probed list against the queries probing it, one wavefront per
+/// (list, column block of 32 queries), no LDS: both operands come straight from memory in MFMA register order -- the
+/// rows as in the main launch (1 KiB per step, coalesced), the queries as a gather (lane (q, h) reads 16 bytes of
+/// query q's image; the four steps of a chunk use up the 128-byte line).  The plan behind pair_off / work_off is built
+/// with T = 32 over the row range [list_off, list_off + 32).  Writes the 32 x 32 ordered distance words of the item
+/// to a.sample_out[pair][row].
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) void h16_sample_kernel(const H16Params a)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
+    const uint32_t nch = a.nch, total = a.work_off[a.nlist];
+    for (uint32_t w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4)
+    {
+        uint32_t lo = 0, hi = a.nlist;
+        while (hi - lo > 1)
+        {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.work_off[mid] <= w)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t l = lo;
+        const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
+        const uint32_t pe = a.pair_off[l + 1];
+        const uint32_t pb = a.pair_off[l] + (w - a.work_off[l]) * 32;
+        const uint32_t nvalid = pe - pb < 32u ? pe - pb : 32u;
+        // this lane's query (A operand row r32); short tiles repeat their last pair
+        const uint32_t qp = a.pairs[pb + (r32 < nvalid ? r32 : nvalid - 1)];
+        const uint32_t q = qp / a.nprobe;
+        const float2 qi = a.qinfo[q];
+        const u32x4 * const ap = reinterpret_cast<const u32x4 *>(a.Qh) + (size_t)q * nch * 8 + h;
+        const u32x4 * const bp = reinterpret_cast<const u32x4 *>(a.H) + (size_t)a.hoff[l] * nch * 256 + lane;
+        const int64_t row = lbeg + r32;
+        bool ok = row < lend;
+        float xn = 0.f;
+        if (ok)
+        {
+            if (METRIC == M_L2)
+                xn = a.xnorm[row];
+            if (a.alive)
+            {
+                const uint32_t id = a.ids[row];
+                ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            acc[r] = 0.f;
+        u32x4 ar[2][4], br[2][4];
+        auto load = [&](const int s, const uint32_t c) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                ar[s][j] = ap[(size_t)c * 8 + 2 * j];
+                br[s][j] = bp[(size_t)c * 256 + j * 64];
+            }
+        };
+        load(0, 0);
+        const uint32_t last = nch - 1;
+        for (uint32_t c = 0; c < nch; c += 2)
+        {
+            load(1, c + 1 < last ? c + 1 : last);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ar[0][j]),
+                                                             __builtin_bit_cast(half8, br[0][j]), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 >= nch)
+                break;
+            load(0, c + 2 < last ? c + 2 : last);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ar[1][j]),
+                                                             __builtin_bit_cast(half8, br[1][j]), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // accumulator register i = query (i & 3) + 8 (i >> 2) + 4 h of the tile, row r32: the query's constants live in the
+        // lane that fed it as A operand
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            const int qidx = (i & 3) + 8 * (i >> 2) + 4 * (int)h; // lanes qidx and qidx + 32 hold the same query
+            const float m2 = __shfl(qi.x, qidx), qn = __shfl(qi.y, qidx);
+            const uint32_t pair = (uint32_t)__shfl((int)qp, qidx);
+            const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2, acc[i], xn), qn) : __fmul_rn(m2, acc[i]);
+            const uint64_t key = ok ? make_key<METRIC>(v, (uint32_t)row) : KEY_NONE;
+            if ((uint32_t)qidx < nvalid)
+                a.sample_out[(size_t)pair * H_ROWS + r32] = (uint32_t)(key >> 32);
+        }
+    }
+}
+
+/// One wavefront per query: the m-th smallest of its nprobe x 32 sample words becomes the cut qthr[q], and the sample
+/// rows below the cut open the candidate buffer (qcnt[q] = their number).  m is chosen per query so that about
+/// `target` rows of everything the query probes lie below the cut: m = target * S / R with S = sample rows that exist
+/// (and pass the filter) and R = rows of the probed lists, clamped to [4, 64] -- lists of very different lengths
+/// (a sample block is 32 rows of ANY list) would otherwise let a query that probes the long lists overflow its buffer.
+/// Fewer than m sample rows: no cut (0xFFFFFFFF), everything is appended.
+static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint32_t * sample, const int32_t * probes,
+                                                                       const int64_t * list_off, uint32_t nq,
+                                                                       uint32_t nprobe, uint32_t target, uint32_t * qthr,
+                                                                       uint32_t * qcnt, uint64_t * partial, uint32_t cap)
+{
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq)
+        return;
+    const uint32_t * src = sample + (size_t)q * nprobe * H_ROWS;
+    const uint32_t n = nprobe * H_ROWS;
+    // R and S
+    uint64_t rows = 0;
+    for (uint32_t p = lane; p < nprobe; p += 64)
+    {
+        const int32_t l = probes[(size_t)q * nprobe + p];
+        if (l >= 0)
+            rows += (uint64_t)(list_off[l + 1] - list_off[l]);
+    }
+    uint32_t have = 0;
+    for (uint32_t i = lane; i < n; i += 64)
+        have += probes[(size_t)q * nprobe + i / H_ROWS] >= 0 && src[i] != 0xFFFFFFFFu;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        rows += (uint64_t)__shfl_xor((int)(uint32_t)rows, o) | ((uint64_t)__shfl_xor((int)(uint32_t)(rows >> 32), o) << 32);
+        have += (uint32_t)__shfl_xor((int)have, o);
+    }
+    uint32_t m = rows ? (uint32_t)(((uint64_t)target * have + rows - 1) / rows) : 4u;
+    m = m < 4 ? 4 : (m > 64 ? 64 : m);
+    WaveTopK<1> top;
+    top.init();
+    for (uint32_t base = 0; base < n; base += 4 * WAVE)
+    {
+        uint64_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const uint32_t i = base + u * WAVE + lane;
+            const uint32_t word = i < n && probes[(size_t)q * nprobe + i / H_ROWS] >= 0 ? src[i] : 0xFFFFFFFFu;
+            key[u] = word == 0xFFFFFFFFu ? KEY_NONE : ((uint64_t)word << 32 | i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            top.offer(key[u], m, lane);
+    }
+    const uint32_t cut = top.thr == KEY_NONE ? 0xFFFFFFFFu : (uint32_t)(top.thr >> 32);
+    uint32_t count = 0;
+    for (uint32_t base = 0; base < n; base += WAVE)
+    {
+        const uint32_t i = base + lane;
+        const int32_t l = i < n ? probes[(size_t)q * nprobe + i / H_ROWS] : -1;
+        const uint32_t word = l >= 0 ? src[i] : 0xFFFFFFFFu;
+        const bool take = word < cut; // 0xFFFFFFFF (no row) is never below a cut
+        const uint64_t mask = __ballot(take);
+        if (take)
+        {
+            const uint32_t pos = count + __popcll(mask & ((1ull << lane) - 1));
+            if (pos < cap)
+                partial[(size_t)q * cap + pos] = (uint64_t)word << 32 | (uint32_t)(list_off[l] + (i & (H_ROWS - 1)));
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0)
+    {
+        qthr[q] = cut;
+        qcnt[q] = count;
+    }
+}
+
+}

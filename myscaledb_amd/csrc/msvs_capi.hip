@@ -11,6 +11,7 @@
 
 #include "device_ops.hpp"
 #include "ivf_build_kernels.hpp"
+#include "h16_scan_kernels.hpp"
 
 namespace msvs
 {
@@ -257,8 +258,82 @@ struct msvs_index
     DevBuf<float> cnorm; // same for the centroids (the coarse quantiser goes through the same pass)
     float cnorm_max = 0.f;
     DevBuf<int64_t> list_mid; // nlist: end of the SAMPLE slice of list l = min(list_off[l] + 128, list_off[l+1])
+    // fp16 shadow of the lists (h16_scan_kernels.hpp): the list scan of batched searches reads this instead of vecs
+    int want_shadow = 1;        // build parameter `shadow=0|1`
+    DevBuf<uint4> shadow;       // blocks of 32 rows in MFMA operand order
+    DevBuf<uint32_t> hoff;      // nlist + 1: first block of list l
+    DevBuf<int64_t> list_mid32; // nlist: end of block 0 of list l = min(list_off[l] + 32, list_off[l+1])
+    uint32_t h_nks = 0, h_nch = 0;
+    float h_scale = 0.f, h_inv_scale = 0.f; // stored value = fp16(x * h_scale)
+    bool shadow_ready = false;
     bool ready = false;
 };
+
+/// The fp16 shadow of an IVF index (see h16_scan_kernels.hpp); called once the final storage and the norms are in place.
+static void index_build_shadow(msvs_index & ix, hipStream_t stream)
+{
+    ix.shadow_ready = false;
+    if (ix.type != MSVS_INDEX_IVFFLAT || !ix.want_shadow || ix.n == 0 || ix.nlist == 0 || !(ix.xnorm_max < 1e30f)
+        || ix.n > 0xfffffff0ull)
+        return;
+    DevBuf<uint32_t> mx(1);
+    MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
+    const size_t n4 = ix.n * (size_t)(ix.ld / 4);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>(ceil_div(n4, (size_t)256), 4096)), dim3(256), 0,
+                       stream, reinterpret_cast<const float4 *>(ix.vecs.p), n4, mx.p);
+    MSVS_HIP(hipGetLastError());
+    uint32_t bits = 0;
+    MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
+    MSVS_HIP(hipStreamSynchronize(stream));
+    float maxabs;
+    memcpy(&maxabs, &bits, 4);
+    if (!(maxabs < 3.0e38f))
+        return;
+    int ex = 0;
+    if (maxabs > 0.f)
+        (void)frexpf(maxabs, &ex); // maxabs < 2^ex  =>  |x| * 2^(14 - ex) < 2^14: no fp16 overflow
+    const int sh = 14 - ex;
+    if (sh > 100 || sh < -100)
+        return; // the error model assumes the fp16 subnormal quantum is <= 2^-38 max|x|
+    ix.h_scale = ldexpf(1.f, sh);
+    ix.h_inv_scale = ldexpf(1.f, -sh);
+    ix.h_nch = (uint32_t)ceil_div(ix.dim, (size_t)H_CHUNK);
+    ix.h_nks = 4 * ix.h_nch; // whole chunks: the scan's inner loop has no tail
+    std::vector<uint32_t> hoff(ix.nlist + 1, 0);
+    std::vector<int64_t> mid(ix.nlist);
+    for (size_t l = 0; l < ix.nlist; l++)
+    {
+        const size_t len = (size_t)(ix.h_list_off[l + 1] - ix.h_list_off[l]);
+        const size_t nb = hoff[l] + ceil_div(len, (size_t)H_ROWS);
+        if (nb > 0xfffffff0ull)
+            return;
+        hoff[l + 1] = (uint32_t)nb;
+        mid[l] = std::min<int64_t>(ix.h_list_off[l] + H_ROWS, ix.h_list_off[l + 1]);
+    }
+    const size_t nblocks = hoff[ix.nlist];
+    std::vector<uint32_t> blk_list(nblocks);
+    for (size_t l = 0; l < ix.nlist; l++)
+        std::fill(blk_list.begin() + hoff[l], blk_list.begin() + hoff[l + 1], (uint32_t)l);
+    DevBuf<uint32_t> d_blk(std::max<size_t>(nblocks, 1));
+    ix.hoff.alloc(ix.nlist + 1);
+    ix.list_mid32.alloc(ix.nlist);
+    const size_t npieces = nblocks * (size_t)ix.h_nks * 64;
+    ix.shadow.alloc(std::max<size_t>(npieces, 1));
+    MSVS_HIP(hipMemcpyAsync(d_blk.p, blk_list.data(), nblocks * 4, hipMemcpyHostToDevice, stream));
+    MSVS_HIP(hipMemcpyAsync(ix.hoff.p, hoff.data(), (ix.nlist + 1) * 4, hipMemcpyHostToDevice, stream));
+    MSVS_HIP(hipMemcpyAsync(ix.list_mid32.p, mid.data(), ix.nlist * 8, hipMemcpyHostToDevice, stream));
+    const size_t per_launch = (size_t)1 << 30; // pieces per launch (grid dimension limit)
+    for (size_t p0 = 0; p0 < npieces; p0 += per_launch)
+    {
+        const size_t m = std::min(per_launch, npieces - p0);
+        // p0 is a multiple of 2^30 pieces; the kernel indexes from the start of the shadow, so shift the base
+        hipLaunchKernelGGL(h16_build_kernel, dim3((unsigned)ceil_div(m, (size_t)256)), dim3(256), 0, stream, ix.vecs.p,
+                           ix.ld, ix.list_off.p, d_blk.p, ix.hoff.p, ix.h_nks, ix.h_scale, ix.shadow.p, p0, m);
+    }
+    MSVS_HIP(hipGetLastError());
+    MSVS_HIP(hipStreamSynchronize(stream));
+    ix.shadow_ready = true;
+}
 
 /// Row norms for the approximate pass and its error bound; called once the final storage is in place.
 static void index_finalize_norms(msvs_index & ix, hipStream_t stream)
@@ -290,6 +365,7 @@ static void index_finalize_norms(msvs_index & ix, hipStream_t stream)
     MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
     MSVS_HIP(hipStreamSynchronize(stream));
     memcpy(&ix.xnorm_max, &bits, 4); // NaN / inf / huge values switch the candidate pass off (see plan_ivf)
+    index_build_shadow(ix, stream);
 }
 
 /// Process-wide counters of the candidate pass: [0] = queries whose certificate failed (device side).
@@ -360,6 +436,7 @@ extern "C" int msvs_index_create(int index_type, int metric, size_t dim, const c
         ix->seed = (uint64_t)param_int(p, "seed", 1234);
         ix->shard_rank = (int)param_int(p, "shard_rank", 0);
         ix->shard_world = (int)param_int(p, "shard_world", 1);
+        ix->want_shadow = (int)param_int(p, "shadow", 1);
         if (ix->ncentroids == 0 || ix->shard_world < 1 || ix->shard_rank < 0 || ix->shard_rank >= ix->shard_world)
             fail(MSVS_ERR_INVALID_ARGUMENT, "bad ncentroids / shard parameters");
         *out = ix.release();
@@ -642,7 +719,8 @@ extern "C" size_t msvs_index_num_lists(const msvs_index_t * ix)
 extern "C" size_t msvs_index_memory_usage(const msvs_index_t * ix)
 {
     return ix ? ix->vecs.bytes() + ix->row_ids.bytes() + ix->centroids.bytes() + ix->list_off.bytes()
-            + ix->xnorm.bytes() + ix->cnorm.bytes() + ix->list_mid.bytes()
+            + ix->xnorm.bytes() + ix->cnorm.bytes() + ix->list_mid.bytes() + ix->shadow.bytes() + ix->hoff.bytes()
+            + ix->list_mid32.bytes()
               : 0;
 }
 
@@ -663,6 +741,10 @@ struct IvfSearchPlan
     uint32_t seg_max1;
     uint32_t fb_slots; // block slots (grid z) of the fallback
     uint32_t nqg;      // 128-query groups per workgroup of the candidate pass (1 or 2)
+    bool h16;          // the candidate pass runs over the fp16 shadow (h16_scan_kernels.hpp)
+    uint32_t h_mth;    // ... the number of rows per query its cut aims to leave below it (h16_sample_thr_kernel)
+    uint32_t h_cap;    // ... and its candidate-buffer capacity per query
+    uint32_t h_ncb;    // ... and its query tile: 32 * h_ncb queries resident in LDS
     bool mfma() const { return nqg != 0; }
 };
 
@@ -675,31 +757,58 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     // Matrix-core candidate pass: pays once ~4 queries share a list pass (the canonical scan is VALU-bound there);
     // needs finite, sane row norms for its error bound and k small enough for a 64-entry candidate list.
     {
-        const char * e = getenv("MSVS_IVF_MFMA"); // experiment knob: 0 = never, 2 = whenever eligible
-        const int mode = e ? atoi(e) : 1;
+        const int mode = (int)options().ivf_pass; // experiment knob: 0 = never, 2 = whenever eligible
         // row positions travel in the low word of the candidate keys: < 2^32 rows; NaN norms compare false
         const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f && ix.n <= 0xfffffff0ull;
-        if (mode != 0 && eligible && (pairs >= 4 * nlist || mode >= 2))
+        // the shadow pass keeps a whole query tile in LDS: at least one column block of 32 queries must fit
+        const bool h16 = ix.shadow_ready && options().ivf_h16 != 0 && h16_lds_bytes(1, ix.h_nch) <= 160 * 1024;
+        const double min_pairs = h16 ? options().h16_min_pairs : 4.0;
+        if (mode != 0 && eligible && ((double)pairs >= min_pairs * (double)nlist || mode >= 2))
         {
+            p.h16 = h16;
+            if (h16)
+            {
+                // queries per tile: what the average list is probed by, up to what LDS holds (and 4 accumulators)
+                // (twice the average: probes concentrate on the popular lists; measured: 64-query tiles beat 32-query
+                // ones from 8 pairs per list on)
+                uint32_t ncb = (uint32_t)std::min<size_t>(4, std::max<size_t>(2, ceil_div(2 * ceil_div(pairs, nlist), (size_t)32)));
+                if (options().h16_ncb >= 1)
+                    ncb = (uint32_t)std::min(4.0, options().h16_ncb);
+                while (ncb > 1 && h16_lds_bytes(ncb, ix.h_nch) > 160 * 1024)
+                    ncb--;
+                p.h_ncb = ncb;
+            }
+            {
+                // sample = block 0 (<= 32 rows) of every probed list; the cut of a query = its m-th best sample row with
+                // m = target * (sample rows) / (probed rows), i.e. about `target` rows of everything it probes lie below the
+                // cut (h16_sample_thr_kernel).  target = 25 k: m ~ 9 on lists of ~1000 rows; the certificate fails when
+                // fewer than k rows do (>= m of the k + m best rows fell into the sample: ~1e-6 there, and the floor m = 4
+                // is only reached when the sample is a small fraction of the probed rows)
+                p.h_mth = (uint32_t)std::max<size_t>(64, 25 * (size_t)k); // the target
+                // capacity: 8 x the target, and 2.5 x what the floor m = 4 leaves below the cut when every probed list is as
+                // long as the longest one (sample fraction 32 / max_list_len)
+                size_t cap = std::min<size_t>(std::max<size_t>(std::max<size_t>(1024, round_up(8 * (size_t)p.h_mth, 256)),
+                                                               round_up(10 * ceil_div(ix.max_list_len, (size_t)H_ROWS), 256)),
+                                              16384);
+                if (options().cand_cap >= 1)
+                    cap = std::max<size_t>(64, (size_t)options().cand_cap);
+                // never more than the rows a query can meet
+                p.h_cap = (uint32_t)std::min<size_t>(cap, std::max<size_t>(64, nprobe * round_up(ix.max_list_len, H_ROWS)));
+            }
             // 256-query tiles (nqg = 2: one workgroup of 8 wavefronts per CU, the rows read once per 256 probing
             // queries) measured SLOWER than two independent 128-query workgroups per CU at every batch size
             // (4096 q/step: 1.92 vs 1.70 ms, 16384: 6.01 vs 5.89 ms): kept as a knob only
-            p.nqg = 1;
-            if (const char * g = getenv("MSVS_IVF_NQG"))
-                if (atoi(g) == 1 || atoi(g) == 2)
-                    p.nqg = (uint32_t)atoi(g);
+            p.nqg = options().ivf_nqg == 2 ? 2 : 1;
             p.T = BG_TQ * p.nqg;
             p.kc = k <= 12 ? 32 : 64;
             // work item = 1 slice of a list for a tile of <= 128 queries, a grid of 4096 blocks: with the selection cheap,
             // the finest granularity balances best (2 slices / 2048 blocks: +5-8 % step time at 1024 .. 16384 q/step)
             p.rpb = BG_ROWS;
-            if (const char * r = getenv("MSVS_IVF_RPB"))
-                if (atoi(r) >= BG_ROWS)
-                    p.rpb = (uint32_t)round_up((size_t)atoi(r), (size_t)BG_ROWS);
+            if (options().ivf_rpb >= BG_ROWS)
+                p.rpb = (uint32_t)round_up((size_t)options().ivf_rpb, (size_t)BG_ROWS);
             p.grid = 4096 / p.nqg;
-            if (const char * g = getenv("MSVS_IVF_GRID"))
-                if (atoi(g) >= 1)
-                    p.grid = (uint32_t)atoi(g);
+            if (options().ivf_grid >= 1)
+                p.grid = (uint32_t)options().ivf_grid;
             // the candidate lists are per 128-row SLICE (<= 16 keys each), whatever the work-item size
             p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, (size_t)BG_ROWS));
             size_t rpb1 = round_up(std::max<size_t>(64, nprobe * avg * 3 / 2 / 400), 16);
@@ -730,21 +839,12 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     }
     p.grid = 4096;
     // tuning knobs for experiments (never needed in production): MSVS_IVF_T / MSVS_IVF_RPB / MSVS_IVF_GRID
-    if (const char * e = getenv("MSVS_IVF_T"))
     {
-        int t = atoi(e);
+        const int t = (int)options().ivf_t, r = (int)options().ivf_rpb, g = (int)options().ivf_grid;
         if (t == 1 || t == 2 || t == 4 || t == 8)
             p.T = (uint32_t)t;
-    }
-    if (const char * e = getenv("MSVS_IVF_RPB"))
-    {
-        int r = atoi(e);
         if (r >= 16)
             p.rpb = (uint32_t)round_up((size_t)r, 16);
-    }
-    if (const char * e = getenv("MSVS_IVF_GRID"))
-    {
-        int g = atoi(e);
         if (g >= 1)
             p.grid = (uint32_t)g;
     }
@@ -758,8 +858,8 @@ static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k);
 static size_t big_cand_cap(size_t nprobe, size_t slices_max)
 {
     size_t limit = 16384;
-    if (const char * e = getenv("MSVS_CAND_CAP")) // experiment / test knob
-        limit = std::max<size_t>(64, (size_t)atol(e));
+    if (options().cand_cap >= 1) // experiment / test knob
+        limit = std::max<size_t>(64, (size_t)options().cand_cap);
     return std::min<size_t>(nprobe * slices_max * BG_SLICE_K, limit);
 }
 
@@ -774,9 +874,10 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + nq * nprobe * 4
         + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
     if (p.mfma())
-        need += nq * big_cand_cap(nprobe, p.seg_max) * 8
+        need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
             + nq * (size_t)p.kc * 8 + nq * 24 + 8192
-            + nq * nprobe * (size_t)p.seg_max1 * k * 8;
+            + nq * nprobe * (size_t)p.seg_max1 * k * 8
+            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8) + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
     return need;
@@ -785,8 +886,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
 /// Error model of the split-bf16 candidate pass (mfma_scan_kernels.hpp header), times the test knob MSVS_IVF_EPS_SCALE.
 static void set_error_model(RerankParams & rp, size_t dim)
 {
-    const char * es = getenv("MSVS_IVF_EPS_SCALE"); // experiment / test knob: inflate eps to force the fallback
-    const double scale = 1.05 * (es ? atof(es) : 1.0), dd = (double)dim;
+    const double scale = 1.05 * options().ivf_eps_scale, dd = (double)dim; // knob: inflate eps to force the fallback
     rp.c_dot = scale * (3.1 * ldexp(1.0, -16) + 3.05 * dd * ldexp(1.0, -23));
     rp.c_norm = scale * (dd + 8.0) * ldexp(1.0, -24);
     rp.c_canon = scale * 32.0 * ldexp(1.0, -24);
@@ -825,10 +925,9 @@ static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k)
 /// Worth it once the (query tile) x (128-row slice) grid can occupy the chip (64 work items measured no better than
 /// the canonical scan on the 1024-centroid table, 256 items 2x better; the tiles shrink to 32 queries to get there)
 /// and enough queries share each pass over the rows for the canonical scan to be VALU-bound (>= 16).
-static bool table_pass_eligible(size_t n, const float * norms, float norm_max, size_t nq, uint32_t k, const char * knob)
+static bool table_pass_eligible(size_t n, const float * norms, float norm_max, size_t nq, uint32_t k, double knob)
 {
-    const char * e = getenv(knob); // experiment knob: 0 = never, 2 = whenever possible
-    const int mode = e ? atoi(e) : 1;
+    const int mode = (int)knob; // experiment knob: 0 = never, 2 = whenever possible
     const size_t items = ceil_div(nq, (size_t)32) * ceil_div(n, (size_t)BG_ROWS); // at the smallest tile (32 queries)
     return mode != 0 && norms && norm_max < 1e30f /* false for NaN */ && k <= 40 && n >= 256 && n <= 0xfffffff0ull
         && ((items >= 256 && nq >= 16) || mode == 2);
@@ -838,10 +937,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
                                  const TablePass & t, hipStream_t stream)
 {
     const uint32_t ld = ix.ld, nrows = (uint32_t)t.n, kc = t.k <= 12 ? 32 : 64;
-    uint32_t nqg = 1; // 256-query tiles: see plan_ivf
-    if (const char * g = getenv("MSVS_IVF_NQG")) // experiment / test knob
-        if (atoi(g) == 1 || atoi(g) == 2)
-            nqg = (uint32_t)atoi(g);
+    const uint32_t nqg = options().ivf_nqg == 2 ? 2 : 1; // 256-query tiles: see plan_ivf
     // queries per tile: the full 128 when that still gives the chip >= 512 work items, else 64 or 32 (the rows are then
     // re-read by more tiles -- cheap for a table that lives in L2, like the centroids)
     uint32_t tq = BG_TQ * nqg;
@@ -985,6 +1081,230 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     launch_ivf_merge_subset(scan_metric(m), fm, slots, stream);
 }
 
+/// Error model of the fp16 shadow pass (h16_scan_kernels.hpp), u = 2^-11:
+///   stored values: |fp16(x s) / s - x| <= u |x| + 2^-38 max|x| (rounding to nearest; the second term covers fp16
+///   subnormals, the scale s puts max|x| in [2^13, 2^14)); same for the query with its own scale, so
+///   |<x', q'> - <x, q>| <= (2u + u^2) |x||q| + 2.01 sqrt(d) 2^-38 |x|max |q| + d 2^-76 |x|max |q|;
+///   products of two fp16 are exact in f32; the MFMA accumulates n = 16 ceil(d/16) of them in f32 in an order and with a
+///   per-addition rounding we do not rely on: <= n 2^-23 sum|x'_i q'_i| <= 1.01 n 2^-23 |x||q|
+///   (tests/test_gpu_parity.py::test_mfma_accumulation_error_bound_on_hardware measures it);
+/// c_norm / c_canon as in set_error_model (the norms and the canonical distance do not change).
+static void set_error_model_h16(RerankParams & rp, size_t dim)
+{
+    const double scale = 1.05 * options().ivf_eps_scale, dd = (double)round_up(dim, H_CHUNK);
+    rp.c_dot = scale * (ldexp(1.0, -10) + ldexp(1.0, -22) + 2.01 * sqrt(dd) * ldexp(1.0, -38) + dd * ldexp(1.0, -76)
+                        + 1.01 * dd * ldexp(1.0, -23));
+    rp.c_norm = scale * ((double)dim + 8.0) * ldexp(1.0, -24);
+    rp.c_canon = scale * 32.0 * ldexp(1.0, -24);
+}
+
+template <int METRIC, int NCB>
+static void h16_launch(bool nt, uint32_t grid, size_t lds, const H16Params & a, hipStream_t stream)
+{
+    // more than 64 KiB of dynamic LDS needs the attribute raised once per kernel
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&h16_scan_kernel<METRIC, NCB, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&h16_scan_kernel<METRIC, NCB, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (nt)
+        hipLaunchKernelGGL((h16_scan_kernel<METRIC, NCB, true>), dim3(grid), dim3(64 * H_NW), lds, stream, a);
+    else
+        hipLaunchKernelGGL((h16_scan_kernel<METRIC, NCB, false>), dim3(grid), dim3(64 * H_NW), lds, stream, a);
+}
+
+template <int METRIC>
+static void h16_dispatch(uint32_t ncb, bool nt, uint32_t grid, size_t lds, const H16Params & a, hipStream_t stream)
+{
+    switch (ncb)
+    {
+        case 1:
+            h16_launch<METRIC, 1>(nt, grid, lds, a, stream);
+            break;
+        case 2:
+            h16_launch<METRIC, 2>(nt, grid, lds, a, stream);
+            break;
+        case 3:
+            h16_launch<METRIC, 3>(nt, grid, lds, a, stream);
+            break;
+        default:
+            h16_launch<METRIC, 4>(nt, grid, lds, a, stream);
+            break;
+    }
+}
+
+static uint32_t device_cu_count()
+{
+    static std::mutex mu;
+    static std::map<int, uint32_t> cus;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end())
+        return it->second;
+    int n = 0;
+    MSVS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    return cus[dev] = (uint32_t)std::max(n, 1);
+}
+
+/// List scan of a batch over the fp16 shadow: sample launch -> cut -> main launch -> candidate select -> canonical
+/// re-rank + certificate -> canonical fallback for the queries without one (h16_scan_kernels.hpp).
+static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq, uint32_t k,
+                          size_t nprobe, const IvfSearchPlan & pl, const int32_t * d_probes, const uint64_t * d_alive,
+                          size_t nbits, uint64_t * partial, int64_t * d_ids, float * d_dis, hipStream_t stream)
+{
+    const uint32_t ld = ix.ld;
+    // work item = (list, tile of 32 * h_ncb probing queries); main launch: rows [list_off + 32, end), sample launch: block 0
+    IvfPlanParams pp{};
+    pp.probes = d_probes;
+    pp.list_off = ix.list_mid32.p;
+    pp.list_end = ix.list_off.p + 1;
+    pp.whole_off = ix.list_off.p;
+    pp.n_pairs = (uint32_t)(nq * nprobe);
+    pp.nlist = (uint32_t)ix.nlist;
+    pp.rows_per_block = 0x7fffffffu; // one segment per non-empty row range
+    pp.T = 32 * pl.h_ncb;
+    uint32_t * counters = scr.take<uint32_t>(2 * ix.nlist + 1 + 16);
+    pp.cnt = counters;
+    pp.fill = counters + ix.nlist;
+    uint32_t * nfail = counters + 2 * ix.nlist;
+    uint32_t * sched = nfail + 1; // 8 work-queue cursors per launch
+    pp.pair_off = scr.take<uint32_t>(ix.nlist + 1);
+    pp.work_off = scr.take<uint32_t>(ix.nlist + 1);
+    pp.pairs = scr.take<uint32_t>(nq * nprobe);
+    MSVS_HIP(hipMemsetAsync(counters, 0, (2 * ix.nlist + 1 + 16) * sizeof(uint32_t), stream));
+    launch_ivf_plan(pp, stream);
+    IvfPlanParams pa = pp; // the sample launch: block 0 of every probed list, tiles of 32 queries (small workgroups)
+    pa.list_off = ix.list_off.p;
+    pa.list_end = ix.list_mid32.p;
+    pa.T = 32;
+    pa.work_off = scr.take<uint32_t>(ix.nlist + 1);
+    launch_ivf_plan_rescan(pa, stream);
+    float * qnorm = scr.take<float>(nq);
+    launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
+    uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8);
+    float2 * qinfo = scr.take<float2>(nq);
+    uint32_t * sample = scr.take<uint32_t>(nq * nprobe * H_ROWS);
+    uint32_t * qstate = scr.take<uint32_t>(2 * nq);
+    uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
+    uint64_t * bound = scr.take<uint64_t>(nq);
+    uint32_t * failq = scr.take<uint32_t>(nq);
+    {
+        ProfileScope prof("ivf_prep", stream);
+        hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq,
+                           (uint32_t)nq, ld, ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm);
+        MSVS_HIP(hipMemsetAsync(sample, 0xFF, nq * nprobe * H_ROWS * sizeof(uint32_t), stream));
+    }
+    H16Params a{};
+    a.H = ix.shadow.p;
+    a.hoff = ix.hoff.p;
+    a.nks = ix.h_nks;
+    a.nch = ix.h_nch;
+    a.Qh = qh;
+    a.qinfo = qinfo;
+    a.xnorm = ix.xnorm.p;
+    a.list_off = ix.list_off.p;
+    a.ids = ix.row_ids.p;
+    a.alive = d_alive;
+    a.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
+    a.pairs = pp.pairs;
+    a.pair_off = pp.pair_off;
+    a.nlist = (uint32_t)ix.nlist;
+    a.nprobe = (uint32_t)nprobe;
+    a.xcd_order = (uint32_t)options().ivf_xcd;
+    a.qthr = qstate;
+    a.qcnt = qstate + nq;
+    a.partial = partial;
+    a.cand_cap = pl.h_cap;
+    a.sample_out = sample;
+    // persistent workgroups pulling work items from per-XCD queues: one per CU (the tile takes most of the LDS)
+    const size_t lds = h16_lds_bytes(pl.h_ncb, ix.h_nch);
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
+    const uint32_t grid = options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count() * per_cu;
+    const bool nt = options().h16_nt != 0;
+    {
+        ProfileScope prof("ivf_sample_scan", stream);
+        a.work_off = pa.work_off;
+        const uint32_t sgrid = device_cu_count() * 8; // one wavefront per (list, 32-query column block), grid-stride
+        if (scan_metric(m) == M_IP)
+            hipLaunchKernelGGL((h16_sample_kernel<M_IP>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
+        else
+            hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
+        hipLaunchKernelGGL(h16_sample_thr_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
+                           sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
+                           qstate + nq, partial, pl.h_cap);
+    }
+    {
+        ProfileScope prof("ivf_scan", stream);
+        a.work_off = pp.work_off;
+        a.sched = sched + 8;
+        if (scan_metric(m) == M_IP)
+            h16_dispatch<M_IP>(pl.h_ncb, nt, grid, lds, a, stream);
+        else
+            h16_dispatch<M_L2>(pl.h_ncb, nt, grid, lds, a, stream);
+    }
+    MSVS_HIP(hipGetLastError());
+    launch_cand_select(partial, qstate + nq, qstate, pl.h_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
+    RerankParams rp{};
+    rp.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
+    rp.ids = ix.row_ids.p;
+    rp.Q = reinterpret_cast<const float4 *>(dq);
+    rp.qnorm = qnorm;
+    rp.cand = cand;
+    rp.bound = bound;
+    rp.kc = pl.kc;
+    rp.k = k;
+    rp.ld4 = ld / 4;
+    rp.out_ids = d_ids;
+    rp.out_dis = d_dis;
+    rp.cosine = ix.metric == MSVS_METRIC_COSINE;
+    set_error_model_h16(rp, ix.dim);
+    rp.xmax = ix.xnorm_max;
+    rp.failq = failq;
+    rp.nfail = nfail;
+    rp.stat_fail = prefilter_fail_counter();
+    launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
+    g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
+    // queries without a certificate: canonical scan, one query per block (normally zero of them)
+    uint64_t * partial1 = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max1 * k);
+    ScanParams c{};
+    c.Y = rp.Y;
+    c.ids = ix.row_ids.p;
+    c.alive = d_alive;
+    c.nbits = a.nbits;
+    c.Q = rp.Q;
+    c.ld4 = ld / 4;
+    c.nq = (uint32_t)nq;
+    c.probes = d_probes;
+    c.list_off = ix.list_off.p;
+    c.nprobe = (uint32_t)nprobe;
+    c.nlist = (uint32_t)ix.nlist;
+    c.k = k;
+    c.partial = partial1;
+    c.rows_per_block = pl.rpb1;
+    c.seg_max = pl.seg_max1;
+    c.qmap = failq;
+    c.qcount = nfail;
+    launch_ivf_scan_subset(scan_metric(m), c, pl.fb_slots, stream);
+    IvfMergeParams fm{};
+    fm.partial = partial1;
+    fm.probes = d_probes;
+    fm.list_off = ix.list_off.p;
+    fm.nprobe = (uint32_t)nprobe;
+    fm.seg_max = pl.seg_max1;
+    fm.rows_per_block = pl.rpb1;
+    fm.k = k;
+    fm.out_ids = d_ids;
+    fm.out_dis = d_dis;
+    fm.cosine = ix.metric == MSVS_METRIC_COSINE;
+    fm.qmap = failq;
+    fm.qcount = nfail;
+    launch_ivf_merge_subset(scan_metric(m), fm, pl.fb_slots, stream);
+}
+
 /// The search proper: all pointers on the device, everything enqueued on `stream`.
 static void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
                                 uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
@@ -1022,7 +1342,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     const int m = ix.metric == MSVS_METRIC_L2 ? MSVS_METRIC_L2 : MSVS_METRIC_IP;
     if (ix.type == MSVS_INDEX_FLAT)
     {
-        if (table_pass_eligible(ix.n, ix.xnorm.p, ix.xnorm_max, nq, k, "MSVS_FLAT_MFMA"))
+        if (table_pass_eligible(ix.n, ix.xnorm.p, ix.xnorm_max, nq, k, options().flat_mfma))
         {
             // a batch against the whole table: matrix-core candidate pass + canonical re-rank (exact, certified)
             TablePass t{};
@@ -1047,7 +1367,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     }
     // 1. coarse quantiser: exact top-nprobe of the centroids (canonical arithmetic, so probes match the oracle)
     int32_t * d_probes = scr.take<int32_t>(nq * nprobe);
-    if (table_pass_eligible(ix.nlist, ix.cnorm.p, ix.cnorm_max, nq, (uint32_t)nprobe, "MSVS_COARSE_MFMA"))
+    if (table_pass_eligible(ix.nlist, ix.cnorm.p, ix.cnorm_max, nq, (uint32_t)nprobe, options().coarse_mfma))
     {
         TablePass t{};
         t.rows = ix.centroids.p;
@@ -1071,7 +1391,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");
     const IvfSearchPlan pl = plan_ivf(ix, nq, nprobe, k);
-    uint64_t * partial = scr.take<uint64_t>(pl.mfma() ? nq * big_cand_cap(nprobe, pl.seg_max)
+    uint64_t * partial = scr.take<uint64_t>(pl.mfma() ? nq * (pl.h16 ? (size_t)pl.h_cap : big_cand_cap(nprobe, pl.seg_max))
                                                       : nq * nprobe * (size_t)pl.seg_max * k);
     ScanParams a{};
     a.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
@@ -1089,6 +1409,11 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
     a.nprobe = (uint32_t)nprobe;
     a.seg_max = pl.seg_max;
     a.nlist = (uint32_t)ix.nlist;
+    if (pl.mfma() && pl.h16)
+    {
+        h16_list_scan(ix, scr, m, dq, nq, k, nprobe, pl, d_probes, d_alive, nbits, partial, d_ids, d_dis, stream);
+        return;
+    }
     if (pl.mfma())
     {
         // many queries per list: matrix-core candidate pass, canonical re-rank, certified (mfma_scan_kernels.hpp).
@@ -1126,8 +1451,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         a.Qsplit = qsplit;
         a.pairs = pp.pairs;
         a.pair_off = pp.pair_off;
-        const char * xo = getenv("MSVS_IVF_XCD");
-        a.xcd_order = xo ? (uint32_t)atoi(xo) : 1u;
+        a.xcd_order = (uint32_t)options().ivf_xcd;
         a.k = pl.kc;
         a.qnorm = qnorm;
         a.xnorm = ix.xnorm.p;
@@ -1246,8 +1570,7 @@ static void index_search_device(const msvs_index & ix, const float * d_queries /
         a.pairs = pp.pairs;
         a.pair_off = pp.pair_off;
         a.work_off = pp.work_off;
-        const char * xo = getenv("MSVS_IVF_XCD"); // experiment knob; default on
-        a.xcd_order = xo ? (uint32_t)atoi(xo) : 1u;
+        a.xcd_order = (uint32_t)options().ivf_xcd; // experiment knob; default on
         launch_ivf_batched_scan(scan_metric(m), pl.T, pl.grid, a, stream);
     }
     // 3. per-query top-k over the valid segments of its probed lists
@@ -1443,6 +1766,14 @@ extern "C" int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks)
             *queries = g_prefilter_queries.load();
         if (fallbacks)
             *fallbacks = f;
+    });
+}
+
+extern "C" int msvs_set_option(const char * name, const char * value)
+{
+    return guarded([&] {
+        if (!set_option(name, value))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "unknown option `%s`", name ? name : "(null)");
     });
 }
 

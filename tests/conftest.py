@@ -28,3 +28,19 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def opt():
+    """Experiment / test knobs of libmsvs (msvs_set_option); everything a test touched is restored afterwards."""
+    import myscaledb_amd.capi as capi
+
+    touched = set()
+
+    def set_(name, value):
+        touched.add(name)
+        capi.set_option(name, value)
+
+    yield set_
+    for name in touched:
+        capi.set_option(name, None)

@@ -190,7 +190,7 @@ def test_flat_index_filter_and_labels(metric, n, d, nq, k):
 
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
 @pytest.mark.parametrize("n,d,nq,k", [(40000, 96, 200, 10), (20000, 768, 48, 10), (33000, 100, 130, 40), (5000, 20, 17, 1)])
-def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, monkeypatch):
+def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, opt):
     """A batch against the whole table: matrix-core candidate pass + canonical re-rank, exact and certified; the
     answer (ids, distance bits) must be the canonical exhaustive one, with filters, labels and forced fallbacks."""
     rng = np.random.default_rng(n + d + nq)
@@ -200,7 +200,7 @@ def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, monk
     ix = capi.Index(capi.INDEX_FLAT, metric, d)
     ix.add(x, labels)
     ix.build()
-    monkeypatch.setenv("MSVS_FLAT_MFMA", "2")  # also for the shapes below the automatic threshold
+    opt("flat_mfma", "2")  # also for the shapes below the automatic threshold
     xs, qs, om = (o.normalize_rows(x), o.normalize_rows(q), o.METRIC_IP) if metric == capi.METRIC_COSINE else (x, q, OM[metric])
 
     def expect(alive=None):
@@ -214,22 +214,22 @@ def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, monk
     alive = rng.random(n * 2) < 0.4
     ids, dis = ix.search(q, k, alive=alive)
     same(ids, dis, *expect(alive))
-    monkeypatch.setenv("MSVS_IVF_EPS_SCALE", "1e12")  # no certificates: canonical fallback for every query
+    opt("ivf_eps_scale", "1e12")  # no certificates: canonical fallback for every query
     ids, dis = ix.search(q, k)
     same(ids, dis, *expect())
-    monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
-    monkeypatch.setenv("MSVS_IVF_NQG", "2")  # 256-query tiles
+    opt("ivf_eps_scale", None)
+    opt("ivf_nqg", "2")  # 256-query tiles
     ids, dis = ix.search(q, k)
     same(ids, dis, *expect())
-    monkeypatch.delenv("MSVS_IVF_NQG")
+    opt("ivf_nqg", None)
     # small candidate buffers = what a long table looks like: sample first, its m-th candidate cuts the rest
-    monkeypatch.setenv("MSVS_CAND_CAP", "1024")
+    opt("cand_cap", "1024")
     ids, dis = ix.search(q, k)
     same(ids, dis, *expect())
     ids, dis = ix.search(q, k, alive=alive)
     same(ids, dis, *expect(alive))
-    monkeypatch.delenv("MSVS_CAND_CAP")
-    monkeypatch.setenv("MSVS_FLAT_MFMA", "0")
+    opt("cand_cap", None)
+    opt("flat_mfma", "0")
     ids, dis = ix.search(q, k)
     same(ids, dis, *expect())
 
@@ -278,15 +278,18 @@ def test_ivfflat_matches_oracle_on_exported_structure(metric, n, d, nlist, nq, n
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
 @pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(40000, 768, 16, 200, 4, 10), (30000, 100, 8, 256, 8, 40),
                                                    (20000, 20, 8, 129, 3, 1), (3000, 64, 4, 100, 4, 12),
-                                                   (6000, 1536, 4, 64, 2, 10)])
-def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, nq, nprobe, k, monkeypatch):
-    """>= 16 queries per list: MFMA candidate pass + canonical re-rank + certificate (mfma_scan_kernels.hpp).  The
-    result must be the canonical one bit for bit, with and without certificates."""
+                                                   (6000, 1536, 4, 64, 2, 10), (50000, 200, 40, 700, 5, 10)])
+@pytest.mark.parametrize("h16", [1, 0])
+def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, nq, nprobe, k, h16, opt):
+    """>= 16 queries per list: MFMA candidate pass + canonical re-rank + certificate.  h16 = 1: over the fp16 shadow
+    (h16_scan_kernels.hpp, the default); h16 = 0: split bf16 over the f32 rows (mfma_scan_kernels.hpp).  The result
+    must be the canonical one bit for bit, with and without certificates."""
     rng = np.random.default_rng(n + d + nlist + 5)
     centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
     x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
     q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
     ix = build_ivf(x, metric, nlist)
+    opt("ivf_h16", str(h16))
     q0, f0 = capi.prefilter_stats()
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
@@ -299,34 +302,46 @@ def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, 
     assert q1 - q0 == 2 * nq  # the matrix-core pass is the one that ran
     assert f1 - f0 <= nq // 4  # and it certified (almost) every query
     # no certificate for anybody: every query takes the canonical fallback, same answer
-    monkeypatch.setenv("MSVS_IVF_EPS_SCALE", "1e12")
+    opt("ivf_eps_scale", "1e12")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
     q2, f2 = capi.prefilter_stats()
     assert f2 - f1 == nq
-    monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
-    # 256-query tiles (one 8-wavefront workgroup per CU; the default from ~96 queries per list on): same answer
-    monkeypatch.setenv("MSVS_IVF_NQG", "2")
-    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
-    same(ids, dis, oi, od)
-    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=alive)
-    same(ids, dis, oa, oda)
-    monkeypatch.delenv("MSVS_IVF_NQG")
+    opt("ivf_eps_scale", None)
+    if not h16:
+        # 256-query tiles (one 8-wavefront workgroup per CU): same answer
+        opt("ivf_nqg", "2")
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=alive)
+        same(ids, dis, oa, oda)
+        opt("ivf_nqg", None)
+    else:
+        # non-temporal row loads, every tile size that fits LDS: same answer
+        opt("h16_nt", "1")
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=alive)
+        same(ids, dis, oa, oda)
+        opt("h16_nt", None)
+        for ncb in (1, 2, 3, 4):
+            opt("h16_ncb", str(ncb))
+            ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+            same(ids, dis, oi, od)
+        opt("h16_ncb", None)
     # candidate buffers far too small: overflowing queries lose their certificate and take the fallback, same answer
-    monkeypatch.setenv("MSVS_CAND_CAP", "64")
+    opt("cand_cap", "64")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
-    monkeypatch.delenv("MSVS_CAND_CAP")
+    opt("cand_cap", None)
     q2 = capi.prefilter_stats()[0]
     # the pass switched off: the list-batched canonical scan, same answer
-    monkeypatch.setenv("MSVS_IVF_MFMA", "0")
+    opt("ivf_pass", "0")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
     assert capi.prefilter_stats()[0] == q2
 
 
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
-def test_coarse_quantiser_through_the_candidate_pass(metric, monkeypatch):
+def test_coarse_quantiser_through_the_candidate_pass(metric, opt):
     """nlist >= 256 and >= 512 queries: the top-nprobe centroids come from the matrix-core pass + canonical re-rank;
     the probe SETS must equal the exact scan's, hence so must the final answer (with and without certificates)."""
     rng = np.random.default_rng(2025)
@@ -336,7 +351,7 @@ def test_coarse_quantiser_through_the_candidate_pass(metric, monkeypatch):
     q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
     ix = build_ivf(x, metric, nlist)
     oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
-    monkeypatch.setenv("MSVS_COARSE_MFMA", "2")  # whenever eligible (by default only from ~128 tile x slice items on)
+    opt("coarse_mfma", "2")  # whenever eligible (by default only from ~128 tile x slice items on)
     capi.profile_reset()
     capi.profile_enable(True)
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
@@ -344,11 +359,11 @@ def test_coarse_quantiser_through_the_candidate_pass(metric, monkeypatch):
     assert capi.profile_get("coarse_pass")[0] == 1  # the pass is the one that ran
     capi.profile_reset()
     same(ids, dis, oi, od)
-    monkeypatch.setenv("MSVS_IVF_EPS_SCALE", "1e12")  # every certificate fails: canonical fallbacks everywhere
+    opt("ivf_eps_scale", "1e12")  # every certificate fails: canonical fallbacks everywhere
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
-    monkeypatch.delenv("MSVS_IVF_EPS_SCALE")
-    monkeypatch.setenv("MSVS_COARSE_MFMA", "0")
+    opt("ivf_eps_scale", None)
+    opt("coarse_mfma", "0")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
 
@@ -557,7 +572,7 @@ def test_bm25_many_doc_blocks_two_level_merge():
 
 # ---------------------------------------------------------------------------------------- BASELINE-size properties
 
-def test_full_size_1m_x_768_properties():
+def test_full_size_1m_x_768_properties(opt):
     """BASELINE config 2 shape (1M x 768, nlist 1024, nprobe 32, top-10): the oracle cannot redo all of it in
     seconds, so check size-independent properties + a handful of oracle-verified queries."""
     import torch
@@ -608,11 +623,17 @@ def test_full_size_1m_x_768_properties():
     q1, f1 = capi.prefilter_stats()
     assert q1 - q0 == 2048 and f1 - f0 <= 64
     pick = np.arange(0, 2048, 64)
+    opt("ivf_pass", "0")
     si, sd = ix.search(big[pick[:16]], k, "nprobe=%d" % nprobe)
     same(bi[pick[:16]], bd[pick[:16]], si, sd)
     si, sd = ix.search(big[pick[16:]], k, "nprobe=%d" % nprobe)
     same(bi[pick[16:]], bd[pick[16:]], si, sd)
     assert capi.prefilter_stats()[0] == q1  # those really were canonical runs
+    opt("ivf_pass", None)
+    # small batches take the shadow pass too (from a quarter of a pair per list on): same answer
+    si, sd = ix.search(big[pick[:16]], k, "nprobe=%d" % nprobe)
+    same(bi[pick[:16]], bd[pick[:16]], si, sd)
+    assert capi.prefilter_stats()[0] == q1 + 16
     oi, od, _ = o.ivf_search(cent, off, vecs, lids, big[pick[:4]], nprobe, k, o.METRIC_L2, threads=8)
     same(bi[pick[:4]], bd[pick[:4]], oi, od)
     # (7) the exact FLAT scan of a batch (two-phase table pass) == the canonical exhaustive scan
