@@ -130,8 +130,34 @@ MSVS_API int msvs_index_search_device(const msvs_index_t * index, const float * 
  * Cosine indexes export the stored (normalised) rows. */
 MSVS_API int msvs_index_export(const msvs_index_t * index, float * centroids, int64_t * list_off, float * vecs,
                                int64_t * ids);
-MSVS_API int msvs_index_serialize(const msvs_index_t * index, const char * path);
-MSVS_API int msvs_index_load(const char * path, msvs_index_t ** out);
+
+/* Serialisation through caller-supplied streams -- the form the reference's library uses: Search::VectorIndex::serialize
+ * (IndexDataFileWriter<OS>*) / saveDataID / load(IndexDataFileReader<IS>*) / loadDataID open every file of the index
+ * through the host's opener, a VectorIndexWriter / VectorIndexReader over IDisk (local disk or S3 alike):
+ * src/VectorIndex/Common/VectorIndexIO.h:25-166, VIWithDataPart.cpp:461-473 and :688-700.
+ * The index is a set of NAMED files ("data_bin": header, centroids, list offsets, rows; "id_list": the row ids); the
+ * host shim maps NAME to <index_name>-NAME.vidx3 inside the part directory (VICommon.h:55, SegmentId).
+ *   open(ctx, name, write) -> stream handle or NULL;  write / read -> bytes moved (a short count is an error / EOF);
+ *   close -> 0 on success.  All four are called from the thread that called serialize / load.
+ * load validates everything it reads (MSVS_ERR_IO on a corrupt or truncated file; nothing is searched before). */
+typedef struct msvs_io
+{
+    void * ctx;
+    void * (*open)(void * ctx, const char * name, int write);
+    int64_t (*write)(void * ctx, void * stream, const void * buf, size_t n);
+    int64_t (*read)(void * ctx, void * stream, void * buf, size_t n);
+    int (*close)(void * ctx, void * stream);
+} msvs_io_t;
+MSVS_API int msvs_index_serialize_io(const msvs_index_t * index, const msvs_io_t * io);
+MSVS_API int msvs_index_load_io(const msvs_io_t * io, msvs_index_t ** out);
+/* Convenience over stdio: the file set <path_prefix>-data_bin.vidx3 and <path_prefix>-id_list.vidx3. */
+MSVS_API int msvs_index_serialize(const msvs_index_t * index, const char * path_prefix);
+MSVS_API int msvs_index_load(const char * path_prefix, msvs_index_t ** out);
+/* getVersion().toString() and getResourceUsage() of the reference's index object (VIWithDataPart.cpp:368-385,
+ * :485-488): the host records them in <index>-vector_index_description.vidx3 (VIMetadata.cpp:115-187). */
+MSVS_API const char * msvs_index_version(void);
+MSVS_API int msvs_index_resource_usage(const msvs_index_t * index, size_t * memory_usage_bytes,
+                                       size_t * disk_usage_bytes, size_t * build_memory_usage_bytes);
 
 /* Measurement support (bench.py): rows the list scan of msvs_index_search(queries, nprobe) has to look at.
  *   *rows          = sum over (query, probed list) of the list length (the per-query model of SURVEY.md 8d);

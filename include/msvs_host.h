@@ -68,6 +68,15 @@ MSVS_HOST_API size_t msvs_host_hybrid_search(int fusion_type, const float * vec_
 MSVS_HOST_API int msvs_host_merge_topk(const int64_t * ids, const float * dis, size_t nparts, size_t nq, size_t k,
                                        int metric, int64_t * out_ids, float * out_dis);
 
+/* MergeTreeVSManager::generateVectorDataset + getQueryVector / getFloatQueryVectorInBatch
+ * (MergeTreeVSManager.cpp:59-181): the query column of distance() / batch_distance() -- Array(Float32 | Float64) or
+ * Array(Array(...)) -- flattened to nq x dim f32 row-major (Float64 by static_cast<float>, i.e. round to nearest).
+ * values: the inner column's data (float or double, is_float64), offsets: the outer ColumnArray offsets (end of query q
+ * in `values`), NULL for a single query of `dim` values.  A query whose length is not `dim` is the reference's
+ * LOGICAL_ERROR "Dimension is not equal" / "wrong dimension": returns MSVS_ERR_INVALID_ARGUMENT (msvs_last_error()). */
+MSVS_HOST_API int msvs_host_generate_vector_dataset(const void * values, int is_float64, const uint64_t * offsets,
+                                                    size_t nq, size_t dim, float * out);
+
 /* BM25InfoInDataParts-style statistics reduction (src/VectorIndex/Common/BM25InfoInDataParts.cpp:40-93):
  * element-wise sums of per-part (total_docs, total_tokens, df[n_terms]) vectors laid out [nparts][2 + n_terms]. */
 MSVS_HOST_API void msvs_host_sum_bm25_stats(const uint64_t * per_part, size_t nparts, size_t n_terms, uint64_t * out);

@@ -27,7 +27,8 @@ SYMBOLS = [
     "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
     "msvs_postings_create", "msvs_postings_free", "msvs_bm25_search", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
-    "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option",
+    "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option", "msvs_index_serialize_io",
+    "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage",
 ]
 
 
@@ -164,6 +165,56 @@ def merge_topk(ids, dis, metric):
     return oi, od
 
 
+class _MsvsIO(C.Structure):
+    _fields_ = [("ctx", C.c_void_p),
+                ("open", C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_char_p, C.c_int)),
+                ("write", C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("read", C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("close", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p))]
+
+
+class _DictIO:
+    """msvs_io_t over a dict NAME -> bytearray: stands in for the host's IDisk-backed streams in tests."""
+
+    def __init__(self, store):
+        self.store, self.streams, self.next = store, {}, 1
+
+        def op(_ctx, name, write):
+            name = name.decode()
+            if write:
+                self.store[name] = bytearray()
+            elif name not in self.store:
+                return None
+            h = self.next
+            self.next += 1
+            self.streams[h] = [name, 0]
+            return h
+
+        def wr(_ctx, h, buf, n):
+            self.store[self.streams[h][0]] += C.string_at(buf, n)
+            return n
+
+        def rd(_ctx, h, buf, n):
+            name, pos = self.streams[h]
+            data = self.store[name][pos:pos + n]
+            C.memmove(buf, bytes(data), len(data))
+            self.streams[h][1] = pos + len(data)
+            return len(data)
+
+        def cl(_ctx, h):
+            self.streams.pop(h, None)
+            return 0
+
+        t = _MsvsIO
+        self._keep = (t._fields_[1][1](op), t._fields_[2][1](wr), t._fields_[3][1](rd), t._fields_[4][1](cl))
+        self.io = _MsvsIO(None, *self._keep)
+
+
+def index_version():
+    lib().msvs_index_version.restype = C.c_char_p
+    return lib().msvs_index_version().decode()
+
+
 class Index:
     """msvs_index_t (seam A1)."""
 
@@ -269,14 +320,31 @@ class Index:
                                        _p(ids, C.c_int64)))
         return cent, off, vecs, ids
 
-    def serialize(self, path):
-        _check(lib().msvs_index_serialize(self._h, path.encode()))
+    def serialize(self, path_prefix):
+        """-> files <path_prefix>-data_bin.vidx3, <path_prefix>-id_list.vidx3 (stdio convenience)."""
+        _check(lib().msvs_index_serialize(self._h, path_prefix.encode()))
 
     @classmethod
-    def load(cls, path, index_type, metric, dim):
+    def load(cls, path_prefix, index_type, metric, dim):
         h = C.c_void_p()
-        _check(lib().msvs_index_load(path.encode(), C.byref(h)))
+        _check(lib().msvs_index_load(path_prefix.encode(), C.byref(h)))
         return cls(index_type, metric, dim, _handle=h)
+
+    def serialize_io(self, store):
+        """msvs_index_serialize_io through stream callbacks; `store` = dict NAME -> bytearray (filled in)."""
+        _check(lib().msvs_index_serialize_io(self._h, C.byref(_DictIO(store).io)))
+
+    @classmethod
+    def load_io(cls, store, index_type, metric, dim):
+        h = C.c_void_p()
+        _check(lib().msvs_index_load_io(C.byref(_DictIO(store).io), C.byref(h)))
+        return cls(index_type, metric, dim, _handle=h)
+
+    def resource_usage(self):
+        """-> (memory_usage_bytes, disk_usage_bytes, build_memory_usage_bytes)"""
+        m, dk, b = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        _check(lib().msvs_index_resource_usage(self._h, C.byref(m), C.byref(dk), C.byref(b)))
+        return m.value, dk.value, b.value
 
 
 class Postings:

@@ -108,10 +108,14 @@ void profile_reset()
     g_samples.clear();
 }
 
-FlatPlan plan_flat(size_t n_rows, size_t nq)
+FlatPlan plan_flat(size_t n_rows, size_t nq, uint32_t ld4, uint32_t k)
 {
     FlatPlan p;
     p.T = nq <= 1 ? 1 : (nq <= 2 ? 2 : (nq <= 4 ? 4 : 8));
+    // the query tile and the block's merge lists live in LDS: halve the tile until they fit the default dynamic LDS
+    // (64 KiB; one query of 8192 dimensions with k = 256 takes 42 KiB)
+    while (p.T > 1 && scan_lds_bytes(p.T, ld4, k) > SCAN_LDS_BUDGET)
+        p.T /= 2;
     p.n_qtiles = (uint32_t)ceil_div(nq ? nq : 1, p.T);
     // enough blocks to fill 256 CUs a few times over, but at least 16 rows (one block iteration) each
     size_t want = 2048 / p.n_qtiles;

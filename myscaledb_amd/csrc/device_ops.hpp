@@ -54,7 +54,8 @@ struct FlatPlan
     uint32_t T, n_qtiles, rows_per_block, n_blocks;
 };
 
-FlatPlan plan_flat(size_t n_rows, size_t nq);
+/// ld4 / k: the tile shrinks until its LDS image (scan_lds_bytes) fits SCAN_LDS_BUDGET.
+FlatPlan plan_flat(size_t n_rows, size_t nq, uint32_t ld4, uint32_t k);
 
 /// bytes of partial keys a flat scan writes
 inline size_t flat_partial_keys(const FlatPlan & p, size_t nq, uint32_t k) { return nq * (size_t)p.n_blocks * k; }

@@ -53,9 +53,9 @@ static void check_k(size_t k)
 
 /// Exhaustive top-k of device queries (nq x ld) against device rows (n x ld) -> device ids/dis.
 /// `scr` must have been reserved by the caller for flat_scratch_bytes().
-static size_t flat_scratch_bytes(size_t n, size_t nq, uint32_t k)
+static size_t flat_scratch_bytes(size_t n, size_t nq, uint32_t k, uint32_t ld)
 {
-    FlatPlan p = plan_flat(n, nq);
+    FlatPlan p = plan_flat(n, nq, ld / 4, k);
     return flat_partial_keys(p, nq, k) * 8 + 1024;
 }
 
@@ -63,7 +63,7 @@ static void flat_search_device(Scratch & scr, int metric, const float * d_rows, 
                                uint32_t ld, const float * d_q, size_t nq, uint32_t k, const uint64_t * d_alive,
                                size_t nbits, MergeParams out, hipStream_t stream)
 {
-    FlatPlan p = plan_flat(n, nq);
+    FlatPlan p = plan_flat(n, nq, ld / 4, k);
     uint64_t * partial = scr.take<uint64_t>(flat_partial_keys(p, nq, k));
     ScanParams a{};
     a.Y = reinterpret_cast<const float4 *>(d_rows);
@@ -136,7 +136,7 @@ static void knn_host(const float * x, const float * y, size_t d, size_t k, size_
     const bool rounds = k > MSVS_MAX_K;
     Scratch & scr = scratch_for(stream);
     size_t need = (nx + ny) * (size_t)ld * 4 + nx * k * 12 + bw * 8
-        + flat_scratch_bytes(ny, rounds ? 1 : nx, kpass) + 16384;
+        + flat_scratch_bytes(ny, rounds ? 1 : nx, kpass, ld) + 16384;
     scr.reserve(need, stream);
     float * dq = scr.take<float>(nx * ld);
     float * dy = scr.take<float>(std::max<size_t>(ny, 1) * ld);
@@ -811,9 +811,11 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 p.grid = (uint32_t)options().ivf_grid;
             // the candidate lists are per 128-row SLICE (<= 16 keys each), whatever the work-item size
             p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, (size_t)BG_ROWS));
-            size_t rpb1 = round_up(std::max<size_t>(64, nprobe * avg * 3 / 2 / 400), 16);
-            p.rpb1 = (uint32_t)std::min<size_t>(rpb1, 256);
-            p.seg_max1 = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, p.rpb1));
+            // the canonical fallback (normally no query at all) scans a probed list with ONE block: its partial lists are
+            // nq * nprobe * k keys whatever the longest list is (segments of 256 rows made that 84 x larger on a skewed
+            // index, for a buffer that is reserved on every search)
+            p.rpb1 = (uint32_t)round_up(std::max<size_t>(ix.max_list_len, 16), 16);
+            p.seg_max1 = 1;
             p.fb_slots = (uint32_t)std::min<size_t>(nq, 8);
             return p;
         }
@@ -822,6 +824,8 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     // (measured on MI355X, 1M x 768, nlist 1024, nprobe 32: T=4 beats T=8 up to ~8 pairs per list because its 128
     // VGPRs allow 4 waves/SIMD against 2; see profiles/r01_ivf_tuning_sweep.txt)
     p.T = pairs >= 16 * nlist ? 8 : (pairs >= 2 * nlist ? 4 : (pairs >= nlist ? 2 : 1));
+    while (p.T > 1 && scan_lds_bytes(p.T, ix.ld / 4, k) > SCAN_LDS_BUDGET) // see plan_flat
+        p.T /= 2;
     const size_t tiles = std::max<size_t>(1, pairs / p.T);
     if (p.T == 1)
     {
@@ -867,9 +871,9 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
 {
     size_t b = nq * (size_t)ix.ld * 4 + 2 * (nq * (size_t)(ix.ld + 32) * 4 + 4096) + 4096; // queries (+ split copies)
     if (ix.type == MSVS_INDEX_FLAT)
-        return b + flat_scratch_bytes(ix.n, nq, k) + table_pass_scratch(ix.n, nq, std::min<uint32_t>(k, 40));
+        return b + flat_scratch_bytes(ix.n, nq, k, ix.ld) + table_pass_scratch(ix.n, nq, std::min<uint32_t>(k, 40));
     IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k);
-    size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe)
+    size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe, ix.ld)
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
         + nq * nprobe * 4
         + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
@@ -1305,10 +1309,32 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     launch_ivf_merge_subset(scan_metric(m), fm, pl.fb_slots, stream);
 }
 
-/// The search proper: all pointers on the device, everything enqueued on `stream`.
+static void index_search_device_one(const msvs_index & ix, const float * d_queries, size_t nq, uint32_t k, size_t nprobe,
+                                    const uint64_t * d_alive, size_t nbits, int64_t * d_ids, float * d_dis,
+                                    hipStream_t stream);
+
+/// The search proper: all pointers on the device, everything enqueued on `stream`.  Very large batches are cut into
+/// sub-batches of at most 2^21 (query, probe) pairs, stream-ordered one after the other: every scratch buffer of a search
+/// is proportional to the pairs of ONE sub-batch, so the per-(thread, stream) arena stays bounded (~0.5 GB) whatever nq.
 static void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
                                 uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
                                 float * d_dis, hipStream_t stream)
+{
+    const size_t per_q = ix.type == MSVS_INDEX_IVFFLAT ? std::max<size_t>(1, std::min(nprobe, std::max<size_t>(ix.nlist, 1))) : 1;
+    const size_t sub = std::max<size_t>(256, ((size_t)1 << 21) / per_q);
+    if (nq <= sub)
+        return index_search_device_one(ix, d_queries, nq, k, nprobe, d_alive, nbits, d_ids, d_dis, stream);
+    for (size_t q0 = 0; q0 < nq; q0 += sub)
+    {
+        const size_t m = std::min(sub, nq - q0);
+        index_search_device_one(ix, d_queries + q0 * ix.dim, m, k, nprobe, d_alive, nbits, d_ids + q0 * k, d_dis + q0 * k,
+                                stream);
+    }
+}
+
+static void index_search_device_one(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
+                                    uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
+                                    float * d_dis, hipStream_t stream)
 {
     if (!ix.ready)
         fail(MSVS_ERR_NOT_READY, "index is not ready");
@@ -1622,7 +1648,10 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         if (nprobe < 1)
             fail(MSVS_ERR_INVALID_ARGUMENT, "nprobe must be >= 1");
         hipStream_t stream = nullptr;
-        const size_t words = alive_bits ? ceil_div(nbits, 64) : 0;
+        // a filter that is PRESENT with zero valid bits means "no row passes" (not "no filter"): it still travels as one
+        // zero word with nbits = 0, and every id fails the `id < nbits` test
+        const bool filtered = alive_bits != nullptr;
+        const size_t words = filtered ? std::max<size_t>(1, ceil_div(nbits, 64)) : 0;
         // host staging lives in its own arena (scratch_for() belongs to the device-level search underneath)
         Scratch & stg = staging_for(stream);
         stg.reserve(nq * ix->dim * 4 + nq * (size_t)k * 12 + words * 8 + 4096, stream);
@@ -1631,8 +1660,12 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         const DevView<float> d_dis{stg.take<float>(nq * (size_t)k)};
         const DevView<uint64_t> d_alive{words ? stg.take<uint64_t>(words) : nullptr};
         MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
-        if (words)
-            MSVS_HIP(hipMemcpyAsync(d_alive.p, alive_bits, words * 8, hipMemcpyHostToDevice, stream));
+        if (filtered)
+        {
+            MSVS_HIP(hipMemsetAsync(d_alive.p, 0, words * 8, stream));
+            if (nbits)
+                MSVS_HIP(hipMemcpyAsync(d_alive.p, alive_bits, ceil_div(nbits, 64) * 8, hipMemcpyHostToDevice, stream));
+        }
         if ((size_t)k <= MSVS_MAX_K)
             index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, words ? d_alive.p : nullptr, nbits,
                                 d_ids.p, d_dis.p, stream);
@@ -1640,12 +1673,12 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         {
             // k beyond one wavefront top-k pass: rounds of MSVS_MAX_K per query, each round excluding the rows already
             // returned through a private copy of the filter bitmap (exact: round r returns ranks 256r .. 256r+255)
-            const size_t idspace = std::max<size_t>(words ? nbits : 0, (size_t)ix->max_id + 1);
+            const size_t idspace = std::max<size_t>(filtered ? nbits : 0, (size_t)ix->max_id + 1);
             const size_t bw = ceil_div(idspace, 64);
             DevBuf<uint64_t> bm(bw);
             for (size_t q = 0; q < nq; q++)
             {
-                if (words)
+                if (filtered)
                 {
                     MSVS_HIP(hipMemsetAsync(bm.p, 0, bw * 8, stream));
                     MSVS_HIP(hipMemcpyAsync(bm.p, d_alive.p, words * 8, hipMemcpyDeviceToDevice, stream));
@@ -1656,7 +1689,7 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
                 {
                     const uint32_t kr = (uint32_t)std::min<size_t>(MSVS_MAX_K, (size_t)k - done);
                     int64_t * oi = d_ids.p + q * (size_t)k + done;
-                    index_search_device(*ix, dq.p + q * ix->dim, 1, kr, (size_t)nprobe, bm.p, words ? nbits : idspace,
+                    index_search_device(*ix, dq.p + q * ix->dim, 1, kr, (size_t)nprobe, bm.p, filtered ? nbits : idspace,
                                         oi, d_dis.p + q * (size_t)k + done, stream);
                     hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(256), 0, stream, bm.p, oi, kr);
                     MSVS_HIP(hipGetLastError());
@@ -1688,7 +1721,7 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
         {
             *rows = (uint64_t)nq * ix->n;
             if (rows_streamed)
-                *rows_streamed = (uint64_t)plan_flat(ix->n, nq).n_qtiles * ix->n;
+                *rows_streamed = (uint64_t)plan_flat(ix->n, nq, ix->ld / 4, 10).n_qtiles * ix->n;
             if (rows_unique)
                 *rows_unique = ix->n;
             return;
@@ -1703,7 +1736,7 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
         if (ix->metric == MSVS_METRIC_COSINE)
             normalize_device_rows(dq.p, nq, d, ld, stream);
         Scratch & scr = scratch_for(stream);
-        scr.reserve(flat_scratch_bytes(ix->nlist, nq, (uint32_t)np) + 4096, stream);
+        scr.reserve(flat_scratch_bytes(ix->nlist, nq, (uint32_t)np, ix->ld) + 4096, stream);
         MergeParams co{};
         co.mode = 1;
         co.out_probes = d_probes.p;
@@ -1807,109 +1840,278 @@ extern "C" int msvs_index_export(const msvs_index_t * ix, float * centroids, int
 
 // ------------------------------------------------------------------------------------------- serialisation
 
+// The index is a set of NAMED files written / read through caller-supplied stream callbacks (msvs_io_t), which is how
+// the reference's library does it: Search::IndexDataFileWriter<OS>(path_prefix, opener) opens every file of the set through
+// the host's opener -- a VectorIndexWriter over IDisk::writeFile, local disk or S3 alike (VectorIndexIO.h:25-166,
+// VIWithDataPart.cpp:461-473, :688-700).  Files (the shim turns NAME into <index_name>-NAME.vidx3):
+//   data_bin : DataHeader, centroids [nlist][dim] f32 (IVFFLAT), list offsets [nlist + 1] i64, rows [n][dim] f32
+//              list-major (cosine: normalised)              -- serialize() / load()
+//   id_list  : u64 n, ids [n] i64 in storage order          -- saveDataID() / loadDataID()
+// The fp16 shadow and the norms are derived data and are rebuilt at load.
+
 namespace
 {
-struct FileHeader
+struct DataHeader
 {
-    char magic[8]; // "MSVSIDX1"
+    char magic[8]; // "MSVSIDX2"
+    uint32_t version;
     int32_t type, metric;
+    uint32_t shard_rank, shard_world;
+    uint32_t reserved;
     uint64_t dim, nlist, n;
-    int32_t shard_rank, shard_world;
 };
+constexpr uint32_t DATA_VERSION = 2;
+constexpr size_t IO_CHUNK = (size_t)64 << 20;
+
+struct IoStream
+{
+    const msvs_io_t * io;
+    void * h;
+    const char * name;
+    IoStream(const msvs_io_t * io_, const char * name_, int write) : io(io_), h(nullptr), name(name_)
+    {
+        if (!io || !io->open || !io->close || (write ? !io->write : !io->read))
+            msvs::fail(MSVS_ERR_INVALID_ARGUMENT, "msvs_io_t lacks a callback");
+        h = io->open(io->ctx, name, write);
+        if (!h)
+            msvs::fail(MSVS_ERR_IO, "cannot open index file `%s` for %s", name, write ? "writing" : "reading");
+    }
+    ~IoStream()
+    {
+        if (h)
+            (void)io->close(io->ctx, h);
+    }
+    void write(const void * p, size_t n)
+    {
+        const char * c = static_cast<const char *>(p);
+        while (n)
+        {
+            const size_t m = std::min(n, IO_CHUNK);
+            if (io->write(io->ctx, h, c, m) != (int64_t)m)
+                msvs::fail(MSVS_ERR_IO, "short write to index file `%s`", name);
+            c += m;
+            n -= m;
+        }
+    }
+    void read(void * p, size_t n)
+    {
+        char * c = static_cast<char *>(p);
+        while (n)
+        {
+            const int64_t got = io->read(io->ctx, h, c, std::min(n, IO_CHUNK));
+            if (got <= 0)
+                msvs::fail(MSVS_ERR_IO, "index file `%s` is truncated", name);
+            c += got;
+            n -= (size_t)got;
+        }
+    }
+    void finish()
+    {
+        void * t = h;
+        h = nullptr;
+        if (io->close(io->ctx, t) != 0)
+            msvs::fail(MSVS_ERR_IO, "closing index file `%s` failed", name);
+    }
+};
+
+/// stdio implementation behind the path convenience calls: file NAME of the set is <prefix>-NAME.vidx3
+struct StdioCtx
+{
+    std::string prefix;
+};
+void * stdio_open(void * ctx, const char * name, int write)
+{
+    const std::string path = static_cast<StdioCtx *>(ctx)->prefix + "-" + name + ".vidx3";
+    return fopen(path.c_str(), write ? "wb" : "rb");
+}
+int64_t stdio_write(void *, void * s, const void * p, size_t n) { return (int64_t)fwrite(p, 1, n, static_cast<FILE *>(s)); }
+int64_t stdio_read(void *, void * s, void * p, size_t n) { return (int64_t)fread(p, 1, n, static_cast<FILE *>(s)); }
+int stdio_close(void *, void * s) { return fclose(static_cast<FILE *>(s)); }
+msvs_io_t stdio_io(StdioCtx * c) { return msvs_io_t{c, stdio_open, stdio_write, stdio_read, stdio_close}; }
 }
 
-extern "C" int msvs_index_serialize(const msvs_index_t * ix, const char * path)
+extern "C" int msvs_index_serialize_io(const msvs_index_t * ix, const msvs_io_t * io)
 {
     return guarded([&] {
-        if (!ix || !ix->ready || !path)
+        if (!ix || !ix->ready)
             fail(MSVS_ERR_NOT_READY, "index is not ready");
-        const size_t nlist = msvs_index_num_lists(ix);
-        std::vector<float> cent(ix->type == MSVS_INDEX_IVFFLAT ? nlist * ix->dim : 0), vecs(ix->n * ix->dim);
-        std::vector<int64_t> off(nlist + 1), ids(ix->n);
-        int rc = msvs_index_export(ix, cent.empty() ? nullptr : cent.data(), off.data(), vecs.data(), ids.data());
-        if (rc)
-            fail(rc, "%s", msvs_last_error());
-        FILE * f = fopen(path, "wb");
-        if (!f)
-            fail(MSVS_ERR_IO, "cannot open %s for writing", path);
-        FileHeader h{};
-        memcpy(h.magic, "MSVSIDX1", 8);
-        h.type = ix->type;
-        h.metric = ix->metric;
-        h.dim = ix->dim;
-        h.nlist = nlist;
-        h.n = ix->n;
-        h.shard_rank = ix->shard_rank;
-        h.shard_world = ix->shard_world;
-        bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
-        ok = ok && (cent.empty() || fwrite(cent.data(), 4, cent.size(), f) == cent.size());
-        ok = ok && fwrite(off.data(), 8, off.size(), f) == off.size();
-        ok = ok && (vecs.empty() || fwrite(vecs.data(), 4, vecs.size(), f) == vecs.size());
-        ok = ok && (ids.empty() || fwrite(ids.data(), 8, ids.size(), f) == ids.size());
-        ok = (fclose(f) == 0) && ok;
-        if (!ok)
-            fail(MSVS_ERR_IO, "short write to %s", path);
+        const size_t nlist = msvs_index_num_lists(ix), d = ix->dim, ld = ix->ld;
+        {
+            IoStream f(io, "data_bin", 1);
+            DataHeader h{};
+            memcpy(h.magic, "MSVSIDX2", 8);
+            h.version = DATA_VERSION;
+            h.type = ix->type;
+            h.metric = ix->metric;
+            h.shard_rank = (uint32_t)ix->shard_rank;
+            h.shard_world = (uint32_t)ix->shard_world;
+            h.dim = d;
+            h.nlist = nlist;
+            h.n = ix->n;
+            f.write(&h, sizeof(h));
+            if (ix->type == MSVS_INDEX_IVFFLAT)
+            {
+                std::vector<float> cent(nlist * d);
+                MSVS_HIP(hipMemcpy2D(cent.data(), d * 4, ix->centroids.p, ld * 4, d * 4, nlist, hipMemcpyDeviceToHost));
+                f.write(cent.data(), cent.size() * 4);
+            }
+            f.write(ix->h_list_off.data(), (nlist + 1) * 8);
+            // rows in chunks: a 77 GB shard never sits in host memory at once
+            const size_t rows_per = std::max<size_t>(1, IO_CHUNK / (d * 4));
+            std::vector<float> buf(std::min(rows_per, std::max<size_t>(ix->n, 1)) * d);
+            for (size_t r0 = 0; r0 < ix->n; r0 += rows_per)
+            {
+                const size_t m = std::min(rows_per, ix->n - r0);
+                MSVS_HIP(hipMemcpy2D(buf.data(), d * 4, ix->vecs.p + r0 * ld, ld * 4, d * 4, m, hipMemcpyDeviceToHost));
+                f.write(buf.data(), m * d * 4);
+            }
+            f.finish();
+        }
+        {
+            IoStream f(io, "id_list", 1);
+            const uint64_t n = ix->n;
+            f.write(&n, 8);
+            std::vector<uint32_t> h32(ix->n);
+            if (ix->n)
+                MSVS_HIP(hipMemcpy(h32.data(), ix->row_ids.p, ix->n * 4, hipMemcpyDeviceToHost));
+            std::vector<int64_t> ids(h32.begin(), h32.end());
+            f.write(ids.data(), ids.size() * 8);
+            f.finish();
+        }
     });
 }
 
-extern "C" int msvs_index_load(const char * path, msvs_index_t ** out)
+extern "C" int msvs_index_load_io(const msvs_io_t * io, msvs_index_t ** out)
 {
     return guarded([&] {
-        if (!path || !out)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null path/out");
+        if (!out)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "out is null");
         *out = nullptr;
-        FILE * f = fopen(path, "rb");
-        if (!f)
-            fail(MSVS_ERR_IO, "cannot open %s", path);
-        std::unique_ptr<FILE, int (*)(FILE *)> guard(f, fclose);
-        FileHeader h{};
-        if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "MSVSIDX1", 8) != 0)
-            fail(MSVS_ERR_IO, "%s is not an msvs index file", path);
         std::unique_ptr<msvs_index> ix(new msvs_index);
-        ix->type = h.type;
-        ix->metric = h.metric;
-        ix->dim = h.dim;
-        ix->ld = padded_dim(h.dim);
-        ix->shard_rank = h.shard_rank;
-        ix->shard_world = h.shard_world;
         MSVS_HIP(hipGetDevice(&ix->device));
-        const size_t nlist = h.nlist, n = h.n, d = h.dim;
-        std::vector<float> cent(ix->type == MSVS_INDEX_IVFFLAT ? nlist * d : 0), vecs(n * d);
-        std::vector<int64_t> off(nlist + 1), ids(n);
-        bool ok = cent.empty() || fread(cent.data(), 4, cent.size(), f) == cent.size();
-        ok = ok && fread(off.data(), 8, off.size(), f) == off.size();
-        ok = ok && (vecs.empty() || fread(vecs.data(), 4, vecs.size(), f) == vecs.size());
-        ok = ok && (ids.empty() || fread(ids.data(), 8, ids.size(), f) == ids.size());
-        if (!ok)
-            fail(MSVS_ERR_IO, "%s is truncated", path);
-        if (ix->type == MSVS_INDEX_IVFFLAT)
+        size_t nlist = 0, n = 0, d = 0;
         {
-            ix->nlist = nlist;
-            ix->centroids.alloc(nlist * ix->ld);
-            upload_rows(ix->centroids.p, cent.data(), nlist, (uint32_t)d, ix->ld, MSVS_MEM_HOST, nullptr);
+            IoStream f(io, "data_bin", 0);
+            DataHeader h{};
+            f.read(&h, sizeof(h));
+            // nothing of the file is trusted: a corrupt header must not turn into out-of-bounds device reads or TB allocations
+            if (memcmp(h.magic, "MSVSIDX2", 8) != 0 || h.version != DATA_VERSION)
+                fail(MSVS_ERR_IO, "not an msvs index (data_bin: bad magic / version)");
+            if ((h.type != MSVS_INDEX_FLAT && h.type != MSVS_INDEX_IVFFLAT)
+                || (h.metric != MSVS_METRIC_L2 && h.metric != MSVS_METRIC_IP && h.metric != MSVS_METRIC_COSINE)
+                || h.dim == 0 || h.dim > 8192 || h.nlist == 0 || h.nlist > 0x7fffffffull || h.n > 0xfffffff0ull
+                || (h.type == MSVS_INDEX_FLAT && h.nlist != 1) || h.shard_world == 0 || h.shard_rank >= h.shard_world)
+                fail(MSVS_ERR_IO, "corrupt msvs index header");
+            ix->type = h.type;
+            ix->metric = h.metric;
+            ix->dim = d = h.dim;
+            ix->ld = padded_dim(d);
+            ix->shard_rank = (int)h.shard_rank;
+            ix->shard_world = (int)h.shard_world;
+            nlist = h.nlist;
+            n = h.n;
+            const uint32_t ld = ix->ld;
+            if (ix->type == MSVS_INDEX_IVFFLAT)
+            {
+                std::vector<float> cent(nlist * d);
+                f.read(cent.data(), cent.size() * 4);
+                ix->nlist = nlist;
+                ix->centroids.alloc(nlist * ld);
+                upload_rows(ix->centroids.p, cent.data(), nlist, (uint32_t)d, ld, MSVS_MEM_HOST, nullptr);
+                MSVS_HIP(hipStreamSynchronize(nullptr));
+            }
+            std::vector<int64_t> off(nlist + 1);
+            f.read(off.data(), off.size() * 8);
+            bool ok = off[0] == 0 && off[nlist] == (int64_t)n;
+            for (size_t l = 0; ok && l < nlist; l++)
+                ok = off[l + 1] >= off[l];
+            if (!ok)
+                fail(MSVS_ERR_IO, "corrupt msvs index: list offsets are not a partition of the rows");
+            ix->n = n;
+            ix->h_list_off = off;
+            ix->max_list_len = 0;
+            for (size_t l = 0; l < nlist; l++)
+                ix->max_list_len = std::max<size_t>(ix->max_list_len, (size_t)(off[l + 1] - off[l]));
+            ix->vecs.alloc(std::max<size_t>(n, 1) * ld);
+            ix->list_off.alloc(nlist + 1);
+            MSVS_HIP(hipMemcpy(ix->list_off.p, off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
+            const size_t rows_per = std::max<size_t>(1, IO_CHUNK / (d * 4));
+            std::vector<float> buf(std::min(rows_per, std::max<size_t>(n, 1)) * d);
+            for (size_t r0 = 0; r0 < n; r0 += rows_per)
+            {
+                const size_t m = std::min(rows_per, n - r0);
+                f.read(buf.data(), m * d * 4); // a short file fails here, before anything is searched
+                upload_rows(ix->vecs.p + r0 * ld, buf.data(), m, (uint32_t)d, ld, MSVS_MEM_HOST, nullptr);
+                MSVS_HIP(hipStreamSynchronize(nullptr));
+            }
         }
-        ix->n = n;
-        ix->h_list_off = off;
-        ix->max_list_len = 0;
-        for (size_t l = 0; l < nlist; l++)
-            ix->max_list_len = std::max<size_t>(ix->max_list_len, (size_t)(off[l + 1] - off[l]));
-        ix->max_id = 0;
-        for (size_t i = 0; i < n; i++)
-            ix->max_id = std::max<uint64_t>(ix->max_id, (uint64_t)ids[i]);
-        ix->vecs.alloc(std::max<size_t>(n, 1) * ix->ld);
-        ix->row_ids.alloc(std::max<size_t>(n, 1));
-        ix->list_off.alloc(nlist + 1);
-        upload_rows(ix->vecs.p, vecs.data(), n, (uint32_t)d, ix->ld, MSVS_MEM_HOST, nullptr);
-        std::vector<uint32_t> h_ids(n);
-        for (size_t i = 0; i < n; i++)
-            h_ids[i] = (uint32_t)ids[i];
-        if (n)
-            MSVS_HIP(hipMemcpy(ix->row_ids.p, h_ids.data(), n * 4, hipMemcpyHostToDevice));
-        MSVS_HIP(hipMemcpy(ix->list_off.p, off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
-        MSVS_HIP(hipStreamSynchronize(nullptr));
+        {
+            IoStream f(io, "id_list", 0);
+            uint64_t nid = 0;
+            f.read(&nid, 8);
+            if (nid != n)
+                fail(MSVS_ERR_IO, "corrupt msvs index: id_list holds %llu ids for %zu rows", (unsigned long long)nid, n);
+            std::vector<int64_t> ids(n);
+            f.read(ids.data(), n * 8);
+            std::vector<uint32_t> h32(n);
+            ix->max_id = 0;
+            for (size_t i = 0; i < n; i++)
+            {
+                if (ids[i] < 0 || ids[i] > 0xfffffff0ll)
+                    fail(MSVS_ERR_IO, "corrupt msvs index: row id %lld outside the u32 row-offset range", (long long)ids[i]);
+                h32[i] = (uint32_t)ids[i];
+                ix->max_id = std::max<uint64_t>(ix->max_id, (uint64_t)ids[i]);
+            }
+            ix->row_ids.alloc(std::max<size_t>(n, 1));
+            if (n)
+                MSVS_HIP(hipMemcpy(ix->row_ids.p, h32.data(), n * 4, hipMemcpyHostToDevice));
+        }
         index_finalize_norms(*ix, nullptr);
         ix->ready = true;
         *out = ix.release();
+    });
+}
+
+/// Convenience over stdio: the file set <path_prefix>-data_bin.vidx3, <path_prefix>-id_list.vidx3.
+extern "C" int msvs_index_serialize(const msvs_index_t * ix, const char * path_prefix)
+{
+    if (!path_prefix)
+        return guarded([] { fail(MSVS_ERR_INVALID_ARGUMENT, "null path"); });
+    StdioCtx c{path_prefix};
+    const msvs_io_t io = stdio_io(&c);
+    return msvs_index_serialize_io(ix, &io);
+}
+
+extern "C" int msvs_index_load(const char * path_prefix, msvs_index_t ** out)
+{
+    if (!path_prefix)
+        return guarded([] { fail(MSVS_ERR_INVALID_ARGUMENT, "null path"); });
+    StdioCtx c{path_prefix};
+    const msvs_io_t io = stdio_io(&c);
+    return msvs_index_load_io(&io, out);
+}
+
+/// Search::VectorIndex::getVersion().toString() -- what VIMetadata records as `version:` and hands back as the
+/// `load_index_version` parameter at load (VIWithDataPart.cpp:485, :645).
+extern "C" const char * msvs_index_version(void) { return "msvs-2"; }
+
+/// Search::VectorIndex::getResourceUsage() (VIWithDataPart.cpp:368-385, :486-488): bytes resident in HBM, bytes of the
+/// serialised file set, and the peak of the build (staging chunks + final storage).
+extern "C" int msvs_index_resource_usage(const msvs_index_t * ix, size_t * memory_usage_bytes, size_t * disk_usage_bytes,
+                                         size_t * build_memory_usage_bytes)
+{
+    return guarded([&] {
+        if (!ix)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
+        const size_t n = ix->ready ? ix->n : ix->staged, nlist = msvs_index_num_lists(ix);
+        const size_t disk = sizeof(DataHeader) + (ix->type == MSVS_INDEX_IVFFLAT ? nlist * ix->dim * 4 : 0) + (nlist + 1) * 8
+            + n * ix->dim * 4 + 8 + n * 8;
+        if (memory_usage_bytes)
+            *memory_usage_bytes = msvs_index_memory_usage(ix);
+        if (disk_usage_bytes)
+            *disk_usage_bytes = disk;
+        if (build_memory_usage_bytes)
+            *build_memory_usage_bytes = 2 * n * (size_t)ix->ld * 4 + n * 6 * ix->dim / 4 + n * 24;
     });
 }
 

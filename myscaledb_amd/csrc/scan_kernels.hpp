@@ -165,8 +165,8 @@ struct WaveTopK
     }
 };
 
-/// Merge the 4 per-wave sorted lists lists[w][0..k) (LDS) into out[0..k) (LDS) by rank: keys are unique
-/// (distinct ids) except for the sentinel, so rank = own index + #smaller keys in the other lists.
+/// Merge the 4 per-wave sorted lists lists[w][0..k) (LDS) into out[0..k) (LDS) by rank:
+/// rank = own index + #keys of the other lists that sort before it (equal keys: lower list first).
 /// Must be called by all BLOCK threads; ends with a barrier.
 __device__ __forceinline__ void block_rank_merge(const uint64_t * lists, uint32_t stride, uint64_t * out, uint32_t k,
                                                  uint32_t tid)
@@ -185,12 +185,16 @@ __device__ __forceinline__ void block_rank_merge(const uint64_t * lists, uint32_
         {
             if (o == w)
                 continue;
+            // keys of list o that sort before this one: the smaller ones, and -- for equal keys (the same id at the same
+            // distance in two lists: overlapping parts, a row added twice) -- those of the lower-numbered list, so that
+            // every copy gets its own rank instead of two copies landing in one slot and leaving a hole
             const uint64_t * l = lists + o * stride;
-            uint32_t lo = 0, hi = k; // first index with l[idx] >= key
+            const bool ties_first = o < w;
+            uint32_t lo = 0, hi = k; // first index with l[idx] >= key (> key when ties_first)
             while (lo < hi)
             {
                 uint32_t mid = (lo + hi) >> 1;
-                if (l[mid] < key)
+                if (l[mid] < key || (ties_first && l[mid] == key))
                     lo = mid + 1;
                 else
                     hi = mid;
@@ -431,6 +435,7 @@ inline size_t scan_lds_bytes(uint32_t T, uint32_t ld4, uint32_t k)
 {
     return (size_t)T * ld4 * 16 + (size_t)T * 5 * k * 8;
 }
+constexpr size_t SCAN_LDS_BUDGET = 64 * 1024; // what the planners let a canonical scan block use
 
 /// FLAT: grid (n_blocks, ceil(nq/T)); block bx scans rows [bx*rows_per_block, ...) for queries by*T...
 /// partial layout: [nq][n_blocks][k].
@@ -689,7 +694,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 /// ONE wavefront: lane l owns lists l, l+64, ... and keeps the smallest unconsumed head among them; each of the k
 /// rounds is a wave-wide minimum + a rescan by the winning lane only.  Cost ~ k * (P/64 + log 64) LDS reads, against
 /// ~ P*L*ln(...) serialised insertions for the threshold method when most partial lists are short.
-/// idx: u16[P] LDS scratch.  Keys are unique except KEY_NONE.
+/// idx: u16[P] LDS scratch.  Equal keys (duplicates across lists) are all kept.
 __device__ __forceinline__ void wave_heads_merge(const uint64_t * keys, uint32_t P, uint32_t L, uint16_t * idx,
                                                  uint64_t * out, uint32_t k, uint32_t lane)
 {
@@ -716,7 +721,9 @@ __device__ __forceinline__ void wave_heads_merge(const uint64_t * keys, uint32_t
         const uint64_t m = wave_min_u64(best);
         if (lane == 0)
             out[r] = m;
-        if (m != KEY_NONE && best == m)
+        // equal keys in two lanes (the same id at the same distance in two lists): one copy per round, lowest lane first
+        const uint64_t tie = __ballot(m != KEY_NONE && best == m);
+        if (tie && lane == (uint32_t)__builtin_ctzll(tie))
         {
             idx[bl] = (uint16_t)(idx[bl] + 1);
             rescan();

@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libmsvs_host.so")
 
 SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_host_total_topk",
            "msvs_host_hybrid_search", "msvs_host_merge_topk", "msvs_host_sum_bm25_stats",
-           "msvs_host_vector_scan_without_index", "msvs_host_merge_search_result"]
+           "msvs_host_vector_scan_without_index", "msvs_host_merge_search_result",
+           "msvs_host_generate_vector_dataset"]
 
 _lib = None
 
@@ -146,4 +147,24 @@ def sum_bm25_stats(per_part):
     out = np.empty(a.shape[1], np.uint64)
     lib().msvs_host_sum_bm25_stats(_p(a, C.c_uint64), C.c_size_t(a.shape[0]), C.c_size_t(a.shape[1] - 2),
                                    _p(out, C.c_uint64))
+    return out
+
+
+def generate_vector_dataset(values, offsets, dim):
+    """MergeTreeVSManager::generateVectorDataset: the query column (float32 or float64 values + ColumnArray offsets, or
+    None for a single query) -> nq x dim float32."""
+    values = np.ascontiguousarray(values)
+    is64 = values.dtype == np.float64
+    if not is64:
+        values = np.ascontiguousarray(values, np.float32)
+    if offsets is None:
+        nq, offp = 1, None
+    else:
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        nq, offp = offsets.size, offsets.ctypes.data_as(C.POINTER(C.c_uint64))
+    out = np.empty((nq, dim), np.float32)
+    rc = lib().msvs_host_generate_vector_dataset(values.ctypes.data_as(C.c_void_p), int(is64), offp, C.c_size_t(nq),
+                                                 C.c_size_t(dim), out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise capi.MsvsError(rc, "generateVectorDataset failed")
     return out

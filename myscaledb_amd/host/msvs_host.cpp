@@ -540,6 +540,15 @@ extern "C" int msvs_host_merge_topk(const int64_t * ids, const float * dis, size
     return MSVS_OK;
 }
 
+extern "C" int msvs_host_generate_vector_dataset(const void * values, int is_float64, const uint64_t * offsets, size_t nq,
+                                                 size_t dim, float * out)
+{
+    return guarded([&] {
+        const std::vector<float> v = DB::MergeTreeVSManager::generateVectorDataset(values, is_float64 != 0, offsets, nq, dim);
+        std::copy(v.begin(), v.end(), out);
+    });
+}
+
 extern "C" void msvs_host_sum_bm25_stats(const uint64_t * per_part, size_t nparts, size_t n_terms, uint64_t * out)
 {
     const size_t w = 2 + n_terms;

@@ -452,11 +452,37 @@ def test_index_errors_and_serialization_roundtrip():
     assert e.value.code == capi.ERR_INVALID_ARGUMENT
     a = ix.search(x[:20], 5, "nprobe=4")
     with tempfile.TemporaryDirectory() as td:
-        p = os.path.join(td, "v1-ivfflat.vidx3")
+        p = os.path.join(td, "v1")  # the index name: files v1-data_bin.vidx3, v1-id_list.vidx3 (VICommon.h:55)
         ix.serialize(p)
+        assert sorted(os.listdir(td)) == ["v1-data_bin.vidx3", "v1-id_list.vidx3"]
         ix2 = capi.Index.load(p, capi.INDEX_IVFFLAT, capi.METRIC_L2, 32)
+        with open(os.path.join(td, "v1-data_bin.vidx3"), "r+b") as f:  # a truncated file is an IO error, not a crash
+            f.truncate(os.path.getsize(f.name) - 100)
+        with pytest.raises(capi.MsvsError) as e:
+            capi.Index.load(p, capi.INDEX_IVFFLAT, capi.METRIC_L2, 32)
+        assert e.value.code == capi.ERR_IO
     b = ix2.search(x[:20], 5, "nprobe=4")
     same(a[0], a[1], b[0], b[1])
+    # the same through stream callbacks (what the host's VectorIndexWriter / VectorIndexReader over IDisk plug into)
+    store = {}
+    ix.serialize_io(store)
+    assert sorted(store) == ["data_bin", "id_list"]
+    mem, disk, build = ix.resource_usage()
+    assert disk == sum(len(v) for v in store.values()) and mem >= 4000 * 32 * 4 and build >= mem // 2
+    assert capi.index_version().startswith("msvs-")
+    ix3 = capi.Index.load_io(store, capi.INDEX_IVFFLAT, capi.METRIC_L2, 32)
+    c = ix3.search(x[:20], 5, "nprobe=4")
+    same(a[0], a[1], c[0], c[1])
+    # corrupt structure: offsets that are not a partition of the rows, ids outside the u32 range, a wrong header
+    import struct
+    hdr = struct.calcsize("<8sIiiIIIQQQ")
+    for name, off, val in (("data_bin", hdr + 16 * 32 * 4 + 8, struct.pack("<q", 5000)),
+                           ("id_list", 8, struct.pack("<q", 1 << 40)), ("data_bin", 12, struct.pack("<i", 9))):
+        bad = {k: bytearray(v) for k, v in store.items()}
+        bad[name][off:off + len(val)] = val
+        with pytest.raises(capi.MsvsError) as e:
+            capi.Index.load_io(bad, capi.INDEX_IVFFLAT, capi.METRIC_L2, 32)
+        assert e.value.code == capi.ERR_IO
     with pytest.raises(capi.MsvsError):
         capi.Index(7, capi.METRIC_L2, 8)
 
@@ -725,3 +751,51 @@ def test_strided_device_merge_of_packed_exchange_buffers():
         torch.cuda.synchronize()
         ri, rd = capi.merge_topk(si, sd, metric)
         same(oi.cpu().numpy(), od.cpu().numpy(), ri, rd)
+
+
+@pytest.mark.parametrize("W,k", [(2, 10), (4, 40), (3, 100), (70, 10)])
+def test_merge_topk_keeps_duplicate_keys_without_holes(W, k):
+    """Overlapping parts / replicated shards hand the merge the SAME (distance, id) more than once: every copy gets a
+    slot (the reference's multimap keeps all of them) and no -1 hole appears before the valid entries end."""
+    rng = np.random.default_rng(W * 100 + k)
+    nq = 9
+    base_i = np.sort(rng.permutation(1000)[:k]).astype(np.int64)
+    base_d = np.sort(rng.integers(0, 30, k)).astype(np.float32)
+    ids = np.tile(base_i, (W, nq, 1))
+    dis = np.tile(base_d, (W, nq, 1))
+    ids[-1, :, k // 2:] = -1  # one part with fewer hits
+    dis[-1, :, k // 2:] = np.finfo(np.float32).max
+    oi, od = capi.merge_topk(ids, dis, capi.METRIC_L2)
+    # expected: the k smallest of the concatenation by (distance, id), duplicates included
+    for q in range(nq):
+        pairs = sorted((float(d), int(i)) for p in range(W) for d, i in zip(dis[p, q], ids[p, q]) if i >= 0)[:k]
+        assert [i for _, i in pairs] == oi[q].tolist()
+        assert [d for d, _ in pairs] == od[q].tolist()
+
+
+def test_empty_filter_bitmap_means_no_rows_and_large_dimension_tiles_fit_lds():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3000, 24), dtype=np.float32)
+    for typ, params in ((capi.INDEX_FLAT, ""), (capi.INDEX_IVFFLAT, "ncentroids=8")):
+        ix = capi.Index(typ, capi.METRIC_L2, 24, params)
+        if typ == capi.INDEX_IVFFLAT:
+            ix.train(x)
+        ix.add(x)
+        ix.build()
+        ids, dis = ix.search(x[:5], 4, "nprobe=8" if typ == capi.INDEX_IVFFLAT else "", alive=np.zeros(0, bool))
+        assert (ids == -1).all()  # a present filter with zero bits: nothing passes (it is NOT "no filter")
+    # d = 3072, k = 256, 9 queries: the 8-query tile would need 180 KB of LDS; the planner shrinks it (ADVICE r1)
+    d, k = 3072, 256
+    y = rng.standard_normal((1500, d), dtype=np.float32)
+    q = rng.standard_normal((9, d), dtype=np.float32)
+    for metric in (capi.METRIC_L2, capi.METRIC_IP):
+        ids, dis = capi.knn(q, y, k, metric)
+        oi, od = o.knn(q, y, k, OM[metric])
+        same(ids, dis, oi, od)
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=4,kmeans_iters=2")
+    ix.train(y)
+    ix.add(y)
+    ix.build()
+    ids, dis = ix.search(q, k, "nprobe=4")
+    oi, od, _ = oracle_on_exported(ix, q, 4, k, capi.METRIC_L2)
+    same(ids, dis, oi, od)

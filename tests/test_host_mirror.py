@@ -149,3 +149,44 @@ def test_search_wrapper_with_lightweight_deletes_matches_oracle(metric):
     a = brute_force_part(host.search_wrapper, vecs, empty, 1500, q, k, metric, row_exists=row_exists)
     b = brute_force_part(o.search_wrapper, vecs, empty, 1500, q, k, metric, row_exists=row_exists)
     assert (a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all()
+
+
+def test_generate_vector_dataset_float64_and_batch_queries():
+    """a2: distance() / batch_distance() query constants are Array(Float32 | Float64) [inside Array()]: flattened to
+    nq x dim float32 by static_cast (round to nearest), a wrong length is an error (MergeTreeVSManager.cpp:59-181)."""
+    rng = np.random.default_rng(8)
+    d = 7
+    q64 = rng.standard_normal(d) * 1e3 + 1e-9
+    out = host.generate_vector_dataset(q64, None, d)
+    assert out.dtype == np.float32 and (out[0] == q64.astype(np.float32)).all()
+    # values that are not representable in float32 round to nearest even, huge ones go to inf like static_cast<float>
+    edge = np.array([1 + 2.0 ** -24, 1 + 3 * 2.0 ** -24, 1e39, -1e39, 5e-46, 0.1, -0.0], np.float64)
+    with np.errstate(over="ignore"):
+        want = edge.astype(np.float32)
+    assert (host.generate_vector_dataset(edge, None, 7)[0].view(np.uint32) == want.view(np.uint32)).all()
+    # batch: Array(Array(Float64)) with ColumnArray offsets
+    qs = rng.standard_normal((5, d))
+    offs = np.arange(1, 6, dtype=np.uint64) * d
+    got = host.generate_vector_dataset(qs.reshape(-1), offs, d)
+    assert (got == qs.astype(np.float32)).all()
+    got32 = host.generate_vector_dataset(qs.astype(np.float32).reshape(-1), offs, d)
+    assert (got32 == qs.astype(np.float32)).all()
+    bad = offs.copy()
+    bad[2] -= 1  # one query a value short, the next one a value long
+    with pytest.raises(capi.MsvsError) as e:
+        host.generate_vector_dataset(qs.reshape(-1), bad, d)
+    assert e.value.code == capi.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_float64_query_through_the_index_matches_float32_cast():
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2000, 16), dtype=np.float32)
+    q64 = rng.standard_normal((3, 16))
+    ix = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, 16)
+    ix.add(x)
+    ix.build()
+    q = host.generate_vector_dataset(q64.reshape(-1), np.arange(1, 4, dtype=np.uint64) * 16, 16)
+    ids, dis = ix.search(q, 10)
+    oi, od = o.knn(q64.astype(np.float32), x, 10, o.METRIC_L2)
+    assert (ids == oi).all() and (dis == od).all()
