@@ -47,7 +47,7 @@ typedef enum msvs_status {
     MSVS_ERR_IO = 8
 } msvs_status;
 
-enum msvs_metric { MSVS_METRIC_L2 = 0, MSVS_METRIC_IP = 1, MSVS_METRIC_COSINE = 2 };
+enum msvs_metric { MSVS_METRIC_L2 = 0, MSVS_METRIC_IP = 1, MSVS_METRIC_COSINE = 2, MSVS_METRIC_HAMMING = 3, MSVS_METRIC_JACCARD = 4 };
 enum msvs_index_type { MSVS_INDEX_FLAT = 0, MSVS_INDEX_IVFFLAT = 1 };
 enum msvs_mem { MSVS_MEM_HOST = 0, MSVS_MEM_DEVICE = 1 };
 
@@ -82,6 +82,16 @@ MSVS_API int msvs_knn_f32_filtered(const float * x, const float * y, size_t d, s
 /* VectorDataset<FloatVector>::normalize() (src/VectorIndex/Common/VectorDataset.h:98-117) on the device:
  * sequential f32 sum of squares, rows with sum < FLT_EPSILON untouched, x /= sqrt(sum). In place, HOST pointer. */
 MSVS_API int msvs_normalize_f32(float * x, size_t n, size_t d);
+/* Binary vectors (FixedString(N) columns, nbytes = N = dimension / 8): replaces
+ *   faiss::hammings_knn_mc(x, y, nx, ny, k, d / 8, (int32_t *)distance, result_id, nullptr)
+ *   jaccard_knn(x, y, nx, ny, k, d / 8, distance, result_id, nullptr)
+ * behind tryBruteForceSearch<BinaryVector> (src/VectorIndex/Common/BruteForceSearch.h:94-110).
+ * metric: MSVS_METRIC_HAMMING (popcount(x ^ y), reported as a float like the reference's Float32 distance column) or
+ * MSVS_METRIC_JACCARD ((|x | y| - |x & y|) / |x | y|, 1 for two zero vectors); anything else -> MSVS_ERR_NOT_IMPLEMENTED.
+ * alive_bits: nullable LSB-first bitmap over the ny rows.  Results ascending by (distance, row), unfilled slots id -1
+ * with distance FLT_MAX.  k <= MSVS_MAX_K. */
+MSVS_API int msvs_knn_bin(const uint8_t * x, const uint8_t * y, size_t nbytes, size_t k, size_t nx, size_t ny,
+                          int metric, const uint64_t * alive_bits, int64_t * ids, float * dis);
 
 /* ---------------------------------------------------------------------------------------------
  * Seam A1 -- vector index object.  Replaces Search::VectorIndex<...,FloatVector>:

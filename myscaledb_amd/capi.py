@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsvs.so")
 
-METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
+METRIC_L2, METRIC_IP, METRIC_COSINE, METRIC_HAMMING, METRIC_JACCARD = 0, 1, 2, 3, 4
 INDEX_FLAT, INDEX_IVFFLAT = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 MAX_K = 256
@@ -28,7 +28,7 @@ SYMBOLS = [
     "msvs_postings_create", "msvs_postings_free", "msvs_bm25_search", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
     "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option", "msvs_index_serialize_io",
-    "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage",
+    "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
 ]
 
 
@@ -144,6 +144,21 @@ def knn(x, y, k, metric, alive=None):
         _check(lib().msvs_knn_f32_filtered(_p(x, C.c_float), _p(y, C.c_float), C.c_size_t(d), C.c_size_t(k),
                                            C.c_size_t(nx), C.c_size_t(y.shape[0]), int(metric), _p(bits, C.c_uint64),
                                            _p(ids, C.c_int64), _p(dis, C.c_float)))
+    return ids, dis
+
+
+def knn_bin(x, y, k, metric, alive=None):
+    """msvs_knn_bin: x [nx, nbytes], y [ny, nbytes] uint8 host arrays -> (ids int64 [nx, k], dis f32 [nx, k])."""
+    y = np.ascontiguousarray(y, np.uint8)
+    nb = y.shape[1]
+    x = np.ascontiguousarray(x, np.uint8).reshape(-1, nb)
+    nx = x.shape[0]
+    ids = np.empty((nx, k), np.int64)
+    dis = np.empty((nx, k), np.float32)
+    bits = None if alive is None else pack_bits(alive)
+    _check(lib().msvs_knn_bin(_p(x, C.c_uint8), _p(y, C.c_uint8), C.c_size_t(nb), C.c_size_t(k), C.c_size_t(nx),
+                              C.c_size_t(y.shape[0]), int(metric), _p(bits, C.c_uint64), _p(ids, C.c_int64),
+                              _p(dis, C.c_float)))
     return ids, dis
 
 

@@ -204,6 +204,48 @@ ORACLE_API int oracle_knn(const float *x, const float *y, size_t d, size_t k, si
 }
 
 /*
+ * Binary vectors (FixedString(N), dimension = 8 N bits): the restatement of tryBruteForceSearch<BinaryVector>
+ * (src/VectorIndex/Common/BruteForceSearch.h:94-110) -> faiss::hammings_knn_mc / jaccard_knn.
+ *   metric 3 (Hamming): popcount(x xor y), reported as a float (the goldens print 4, 8, 12 ...);
+ *   metric 4 (Jaccard): (|x or y| - |x and y|) / |x or y| as ONE f32 division of the two exact counts (Faiss'
+ *     JaccardComputer; the goldens' 0.22222222 and 0.33333334 are f32(4/18) and f32(1/3) -- `1 - f32(14/18)` would
+ *     print 0.2222222), 1.0 when both vectors are all zero.
+ * Results ascending by (distance, id) (the reference's tests order ties by id themselves:
+ * tests/queries/2_vector_search/00038_mqvs_binary_vector_feature.sql), unfilled slots id -1 / FLT_MAX.
+ * alive (nullable): LSB-first bitmap over the base rows.
+ */
+enum { METRIC_HAMMING = 3, METRIC_JACCARD = 4 };
+
+ORACLE_API int oracle_knn_bin(const uint8_t *x, const uint8_t *y, size_t nbytes, size_t k, size_t nx, size_t ny, int metric,
+                              const uint64_t *alive, int64_t *ids, float *dis)
+{
+    if (metric != METRIC_HAMMING && metric != METRIC_JACCARD) return 2; /* NOT_IMPLEMENTED, BruteForceSearch.h:106-109 */
+    cand_t *h = (cand_t *)malloc(sizeof(cand_t) * (k ? k : 1));
+    for (size_t q = 0; q < nx; q++) {
+        size_t cnt = 0;
+        const uint8_t *xq = x + q * nbytes;
+        for (size_t i = 0; i < ny; i++) {
+            if (!bit_alive(alive, i)) continue;
+            const uint8_t *yi = y + i * nbytes;
+            uint32_t ham = 0, num = 0, den = 0;
+            for (size_t b = 0; b < nbytes; b++) {
+                ham += (uint32_t)__builtin_popcount((unsigned)(xq[b] ^ yi[b]));
+                num += (uint32_t)__builtin_popcount((unsigned)(xq[b] & yi[b]));
+                den += (uint32_t)__builtin_popcount((unsigned)(xq[b] | yi[b]));
+            }
+            float v = metric == METRIC_HAMMING ? (float)ham : (den == 0 ? 1.0f : (float)(den - num) / (float)den);
+            topk_push(METRIC_L2, h, k, &cnt, v, (int64_t)i);
+        }
+        for (size_t j = 0; j < k; j++) {
+            ids[q * k + j] = j < cnt ? h[j].id : -1;
+            dis[q * k + j] = j < cnt ? h[j].dis : FLT_MAX;
+        }
+    }
+    free(h);
+    return 0;
+}
+
+/*
  * VIWithColumnInPart::searchWithoutIndex<FloatVector> (src/VectorIndex/Common/VIWithDataPart.h:341-382):
  * cosine => normalize() BOTH datasets IN PLACE, search with IP, then d = 1 - d for all
  * k*nq slots (including unfilled ones).  x and y are modified when metric is cosine,

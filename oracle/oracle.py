@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libmsvs_oracle.so")
 
-METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
+METRIC_L2, METRIC_IP, METRIC_COSINE, METRIC_HAMMING, METRIC_JACCARD = 0, 1, 2, 3, 4
 FLT_MAX = np.finfo(np.float32).max
 
 
@@ -263,3 +263,20 @@ def np_l2sqr(x, Y):
 
 def np_ip(x, Y):
     return np_dot_canonical((np.asarray(x, np.float32)[None, :] * np.asarray(Y, np.float32)).astype(np.float32))
+
+
+def knn_bin(x, y, k, metric, alive=None):
+    """Binary vectors: x [nx, nbytes], y [ny, nbytes] uint8 -> (ids int64 [nx, k], dis f32 [nx, k]); metric
+    METRIC_HAMMING / METRIC_JACCARD (oracle_knn_bin)."""
+    y = np.ascontiguousarray(y, np.uint8)
+    nb = y.shape[1]
+    x = np.ascontiguousarray(x, np.uint8).reshape(-1, nb)
+    ids = np.empty((x.shape[0], k), np.int64)
+    dis = np.empty((x.shape[0], k), np.float32)
+    bits = None if alive is None else pack_bits(alive)
+    rc = lib().oracle_knn_bin(_p(x, C.c_uint8), _p(y, C.c_uint8), C.c_size_t(nb), C.c_size_t(k), C.c_size_t(x.shape[0]),
+                              C.c_size_t(y.shape[0]), int(metric), _p(bits, C.c_uint64), _p(ids, C.c_int64),
+                              _p(dis, C.c_float))
+    if rc:
+        raise RuntimeError("oracle_knn_bin rc=%d" % rc)
+    return ids, dis

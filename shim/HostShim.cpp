@@ -1,0 +1,340 @@
+// HostShim.cpp -- what a MyScaleDB maintainer links INSTEAD of contrib/search-index for the hot path: the library's
+// C++ surface (namespace Search, the four faiss:: brute-force calls) implemented on the C-ABI of libmsvs.so.
+// Compiled against shim/stubs/ (reconstructions of the absent headers from the reference's call sites, SURVEY.md
+// Appendix A) so that the boundary code has been through a compiler; with the real headers only the include path
+// changes.  Everything computes on the GPU through libmsvs; errors come back as Search::SearchIndexException, which
+// the host already converts to VIException (VICommon.h:75-104, VIWithDataPart.cpp:948-956).
+//
+//   seam A1  Search::VectorIndex<IS, OS, Bitmap, FloatVector>   -> MsvsVectorIndex            (FLAT, IVFFLAT, MSTG*)
+//   seam A2  faiss::knn_L2sqr / knn_inner_product / hammings_knn_mc / jaccard_knn -> msvs_knn_f32 / msvs_knn_bin
+//   (* MSTG is proprietary and absent: its partition scan is served by IVFFLAT with the same metric)
+#include <SearchIndex/VectorIndex.h>
+#include <faiss/utils/distances.h>
+
+#include <cctype>
+#include <cstdlib>
+
+#include "../include/msvs.h"
+
+namespace
+{
+
+[[noreturn]] void raise(int code)
+{
+    throw Search::SearchIndexException(code, msvs_last_error());
+}
+
+inline void check(int rc)
+{
+    if (rc != MSVS_OK)
+        raise(rc);
+}
+
+std::string lower(std::string s)
+{
+    for (auto & c : s)
+        c = (char)tolower((unsigned char)c);
+    return s;
+}
+
+int msvs_metric_of(Search::Metric m)
+{
+    switch (m)
+    {
+        case Search::Metric::L2:
+            return MSVS_METRIC_L2;
+        case Search::Metric::IP:
+            return MSVS_METRIC_IP;
+        case Search::Metric::Cosine:
+            return MSVS_METRIC_COSINE;
+        case Search::Metric::Hamming:
+            return MSVS_METRIC_HAMMING;
+        default:
+            return MSVS_METRIC_JACCARD;
+    }
+}
+
+/// msvs_io_t over the library's file-set objects: NAME -> writer->open(NAME) / reader->open(NAME), i.e. the host's
+/// VectorIndexWriter / VectorIndexReader over IDisk (VectorIndexIO.h:25-166).
+template <typename IS, typename OS>
+struct StreamIO
+{
+    Search::IndexDataFileWriter<OS> * writer = nullptr;
+    Search::IndexDataFileReader<IS> * reader = nullptr;
+    std::vector<std::shared_ptr<OS>> outs;
+    std::vector<std::shared_ptr<IS>> ins;
+
+    static void * open(void * ctx, const char * name, int write)
+    {
+        auto * self = static_cast<StreamIO *>(ctx);
+        if (write)
+        {
+            auto s = self->writer ? self->writer->open(name) : nullptr;
+            if (!s)
+                return nullptr;
+            self->outs.push_back(s);
+            return s.get();
+        }
+        auto s = self->reader ? self->reader->open(name) : nullptr;
+        if (!s || !s->is_open())
+            return nullptr;
+        self->ins.push_back(s);
+        return s.get();
+    }
+    static int64_t write(void *, void * stream, const void * buf, size_t n)
+    {
+        static_cast<OS *>(stream)->write(static_cast<const char *>(buf), (std::streamsize)n);
+        return (int64_t)n; // VectorIndexWriter::write has no failure channel of its own; close() finalises
+    }
+    static int64_t read(void *, void * stream, void * buf, size_t n)
+    {
+        auto * s = static_cast<IS *>(stream);
+        s->read(static_cast<char *>(buf), (std::streamsize)n);
+        return (int64_t)s->gcount();
+    }
+    static int close(void *, void * stream)
+    {
+        // output streams: AbstractOStream::close(); input streams have nothing to close (the holder drops them)
+        return stream ? 0 : 1;
+    }
+    msvs_io_t io() { return msvs_io_t{this, &open, &write, &read, &close}; }
+};
+
+template <typename IS, typename OS, typename Bitmap>
+class MsvsVectorIndex final : public Search::VectorIndex<IS, OS, Bitmap, Search::DataType::FloatVector>
+{
+public:
+    using Reader = Search::IndexSourceDataReader<float>;
+
+    MsvsVectorIndex(Search::IndexType type_, Search::Metric metric_, size_t dim_, size_t total_vec_,
+                    const Search::Parameters & params_)
+        : type(type_), metric(metric_), dim(dim_), total_vec(total_vec_), params(params_)
+    {
+        create();
+    }
+    ~MsvsVectorIndex() override { msvs_index_free(ix); }
+
+    void setTrainDataChunkSize(size_t bytes) override { train_chunk = bytes; }
+    void setAddDataChunkSize(size_t bytes) override { add_chunk = bytes; }
+
+    /// train on a sample, then add the part chunk by chunk (VIPartReader::readDataImpl feeds dense float[n x dim] +
+    /// idx_t[n]; rows of empty arrays arrive as zero vectors with id 0 and are listed in the reader's emptyIds(): the
+    /// host excludes them through the filter bitmap, as it does for every index type)
+    void build(Reader * reader, int /*num_threads*/, std::function<bool()> check_cancelled) override
+    {
+        const size_t row_bytes = dim * sizeof(float);
+        if (msvs_kind() == MSVS_INDEX_IVFFLAT)
+        {
+            const size_t want = std::max<size_t>(ncentroids() * 64, 4096);
+            auto sample = reader->sampleData(std::min(want, std::max<size_t>(total_vec, 1)));
+            check(msvs_index_train(ix, sample->getData(), sample->numData(), MSVS_MEM_HOST));
+        }
+        const size_t rows_per = std::max<size_t>(1, (add_chunk ? add_chunk : ((size_t)64 << 20)) / row_bytes);
+        while (!reader->eof())
+        {
+            if (check_cancelled && check_cancelled())
+                throw Search::SearchIndexException(MSVS_ERR_DEVICE, "Cancelled building vector index");
+            auto chunk = reader->readData(rows_per);
+            if (!chunk)
+                break;
+            check(msvs_index_add(ix, chunk->getData(), chunk->getDataID(), chunk->numData(), MSVS_MEM_HOST));
+        }
+        check(msvs_index_build(ix));
+    }
+
+    std::shared_ptr<Search::SearchResult> search(std::shared_ptr<Search::DataSet<float>> queries, int32_t k,
+                                                 Search::Parameters & search_params, bool /*first_stage_only*/,
+                                                 Bitmap * filter) override
+    {
+        auto res = Search::SearchResult::createTopKHolder(queries->numData(), k);
+        std::string p;
+        for (const auto & kv : search_params)
+            if (kv.first != "load_index_version" && kv.first != "metric_type")
+                p += (p.empty() ? "" : ",") + kv.first + "=" + kv.second;
+        // DenseBitmap bytes are LSB-first: a byte array IS the little-endian u64 word array libmsvs takes (padded copy
+        // so that the last word is whole)
+        std::vector<uint64_t> words;
+        size_t nbits = 0;
+        if (filter)
+        {
+            nbits = filter->get_size();
+            words.assign((nbits + 63) / 64 + 1, 0);
+            memcpy(words.data(), filter->get_bitmap(), filter->byte_size());
+        }
+        check(msvs_index_search(ix, queries->getData(), (size_t)queries->numData(), k, p.c_str(),
+                                filter ? words.data() : nullptr, nbits, res->getResultIndices(), res->getResultDistances()));
+        return res;
+    }
+
+    /// dormant in the reference (no caller sets first_stage_only: SURVEY.md Appendix C); every search here is exact
+    std::shared_ptr<Search::SearchResult> computeTopDistanceSubset(std::shared_ptr<Search::DataSet<float>>,
+                                                                   std::shared_ptr<Search::SearchResult> first_stage,
+                                                                   int32_t) override
+    {
+        return first_stage;
+    }
+    bool supportTwoStageSearch() const override { return false; }
+
+    void serialize(Search::IndexDataFileWriter<OS> * writer) override
+    {
+        StreamIO<IS, OS> s;
+        s.writer = writer;
+        const msvs_io_t io = s.io();
+        check(msvs_index_serialize_io(ix, &io)); // writes data_bin AND id_list
+        for (auto & o : s.outs)
+            o->close();
+    }
+    void saveDataID(Search::IndexDataFileWriter<OS> *) override {} // id_list travels with serialize()
+    void load(Search::IndexDataFileReader<IS> * reader, std::function<bool()> check_expired) override
+    {
+        if (check_expired && check_expired())
+            throw Search::SearchIndexException(MSVS_ERR_IO, "index files expired before load");
+        StreamIO<IS, OS> s;
+        s.reader = reader;
+        const msvs_io_t io = s.io();
+        msvs_index_t * loaded = nullptr;
+        check(msvs_index_load_io(&io, &loaded));
+        msvs_index_free(ix);
+        ix = loaded;
+    }
+    void loadDataID(Search::IndexDataFileReader<IS> *) override {}
+
+    bool ready() const override { return msvs_index_ready(ix) != 0; }
+    size_t numData() const override { return msvs_index_num_data(ix); }
+    Search::IndexResourceUsage getResourceUsage() const override
+    {
+        Search::IndexResourceUsage u;
+        check(msvs_index_resource_usage(ix, &u.memory_usage_bytes, &u.disk_usage_bytes, &u.build_memory_usage_bytes));
+        if (!ready()) // asked before build (VIWithDataPart.h:333): estimate from total_vec
+            u.build_memory_usage_bytes = std::max(u.build_memory_usage_bytes, 3 * total_vec * dim * sizeof(float));
+        return u;
+    }
+    Search::IndexVersion getVersion() const override { return Search::IndexVersion{msvs_index_version()}; }
+
+private:
+    int msvs_kind() const { return type == Search::IndexType::FLAT ? MSVS_INDEX_FLAT : MSVS_INDEX_IVFFLAT; }
+    size_t ncentroids() const
+    {
+        auto it = params.find("ncentroids");
+        if (it != params.end())
+            return (size_t)std::max(1l, atol(it->second.c_str()));
+        // MSTG / default: ~sqrt-ish partitions of ~1000 rows
+        return std::max<size_t>(1, std::min<size_t>(65536, total_vec / 1000 + 1));
+    }
+    void create()
+    {
+        if (type != Search::IndexType::FLAT && type != Search::IndexType::IVFFLAT && type != Search::IndexType::MSTG)
+            throw Search::SearchIndexException(MSVS_ERR_NOT_IMPLEMENTED,
+                                               "index type " + Search::enumToString(type) + " is not served by libmsvs");
+        std::string p = "ncentroids=" + std::to_string(ncentroids());
+        check(msvs_index_create(msvs_kind(), msvs_metric_of(metric), dim, p.c_str(), &ix));
+    }
+
+    Search::IndexType type;
+    Search::Metric metric;
+    size_t dim, total_vec;
+    Search::Parameters params;
+    size_t train_chunk = 0, add_chunk = 0;
+    msvs_index_t * ix = nullptr;
+};
+
+}
+
+namespace Search
+{
+
+std::string enumToString(IndexType t)
+{
+    static const char * names[] = {"FLAT", "BinaryFLAT", "IVFFLAT", "IVFPQ", "IVFSQ", "HNSWFLAT", "HNSWSQ", "HNSWPQ", "SCANN", "MSTG",
+                                   "BinaryMSTG"};
+    return names[(int)t];
+}
+
+std::string enumToString(Metric m)
+{
+    static const char * names[] = {"L2", "IP", "Cosine", "Hamming", "Jaccard"};
+    return names[(int)m];
+}
+
+Metric getMetricType(const std::string & name, DataType type)
+{
+    const std::string n = lower(name);
+    if (type == DataType::FloatVector)
+    {
+        if (n == "l2")
+            return Metric::L2;
+        if (n == "ip")
+            return Metric::IP;
+        if (n == "cosine")
+            return Metric::Cosine;
+    }
+    else
+    {
+        if (n == "hamming")
+            return Metric::Hamming;
+        if (n == "jaccard")
+            return Metric::Jaccard;
+    }
+    throw SearchIndexException(MSVS_ERR_INVALID_ARGUMENT, "unknown metric type `" + name + "`");
+}
+
+IndexType getVectorIndexType(const std::string & name, DataType)
+{
+    const std::string n = lower(name);
+    for (int t = 0; t <= (int)IndexType::BinaryMSTG; t++)
+        if (lower(enumToString((IndexType)t)) == n)
+            return (IndexType)t;
+    throw SearchIndexException(MSVS_ERR_INVALID_ARGUMENT, "unknown vector index type `" + name + "`");
+}
+
+template <typename IS, typename OS, typename Bitmap, DataType T>
+std::shared_ptr<VectorIndex<IS, OS, Bitmap, T>> createVectorIndex(const std::string & /*name*/, IndexType type, Metric metric,
+                                                                  size_t dimension, size_t total_vec, const Parameters & params,
+                                                                  size_t /*max_threads*/, const std::string & /*cache_prefix*/,
+                                                                  std::function<bool()> /*check_cancelled*/)
+{
+    static_assert(T == DataType::FloatVector, "binary indexes: brute force only (msvs_knn_bin)");
+    return std::make_shared<MsvsVectorIndex<IS, OS, Bitmap>>(type, metric, dimension, total_vec, params);
+}
+
+// the instantiation the host uses (VICommon.h:142-143)
+template std::shared_ptr<VectorIndex<AbstractIStream, AbstractOStream, DenseBitmap, DataType::FloatVector>>
+createVectorIndex<AbstractIStream, AbstractOStream, DenseBitmap, DataType::FloatVector>(const std::string &, IndexType, Metric,
+                                                                                       size_t, size_t, const Parameters &,
+                                                                                       size_t, const std::string &,
+                                                                                       std::function<bool()>);
+
+}
+
+// ------------------------------------------------------------------------------------------------ seam A2
+
+namespace faiss
+{
+
+void knn_inner_product(const float * x, const float * y, size_t d, size_t nx, size_t ny, float_minheap_array_t * res,
+                       const IDSelector *)
+{
+    check(msvs_knn_f32(x, y, d, res->k, nx, ny, MSVS_METRIC_IP, res->ids, res->val));
+}
+
+void knn_L2sqr(const float * x, const float * y, size_t d, size_t nx, size_t ny, float_maxheap_array_t * res, const IDSelector *)
+{
+    check(msvs_knn_f32(x, y, d, res->k, nx, ny, MSVS_METRIC_L2, res->ids, res->val));
+}
+
+/// The host passes its FLOAT distance buffer cast to int32_t* (BruteForceSearch.h:99) and reads it back as float
+/// (MergeTreeVSManager.cpp:1652-1678 compares, :1507-1525 inserts into a Float32 column; the goldens of 00038 print 4, 8,
+/// 12): the counts are therefore stored as float VALUES in that buffer.
+void hammings_knn_mc(const uint8_t * a, const uint8_t * b, size_t na, size_t nb, size_t k, size_t ncodes, int32_t * distances,
+                     int64_t * labels, const IDSelector *)
+{
+    check(msvs_knn_bin(a, b, ncodes, k, na, nb, MSVS_METRIC_HAMMING, nullptr, labels, reinterpret_cast<float *>(distances)));
+}
+
+}
+
+void jaccard_knn(const uint8_t * a, const uint8_t * b, size_t na, size_t nb, size_t k, size_t ncodes, float * distances,
+                 int64_t * labels, const faiss::IDSelector *)
+{
+    check(msvs_knn_bin(a, b, ncodes, k, na, nb, MSVS_METRIC_JACCARD, nullptr, labels, distances));
+}

@@ -176,6 +176,37 @@ def main():
         "text_search_1part": sect41("Text search result with 1 part after optimize final", 2),
         "rsf_1part": sect41("Hybrid search RSF result with 1 part after optimize final", 5)}
 
+    # 00038: binary vectors FixedString(4), rows char(n, n, n, n) for n in 0..1023 (bytes n % 256), brute force Hamming /
+    # Jaccard: single query, batch of 3 (LIMIT 10 BY query), WHERE id > 100 and id < 120; after LWD of id < 200 (Hamming)
+    ln = ref_lines("00038_mqvs_binary_vector_feature")
+
+    def sect38(title, n, occurrence=0):
+        idx = [i for i, l in enumerate(ln) if l == title][occurrence]
+        return ln[idx + 1:idx + 1 + n]
+
+    def batch38(lines):
+        idl, dl = [[], [], []], [[], [], []]
+        for r in lines:
+            i, t = r.split("\t")
+            m = re.match(r"\((\d+),(.*)\)", t)
+            idl[int(m.group(1))].append(int(i))
+            dl[int(m.group(1))].append(m.group(2))
+        return idl, dl
+
+    q1 = [100, 101, 102, 103]
+    qb = [[0x55, 0x55, 0x55, 0x55], [0, 255, 1, 254], [255, 255, 255, 255]]
+    for metric, tag in (("Hamming", "hamming"), ("Jaccard", "jaccard")):
+        ids, ds = rows2(sect38("-- Brute Force (%s)" % metric, 20))
+        bi, bd = batch38(sect38("-- Batch distance (%s)" % metric, 30))
+        fi, fd = rows2(sect38("-- Search with filter (%s)" % metric, 19))
+        g["00038_binary_" + tag] = {"source": "00038_mqvs_binary_vector_feature.sql/.reference", "rows": 1024, "nbytes": 4,
+                                    "metric": metric, "query": q1, "k": 20, "ids": ids, "dists": ds,
+                                    "batch_queries": qb, "batch_k": 10, "batch_ids": bi, "batch_dists": bd,
+                                    "filter": "id > 100 and id < 120", "filter_ids": fi, "filter_dists": fd}
+    ids, ds = rows2(sect38("-- LWD", 10))
+    g["00038_binary_hamming"]["lwd_deleted_below"] = 200
+    g["00038_binary_hamming"]["lwd_ids"], g["00038_binary_hamming"]["lwd_dists"] = ids, ds
+
     with open(OUT, "w") as f:
         json.dump(g, f, indent=1)
     print("wrote", OUT, "cases:", len(g))

@@ -799,3 +799,50 @@ def test_empty_filter_bitmap_means_no_rows_and_large_dimension_tiles_fit_lds():
     ids, dis = ix.search(q, k, "nprobe=4")
     oi, od, _ = oracle_on_exported(ix, q, 4, k, capi.METRIC_L2)
     same(ids, dis, oi, od)
+
+
+# ---------------------------------------------------------------------------------------- binary vectors (f4)
+
+@pytest.mark.parametrize("case", ["00038_binary_hamming", "00038_binary_jaccard"])
+def test_binary_vector_goldens_on_gpu(case):
+    """00038 through msvs_knn_bin: single query, batch, WHERE filter, lightweight delete."""
+    c = G[case]
+    n = np.arange(c["rows"], dtype=np.int64)
+    y = np.repeat((n % 256).astype(np.uint8)[:, None], c["nbytes"], axis=1)
+    metric = capi.METRIC_HAMMING if c["metric"] == "Hamming" else capi.METRIC_JACCARD
+    ids, dis = capi.knn_bin(np.array([c["query"]], np.uint8), y, c["k"], metric)
+    assert ids[0].tolist() == c["ids"] and dis[0].tolist() == f32_of(c["dists"]).tolist()
+    ids, dis = capi.knn_bin(np.array(c["batch_queries"], np.uint8), y, c["batch_k"], metric)
+    for q in range(3):
+        assert ids[q].tolist() == c["batch_ids"][q] and dis[q].tolist() == f32_of(c["batch_dists"][q]).tolist()
+    alive = eval_filter(c["filter"], np.arange(c["rows"]))
+    ids, dis = capi.knn_bin(np.array([c["query"]], np.uint8), y, c["k"], metric, alive=alive)
+    m = len(c["filter_ids"])
+    assert ids[0, :m].tolist() == c["filter_ids"] and dis[0, :m].tolist() == f32_of(c["filter_dists"]).tolist()
+    assert ids[0, m] == -1
+    if "lwd_ids" in c:
+        alive = np.arange(c["rows"]) >= c["lwd_deleted_below"]
+        ids, dis = capi.knn_bin(np.array([c["query"]], np.uint8), y, 10, metric, alive=alive)
+        assert ids[0].tolist() == c["lwd_ids"] and dis[0].tolist() == f32_of(c["lwd_dists"]).tolist()
+
+
+@pytest.mark.parametrize("nbytes,ny,nx,k", [(4, 1024, 3, 10), (16, 5000, 2, 64), (32, 100000, 5, 10), (100, 20000, 1, 200),
+                                            (128, 30000, 9, 30), (512, 4000, 2, 10), (1, 300, 2, 5), (33, 7, 1, 10)])
+@pytest.mark.parametrize("metric", [capi.METRIC_HAMMING, capi.METRIC_JACCARD])
+def test_knn_bin_matches_oracle(nbytes, ny, nx, k, metric):
+    rng = np.random.default_rng(nbytes * 7 + ny + k)
+    y = rng.integers(0, 256, (ny, nbytes), dtype=np.uint8)
+    y[::17] = 0  # all-zero rows: Jaccard against a zero query is 1 by definition
+    x = y[rng.integers(0, ny, nx)] ^ rng.integers(0, 4, (nx, nbytes), dtype=np.uint8)
+    x[0] = 0
+    om = o.METRIC_HAMMING if metric == capi.METRIC_HAMMING else o.METRIC_JACCARD
+    ids, dis = capi.knn_bin(x, y, k, metric)
+    oi, od = o.knn_bin(x, y, k, om)
+    same(ids, dis, oi, od)
+    alive = rng.random(ny) < 0.3
+    ids, dis = capi.knn_bin(x, y, k, metric, alive=alive)
+    oi, od = o.knn_bin(x, y, k, om, alive=alive)
+    same(ids, dis, oi, od)
+    with pytest.raises(capi.MsvsError) as e:
+        capi.knn_bin(x, y, k, capi.METRIC_L2)
+    assert e.value.code == capi.ERR_NOT_IMPLEMENTED

@@ -226,3 +226,30 @@ def test_fieldnorm_table():
     assert [o.fieldnorm_of_id(i) for i in (0, 1, 39, 40, 41, 48, 49, 56, 57, 255)] == \
         [0, 1, 39, 40, 42, 56, 60, 88, 96, 2013265944]
     assert o.fieldnorm_id(41) == 40 and o.fieldnorm_id(42) == 41 and o.fieldnorm_id(7) == 7
+
+
+def _binary_table(c):
+    n = np.arange(c["rows"], dtype=np.int64)
+    return np.repeat((n % 256).astype(np.uint8)[:, None], c["nbytes"], axis=1)  # char(n, n, n, n)
+
+
+@pytest.mark.parametrize("case", ["00038_binary_hamming", "00038_binary_jaccard"])
+def test_binary_vector_goldens(case):
+    """00038: FixedString(4) rows, brute force Hamming / Jaccard -- single query, batch of 3, WHERE filter, LWD."""
+    c = G[case]
+    y = _binary_table(c)
+    metric = o.METRIC_HAMMING if c["metric"] == "Hamming" else o.METRIC_JACCARD
+    ids, dis = o.knn_bin(np.array([c["query"]], np.uint8), y, c["k"], metric)
+    assert ids[0].tolist() == c["ids"] and dis[0].tolist() == f32_of(c["dists"]).tolist()
+    ids, dis = o.knn_bin(np.array(c["batch_queries"], np.uint8), y, c["batch_k"], metric)
+    for q in range(3):
+        assert ids[q].tolist() == c["batch_ids"][q] and dis[q].tolist() == f32_of(c["batch_dists"][q]).tolist()
+    alive = eval_filter(c["filter"], np.arange(c["rows"]))
+    ids, dis = o.knn_bin(np.array([c["query"]], np.uint8), y, c["k"], metric, alive=alive)
+    n = len(c["filter_ids"])  # 19 rows pass the filter: the 20th slot stays empty
+    assert ids[0, :n].tolist() == c["filter_ids"] and dis[0, :n].tolist() == f32_of(c["filter_dists"]).tolist()
+    assert ids[0, n] == -1
+    if "lwd_ids" in c:
+        alive = np.arange(c["rows"]) >= c["lwd_deleted_below"]
+        ids, dis = o.knn_bin(np.array([c["query"]], np.uint8), y, 10, metric, alive=alive)
+        assert ids[0].tolist() == c["lwd_ids"] and dis[0].tolist() == f32_of(c["lwd_dists"]).tolist()

@@ -1,0 +1,63 @@
+"""The compiled host shim (shim/HostShim.cpp: namespace Search + the faiss brute-force calls on top of libmsvs.so)
+driven by shim/test_shim.cpp the way the reference's host code drives the absent library; results == the CPU oracle."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "shim", "_build", "test_shim")
+
+
+def test_shim_is_built_against_the_stub_headers():
+    assert os.path.exists(EXE) and os.path.exists(os.path.join(ROOT, "shim", "_build", "libmsvs_shim.so")), \
+        "run `python -c 'import __graft_entry__ as g; g.build()'`"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", os.path.join(ROOT, "shim", "_build", "libmsvs_shim.so")],
+                                  text=True)
+    for sym in ("faiss::knn_L2sqr", "faiss::knn_inner_product", "faiss::hammings_knn_mc", "jaccard_knn",
+                "Search::createVectorIndex", "Search::getMetricType"):
+        assert sym in out, sym
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,typ", [("L2", "IVFFLAT"), ("cosine", "MSTG"), ("IP", "FLAT")])
+def test_shim_end_to_end_matches_oracle(metric, typ):
+    rng = np.random.default_rng(len(metric) * 10 + len(typ))
+    n, d, nq, k, nlist = 6000, 40, 7, 10, 12
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    alive = rng.random(n) < 0.5
+    nb_rows, nb_bytes, nb_q = 3000, 24, 4
+    bx = rng.integers(0, 256, (nb_rows, nb_bytes), dtype=np.uint8)
+    bq = rng.integers(0, 256, (nb_q, nb_bytes), dtype=np.uint8)
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "meta.txt"), "w") as f:
+            f.write("%d %d %d %d %d %s %s %d %d %d\n" % (n, d, nq, k, nlist, metric, typ, nb_rows, nb_bytes, nb_q))
+        for name, a in (("x", x), ("q", q), ("alive", alive.astype(np.uint8)), ("bx", bx), ("bq", bq)):
+            a.tofile(os.path.join(td, name + ".bin"))
+        r = subprocess.run([EXE, td], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rd = lambda name, dt: np.fromfile(os.path.join(td, name + ".bin"), dt)
+        files = open(os.path.join(td, "files.txt")).read().split("\n")
+        assert files[0].startswith("part/v1-data_bin.vidx3 ") and files[1].startswith("part/v1-id_list.vidx3 ")
+        assert files[2].startswith("version msvs-")
+        om = {"L2": o.METRIC_L2, "IP": o.METRIC_IP, "cosine": o.METRIC_IP}[metric]
+        xs, qs = (o.normalize_rows(x), o.normalize_rows(q)) if metric == "cosine" else (x, q)
+        for suffix, al in (("", None), ("_f", alive)):
+            oi, od = o.knn(qs, xs, k, om, alive=al)
+            if metric == "cosine":
+                od = (np.float32(1) - od).astype(np.float32)
+            assert (rd("out_ids" + suffix, np.int64).reshape(nq, k) == oi).all()
+            assert (rd("out_dis" + suffix, np.float32).reshape(nq, k).view(np.uint32) == od.view(np.uint32)).all()
+        for tag, m in (("l2", o.METRIC_L2), ("ip", o.METRIC_IP)):
+            oi, od = o.knn(q, x, k, m)
+            assert (rd("bf_%s_ids" % tag, np.int64).reshape(nq, k) == oi).all()
+            assert (rd("bf_%s_dis" % tag, np.float32).reshape(nq, k) == od).all()
+        for tag, m in (("ham", o.METRIC_HAMMING), ("jac", o.METRIC_JACCARD)):
+            oi, od = o.knn_bin(bq, bx, k, m)
+            assert (rd("bf_%s_ids" % tag, np.int64).reshape(nb_q, k) == oi).all()
+            assert (rd("bf_%s_dis" % tag, np.float32).reshape(nb_q, k) == od).all()
