@@ -93,6 +93,31 @@ MSVS_API int msvs_normalize_f32(float * x, size_t n, size_t d);
 MSVS_API int msvs_knn_bin(const uint8_t * x, const uint8_t * y, size_t nbytes, size_t k, size_t nx, size_t ny,
                           int metric, const uint64_t * alive_bits, int64_t * ids, float * dis);
 
+/* Resident blocks for the brute-force path: the GPU analogue of VICacheManager / VIWithMeta
+ * (src/VectorIndex/Cache/VICacheObject.h:40-162) for the dense block a mark of a part turns into
+ * (MergeTreeVSManager.cpp:1380-1392).  msvs_knn_f32 moves that block over PCIe on every query; here it is uploaded
+ * once, keyed by (part key, mark) -- CacheKey::toString() is a natural part key -- and kept in HBM in an LRU bounded by
+ * bytes.  Blocks are immutable: lightweight deletes arrive per search as the row_exists bitmap like in the reference
+ * (searchWrapper, MergeTreeVSManager.cpp:1612-1633); a dropped / mutated part is evicted by key prefix.
+ * upload: returns the resident block PINNED (an identical key already resident is returned instead -- concurrent
+ * part-pool threads race benignly); normalize != 0 stores VectorDataset::normalize()'d rows (the cosine composition of
+ * searchWithoutIndex normalises the block in place before the IP search).  lookup: *out = NULL when absent.
+ * release unpins; a pinned block is never freed, an evicted one disappears at its last release.  Thread-safe. */
+typedef struct msvs_cache msvs_cache_t;
+typedef struct msvs_block msvs_block_t;
+MSVS_API int msvs_cache_create(size_t capacity_bytes, msvs_cache_t ** out);
+MSVS_API void msvs_cache_free(msvs_cache_t * cache);
+MSVS_API int msvs_block_upload(msvs_cache_t * cache, const char * part_key, uint64_t mark, const float * rows, size_t n,
+                               size_t d, int normalize, msvs_block_t ** out);
+MSVS_API int msvs_block_lookup(msvs_cache_t * cache, const char * part_key, uint64_t mark, msvs_block_t ** out);
+MSVS_API void msvs_block_release(msvs_block_t * block);
+MSVS_API int msvs_cache_evict(msvs_cache_t * cache, const char * key_prefix, size_t * evicted);
+MSVS_API int msvs_cache_stats(msvs_cache_t * cache, size_t * bytes, size_t * blocks, uint64_t * hits, uint64_t * misses,
+                              uint64_t * evictions);
+/* msvs_knn_f32[_filtered] against a resident block: x nx*d (HOST), alive_bits nullable over the block's rows. */
+MSVS_API int msvs_knn_resident(const msvs_block_t * block, const float * x, size_t k, size_t nx, int metric,
+                               const uint64_t * alive_bits, int64_t * ids, float * dis);
+
 /* ---------------------------------------------------------------------------------------------
  * Seam A1 -- vector index object.  Replaces Search::VectorIndex<...,FloatVector>:
  *   createVectorIndex(name, type, metric, dim, total_vec, params, ...)   VIWithDataPart.cpp:415-446
@@ -134,6 +159,20 @@ MSVS_API int msvs_index_search(const msvs_index_t * index, const float * queries
 MSVS_API int msvs_index_search_device(const msvs_index_t * index, const float * d_queries, size_t nq, int k,
                                       int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
                                       float * d_dis, void * hip_stream);
+
+/* VIWithMeta state of a cached index (src/VectorIndex/Cache/VICacheObject.h:40-117), resident in HBM:
+ *  - set_delete_bitmap: the lightweight-delete bitmap (1 = alive, over the index labels), swapped atomically like
+ *    VIWithMeta::setDeleteBitmap; every search ANDs it into its filter on the device (VIWithDataPart.cpp:903-908) instead
+ *    of the host intersecting and re-uploading bitmaps per query.  NULL clears it.
+ *  - set_merged_maps: the row-id maps of a DECOUPLED part (a merged part still served by its source parts' indexes,
+ *    SegmentId::getMergedMaps): row_ids_map[label] = row of the merged part; inverted_row_ids_map /
+ *    inverted_row_sources_map [merged row] = (label, source part).  Once set, a search takes its filter in the merged
+ *    part's row space (getRealBitmap, src/VectorIndex/Utils/VIUtils.cpp:479-498) and reports merged-part rows
+ *    (transferToNewRowIds, VIWithDataPart.cpp:56-67). */
+MSVS_API int msvs_index_set_delete_bitmap(msvs_index_t * index, const uint64_t * alive_bits, size_t nbits);
+MSVS_API int msvs_index_set_merged_maps(msvs_index_t * index, const uint64_t * row_ids_map, size_t n_old,
+                                        const uint64_t * inverted_row_ids_map, const uint8_t * inverted_row_sources_map,
+                                        size_t n_new, uint32_t own_id);
 
 /* Export the index structure (for parity checks against the oracle and for serialisation):
  * any output may be NULL; sizes: centroids nlist*dim, list_off nlist+1, vecs num_data*dim, ids num_data.

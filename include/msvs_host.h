@@ -42,6 +42,17 @@ MSVS_HOST_API int msvs_host_vector_scan_without_index(const uint64_t * offsets, 
                                                       uint32_t * out_labels, uint32_t * out_query_ids,
                                                       float * out_distances, size_t * n_out);
 
+/* The same scan over RESIDENT blocks (include/msvs.h msvs_cache_t): marks are uploaded once per part
+ * (key = part_key / mark index), later queries only send their vectors; filters and lightweight deletes travel as row
+ * bitmaps over the resident block.  Results are identical to msvs_host_vector_scan_without_index. */
+struct msvs_cache;
+MSVS_HOST_API int msvs_host_vector_scan_resident(struct msvs_cache * cache, const char * part_key, const uint64_t * offsets,
+                                                 const float * data, size_t rows, size_t dim, size_t index_granularity,
+                                                 const float * queries, size_t nq, int k, int metric, int is_batch,
+                                                 const uint64_t * filter_bits, const uint64_t * row_exists_bits,
+                                                 uint32_t * out_labels, uint32_t * out_query_ids, float * out_distances,
+                                                 size_t * n_out);
+
 /* Join of mergeSearchResultImpl (MergeTreeBaseSearchManager.cpp:23-164): out_pos[r] = index of part_offsets[r] in
  * labels, or -1 when the read row is not among the part's search results. */
 MSVS_HOST_API void msvs_host_merge_search_result(const uint64_t * part_offsets, size_t n_rows, const uint32_t * labels,

@@ -29,6 +29,9 @@ SYMBOLS = [
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
     "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option", "msvs_index_serialize_io",
     "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
+    "msvs_cache_create", "msvs_cache_free", "msvs_block_upload", "msvs_block_lookup", "msvs_block_release",
+    "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
+    "msvs_index_set_merged_maps",
 ]
 
 
@@ -178,6 +181,65 @@ def merge_topk(ids, dis, metric):
     _check(lib().msvs_merge_topk(_p(ids, C.c_int64), _p(dis, C.c_float), C.c_size_t(nparts), C.c_size_t(nq),
                                  C.c_size_t(k), int(metric), _p(oi, C.c_int64), _p(od, C.c_float)))
     return oi, od
+
+
+class Cache:
+    """msvs_cache_t: LRU of resident brute-force blocks (seam A2)."""
+
+    def __init__(self, capacity_bytes):
+        h = C.c_void_p()
+        _check(lib().msvs_cache_create(C.c_size_t(capacity_bytes), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.msvs_cache_free.argtypes = [C.c_void_p]
+            _lib.msvs_cache_free.restype = None
+            _lib.msvs_cache_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload(self, key, mark, rows, normalize=False):
+        rows = _f32(rows)
+        b = C.c_void_p()
+        _check(lib().msvs_block_upload(self._h, key.encode(), C.c_uint64(mark), _p(rows, C.c_float),
+                                       C.c_size_t(rows.shape[0]), C.c_size_t(rows.shape[1]), int(normalize), C.byref(b)))
+        return b
+
+    def lookup(self, key, mark):
+        b = C.c_void_p()
+        _check(lib().msvs_block_lookup(self._h, key.encode(), C.c_uint64(mark), C.byref(b)))
+        return b if b.value else None
+
+    @staticmethod
+    def release(block):
+        lib().msvs_block_release.argtypes = [C.c_void_p]
+        lib().msvs_block_release.restype = None
+        lib().msvs_block_release(block)
+
+    def evict(self, prefix):
+        n = C.c_size_t(0)
+        _check(lib().msvs_cache_evict(self._h, prefix.encode(), C.byref(n)))
+        return n.value
+
+    def stats(self):
+        """-> dict(bytes, blocks, hits, misses, evictions)"""
+        by, bl = C.c_size_t(0), C.c_size_t(0)
+        h, m, e = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().msvs_cache_stats(self._h, C.byref(by), C.byref(bl), C.byref(h), C.byref(m), C.byref(e)))
+        return dict(bytes=by.value, blocks=bl.value, hits=h.value, misses=m.value, evictions=e.value)
+
+
+def knn_resident(block, x, k, metric, d, alive=None):
+    x = _f32(x).reshape(-1, d)
+    nx = x.shape[0]
+    ids = np.empty((nx, k), np.int64)
+    dis = np.empty((nx, k), np.float32)
+    bits = None if alive is None else pack_bits(alive)
+    _check(lib().msvs_knn_resident(block, _p(x, C.c_float), C.c_size_t(k), C.c_size_t(nx), int(metric),
+                                   _p(bits, C.c_uint64), _p(ids, C.c_int64), _p(dis, C.c_float)))
+    return ids, dis
 
 
 class _MsvsIO(C.Structure):
@@ -354,6 +416,21 @@ class Index:
         h = C.c_void_p()
         _check(lib().msvs_index_load_io(C.byref(_DictIO(store).io), C.byref(h)))
         return cls(index_type, metric, dim, _handle=h)
+
+    def set_delete_bitmap(self, alive):
+        """VIWithMeta::setDeleteBitmap: bool[n] over the index labels (1 = alive), resident; None clears."""
+        if alive is None:
+            _check(lib().msvs_index_set_delete_bitmap(self._h, None, C.c_size_t(0)))
+        else:
+            bits = pack_bits(alive)
+            _check(lib().msvs_index_set_delete_bitmap(self._h, _p(bits, C.c_uint64), C.c_size_t(len(alive))))
+
+    def set_merged_maps(self, row_ids_map, inverted_row_ids_map, inverted_row_sources_map, own_id):
+        a = np.ascontiguousarray(row_ids_map, np.uint64)
+        b = np.ascontiguousarray(inverted_row_ids_map, np.uint64)
+        c = np.ascontiguousarray(inverted_row_sources_map, np.uint8)
+        _check(lib().msvs_index_set_merged_maps(self._h, _p(a, C.c_uint64), C.c_size_t(a.size), _p(b, C.c_uint64),
+                                                _p(c, C.c_uint8), C.c_size_t(b.size), C.c_uint32(own_id)))
 
     def resource_usage(self):
         """-> (memory_usage_bytes, disk_usage_bytes, build_memory_usage_bytes)"""

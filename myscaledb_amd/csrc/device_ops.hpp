@@ -33,6 +33,8 @@ Scratch & scratch_for(hipStream_t stream);
 /// A second arena of the same kind for the host-pointer entry points' staging copies (queries in, results out): the
 /// device-level search underneath owns scratch_for(); a hipMalloc / hipFree pair per call costs ~0.1 ms.
 Scratch & staging_for(hipStream_t stream);
+/// A third one for the effective filter of a search (per-search filter AND resident delete bitmap, id-space conversion).
+Scratch & aux_for(hipStream_t stream);
 
 /// Optional HIP-event timing of kernel launches (msvs_profile_* in the C-ABI); a no-op unless enabled.
 struct ProfileScope

@@ -116,14 +116,16 @@ extern "C" int msvs_device_synchronize(void)
 namespace msvs
 {
 /// Shared body of msvs_knn_f32 / msvs_knn_f32_filtered: host buffers in, host buffers out.
+/// d_resident (nullable): the base rows already in HBM (row stride = padded_dim(d) floats, zero padded) -- a block of
+/// the resident cache (msvs_block_t); y is then ignored and nothing but the queries crosses PCIe.
 static void knn_host(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny, int metric,
-                     const uint64_t * alive_bits, int64_t * ids, float * dis)
+                     const uint64_t * alive_bits, int64_t * ids, float * dis, const float * d_resident = nullptr)
 {
     if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
         fail(MSVS_ERR_NOT_IMPLEMENTED, "Metric not implemented in brute force search for Float32 Vector");
     if (nx == 0 || k == 0)
         return;
-    if (!x || !ids || !dis || (ny && !y) || d == 0)
+    if (!x || !ids || !dis || (ny && !y && !d_resident) || d == 0)
         fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer or zero dimension");
     if (k > MSVS_MAX_K_ROUNDS)
         fail(MSVS_ERR_UNSUPPORTED_K, "k = %zu exceeds the limit %d", k, MSVS_MAX_K_ROUNDS);
@@ -135,17 +137,22 @@ static void knn_host(const float * x, const float * y, size_t d, size_t k, size_
     const size_t bw = ceil_div(std::max<size_t>(ny, 1), 64);
     const bool rounds = k > MSVS_MAX_K;
     Scratch & scr = scratch_for(stream);
-    size_t need = (nx + ny) * (size_t)ld * 4 + nx * k * 12 + bw * 8
+    size_t need = (nx + (d_resident ? 0 : ny)) * (size_t)ld * 4 + nx * k * 12 + bw * 8
         + flat_scratch_bytes(ny, rounds ? 1 : nx, kpass, ld) + 16384;
     scr.reserve(need, stream);
     float * dq = scr.take<float>(nx * ld);
-    float * dy = scr.take<float>(std::max<size_t>(ny, 1) * ld);
+    const float * dy = d_resident;
+    if (!d_resident)
+    {
+        float * up = scr.take<float>(std::max<size_t>(ny, 1) * ld);
+        upload_rows(up, y, ny, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
+        dy = up;
+    }
     int64_t * d_ids = scr.take<int64_t>(nx * k);
     float * d_dis = scr.take<float>(nx * k);
     uint64_t * bm = (alive_bits || rounds) ? scr.take<uint64_t>(bw) : nullptr;
     const size_t mark = scr.used; // everything taken after this point is per-pass scratch
     upload_rows(dq, x, nx, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
-    upload_rows(dy, y, ny, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
     auto load_filter = [&]() {
         if (alive_bits)
             MSVS_HIP(hipMemcpyAsync(bm, alive_bits, bw * 8, hipMemcpyHostToDevice, stream));
@@ -216,6 +223,234 @@ extern "C" int msvs_normalize_f32(float * x, size_t n, size_t d)
     });
 }
 
+// =========================================================================================== resident blocks (f1)
+//
+// The GPU analogue of the reference's VICacheManager / VIWithMeta for the BRUTE-FORCE path: the
+// dense block a mark of a part turns into (MergeTreeVSManager.cpp:1380-1392) is uploaded once, keyed by
+// (part key, mark), and stays in HBM in an LRU bounded by bytes; later queries against the same part send only the
+// query vectors over PCIe.  Blocks are immutable; lightweight deletes arrive per search as the row_exists bitmap, like in
+// the reference.  A part that is dropped or mutated is evicted by key prefix (CacheKey: table path / part name, VICacheObject.h:119-162).
+
+#include <list>
+#include <unordered_map>
+
+struct msvs_block
+{
+    msvs_cache_t * owner = nullptr;
+    std::string key;
+    DevBuf<float> rows; // n x ld, zero padded; normalised when `normalized`
+    size_t n = 0, d = 0;
+    uint32_t ld = 0;
+    int normalized = 0;
+    int pins = 0;
+    bool doomed = false; // evicted while pinned: freed at the last release
+    std::list<msvs_block *>::iterator pos;
+    size_t bytes() const { return rows.bytes(); }
+};
+
+struct msvs_cache
+{
+    std::mutex mu;
+    size_t capacity = 0, used = 0;
+    std::list<msvs_block *> lru; // front = most recently used
+    std::unordered_map<std::string, msvs_block *> map;
+    uint64_t hits = 0, misses = 0, evictions = 0;
+    int device = 0;
+
+    static std::string full_key(const char * key, uint64_t mark) { return std::string(key ? key : "") + "#" + std::to_string(mark); }
+    void drop_locked(msvs_block * b)
+    {
+        map.erase(b->key);
+        lru.erase(b->pos);
+        used -= b->bytes();
+        evictions++;
+        if (b->pins == 0)
+            delete b;
+        else
+            b->doomed = true;
+    }
+    void make_room_locked(size_t need)
+    {
+        // least recently used first; pinned blocks stay (the bound is soft while searches hold more than the capacity)
+        std::vector<msvs_block *> victims;
+        size_t freed = 0;
+        for (auto it = lru.rbegin(); it != lru.rend() && used - freed + need > capacity; ++it)
+            if ((*it)->pins == 0)
+            {
+                victims.push_back(*it);
+                freed += (*it)->bytes();
+            }
+        for (msvs_block * b : victims)
+            drop_locked(b);
+    }
+};
+
+extern "C" int msvs_cache_create(size_t capacity_bytes, msvs_cache_t ** out)
+{
+    return guarded([&] {
+        if (!out)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "out is null");
+        std::unique_ptr<msvs_cache> c(new msvs_cache);
+        c->capacity = capacity_bytes;
+        MSVS_HIP(hipGetDevice(&c->device));
+        *out = c.release();
+    });
+}
+
+extern "C" void msvs_cache_free(msvs_cache_t * c)
+{
+    if (!c)
+        return;
+    for (msvs_block * b : c->lru)
+        delete b;
+    delete c;
+}
+
+extern "C" int msvs_block_lookup(msvs_cache_t * c, const char * key, uint64_t mark, msvs_block_t ** out)
+{
+    return guarded([&] {
+        if (!c || !out)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null cache / out");
+        *out = nullptr;
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->map.find(msvs_cache::full_key(key, mark));
+        if (it == c->map.end())
+        {
+            c->misses++;
+            return;
+        }
+        msvs_block * b = it->second;
+        c->lru.splice(c->lru.begin(), c->lru, b->pos);
+        b->pins++;
+        c->hits++;
+        *out = b;
+    });
+}
+
+extern "C" int msvs_block_upload(msvs_cache_t * c, const char * key, uint64_t mark, const float * rows, size_t n, size_t d,
+                                 int normalize, msvs_block_t ** out)
+{
+    return guarded([&] {
+        if (!c || !out || (n && !rows) || d == 0 || d > 8192)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null cache / rows / out or bad dimension");
+        if (n > 0xfffffff0ull)
+            fail(MSVS_ERR_ID_RANGE, "block exceeds the u32 row range");
+        *out = nullptr;
+        const std::string fk = msvs_cache::full_key(key, mark);
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            auto it = c->map.find(fk);
+            if (it != c->map.end()) // another thread was faster: the resident copy wins
+            {
+                msvs_block * b = it->second;
+                if (b->n != n || b->d != d || b->normalized != (normalize ? 1 : 0))
+                    fail(MSVS_ERR_INVALID_ARGUMENT, "block `%s` is resident with another shape", fk.c_str());
+                c->lru.splice(c->lru.begin(), c->lru, b->pos);
+                b->pins++;
+                *out = b;
+                return;
+            }
+        }
+        std::unique_ptr<msvs_block> b(new msvs_block);
+        b->owner = c;
+        b->key = fk;
+        b->n = n;
+        b->d = d;
+        b->ld = padded_dim(d);
+        b->normalized = normalize ? 1 : 0;
+        b->rows.alloc(std::max<size_t>(n, 1) * b->ld);
+        hipStream_t stream = nullptr;
+        upload_rows(b->rows.p, rows, n, (uint32_t)d, b->ld, MSVS_MEM_HOST, stream);
+        if (normalize && n)
+        {
+            hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, b->rows.p, n,
+                               (uint32_t)d, b->ld);
+            MSVS_HIP(hipGetLastError());
+        }
+        MSVS_HIP(hipStreamSynchronize(stream));
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->map.find(fk);
+        if (it != c->map.end())
+        {
+            msvs_block * e = it->second;
+            c->lru.splice(c->lru.begin(), c->lru, e->pos);
+            e->pins++;
+            *out = e;
+            return; // b is dropped
+        }
+        c->make_room_locked(b->bytes());
+        c->lru.push_front(b.get());
+        b->pos = c->lru.begin();
+        b->pins = 1;
+        c->used += b->bytes();
+        c->map[fk] = b.get();
+        *out = b.release();
+    });
+}
+
+extern "C" void msvs_block_release(msvs_block_t * b)
+{
+    if (!b)
+        return;
+    msvs_cache_t * c = b->owner;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (--b->pins == 0 && b->doomed)
+        delete b;
+}
+
+extern "C" int msvs_cache_evict(msvs_cache_t * c, const char * key_prefix, size_t * evicted)
+{
+    return guarded([&] {
+        if (!c)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null cache");
+        const std::string pre = key_prefix ? key_prefix : "";
+        size_t cnt = 0;
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (auto it = c->lru.begin(); it != c->lru.end();)
+        {
+            msvs_block * b = *it;
+            ++it;
+            if (b->key.compare(0, pre.size(), pre) == 0)
+            {
+                c->drop_locked(b);
+                cnt++;
+            }
+        }
+        if (evicted)
+            *evicted = cnt;
+    });
+}
+
+extern "C" int msvs_cache_stats(msvs_cache_t * c, size_t * bytes, size_t * blocks, uint64_t * hits, uint64_t * misses,
+                                uint64_t * evictions)
+{
+    return guarded([&] {
+        if (!c)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null cache");
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (bytes)
+            *bytes = c->used;
+        if (blocks)
+            *blocks = c->map.size();
+        if (hits)
+            *hits = c->hits;
+        if (misses)
+            *misses = c->misses;
+        if (evictions)
+            *evictions = c->evictions;
+    });
+}
+
+extern "C" int msvs_knn_resident(const msvs_block_t * b, const float * x, size_t k, size_t nx, int metric,
+                                 const uint64_t * alive_bits, int64_t * ids, float * dis)
+{
+    return guarded([&] {
+        if (!b)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null block");
+        knn_host(x, nullptr, b->d, k, nx, b->n, metric, alive_bits, ids, dis, b->rows.p);
+    });
+}
+
 // =========================================================================================== seam A1
 
 struct msvs_index
@@ -267,7 +502,118 @@ struct msvs_index
     float h_scale = 0.f, h_inv_scale = 0.f; // stored value = fp16(x * h_scale)
     bool shadow_ready = false;
     bool ready = false;
+    // VIWithMeta (src/VectorIndex/Cache/VICacheObject.h:40-117): state that rides on a cached index.  Swapped under `meta_mu`
+    // (setDeleteBitmap is an atomic_store in the reference); a search keeps its own shared_ptr while it runs.
+    struct Meta
+    {
+        DevBuf<uint64_t> delete_alive; // 1 = not deleted, over the index labels; empty = nothing deleted
+        size_t delete_nbits = 0;
+        DevBuf<uint64_t> row_ids_map;  // decoupled part: label -> row of the merged part (transferToNewRowIds)
+        size_t row_ids_n = 0;
+        DevBuf<uint64_t> inv_row_ids;  // merged-part row -> label of its source part ...
+        DevBuf<uint8_t> inv_sources;   // ... and which source part (getRealBitmap keeps those of own_id)
+        size_t inv_n = 0;
+        uint32_t own_id = 0;
+    };
+    mutable std::mutex meta_mu;
+    std::shared_ptr<Meta> meta;
+    std::shared_ptr<Meta> get_meta() const
+    {
+        std::lock_guard<std::mutex> lk(meta_mu);
+        return meta;
+    }
 };
+
+static __global__ void and_bits_kernel(const uint64_t * a, size_t na, const uint64_t * b, size_t nb, uint64_t * out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = (i < na ? a[i] : 0ull) & (i < nb ? b[i] : 0ull);
+}
+
+/// getRealBitmap (src/VectorIndex/Utils/VIUtils.cpp:479-498): a filter over the rows of the merged (decoupled) part ->
+/// a filter over the labels of this source part's index.  out must be zeroed.
+static __global__ void real_bitmap_kernel(const uint64_t * filter_new, size_t nbits_new, const uint64_t * inv_ids,
+                                          const uint8_t * inv_src, uint32_t own_id, size_t n_new, size_t total_vec,
+                                          unsigned long long * out)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_new || r >= nbits_new)
+        return;
+    if (((filter_new[r >> 6] >> (r & 63)) & 1) && inv_src[r] == own_id)
+    {
+        const uint64_t old = inv_ids[r];
+        if (old < total_vec)
+            atomicOr(out + (old >> 6), 1ull << (old & 63));
+    }
+}
+
+/// transferToNewRowIds (VIWithDataPart.cpp:56-67): label -> row_ids_map[label] for every non-empty result slot.
+static __global__ void remap_ids_kernel(int64_t * ids, size_t n, const uint64_t * map, size_t map_n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ids[i] >= 0 && (uint64_t)ids[i] < map_n)
+        ids[i] = (int64_t)map[ids[i]];
+}
+
+/// The filter a search really runs with: (per-search filter, converted to label space for a decoupled part) AND the resident
+/// delete bitmap.  Returns the device pointer (nullptr = no filter) and its valid bits; scratch from aux_for(stream).
+static const uint64_t * effective_filter(const msvs_index & ix, const msvs_index::Meta * meta, const uint64_t * d_alive,
+                                         size_t nbits, size_t * eff_nbits, hipStream_t stream)
+{
+    *eff_nbits = nbits;
+    if (!meta)
+        return d_alive;
+    const bool convert = d_alive && meta->inv_n;
+    const bool deleted = meta->delete_alive.p != nullptr;
+    if (!convert && !deleted)
+        return d_alive;
+    const size_t total = (size_t)ix.max_id + 1;
+    const size_t words = ceil_div(total, (size_t)64) + 1;
+    Scratch & aux = aux_for(stream);
+    aux.reserve(2 * words * 8 + 1024, stream);
+    const uint64_t * cur = d_alive;
+    size_t cur_bits = nbits;
+    if (convert)
+    {
+        uint64_t * real = aux.take<uint64_t>(words);
+        MSVS_HIP(hipMemsetAsync(real, 0, words * 8, stream));
+        const size_t n = std::min(meta->inv_n, nbits);
+        if (n)
+            hipLaunchKernelGGL(real_bitmap_kernel, dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, d_alive, nbits,
+                               meta->inv_row_ids.p, meta->inv_sources.p, meta->own_id, meta->inv_n, total,
+                               reinterpret_cast<unsigned long long *>(real));
+        cur = real;
+        cur_bits = total;
+    }
+    if (deleted)
+    {
+        if (!cur) // no per-search filter: the delete bitmap alone
+        {
+            *eff_nbits = meta->delete_nbits;
+            return meta->delete_alive.p;
+        }
+        uint64_t * both = aux.take<uint64_t>(words);
+        const size_t bits = std::min(cur_bits, meta->delete_nbits);
+        hipLaunchKernelGGL(and_bits_kernel, dim3((unsigned)ceil_div(words, (size_t)256)), dim3(256), 0, stream, cur,
+                           ceil_div(cur_bits, (size_t)64), meta->delete_alive.p, ceil_div(meta->delete_nbits, (size_t)64), both,
+                           words);
+        cur = both;
+        cur_bits = bits;
+    }
+    MSVS_HIP(hipGetLastError());
+    *eff_nbits = cur_bits;
+    return cur;
+}
+
+static void apply_row_ids_map(const msvs_index::Meta * meta, int64_t * d_ids, size_t n, hipStream_t stream)
+{
+    if (!meta || !meta->row_ids_n || !n)
+        return;
+    hipLaunchKernelGGL(remap_ids_kernel, dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, d_ids, n,
+                       meta->row_ids_map.p, meta->row_ids_n);
+    MSVS_HIP(hipGetLastError());
+}
 
 /// The fp16 shadow of an IVF index (see h16_scan_kernels.hpp); called once the final storage and the norms are in place.
 static void index_build_shadow(msvs_index & ix, hipStream_t stream)
@@ -1623,8 +1969,12 @@ extern "C" int msvs_index_search_device(const msvs_index_t * ix, const float * d
     return guarded([&] {
         if (!ix || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index/buffer or negative k");
-        index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), d_alive_bits, nbits, d_ids,
-                            d_dis, as_stream(hip_stream));
+        const auto meta = ix->get_meta();
+        size_t eff_bits = nbits;
+        const uint64_t * eff = effective_filter(*ix, meta.get(), d_alive_bits, nbits, &eff_bits, as_stream(hip_stream));
+        index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids, d_dis,
+                            as_stream(hip_stream));
+        apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, as_stream(hip_stream));
     });
 }
 
@@ -1666,22 +2016,26 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
             if (nbits)
                 MSVS_HIP(hipMemcpyAsync(d_alive.p, alive_bits, ceil_div(nbits, 64) * 8, hipMemcpyHostToDevice, stream));
         }
+        const auto meta = ix->get_meta();
+        size_t eff_bits = nbits;
+        const uint64_t * eff = effective_filter(*ix, meta.get(), words ? d_alive.p : nullptr, nbits, &eff_bits, stream);
+        const bool eff_filtered = eff != nullptr;
         if ((size_t)k <= MSVS_MAX_K)
-            index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, words ? d_alive.p : nullptr, nbits,
-                                d_ids.p, d_dis.p, stream);
+            index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, d_ids.p, d_dis.p, stream);
         else
         {
             // k beyond one wavefront top-k pass: rounds of MSVS_MAX_K per query, each round excluding the rows already
             // returned through a private copy of the filter bitmap (exact: round r returns ranks 256r .. 256r+255)
-            const size_t idspace = std::max<size_t>(filtered ? nbits : 0, (size_t)ix->max_id + 1);
+            const size_t idspace = std::max<size_t>(eff_filtered ? eff_bits : 0, (size_t)ix->max_id + 1);
             const size_t bw = ceil_div(idspace, 64);
             DevBuf<uint64_t> bm(bw);
             for (size_t q = 0; q < nq; q++)
             {
-                if (filtered)
+                if (eff_filtered)
                 {
                     MSVS_HIP(hipMemsetAsync(bm.p, 0, bw * 8, stream));
-                    MSVS_HIP(hipMemcpyAsync(bm.p, d_alive.p, words * 8, hipMemcpyDeviceToDevice, stream));
+                    MSVS_HIP(hipMemcpyAsync(bm.p, eff, std::max<size_t>(1, ceil_div(eff_bits, (size_t)64)) * 8,
+                                            hipMemcpyDeviceToDevice, stream));
                 }
                 else
                     MSVS_HIP(hipMemsetAsync(bm.p, 0xFF, bw * 8, stream));
@@ -1689,16 +2043,93 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
                 {
                     const uint32_t kr = (uint32_t)std::min<size_t>(MSVS_MAX_K, (size_t)k - done);
                     int64_t * oi = d_ids.p + q * (size_t)k + done;
-                    index_search_device(*ix, dq.p + q * ix->dim, 1, kr, (size_t)nprobe, bm.p, filtered ? nbits : idspace,
+                    index_search_device(*ix, dq.p + q * ix->dim, 1, kr, (size_t)nprobe, bm.p, eff_filtered ? eff_bits : idspace,
                                         oi, d_dis.p + q * (size_t)k + done, stream);
                     hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(256), 0, stream, bm.p, oi, kr);
                     MSVS_HIP(hipGetLastError());
                 }
             }
         }
+        apply_row_ids_map(meta.get(), d_ids.p, nq * (size_t)k, stream);
         MSVS_HIP(hipMemcpyAsync(ids, d_ids.p, nq * (size_t)k * 8, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipMemcpyAsync(dis, d_dis.p, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipStreamSynchronize(stream));
+    });
+}
+
+/// VIWithMeta::setDeleteBitmap (VICacheObject.h:100-102): the lightweight-delete state of a cached index, resident in HBM
+/// and swapped atomically; every search ANDs it into its filter (VIWithDataPart.cpp:903-908).  alive_bits NULL clears it.
+extern "C" int msvs_index_set_delete_bitmap(msvs_index_t * ix, const uint64_t * alive_bits, size_t nbits)
+{
+    return guarded([&] {
+        if (!ix)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
+        auto cur = ix->get_meta();
+        auto next = std::make_shared<msvs_index::Meta>();
+        if (alive_bits)
+        {
+            const size_t words = std::max<size_t>(1, ceil_div(nbits, (size_t)64));
+            next->delete_alive.alloc(words);
+            MSVS_HIP(hipMemset(next->delete_alive.p, 0, words * 8));
+            if (nbits)
+                MSVS_HIP(hipMemcpy(next->delete_alive.p, alive_bits, ceil_div(nbits, (size_t)64) * 8, hipMemcpyHostToDevice));
+            next->delete_nbits = nbits;
+        }
+        if (cur) // the maps are immutable once set: share them by copying device to device
+        {
+            auto dup = [](auto & dst, const auto & src) {
+                if (src.n)
+                {
+                    dst.alloc(src.n);
+                    MSVS_HIP(hipMemcpy(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice));
+                }
+            };
+            dup(next->row_ids_map, cur->row_ids_map);
+            dup(next->inv_row_ids, cur->inv_row_ids);
+            dup(next->inv_sources, cur->inv_sources);
+            next->row_ids_n = cur->row_ids_n;
+            next->inv_n = cur->inv_n;
+            next->own_id = cur->own_id;
+        }
+        std::lock_guard<std::mutex> lk(ix->meta_mu);
+        ix->meta = next;
+    });
+}
+
+/// The row-id maps of a decoupled part (SegmentId::getMergedMaps, VIWithDataPart.cpp:722): once set, a search takes its
+/// filter in the MERGED part's row space (getRealBitmap) and reports the MERGED part's rows (transferToNewRowIds).
+extern "C" int msvs_index_set_merged_maps(msvs_index_t * ix, const uint64_t * row_ids_map, size_t n_old,
+                                          const uint64_t * inverted_row_ids_map, const uint8_t * inverted_row_sources_map,
+                                          size_t n_new, uint32_t own_id)
+{
+    return guarded([&] {
+        if (!ix || (n_old && !row_ids_map) || (n_new && (!inverted_row_ids_map || !inverted_row_sources_map)))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index / map");
+        auto cur = ix->get_meta();
+        auto next = std::make_shared<msvs_index::Meta>();
+        if (cur && cur->delete_alive.n)
+        {
+            next->delete_alive.alloc(cur->delete_alive.n);
+            MSVS_HIP(hipMemcpy(next->delete_alive.p, cur->delete_alive.p, cur->delete_alive.bytes(), hipMemcpyDeviceToDevice));
+            next->delete_nbits = cur->delete_nbits;
+        }
+        if (n_old)
+        {
+            next->row_ids_map.alloc(n_old);
+            MSVS_HIP(hipMemcpy(next->row_ids_map.p, row_ids_map, n_old * 8, hipMemcpyHostToDevice));
+            next->row_ids_n = n_old;
+        }
+        if (n_new)
+        {
+            next->inv_row_ids.alloc(n_new);
+            next->inv_sources.alloc(n_new);
+            MSVS_HIP(hipMemcpy(next->inv_row_ids.p, inverted_row_ids_map, n_new * 8, hipMemcpyHostToDevice));
+            MSVS_HIP(hipMemcpy(next->inv_sources.p, inverted_row_sources_map, n_new, hipMemcpyHostToDevice));
+            next->inv_n = n_new;
+        }
+        next->own_id = own_id;
+        std::lock_guard<std::mutex> lk(ix->meta_mu);
+        ix->meta = next;
     });
 }
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsvs_host.so")
 SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_host_total_topk",
            "msvs_host_hybrid_search", "msvs_host_merge_topk", "msvs_host_sum_bm25_stats",
            "msvs_host_vector_scan_without_index", "msvs_host_merge_search_result",
-           "msvs_host_generate_vector_dataset"]
+           "msvs_host_generate_vector_dataset", "msvs_host_vector_scan_resident"]
 
 _lib = None
 
@@ -73,9 +73,10 @@ def search_wrapper(query, base, k, metric, final_id, final_distance, num_rows_re
 
 
 def vector_scan_without_index(rows, dim, index_granularity, queries, k, metric, is_batch=False, filt=None,
-                              row_exists=None):
+                              row_exists=None, cache=None, part_key=""):
     """MergeTreeVSManager::vectorScanWithoutIndex over one part given as a list of per-row vectors (an empty list /
     None = a row without a vector), converted to the ColumnArray layout (offsets + flat data).
+    cache (capi.Cache) + part_key: the resident-block variant (msvs_host_vector_scan_resident).
     -> (labels uint32[n], query_ids uint32[n] or None, distances f32[n])"""
     offsets = np.zeros(len(rows), np.uint64)
     flat = []
@@ -94,6 +95,13 @@ def vector_scan_without_index(rows, dim, index_granularity, queries, k, metric, 
     qids = np.empty(nq * k, np.uint32)
     dist = np.empty(nq * k, np.float32)
     n = C.c_size_t(0)
+    if cache is not None:
+        capi._check(lib().msvs_host_vector_scan_resident(
+            cache._h, part_key.encode(), _p(offsets, C.c_uint64), _p(data, C.c_float), C.c_size_t(len(rows)),
+            C.c_size_t(dim), C.c_size_t(index_granularity), _p(q, C.c_float), C.c_size_t(nq), int(k), int(metric),
+            int(is_batch), _p(fb, C.c_uint64), _p(eb, C.c_uint64), _p(labels, C.c_uint32), _p(qids, C.c_uint32),
+            _p(dist, C.c_float), C.byref(n)))
+        return labels[:n.value], (qids[:n.value] if is_batch else None), dist[:n.value]
     capi._check(lib().msvs_host_vector_scan_without_index(
         _p(offsets, C.c_uint64), _p(data, C.c_float), C.c_size_t(len(rows)), C.c_size_t(dim),
         C.c_size_t(index_granularity), _p(q, C.c_float), C.c_size_t(nq), int(k), int(metric), int(is_batch),

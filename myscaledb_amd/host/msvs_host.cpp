@@ -105,9 +105,16 @@ void MergeTreeVSManager::searchWrapper(bool prewhere, VectorIndex::VectorDataset
         for (auto & id : per_id)
             if (id > -1)
                 id = static_cast<int64_t>(actual_id_in_range[static_cast<size_t>(id)]);
+    mergeBlockResult(per_id, per_distance, k, nq, num_rows_read, final_id, final_distance, metric);
+}
 
+void MergeTreeVSManager::mergeBlockResult(const std::vector<int64_t> & per_id, const std::vector<float> & per_distance, int k,
+                                          int nq, int num_rows_read, std::vector<int64_t> & final_id,
+                                          std::vector<float> & final_distance, const VIMetric & metric)
+{
     // two-way merge of the sorted block result into the sorted running result; strict comparison, so on equal
     // distances the running (earlier block) entry is kept first
+    const size_t slots = static_cast<size_t>(k) * nq;
     std::vector<float> merged_distance(slots);
     std::vector<int64_t> merged_id(slots);
     const bool larger_is_better = metric == VIMetric::IP;
@@ -224,6 +231,91 @@ VectorScanResult MergeTreeVSManager::vectorScanWithoutIndex(const ColumnArrayVie
     // result columns: only filled slots (id > -1); batch_distance adds the query id = slot / k
     VectorScanResult res;
     for (size_t slot = 0; slot < static_cast<size_t>(k) * nq; slot++)
+    {
+        if (final_id[slot] <= -1)
+            continue;
+        res.labels.push_back(static_cast<uint32_t>(final_id[slot]));
+        if (is_batch)
+            res.query_ids.push_back(static_cast<uint32_t>(slot / static_cast<size_t>(k)));
+        res.distances.push_back(final_distance[slot]);
+    }
+    res.computed = true;
+    return res;
+}
+
+VectorScanResult MergeTreeVSManager::vectorScanWithoutIndexResident(msvs_cache_t * cache, const std::string & part_key,
+                                                                    const ColumnArrayView & column, size_t dim,
+                                                                    size_t index_granularity, const std::vector<float> & queries,
+                                                                    size_t nq, int k, const VIMetric & metric, bool is_batch,
+                                                                    const VIBitmapView * filter, const VIBitmapView * row_exists)
+{
+    const float worst = metric == VIMetric::IP ? std::numeric_limits<float>::min() : std::numeric_limits<float>::max();
+    const size_t slots = static_cast<size_t>(k) * nq;
+    std::vector<float> final_distance(slots, worst);
+    std::vector<int64_t> final_id(slots, -1);
+    const size_t total_rows = column.rows;
+    auto row_begin = [&](size_t r) { return r == 0 ? 0 : column.offsets[r - 1]; };
+    // cosine: the block is stored normalised (once, at upload); the queries are normalised per call like searchWithoutIndex does
+    std::vector<float> q = queries;
+    VIMetric m = metric;
+    if (metric == VIMetric::Cosine)
+    {
+        m = VIMetric::IP;
+        VectorIndex::VectorDataset qd{q.data(), static_cast<int64_t>(nq), static_cast<int64_t>(dim)};
+        qd.normalize();
+    }
+    std::vector<float> block;
+    for (size_t mark_start = 0, mark = 0; mark_start < total_rows; mark_start += index_granularity, mark++)
+    {
+        const size_t mark_end = std::min(total_rows, mark_start + index_granularity), block_rows = mark_end - mark_start;
+        msvs_block_t * blk = nullptr;
+        VectorIndex::throwIfError(msvs_block_lookup(cache, part_key.c_str(), mark, &blk));
+        if (!blk)
+        {
+            // the dense block of the mark exactly as the scan builds it: rows without a vector padded with FLT_MAX
+            block.assign(block_rows * dim, std::numeric_limits<float>::max());
+            for (size_t r = mark_start; r < mark_end; r++)
+            {
+                const uint64_t b = row_begin(r), e = column.offsets[r];
+                if (e - b == dim)
+                    std::copy(column.data + b, column.data + e, block.begin() + (r - mark_start) * dim);
+            }
+            VectorIndex::throwIfError(msvs_block_upload(cache, part_key.c_str(), mark, block.data(), block_rows, dim,
+                                                        metric == VIMetric::Cosine ? 1 : 0, &blk));
+        }
+        // rows the search may return: not lightweight-deleted; with a filter only the passing rows that carry a vector
+        // (the filter path of the reference compacts exactly those rows, :1042-1330)
+        std::vector<uint64_t> alive;
+        if (filter || row_exists)
+        {
+            alive.assign((block_rows + 63) / 64, 0);
+            for (size_t r = mark_start; r < mark_end; r++)
+            {
+                bool ok = !row_exists || row_exists->is_member(r);
+                if (ok && filter)
+                    ok = filter->is_member(r) && column.offsets[r] != row_begin(r);
+                if (ok)
+                    alive[(r - mark_start) >> 6] |= 1ull << ((r - mark_start) & 63);
+            }
+        }
+        std::vector<float> per_distance(slots, worst);
+        std::vector<int64_t> per_id(slots, -1);
+        const int rc = msvs_knn_resident(blk, q.data(), static_cast<size_t>(k), nq, static_cast<int>(m),
+                                         alive.empty() ? nullptr : alive.data(), per_id.data(), per_distance.data());
+        msvs_block_release(blk);
+        VectorIndex::throwIfError(rc);
+        for (size_t i = 0; i < slots; i++)
+        {
+            if (metric == VIMetric::Cosine)
+                per_distance[i] = 1 - per_distance[i];
+            if (per_id[i] < 0)
+                per_distance[i] = worst;
+        }
+        mergeBlockResult(per_id, per_distance, k, static_cast<int>(nq), static_cast<int>(mark_start), final_id, final_distance,
+                         metric);
+    }
+    VectorScanResult res;
+    for (size_t slot = 0; slot < slots; slot++)
     {
         if (final_id[slot] <= -1)
             continue;
@@ -451,6 +543,31 @@ extern "C" int msvs_host_vector_scan_without_index(const uint64_t * offsets, con
         auto res = DB::MergeTreeVSManager::vectorScanWithoutIndex(col, dim, index_granularity, q, nq, k,
                                                                   static_cast<VectorIndex::VIMetric>(metric), is_batch != 0,
                                                                   filter_bits ? &f : nullptr, row_exists_bits ? &e : nullptr);
+        for (size_t i = 0; i < res.labels.size(); i++)
+        {
+            out_labels[i] = res.labels[i];
+            out_distances[i] = res.distances[i];
+            if (is_batch)
+                out_query_ids[i] = res.query_ids[i];
+        }
+        *n_out = res.labels.size();
+    });
+}
+
+extern "C" int msvs_host_vector_scan_resident(msvs_cache_t * cache, const char * part_key, const uint64_t * offsets,
+                                              const float * data, size_t rows, size_t dim, size_t index_granularity,
+                                              const float * queries, size_t nq, int k, int metric, int is_batch,
+                                              const uint64_t * filter_bits, const uint64_t * row_exists_bits,
+                                              uint32_t * out_labels, uint32_t * out_query_ids, float * out_distances,
+                                              size_t * n_out)
+{
+    return guarded([&] {
+        DB::ColumnArrayView col{offsets, data, rows};
+        std::vector<float> q(queries, queries + nq * dim);
+        DB::VIBitmapView f{filter_bits}, e{row_exists_bits};
+        auto res = DB::MergeTreeVSManager::vectorScanWithoutIndexResident(
+            cache, part_key ? part_key : "", col, dim, index_granularity, q, nq, k, static_cast<VectorIndex::VIMetric>(metric),
+            is_batch != 0, filter_bits ? &f : nullptr, row_exists_bits ? &e : nullptr);
         for (size_t i = 0; i < res.labels.size(); i++)
         {
             out_labels[i] = res.labels[i];

@@ -108,6 +108,11 @@ struct MergeTreeVSManager
                               const std::vector<size_t> & actual_id_in_range, const VIMetric & metric,
                               const VIBitmapView & row_exists, int delete_id_num);
 
+    /// The block-vs-running two-way merge at the end of searchWrapper (MergeTreeVSManager.cpp:1652-1678).
+    static void mergeBlockResult(const std::vector<int64_t> & per_id, const std::vector<float> & per_distance, int k, int nq,
+                                 int num_rows_read, std::vector<int64_t> & final_id, std::vector<float> & final_distance,
+                                 const VIMetric & metric);
+
     /// getQueryVector / getFloatQueryVectorInBatch (MergeTreeVSManager.cpp:59-181): Array(Float32|Float64) query
     /// constants -> row-major f32; a row whose length differs from `dim` is an error like in the reference.
     static std::vector<float> generateVectorDataset(const void * values, bool is_float64, const uint64_t * offsets,
@@ -121,6 +126,16 @@ struct MergeTreeVSManager
                                                    const std::vector<float> & queries, size_t nq, int k,
                                                    const VIMetric & metric, bool is_batch, const VIBitmapView * filter,
                                                    const VIBitmapView * row_exists);
+
+    /// The same scan over RESIDENT blocks (msvs_cache_t): the dense block of a mark is uploaded the
+    /// first time any query touches the part (keyed by part_key / mark) and searched in HBM afterwards; lightweight
+    /// deletes and PREWHERE filters become the search's row bitmap over the resident block instead of a per-query
+    /// compaction + upload.  Same result columns as vectorScanWithoutIndex.
+    static VectorScanResult vectorScanWithoutIndexResident(msvs_cache_t * cache, const std::string & part_key,
+                                                           const ColumnArrayView & column, size_t dim,
+                                                           size_t index_granularity, const std::vector<float> & queries,
+                                                           size_t nq, int k, const VIMetric & metric, bool is_batch,
+                                                           const VIBitmapView * filter, const VIBitmapView * row_exists);
 };
 
 /// MergeTreeBaseSearchManager::mergeSearchResultImpl (MergeTreeBaseSearchManager.cpp:23-164), reduced to its join:

@@ -176,6 +176,17 @@ def main():
         "text_search_1part": sect41("Text search result with 1 part after optimize final", 2),
         "rsf_1part": sect41("Hybrid search RSF result with 1 part after optimize final", 5)}
 
+    # 00016 / 00032: lightweight deletes (delete bitmap over an index that is exact on these sizes; small marks in 00032)
+    ids, ds = rows3(ref_lines("00016_mqvs_lightweight_delete_with_vector")[2:12])
+    g["00016_lwd"] = {"source": "00016_mqvs_lightweight_delete_with_vector.sql/.reference",
+                      "base": [{"kind": "nnn", "start": 0, "count": 2100, "dim": 3}], "index_granularity": 1024,
+                      "metric": "L2", "queries": [[0.1, 0.1, 0.1]], "k": 10, "deleted": [2], "ids": [ids], "dists": [ds]}
+    ids, ds = rows3(ref_lines("00032_mqvs_lightweight_delete_small_ranges")[2:12])
+    g["00032_lwd_small_ranges"] = {"source": "00032_mqvs_lightweight_delete_small_ranges.sql/.reference",
+                                   "base": [{"kind": "nnn", "start": 0, "count": 100, "dim": 3}], "index_granularity": 3,
+                                   "metric": "L2", "queries": [[1.0, 1.0, 1.0]], "k": 10, "deleted": [2, 3, 8],
+                                   "ids": [ids], "dists": [ds]}
+
     # 00038: binary vectors FixedString(4), rows char(n, n, n, n) for n in 0..1023 (bytes n % 256), brute force Hamming /
     # Jaccard: single query, batch of 3 (LIMIT 10 BY query), WHERE id > 100 and id < 120; after LWD of id < 200 (Hamming)
     ln = ref_lines("00038_mqvs_binary_vector_feature")

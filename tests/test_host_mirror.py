@@ -190,3 +190,133 @@ def test_float64_query_through_the_index_matches_float32_cast():
     ids, dis = ix.search(q, 10)
     oi, od = o.knn(q64.astype(np.float32), x, 10, o.METRIC_L2)
     assert (ids == oi).all() and (dis == od).all()
+
+
+# ---------------------------------------------------------------------------------------- resident blocks (f1)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["00012_brute_force", "00009_brute_force_filter", "00010_brute_force_filter",
+                                  "00011_brute_force_filter", "00014_cosine_bruteforce", "00016_lwd",
+                                  "00032_lwd_small_ranges"])
+def test_brute_force_goldens_through_resident_blocks(name):
+    """The same goldens through the resident-block scan: the first query uploads the part's marks, the second one only
+    sends its vector; filters and lightweight deletes are row bitmaps over the resident blocks."""
+    c = G[name]
+    ids, vecs, empty = materialize(c["base"])
+    filt = eval_filter(c["filter"], ids) if c.get("filter") else None
+    exists = ~np.isin(ids, c["deleted"]) if c.get("deleted") else None
+    gran = c.get("index_granularity", 8192)
+    cache = capi.Cache(64 << 20)
+    marks = -(-len(ids) // gran)
+    for round_ in range(2):
+        labels, _, dist = host.vector_scan_without_index(_rows(vecs, empty), vecs.shape[1], gran, c["queries"], c["k"],
+                                                         capi.METRICS[c["metric"]], filt=filt, row_exists=exists,
+                                                         cache=cache, part_key="all_1_1_0/" + name)
+        assert ids[labels].tolist() == c["ids"][0]
+        assert dist.tolist() == f32_of(c["dists"][0]).tolist()
+        st = cache.stats()
+        assert st["blocks"] == marks and st["misses"] == marks and st["hits"] == round_ * marks
+    assert cache.evict("all_1_1_0/") == marks and cache.stats()["blocks"] == 0 and cache.stats()["bytes"] == 0
+    cache.close()
+
+
+@pytest.mark.gpu
+def test_resident_cache_lru_pins_and_eviction():
+    rng = np.random.default_rng(3)
+    d, n = 64, 1000
+    blk = n * d * 4
+    cache = capi.Cache(3 * blk + 100)  # room for three blocks
+    xs = [rng.standard_normal((n, d), dtype=np.float32) for _ in range(5)]
+    q = rng.standard_normal((2, d), dtype=np.float32)
+    hs = [cache.upload("t/p1", m, xs[m]) for m in range(3)]
+    for h in hs:
+        cache.release(h)
+    assert cache.stats()["blocks"] == 3
+    h0 = cache.lookup("t/p1", 0)  # touch + pin mark 0: marks 1, 2 are now the least recently used
+    h3 = cache.upload("t/p1", 3, xs[3])
+    assert cache.lookup("t/p1", 1) is None and cache.stats()["evictions"] == 1
+    h4 = cache.upload("t/p2", 4, xs[4])
+    assert cache.lookup("t/p1", 2) is None  # evicted; the pinned mark 0 survived although it was the oldest upload
+    ids, dis = capi.knn_resident(h0, q, 5, capi.METRIC_L2, d)
+    oi, od = o.knn(q, xs[0], 5, o.METRIC_L2)
+    assert (ids == oi).all() and (dis == od).all()
+    alive = rng.random(n) < 0.5
+    ids, dis = capi.knn_resident(h3, q, 5, capi.METRIC_IP, d, alive=alive)
+    oi, od = o.knn(q, xs[3], 5, o.METRIC_IP, alive=alive)
+    assert (ids == oi).all() and (dis == od).all()
+    # an evicted-while-pinned block stays usable until its last release
+    assert cache.evict("t/p1") == 2
+    ids, dis = capi.knn_resident(h0, q, 5, capi.METRIC_L2, d)
+    oi, od = o.knn(q, xs[0], 5, o.METRIC_L2)
+    assert (ids == oi).all()
+    for h in (h0, h3, h4):
+        cache.release(h)
+    st = cache.stats()
+    assert st["blocks"] == 1 and st["bytes"] == blk
+    # cosine: the block is stored normalised
+    hc = cache.upload("t/cos", 0, xs[1], normalize=True)
+    qn = o.normalize_rows(q)
+    ids, dis = capi.knn_resident(hc, qn, 5, capi.METRIC_IP, d)
+    oi, od = o.knn(qn, o.normalize_rows(xs[1]), 5, o.METRIC_IP)
+    assert (ids == oi).all() and (dis == od).all()
+    cache.release(hc)
+    cache.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", [capi.INDEX_FLAT, capi.INDEX_IVFFLAT])
+def test_index_meta_delete_bitmap_and_decoupled_part_row_ids(typ):
+    """VIWithMeta on a cached index: resident delete bitmap (goldens 00016 / 00032) and the row-id maps of a decoupled
+    part -- the filter arrives in the merged part's row space (getRealBitmap), results leave in it (transferToNewRowIds)."""
+    for name in ("00016_lwd", "00032_lwd_small_ranges"):
+        c = G[name]
+        ids, vecs, empty = materialize(c["base"])
+        ix = capi.Index(typ, capi.METRIC_L2, 3, "ncentroids=4,kmeans_iters=3")
+        if typ == capi.INDEX_IVFFLAT:
+            ix.train(vecs)
+        ix.add(vecs)
+        ix.build()
+        ix.set_delete_bitmap(~np.isin(ids, c["deleted"]))
+        got, dist = ix.search(np.array(c["queries"], np.float32), c["k"], "nprobe=4" if typ == capi.INDEX_IVFFLAT else "")
+        assert got[0].tolist() == c["ids"][0] and dist[0].tolist() == f32_of(c["dists"][0]).tolist()
+        # a per-search filter is ANDed with it on the device
+        flt = ids % 2 == 0
+        got, _ = ix.search(np.array(c["queries"], np.float32), c["k"], "nprobe=4" if typ == capi.INDEX_IVFFLAT else "", alive=flt)
+        oi, _ = o.knn(np.array(c["queries"], np.float32), vecs, c["k"], o.METRIC_L2, alive=flt & ~np.isin(ids, c["deleted"]))
+        assert got[0].tolist() == oi[0].tolist()
+        ix.set_delete_bitmap(None)
+        got, _ = ix.search(np.array(c["queries"], np.float32), c["k"], "nprobe=4" if typ == capi.INDEX_IVFFLAT else "")
+        oi, _ = o.knn(np.array(c["queries"], np.float32), vecs, c["k"], o.METRIC_L2)
+        assert got[0].tolist() == oi[0].tolist()
+    # decoupled part: this source part (own_id 1) owns the odd rows of a merged part of 2 n rows, shuffled
+    rng = np.random.default_rng(12)
+    n, d = 1500, 24
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((4, d), dtype=np.float32)
+    new_rows = rng.permutation(2 * n)
+    row_ids_map = np.sort(new_rows[:n])  # label i of the old part lives at merged row row_ids_map[i]
+    inv_ids = np.zeros(2 * n, np.uint64)
+    inv_src = np.zeros(2 * n, np.uint8)
+    inv_ids[row_ids_map] = np.arange(n)
+    inv_src[row_ids_map] = 1
+    other = np.setdiff1d(np.arange(2 * n), row_ids_map)
+    inv_ids[other] = np.arange(n)  # the other source part's labels
+    inv_src[other] = 0
+    ix = capi.Index(typ, capi.METRIC_L2, d, "ncentroids=8,kmeans_iters=3")
+    if typ == capi.INDEX_IVFFLAT:
+        ix.train(x)
+    ix.add(x)
+    ix.build()
+    ix.set_merged_maps(row_ids_map, inv_ids, inv_src, 1)
+    params = "nprobe=8" if typ == capi.INDEX_IVFFLAT else ""
+    got, dist = ix.search(q, 10, params)
+    oi, od = o.knn(q, x, 10, o.METRIC_L2)
+    assert (got == row_ids_map[oi]).all() and (dist == od).all()
+    flt_new = rng.random(2 * n) < 0.4  # a filter over the MERGED part's rows
+    got, dist = ix.search(q, 10, params, alive=flt_new)
+    oi, od = o.knn(q, x, 10, o.METRIC_L2, alive=flt_new[row_ids_map])
+    assert (got == np.where(oi >= 0, row_ids_map[np.maximum(oi, 0)], -1)).all() and (dist == od).all()
+    ix.set_delete_bitmap(np.arange(n) % 3 != 0)  # plus a delete bitmap in the OLD label space
+    got, dist = ix.search(q, 10, params, alive=flt_new)
+    oi, od = o.knn(q, x, 10, o.METRIC_L2, alive=flt_new[row_ids_map] & (np.arange(n) % 3 != 0))
+    assert (got == np.where(oi >= 0, row_ids_map[np.maximum(oi, 0)], -1)).all() and (dist == od).all()

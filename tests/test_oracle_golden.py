@@ -253,3 +253,13 @@ def test_binary_vector_goldens(case):
         alive = np.arange(c["rows"]) >= c["lwd_deleted_below"]
         ids, dis = o.knn_bin(np.array([c["query"]], np.uint8), y, 10, metric, alive=alive)
         assert ids[0].tolist() == c["lwd_ids"] and dis[0].tolist() == f32_of(c["lwd_dists"]).tolist()
+
+
+@pytest.mark.parametrize("name", ["00016_lwd", "00032_lwd_small_ranges"])
+def test_lightweight_delete_goldens(name):
+    """00016 / 00032: rows deleted by lightweight delete never come back (delete bitmap over the part's rows)."""
+    c = G[name]
+    ids, vecs, empty = materialize(c["base"])
+    alive = ~np.isin(ids, c["deleted"])
+    oi, od = o.knn(np.array(c["queries"], np.float32), vecs, c["k"], o.METRIC_L2, alive=alive)
+    assert ids[oi[0]].tolist() == c["ids"][0] and od[0].tolist() == f32_of(c["dists"][0]).tolist()
