@@ -234,6 +234,31 @@ MSVS_API int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks);
  * MSVS_ERR_INVALID_ARGUMENT for an unknown name. */
 MSVS_API int msvs_set_option(const char * name, const char * value);
 
+/* Multi-GPU: one process per GPU, every process holds ONE shard of the index (msvs_index_create params
+ * shard_rank / shard_world: IVF lists list_id % world, FLAT row ranges; centroids replicated) and a communicator.
+ * msvs_shard_search_device is the whole sharded search as ONE stream-ordered call: the coarse quantiser sharded by
+ * query + one all-gather of the probe lists, the scan of the local lists, one all-gather of the packed partial top-k
+ * (nq * k * 12 B per rank over xGMI) and the canonical W-way merge -- the device-side analogue of the per-part searches
+ * + getTotalTopSearchResultImpl (MergeTreeBaseSearchManager.cpp:207-299).  Every rank calls it with the SAME queries
+ * and gets the SAME result (ids bit-exact with the unsharded index).
+ * The communicator is RCCL (librccl resolved at first use, straight rccl.h calls): rank 0 creates the id
+ * (msvs_comm_unique_id), the host distributes its MSVS_COMM_ID_BYTES bytes by any means it has (ClickHouse: its own
+ * TCP / Keeper), every rank calls msvs_comm_init on its device.  msvs_comm_init_custom plugs a caller-supplied
+ * all-gather instead (tests run two ranks on one GPU over gloo): it must gather `bytes` from d_send of every rank into
+ * d_recv[rank * bytes ...] of every rank, ordered after the work already enqueued on `hip_stream`, and return 0. */
+#define MSVS_COMM_ID_BYTES 128
+typedef struct msvs_comm msvs_comm_t;
+typedef int (*msvs_allgather_fn)(void * ctx, const void * d_send, void * d_recv, size_t bytes, void * hip_stream);
+MSVS_API int msvs_comm_unique_id(void * id_out /* MSVS_COMM_ID_BYTES */);
+MSVS_API int msvs_comm_init(const void * id, int nranks, int rank, msvs_comm_t ** out);
+MSVS_API int msvs_comm_init_custom(int nranks, int rank, msvs_allgather_fn all_gather, void * ctx, msvs_comm_t ** out);
+MSVS_API void msvs_comm_free(msvs_comm_t * comm);
+MSVS_API int msvs_comm_rank(const msvs_comm_t * comm);
+MSVS_API int msvs_comm_size(const msvs_comm_t * comm);
+MSVS_API int msvs_shard_search_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries,
+                                      size_t nq, int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits,
+                                      int64_t * d_ids, float * d_dis, void * hip_stream);
+
 /* Multi-part / multi-GPU merge of partial top-k lists with the canonical total order -- the
  * device-side analogue of MergeTreeBaseSearchManager::getTotalTopSearchResultImpl
  * (src/VectorIndex/Storages/MergeTreeBaseSearchManager.cpp:207-299) for lists that share one id space.

@@ -31,7 +31,8 @@ SYMBOLS = [
     "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
     "msvs_cache_create", "msvs_cache_free", "msvs_block_upload", "msvs_block_lookup", "msvs_block_release",
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
-    "msvs_index_set_merged_maps",
+    "msvs_index_set_merged_maps", "msvs_comm_unique_id", "msvs_comm_init", "msvs_comm_init_custom",
+    "msvs_comm_free", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device",
 ]
 
 
@@ -242,6 +243,43 @@ def knn_resident(block, x, k, metric, d, alive=None):
     return ids, dis
 
 
+COMM_ID_BYTES = 128
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+def comm_unique_id():
+    """msvs_comm_unique_id (rank 0): the bytes every rank needs for Comm(id=...)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(lib().msvs_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """msvs_comm_t: RCCL communicator owned by libmsvs (id = bytes from comm_unique_id()), or a caller-supplied
+    all-gather (all_gather = python callable(d_send, d_recv, nbytes, stream) -> 0) for tests."""
+
+    def __init__(self, nranks, rank, id=None, all_gather=None):
+        h = C.c_void_p()
+        self._cb = None
+        if all_gather is not None:
+            self._cb = ALLGATHER_FN(lambda ctx, s, r, n, st: int(all_gather(s, r, n, st) or 0))
+            _check(lib().msvs_comm_init_custom(int(nranks), int(rank), self._cb, None, C.byref(h)))
+        else:
+            buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(id) if id is not None else None
+            _check(lib().msvs_comm_init(buf, int(nranks), int(rank), C.byref(h)))
+        self._h = h
+        self.nranks, self.rank = nranks, rank
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.msvs_comm_free.argtypes = [C.c_void_p]
+            _lib.msvs_comm_free.restype = None
+            _lib.msvs_comm_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
 class _MsvsIO(C.Structure):
     _fields_ = [("ctx", C.c_void_p),
                 ("open", C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_char_p, C.c_int)),
@@ -378,6 +416,14 @@ class Index:
         _check(lib().msvs_index_search_device(self._h, C.c_void_p(int(d_queries)), C.c_size_t(nq), int(k), int(nprobe),
                                               C.c_void_p(int(d_alive)) if d_alive else None, C.c_size_t(nbits),
                                               C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
+                                              C.c_void_p(int(stream)) if stream else None))
+
+    def shard_search_device(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0):
+        """msvs_shard_search_device: the whole sharded search (coarse by query + probe all-gather + local scan + packed
+        all-gather + merge) on `stream`; raw device addresses."""
+        _check(lib().msvs_shard_search_device(self._h, comm._h, C.c_void_p(int(d_queries)), C.c_size_t(nq), int(k),
+                                              int(nprobe), C.c_void_p(int(d_alive)) if d_alive else None,
+                                              C.c_size_t(nbits), C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
                                               C.c_void_p(int(stream)) if stream else None))
 
     def scanned_rows(self, queries, nprobe):

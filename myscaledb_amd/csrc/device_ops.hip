@@ -41,6 +41,14 @@ Scratch & aux_for(hipStream_t stream)
     return arenas[{dev, stream}];
 }
 
+Scratch & shard_for(hipStream_t stream)
+{
+    static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    return arenas[{dev, stream}];
+}
+
 Scratch & staging_for(hipStream_t stream)
 {
     static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;

@@ -35,6 +35,8 @@ Scratch & scratch_for(hipStream_t stream);
 Scratch & staging_for(hipStream_t stream);
 /// A third one for the effective filter of a search (per-search filter AND resident delete bitmap, id-space conversion).
 Scratch & aux_for(hipStream_t stream);
+/// ... and one for the exchange buffers of a sharded search (probe lists, packed partial top-k of every rank).
+Scratch & shard_for(hipStream_t stream);
 
 /// Optional HIP-event timing of kernel launches (msvs_profile_* in the C-ABI); a no-op unless enabled.
 struct ProfileScope

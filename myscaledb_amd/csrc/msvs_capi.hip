@@ -1655,32 +1655,38 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     launch_ivf_merge_subset(scan_metric(m), fm, pl.fb_slots, stream);
 }
 
+/// given_probes (nullable): [nq][nprobe] list ids computed elsewhere (another rank's share of the coarse quantiser):
+/// step 1 is skipped.  probes_only (nullable): run ONLY step 1 and leave the probe lists there.
 static void index_search_device_one(const msvs_index & ix, const float * d_queries, size_t nq, uint32_t k, size_t nprobe,
                                     const uint64_t * d_alive, size_t nbits, int64_t * d_ids, float * d_dis,
-                                    hipStream_t stream);
+                                    hipStream_t stream, const int32_t * given_probes = nullptr,
+                                    int32_t * probes_only = nullptr);
 
 /// The search proper: all pointers on the device, everything enqueued on `stream`.  Very large batches are cut into
 /// sub-batches of at most 2^21 (query, probe) pairs, stream-ordered one after the other: every scratch buffer of a search
 /// is proportional to the pairs of ONE sub-batch, so the per-(thread, stream) arena stays bounded (~0.5 GB) whatever nq.
 static void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
                                 uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
-                                float * d_dis, hipStream_t stream)
+                                float * d_dis, hipStream_t stream, const int32_t * given_probes = nullptr,
+                                int32_t * probes_only = nullptr)
 {
-    const size_t per_q = ix.type == MSVS_INDEX_IVFFLAT ? std::max<size_t>(1, std::min(nprobe, std::max<size_t>(ix.nlist, 1))) : 1;
-    const size_t sub = std::max<size_t>(256, ((size_t)1 << 21) / per_q);
+    const size_t np_eff = ix.type == MSVS_INDEX_IVFFLAT ? std::max<size_t>(1, std::min(nprobe, std::max<size_t>(ix.nlist, 1))) : 1;
+    const size_t sub = std::max<size_t>(256, ((size_t)1 << 21) / np_eff);
     if (nq <= sub)
-        return index_search_device_one(ix, d_queries, nq, k, nprobe, d_alive, nbits, d_ids, d_dis, stream);
+        return index_search_device_one(ix, d_queries, nq, k, nprobe, d_alive, nbits, d_ids, d_dis, stream, given_probes,
+                                       probes_only);
     for (size_t q0 = 0; q0 < nq; q0 += sub)
     {
         const size_t m = std::min(sub, nq - q0);
-        index_search_device_one(ix, d_queries + q0 * ix.dim, m, k, nprobe, d_alive, nbits, d_ids + q0 * k, d_dis + q0 * k,
-                                stream);
+        index_search_device_one(ix, d_queries + q0 * ix.dim, m, k, nprobe, d_alive, nbits, d_ids ? d_ids + q0 * k : nullptr,
+                                d_dis ? d_dis + q0 * k : nullptr, stream, given_probes ? given_probes + q0 * np_eff : nullptr,
+                                probes_only ? probes_only + q0 * np_eff : nullptr);
     }
 }
 
 static void index_search_device_one(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
                                     uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
-                                    float * d_dis, hipStream_t stream)
+                                    float * d_dis, hipStream_t stream, const int32_t * given_probes, int32_t * probes_only)
 {
     if (!ix.ready)
         fail(MSVS_ERR_NOT_READY, "index is not ready");
@@ -1738,8 +1744,10 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         return;
     }
     // 1. coarse quantiser: exact top-nprobe of the centroids (canonical arithmetic, so probes match the oracle)
-    int32_t * d_probes = scr.take<int32_t>(nq * nprobe);
-    if (table_pass_eligible(ix.nlist, ix.cnorm.p, ix.cnorm_max, nq, (uint32_t)nprobe, options().coarse_mfma))
+    int32_t * d_probes = probes_only ? probes_only : scr.take<int32_t>(nq * nprobe);
+    if (given_probes)
+        MSVS_HIP(hipMemcpyAsync(d_probes, given_probes, nq * nprobe * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    else if (table_pass_eligible(ix.nlist, ix.cnorm.p, ix.cnorm_max, nq, (uint32_t)nprobe, options().coarse_mfma))
     {
         TablePass t{};
         t.rows = ix.centroids.p;
@@ -1759,6 +1767,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co,
                            stream);
     }
+    if (probes_only)
+        return;
     // 2. scan the probed lists
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");
@@ -2621,5 +2631,206 @@ extern "C" int msvs_merge_topk(const int64_t * ids, const float * dis, size_t np
         merge_topk_device(d_ids.p, nq * k, d_dis.p, nq * k, nparts, nq, k, metric, d_oi.p, d_od.p, nullptr);
         MSVS_HIP(hipMemcpy(out_ids, d_oi.p, nq * k * 8, hipMemcpyDeviceToHost));
         MSVS_HIP(hipMemcpy(out_dis, d_od.p, nq * k * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+// =========================================================================================== multi-GPU
+//
+// One process per GPU, lists sharded list_id % world (index params shard_rank / shard_world; FLAT: row ranges), centroids
+// replicated.  A sharded search is ONE call on ONE stream that owns its communicator -- RCCL over xGMI, straight from
+// rccl.h, no Python in the data path:
+//   1. the coarse quantiser is sharded BY QUERY: rank r ranks the centroids for queries [r c, (r + 1) c), c = ceil(nq / W),
+//      and ONE all-gather of c * nprobe int32 per rank gives every rank the probe lists of the whole batch -- nothing of
+//      the per-step work is replicated (round 1 ran coarse quantiser, plan and selection on every rank: Amdahl ~3x at 8);
+//   2. every rank scans its LOCAL probed lists for the whole batch (pairs that point at lists it does not own are dropped
+//      by the plan), exact local top-k straight into its slot of the packed exchange buffer {ids i64 | dis f32}[nq][k];
+//   3. ONE all-gather of nq * k * 12 B per rank, then the canonical W-way merge in place (identical on every rank) --
+//      the device-side getTotalTopSearchResultImpl (MergeTreeBaseSearchManager.cpp:207-299).
+// RCCL is resolved with dlopen at first use (the host process -- ClickHouse, or PyTorch in the bench -- may already carry
+// its own librccl: the loader then hands back that one instead of a second copy).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace
+{
+struct RcclApi
+{
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char * (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const RcclApi & rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    static std::string err;
+    std::call_once(once, [] {
+        void * h = nullptr;
+        for (const char * name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+                break;
+        if (!h)
+        {
+            err = std::string("cannot load librccl: ") + dlerror();
+            return;
+        }
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather)
+            err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+    });
+    if (!err.empty())
+        msvs::fail(MSVS_ERR_DEVICE, "%s", err.c_str());
+    return api;
+}
+
+void nccl_check(ncclResult_t r, const char * what)
+{
+    if (r != ncclSuccess)
+        msvs::fail(MSVS_ERR_DEVICE, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
+}
+}
+
+struct msvs_comm
+{
+    int nranks = 1, rank = 0;
+    ncclComm_t nccl = nullptr;
+    msvs_allgather_fn custom = nullptr;
+    void * ctx = nullptr;
+    /// every rank contributes `bytes` at d_buf + rank * bytes; afterwards d_buf holds all nranks slots (in place)
+    void all_gather(unsigned char * d_buf, size_t bytes, hipStream_t stream) const
+    {
+        if ((nranks == 1 && !nccl) || bytes == 0)
+            return;
+        if (custom)
+        {
+            if (custom(ctx, d_buf + (size_t)rank * bytes, d_buf, bytes, stream) != 0)
+                msvs::fail(MSVS_ERR_DEVICE, "the caller-supplied all-gather failed");
+            return;
+        }
+        nccl_check(rccl().AllGather(d_buf + (size_t)rank * bytes, d_buf, bytes, ncclInt8, nccl, stream), "ncclAllGather");
+    }
+};
+
+extern "C" int msvs_comm_unique_id(void * id_out)
+{
+    return guarded([&] {
+        static_assert(MSVS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+        if (!id_out)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null id buffer");
+        ncclUniqueId id;
+        nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+        memcpy(id_out, &id, sizeof(id));
+    });
+}
+
+extern "C" int msvs_comm_init(const void * id, int nranks, int rank, msvs_comm_t ** out)
+{
+    return guarded([&] {
+        if (!out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+        std::unique_ptr<msvs_comm> c(new msvs_comm);
+        c->nranks = nranks;
+        c->rank = rank;
+        if (nranks > 1 || id) // a single rank WITH an id still gets a real RCCL communicator (self-test of the transport)
+        {
+            ncclUniqueId uid;
+            memcpy(&uid, id, sizeof(uid));
+            nccl_check(rccl().CommInitRank(&c->nccl, nranks, uid, rank), "ncclCommInitRank"); // on the current device
+        }
+        *out = c.release();
+    });
+}
+
+extern "C" int msvs_comm_init_custom(int nranks, int rank, msvs_allgather_fn all_gather, void * ctx, msvs_comm_t ** out)
+{
+    return guarded([&] {
+        if (!out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !all_gather))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+        std::unique_ptr<msvs_comm> c(new msvs_comm);
+        c->nranks = nranks;
+        c->rank = rank;
+        c->custom = all_gather;
+        c->ctx = ctx;
+        *out = c.release();
+    });
+}
+
+extern "C" void msvs_comm_free(msvs_comm_t * c)
+{
+    if (!c)
+        return;
+    if (c->nccl)
+        (void)rccl().CommDestroy(c->nccl);
+    delete c;
+}
+
+extern "C" int msvs_comm_rank(const msvs_comm_t * c) { return c ? c->rank : -1; }
+extern "C" int msvs_comm_size(const msvs_comm_t * c) { return c ? c->nranks : 0; }
+
+extern "C" int msvs_shard_search_device(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq,
+                                        int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
+                                        float * d_dis, void * hip_stream)
+{
+    return guarded([&] {
+        if (!ix || !comm || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index / communicator / buffer or negative k");
+        if (comm->nranks != ix->shard_world || comm->rank != ix->shard_rank)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "the index is shard %d of %d but the communicator is rank %d of %d", ix->shard_rank,
+                 ix->shard_world, comm->rank, comm->nranks);
+        hipStream_t stream = as_stream(hip_stream);
+        if (nq == 0 || k == 0)
+            return;
+        const auto meta = ix->get_meta();
+        size_t eff_bits = nbits;
+        const uint64_t * eff = effective_filter(*ix, meta.get(), d_alive_bits, nbits, &eff_bits, stream);
+        const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank;
+        if (W == 1 && !comm->nccl)
+        {
+            index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids, d_dis, stream);
+            apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
+            return;
+        }
+        const size_t part = round_up(nq * (size_t)k * 12, 16); // one rank's {ids | dis}
+        const bool ivf = ix->type == MSVS_INDEX_IVFFLAT;
+        const size_t np = ivf ? std::min<size_t>(std::max(nprobe, 1), ix->nlist) : 0;
+        const size_t chunk = ceil_div(nq, W);
+        Scratch & sh = shard_for(stream);
+        sh.reserve(W * part + W * chunk * np * 4 + 4096, stream);
+        unsigned char * packed = sh.take<unsigned char>(W * part);
+        int64_t * my_ids = reinterpret_cast<int64_t *>(packed + r * part);
+        float * my_dis = reinterpret_cast<float *>(packed + r * part + nq * (size_t)k * 8);
+        if (ivf)
+        {
+            int32_t * probes = sh.take<int32_t>(W * chunk * np);
+            int32_t * mine = probes + r * chunk * np;
+            const size_t q0 = std::min(nq, r * chunk), m = std::min(chunk, nq - q0);
+            MSVS_HIP(hipMemsetAsync(mine, 0xFF, chunk * np * 4, stream)); // queries past nq: no probes
+            if (m)
+                index_search_device(*ix, d_queries + q0 * ix->dim, m, 1, np, nullptr, 0, nullptr, nullptr, stream, nullptr, mine);
+            {
+                ProfileScope prof("shard_exchange", stream);
+                comm->all_gather(reinterpret_cast<unsigned char *>(probes), chunk * np * 4, stream);
+            }
+            index_search_device(*ix, d_queries, nq, (uint32_t)k, np, eff, eff_bits, my_ids, my_dis, stream, probes, nullptr);
+        }
+        else
+            index_search_device(*ix, d_queries, nq, (uint32_t)k, 0, eff, eff_bits, my_ids, my_dis, stream);
+        {
+            ProfileScope prof("shard_exchange", stream);
+            comm->all_gather(packed, part, stream);
+        }
+        // cosine distances leave the search as 1 - ip: ascending like L2
+        const int order = ix->metric == MSVS_METRIC_IP ? MSVS_METRIC_IP : MSVS_METRIC_L2;
+        merge_topk_device(reinterpret_cast<const int64_t *>(packed), part / 8,
+                          reinterpret_cast<const float *>(packed + nq * (size_t)k * 8), part / 4, W, nq, (size_t)k, order, d_ids,
+                          d_dis, stream);
+        apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
     });
 }

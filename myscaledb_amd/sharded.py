@@ -110,3 +110,34 @@ class ShardedIndex:
         self.index.search_device(q.data_ptr(), nq, k, nprobe, ids.data_ptr(), dis.data_ptr(), stream)
         order = capi.METRIC_IP if self.metric == capi.METRIC_IP else capi.METRIC_L2
         return exchange_and_merge(ids, dis, order, self.group, stream)
+
+
+def rccl_comm(group=None):
+    """A communicator OWNED BY libmsvs (RCCL through rccl.h, msvs_comm_init) for the ranks of a torch.distributed
+    group: torch only carries the 128-byte unique id from rank 0 to the others (bootstrap, not data path)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return capi.Comm(1, 0)
+    box = [capi.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return capi.Comm(world, rank, id=box[0])
+
+
+def gloo_comm(group=None):
+    """The same communicator with the all-gather done by torch.distributed on HOST copies (gloo): lets two processes
+    that share one GPU run the product's sharded search in tests.  Ordered after the stream's work by a device sync."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def all_gather(d_send, d_recv, nbytes, _stream):
+        torch.cuda.synchronize()
+        mine = torch.empty(nbytes, dtype=torch.uint8)
+        if hip.hipMemcpy(C.c_void_p(mine.data_ptr()), C.c_void_p(d_send), nbytes, 2) != 0:  # device -> host
+            return 1
+        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        allb = torch.cat(parts)
+        return hip.hipMemcpy(C.c_void_p(d_recv), C.c_void_p(allb.data_ptr()), nbytes * world, 1)  # host -> device
+
+    return capi.Comm(world, rank, all_gather=all_gather)

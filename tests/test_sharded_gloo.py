@@ -105,3 +105,111 @@ def test_sharded_ip_equals_unsharded():
     fi, fd, _ = o.ivf_search(cent, off, vecs, lids, q, nprobe, k, o.METRIC_IP)
     for _, mi, md, _, _, _ in res:
         assert (mi == fi).all() and (md.view(np.uint32) == fd.view(np.uint32)).all()
+
+
+# ---------------------------------------------------------------------------------------- the product's sharded search
+
+def _gpu_worker(rank, world, port, metric_name, typ, out):
+    """Two processes on ONE GPU, each holding its shard of a libmsvs index, through msvs_shard_search_device with the
+    all-gather carried by gloo (the RCCL transport needs one GPU per rank; everything else is the product path:
+    coarse quantiser sharded by query, probe exchange, local scan, packed exchange, strided merge)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import myscaledb_amd.capi as capi
+        from myscaledb_amd import sharded
+        capi.set_device(0)
+        metric = {"L2": capi.METRIC_L2, "IP": capi.METRIC_IP, "cosine": capi.METRIC_COSINE}[metric_name]
+        rng = np.random.default_rng(2024)
+        n, d, nlist, k, nprobe = 20000, 40, 24, 10, 7
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        x[500:540] = x[3]  # duplicates across lists' members: ties must merge deterministically
+        cent = o.kmeans(x, nlist, 3)
+        ix = capi.Index(typ, metric, d, "ncentroids=%d,shard_rank=%d,shard_world=%d" % (nlist, rank, world))
+        if typ == capi.INDEX_IVFFLAT:
+            ix.set_centroids(cent)
+        ix.add(x)
+        ix.build()
+        comm = sharded.gloo_comm()
+        res = {}
+        for nq in (5, 64, 700):  # per-query kernels, small batch, candidate pass; 5 and 700 are not multiples of the world
+            q = rng.standard_normal((nq, d), dtype=np.float32)
+            q[0] = x[3]
+            dq = torch.from_numpy(q).cuda()
+            oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+            od = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+            ix.shard_search_device(comm, dq.data_ptr(), nq, k, nprobe, oi.data_ptr(), od.data_ptr())
+            torch.cuda.synchronize()
+            res[nq] = (q, oi.cpu().numpy(), od.cpu().numpy())
+        out.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric_name,typ", [("L2", 1), ("cosine", 1), ("IP", 0)])
+def test_product_sharded_search_two_processes_equals_unsharded(metric_name, typ):
+    import myscaledb_amd.capi as capi
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, metric_name, typ, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # the unsharded index in this process, same data / centroids
+    metric = {"L2": capi.METRIC_L2, "IP": capi.METRIC_IP, "cosine": capi.METRIC_COSINE}[metric_name]
+    rng = np.random.default_rng(2024)
+    n, d, nlist, k, nprobe = 20000, 40, 24, 10, 7
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x[500:540] = x[3]
+    cent = o.kmeans(x, nlist, 3)
+    ix = capi.Index(typ, metric, d, "ncentroids=%d" % nlist)
+    if typ == capi.INDEX_IVFFLAT:
+        ix.set_centroids(cent)
+    ix.add(x)
+    ix.build()
+    for nq in (5, 64, 700):
+        q = res[0][1][nq][0]
+        assert (q == res[1][1][nq][0]).all()
+        fi, fd = ix.search(q, k, "nprobe=%d" % nprobe if typ == capi.INDEX_IVFFLAT else "")
+        for r in range(world):
+            assert (res[r][1][nq][1] == fi).all()
+            assert (res[r][1][nq][2].view(np.uint32) == fd.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_rccl_transport_single_rank_roundtrip():
+    """The RCCL code path itself (dlopen'd librccl: ncclGetUniqueId, ncclCommInitRank, in-place ncclAllGather on the
+    search stream) with the one rank a 1-GPU box can host: the sharded search through it == the plain search."""
+    import myscaledb_amd.capi as capi
+    capi.set_device(0)
+    comm = capi.Comm(1, 0, id=capi.comm_unique_id())
+    rng = np.random.default_rng(5)
+    n, d, k = 8000, 32, 10
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    for typ, params in ((capi.INDEX_IVFFLAT, "ncentroids=16"), (capi.INDEX_FLAT, "")):
+        ix = capi.Index(typ, capi.METRIC_L2, d, params)
+        if typ == capi.INDEX_IVFFLAT:
+            ix.train(x)
+        ix.add(x)
+        ix.build()
+        for nq in (3, 200):
+            q = rng.standard_normal((nq, d), dtype=np.float32)
+            dq = torch.from_numpy(q).cuda()
+            oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+            od = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+            ix.shard_search_device(comm, dq.data_ptr(), nq, k, 5, oi.data_ptr(), od.data_ptr())
+            torch.cuda.synchronize()
+            fi, fd = ix.search(q, k, "nprobe=5" if typ == capi.INDEX_IVFFLAT else "")
+            assert (oi.cpu().numpy() == fi).all() and (od.cpu().numpy() == fd).all()
+    comm.close()
