@@ -285,7 +285,16 @@ typedef struct msvs_postings msvs_postings_t;
 MSVS_API int msvs_postings_create(const int64_t * post_off, size_t num_terms, const uint32_t * doc_ids,
                                   const uint32_t * tfs, const uint8_t * fieldnorm_ids, size_t num_docs,
                                   msvs_postings_t ** out);
+/* Several text columns in one index (fts index on (doc, doc2): TantivyIndexStore passes column_names): every
+ * (field, token) pair is a term of its own with term_field[t] = its field; fieldnorm_ids is [num_fields][num_docs].
+ * num_fields <= 4. */
+MSVS_API int msvs_postings_create_fields(const int64_t * post_off, size_t num_terms, const uint8_t * term_field,
+                                         const uint32_t * doc_ids, const uint32_t * tfs, const uint8_t * fieldnorm_ids,
+                                         size_t num_fields, size_t num_docs, msvs_postings_t ** out);
 MSVS_API void msvs_postings_free(msvs_postings_t * postings);
+/* The part's lightweight-delete bitmap (1 = alive; what MergeTreeTextSearchManager.cpp:199-255 hands to tantivy as
+ * u8_alive_bitmap on every call), resident in HBM and swapped atomically; NULL clears.  A per-call filter is ANDed in. */
+MSVS_API int msvs_postings_set_alive(msvs_postings_t * postings, const uint64_t * alive_bits, size_t nbits);
 /* qterms/df: the query's term ids and their TABLE-level document frequencies (TANTIVY::Statistics.docs_freq,
  * src/VectorIndex/Processors/ReadWithHybridSearch.cpp:89-209); total_docs / total_tokens likewise.
  * Output: up to k (row id, score) best-first (score desc, row asc); *n_out = number written. */
@@ -293,6 +302,24 @@ MSVS_API int msvs_bm25_search(const msvs_postings_t * postings, const uint32_t *
                               size_t num_qterms, uint64_t total_docs, uint64_t total_tokens,
                               const uint64_t * alive_bits, size_t nbits, size_t k, uint64_t * row_ids, float * scores,
                               size_t * n_out);
+/* A BATCH of nq queries in one pass (one query is far too little work for the chip: a few MB of postings).
+ * Query q owns the flat terms [qoff[q], qoff[q + 1]) of qterms / df (table-level document frequency of each
+ * (field, token) term) / qgroups (nullable: the index of the query TOKEN a term stands for -- a token searched in two
+ * fields is two terms of one group; NULL = every term its own group).  total_tokens: [num_fields].
+ * operator_or != 0: any term matches (tantivy's default, ffi_bm25_search(..., operator_or = true)); 0: every token
+ * group must match (at most 16 tokens).  Outputs [nq][k] best-first (score desc, row asc), n_out[q] = hits of query q.
+ * The _device form leaves int64 ids (-1 = no hit) and scores in device buffers, stream-ordered, no host sync; its filter
+ * is a DEVICE pointer. */
+MSVS_API int msvs_bm25_search_batch(const msvs_postings_t * postings, size_t nq, const uint32_t * qoff,
+                                    const uint32_t * qterms, const uint32_t * qgroups, const uint64_t * df,
+                                    uint64_t total_docs, const uint64_t * total_tokens, int operator_or,
+                                    const uint64_t * alive_bits, size_t nbits, size_t k, uint64_t * row_ids, float * scores,
+                                    uint32_t * n_out);
+MSVS_API int msvs_bm25_search_batch_device(const msvs_postings_t * postings, size_t nq, const uint32_t * qoff,
+                                           const uint32_t * qterms, const uint32_t * qgroups, const uint64_t * df,
+                                           uint64_t total_docs, const uint64_t * total_tokens, int operator_or,
+                                           const uint64_t * d_alive_bits, size_t nbits, size_t k, int64_t * d_row_ids,
+                                           float * d_scores, void * hip_stream);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,57 @@ MSVS_HOST_API int msvs_host_generate_vector_dataset(const void * values, int is_
  * element-wise sums of per-part (total_docs, total_tokens, df[n_terms]) vectors laid out [nparts][2 + n_terms]. */
 MSVS_HOST_API void msvs_host_sum_bm25_stats(const uint64_t * per_part, size_t nparts, size_t n_terms, uint64_t * out);
 
+/* ---------------------------------------------------------------------------------------------- seam B host side
+ * A part's text index as the device scorer consumes it (myscaledb_amd/host/text_store.cpp): the search-side interface
+ * of TantivyIndexStore (src/Storages/MergeTree/TantivyIndexStore.cpp:900-992) over a POSTINGS EXPORT instead of a
+ * tantivy index directory.  Errors: status code + msvs_text_last_error() (the host rethrows
+ * TANTIVY_SEARCH_INTERNAL_ERROR, TantivyIndexStore.cpp:919-923). */
+typedef struct msvs_text_index msvs_text_index_t;
+typedef struct { const char * term; uint32_t field_id; uint64_t doc_freq; } msvs_doc_freq_t;       /* TANTIVY::DocWithFreq */
+typedef struct { uint32_t field_id; uint64_t field_total_tokens; } msvs_field_tokens_t;            /* TANTIVY::FieldTokenNums */
+typedef struct                                                                                     /* TANTIVY::Statistics */
+{
+    const msvs_doc_freq_t * docs_freq;
+    size_t n_docs_freq;
+    const msvs_field_tokens_t * total_num_tokens;
+    size_t n_fields;
+    uint64_t total_num_docs;
+} msvs_bm25_stats_t;
+
+MSVS_HOST_API const char * msvs_text_last_error(void);
+/* The exporter (stands where ffi_create_index_with_parameter / ffi_index_multi_column_docs / ffi_index_writer_commit
+ * stand, TantivyIndexStore.cpp:654-769): rows arrive in row order (row_id = 0, 1, ...); column_names[i] / docs[i] are
+ * the (column, text) pairs of the row, an Array(String) column contributing several pairs.  commit() freezes the flat
+ * postings and uploads them; save() writes the export file ("MSVSPOST" v1, layout in text_store.cpp), load() reads and
+ * VALIDATES one (MSVS_ERR_IO on anything malformed) and uploads it. */
+MSVS_HOST_API int msvs_text_index_create(const char * const * column_names, size_t ncols, msvs_text_index_t ** out);
+MSVS_HOST_API void msvs_text_index_free(msvs_text_index_t * ix);
+MSVS_HOST_API int msvs_text_index_add_doc(msvs_text_index_t * ix, uint64_t row_id, const char * const * column_names,
+                                          const char * const * docs, size_t ncols);
+MSVS_HOST_API int msvs_text_index_commit(msvs_text_index_t * ix);
+MSVS_HOST_API int msvs_text_index_save(const msvs_text_index_t * ix, const char * path);
+MSVS_HOST_API int msvs_text_index_load(const char * path, msvs_text_index_t ** out);
+/* ffi_get_total_num_docs / ffi_get_total_num_tokens / ffi_get_doc_freq (TantivyIndexStore.cpp:957-992) */
+MSVS_HOST_API uint64_t msvs_text_index_total_num_docs(const msvs_text_index_t * ix);
+MSVS_HOST_API int msvs_text_index_total_num_tokens(const msvs_text_index_t * ix, msvs_field_tokens_t * out, size_t cap, size_t * n);
+MSVS_HOST_API int msvs_text_index_doc_freq(const msvs_text_index_t * ix, const char * sentence, msvs_doc_freq_t * out, size_t cap,
+                                           size_t * n);
+/* The part's lightweight-delete bitmap in the reference's byte form (bit j of byte i = row 8 i + j,
+ * MergeTreeTextSearchManager.cpp:199-255), kept resident on the device; NULL clears. */
+MSVS_HOST_API int msvs_text_index_set_alive(msvs_text_index_t * ix, const uint8_t * u8_alive_bitmap, size_t nbytes);
+/* TANTIVY::ffi_bm25_search(index_path, sentence, column_names, topk, u8_alive_bitmap, use_filter, enable_nlq, operator_or,
+ * statistics) (call sites TantivyIndexStore.cpp:908-917, 939-948) and its batched form.  Outputs [nq][topk], n_out[q] hits
+ * each, best first.  enable_nlq != 0 -> MSVS_ERR_NOT_IMPLEMENTED. */
+MSVS_HOST_API int msvs_text_index_bm25_search(const msvs_text_index_t * ix, const char * sentence, const char * const * column_names,
+                                              size_t ncols, uint32_t topk, const uint8_t * u8_alive_bitmap, size_t nbytes,
+                                              int use_filter, int enable_nlq, int operator_or, const msvs_bm25_stats_t * stats,
+                                              uint64_t * row_ids, float * scores, uint32_t * n_out);
+MSVS_HOST_API int msvs_text_index_bm25_search_batch(const msvs_text_index_t * ix, const char * const * sentences, size_t nq,
+                                                    const char * const * column_names, size_t ncols, uint32_t topk,
+                                                    const uint8_t * u8_alive_bitmap, size_t nbytes, int use_filter,
+                                                    int enable_nlq, int operator_or, const msvs_bm25_stats_t * stats,
+                                                    uint64_t * row_ids, float * scores, uint32_t * n_out);
+
 #ifdef __cplusplus
 }
 #endif

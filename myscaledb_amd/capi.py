@@ -25,7 +25,8 @@ SYMBOLS = [
     "msvs_index_set_centroids", "msvs_index_add", "msvs_index_build", "msvs_index_ready", "msvs_index_num_data",
     "msvs_index_num_lists", "msvs_index_memory_usage", "msvs_index_search", "msvs_index_search_device",
     "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
-    "msvs_postings_create", "msvs_postings_free", "msvs_bm25_search", "msvs_index_scanned_rows",
+    "msvs_postings_create", "msvs_postings_create_fields", "msvs_postings_set_alive", "msvs_postings_free",
+    "msvs_bm25_search", "msvs_bm25_search_batch", "msvs_bm25_search_batch_device", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
     "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option", "msvs_index_serialize_io",
     "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
@@ -486,19 +487,65 @@ class Index:
 
 
 class Postings:
-    """msvs_postings_t (seam B): flat-array export of one part's inverted index."""
+    """msvs_postings_t (seam B): flat-array export of one part's inverted index.  fieldnorm_ids: [num_docs] (one text
+    column) or [num_fields, num_docs] with term_field[t] = the column of term t."""
 
-    def __init__(self, post_off, doc_ids, tfs, fieldnorm_ids):
+    def __init__(self, post_off, doc_ids, tfs, fieldnorm_ids, term_field=None):
         post_off = np.ascontiguousarray(post_off, np.int64)
         doc_ids = np.ascontiguousarray(doc_ids, np.uint32)
         tfs = np.ascontiguousarray(tfs, np.uint32)
-        fieldnorm_ids = np.ascontiguousarray(fieldnorm_ids, np.uint8)
+        fieldnorm_ids = np.ascontiguousarray(np.atleast_2d(fieldnorm_ids), np.uint8)
+        self.num_fields, self.num_docs = fieldnorm_ids.shape
+        tf_ = None if term_field is None else np.ascontiguousarray(term_field, np.uint8)
         h = C.c_void_p()
-        _check(lib().msvs_postings_create(_p(post_off, C.c_int64), C.c_size_t(post_off.size - 1), _p(doc_ids, C.c_uint32),
-                                          _p(tfs, C.c_uint32), _p(fieldnorm_ids, C.c_uint8),
-                                          C.c_size_t(fieldnorm_ids.size), C.byref(h)))
+        _check(lib().msvs_postings_create_fields(_p(post_off, C.c_int64), C.c_size_t(post_off.size - 1), _p(tf_, C.c_uint8),
+                                                 _p(doc_ids, C.c_uint32), _p(tfs, C.c_uint32), _p(fieldnorm_ids, C.c_uint8),
+                                                 C.c_size_t(self.num_fields), C.c_size_t(self.num_docs), C.byref(h)))
         self._h = h
-        self.num_docs = fieldnorm_ids.size
+
+    def set_alive(self, alive):
+        """Resident lightweight-delete bitmap of the part (None clears)."""
+        if alive is None:
+            _check(lib().msvs_postings_set_alive(self._h, None, C.c_size_t(0)))
+        else:
+            bits = pack_bits(alive)
+            _check(lib().msvs_postings_set_alive(self._h, _p(bits, C.c_uint64), C.c_size_t(len(alive))))
+
+    def _batch_args(self, queries, dfs, groups, total_tokens):
+        qoff = np.zeros(len(queries) + 1, np.uint32)
+        qoff[1:] = np.cumsum([len(q) for q in queries])
+        cat = lambda xs, dt: np.ascontiguousarray(np.concatenate([np.asarray(x, dt).ravel() for x in xs]) if len(xs) else [], dt)
+        qterms, df = cat(queries, np.uint32), cat(dfs, np.uint64)
+        qg = None if groups is None else cat(groups, np.uint32)
+        tokens = np.ascontiguousarray(np.broadcast_to(np.asarray(total_tokens, np.uint64), (self.num_fields,)))
+        return qoff, qterms, qg, df, tokens
+
+    def bm25_search_batch(self, queries, dfs, total_docs, total_tokens, k, alive=None, groups=None, operator_or=True):
+        """queries / dfs (/ groups): one sequence per query.  Returns lists of (rows, scores)."""
+        nq = len(queries)
+        qoff, qterms, qg, df, tokens = self._batch_args(queries, dfs, groups, total_tokens)
+        bits, nbits = None, 0
+        if alive is not None:
+            nbits = len(alive)
+            bits = pack_bits(alive)
+        rows, scores, cnt = np.empty((nq, k), np.uint64), np.empty((nq, k), np.float32), np.zeros(nq, np.uint32)
+        _check(lib().msvs_bm25_search_batch(self._h, C.c_size_t(nq), _p(qoff, C.c_uint32), _p(qterms, C.c_uint32),
+                                            _p(qg, C.c_uint32), _p(df, C.c_uint64), C.c_uint64(int(total_docs)),
+                                            _p(tokens, C.c_uint64), 1 if operator_or else 0, _p(bits, C.c_uint64),
+                                            C.c_size_t(nbits), C.c_size_t(k), _p(rows, C.c_uint64), _p(scores, C.c_float),
+                                            _p(cnt, C.c_uint32)))
+        return [(rows[q, :cnt[q]].copy(), scores[q, :cnt[q]].copy()) for q in range(nq)]
+
+    def bm25_search_batch_device(self, queries, dfs, total_docs, total_tokens, k, d_row_ids, d_scores, stream=0,
+                                 d_alive=0, nbits=0, groups=None, operator_or=True):
+        """Stream-ordered: int64 ids (-1 = no hit) / f32 scores into DEVICE buffers [nq, k] given by address."""
+        nq = len(queries)
+        qoff, qterms, qg, df, tokens = self._batch_args(queries, dfs, groups, total_tokens)
+        _check(lib().msvs_bm25_search_batch_device(self._h, C.c_size_t(nq), _p(qoff, C.c_uint32), _p(qterms, C.c_uint32),
+                                                   _p(qg, C.c_uint32), _p(df, C.c_uint64), C.c_uint64(int(total_docs)),
+                                                   _p(tokens, C.c_uint64), 1 if operator_or else 0, C.c_void_p(d_alive),
+                                                   C.c_size_t(nbits), C.c_size_t(k), C.c_void_p(d_row_ids),
+                                                   C.c_void_p(d_scores), C.c_void_p(stream)))
 
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:

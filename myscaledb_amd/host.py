@@ -13,7 +13,11 @@ LIB_PATH = os.path.join(_HERE, "libmsvs_host.so")
 SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_host_total_topk",
            "msvs_host_hybrid_search", "msvs_host_merge_topk", "msvs_host_sum_bm25_stats",
            "msvs_host_vector_scan_without_index", "msvs_host_merge_search_result",
-           "msvs_host_generate_vector_dataset", "msvs_host_vector_scan_resident"]
+           "msvs_host_generate_vector_dataset", "msvs_host_vector_scan_resident",
+           "msvs_text_last_error", "msvs_text_index_create", "msvs_text_index_free", "msvs_text_index_add_doc",
+           "msvs_text_index_commit", "msvs_text_index_save", "msvs_text_index_load", "msvs_text_index_total_num_docs",
+           "msvs_text_index_total_num_tokens", "msvs_text_index_doc_freq", "msvs_text_index_set_alive",
+           "msvs_text_index_bm25_search", "msvs_text_index_bm25_search_batch"]
 
 _lib = None
 
@@ -28,6 +32,11 @@ def lib():
         _lib.msvs_host_total_topk.restype = C.c_size_t
         _lib.msvs_host_hybrid_search.restype = C.c_size_t
         _lib.msvs_host_sum_bm25_stats.restype = None
+        _lib.msvs_text_last_error.restype = C.c_char_p
+        _lib.msvs_text_index_total_num_docs.restype = C.c_uint64
+        _lib.msvs_text_index_total_num_docs.argtypes = [C.c_void_p]
+        _lib.msvs_text_index_free.restype = None
+        _lib.msvs_text_index_free.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -176,3 +185,135 @@ def generate_vector_dataset(values, offsets, dim):
     if rc != 0:
         raise capi.MsvsError(rc, "generateVectorDataset failed")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ seam B host side
+
+class _DocFreq(C.Structure):
+    _fields_ = [("term", C.c_char_p), ("field_id", C.c_uint32), ("doc_freq", C.c_uint64)]
+
+
+class _FieldTokens(C.Structure):
+    _fields_ = [("field_id", C.c_uint32), ("field_total_tokens", C.c_uint64)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("docs_freq", C.POINTER(_DocFreq)), ("n_docs_freq", C.c_size_t), ("total_num_tokens", C.POINTER(_FieldTokens)),
+                ("n_fields", C.c_size_t), ("total_num_docs", C.c_uint64)]
+
+
+def _tcheck(rc):
+    if rc != 0:
+        raise capi.MsvsError(rc, lib().msvs_text_last_error().decode())
+
+
+def _strs(xs):
+    arr = (C.c_char_p * max(1, len(xs)))()
+    for i, x in enumerate(xs):
+        arr[i] = x.encode()
+    return arr
+
+
+class Statistics:
+    """TANTIVY::Statistics: table-level (term, field_id, doc_freq) triples, (field_id, total tokens) pairs, total docs."""
+
+    def __init__(self, docs_freq, total_num_tokens, total_num_docs):
+        self.docs_freq, self.total_num_tokens, self.total_num_docs = list(docs_freq), list(total_num_tokens), int(total_num_docs)
+
+    def _c(self):
+        df = (_DocFreq * max(1, len(self.docs_freq)))()
+        for i, (t, f, d) in enumerate(self.docs_freq):
+            df[i] = _DocFreq(t.encode(), f, d)
+        tk = (_FieldTokens * max(1, len(self.total_num_tokens)))()
+        for i, (f, n) in enumerate(self.total_num_tokens):
+            tk[i] = _FieldTokens(f, n)
+        st = _Stats(df, len(self.docs_freq), tk, len(self.total_num_tokens), self.total_num_docs)
+        st._keep = (df, tk)
+        return st
+
+    @staticmethod
+    def sum(parts):
+        """BM25InfoInDataParts: add the parts' statistics up (src/VectorIndex/Common/BM25InfoInDataParts.cpp:40-93)."""
+        df, tk, n = {}, {}, 0
+        for p in parts:
+            n += p.total_num_docs
+            for t, f, d in p.docs_freq:
+                df[(t, f)] = df.get((t, f), 0) + d
+            for f, c in p.total_num_tokens:
+                tk[f] = tk.get(f, 0) + c
+        return Statistics([(t, f, d) for (t, f), d in df.items()], list(tk.items()), n)
+
+
+class TextIndexStore:
+    """TantivyIndexStore's search-side interface over a postings export (myscaledb_amd/host/text_store.cpp)."""
+
+    def __init__(self, column_names=None, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
+        h = C.c_void_p()
+        _tcheck(lib().msvs_text_index_create(_strs(column_names), C.c_size_t(len(column_names)), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        _tcheck(lib().msvs_text_index_load(path.encode(), C.byref(h)))
+        return cls(_handle=h)
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.msvs_text_index_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def add_doc(self, row_id, column_names, docs):
+        _tcheck(lib().msvs_text_index_add_doc(self._h, C.c_uint64(row_id), _strs(column_names), _strs(docs),
+                                              C.c_size_t(len(docs))))
+
+    def commit(self):
+        _tcheck(lib().msvs_text_index_commit(self._h))
+
+    def save(self, path):
+        _tcheck(lib().msvs_text_index_save(self._h, path.encode()))
+
+    def total_num_docs(self):
+        return int(lib().msvs_text_index_total_num_docs(self._h))
+
+    def total_num_tokens(self):
+        out, n = (_FieldTokens * 4)(), C.c_size_t(0)
+        _tcheck(lib().msvs_text_index_total_num_tokens(self._h, out, C.c_size_t(4), C.byref(n)))
+        return [(out[i].field_id, out[i].field_total_tokens) for i in range(n.value)]
+
+    def doc_freq(self, sentence):
+        out, n = (_DocFreq * 256)(), C.c_size_t(0)
+        _tcheck(lib().msvs_text_index_doc_freq(self._h, sentence.encode(), out, C.c_size_t(256), C.byref(n)))
+        return [(out[i].term.decode(), out[i].field_id, out[i].doc_freq) for i in range(min(n.value, 256))]
+
+    def statistics(self, sentence):
+        return Statistics(self.doc_freq(sentence), self.total_num_tokens(), self.total_num_docs())
+
+    def set_alive(self, alive):
+        if alive is None:
+            _tcheck(lib().msvs_text_index_set_alive(self._h, None, C.c_size_t(0)))
+        else:
+            b = np.packbits(np.asarray(alive, bool), bitorder="little")
+            _tcheck(lib().msvs_text_index_set_alive(self._h, _p(b, C.c_uint8), C.c_size_t(b.size)))
+
+    def bm25_search_batch(self, sentences, topk, statistics=None, column_names=None, alive=None, enable_nlq=False,
+                          operator_or=True):
+        """ffi_bm25_search for a list of sentences -> [(row_ids, scores)]; alive: bool per row (use_filter = True)."""
+        nq = len(sentences)
+        rows, scores, cnt = np.empty((nq, topk), np.uint64), np.empty((nq, topk), np.float32), np.zeros(nq, np.uint32)
+        b = None if alive is None else np.packbits(np.asarray(alive, bool), bitorder="little")
+        st = None if statistics is None else statistics._c()
+        cols = column_names or []
+        _tcheck(lib().msvs_text_index_bm25_search_batch(
+            self._h, _strs(sentences), C.c_size_t(nq), _strs(cols) if cols else None, C.c_size_t(len(cols)), C.c_uint32(topk),
+            _p(b, C.c_uint8), C.c_size_t(0 if b is None else b.size), int(alive is not None), int(enable_nlq), int(operator_or),
+            None if st is None else C.byref(st), _p(rows, C.c_uint64), _p(scores, C.c_float), _p(cnt, C.c_uint32)))
+        return [(rows[q, :cnt[q]].copy(), scores[q, :cnt[q]].copy()) for q in range(nq)]
+
+    def bm25_search(self, sentence, topk, statistics=None, column_names=None, alive=None, enable_nlq=False, operator_or=True):
+        return self.bm25_search_batch([sentence], topk, statistics, column_names, alive, enable_nlq, operator_or)[0]

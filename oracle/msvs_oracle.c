@@ -600,6 +600,61 @@ ORACLE_API size_t oracle_bm25_search(const int64_t *post_off, const uint32_t *do
     return cnt;
 }
 
+/*
+ * The same scorer with several text columns and the AND operator (TantivyIndexStore.cpp:900-954 passes
+ * `operator_or`; an fts index over several columns searches a token in every column).  Every (field, token) pair is a
+ * term of its own: term_field[t] = its field (NULL: all field 0), fieldnorm_ids is [num_fields][num_docs],
+ * total_tokens[num_fields]; df[j] is the TABLE-level document frequency of flat query term j, qgroups[j] the index of
+ * the query token it stands for (NULL: j).  operator_or = 0 keeps the documents in which EVERY token group matched
+ * (tantivy's conjunction of per-field disjunctions).  Scores sum in flat-term order.  PARITY UNPINNED for the
+ * multi-field / AND cases: the reference's tests hold no golden for them (00040 / 00041 are single-column OR).
+ */
+ORACLE_API size_t oracle_bm25_search_ex(const int64_t *post_off, const uint8_t *term_field, const uint32_t *doc_ids,
+                                        const uint32_t *tfs, const uint8_t *fieldnorm_ids, size_t num_fields,
+                                        size_t num_docs, const uint32_t *qterms, const uint32_t *qgroups,
+                                        const uint64_t *df, size_t nq_terms, uint64_t total_docs,
+                                        const uint64_t *total_tokens, int operator_or, const uint64_t *alive, size_t k,
+                                        uint64_t *out_rows, float *out_scores)
+{
+    init_fieldnorm_table();
+    const float K1 = 1.2f, B = 0.75f;
+    float *cache = (float *)malloc(sizeof(float) * 256 * num_fields);
+    for (size_t f = 0; f < num_fields; f++) {
+        float avg = (float)total_tokens[f] / (float)total_docs;
+        for (int i = 0; i < 256; i++) cache[f * 256 + i] = K1 * (1.0f - B + B * (float)fieldnorm_table[i] / avg);
+    }
+    float *score = (float *)calloc(num_docs ? num_docs : 1, sizeof(float));
+    uint32_t *hit = (uint32_t *)calloc(num_docs ? num_docs : 1, sizeof(uint32_t));
+    uint32_t full = 0;
+    for (size_t t = 0; t < nq_terms; t++) {
+        uint32_t g = (qgroups ? qgroups[t] : (uint32_t)t) % 16;
+        size_t f = term_field ? term_field[qterms[t]] : 0;
+        full |= 1u << g;
+        float weight = oracle_bm25_idf(df[t], total_docs) * (1.0f + K1);
+        for (int64_t p = post_off[qterms[t]]; p < post_off[qterms[t] + 1]; p++) {
+            uint32_t doc = doc_ids[p];
+            float tf = (float)tfs[p];
+            float s = weight * (tf / (tf + cache[f * 256 + fieldnorm_ids[f * num_docs + doc]]));
+            score[doc] = score[doc] + s;
+            hit[doc] |= 1u << g;
+        }
+    }
+    cand_t *h = (cand_t *)malloc(sizeof(cand_t) * (k ? k : 1));
+    size_t cnt = 0;
+    for (size_t doc = 0; doc < num_docs; doc++)
+        if (hit[doc] && (operator_or || hit[doc] == full) && bit_alive(alive, doc))
+            topk_push(METRIC_IP, h, k, &cnt, score[doc], (int64_t)doc);
+    for (size_t j = 0; j < cnt; j++) {
+        out_rows[j] = (uint64_t)h[j].id;
+        out_scores[j] = h[j].dis;
+    }
+    free(h);
+    free(score);
+    free(hit);
+    free(cache);
+    return cnt;
+}
+
 /* ------------------------------------------------------------------ fusion */
 
 /*

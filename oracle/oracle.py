@@ -37,7 +37,7 @@ def lib():
         _lib.oracle_bm25_idf.restype = C.c_float
         _lib.oracle_fieldnorm_id.restype = C.c_uint8
         _lib.oracle_fieldnorm_of_id.restype = C.c_uint32
-        for n in ("oracle_total_topk", "oracle_bm25_search", "oracle_hybrid_fusion"):
+        for n in ("oracle_total_topk", "oracle_bm25_search", "oracle_bm25_search_ex", "oracle_hybrid_fusion"):
             getattr(_lib, n).restype = C.c_size_t
     return _lib
 
@@ -225,6 +225,30 @@ def bm25_search(post_off, doc_ids, tfs, fieldnorm_ids, qterms, df, total_docs, t
     return rows[:cnt], scores[:cnt]
 
 
+def bm25_search_ex(post_off, doc_ids, tfs, fieldnorm_ids, qterms, df, total_docs, total_tokens, k, alive=None,
+                   term_field=None, qgroups=None, operator_or=True):
+    """fieldnorm_ids [num_fields, num_docs]; total_tokens [num_fields]; see oracle_bm25_search_ex."""
+    post_off = np.ascontiguousarray(post_off, dtype=np.int64)
+    doc_ids = np.ascontiguousarray(doc_ids, dtype=np.uint32)
+    tfs = np.ascontiguousarray(tfs, dtype=np.uint32)
+    fieldnorm_ids = np.ascontiguousarray(np.atleast_2d(fieldnorm_ids), dtype=np.uint8)
+    num_fields, num_docs = fieldnorm_ids.shape
+    qterms = np.ascontiguousarray(qterms, dtype=np.uint32)
+    df = np.ascontiguousarray(df, dtype=np.uint64)
+    tokens = np.ascontiguousarray(np.broadcast_to(np.asarray(total_tokens, np.uint64), (num_fields,)))
+    tf_ = None if term_field is None else np.ascontiguousarray(term_field, np.uint8)
+    qg = None if qgroups is None else np.ascontiguousarray(qgroups, np.uint32)
+    bits = None if alive is None else pack_bits(alive)
+    rows, scores = np.empty(k, np.uint64), np.empty(k, np.float32)
+    cnt = lib().oracle_bm25_search_ex(_p(post_off, C.c_int64), _p(tf_, C.c_uint8), _p(doc_ids, C.c_uint32),
+                                      _p(tfs, C.c_uint32), _p(fieldnorm_ids, C.c_uint8), C.c_size_t(num_fields),
+                                      C.c_size_t(num_docs), _p(qterms, C.c_uint32), _p(qg, C.c_uint32),
+                                      _p(df, C.c_uint64), C.c_size_t(qterms.size), C.c_uint64(int(total_docs)),
+                                      _p(tokens, C.c_uint64), 1 if operator_or else 0, _p(bits, C.c_uint64),
+                                      C.c_size_t(k), _p(rows, C.c_uint64), _p(scores, C.c_float))
+    return rows[:cnt], scores[:cnt]
+
+
 def hybrid_fusion(fusion_type, vec, txt, topk, fusion_k=60, fusion_weight=0.5, vector_scan_direction=1):
     """vec / txt: (scores, parts, labels) already ordered best-first. fusion_type 'rrf' | 'rsf'."""
     vs, vp, vl = _f32(vec[0]), np.ascontiguousarray(vec[1], np.uint64), np.ascontiguousarray(vec[2], np.uint64)
@@ -280,3 +304,49 @@ def knn_bin(x, y, k, metric, alive=None):
     if rc:
         raise RuntimeError("oracle_knn_bin rc=%d" % rc)
     return ids, dis
+
+
+# ------------------------------------------------------------------ CPU baseline (simd_baseline.c; bench.py only)
+
+_simd = None
+
+
+def simd_lib(native=True):
+    """libmsvs_simd_native.so (built HERE, on the machine that runs the bench, -march=native) or the portable AVX2 build."""
+    global _simd
+    if _simd is None:
+        path = os.path.join(_HERE, "_build", "libmsvs_simd.so")
+        if native:
+            try:
+                subprocess.check_call(["make", "-C", _HERE, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                path = os.path.join(_HERE, "_build", "libmsvs_simd_native.so")
+            except Exception:
+                pass
+        _simd = C.CDLL(path)
+    return _simd
+
+
+def simd_ivf_search(cent, off, vecs, ids, q, nprobe, k, metric, threads):
+    cent, vecs, q = _f32(cent), _f32(vecs), _f32(q)
+    off = np.ascontiguousarray(off, np.int64)
+    ids = np.ascontiguousarray(ids, np.int64)
+    oi = np.empty((q.shape[0], k), np.int64)
+    od = np.empty((q.shape[0], k), np.float32)
+    simd_lib().simd_ivf_search(_p(cent, C.c_float), C.c_size_t(cent.shape[0]), _p(off, C.c_int64), _p(vecs, C.c_float),
+                               _p(ids, C.c_int64), _p(q, C.c_float), C.c_size_t(q.shape[0]), C.c_size_t(q.shape[1]),
+                               C.c_size_t(nprobe), C.c_size_t(k), int(metric), _p(oi, C.c_int64), _p(od, C.c_float),
+                               int(threads))
+    return oi, od
+
+
+def simd_knn(x, y, k, metric, threads):
+    x, y = _f32(x), _f32(y)
+    oi = np.empty((x.shape[0], k), np.int64)
+    od = np.empty((x.shape[0], k), np.float32)
+    simd_lib().simd_knn(_p(x, C.c_float), _p(y, C.c_float), C.c_size_t(y.shape[1]), C.c_size_t(k), C.c_size_t(x.shape[0]),
+                        C.c_size_t(y.shape[0]), int(metric), _p(oi, C.c_int64), _p(od, C.c_float), int(threads))
+    return oi, od
+
+
+def simd_lanes():
+    return int(simd_lib().simd_lanes())

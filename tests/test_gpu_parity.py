@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import myscaledb_amd.capi as capi
+import myscaledb_amd.host as mhost
 from golden_util import TextIndex, eval_filter, f32_of, load_goldens, materialize, tokenize
 from oracle import oracle as o
 
@@ -594,6 +595,234 @@ def test_bm25_many_doc_blocks_two_level_merge():
             exp = o.bm25_search(post_off, doc, tf.astype(np.uint32), fn_ids, qt, df, n_docs, int(lens.sum()), k, alive=al)
             assert got[0].tolist() == exp[0].tolist()
             assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
+
+
+def synthetic_postings(rng, n_docs, vocab, mean_len, num_fields=1):
+    """Zipf corpus as flat arrays.  Several fields: term id = field * vocab + token."""
+    p = 1.0 / np.arange(1, vocab + 1) ** 1.1
+    p /= p.sum()
+    terms, docs, tfs, fns, tokens = [], [], [], [], []
+    for f in range(num_fields):
+        lens = np.maximum(1, rng.poisson(mean_len * (1 + f), n_docs))
+        toks = rng.choice(vocab, int(lens.sum()), p=p)
+        doc_of = np.repeat(np.arange(n_docs, dtype=np.int64), lens)
+        uk, tf = np.unique((toks.astype(np.int64) + f * vocab) * n_docs + doc_of, return_counts=True)
+        terms.append(uk // n_docs)
+        docs.append((uk % n_docs).astype(np.uint32))
+        tfs.append(tf.astype(np.uint32))
+        fn_of_len = np.array([o.fieldnorm_id(int(n)) for n in range(int(lens.max()) + 1)], np.uint8)
+        fns.append(fn_of_len[lens])
+        tokens.append(int(lens.sum()))
+    term = np.concatenate(terms)
+    post_off = np.zeros(vocab * num_fields + 1, np.int64)
+    np.cumsum(np.bincount(term, minlength=vocab * num_fields), out=post_off[1:])
+    term_field = np.repeat(np.arange(num_fields, dtype=np.uint8), vocab)
+    return post_off, np.concatenate(docs), np.concatenate(tfs), np.stack(fns), term_field, np.asarray(tokens, np.uint64)
+
+
+def test_bm25_batch_equals_single_queries_and_oracle():
+    """msvs_bm25_search_batch: every query of a batch == the one-query entry point == the oracle, bit for bit; the
+    resident alive bitmap (msvs_postings_set_alive) ANDs with the per-call one."""
+    rng = np.random.default_rng(91)
+    n_docs, vocab = 300_000, 2000
+    post_off, doc, tf, fn, _, tokens = synthetic_postings(rng, n_docs, vocab, 14)
+    ps = capi.Postings(post_off, doc, tf, fn[0])
+    df_all = np.diff(post_off)
+    queries = [list(rng.choice(vocab, rng.integers(1, 6), replace=False)) for _ in range(67)]
+    queries += [[0, 1, 2, 3, 4, 5, 6, 7], [vocab - 1], []]
+    dfs = [[int(df_all[t]) for t in q] for q in queries]
+    total_tokens = int(tokens[0])
+    alive = rng.random(n_docs) < 0.6
+    part_alive = rng.random(n_docs) < 0.9
+    for k in (10, 100):
+        for al in (None, alive):
+            got = ps.bm25_search_batch(queries, dfs, n_docs, total_tokens, k, alive=al)
+            for q, dfq, (gr, gs) in zip(queries, dfs, got):
+                er, es = o.bm25_search(post_off, doc, tf, fn[0], q, dfq, n_docs, total_tokens, k, alive=al)
+                assert gr.tolist() == er.tolist()
+                assert (gs.view(np.uint32) == es.view(np.uint32)).all()
+            for qi in (0, 5, 67):
+                sr, ss = ps.bm25_search(queries[qi], dfs[qi], n_docs, total_tokens, k, alive=al)
+                assert sr.tolist() == got[qi][0].tolist() and (ss.view(np.uint32) == got[qi][1].view(np.uint32)).all()
+    ps.set_alive(part_alive)
+    for al, eff in ((None, part_alive), (alive, alive & part_alive)):
+        got = ps.bm25_search_batch(queries[:16], dfs[:16], n_docs, total_tokens, 10, alive=al)
+        for q, dfq, (gr, gs) in zip(queries, dfs, got):
+            er, es = o.bm25_search(post_off, doc, tf, fn[0], q, dfq, n_docs, total_tokens, 10, alive=eff)
+            assert gr.tolist() == er.tolist() and (gs.view(np.uint32) == es.view(np.uint32)).all()
+    ps.set_alive(None)
+    got = ps.bm25_search_batch(queries[:4], dfs[:4], n_docs, total_tokens, 10)
+    er, _ = o.bm25_search(post_off, doc, tf, fn[0], queries[0], dfs[0], n_docs, total_tokens, 10)
+    assert got[0][0].tolist() == er.tolist()
+    # stream-ordered device form
+    import torch
+
+    oi = torch.empty((len(queries), 10), device="cuda", dtype=torch.int64)
+    od = torch.empty((len(queries), 10), device="cuda", dtype=torch.float32)
+    ps.bm25_search_batch_device(queries, dfs, n_docs, total_tokens, 10, oi.data_ptr(), od.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host = ps.bm25_search_batch(queries, dfs, n_docs, total_tokens, 10)
+    for qi, (gr, gs) in enumerate(host):
+        ids = oi[qi].cpu().numpy()
+        assert ids[:len(gr)].tolist() == gr.astype(np.int64).tolist() and (ids[len(gr):] == -1).all()
+        assert (od[qi].cpu().numpy()[:len(gr)].view(np.uint32) == gs.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("num_fields", [1, 3])
+def test_bm25_and_operator_and_text_columns(num_fields):
+    """operator_or = false (every token must match, in any column) and an index over several text columns: one term
+    per (column, token), one token group per query token -- against the oracle's restatement."""
+    rng = np.random.default_rng(92 + num_fields)
+    n_docs, vocab = 120_000, 400
+    post_off, doc, tf, fn, term_field, tokens = synthetic_postings(rng, n_docs, vocab, 6, num_fields)
+    ps = capi.Postings(post_off, doc, tf, fn, term_field=term_field)
+    df_all = np.diff(post_off)
+    alive = rng.random(n_docs) < 0.8
+    queries, groups = [], []
+    for _ in range(40):
+        toks = rng.choice(60, rng.integers(1, 5), replace=False)
+        queries.append([int(f * vocab + t) for t in toks for f in range(num_fields)])
+        groups.append([g for g in range(len(toks)) for _ in range(num_fields)])
+    dfs = [[int(df_all[t]) for t in q] for q in queries]
+    for op_or in (False, True):
+        for al in (None, alive):
+            got = ps.bm25_search_batch(queries, dfs, n_docs, tokens, 20, alive=al, groups=groups, operator_or=op_or)
+            n_hits = 0
+            for q, g, dfq, (gr, gs) in zip(queries, groups, dfs, got):
+                er, es = o.bm25_search_ex(post_off, doc, tf, fn, q, dfq, n_docs, tokens, 20, alive=al, term_field=term_field,
+                                          qgroups=g, operator_or=op_or)
+                assert gr.tolist() == er.tolist()
+                assert (gs.view(np.uint32) == es.view(np.uint32)).all()
+                n_hits += len(gr)
+            assert n_hits > 0
+
+
+def build_store(docs, columns=("doc",)):
+    """docs: list of {column: text | [texts]}; row id = position."""
+    st = mhost.TextIndexStore(list(columns))
+    for r, d in enumerate(docs):
+        names, texts = [], []
+        for c in columns:
+            for t in (d[c] if isinstance(d[c], list) else [d[c]]):
+                names.append(c)
+                texts.append(t)
+        st.add_doc(r, names, texts)
+    st.commit()
+    return st
+
+
+def test_text_store_replays_the_bm25_goldens(tmp_path):
+    """Seam B end to end through the native host side (text_store.cpp: exporter -> export file -> loader -> device):
+    the sentence goes in as a string like TantivyIndexStore::bm25Search's, the goldens of 00040 / 00041 come out."""
+    c = G["00040_hybrid"]
+    docs = c["docs"]
+    st = build_store([{"doc": d["texts"]} for d in docs])
+    path = str(tmp_path / "part0.mspost")
+    st.save(path)
+    st2 = mhost.TextIndexStore.load(path)
+    for s_ in (st, st2):
+        rows, scores = s_.bm25_search(c["text_query"], c["limit"], statistics=s_.statistics(c["text_query"]))
+        assert [docs[int(r)]["id"] for r in rows] == c["text_search"][0]
+        assert scores.tolist() == f32_of(c["text_search"][1]).tolist()
+        alive = np.array([d["id"] < 10 for d in docs])
+        rows, scores = s_.bm25_search(c["text_query"], c["limit"], alive=alive)
+        assert [docs[int(r)]["id"] for r in rows] == c["text_search_where_id_lt_10"][0]
+        assert scores.tolist() == f32_of(c["text_search_where_id_lt_10"][1]).tolist()
+        # the same filter, resident (lightweight delete of the part)
+        s_.set_alive(alive)
+        rows2, scores2 = s_.bm25_search(c["text_query"], c["limit"])
+        assert rows2.tolist() == rows.tolist() and scores2.tolist() == scores.tolist()
+        s_.set_alive(None)
+    # Array(String) column
+    a = G["00040_text_array"]
+    st = build_store([{"doc": d["texts"]} for d in a["docs"]])
+    rows, scores = st.bm25_search(a["text_query"], a["limit"])
+    assert [a["docs"][int(r)]["id"] for r in rows] == a["text_search"][0]
+    assert scores.tolist() == f32_of(a["text_search"][1]).tolist()
+    # 00041: two parts, table-level statistics summed over the parts (BM25InfoInDataParts)
+    t = G["00041_two_parts"]
+    docs = t["docs"]
+    n0 = t["part_sizes"][0]
+    parts = [build_store([{"doc": d["texts"]} for d in docs[:n0]]), build_store([{"doc": d["texts"]} for d in docs[n0:]])]
+    stats = mhost.Statistics.sum([p.statistics(t["text_query"]) for p in parts])
+    hits = []
+    for pi, p in enumerate(parts):
+        rows, scores = p.bm25_search(t["text_query"], t["limit"], statistics=stats)
+        hits += [(float(s), docs[int(r) + pi * n0]["id"]) for r, s in zip(rows, scores)]
+    hits.sort(key=lambda h: (-h[0], h[1]))
+    assert [h[1] for h in hits[:2]] == t["text_search_2parts"][0]
+    assert np.array([h[0] for h in hits[:2]], np.float32).tolist() == f32_of(t["text_search_2parts"][1]).tolist()
+    # a corrupt export is refused
+    raw = bytearray(open(path, "rb").read())
+    for cut in (10, 64, len(raw) - 3):
+        bad = str(tmp_path / "bad.mspost")
+        open(bad, "wb").write(bytes(raw[:cut]))
+        with pytest.raises(capi.MsvsError):
+            mhost.TextIndexStore.load(bad)
+    raw[0] ^= 0xFF
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(capi.MsvsError):
+        mhost.TextIndexStore.load(bad)
+    with pytest.raises(capi.MsvsError):
+        st.bm25_search("x", 5, enable_nlq=True)
+
+
+def test_text_store_two_columns_and_operator_against_oracle():
+    """An fts index over two columns + operator_or = false: the store's term / group construction against the oracle
+    fed with a python-built index of the same documents."""
+    rng = np.random.default_rng(77)
+    words = ["w%d" % i for i in range(120)]
+    p = 1.0 / np.arange(1, len(words) + 1)
+    p /= p.sum()
+    docs = [{"a": " ".join(rng.choice(words, rng.integers(1, 12), p=p)), "b": " ".join(rng.choice(words, rng.integers(1, 30), p=p))}
+            for _ in range(20000)]
+    st = build_store(docs, columns=("a", "b"))
+    ia = TextIndex([[d["a"]] for d in docs], o.fieldnorm_id)
+    ib = TextIndex([[d["b"]] for d in docs], o.fieldnorm_id)
+    # the python twin of the export: terms of column a, then of column b, each sorted by bytes
+    order_a, order_b = sorted(ia.vocab), sorted(ib.vocab)
+    term_id = {("a", t): i for i, t in enumerate(order_a)}
+    term_id.update({("b", t): len(order_a) + i for i, t in enumerate(order_b)})
+
+    def lists(ix, order):
+        return [(ix.doc_ids[ix.post_off[ix.vocab[t]]:ix.post_off[ix.vocab[t] + 1]], ix.tfs[ix.post_off[ix.vocab[t]]:ix.post_off[ix.vocab[t] + 1]])
+                for t in order]
+
+    pl = lists(ia, order_a) + lists(ib, order_b)
+    post_off = np.zeros(len(pl) + 1, np.int64)
+    np.cumsum([len(x[0]) for x in pl], out=post_off[1:])
+    doc_ids = np.concatenate([x[0] for x in pl]).astype(np.uint32)
+    tfs = np.concatenate([x[1] for x in pl]).astype(np.uint32)
+    fn = np.stack([ia.fieldnorm_ids, ib.fieldnorm_ids])
+    term_field = np.array([0] * len(order_a) + [1] * len(order_b), np.uint8)
+    tokens = [ia.total_tokens, ib.total_tokens]
+    assert st.total_num_tokens() == [(0, ia.total_tokens), (1, ib.total_tokens)] and st.total_num_docs() == len(docs)
+    alive = rng.random(len(docs)) < 0.7
+    for sentence in ("w0 w3", "w1 W7 w40", "w5", "w2 w2 w9", "w100 w90 nosuchword"):
+        for op_or in (True, False):
+            for cols in (None, ["b"], ["a", "b"]):
+                fields = ["a", "b"] if cols is None else cols
+                q, g, df, grp, dead = [], [], [], 0, False
+                for t in dict.fromkeys(tokenize(sentence)):
+                    hit = False
+                    for f in fields:
+                        if (f, t) in term_id:
+                            q.append(term_id[(f, t)])
+                            g.append(grp)
+                            df.append(int(post_off[q[-1] + 1] - post_off[q[-1]]))
+                            hit = True
+                    grp += hit
+                    dead |= (not hit) and not op_or
+                if dead:
+                    q, g, df = [], [], []
+                for al in (None, alive):
+                    rows, scores = st.bm25_search(sentence, 15, column_names=cols, alive=al, operator_or=op_or)
+                    er, es = o.bm25_search_ex(post_off, doc_ids, tfs, fn, q, df, len(docs), tokens, 15, alive=al,
+                                              term_field=term_field, qgroups=g, operator_or=op_or)
+                    assert rows.tolist() == er.tolist(), (sentence, op_or, cols)
+                    assert (scores.view(np.uint32) == es.view(np.uint32)).all()
+    assert st.doc_freq("w0 nosuchword")[0] == ("nosuchword", 0, 0)
 
 
 # ---------------------------------------------------------------------------------------- BASELINE-size properties

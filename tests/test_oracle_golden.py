@@ -263,3 +263,30 @@ def test_lightweight_delete_goldens(name):
     alive = ~np.isin(ids, c["deleted"])
     oi, od = o.knn(np.array(c["queries"], np.float32), vecs, c["k"], o.METRIC_L2, alive=alive)
     assert ids[oi[0]].tolist() == c["ids"][0] and od[0].tolist() == f32_of(c["dists"][0]).tolist()
+
+
+def test_bm25_ex_restates_the_single_column_scorer_and_the_and_operator():
+    """oracle_bm25_search_ex: one column + OR == oracle_bm25_search (which the 00040 / 00041 goldens pin); AND keeps
+    exactly the documents holding every token (checked with python sets)."""
+    rng = np.random.default_rng(5)
+    n_docs, vocab = 3000, 50
+    lens = np.maximum(1, rng.poisson(8, n_docs))
+    toks = rng.integers(0, vocab, int(lens.sum()))
+    doc_of = np.repeat(np.arange(n_docs, dtype=np.int64), lens)
+    uk, tf = np.unique(toks.astype(np.int64) * n_docs + doc_of, return_counts=True)
+    term, doc = uk // n_docs, (uk % n_docs).astype(np.uint32)
+    post_off = np.zeros(vocab + 1, np.int64)
+    np.cumsum(np.bincount(term, minlength=vocab), out=post_off[1:])
+    fn = np.array([o.fieldnorm_id(int(n)) for n in lens], np.uint8)
+    df_all = np.diff(post_off)
+    for qt in ([1, 2], [7], [3, 9, 11]):
+        df = [int(df_all[t]) for t in qt]
+        a = o.bm25_search(post_off, doc, tf, fn, qt, df, n_docs, int(lens.sum()), 25)
+        b = o.bm25_search_ex(post_off, doc, tf, fn, qt, df, n_docs, int(lens.sum()), 25)
+        assert a[0].tolist() == b[0].tolist() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all()
+        both = set.intersection(*[set(doc[post_off[t]:post_off[t + 1]].tolist()) for t in qt])
+        c = o.bm25_search_ex(post_off, doc, tf, fn, qt, df, n_docs, int(lens.sum()), n_docs, operator_or=False)
+        assert set(c[0].tolist()) == both
+        full = o.bm25_search_ex(post_off, doc, tf, fn, qt, df, n_docs, int(lens.sum()), n_docs)
+        score_of = dict(zip(full[0].tolist(), full[1].tolist()))
+        assert all(score_of[r] == s for r, s in zip(c[0].tolist(), c[1].tolist()))
