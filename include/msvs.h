@@ -315,6 +315,9 @@ MSVS_API int msvs_bm25_search_batch(const msvs_postings_t * postings, size_t nq,
                                     uint64_t total_docs, const uint64_t * total_tokens, int operator_or,
                                     const uint64_t * alive_bits, size_t nbits, size_t k, uint64_t * row_ids, float * scores,
                                     uint32_t * n_out);
+/* Monitoring: queries scored through the sample / cut / emit path of long corpora, and how many of them needed the
+ * exact fallback (speed only; results never differ). */
+MSVS_API int msvs_bm25_stats(uint64_t * queries, uint64_t * fallbacks);
 MSVS_API int msvs_bm25_search_batch_device(const msvs_postings_t * postings, size_t nq, const uint32_t * qoff,
                                            const uint32_t * qterms, const uint32_t * qgroups, const uint64_t * df,
                                            uint64_t total_docs, const uint64_t * total_tokens, int operator_or,

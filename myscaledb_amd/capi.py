@@ -26,7 +26,7 @@ SYMBOLS = [
     "msvs_index_num_lists", "msvs_index_memory_usage", "msvs_index_search", "msvs_index_search_device",
     "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
     "msvs_postings_create", "msvs_postings_create_fields", "msvs_postings_set_alive", "msvs_postings_free",
-    "msvs_bm25_search", "msvs_bm25_search_batch", "msvs_bm25_search_batch_device", "msvs_index_scanned_rows",
+    "msvs_bm25_search", "msvs_bm25_search_batch", "msvs_bm25_search_batch_device", "msvs_bm25_stats", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
     "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option", "msvs_index_serialize_io",
     "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
@@ -484,6 +484,13 @@ class Index:
         m, dk, b = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         _check(lib().msvs_index_resource_usage(self._h, C.byref(m), C.byref(dk), C.byref(b)))
         return m.value, dk.value, b.value
+
+
+def bm25_stats():
+    """(queries through the sample / emit path, of which fallbacks)."""
+    q, f = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().msvs_bm25_stats(C.byref(q), C.byref(f)))
+    return q.value, f.value
 
 
 class Postings:

@@ -1,5 +1,7 @@
 // bm25.hip -- seam B of include/msvs.h: BM25 scoring of exported posting lists on the GPU.
+#include <atomic>
 #include <cmath>
+#include <map>
 #include <memory>
 #include <mutex>
 
@@ -15,6 +17,7 @@ struct msvs_postings
     DevBuf<uint8_t> fieldnorm_ids; // [num_fields][num_docs]
     DevBuf<uint8_t> term_field;    // empty: every term belongs to field 0
     std::vector<int64_t> h_post_off;
+    std::vector<uint8_t> h_term_field; // empty: field 0
     size_t num_terms = 0, num_docs = 0, num_postings = 0, num_fields = 1;
     // resident alive bitmap (lightweight deletes of the part): swapped under `mu`, a search keeps its own reference
     mutable std::mutex mu;
@@ -34,6 +37,26 @@ uint32_t fieldnorm_of_id(uint32_t b)
     uint64_t dec = shift < 0 ? bits : ((uint64_t)(bits | 8) << shift);
     uint64_t v = 24 + dec;
     return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
+}
+
+/// msvs_bm25_stats: queries that went through the sample / emit path, and (device side) how many of them had to take the
+/// exact fallback.
+std::atomic<unsigned long long> g_bm25_queries{0};
+unsigned long long * bm25_fail_counter()
+{
+    static std::map<int, unsigned long long *> per_device;
+    static std::mutex mu;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_device.find(dev);
+    if (it != per_device.end())
+        return it->second;
+    unsigned long long * p = nullptr;
+    MSVS_HIP(hipMalloc(&p, 8));
+    MSVS_HIP(hipMemset(p, 0, 8));
+    per_device[dev] = p;
+    return p;
 }
 
 __global__ void and_words_kernel(const uint64_t * a, size_t na, const uint64_t * b, size_t nb, uint64_t * out, size_t n)
@@ -60,8 +83,14 @@ extern "C" int msvs_postings_create_fields(const int64_t * post_off, size_t num_
         if (num_docs > 0xfffffff0ull)
             fail(MSVS_ERR_ID_RANGE, "num_docs exceeds the u32 row id range");
         for (size_t t = 0; t < num_terms; t++)
+        {
             if (post_off[t + 1] < post_off[t] || (term_field && term_field[t] >= num_fields))
                 fail(MSVS_ERR_INVALID_ARGUMENT, "posting offsets must ascend and term fields must be < num_fields");
+            // the scorer indexes LDS by doc id and relies on one posting per (term, doc): never trust the export blindly
+            for (int64_t p = post_off[t]; p < post_off[t + 1]; p++)
+                if (doc_ids[p] >= num_docs || (p > post_off[t] && doc_ids[p] <= doc_ids[p - 1]))
+                    fail(MSVS_ERR_INVALID_ARGUMENT, "doc ids must ascend inside a posting list and stay below num_docs");
+        }
         std::unique_ptr<msvs_postings> p(new msvs_postings);
         p->num_terms = num_terms;
         p->num_docs = num_docs;
@@ -82,6 +111,7 @@ extern "C" int msvs_postings_create_fields(const int64_t * post_off, size_t num_
             MSVS_HIP(hipMemcpy(p->fieldnorm_ids.p, fieldnorm_ids, num_docs * num_fields, hipMemcpyHostToDevice));
         if (term_field && num_terms)
         {
+            p->h_term_field.assign(term_field, term_field + num_terms);
             p->term_field.alloc(num_terms);
             MSVS_HIP(hipMemcpy(p->term_field.p, term_field, num_terms, hipMemcpyHostToDevice));
         }
@@ -130,9 +160,10 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
 {
     const size_t f0 = qoff[0], n_flat = qoff[nq] - f0, nf1 = std::max<size_t>(n_flat, 1), nc = ps.num_fields * 256;
     const float K1 = 1.2f;
-    // one host blob -> one copy: [qoff u32][qterms u32][weight f32][cache f32][full u16][group u8]
+    // one host blob -> one copy: [qoff u32][qterms u32][weight f32][cache f32][full u16][group u8][field u8]
     const size_t o_qoff = 0, o_terms = o_qoff + (nq + 1) * 4, o_w = o_terms + nf1 * 4, o_cache = o_w + nf1 * 4,
-                 o_full = o_cache + nc * 4, o_group = o_full + round_up(nq * 2, (size_t)4), blob_bytes = round_up(o_group + nf1, (size_t)16);
+                 o_full = o_cache + nc * 4, o_group = o_full + round_up(nq * 2, (size_t)4), o_field = o_group + nf1,
+                 blob_bytes = round_up(o_field + nf1, (size_t)16);
     auto * blob = new std::vector<unsigned char>(blob_bytes);
     std::unique_ptr<std::vector<unsigned char>> blob_owner(blob);
     uint32_t * h_qoff = reinterpret_cast<uint32_t *>(blob->data() + o_qoff);
@@ -140,6 +171,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     float * weight = reinterpret_cast<float *>(blob->data() + o_w);
     uint16_t * full = reinterpret_cast<uint16_t *>(blob->data() + o_full);
     uint8_t * group = blob->data() + o_group;
+    uint8_t * field = blob->data() + o_field;
     memcpy(blob->data() + o_cache, cache, nc * 4);
     h_qoff[0] = 0;
     for (size_t q = 0; q < nq; q++)
@@ -160,6 +192,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
             group[j - f0] = (uint8_t)(g % BM25_MAX_GROUPS);
             m |= (uint16_t)(1u << group[j - f0]);
             h_terms[j - f0] = qterms[j];
+            field[j - f0] = ps.h_term_field.empty() ? (uint8_t)0 : ps.h_term_field[qterms[j]];
             // tantivy Bm25Weight (bm25.rs): idf in f32
             volatile float x = ((float)(total_docs - df[j]) + 0.5f) / ((float)df[j] + 0.5f);
             volatile float idf = logf(1.0f + x);
@@ -168,86 +201,159 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         full[q] = m;
     }
     const uint32_t n_blocks = (uint32_t)std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)BM25_DOCS));
-    // many doc blocks: their top-k lists are merged in two levels (32 groups per query, then the group lists)
-    const uint32_t groups = n_blocks > 64 ? 32 : 1;
-    const uint32_t n_pad = (uint32_t)round_up((size_t)n_blocks, (size_t)groups);
+    // long corpora: sample -> cut -> emit -> select (+ exact fallback); short ones: per-block top-k lists, one merge
+    const bool emit = n_blocks >= 64 && options().bm25_emit != 0;
+    const uint32_t cand_cap = options().bm25_cand_cap > 0 ? (uint32_t)std::min<double>(options().bm25_cand_cap, BM25_CAND_CAP) : BM25_CAND_CAP;
+    unsigned long long * stat_fail = bm25_fail_counter();
+    const uint32_t n_sb = (uint32_t)ceil_div((size_t)n_blocks, (size_t)BM25_SAMPLE_STEP);
+    // m-th best of the sample as the cut: about STEP * m documents pass, 4 sigma (STEP * sqrt(m)) above k
+    const double rs = 2.0 + std::sqrt(4.0 + (double)k / BM25_SAMPLE_STEP);
+    const uint32_t cut_m = (uint32_t)std::min<double>(64.0, std::ceil(rs * rs));
     Scratch & scr = scratch_for(stream);
-    scr.reserve(nq * (size_t)(n_pad + groups) * k * 8 + nf1 * (size_t)(n_blocks + 1) * 8 + blob_bytes + 65536, stream);
+    scr.reserve(nq * (size_t)n_blocks * k * 8 + nf1 * (size_t)(n_blocks + 1) * 16 + blob_bytes
+                    + (emit ? nq * ((size_t)(n_sb + 1) * cut_m * 8 + (size_t)BM25_CAND_CAP * 8 + 16) : 0) + 65536,
+                stream);
     Bm25Params a{};
     unsigned char * d_blob = scr.take<unsigned char>(blob_bytes);
     int64_t * d_bounds = scr.take<int64_t>(nf1 * (n_blocks + 1));
-    uint64_t * partial = scr.take<uint64_t>(nq * (size_t)n_pad * k);
+    int64_t * d_bounds_hi = scr.take<int64_t>(nf1 * (n_blocks + 1));
+    uint64_t * partial = scr.take<uint64_t>(nq * (size_t)n_blocks * k);
     MSVS_HIP(hipMemcpyAsync(d_blob, blob->data(), blob_bytes, hipMemcpyHostToDevice, stream));
     // the blob lives until the copy has run (no host synchronisation on this path)
     MSVS_HIP(hipLaunchHostFunc(stream, [](void * p) { delete static_cast<std::vector<unsigned char> *>(p); }, blob));
     blob_owner.release();
+    a.post_off = ps.post_off.p;
+    a.doc_ids = ps.doc_ids.p;
+    a.tfs = ps.tfs.p;
+    a.fieldnorm_ids = ps.fieldnorm_ids.p;
+    a.term_field = ps.term_field.p;
     a.alive = d_alive;
     a.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
+    a.num_docs = (uint32_t)ps.num_docs;
+    a.num_fields = (uint32_t)ps.num_fields;
+    a.n_blocks = n_blocks;
+    a.last_posting = ps.num_postings ? ps.num_postings - 1 : 0;
+    a.nq = (uint32_t)nq;
+    a.n_flat = (uint32_t)nf1;
+    a.operator_or = operator_or;
     a.qoff = reinterpret_cast<uint32_t *>(d_blob + o_qoff);
     a.qterms = reinterpret_cast<uint32_t *>(d_blob + o_terms);
     a.weight = reinterpret_cast<float *>(d_blob + o_w);
     a.norm_cache = reinterpret_cast<float *>(d_blob + o_cache);
     a.qfull = reinterpret_cast<uint16_t *>(d_blob + o_full);
     a.qgroup = d_blob + o_group;
+    a.qfield = d_blob + o_field;
     a.bounds = d_bounds;
-    a.partial = partial;
-    a.post_off = ps.post_off.p;
-    a.doc_ids = ps.doc_ids.p;
-    a.tfs = ps.tfs.p;
-    a.fieldnorm_ids = ps.fieldnorm_ids.p;
-    a.term_field = ps.term_field.p;
-    a.num_docs = (uint32_t)ps.num_docs;
-    a.num_fields = (uint32_t)ps.num_fields;
-    a.n_blocks = n_blocks;
-    a.n_pad = n_pad;
-    a.k = (uint32_t)k;
-    a.nq = (uint32_t)nq;
-    a.operator_or = operator_or;
-    if (n_pad > n_blocks) // the padding lists are empty
-        for (size_t q = 0; q < nq; q++)
-            MSVS_HIP(hipMemsetAsync(partial + (q * n_pad + n_blocks) * k, 0xFF, (size_t)(n_pad - n_blocks) * k * 8, stream));
-    {
-        ProfileScope prof("bm25_score", stream);
-        if (n_flat)
-            hipLaunchKernelGGL(bm25_bounds_kernel, dim3((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256)), dim3(256),
-                               0, stream, a, (uint32_t)n_flat);
-        // enough blocks for the chip: split the batch over grid.y when the corpus has few document blocks
-        const uint32_t y = (uint32_t)std::min<size_t>(nq, std::max<size_t>(1, 2048 / n_blocks));
-        const size_t lds = (size_t)5 * k * 8;
-        const dim3 grid(n_blocks, y);
-        switch (r_for_k((uint32_t)k))
+    a.bounds_hi = d_bounds_hi;
+    auto launch_topk = [&](const Bm25Params & p, dim3 grid) {
+        const size_t lds = (size_t)5 * p.kk * 8;
+        switch (r_for_k(p.kk))
         {
             case 1:
-                hipLaunchKernelGGL((bm25_score_kernel<1>), grid, dim3(BLOCK), lds, stream, a);
+                hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 1>), grid, dim3(BLOCK), lds, stream, p);
                 break;
             case 2:
-                hipLaunchKernelGGL((bm25_score_kernel<2>), grid, dim3(BLOCK), lds, stream, a);
+                hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 2>), grid, dim3(BLOCK), lds, stream, p);
                 break;
             default:
-                hipLaunchKernelGGL((bm25_score_kernel<4>), grid, dim3(BLOCK), lds, stream, a);
+                hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 4>), grid, dim3(BLOCK), lds, stream, p);
                 break;
         }
         MSVS_HIP(hipGetLastError());
-    }
-    MergeParams m{};
-    m.partial = partial;
-    m.n_lists = n_blocks;
-    m.k = (uint32_t)k;
-    if (groups > 1)
+    };
+    ProfileScope prof("bm25_score", stream);
+    if (n_flat)
+        hipLaunchKernelGGL(bm25_bounds_kernel, dim3((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256)), dim3(256), 0,
+                           stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat);
+    if (!emit)
     {
-        uint64_t * level1 = scr.take<uint64_t>(nq * (size_t)groups * k);
-        m.n_lists = n_pad / groups; // "query" (q, g) merges lists [g * n_lists, (g + 1) * n_lists) of query q
-        m.mode = 2;
-        m.out_keys = level1;
-        launch_merge(M_IP, m, (uint32_t)(nq * groups), stream);
-        m.partial = level1;
-        m.n_lists = groups;
-        m.mode = 0;
-        m.out_keys = nullptr;
+        a.partial = partial;
+        a.kk = (uint32_t)k;
+        a.n_pad = n_blocks;
+        a.bstep = 1;
+        launch_topk(a, dim3(n_blocks, (uint32_t)std::min<size_t>(nq, std::max<size_t>(1, 2048 / n_blocks))));
+        MergeParams m{};
+        m.partial = partial;
+        m.n_lists = n_blocks;
+        m.k = (uint32_t)k;
+        m.out_ids = d_ids;
+        m.out_dis = d_scores;
+        launch_merge(M_IP, m, (uint32_t)nq, stream);
+        return;
     }
-    m.out_ids = d_ids;
-    m.out_dis = d_scores;
+    uint64_t * sample = scr.take<uint64_t>(nq * (size_t)n_sb * cut_m);
+    uint64_t * cut_keys = scr.take<uint64_t>(nq * (size_t)cut_m);
+    uint64_t * cand = scr.take<uint64_t>(nq * (size_t)BM25_CAND_CAP);
+    uint32_t * counters = scr.take<uint32_t>(2 * nq + 4); // ccnt[nq] | nfail | failq[nq]
+    MSVS_HIP(hipMemsetAsync(counters, 0, (nq + 1) * 4, stream));
+    uint32_t * ccnt = counters, * nfail = counters + nq, * failq = counters + nq + 1;
+    // 1. the sample: every 16th block, short lists
+    Bm25Params sp = a;
+    sp.partial = sample;
+    sp.kk = cut_m;
+    sp.n_pad = n_sb;
+    sp.bstep = BM25_SAMPLE_STEP;
+    launch_topk(sp, dim3(n_sb, (uint32_t)std::min<size_t>(nq, std::max<size_t>(1, 2048 / n_sb))));
+    MergeParams m{};
+    m.partial = sample;
+    m.n_lists = n_sb;
+    m.k = cut_m;
+    m.mode = 2;
+    m.out_keys = cut_keys;
     launch_merge(M_IP, m, (uint32_t)nq, stream);
+    // 2. every block: emit what passes the cut
+    Bm25Params ep = a;
+    ep.bstep = 1;
+    ep.cut_keys = cut_keys;
+    ep.cut_m = cut_m;
+    ep.cand = cand;
+    ep.ccnt = ccnt;
+    ep.cand_cap = cand_cap;
+    hipLaunchKernelGGL((bm25_score_kernel<BM25_EMIT, 1>), dim3(n_blocks, (uint32_t)std::min<size_t>(nq, ceil_div((size_t)4096, (size_t)n_blocks))),
+                       dim3(BLOCK), 0, stream, ep);
+    // 3. select, or queue for the fallback
+    const size_t lds_k = (size_t)5 * k * 8;
+    switch (r_for_k((uint32_t)k))
+    {
+        case 1:
+            hipLaunchKernelGGL((bm25_select_kernel<1>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, cand, ccnt, cand_cap, cut_keys,
+                               cut_m, (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
+            break;
+        case 2:
+            hipLaunchKernelGGL((bm25_select_kernel<2>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, cand, ccnt, cand_cap, cut_keys,
+                               cut_m, (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
+            break;
+        default:
+            hipLaunchKernelGGL((bm25_select_kernel<4>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, cand, ccnt, cand_cap, cut_keys,
+                               cut_m, (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
+            break;
+    }
+    // 4. the exact fallback over the queue (empty launches when nobody queued)
+    Bm25Params fp = a;
+    fp.partial = partial;
+    fp.kk = (uint32_t)k;
+    fp.n_pad = n_blocks;
+    fp.bstep = 1;
+    fp.qsel = failq;
+    fp.nsel = nfail;
+    launch_topk(fp, dim3(n_blocks, (uint32_t)std::min<size_t>(nq, 4)));
+    switch (r_for_k((uint32_t)k))
+    {
+        case 1:
+            hipLaunchKernelGGL((bm25_fb_merge_kernel<1>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_blocks, n_blocks,
+                               (uint32_t)k, failq, nfail, d_ids, d_scores);
+            break;
+        case 2:
+            hipLaunchKernelGGL((bm25_fb_merge_kernel<2>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_blocks, n_blocks,
+                               (uint32_t)k, failq, nfail, d_ids, d_scores);
+            break;
+        default:
+            hipLaunchKernelGGL((bm25_fb_merge_kernel<4>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_blocks, n_blocks,
+                               (uint32_t)k, failq, nfail, d_ids, d_scores);
+            break;
+    }
+    MSVS_HIP(hipGetLastError());
+    g_bm25_queries.fetch_add(nq, std::memory_order_relaxed);
 }
 
 /// The batched search: statistics -> fieldnorm caches, effective filter (resident bitmap of the part AND the per-call
@@ -304,7 +410,7 @@ void bm25_batch_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         }
     }
     const size_t n_blocks = std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)BM25_DOCS));
-    const size_t per_q = (n_blocks + 64) * k * 8;
+    const size_t per_q = (n_blocks + 64) * k * 8 + (size_t)BM25_CAND_CAP * 8;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)256 << 20) / per_q));
     for (size_t q0 = 0; q0 < nq; q0 += chunk)
     {
@@ -401,4 +507,18 @@ extern "C" int msvs_bm25_search(const msvs_postings_t * ps, const uint32_t * qte
                                           scores, &cnt);
     *n_out = cnt;
     return rc;
+}
+
+extern "C" int msvs_bm25_stats(uint64_t * queries, uint64_t * fallbacks)
+{
+    return guarded([&] {
+        unsigned long long f = 0;
+        unsigned long long * p = bm25_fail_counter();
+        MSVS_HIP(hipDeviceSynchronize());
+        MSVS_HIP(hipMemcpy(&f, p, 8, hipMemcpyDeviceToHost));
+        if (queries)
+            *queries = g_bm25_queries.load();
+        if (fallbacks)
+            *fallbacks = f;
+    });
 }

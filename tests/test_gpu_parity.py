@@ -571,8 +571,14 @@ def test_bm25_synthetic_corpus_matches_oracle():
         assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
 
 
-def test_bm25_many_doc_blocks_two_level_merge():
-    """> 64 document blocks (here 700k documents = 86 blocks): the per-block top-k lists are merged in two levels."""
+@pytest.mark.parametrize("mode", ["emit", "lists", "forced_fallback"])
+def test_bm25_many_doc_blocks(mode, opt):
+    """>= 64 document blocks (here 700k documents = 86 blocks): sample -> cut -> emit -> select; the same with the
+    candidate list too small for any query (every query takes the exact fallback); and per-block lists only."""
+    if mode == "lists":
+        opt("bm25_emit", "0")
+    if mode == "forced_fallback":
+        opt("bm25_cand_cap", "3")
     rng = np.random.default_rng(33)
     n_docs, vocab = 700_000, 1500
     p = 1.0 / np.arange(1, vocab + 1) ** 1.1
@@ -588,13 +594,23 @@ def test_bm25_many_doc_blocks_two_level_merge():
     ps = capi.Postings(post_off, doc, tf.astype(np.uint32), fn_ids)
     df_all = np.diff(post_off)
     alive = rng.random(n_docs) < 0.5
-    for qt in ([3, 40, 700], [0], [1400, 1499, 5, 90]):
+    q0, f0 = capi.bm25_stats()
+    n_q = 0
+    for qt in ([3, 40, 700], [0], [1400, 1499, 5, 90], [1499]):
         df = [int(df_all[t]) for t in qt]
-        for k, al in ((10, None), (100, None), (10, alive)):
+        for k, al in ((10, None), (100, None), (10, alive), (256, None)):
             got = ps.bm25_search(qt, df, n_docs, int(lens.sum()), k, alive=al)
             exp = o.bm25_search(post_off, doc, tf.astype(np.uint32), fn_ids, qt, df, n_docs, int(lens.sum()), k, alive=al)
             assert got[0].tolist() == exp[0].tolist()
             assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
+            n_q += 1
+    q1, f1 = capi.bm25_stats()
+    if mode == "emit":
+        assert q1 - q0 == n_q and f1 - f0 <= 1
+    if mode == "forced_fallback":
+        assert q1 - q0 == n_q and f1 - f0 == n_q
+    if mode == "lists":
+        assert q1 == q0
 
 
 def synthetic_postings(rng, n_docs, vocab, mean_len, num_fields=1):
