@@ -59,7 +59,7 @@ extern "C" int msvs_knn_bin(const uint8_t * x, const uint8_t * y, size_t nbytes,
             fail(MSVS_ERR_UNSUPPORTED_K, "k = %zu exceeds the device top-k limit %d", k, MSVS_MAX_K);
         if (ny > 0xfffffff0ull)
             fail(MSVS_ERR_ID_RANGE, "ny exceeds the u32 id range");
-        hipStream_t stream = nullptr;
+        hipStream_t stream = thread_stream();
         const uint32_t ld16 = (uint32_t)ceil_div(nbytes, (size_t)16);
         const size_t ldb = (size_t)ld16 * 16;
         if (ldb + 5 * k * 8 > SCAN_LDS_BUDGET)

@@ -436,7 +436,7 @@ extern "C" int msvs_bm25_search_batch(const msvs_postings_t * ps, size_t nq, con
             n_out[q] = 0;
         if (nq == 0 || k == 0 || ps->num_docs == 0)
             return;
-        hipStream_t stream = nullptr;
+        hipStream_t stream = thread_stream();
         Scratch & stg = staging_for(stream);
         const size_t words = alive_bits ? std::max<size_t>(1, ceil_div(nbits, (size_t)64)) : 0;
         stg.reserve(nq * k * 12 + words * 8 + 4096, stream);

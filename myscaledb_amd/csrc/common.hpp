@@ -150,6 +150,8 @@ struct Options
     double h16_grid = 0;      // shadow pass: grid size (0 = planned)
     double h16_min_pairs = 0.25; // shadow pass from this many (query, list) pairs per list on
     double h16_ncb = 0;       // shadow pass: column blocks (32 queries each) per tile, 0 = planned
+    double lat_path = 1;      // few-query IVFFLAT searches in two self-merging launches (latency_kernels.hpp): 0 off,
+                              // 1 for 1-2 queries per call, 2 up to 4
     double bm25_emit = 1;     // BM25 over long corpora: sample / cut / emit (1) or per-block top-k lists only (0)
     double bm25_cand_cap = 0; // BM25 candidate slots per query (0 = 2048; small values force the fallback)
 };

@@ -25,6 +25,20 @@ void Scratch::reserve(size_t bytes, hipStream_t stream)
     buf.alloc(cap);
 }
 
+hipStream_t thread_stream()
+{
+    static thread_local std::map<int, hipStream_t> streams;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    auto it = streams.find(dev);
+    if (it != streams.end())
+        return it->second;
+    hipStream_t s = nullptr;
+    MSVS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    streams[dev] = s;
+    return s;
+}
+
 Scratch & scratch_for(hipStream_t stream)
 {
     static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
@@ -532,6 +546,7 @@ const OptionField g_option_fields[] = {
     {"cand_cap", &Options::cand_cap},       {"ivf_eps_scale", &Options::ivf_eps_scale},
     {"h16_nt", &Options::h16_nt},           {"h16_grid", &Options::h16_grid},
     {"h16_min_pairs", &Options::h16_min_pairs}, {"h16_ncb", &Options::h16_ncb},
+    {"lat_path", &Options::lat_path},
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},
 };
 Options g_options;

@@ -29,6 +29,11 @@ struct Scratch
     }
 };
 
+/// The stream of the host-pointer entry points: one per (host thread, device), non-blocking, so that concurrent client
+/// threads (the reference runs searches on up to 2 x cores of them, ScanThreadLimiter.h) overlap on the GPU instead of
+/// queueing on the null stream.  Never destroyed: thread exit may come after the runtime is gone.
+hipStream_t thread_stream();
+
 Scratch & scratch_for(hipStream_t stream);
 /// A second arena of the same kind for the host-pointer entry points' staging copies (queries in, results out): the
 /// device-level search underneath owns scratch_for(); a hipMalloc / hipFree pair per call costs ~0.1 ms.

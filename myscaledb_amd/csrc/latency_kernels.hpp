@@ -1,0 +1,323 @@
+// latency_kernels.hpp -- the few-query (nq <= 4) IVFFLAT search in TWO launches.
+//
+// A single query of BASELINE config 2 moves ~99 MB (3 MB of centroids + 32 lists): 20 us of HBM time.  The general path
+// spends four launches on it (centroid scan, merge, list scan, merge); the two one-block merge kernels alone are 40 of
+// its 80 us -- a cold single block pays every latency (instruction fetch, first loads, LDS round trips) back to back.
+//
+//   lat_coarse_kernel : grid (c_blocks, nq).  Block b: canonical distances of c_rows centroids to the query (scan_rows,
+//                       the same arithmetic as every canonical scan: the probes equal the oracle's) -> the block's
+//                       top-nprobe list; block 0 also copies the query into device memory (it may live in pinned host
+//                       memory).  Every block announces itself on a device counter; the LAST one to arrive merges the
+//                       lists -> probes[nq][nprobe].
+//   lat_scan_kernel   : grid (items + nprobe, nq).  Block i scans the i-th equal slice of the query's probed rows
+//                       (scan_rows), publishes its top-k and arrives; the last block merges the slices' lists -> ids /
+//                       distances (device or pinned host memory) and flips the completion word a host thread may be
+//                       spinning on.
+//   (Tried: no merge in stage 1, every stage-2 block merging the centroid lists itself -- 11 us in front of every
+//   block's scan instead of 13 us once.)
+// Visibility across the 8 XCDs (one L2 each) without fences: a block's list goes out with agent-scope (write-through)
+// stores that are waited for (vmcnt) before the block's arrival, and the last block reads the lists with agent-scope
+// loads.  A __threadfence() per block writes back / invalidates a whole L2 each time: 185 us per search measured.
+// Results are bit-identical to the general path's (same scan_rows, same total order of keys).
+// profiles/r02_latency.txt has the steps that led here.
+#pragma once
+
+#include "scan_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace msvs
+{
+
+constexpr uint32_t LAT_MAX_Q = 4;  // queries per call on this path
+constexpr uint32_t LAT_MAX_K = 64; // k and nprobe (one register of a wavefront top-k)
+
+struct LatParams
+{
+    const float4 * Q; // [nq][ld4] scan-ready queries (padded; normalised for cosine), any device-visible memory
+    float4 * dq;      // [nq][ld4] device copy made by stage 1
+    uint32_t nq, ld4, k, nprobe, nlist;
+    // stage 1
+    const float4 * C;     // centroids [nlist][ld4]
+    uint32_t c_rows;      // centroids per block (a multiple of 16), c_blocks * nprobe <= HEADS_CAP
+    uint32_t c_blocks;    // ceil(nlist / c_rows)
+    uint64_t * c_partial; // [nq][c_blocks][nprobe]
+    int32_t * probes;     // [nq][nprobe]
+    // stage 2
+    const float4 * Y;
+    const uint32_t * ids;
+    const int64_t * list_off;
+    const uint64_t * alive;
+    uint32_t nbits;
+    uint32_t items;     // work items a query's probed rows are cut into (lat_cut); the grid has items + nprobe of them
+    uint64_t * partial; // [nq][items + nprobe][k]
+    int64_t * out_ids;  // [nq][k]
+    float * out_dis;
+    int cosine;
+    uint32_t * done; // [2] arrival counters of the two stages; zero between calls
+    uint32_t * flag; // nullable: host-visible completion word, set to `seq` after the results are written
+    uint32_t seq;
+    unsigned long long * dbg; // nullable: [16] wall-clock stamps (100 MHz) of the two last blocks (experiments)
+};
+
+/// All BLOCK threads: publish this block's list (k keys in LDS) and report whether it is the last block to arrive.
+__device__ __forceinline__ bool lat_publish_and_arrive(const uint64_t * lds_list, uint64_t * dst, uint32_t k, uint32_t * counter,
+                                                       uint32_t expected)
+{
+    __shared__ uint32_t s_last;
+    if (dst && threadIdx.x < k)
+        __hip_atomic_store(dst + threadIdx.x, lds_list[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0); // the write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = atomicAdd(counter, 1u) == expected - 1;
+    __syncthreads();
+    return s_last != 0;
+}
+
+__device__ __forceinline__ uint64_t lat_load_key(const uint64_t * p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/// Top-k of n_lists ascending lists of k keys each (global memory), by all BLOCK threads; returns the merged list (LDS,
+/// k keys, KEY_NONE padded).  lds: lat_merge_lds(n_lists, k) bytes.  FRESH: the lists were written by other blocks of
+/// this launch (agent-scope loads); else by an earlier launch (plain loads).
+/// Few enough keys: all of them into LDS with every load in flight at once, then ONE wavefront pops the k smallest list
+/// heads (wave_heads_merge: a wave-wide minimum and one lane's rescan per result).  More (large k): wavefront top-k over
+/// all keys, 8 loads in flight per thread, + rank merge.
+/// A loop of "load one key, offer it" pays a memory round trip per key: 25 us for 10k keys.
+inline size_t lat_merge_lds(uint32_t n_lists, uint32_t k)
+{
+    const size_t total = (size_t)n_lists * k;
+    return total <= HEADS_CAP ? total * 8 + (size_t)k * 8 + (size_t)n_lists * 2 + 16 : (size_t)5 * k * 8;
+}
+
+/// max_lists: what the launch sized the LDS for (lat_merge_lds(max_lists, k)); the path is chosen from IT, not from
+/// the lists actually present.
+template <bool FRESH>
+__device__ __forceinline__ uint64_t * lat_merge_lists(const uint64_t * src, uint32_t n_lists, uint32_t max_lists, uint32_t k,
+                                                      uint64_t * lds)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t total = n_lists * k;
+    auto load = [&](const uint64_t * p) { return FRESH ? lat_load_key(p) : *p; };
+    __syncthreads(); // whoever used this LDS region before is done
+    if (max_lists * k <= HEADS_CAP)
+    {
+        uint64_t * keys = lds;
+        uint64_t * outk = lds + total;
+        uint16_t * idx = reinterpret_cast<uint16_t *>(outk + k);
+        for (uint32_t i0 = 0; i0 < total; i0 += 8 * BLOCK)
+        {
+            uint64_t key[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const uint32_t i = i0 + u * BLOCK + tid;
+                key[u] = i < total ? load(src + i) : KEY_NONE;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const uint32_t i = i0 + u * BLOCK + tid;
+                if (i < total)
+                    keys[i] = key[u];
+            }
+        }
+        __syncthreads();
+        if (wave == 0)
+            wave_heads_merge(keys, n_lists, k, idx, outk, k, lane);
+        __syncthreads();
+        return outk;
+    }
+    // more keys than the LDS of a block takes (large k): wavefront top-k over all of them, 8 loads in flight per thread
+    WaveTopK<1> top;
+    top.init();
+    for (uint32_t i0 = 0; i0 < total; i0 += 8 * BLOCK)
+    {
+        uint64_t key[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+        {
+            const uint32_t i = i0 + u * BLOCK + tid;
+            key[u] = i < total ? load(src + i) : KEY_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            top.offer(key[u], k, lane);
+    }
+    top.store(lds + wave * k, k, lane);
+    __syncthreads();
+    uint64_t * merged = lds + 4 * k;
+    block_rank_merge(lds, k, merged, k, tid);
+    return merged;
+}
+
+/// dynamic LDS: ld4 * 16 + max(5 * nprobe * 8, lat_merge_lds(c_blocks, nprobe)) bytes
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
+{
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)p.ld4 * 16);
+    const uint32_t tid = threadIdx.x, q = blockIdx.y, b = blockIdx.x, np = p.nprobe;
+    ScanParams a{};
+    a.Y = p.C;
+    a.Q = p.Q;
+    a.ld4 = p.ld4;
+    a.k = np;
+    a.nq = p.nq;
+    __shared__ uint64_t s_list[LAT_MAX_K];
+    const unsigned long long t0 = wall_clock64();
+    uint32_t qidx[1] = {q};
+    uint64_t * out[1] = {s_list};
+    stage_queries<1>(a, qidx, qs);
+    if (b == 0)
+        for (uint32_t c = tid; c < p.ld4; c += BLOCK)
+            p.dq[(size_t)q * p.ld4 + c] = qs[c];
+    const uint32_t rb = b * p.c_rows, re = rb + p.c_rows < p.nlist ? rb + p.c_rows : p.nlist;
+    scan_rows<METRIC, 1, 1>(a, rb, re, qs, lds_merge, out);
+    __syncthreads();
+    const unsigned long long t1 = wall_clock64();
+    if (!lat_publish_and_arrive(s_list, p.c_partial + ((size_t)q * p.c_blocks + b) * np, np, p.done, gridDim.x * gridDim.y))
+        return;
+    const unsigned long long t2 = wall_clock64();
+    for (uint32_t qq = 0; qq < p.nq; qq++)
+    {
+        const uint64_t * merged = lat_merge_lists<true>(p.c_partial + (size_t)qq * p.c_blocks * np, p.c_blocks, p.c_blocks, np, lds_merge);
+        if (tid < np)
+            p.probes[(size_t)qq * np + tid] = merged[tid] == KEY_NONE ? -1 : (int32_t)(uint32_t)merged[tid];
+    }
+    if (tid == 0)
+        p.done[0] = 0;
+    if (p.dbg && tid == 0)
+    {
+        p.dbg[0] = t0;
+        p.dbg[1] = t1;
+        p.dbg[2] = t2;
+        p.dbg[3] = wall_clock64();
+    }
+}
+
+/// The rows of a query's probed lists are cut into work items of equal size WHATEVER the list lengths are (a grid shaped
+/// by the longest list leaves half its blocks without rows): rows per item = the probed rows / `items`, rounded up to the
+/// 16 rows a block scans per step; list p gets ceil(len_p / rpb) items, at most items + nprobe in total.  Every block
+/// derives the same cut from the probe list: s_first[p] = items before list p.
+struct LatCut
+{
+    uint32_t rpb, total;
+};
+__device__ __forceinline__ LatCut lat_cut(const LatParams & p, uint32_t q, int32_t * s_probe /* [nprobe] */,
+                                          uint32_t * s_first /* [nprobe + 1] */)
+{
+    __shared__ uint32_t s_len[LAT_MAX_K];
+    __shared__ uint32_t s_rpb, s_total;
+    const uint32_t tid = threadIdx.x;
+    __syncthreads();
+    if (tid < p.nprobe)
+    {
+        const int32_t l = p.probes[(size_t)q * p.nprobe + tid];
+        s_probe[tid] = l;
+        s_len[tid] = l >= 0 ? (uint32_t)(p.list_off[l + 1] - p.list_off[l]) : 0u;
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        uint64_t rows = 0;
+        for (uint32_t i = 0; i < p.nprobe; i++)
+            rows += s_len[i];
+        uint32_t rpb = (uint32_t)((rows + p.items - 1) / p.items);
+        rpb = rpb < 16 ? 16 : (rpb + 15) / 16 * 16;
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < p.nprobe; i++)
+        {
+            s_first[i] = acc;
+            acc += (s_len[i] + rpb - 1) / rpb;
+        }
+        s_first[p.nprobe] = acc;
+        s_rpb = rpb;
+        s_total = acc;
+    }
+    __syncthreads();
+    return LatCut{s_rpb, s_total};
+}
+
+/// grid (items + nprobe, nq); dynamic LDS: ld4 * 16 + max(5 * k * 8, lat_merge_lds(items + nprobe, k)) bytes
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) void lat_scan_kernel(const LatParams p)
+{
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)p.ld4 * 16);
+    __shared__ int32_t s_probe[LAT_MAX_K];
+    __shared__ uint32_t s_first[LAT_MAX_K + 1];
+    __shared__ uint64_t s_list[LAT_MAX_K];
+    const uint32_t tid = threadIdx.x, k = p.k, item = blockIdx.x, q = blockIdx.y;
+    const unsigned long long t0 = wall_clock64();
+    const LatCut cut = lat_cut(p, q, s_probe, s_first);
+    const unsigned long long t1 = wall_clock64();
+    const bool work = item < cut.total; // uniform
+    if (work)
+    {
+        uint32_t pr = 0; // the list this item belongs to (nprobe <= 64 steps)
+        while (s_first[pr + 1] <= item)
+            pr++;
+        const int32_t list = s_probe[pr];
+        const int64_t lb = p.list_off[list] + (int64_t)(item - s_first[pr]) * cut.rpb;
+        int64_t le = p.list_off[list + 1];
+        if (le > lb + cut.rpb)
+            le = lb + cut.rpb;
+        ScanParams a{};
+        a.Y = p.Y;
+        a.ids = p.ids;
+        a.alive = p.alive;
+        a.nbits = p.nbits;
+        a.Q = p.dq;
+        a.ld4 = p.ld4;
+        a.k = k;
+        a.nq = p.nq;
+        uint32_t qidx[1] = {q};
+        uint64_t * out[1] = {s_list};
+        stage_queries<1>(a, qidx, qs);
+        scan_rows<METRIC, 1, 1>(a, (uint32_t)lb, (uint32_t)le, qs, lds_merge, out);
+        __syncthreads();
+    }
+    const unsigned long long t2 = wall_clock64();
+    if (!lat_publish_and_arrive(s_list, work ? p.partial + ((size_t)q * gridDim.x + item) * k : nullptr, k, p.done + 1,
+                                gridDim.x * gridDim.y))
+        return;
+    const unsigned long long t3 = wall_clock64();
+    for (uint32_t qq = 0; qq < p.nq; qq++)
+    {
+        const uint32_t lists = qq == q ? cut.total : lat_cut(p, qq, s_probe, s_first).total;
+        const uint64_t * merged = lat_merge_lists<true>(p.partial + (size_t)qq * gridDim.x * k, lists, gridDim.x, k, lds_merge);
+        if (tid < k)
+        {
+            const uint64_t key = merged[tid];
+            const float v = key_value<METRIC>(key);
+            // system scope: the destination may be pinned host memory a host thread reads as soon as the word flips
+            __hip_atomic_store(p.out_ids + (size_t)qq * k + tid, key == KEY_NONE ? (int64_t)-1 : (int64_t)(uint32_t)key, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.out_dis + (size_t)qq * k + tid, p.cosine ? __fsub_rn(1.0f, v) : v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (tid == 0)
+        p.done[1] = 0;
+    if (p.dbg && tid == 0)
+    {
+        p.dbg[4] = t0;
+        p.dbg[5] = t1;
+        p.dbg[6] = t2;
+        p.dbg[7] = t3;
+        p.dbg[8] = wall_clock64();
+    }
+    if (p.flag)
+    {
+        __builtin_amdgcn_s_waitcnt(0); // results acknowledged before the word the host polls
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}

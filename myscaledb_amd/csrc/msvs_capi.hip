@@ -12,6 +12,7 @@
 #include "device_ops.hpp"
 #include "ivf_build_kernels.hpp"
 #include "h16_scan_kernels.hpp"
+#include "latency_kernels.hpp"
 
 namespace msvs
 {
@@ -131,7 +132,7 @@ static void knn_host(const float * x, const float * y, size_t d, size_t k, size_
         fail(MSVS_ERR_UNSUPPORTED_K, "k = %zu exceeds the limit %d", k, MSVS_MAX_K_ROUNDS);
     if (ny > 0xfffffff0ull)
         fail(MSVS_ERR_ID_RANGE, "ny exceeds the u32 id range");
-    hipStream_t stream = nullptr;
+    hipStream_t stream = thread_stream();
     const uint32_t ld = padded_dim(d);
     const uint32_t kpass = (uint32_t)std::min<size_t>(k, MSVS_MAX_K);
     const size_t bw = ceil_div(std::max<size_t>(ny, 1), 64);
@@ -1052,6 +1053,7 @@ extern "C" int msvs_index_build(msvs_index_t * ix)
         MSVS_HIP(hipMemcpy(ix->list_off.p, ix->h_list_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
         ix->chunks.clear();
         index_finalize_norms(*ix, stream);
+        MSVS_HIP(hipDeviceSynchronize()); // searches run on other (per-thread, non-blocking) streams
         ix->ready = true;
     });
 }
@@ -1972,6 +1974,212 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
 
 }
 
+// ------------------------------------------------------------------------------------------ few-query path
+
+namespace
+{
+/// Buffers of the two-launch search (latency_kernels.hpp) of one (host thread, stream): grow-only, reused call after call.
+struct LatCtx
+{
+    DevBuf<float> dq;
+    DevBuf<int32_t> probes;
+    DevBuf<uint64_t> c_partial, partial;
+    DevBuf<uint32_t> done;
+    // host side (pinned, device-visible): queries in, results + completion word out
+    unsigned char * pinned = nullptr;
+    size_t pinned_bytes = 0;
+    uint32_t seq = 0;
+    void need_pinned(size_t bytes)
+    {
+        if (bytes <= pinned_bytes)
+            return;
+        if (pinned)
+            MSVS_HIP(hipHostFree(pinned));
+        pinned = nullptr;
+        pinned_bytes = 0;
+        MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), bytes, hipHostMallocDefault));
+        pinned_bytes = bytes;
+        memset(pinned, 0, bytes);
+    }
+};
+
+LatCtx & lat_ctx(hipStream_t stream)
+{
+    static thread_local std::map<std::pair<int, hipStream_t>, LatCtx> ctxs;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    return ctxs[{dev, stream}];
+}
+
+unsigned long long * g_lat_dbg = nullptr; // experiments: msvs_lat_debug()
+
+struct LatShape
+{
+    uint32_t c_rows, c_blocks, items, grid_x;
+    size_t lds1, lds2;
+};
+
+LatShape lat_shape(const msvs_index & ix, size_t nq, size_t k, size_t nprobe)
+{
+    LatShape s{};
+    // stage 1: 32 centroids per block, more when all blocks' lists would not fit the LDS of a stage-2 block
+    s.c_rows = (uint32_t)(32 * ceil_div(ix.nlist * nprobe, (size_t)32 * HEADS_CAP));
+    s.c_blocks = (uint32_t)ceil_div(ix.nlist, (size_t)s.c_rows);
+    // work items per query: the grid (items + nprobe) is exactly 2 blocks per CU over the whole call -- a CU streams
+    // ~22 KB/us whatever runs on it, so one CU with a third block sets the time of the launch (27 us against 19)
+    s.items = (uint32_t)std::max<size_t>(nprobe, 2 * (size_t)device_cu_count() / nq > nprobe ? 2 * (size_t)device_cu_count() / nq - nprobe : nprobe);
+    s.grid_x = s.items + (uint32_t)nprobe;
+    s.lds1 = (size_t)ix.ld * 4 + std::max((size_t)5 * nprobe * 8, lat_merge_lds(s.c_blocks, (uint32_t)nprobe));
+    s.lds2 = (size_t)ix.ld * 4 + std::max((size_t)5 * k * 8, lat_merge_lds(s.grid_x, (uint32_t)k));
+    return s;
+}
+
+bool lat_eligible(const msvs_index & ix, size_t nq, size_t k, size_t nprobe)
+{
+    // beyond two queries per call the general path's batched kernels are as fast (201 vs 195 us at 4 queries)
+    if (options().lat_path == 0 || ix.type != MSVS_INDEX_IVFFLAT || !ix.ready || ix.n == 0 || nq < 1
+        || nq > std::min<size_t>(LAT_MAX_Q, options().lat_path >= 2 ? LAT_MAX_Q : 2) || k < 1
+        || k > LAT_MAX_K)
+        return false;
+    nprobe = std::min<size_t>(std::max<size_t>(nprobe, 1), ix.nlist);
+    if (nprobe > LAT_MAX_K)
+        return false;
+    const LatShape s = lat_shape(ix, nq, k, nprobe);
+    return s.lds1 <= SCAN_LDS_BUDGET && s.lds2 <= SCAN_LDS_BUDGET;
+}
+
+/// Enqueue the two launches.  Q: nq scan-ready rows of ix.ld floats (device or pinned host memory).
+void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, uint32_t k, size_t nprobe, const uint64_t * d_alive,
+                size_t nbits, int64_t * out_ids, float * out_dis, uint32_t * flag, uint32_t seq, hipStream_t stream)
+{
+    nprobe = std::min<size_t>(std::max<size_t>(nprobe, 1), ix.nlist);
+    const uint32_t ld4 = ix.ld / 4;
+    LatParams p{};
+    p.Q = reinterpret_cast<const float4 *>(Q);
+    p.nq = (uint32_t)nq;
+    p.ld4 = ld4;
+    p.k = k;
+    p.nprobe = (uint32_t)nprobe;
+    p.nlist = (uint32_t)ix.nlist;
+    p.C = reinterpret_cast<const float4 *>(ix.centroids.p);
+    const LatShape sh = lat_shape(ix, nq, k, nprobe);
+    p.c_rows = sh.c_rows;
+    p.c_blocks = sh.c_blocks;
+    p.items = sh.items;
+    const size_t grid_x = sh.grid_x;
+    const size_t n_dq = LAT_MAX_Q * (size_t)ix.ld, n_cp = nq * (size_t)p.c_blocks * nprobe, n_part = nq * grid_x * k;
+    const bool grow = c.dq.n < n_dq || c.c_partial.n < n_cp || c.partial.n < n_part || !c.done.p;
+    if (grow)
+    {
+        MSVS_HIP(hipStreamSynchronize(stream)); // an earlier call on this stream may still use the old buffers
+        if (c.dq.n < n_dq)
+            c.dq.alloc(n_dq);
+        if (!c.probes.p)
+            c.probes.alloc(LAT_MAX_Q * LAT_MAX_K);
+        if (c.c_partial.n < n_cp)
+            c.c_partial.alloc(n_cp + n_cp / 2);
+        if (c.partial.n < n_part)
+            c.partial.alloc(n_part + n_part / 2);
+        if (!c.done.p)
+        {
+            c.done.alloc(2);
+            MSVS_HIP(hipMemset(c.done.p, 0, 8));
+            MSVS_HIP(hipDeviceSynchronize());
+        }
+    }
+    p.dq = reinterpret_cast<float4 *>(c.dq.p);
+    p.c_partial = c.c_partial.p;
+    p.probes = c.probes.p;
+    p.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
+    p.ids = ix.row_ids.p;
+    p.list_off = ix.list_off.p;
+    p.alive = d_alive;
+    p.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
+    p.partial = c.partial.p;
+    p.out_ids = out_ids;
+    p.out_dis = out_dis;
+    p.cosine = ix.metric == MSVS_METRIC_COSINE;
+    p.done = c.done.p;
+    p.flag = flag;
+    p.seq = seq;
+    p.dbg = g_lat_dbg;
+    const size_t lds1 = sh.lds1, lds2 = sh.lds2;
+    const dim3 g1(p.c_blocks, (unsigned)nq), g2((unsigned)grid_x, (unsigned)nq);
+    ProfileScope prof("lat_search", stream);
+    if (ix.metric == MSVS_METRIC_L2)
+    {
+        hipLaunchKernelGGL((lat_coarse_kernel<M_L2>), g1, dim3(BLOCK), lds1, stream, p);
+        hipLaunchKernelGGL((lat_scan_kernel<M_L2>), g2, dim3(BLOCK), lds2, stream, p);
+    }
+    else
+    {
+        hipLaunchKernelGGL((lat_coarse_kernel<M_IP>), g1, dim3(BLOCK), lds1, stream, p);
+        hipLaunchKernelGGL((lat_scan_kernel<M_IP>), g2, dim3(BLOCK), lds2, stream, p);
+    }
+    MSVS_HIP(hipGetLastError());
+}
+
+/// VectorDataset::normalize() of one row on the host: the arithmetic of normalize_rows_kernel (strictly sequential f32
+/// sum of squares, IEEE sqrt and divide), so a query prepared here equals one prepared on the device bit for bit.
+void normalize_row_host(float * p, uint32_t d)
+{
+    volatile float sum = 0.f;
+    for (uint32_t j = 0; j < d; j++)
+    {
+        volatile float sq = p[j] * p[j];
+        sum = sum + sq;
+    }
+    if (sum < 1.1920928955078125e-7f)
+        return;
+    const float s = sqrtf(sum);
+    for (uint32_t j = 0; j < d; j++)
+        p[j] = p[j] / s;
+}
+
+/// Host-pointer search of a few queries: queries go in through pinned memory the kernels read directly, results and a
+/// completion word come back the same way (no memcpy calls, no stream synchronisation: the host thread spins on the
+/// word).  d_alive: the effective filter, already on the device and ordered on `stream`.
+void lat_search_host(const msvs_index & ix, const float * queries, size_t nq, uint32_t k, size_t nprobe, const uint64_t * d_alive,
+                     size_t nbits, int64_t * ids, float * dis, hipStream_t stream)
+{
+    LatCtx & c = lat_ctx(stream);
+    const size_t ld = ix.ld, o_ids = round_up(LAT_MAX_Q * ld * 4, (size_t)256), o_dis = o_ids + LAT_MAX_Q * LAT_MAX_K * 8,
+                 o_flag = o_dis + LAT_MAX_Q * LAT_MAX_K * 4;
+    c.need_pinned(o_flag + 256);
+    float * hq = reinterpret_cast<float *>(c.pinned);
+    for (size_t q = 0; q < nq; q++)
+    {
+        float * row = hq + q * ld;
+        memcpy(row, queries + q * ix.dim, ix.dim * 4);
+        for (size_t j = ix.dim; j < ld; j++)
+            row[j] = 0.f;
+        if (ix.metric == MSVS_METRIC_COSINE)
+            normalize_row_host(row, (uint32_t)ix.dim);
+    }
+    volatile uint32_t * flag = reinterpret_cast<volatile uint32_t *>(c.pinned + o_flag);
+    const uint32_t seq = ++c.seq ? c.seq : ++c.seq; // never 0: the word starts at 0
+    int64_t * h_ids = reinterpret_cast<int64_t *>(c.pinned + o_ids);
+    float * h_dis = reinterpret_cast<float *>(c.pinned + o_dis);
+    lat_launch(ix, c, hq, nq, k, nprobe, d_alive, nbits, h_ids, h_dis, const_cast<uint32_t *>(flag), seq, stream);
+    for (uint64_t spins = 1; *flag != seq; spins++)
+    {
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0) // a failed launch never sets the word: look at the stream now and then
+        {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess)
+                break;
+            if (e != hipErrorNotReady)
+                fail(MSVS_ERR_DEVICE, "few-query search: %s", hipGetErrorString(e));
+        }
+    }
+    if (*flag != seq)
+        MSVS_HIP(hipStreamSynchronize(stream));
+    memcpy(ids, h_ids, nq * k * 8);
+    memcpy(dis, h_dis, nq * k * 4);
+}
+}
+
 extern "C" int msvs_index_search_device(const msvs_index_t * ix, const float * d_queries, size_t nq, int k, int nprobe,
                                         const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids, float * d_dis,
                                         void * hip_stream)
@@ -1982,8 +2190,13 @@ extern "C" int msvs_index_search_device(const msvs_index_t * ix, const float * d
         const auto meta = ix->get_meta();
         size_t eff_bits = nbits;
         const uint64_t * eff = effective_filter(*ix, meta.get(), d_alive_bits, nbits, &eff_bits, as_stream(hip_stream));
-        index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids, d_dis,
-                            as_stream(hip_stream));
+        if (k > 0 && lat_eligible(*ix, nq, (size_t)k, (size_t)std::max(nprobe, 0)) && ix->ld == ix->dim && ix->metric != MSVS_METRIC_COSINE)
+            // a few scan-ready queries: two launches (latency_kernels.hpp)
+            lat_launch(*ix, lat_ctx(as_stream(hip_stream)), d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids,
+                       d_dis, nullptr, 0, as_stream(hip_stream));
+        else
+            index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids, d_dis,
+                                as_stream(hip_stream));
         apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, as_stream(hip_stream));
     });
 }
@@ -2007,7 +2220,7 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         long nprobe = param_int(p, "nprobe", 1);
         if (nprobe < 1)
             fail(MSVS_ERR_INVALID_ARGUMENT, "nprobe must be >= 1");
-        hipStream_t stream = nullptr;
+        hipStream_t stream = thread_stream();
         // a filter that is PRESENT with zero valid bits means "no row passes" (not "no filter"): it still travels as one
         // zero word with nbits = 0, and every id fails the `id < nbits` test
         const bool filtered = alive_bits != nullptr;
@@ -2019,7 +2232,6 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         const DevView<int64_t> d_ids{stg.take<int64_t>(nq * (size_t)k)};
         const DevView<float> d_dis{stg.take<float>(nq * (size_t)k)};
         const DevView<uint64_t> d_alive{words ? stg.take<uint64_t>(words) : nullptr};
-        MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
         if (filtered)
         {
             MSVS_HIP(hipMemsetAsync(d_alive.p, 0, words * 8, stream));
@@ -2030,6 +2242,13 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         size_t eff_bits = nbits;
         const uint64_t * eff = effective_filter(*ix, meta.get(), words ? d_alive.p : nullptr, nbits, &eff_bits, stream);
         const bool eff_filtered = eff != nullptr;
+        if (lat_eligible(*ix, nq, (size_t)k, (size_t)nprobe) && !(meta && meta->row_ids_n))
+        {
+            // a few queries: two launches, queries and results through pinned memory (no copies, no stream sync)
+            lat_search_host(*ix, queries, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, ids, dis, stream);
+            return;
+        }
+        MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
         if ((size_t)k <= MSVS_MAX_K)
             index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, d_ids.p, d_dis.p, stream);
         else
@@ -2508,6 +2727,7 @@ extern "C" int msvs_index_load_io(const msvs_io_t * io, msvs_index_t ** out)
                 MSVS_HIP(hipMemcpy(ix->row_ids.p, h32.data(), n * 4, hipMemcpyHostToDevice));
         }
         index_finalize_norms(*ix, nullptr);
+        MSVS_HIP(hipDeviceSynchronize());
         ix->ready = true;
         *out = ix.release();
     });
@@ -2832,5 +3052,20 @@ extern "C" int msvs_shard_search_device(const msvs_index_t * ix, const msvs_comm
                           reinterpret_cast<const float *>(packed + nq * (size_t)k * 8), part / 4, W, nq, (size_t)k, order, d_ids,
                           d_dis, stream);
         apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
+    });
+}
+
+/// Experiments only (not in msvs.h): wall-clock stamps (100 MHz) of the last blocks of the two few-query launches.
+extern "C" __attribute__((visibility("default"))) int msvs_lat_debug(unsigned long long * out16)
+{
+    return guarded([&] {
+        if (!g_lat_dbg)
+        {
+            MSVS_HIP(hipMalloc(&g_lat_dbg, 16 * 8));
+            MSVS_HIP(hipMemset(g_lat_dbg, 0, 16 * 8));
+        }
+        MSVS_HIP(hipDeviceSynchronize());
+        if (out16)
+            MSVS_HIP(hipMemcpy(out16, g_lat_dbg, 16 * 8, hipMemcpyDeviceToHost));
     });
 }

@@ -264,6 +264,96 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
     for (int t = 0; t < T; t++)
         top[t].init();
 
+    // one (query, float4 column) update; the accumulator of component c of query t only ever sees its own
+    // columns in ascending order, whatever the loop nest around it looks like
+    auto fma4 = [&](float4 & s, const float4 q, const float4 y) {
+        if (METRIC == M_L2)
+        {
+            float dx = __fsub_rn(q.x, y.x), dy = __fsub_rn(q.y, y.y), dz = __fsub_rn(q.z, y.z),
+                  dw = __fsub_rn(q.w, y.w);
+            s.x = __fadd_rn(s.x, __fmul_rn(dx, dx));
+            s.y = __fadd_rn(s.y, __fmul_rn(dy, dy));
+            s.z = __fadd_rn(s.z, __fmul_rn(dz, dz));
+            s.w = __fadd_rn(s.w, __fmul_rn(dw, dw));
+        }
+        else
+        {
+            s.x = __fadd_rn(s.x, __fmul_rn(q.x, y.x));
+            s.y = __fadd_rn(s.y, __fmul_rn(q.y, y.y));
+            s.z = __fadd_rn(s.z, __fmul_rn(q.z, y.z));
+            s.w = __fadd_rn(s.w, __fmul_rn(q.w, y.w));
+        }
+    };
+
+
+    // id + filter of a finished row (same value in the 16 lanes of the row; only lane g == 0 offers it), then the
+    // cross-lane sum in tree order and the offer to each query's top-k
+    auto finish_row = [&](uint32_t r, bool rv, const float4 * acc) {
+        uint32_t id = 0;
+        bool ok = rv && g == 0;
+        if (ok)
+        {
+            id = a.ids ? a.ids[r] : r + a.id_base;
+            if (a.alive)
+                ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++)
+        {
+            float s = __fadd_rn(__fadd_rn(acc[t].x, acc[t].y), __fadd_rn(acc[t].z, acc[t].w));
+            s = row16_tree_sum(s);
+            uint64_t key = ok ? make_key<METRIC>(s, id) : KEY_NONE;
+            top[t].offer(key, k, lane);
+        }
+    };
+
+    // One query, rows of exactly 12 float4 per lane (d = 768): the rows of the NEXT step are in flight while this step's
+    // are consumed (two named register sets, swapped by unrolling: a copy of a register waits for its load).  With the
+    // plain loop below every 16-row step pays a full memory round trip; a few-query search is a handful of steps per
+    // block and nothing else hides them.  Same arithmetic, same order.
+    if (T == 1 && jfull == 12 && jtail == 0)
+    {
+        const float4 * qrow = qs + g;
+        auto load_rows = [&](uint32_t base, float4 * y) {
+            const uint32_t r = base + grp;
+            const float4 * yrow = a.Y + (size_t)(r < row_end ? r : row_end - 1) * ld4 + g;
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+                y[u] = yrow[u * 16];
+        };
+        auto consume = [&](uint32_t base, const float4 * y) {
+            float4 acc[T];
+            acc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 q[12];
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+                q[u] = qrow[u * 16];
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+                fma4(acc[0], q[u], y[u]);
+            finish_row(base + grp, base + grp < row_end, acc);
+        };
+        float4 ya[12], yb[12];
+        uint32_t base = row_begin + wave * 4;
+        if (base < row_end)
+            load_rows(base, ya);
+        while (base < row_end)
+        {
+            if (base + 16 < row_end)
+                load_rows(base + 16, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(base, ya);
+            base += 16;
+            if (base >= row_end)
+                break;
+            if (base + 16 < row_end)
+                load_rows(base + 16, ya);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(base, yb);
+            base += 16;
+        }
+    }
+    else
     for (uint32_t base = row_begin + wave * 4; base < row_end; base += 16)
     {
         const uint32_t r = base + grp;
@@ -276,34 +366,13 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
         for (int t = 0; t < T; t++)
             acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-        // one (query, float4 column) update; the accumulator of component c of query t only ever sees its own
-        // columns in ascending order, whatever the loop nest around it looks like
-        auto fma4 = [&](float4 & s, const float4 q, const float4 y) {
-            if (METRIC == M_L2)
-            {
-                float dx = __fsub_rn(q.x, y.x), dy = __fsub_rn(q.y, y.y), dz = __fsub_rn(q.z, y.z),
-                      dw = __fsub_rn(q.w, y.w);
-                s.x = __fadd_rn(s.x, __fmul_rn(dx, dx));
-                s.y = __fadd_rn(s.y, __fmul_rn(dy, dy));
-                s.z = __fadd_rn(s.z, __fmul_rn(dz, dz));
-                s.w = __fadd_rn(s.w, __fmul_rn(dw, dw));
-            }
-            else
-            {
-                s.x = __fadd_rn(s.x, __fmul_rn(q.x, y.x));
-                s.y = __fadd_rn(s.y, __fmul_rn(q.y, y.y));
-                s.z = __fadd_rn(s.z, __fmul_rn(q.z, y.z));
-                s.w = __fadd_rn(s.w, __fmul_rn(q.w, y.w));
-            }
-        };
-
         // The row is consumed in chunks of JC float4 columns per lane: all JC 16-byte loads are issued first
         // (JC KiB in flight per wave), then the queries are walked OUTSIDE the columns, so only one query's
         // LDS operands are live at a time (keeps T = 8 near 128 VGPRs instead of 245).
 #ifndef MSVS_JC8
 #define MSVS_JC8 6
 #endif
-        constexpr int JC = T >= 8 ? MSVS_JC8 : 6;
+        constexpr int JC = T >= 8 ? MSVS_JC8 : (T == 1 ? 12 : 6); // one query: registers to spare, 12 KiB in flight per wave
         uint32_t j = 0;
         for (; j + JC <= jfull; j += JC)
         {
@@ -351,23 +420,7 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
                 fma4(acc[t], qrow[t * ld4 + jfull * 16], y1);
         }
 
-        // id + filter of this row (same value in the 16 lanes of the row; only lane g == 0 offers it)
-        uint32_t id = 0;
-        bool ok = rv && g == 0;
-        if (ok)
-        {
-            id = a.ids ? a.ids[r] : r + a.id_base;
-            if (a.alive)
-                ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
-        }
-#pragma unroll
-        for (int t = 0; t < T; t++)
-        {
-            float s = __fadd_rn(__fadd_rn(acc[t].x, acc[t].y), __fadd_rn(acc[t].z, acc[t].w));
-            s = row16_tree_sum(s);
-            uint64_t key = ok ? make_key<METRIC>(s, id) : KEY_NONE;
-            top[t].offer(key, k, lane);
-        }
+        finish_row(r, rv, acc);
     }
 
     // 4 wave lists -> 1 block list per query, all T queries in one pass (3 barriers per work item):
@@ -671,23 +724,33 @@ __device__ __forceinline__ uint64_t dpp64(uint64_t v)
     return (uint64_t)hi << 32 | lo;
 }
 
-/// Wave-wide minimum of a u64, result uniform: 4 DPP steps inside each 16-lane row (a few cycles each, unlike the
-/// ~100-cycle ds_bpermute behind __shfl_xor), then 4 readlanes + scalar mins across the rows.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+/// Wave-wide minimum of a u32, result uniform: 4 DPP steps inside each 16-lane row (v_min_u32 with a DPP operand each),
+/// then 4 readlanes + scalar mins across the rows.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, dpp32<0xB1>(v));  // lane ^ 1
+    v = min(v, dpp32<0x4E>(v));  // lane ^ 2
+    v = min(v, dpp32<0x141>(v)); // row_half_mirror
+    v = min(v, dpp32<0x140>(v)); // row_mirror
+    const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16),
+                   r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
+/// Wave-wide minimum of a u64, result uniform: the minimum of the high words, then the minimum of the low words among
+/// the lanes that hold it (two 32-bit reductions of single-instruction steps instead of one chain of 64-bit
+/// compare-and-selects: this sits on the serial path of every heads-merge round).
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
-    uint64_t o;
-    o = dpp64<0xB1>(v);  // lane ^ 1
-    v = o < v ? o : v;
-    o = dpp64<0x4E>(v);  // lane ^ 2
-    v = o < v ? o : v;
-    o = dpp64<0x141>(v); // row_half_mirror
-    v = o < v ? o : v;
-    o = dpp64<0x140>(v); // row_mirror
-    v = o < v ? o : v;
-    uint64_t r0 = readlane64(v, 0), r1 = readlane64(v, 16), r2 = readlane64(v, 32), r3 = readlane64(v, 48);
-    r0 = r1 < r0 ? r1 : r0;
-    r2 = r3 < r2 ? r3 : r2;
-    return r2 < r0 ? r2 : r0;
+    const uint32_t hi = (uint32_t)(v >> 32), mh = wave_min_u32(hi);
+    const uint32_t ml = wave_min_u32(hi == mh ? (uint32_t)v : 0xFFFFFFFFu);
+    return (uint64_t)mh << 32 | ml;
 }
 
 /// P sorted lists of length L staged in LDS (list i at keys[i*L ...]) -> the k smallest keys in out[0..k) (LDS), by

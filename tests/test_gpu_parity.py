@@ -526,6 +526,85 @@ def test_sharded_lists_merge_equals_unsharded():
     same(fi, fd, oi, od)
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("d", [768, 100, 30])
+def test_few_query_path_equals_general_path_and_oracle(metric, d, opt):
+    """latency_kernels.hpp (nq <= 4, k and nprobe <= 64: two self-merging launches, pinned-memory I/O) against the
+    general path (lat_path = 0) and the oracle: host-pointer entry with padding / cosine preparation on the CPU, the
+    device entry, filters, lists shorter than a segment, nprobe = nlist, repeated calls (counters reset themselves)."""
+    import torch
+
+    rng = np.random.default_rng(500 + d + metric)
+    n, nlist = 30000, 96
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    sizes = rng.integers(0, 2 * n // nlist, nlist)
+    sizes[3] = 0
+    sizes[7] = 1
+    x = np.concatenate([centers[i] + rng.standard_normal((int(sizes[i]), d), dtype=np.float32) for i in range(nlist)]).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, 4)] + rng.standard_normal((4, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, metric, nlist)
+    alive = rng.random(len(x)) < 0.3
+    for rep in range(2):
+        for nq in (1, 2, 4):
+            for k, nprobe in ((10, 8), (1, 1), (64, 64), (10, 200)):
+                for al in (None, alive):
+                    opt("lat_path", "2")
+                    ids, dis = ix.search(q[:nq], k, "nprobe=%d" % nprobe, alive=al)
+                    opt("lat_path", "0")
+                    gi, gd = ix.search(q[:nq], k, "nprobe=%d" % nprobe, alive=al)
+                    same(ids, dis, gi, gd)
+                    if rep == 0:
+                        oi, od, _ = oracle_on_exported(ix, q[:nq], nprobe, k, metric, alive=al)
+                        same(ids, dis, oi, od)
+    # the stream-ordered device entry (takes the two-launch path when the queries are scan-ready)
+    qd = torch.from_numpy(q).cuda()
+    oi_t = torch.empty((4, 10), device="cuda", dtype=torch.int64)
+    od_t = torch.empty((4, 10), device="cuda", dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    for nq in (1, 3):
+        for lp in ("2", "0"):
+            opt("lat_path", lp)
+            oi_t.fill_(-7)
+            ix.search_device(qd.data_ptr(), nq, 10, 8, oi_t.data_ptr(), od_t.data_ptr(), stream)
+            torch.cuda.synchronize()
+            hi, hd = ix.search(q[:nq], 10, "nprobe=8")
+            same(oi_t[:nq].cpu().numpy(), od_t[:nq].cpu().numpy(), hi, hd)
+
+
+def test_few_query_path_from_many_host_threads(opt):
+    """Concurrent client threads (one non-blocking stream and one set of pinned buffers per host thread): every thread
+    gets its own queries' results."""
+    import threading
+
+    rng = np.random.default_rng(77)
+    n, d, nlist = 40000, 64, 64
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, 256)] + rng.standard_normal((256, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, capi.METRIC_L2, nlist)
+    opt("lat_path", "0")
+    exp_i, exp_d = ix.search(q, 10, "nprobe=8")
+    opt("lat_path", "1")
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for j in range(t, 256, 16):
+                    i1, d1 = ix.search(q[j:j + 1], 10, "nprobe=8")
+                    if not ((i1 == exp_i[j:j + 1]).all() and (d1.view(np.uint32) == exp_d[j:j + 1].view(np.uint32)).all()):
+                        errors.append((t, j))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
+
+
 # ---------------------------------------------------------------------------------------- seam B: BM25
 
 def bm25_both(docs_texts, query, k, alive=None):
