@@ -3,25 +3,34 @@
 
 Metric   : QPS (+ p50 latency) at recall@10 >= 0.95, 1M x 768-d f32, L2, top-10.
 Workload : BASELINE.json configs[1] -- IVFFLAT nlist=1024, nprobe=32, on synthetic data of that shape.
-A "step" : one batch of `--batch` queries through msvs_index_search_device() (coarse quantiser + list scan +
+A "step" : one batch of `--batch` queries through the search entry point (coarse quantiser + list scan + exact re-rank /
            top-k merge), queries / index / outputs resident in HBM, enqueued on torch's current stream.
-N > 1    : lists sharded list_id % N (one process per GPU, torch.distributed backend nccl == RCCL); every rank
-           scans its local probed lists for the whole batch, then ONE all-gather of the partial top-k
-           (ids i64 + dist f32, batch*k*12 B per rank) and a canonical merge.  Total work is fixed => "strong".
+N = 1    : msvs_index_search_device.
+N > 1    : msvs_shard_search_device (one process per GPU; libmsvs owns the RCCL communicator): lists sharded
+           list_id % N, the coarse quantiser sharded BY QUERY, one all-gather of the probe lists, local list scans, one
+           all-gather of the packed partial top-k, canonical merge.  Total work is fixed => "strong".
 
-Data: there is no network, so vectors are synthetic (see _latent_model): a 1024-blob gaussian mixture of low
-intrinsic dimension embedded in R^768.  recall@10 against the exact FLAT scan
-(the same HIP kernels, verified bit-exact against the CPU oracle in tests/) is measured and reported.
+Data: there is no network, so vectors are synthetic.  The headline uses a 1024-blob gaussian mixture of low intrinsic
+dimension embedded in R^768 (see _latent_model: what an IVF index is built for); the `iid` leg repeats it on iid N(0,1)
+rows and queries (SURVEY 8d's first data model), where no IVF index reaches recall 0.95 at nprobe 32 -- both are reported.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description) with two extra objects:
-  roofline     -- the dominant kernel (ivf_scan_kernel): algorithmic bytes per launch (rows scanned x (4d + 4) B,
-                  rows counted exactly from the probes) / its mean HIP-event duration, vs the 8 TB/s HBM peak.
-  cpu_baseline -- the CPU oracle (same algorithm, AVX2 auto-vectorised, OpenMP over queries) on a bounded sample.
+Prints ONE JSON line on rank 0 (driver contract) with these extra objects:
+  roofline      -- the dominant kernel (the list scan: h16_sample_kernel + h16_scan_kernel, two launches per step).
+  cpu_baseline  -- the SIMD CPU restatement (oracle/simd_baseline.c, built -march=native on this machine) on a bounded sample,
+                   plus a bit-for-bit check of >= 256 bench queries against the parity oracle.
+  other_batches -- the same index at 1 / 16 / 64 / 256 / 1024 queries per step.
+  latency       -- SURVEY 8d's protocol through the host-pointer C-ABI (query in, ids + distances out): p50 / p99 of
+                   single-query calls, QPS at 1 / 8 / 64 concurrent host threads.
+  iid           -- the headline on iid gaussian data.
+  other_configs -- BASELINE configs C1 (FLAT 10k x 128), C3 (10M x 768 cosine, batches of 64), C5 (hybrid: vector top-100
+                   + BM25 top-100 over 10M documents + RRF), each with its own bytes/s figure.
+Every leg but the headline is skipped by --headline-only (profiler runs) and N > 1.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -32,7 +41,6 @@ sys.path.insert(0, ROOT)
 import myscaledb_amd.capi as capi  # noqa: E402  (raises if libmsvs.so is missing: no fallback)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-
 
 LATENT_DIM = 32
 N_BLOBS = 1024
@@ -49,10 +57,10 @@ def _latent_model(d, seed, device, blobs=N_BLOBS):
     return centres, proj
 
 
-def _sample(model, n, g, device, chunk=65536):
+def _sample(model, n, g, device, chunk=65536, out=None):
     centres, proj = model
     d = proj.shape[1]
-    x = torch.empty((n, d), device=device, dtype=torch.float32)
+    x = out if out is not None else torch.empty((n, d), device=device, dtype=torch.float32)
     for lo in range(0, n, chunk):
         hi = min(n, lo + chunk)
         z = torch.randint(0, centres.shape[0], (hi - lo,), generator=g, device=device)
@@ -72,14 +80,97 @@ def make_queries(model, nq, seed, device):
     return _sample(model, nq, g, device).contiguous()
 
 
+def build_postings(n_docs, vocab):
+    """SURVEY 8d C5 corpus on the GPU (torch is plumbing here): Zipf(1.1) vocabulary, document length ~ Poisson(30),
+    seed 5 -> (capi.Postings, df per term, total tokens, number of postings)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(5)
+    p = 1.0 / torch.arange(1, vocab + 1, device=dev, dtype=torch.float64) ** 1.1
+    lens_t = torch.clamp(torch.poisson(torch.full((n_docs,), 30.0, device=dev), generator=g), min=1).to(torch.int64)
+    total = int(lens_t.sum().item())
+    toks = torch.multinomial((p / p.sum()).to(torch.float32), total, replacement=True, generator=g)
+    doc_of = torch.repeat_interleave(torch.arange(n_docs, device=dev, dtype=torch.int64), lens_t)
+    key, _ = torch.sort(toks * n_docs + doc_of)
+    uk_t, tf_t = torch.unique_consecutive(key, return_counts=True)
+    uk, tf = uk_t.cpu().numpy(), tf_t.cpu().numpy()
+    lens = lens_t.cpu().numpy()
+    del toks, doc_of, key, uk_t, tf_t
+    term, doc = uk // n_docs, (uk % n_docs).astype(np.uint32)
+    post_off = np.zeros(vocab + 1, np.int64)
+    np.cumsum(np.bincount(term, minlength=vocab), out=post_off[1:])
+    table = [b if b < 24 else 24 + (((b - 24) & 7) if ((b - 24) >> 3) == 0 else (((b - 24) & 7) | 8) << (((b - 24) >> 3) - 1))
+             for b in range(256)]
+    fn_ids = (np.searchsorted(np.array(table, np.int64), lens, side="right") - 1).astype(np.uint8)
+    ps = capi.Postings(post_off, doc, tf.astype(np.uint32), fn_ids)
+    return ps, np.diff(post_off), total, len(doc)
+
+
+def cpu_cores():
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a cgroup CPU quota smaller than the visible core count is what the threads really get
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def timed(fn, steps, warmup=3):
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps
+
+
+def profiled(fn, steps, families):
+    """HIP-event time per step of the named kernel families (msvs_profile_*), on the launch stream."""
+    capi.profile_reset()
+    capi.profile_enable(True)
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    capi.profile_enable(False)
+    out = {}
+    for f in families:
+        c, ms = capi.profile_get(f)
+        out[f] = ms / steps if c else 0.0
+    capi.profile_reset()
+    return out
+
+
+SCAN_FAMILIES = ("ivf_scan", "ivf_sample_scan")
+STEP_FAMILIES = ("coarse_pass", "flat_scan", "merge", "ivf_plan", "ivf_prep", "ivf_sample_scan", "ivf_scan", "rerank",
+                 "fallback_scan", "fallback_merge", "lat_search")
+
+
+def recall_at_k(got, gt, k):
+    return float(np.mean([len(set(a) & set(b)) / k for a, b in zip(got.tolist(), gt.tolist())]))
+
+
+def leg(name, fn, out):
+    """Optional legs never cost the bench line: a failure is recorded instead."""
+    t = time.time()
+    try:
+        out[name] = fn()
+    except Exception as e:  # noqa: BLE001
+        out[name] = {"error": repr(e)[:300]}
+    if isinstance(out[name], dict):
+        out[name]["leg_s"] = round(time.time() - t, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    # 4096 queries per step: about 2.5 ms of arrivals at the measured rate -- what a batching front end in front of
-    # `ScanThreadLimiter`-many client threads accumulates; single-query latency is reported separately
-    # (profiles/r01_ivf_tuning_sweep.txt has the batch sweep 1 .. 16384)
+    # 4096 queries per step: about 1 ms of arrivals at the measured rate -- what a batching front end in front of
+    # `ScanThreadLimiter`-many client threads accumulates; smaller steps and single calls are reported next to it
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
@@ -88,9 +179,12 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
-                    help="only the timed steps + the roofline pass (for profiler runs: no other batches, latency, recall)")
+                    help="only the timed steps + the roofline pass (profiler runs)")
+    ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,c1,c3,c5,cpu")
+    ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the C3 / C5 legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    skip = set(x for x in args.skip.split(",") if x)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,16 +195,18 @@ def main():
     capi.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    comm = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        from myscaledb_amd import sharded
+        comm = sharded.rccl_comm()  # RCCL communicator owned by libmsvs; torch only carried the unique id
 
     n, d, nlist, nprobe, k, B = args.rows, args.dim, args.nlist, args.nprobe, args.k, args.batch
     t_setup = time.time()
     model, x = make_data(n, d, 1234, dev)
     n_pool = 8
     q_all = make_queries(model, n_pool * B, 4321, dev)
-    q_lat = make_queries(model, 256, 777, dev)
 
     # ---- build: rank 0 trains the coarse quantiser, everyone adopts the same centroids, keeps its own lists
     params = "ncentroids=%d,kmeans_iters=10,train_sample=%d,shard_rank=%d,shard_world=%d" % (
@@ -135,20 +231,15 @@ def main():
     setup_s = time.time() - t_setup
 
     stream = torch.cuda.current_stream().cuda_stream
-    if world > 1:
-        # the search writes straight into the packed exchange buffer: ONE all-gather + in-place strided merge
-        from myscaledb_amd.sharded import PackedExchange
-        xch = PackedExchange(B, k, dev)
-        out_ids, out_dis = xch.ids, xch.dis
-    else:
-        out_ids = torch.empty((B, k), device=dev, dtype=torch.int64)
-        out_dis = torch.empty((B, k), device=dev, dtype=torch.float32)
+    out_ids = torch.empty((B, k), device=dev, dtype=torch.int64)
+    out_dis = torch.empty((B, k), device=dev, dtype=torch.float32)
 
     def step(i):
         q = q_all[(i % n_pool) * B:(i % n_pool + 1) * B]
-        ix.search_device(q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
         if world > 1:
-            xch.run(capi.METRIC_L2, stream)
+            ix.shard_search_device(comm, q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
+        else:
+            ix.search_device(q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -170,197 +261,342 @@ def main():
         elapsed = float(t.item())
     qps = args.steps * B / elapsed
 
-    # ---- roofline of the dominant kernel (HIP events on the launch stream, separate pass)
-    capi.profile_reset()
-    capi.profile_enable(True)
+    # ---- roofline of the dominant kernel: the list scan = h16_sample_kernel + h16_scan_kernel (HIP events on the launch
+    # stream, separate pass over the same steps)
     pf0 = capi.prefilter_stats()
-    for i in range(min(args.steps, n_pool)):
-        step(i)
-    torch.cuda.synchronize()
-    capi.profile_enable(False)
+    n_prof = min(args.steps, n_pool)
+    fam = profiled(step, n_prof, STEP_FAMILIES)
     pf1 = capi.prefilter_stats()
-    calls, total_ms = capi.profile_get("ivf_scan")
-    s_calls, s_ms = capi.profile_get("ivf_sample_scan")  # the list scan's sample phase (candidate pass): same kernel,
-    total_ms += s_ms                                      # same step -- counted into the dominant kernel's time
-    c_calls, c_ms = capi.profile_get("flat_scan")
-    m_calls, m_ms = capi.profile_get("merge")
-    others = {}
-    for fam in ("coarse_pass", "ivf_plan", "rerank", "fallback_scan", "fallback_merge"):
-        fc, fms = capi.profile_get(fam)
-        if fc:
-            others[fam] = round(fms / fc, 4)
-    capi.profile_reset()
-    # which scan ran: the matrix-core candidate pass (split-bf16 MFMA + canonical re-rank) or the canonical VALU scan
     cand_pass = pf1[0] > pf0[0]
-    sr = [ix.scanned_rows(q_all[(i % n_pool) * B:(i % n_pool + 1) * B].cpu().numpy(), nprobe)
-          for i in range(min(args.steps, n_pool))]
-    rows_model = sum(r[0] for r in sr)     # sum over (query, probed list) of list length: SURVEY 8d per-query model
-    rows_streamed = sum(r[1] for r in sr)  # rows streamed if every (list, query tile) pass went to HBM
-    rows_unique = sum(r[2] for r in sr)    # rows probed by >= 1 query of the batch: must come from HBM once
-    # Algorithmic bytes of ONE LAUNCH (a batch): the union of the probed rows (SURVEY 8d's batch definition
-    # "card(U probed rows) x row bytes"); everything above it is re-reads the kernel design is responsible for.
-    bytes_per_launch = rows_unique * (4 * d + 4) / max(calls, 1)
-    model_bytes_per_launch = rows_model * (4 * d + 4) / max(calls, 1)
-    streamed_bytes_per_launch = rows_streamed * (4 * d + 4) / max(calls, 1)
-    scan_ms = total_ms / max(calls, 1)
-    achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    model_gbs = model_bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    streamed_gbs = streamed_bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    # measured HBM traffic of this kernel from the committed rocprofv3 --pmc passes (same workload, same batch)
+    scan_ms = fam["ivf_scan"] + fam["ivf_sample_scan"]
+    sr = [ix.scanned_rows(q_all[(i % n_pool) * B:(i % n_pool + 1) * B].cpu().numpy(), nprobe) for i in range(n_prof)]
+    rows_model = sum(r[0] for r in sr) / n_prof   # sum over (query, probed list) of list length (SURVEY 8d per-query model)
+    rows_unique = sum(r[2] for r in sr) / n_prof  # rows probed by >= 1 query of the batch: must leave HBM once
+    # ALGORITHMIC bytes of one step's list scan (batch form): the union of the probed rows x (4d + 4) B -- the
+    # f32 row + its id, whatever the kernel actually reads.  This round's kernel reads an fp16 shadow of the rows
+    # (2d B + 4 B norm) and re-ranks a few dozen f32 rows per query, so it moves about HALF the algorithmic bytes:
+    # `achieved` can exceed what HBM delivered; moved_gbs / moved_frac price the bytes the launch really has to move.
+    bytes_alg = rows_unique * (4 * d + 4)
+    bytes_moved = rows_unique * (2 * d + 8) if cand_pass else bytes_alg
+    achieved = bytes_alg / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    moved_gbs = bytes_moved / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if world == 1 and os.path.exists(tp):
         with open(tp) as f:
             tj = json.load(f)
         if tj.get("batch") == B and tj.get("rows") == n and tj.get("dim") == d:
-            traffic = tj.get("hbm_bytes_per_launch")
-    # f32 VALU work of the same launch: 3 ops (sub, mul, add) per (query, row, element), vs the 78.6 T lane-op/s
-    # non-packed VALU issue peak (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
-    valu_frac = (rows_model * d * 3 / max(calls, 1)) / (scan_ms * 1e-3) / 78.6e12 if scan_ms > 0 else 0.0
-    # compute roofline of the same launch.  Canonical scan: 3 flop (sub, mul, add; fma is forbidden by the parity
-    # contract) per (query, row, element) against the 157.3 TFLOP/s f32 peak (vector == f32-MFMA rate on gfx950).
-    # Candidate pass: 3 bf16 products (hi*hi, hi*lo, lo*hi) = 6 flop per (query, row, element) against the dense bf16
-    # MFMA peak.
-    F32_PEAK_TF = 2500.0 if cand_pass else 157.3
-    flops_per_launch = rows_model * d * (6 if cand_pass else 3) / max(calls, 1)
-    compute_tf = flops_per_launch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+            traffic = tj.get("hbm_bytes_per_step")
+    # matrix-core work of the same launches: fp16 MFMA, 2 flop per (query, probed row, element padded to 64)
+    mfma_tf = rows_model * 2 * ((d + 63) // 64 * 64) / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 and cand_pass else 0.0
     if world > 1:
-        # report the slowest rank's kernel (bytes / flops are this rank's local lists)
-        t = torch.tensor([achieved, compute_tf], device=dev, dtype=torch.float64)
+        t = torch.tensor([achieved, moved_gbs], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        achieved, compute_tf = float(t[0].item()), float(t[1].item())
-    hbm_frac, compute_frac = achieved / HBM_PEAK_GBS, compute_tf / F32_PEAK_TF
-    # the roofline that binds this launch is the resource driven closest to its peak: small batches are HBM-bound,
-    # at >= ~16 queries per list pass the f32 arithmetic takes over
-    if compute_frac > hbm_frac:
-        roof = {"bound": "mfma", "achieved": round(compute_tf, 2), "peak": F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(compute_frac, 4), "hbm_frac_union_bytes": round(hbm_frac, 4),
-                "hbm_union_gbs": round(achieved, 1)}
-    else:
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(hbm_frac, 4), "f32_compute_frac": round(compute_frac, 4),
-                "f32_compute_tflops": round(compute_tf, 2)}
+        achieved, moved_gbs = float(t[0].item()), float(t[1].item())
+    roof = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "kernel": "h16_scan_kernel + h16_sample_kernel (fp16-shadow MFMA candidate pass of the list scan; exact f32 re-rank + "
+                  "certificate follow)" if cand_pass else "ivf_batched_scan_kernel / ivf_scan_kernel (canonical f32 scan)",
+        "launch_ms": round(scan_ms, 4), "launches_per_step": 2 if fam["ivf_sample_scan"] else 1,
+        "bytes_per_launch": int(bytes_alg), "moved_bytes_per_launch": int(bytes_moved),
+        "moved_gbs": round(moved_gbs, 1), "moved_frac": round(moved_gbs / HBM_PEAK_GBS, 4),
+        "mfma_tflops": round(mfma_tf, 1), "mfma_frac_of_2500": round(mfma_tf / 2500.0, 4),
+        "per_query_model_gbs": round(rows_model * (4 * d + 4) / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else None,
+        "prefilter": [pf1[0] - pf0[0], pf1[1] - pf0[1]],
+        "step_kernels_ms": {f: round(v, 4) for f, v in fam.items() if v},
+        "note": "achieved = union of the step's probed rows x (4d+4) B (SURVEY 8d algorithmic bytes) / (sample + main "
+                "launch time, HIP events); moved_* = the same rows x (2d+8) B, what the fp16-shadow pass has to read; traffic = "
+                "FETCH_SIZE/WRITE_SIZE of both launches from rocprofv3 --pmc (profiles/); prefilter = (queries through the "
+                "candidate pass, queries that needed the canonical fallback) during the profiled steps; per_query_model_gbs "
+                "exceeds HBM speed because one pass over a list serves every query of the step that probes it",
+    }
 
-    # ---- the same index at smaller steps (single GPU only; 20 timed steps each): where the list scan reads every
-    # probed row once it runs much closer to the HBM roofline than at the headline batch
-    other = {}
-    if world == 1 and not args.headline_only:
-        for b2 in (256, 1024):
+    extra = {}
+    solo = world == 1 and not args.headline_only
+
+    # ---- the same index at other step sizes (20 timed steps each)
+    def other_batches():
+        res = {}
+        for b2 in (1, 16, 64, 256, 1024):
             if b2 >= B:
                 continue
-            o_ids = torch.empty((b2, k), device=dev, dtype=torch.int64)
-            o_dis = torch.empty((b2, k), device=dev, dtype=torch.float32)
+            o_i = torch.empty((b2, k), device=dev, dtype=torch.int64)
+            o_d = torch.empty((b2, k), device=dev, dtype=torch.float32)
 
             def step2(i):
                 lo = (i % (n_pool * B // b2)) * b2
-                ix.search_device(q_all[lo:lo + b2].data_ptr(), b2, k, nprobe, o_ids.data_ptr(), o_dis.data_ptr(), stream)
-            for i in range(3):
-                step2(i)
-            torch.cuda.synchronize()
+                ix.search_device(q_all[lo:lo + b2].data_ptr(), b2, k, nprobe, o_i.data_ptr(), o_d.data_ptr(), stream)
+            dt2 = timed(step2, 40 if b2 <= 64 else 20)
+            f2 = profiled(step2, 8, STEP_FAMILIES)
+            u2 = sum(ix.scanned_rows(q_all[i * b2:(i + 1) * b2].cpu().numpy(), nprobe)[2] for i in range(8)) / 8
+            sc = f2["ivf_scan"] + f2["ivf_sample_scan"] + f2["lat_search"]
+            # batch 1: the two-launch path, whole call (3 MB of centroids + the probed rows, f32)
+            by = u2 * (4 * d + 4) + (nlist * d * 4 if f2["lat_search"] else 0)
+            res[str(b2)] = {"qps": round(b2 / dt2, 1), "ms_per_step": round(dt2 * 1e3, 4), "list_scan_ms": round(sc, 4),
+                            "hbm_frac_algorithmic": round(by / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
+                            "path": "two-launch" if f2["lat_search"] else ("fp16-shadow pass" if f2["ivf_sample_scan"] else "canonical")}
+        return res
+
+    # ---- SURVEY 8d latency protocol through the host-pointer entry (query in, k ids + distances out)
+    def latency():
+        qh = q_all[:4096].cpu().numpy()
+        sp = "nprobe=%d" % nprobe
+        for i in range(100):
+            ix.search(qh[i:i + 1], k, sp)
+        lat = np.empty(10000)
+        for i in range(10000):
             t1 = time.perf_counter()
-            for i in range(20):
-                step2(i)
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t1) / 20
-            capi.profile_reset()
-            capi.profile_enable(True)
-            for i in range(8):
-                step2(i)
-            torch.cuda.synchronize()
-            capi.profile_enable(False)
-            c2, ms2 = capi.profile_get("ivf_scan")
-            _, sms2 = capi.profile_get("ivf_sample_scan")
-            capi.profile_reset()
-            u2 = sum(ix.scanned_rows(q_all[i * b2:(i + 1) * b2].cpu().numpy(), nprobe)[2] for i in range(8))
-            scan2 = (ms2 + sms2) / max(c2, 1)
-            other[str(b2)] = {"qps": round(b2 / dt2, 1), "ms_per_step": round(dt2 * 1e3, 4),
-                              "list_scan_ms": round(scan2, 4),
-                              "hbm_frac_union_bytes": round(u2 / 8 * (4 * d + 4) / (scan2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            ix.search(qh[i % 4096:i % 4096 + 1], k, sp)
+            lat[i] = time.perf_counter() - t1
+        res = {"calls": 10000, "p50_us": round(float(np.percentile(lat, 50)) * 1e6, 1),
+               "p99_us": round(float(np.percentile(lat, 99)) * 1e6, 1), "qps_1_thread": round(1.0 / float(lat.mean()), 1),
+               "api": "msvs_index_search (host pointers; includes launch + D2H of the k results; python ctypes call overhead included)"}
+        for c in (8, 64):
+            per = 10000 // c
+            lats = [None] * c
 
-    # ---- single-query latency (batch 1, synchronous, through the same C-ABI)
-    lat = []
-    o1i = torch.empty((1, k), device=dev, dtype=torch.int64)
-    o1d = torch.empty((1, k), device=dev, dtype=torch.float32)
-    if world == 1 and not args.headline_only:
-        for i in range(20 + 200):
-            torch.cuda.synchronize()
+            def worker(t):
+                mine = np.empty(per)
+                for i in range(per):
+                    j = (t * per + i) % 4096
+                    t1 = time.perf_counter()
+                    ix.search(qh[j:j + 1], k, sp)
+                    mine[i] = time.perf_counter() - t1
+                lats[t] = mine
+            ths = [threading.Thread(target=worker, args=(t,)) for t in range(c)]
             t1 = time.perf_counter()
-            ix.search_device(q_lat[i % 256:i % 256 + 1].data_ptr(), 1, k, nprobe, o1i.data_ptr(), o1d.data_ptr(), stream)
-            torch.cuda.synchronize()
-            if i >= 20:
-                lat.append((time.perf_counter() - t1) * 1e3)
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            el = time.perf_counter() - t1
+            al = np.concatenate(lats)
+            res["threads_%d" % c] = {"qps": round(c * per / el, 1), "p50_us": round(float(np.percentile(al, 50)) * 1e6, 1),
+                                     "p99_us": round(float(np.percentile(al, 99)) * 1e6, 1)}
+        return res
 
-    # the same single-query search captured once into a HIP graph and replayed (the C-ABI is stream-ordered and
-    # allocation-free in steady state, so it captures): the latency without the per-kernel launch gaps
-    lat_graph = []
-    if world == 1 and not args.headline_only:
-        try:
-            qg = q_lat[:1].clone()
-            cap_stream = torch.cuda.Stream()
-            with torch.cuda.stream(cap_stream):
-                ix.search_device(qg.data_ptr(), 1, k, nprobe, o1i.data_ptr(), o1d.data_ptr(), cap_stream.cuda_stream)
-            cap_stream.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=cap_stream):
-                ix.search_device(qg.data_ptr(), 1, k, nprobe, o1i.data_ptr(), o1d.data_ptr(), cap_stream.cuda_stream)
-            ref_ids = None
-            for i in range(20 + 200):
-                qg.copy_(q_lat[i % 256:i % 256 + 1])
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                graph.replay()
-                torch.cuda.synchronize()
-                if i >= 20:
-                    lat_graph.append((time.perf_counter() - t1) * 1e3)
-            # the replayed graph must return what the eager call returns
-            ix.search_device(qg.data_ptr(), 1, k, nprobe, out_ids[:1].data_ptr(), out_dis[:1].data_ptr(), stream)
-            torch.cuda.synchronize()
-            if not bool((out_ids[:1] == o1i).all()):
-                lat_graph = []
-        except Exception as e:  # capture is an extra, never a reason to lose the bench line
-            print("hip graph capture skipped: %r" % (e,), file=sys.stderr)
-            lat_graph = []
-
-    # ---- recall@10 against the exact scan of the same rows (rank 0, single GPU only: needs all lists)
+    # ---- recall@10 against the exact scan of the same rows
     recall = None
-    if world == 1 and not args.headline_only:
+    if solo:
         flat = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
         flat.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
         flat.build()
-        nr = min(1000, n_pool * B)
-        qh = q_all[:nr].cpu().numpy()
+        qh = q_all[:1000].cpu().numpy()
         gt, _ = flat.search(qh, k)
         got, _ = ix.search(qh, k, "nprobe=%d" % nprobe)
-        recall = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(got.tolist(), gt.tolist())]))
+        recall = recall_at_k(got, gt, k)
         flat.close()
 
-    # ---- CPU baseline: the oracle's IVF search (same algorithm and arithmetic) on the host cores, bounded sample
-    cpu = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and not args.headline_only:
+    # ---- CPU baseline + oracle check (before the big legs free / reuse memory)
+    def cpu_baseline():
         from oracle import oracle as o
         cent, off, vecs, lids = ix.export()
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        try:  # a cgroup CPU quota smaller than the visible core count is what the threads really get
-            with open("/sys/fs/cgroup/cpu.max") as f:
-                quota, period = f.read().split()
-            if quota != "max":
-                cores = max(1, min(cores, int(int(quota) / int(period))))
-        except (OSError, ValueError):
-            pass
+        cores = cpu_cores()
         qh = q_all[:4096].cpu().numpy()
+        o.simd_ivf_search(cent, off, vecs, lids, qh[:cores], nprobe, k, o.METRIC_L2, cores)  # builds -march=native, warms up
         t1 = time.perf_counter()
-        o.ivf_search(cent, off, vecs, lids, qh[:cores], nprobe, k, o.METRIC_L2, threads=cores)
-        per_round = max(time.perf_counter() - t1, 1e-3)
+        o.simd_ivf_search(cent, off, vecs, lids, qh[:4 * cores], nprobe, k, o.METRIC_L2, cores)
+        per_round = max(time.perf_counter() - t1, 1e-3) / 4
         nqs = int(min(4096, max(cores, cores * int(args.cpu_seconds / per_round))))
         t1 = time.perf_counter()
-        ci, _, _ = o.ivf_search(cent, off, vecs, lids, qh[:nqs], nprobe, k, o.METRIC_L2, threads=cores)
+        si, _ = o.simd_ivf_search(cent, off, vecs, lids, qh[:nqs], nprobe, k, o.METRIC_L2, cores)
         cpu_s = time.perf_counter() - t1
-        gi, _ = ix.search(qh[:nqs], k, "nprobe=%d" % nprobe)
-        cpu = {"value": round(nqs / cpu_s, 2), "unit": "queries/s", "cores": cores, "kind": "port",
-               "sample": "%d of the bench queries, same index structure (exported), oracle/msvs_oracle.c "
-                         "oracle_ivf_search_mt (AVX2 auto-vectorised, OpenMP over queries), %.1f s; ids identical to "
-                         "the GPU result: %s" % (nqs, cpu_s, bool((ci == gi).all()))}
-        del vecs
+        t1 = time.perf_counter()
+        o.simd_ivf_search(cent, off, vecs, lids, qh[:64], nprobe, k, o.METRIC_L2, 1)
+        one_thread = (time.perf_counter() - t1) / 64
+        gi, gd = ix.search(qh[:nqs], k, "nprobe=%d" % nprobe)
+        # the parity oracle (canonical arithmetic, no fma) on 256 of the bench queries: bit for bit
+        nchk = 256
+        oi, od, _ = o.ivf_search(cent, off, vecs, lids, qh[:nchk], nprobe, k, o.METRIC_L2, threads=cores)
+        exact = bool((oi == gi[:nchk]).all() and (od.view(np.uint32) == gd[:nchk].view(np.uint32)).all())
+        return {"value": round(nqs / cpu_s, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+                "simd_lanes_f32": o.simd_lanes(), "single_thread_ms_per_query": round(one_thread * 1e3, 3),
+                "sample": "%d of the bench queries on the exported index structure, oracle/simd_baseline.c (fused multiply-add "
+                          "SIMD loops built -O3 -march=native on this machine, OpenMP across queries, %d threads), %.1f s; "
+                          "recall@%d of its ids against the GPU result %.4f (fma changes last bits: not a parity oracle)"
+                          % (nqs, cores, cpu_s, k, recall_at_k(si, gi, k)),
+                "oracle_check": {"queries": nchk, "ids_and_distances_bit_identical": exact,
+                                 "oracle": "oracle/msvs_oracle.c oracle_ivf_search_mt (canonical f32 arithmetic)"}}
+
+    if solo and "other_batches" not in skip:
+        leg("other_batches", other_batches, extra)
+    if solo and "latency" not in skip:
+        leg("latency", latency, extra)
+    cpu = None
+    if solo and rank == 0 and not args.no_cpu_baseline and "cpu" not in skip:
+        tmp = {}
+        leg("cpu", cpu_baseline, tmp)
+        cpu = tmp["cpu"]
+
+    # ---- the headline on iid gaussian data (SURVEY 8d's first data model)
+    def iid():
+        g = torch.Generator(device=dev).manual_seed(1234)
+        xi = torch.randn((n, d), generator=g, device=dev, dtype=torch.float32)
+        g = torch.Generator(device=dev).manual_seed(4321)
+        qi = torch.randn((2 * B, d), generator=g, device=dev, dtype=torch.float32)
+        iix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=%d,kmeans_iters=10,train_sample=%d" % (nlist, min(n, nlist * 64)))
+        iix.train(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+        iix.add(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+        iix.build()
+
+        def istep(i):
+            iix.search_device(qi[(i % 2) * B:(i % 2 + 1) * B].data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
+        p0 = capi.prefilter_stats()
+        dt = timed(istep, 20)
+        p1 = capi.prefilter_stats()
+        fl = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
+        fl.add(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+        fl.build()
+        qh = qi[:500].cpu().numpy()
+        gt, _ = fl.search(qh, k)
+        res = {"qps": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B,
+               "candidate_pass_queries": p1[0] - p0[0], "fallback_queries": p1[1] - p0[1],
+               "data": "rows and queries iid N(0,1)^768, seeds 1234 / 4321 (torch generators on the GPU)"}
+        for npb in (nprobe, 128, 256):
+            got, _ = iix.search(qh, k, "nprobe=%d" % npb)
+            res["recall_at_%d_nprobe_%d" % (k, npb)] = round(recall_at_k(got, gt, k), 4)
+        fl.close()
+        iix.close()
+        return res
+
+    if solo and "iid" not in skip:
+        leg("iid", iid, extra)
+
+    # ---- other BASELINE configurations
+    other_cfg = {}
+
+    def c1():
+        """FLAT brute force 10k x 128 (configs[0]): the seam-A2 call (host pointers, rows uploaded per call like the
+        reference's per-part scan) and the resident-index form."""
+        rng = np.random.default_rng(1234)
+        xb = rng.standard_normal((10000, 128), dtype=np.float32)
+        qb = np.random.default_rng(4321).standard_normal((1000, 128), dtype=np.float32)
+        for i in range(20):
+            capi.knn(qb[i:i + 1], xb, 10, capi.METRIC_L2)
+        lat = []
+        for i in range(300):
+            t1 = time.perf_counter()
+            capi.knn(qb[i:i + 1], xb, 10, capi.METRIC_L2)
+            lat.append(time.perf_counter() - t1)
+        fl = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, 128)
+        fl.add(xb)
+        fl.build()
+        qd = torch.from_numpy(qb).to(dev)
+        o_i = torch.empty((1000, 10), device=dev, dtype=torch.int64)
+        o_d = torch.empty((1000, 10), device=dev, dtype=torch.float32)
+        dt1 = timed(lambda i: fl.search_device(qd[i % 1000:i % 1000 + 1].data_ptr(), 1, 10, 0, o_i.data_ptr(), o_d.data_ptr(), stream), 200)
+        dtb = timed(lambda i: fl.search_device(qd.data_ptr(), 1000, 10, 0, o_i.data_ptr(), o_d.data_ptr(), stream), 50)
+        fl.close()
+        return {"workload": "FLAT 10000 x 128 f32 L2 top-10",
+                "knn_host_call_p50_us": round(float(np.percentile(lat, 50)) * 1e6, 1),
+                "resident_nq1": {"us_per_call": round(dt1 * 1e6, 1), "hbm_frac": round(10000 * 512 / dt1 / 1e9 / HBM_PEAK_GBS, 4)},
+                "resident_nq1000": {"qps": round(1000 / dtb, 1), "ms_per_step": round(dtb * 1e3, 4)}}
+
+    big = {}
+
+    def c3():
+        """MSTG stand-in (IVFFLAT; MSTG's graph/partition format is closed source): 10M x 768 cosine, batches of 64."""
+        nb, nl, npb, bq = args.big_rows, 4096, 32, 64
+        mdl = _latent_model(d, 99, dev, 4096)
+        g = torch.Generator(device=dev).manual_seed(1234)
+        cix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_COSINE, d, "ncentroids=%d,kmeans_iters=8,train_sample=%d" % (nl, nl * 48))
+        t1 = time.time()
+        chunk = 1_000_000
+        xs = _sample(mdl, min(nb, nl * 48), g, dev)
+        cix.train(xs.data_ptr(), n=xs.shape[0], mem=capi.MEM_DEVICE)
+        del xs
+        buf = torch.empty((chunk, d), device=dev, dtype=torch.float32)
+        g = torch.Generator(device=dev).manual_seed(1234)
+        for lo in range(0, nb, chunk):
+            m = min(chunk, nb - lo)
+            _sample(mdl, m, g, dev, out=buf)
+            cix.add(buf.data_ptr(), n=m, mem=capi.MEM_DEVICE)
+        del buf
+        cix.build()
+        torch.cuda.synchronize()
+        build_s = time.time() - t1
+        qs = make_queries(mdl, 8 * bq, 4321, dev)
+        o_i = torch.empty((bq, k), device=dev, dtype=torch.int64)
+        o_d = torch.empty((bq, k), device=dev, dtype=torch.float32)
+
+        def cstep(i):
+            cix.search_device(qs[(i % 8) * bq:(i % 8 + 1) * bq].data_ptr(), bq, k, npb, o_i.data_ptr(), o_d.data_ptr(), stream)
+        dt = timed(cstep, 30)
+        f3 = profiled(cstep, 8, STEP_FAMILIES)
+        uni = sum(cix.scanned_rows(qs[i * bq:(i + 1) * bq].cpu().numpy(), npb)[2] for i in range(8)) / 8
+        sc = f3["ivf_scan"] + f3["ivf_sample_scan"]
+        big["index"], big["model"], big["nprobe"] = cix, mdl, npb
+        return {"workload": "IVFFLAT (MSTG stand-in) %d x %d cosine, nlist=%d, nprobe=%d, batch %d, top-%d" % (nb, d, nl, npb, bq, k),
+                "qps": round(bq / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "build_s": round(build_s, 1),
+                "union_rows_per_batch": int(uni), "list_scan_ms": round(sc, 4),
+                "list_scan_hbm_frac_algorithmic": round(uni * (4 * d + 4) / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
+                "whole_step_hbm_frac_algorithmic": round(uni * (4 * d + 4) / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "step_kernels_ms": {f: round(v, 4) for f, v in f3.items() if v}}
+
+    def c5():
+        """Hybrid (configs[4]): per query vector top-100 + BM25 top-100 over the same rows + RRF(k=60) -> top-10, in
+        batches of 64 (device entries for both searches, fusion in libmsvs_host.so), and the BM25 scorer alone."""
+        import myscaledb_amd.host as mhost
+        nb = args.big_rows
+        cix, mdl, npb = big["index"], big["model"], big["nprobe"]
+        ps, df_all, total, n_post = build_postings(nb, 200_000)
+        rng = np.random.default_rng(6)
+        mids = np.argsort(-df_all)[50:2000]
+        bq = 64
+        qs = make_queries(mdl, 4 * bq, 4321, dev)
+        v_i = torch.empty((bq, 100), device=dev, dtype=torch.int64)
+        v_d = torch.empty((bq, 100), device=dev, dtype=torch.float32)
+        t_i = torch.empty((bq, 100), device=dev, dtype=torch.int64)
+        t_d = torch.empty((bq, 100), device=dev, dtype=torch.float32)
+        sets = []
+        for _ in range(4):
+            terms = [rng.choice(mids, int(rng.integers(2, 5)), replace=False) for _ in range(bq)]
+            sets.append((terms, [df_all[t] for t in terms]))
+        z = np.zeros(100, np.uint64)
+
+        def hybrid(i):
+            terms, dfs = sets[i % 4]
+            cix.search_device(qs[(i % 4) * bq:(i % 4 + 1) * bq].data_ptr(), bq, 100, npb, v_i.data_ptr(), v_d.data_ptr(), stream)
+            ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), stream)
+            torch.cuda.synchronize()
+            vi, vd, ti, td = v_i.cpu().numpy(), v_d.cpu().numpy(), t_i.cpu().numpy(), t_d.cpu().numpy()
+            for qq in range(bq):
+                nt = int((ti[qq] >= 0).sum())
+                mhost.hybrid_search("rrf", (vd[qq], z, vi[qq].astype(np.uint64)), (td[qq][:nt], z[:nt], ti[qq][:nt].astype(np.uint64)), 10, fusion_k=60)
+        for i in range(2):
+            hybrid(i)
+        t1 = time.perf_counter()
+        for i in range(6):
+            hybrid(i)
+        dt = (time.perf_counter() - t1) / 6
+
+        def bstep(i):
+            terms, dfs = sets[i % 4]
+            ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), stream)
+        dtb = timed(bstep, 12)
+        fb = profiled(bstep, 4, ("bm25_score",))
+        byts = np.mean([sum(int(x_.sum()) * 8 + min(int(x_.sum()), nb) for x_ in dfs) for _, dfs in sets])
+        q0, f0 = capi.bm25_stats()
+        return {"workload": "hybrid: IVFFLAT cosine top-100 + BM25 top-100 over %d rows / documents (%d postings) + RRF k=60 -> top-10, "
+                            "batches of 64" % (nb, n_post),
+                "hybrid_qps": round(bq / dt, 1), "hybrid_ms_per_query": round(dt / bq * 1e3, 4),
+                "bm25_batch64": {"ms_per_batch": round(dtb * 1e3, 4), "us_per_query": round(dtb / bq * 1e6, 2),
+                                 "algorithmic_mb_per_batch": round(byts / 1e6, 1),
+                                 "gbs": round(byts / dtb / 1e9, 1), "hbm_frac": round(byts / dtb / 1e9 / HBM_PEAK_GBS, 4),
+                                 "score_kernels_ms": round(fb["bm25_score"], 4),
+                                 "queries_fallbacks_total": [q0, f0]}}
+
+    if solo and "c1" not in skip:
+        leg("C1", c1, other_cfg)
+    if solo and not ({"c3", "c5"} <= skip):
+        del x  # the 10M-row legs want the memory
+        torch.cuda.empty_cache()
+        leg("C3", c3, other_cfg)
+        if "c5" not in skip and "index" in big:
+            leg("C5", c5, other_cfg)
+        if "index" in big:
+            big["index"].close()
 
     if rank == 0:
         out = {
@@ -371,40 +607,22 @@ def main():
             "config": {"workload": "IVFFLAT nlist=%d, %dx%d f32, L2, nprobe=%d, top-%d, batch %d queries/step "
                                    "(BASELINE.json configs[1])" % (nlist, n, d, nprobe, k, B),
                        "rows": n, "dim": d, "nlist": nlist, "nprobe": nprobe, "k": k, "batch": B,
-                       "parallelism": "lists %% %d + all-gather top-k" % world if world > 1 else "single GPU",
+                       "parallelism": ("lists %% %d, coarse quantiser by query, probe + packed top-k all-gathers (RCCL inside "
+                                       "libmsvs)" % world) if world > 1 else "single GPU",
                        "data_model": "1024-blob gaussian mixture in a 32-d latent space embedded in R^768 + 0.05 noise, seeds 99/1234/4321"},
             "recall_at_10": None if recall is None else round(recall, 4),
-            "p50_ms_batch1": round(float(np.percentile(lat, 50)), 4) if lat else None,
-            "p99_ms_batch1": round(float(np.percentile(lat, 99)), 4) if lat else None,
-            "p50_ms_batch1_hipgraph": round(float(np.percentile(lat_graph, 50)), 4) if lat_graph else None,
-            "roofline": dict(roof, **{
-                "traffic": traffic,
-                "kernel": ("ivf_mfma_scan_big_kernel (128x128 tiles, split-bf16 MFMA candidate pass; canonical re-rank "
-                           "+ certificate follow)") if cand_pass else (
-                    "ivf_batched_scan_kernel (T-query tiles per list pass)" if B * nprobe >= nlist
-                    else "ivf_scan_kernel"), "launch_ms": round(scan_ms, 4),
-                "launches_per_step": 2 if s_calls else 1,
-                "bytes_per_launch": int(bytes_per_launch), "flops_per_launch": int(flops_per_launch),
-                "note": "hbm: achieved = union of the batch's probed rows x (4d+4) B / kernel time (each probed row "
-                        "must leave HBM at least once per launch); mfma: canonical scan = 3 flop per (query,row,element)"
-                        " vs the 157.3 TFLOP/s f32 peak (fma is excluded by the parity contract), candidate pass = 6 "
-                        "flop per (query,row,element) (three bf16 products) vs the 2500 TFLOP/s dense bf16 peak -- the "
-                        "larger fraction is the binding roofline; traffic = FETCH_SIZE x2 + WRITE_SIZE per launch from "
-                        "rocprofv3 --pmc (profiles/); per_query_model_gbs = SURVEY 8d per-query bytes x queries / time: "
-                        "it exceeds HBM speed because one pass over a list serves every query of the batch that probes "
-                        "it; prefilter = (queries through the candidate pass, queries that needed the canonical "
-                        "fallback) during the profiled steps",
-                "per_query_model_gbs": round(model_gbs, 1), "streamed_model_gbs": round(streamed_gbs, 1),
-                "valu_lane_op_frac": None if cand_pass else round(valu_frac, 4),
-                "prefilter": [pf1[0] - pf0[0], pf1[1] - pf0[1]],
-                "other_kernels_ms": dict(others, **{"coarse_flat_scan": round(c_ms / max(c_calls, 1), 4),
-                                                    "merge(avg of 2)": round(m_ms / max(m_calls, 1), 4)})}),
-            "other_batches": other,
+            "p50_ms_batch1": extra.get("latency", {}).get("p50_us", 0) / 1e3 if "latency" in extra and "p50_us" in extra["latency"] else None,
+            "roofline": roof,
             "cpu_baseline": cpu,
+            "other_batches": extra.get("other_batches"),
+            "latency": extra.get("latency"),
+            "iid": extra.get("iid"),
+            "other_configs": other_cfg or None,
             "setup_s": round(setup_s, 1),
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        comm.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -434,11 +434,13 @@ class Index:
                                              C.byref(rows), C.byref(streamed), C.byref(unique)))
         return rows.value, streamed.value, unique.value
 
-    def export(self):
+    def export(self, with_vecs=True):
+        """(centroids, list offsets, rows in storage order, ids in storage order); with_vecs=False leaves the rows on the
+        device (a 10M x 768 index is 30 GB) and returns None for them."""
         n, nl, d = self.num_data, self.num_lists, self.dim
         cent = np.empty((nl, d), np.float32) if self.index_type == INDEX_IVFFLAT else None
         off = np.empty(nl + 1, np.int64)
-        vecs = np.empty((n, d), np.float32)
+        vecs = np.empty((n, d), np.float32) if with_vecs else None
         ids = np.empty(n, np.int64)
         _check(lib().msvs_index_export(self._h, _p(cent, C.c_float), _p(off, C.c_int64), _p(vecs, C.c_float),
                                        _p(ids, C.c_int64)))

@@ -1159,11 +1159,12 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 p.grid = (uint32_t)options().ivf_grid;
             // the candidate lists are per 128-row SLICE (<= 16 keys each), whatever the work-item size
             p.seg_max = (uint32_t)std::max<size_t>(1, ceil_div(ix.max_list_len, (size_t)BG_ROWS));
-            // the canonical fallback (normally no query at all) scans a probed list with ONE block: its partial lists are
-            // nq * nprobe * k keys whatever the longest list is (segments of 256 rows made that 84 x larger on a skewed
-            // index, for a buffer that is reserved on every search)
-            p.rpb1 = (uint32_t)round_up(std::max<size_t>(ix.max_list_len, 16), 16);
-            p.seg_max1 = 1;
+            // the canonical fallback (a handful of queries per 10 000) scans a probed list with FOUR blocks: its partial
+            // lists are nq * nprobe * 4 * k keys whatever the longest list is (segments of 256 rows made that 84 x
+            // larger on a skewed index, for a buffer that is reserved on every search; one block per list made a single
+            // failing query cost 0.8 ms = 10 % of the bench step on average)
+            p.rpb1 = (uint32_t)round_up(std::max<size_t>(ceil_div(ix.max_list_len, (size_t)4), 16), 16);
+            p.seg_max1 = (uint32_t)std::max<size_t>(1, ceil_div(std::max<size_t>(ix.max_list_len, 1), (size_t)p.rpb1));
             p.fb_slots = (uint32_t)std::min<size_t>(nq, 8);
             return p;
         }

@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import myscaledb_amd.capi as capi  # noqa: E402
-from tools.microbench import build_postings  # noqa: E402
+from bench import build_postings  # noqa: E402
 
 
 def main():

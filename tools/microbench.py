@@ -18,7 +18,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import myscaledb_amd.capi as capi  # noqa: E402
-from bench import make_data, make_queries  # noqa: E402
+from bench import build_postings, make_data, make_queries  # noqa: E402
 
 
 def timed(fn, reps):
@@ -92,32 +92,6 @@ def ivf_cosine_case(n, d, nlist, batch, nprobe, k, dev, metric=capi.METRIC_COSIN
              batch / dt, rows / batch, uniq * rb / 1e9, uniq * rb / dt / 1e9, rows * rb / 1e9, f1[0] - f0[0],
              f1[1] - f0[1]), flush=True)
     ix.close()
-
-
-def build_postings(n_docs, vocab):
-    """Synthetic corpus on the GPU -> (capi.Postings, df per term, total tokens)."""
-    rng = np.random.default_rng(5)
-    dev = torch.device("cuda", 0)
-    g = torch.Generator(device=dev).manual_seed(5)
-    p = 1.0 / torch.arange(1, vocab + 1, device=dev, dtype=torch.float64) ** 1.1
-    lens_t = torch.clamp(torch.poisson(torch.full((n_docs,), 30.0, device=dev), generator=g), min=1).to(torch.int64)
-    total = int(lens_t.sum().item())
-    # corpus generation on the GPU (torch is plumbing here): Zipf tokens, then (term, doc) pairs sorted by term, doc
-    toks = torch.multinomial((p / p.sum()).to(torch.float32), total, replacement=True, generator=g)
-    doc_of = torch.repeat_interleave(torch.arange(n_docs, device=dev, dtype=torch.int64), lens_t)
-    key, _ = torch.sort(toks * n_docs + doc_of)
-    uk_t, tf_t = torch.unique_consecutive(key, return_counts=True)
-    uk, tf = uk_t.cpu().numpy(), tf_t.cpu().numpy()
-    lens = lens_t.cpu().numpy()
-    del toks, doc_of, key, uk_t, tf_t
-    term, doc = uk // n_docs, (uk % n_docs).astype(np.uint32)
-    post_off = np.zeros(vocab + 1, np.int64)
-    np.cumsum(np.bincount(term, minlength=vocab), out=post_off[1:])
-    table = [b if b < 24 else 24 + (((b - 24) & 7) if ((b - 24) >> 3) == 0 else (((b - 24) & 7) | 8) << (((b - 24) >> 3) - 1))
-             for b in range(256)]
-    fn_ids = (np.searchsorted(np.array(table, np.int64), lens, side="right") - 1).astype(np.uint8)
-    ps = capi.Postings(post_off, doc, tf.astype(np.uint32), fn_ids)
-    return ps, np.diff(post_off), total, len(doc)
 
 
 def bm25_case(n_docs, vocab, k):
