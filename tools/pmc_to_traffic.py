@@ -2,48 +2,48 @@
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/pmc_workload.py into profiles/traffic.json,
 which bench.py reports as roofline.traffic.  FETCH_SIZE is in KiB and, on gfx950, counts 64 B per 128-B request for
 wide coalesced streams: doubled (MI355X_MICROARCH.md, section HBM; calibrated in the same pass on gather_rows_kernel,
-which reads exactly rows x dim x 4 B).  WRITE_SIZE (KiB) is taken as is.
-Usage: tools/pmc_to_traffic.py <fetch.db> <write.db> <kernel substring> <batch> <rows> <dim> <round tag>"""
+which reads exactly rows x dim x 4 B).  WRITE_SIZE (KiB) is taken as is.  The list scan of a step is two launches
+(h16_sample_kernel, h16_scan_kernel): the per-step value is the sum of their per-launch means.
+Usage: tools/pmc_to_traffic.py <fetch.db> <write.db> <batch> <rows> <dim> <round tag>"""
 import json
 import os
 import sqlite3
 import sys
 
+KERNELS = ("h16_scan_kernel", "h16_sample_kernel")
+
 
 def mean(db, counter, kern):
-    """Per-step value of the list scan: the launches of `kern` with its LARGEST grid (the same kernel also runs the much
-    smaller coarse-quantiser pass) come in pairs -- a short sample phase and the main phase (value >= half the largest);
-    returns (main launches sampled, mean main + mean sample)."""
     c = sqlite3.connect(db)
-    g = list(c.execute("select max(grid_size) from counters_collection where counter_name = ? and kernel_name like ?",
-                       (counter, "%" + kern + "%")))[0][0]
-    mx = list(c.execute("select max(value) from counters_collection where counter_name = ? and kernel_name like ? "
-                        "and grid_size = ?", (counter, "%" + kern + "%", g)))[0][0] or 0.0
-    q = ("select count(*), avg(value) from counters_collection where counter_name = ? and kernel_name like ? "
-         "and grid_size = ? and value %s ?")
-    hi = list(c.execute(q % ">=", (counter, "%" + kern + "%", g, 0.5 * mx)))[0]
-    lo = list(c.execute(q % "<", (counter, "%" + kern + "%", g, 0.5 * mx)))[0]
-    return hi[0], (hi[1] or 0.0) + (lo[1] or 0.0)
+    n, v = list(c.execute("select count(*), avg(value) from counters_collection where counter_name = ? and kernel_name like ?",
+                          (counter, "%" + kern + "%")))[0]
+    return n, v or 0.0
 
 
 def main():
-    fdb, wdb, kern, batch, rows, dim, tag = sys.argv[1:8]
-    nf, f = mean(fdb, "FETCH_SIZE", kern)
-    nw, w = mean(wdb, "WRITE_SIZE", kern)
+    fdb, wdb, batch, rows, dim, tag = sys.argv[1:7]
+    per = {}
+    f_total = w_total = 0.0
+    for kname in KERNELS:
+        nf, f = mean(fdb, "FETCH_SIZE", kname)
+        nw, w = mean(wdb, "WRITE_SIZE", kname)
+        per[kname] = {"launches_sampled": nf, "fetch_kib_raw": f, "fetch_bytes": int(f * 2 * 1024), "write_bytes": int(w * 1024)}
+        f_total += f
+        w_total += w
     c = sqlite3.connect(fdb)  # the largest gather_rows_kernel call is the 1M-row list layout pass
     cal = list(c.execute("select max(value) from counters_collection where counter_name = 'FETCH_SIZE' and "
                          "kernel_name like '%gather_rows_kernel%'"))[0][0] or 0.0
-    out = {"round": tag, "kernel": kern, "batch": int(batch), "rows": int(rows), "dim": int(dim),
-           "launches_sampled": nf, "fetch_kib_raw": f, "fetch_bytes_per_launch": int(f * 2 * 1024),
-           "write_bytes_per_launch": int(w * 1024), "hbm_bytes_per_launch": int(f * 2 * 1024 + w * 1024),
+    out = {"round": tag, "kernels": per, "batch": int(batch), "rows": int(rows), "dim": int(dim),
+           "fetch_bytes_per_step": int(f_total * 2 * 1024), "write_bytes_per_step": int(w_total * 1024),
+           "hbm_bytes_per_step": int(f_total * 2 * 1024 + w_total * 1024),
            "calibration": {"kernel": "gather_rows_kernel", "expected_bytes": int(rows) * int(dim) * 4,
                            "fetch_x2_bytes": int(cal * 2 * 1024)},
-           "unit": "one search step = sample-phase launch + main-phase launch of the list scan",
-           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (separate passes), "
-                     "tools/pmc_workload.py 4 %s; FETCH_SIZE x2 (gfx950), KiB -> bytes" % batch}
+           "unit": "one search step = h16_sample_kernel launch + h16_scan_kernel launch (the list scan)",
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace (separate passes), tools/pmc_workload.py 4 %s; "
+                     "FETCH_SIZE x2 (gfx950), KiB -> bytes" % batch}
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
-    with open(path, "w") as fh:
-        json.dump(out, fh, indent=1)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
     print(json.dumps(out))
 
 
