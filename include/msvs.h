@@ -315,6 +315,36 @@ MSVS_API int msvs_bm25_search_batch(const msvs_postings_t * postings, size_t nq,
                                     uint64_t total_docs, const uint64_t * total_tokens, int operator_or,
                                     const uint64_t * alive_bits, size_t nbits, size_t k, uint64_t * row_ids, float * scores,
                                     uint32_t * n_out);
+/* ---------------------------------------------------------------------------------------------- filters (PREWHERE)
+ * The reference evaluates PREWHERE with a CPU pipeline per query and part, collects the passing `_part_offset`s and
+ * sets one bit per row (performPrefilter / getFilterFromPipeline,
+ * src/VectorIndex/Storages/MergeTreeSelectWithHybridSearchProcessor.cpp:905-1112); the bitmap then rides on the search
+ * (executeSearchWithFilter).  msvs_filter_t is that bitmap, resident on the device, with its population count:
+ *   - built from host / device words, from a list of passing row offsets (exactly getFilterFromPipeline's loop), or from a
+ *     simple predicate `column OP constant` evaluated on the device (row i of the column = `_part_offset` i);
+ *   - combined with AND / OR / AND NOT;
+ *   - handed to msvs_index_search_filter*, which picks the strategy: bit test inside the scan, or -- when few rows pass
+ *     (below 3 % .. 40 % depending on how many queries share a list pass) -- the scan of a compacted view holding only the
+ *     passing rows (same results, a fraction of the bytes).  Results are identical to msvs_index_search with the same bitmap. */
+typedef struct msvs_filter msvs_filter_t;
+typedef struct { int64_t i; double f; } msvs_scalar_t; /* .i for integer columns, .f for float columns */
+enum msvs_dtype { MSVS_DT_UINT8 = 0, MSVS_DT_UINT16, MSVS_DT_UINT32, MSVS_DT_UINT64, MSVS_DT_INT8, MSVS_DT_INT16, MSVS_DT_INT32,
+                  MSVS_DT_INT64, MSVS_DT_FLOAT32, MSVS_DT_FLOAT64 };
+enum msvs_cmp_op { MSVS_OP_EQ = 0, MSVS_OP_NE, MSVS_OP_LT, MSVS_OP_LE, MSVS_OP_GT, MSVS_OP_GE, MSVS_OP_BETWEEN /* lo <= x <= hi */ };
+enum msvs_filter_mode { MSVS_FILTER_AND = 0, MSVS_FILTER_OR = 1, MSVS_FILTER_AND_NOT = 2 };
+MSVS_API int msvs_filter_from_bits(const uint64_t * bits, size_t nbits, msvs_filter_t ** out);
+MSVS_API int msvs_filter_from_offsets(const uint64_t * part_offsets, size_t n, size_t nbits, int mem, msvs_filter_t ** out);
+MSVS_API int msvs_filter_from_predicate(const void * column, int dtype, size_t nrows, int mem, int op, msvs_scalar_t lo,
+                                        msvs_scalar_t hi, msvs_filter_t ** out);
+MSVS_API int msvs_filter_combine(msvs_filter_t * a, const msvs_filter_t * b, int mode); /* a = a MODE b */
+MSVS_API int msvs_filter_count(const msvs_filter_t * f, uint64_t * alive, size_t * nbits);
+MSVS_API int msvs_filter_to_bits(const msvs_filter_t * f, uint64_t * bits_out);
+MSVS_API void msvs_filter_free(msvs_filter_t * f);
+MSVS_API int msvs_index_search_filter(const msvs_index_t * index, const float * queries, size_t nq, int k, const char * params,
+                                      const msvs_filter_t * filter, int64_t * ids, float * dis);
+MSVS_API int msvs_index_search_filter_device(const msvs_index_t * index, const float * d_queries, size_t nq, int k, int nprobe,
+                                             const msvs_filter_t * filter, int64_t * d_ids, float * d_dis, void * hip_stream);
+
 /* Monitoring: queries scored through the sample / cut / emit path of long corpora, and how many of them needed the
  * exact fallback (speed only; results never differ). */
 MSVS_API int msvs_bm25_stats(uint64_t * queries, uint64_t * fallbacks);

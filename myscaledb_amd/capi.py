@@ -26,7 +26,9 @@ SYMBOLS = [
     "msvs_index_num_lists", "msvs_index_memory_usage", "msvs_index_search", "msvs_index_search_device",
     "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
     "msvs_postings_create", "msvs_postings_create_fields", "msvs_postings_set_alive", "msvs_postings_free",
-    "msvs_bm25_search", "msvs_bm25_search_batch", "msvs_bm25_search_batch_device", "msvs_bm25_stats", "msvs_index_scanned_rows",
+    "msvs_bm25_search", "msvs_bm25_search_batch", "msvs_bm25_search_batch_device", "msvs_bm25_stats",
+    "msvs_filter_from_bits", "msvs_filter_from_offsets", "msvs_filter_from_predicate", "msvs_filter_combine", "msvs_filter_count",
+    "msvs_filter_to_bits", "msvs_filter_free", "msvs_index_search_filter", "msvs_index_search_filter_device", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
     "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option", "msvs_index_serialize_io",
     "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
@@ -412,6 +414,21 @@ class Index:
                                        _p(bits, C.c_uint64), C.c_size_t(nbits), _p(ids, C.c_int64), _p(dis, C.c_float)))
         return ids, dis
 
+    def search_filter(self, queries, k, params, flt):
+        """msvs_index_search_filter: the library picks bit test or compacted view from the filter's population count."""
+        q = _f32(queries).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), np.int64)
+        dis = np.empty((nq, k), np.float32)
+        _check(lib().msvs_index_search_filter(self._h, _p(q, C.c_float), C.c_size_t(nq), int(k), params.encode(), flt._h,
+                                              _p(ids, C.c_int64), _p(dis, C.c_float)))
+        return ids, dis
+
+    def search_filter_device(self, d_queries, nq, k, nprobe, flt, d_ids, d_dis, stream=0):
+        _check(lib().msvs_index_search_filter_device(self._h, C.c_void_p(int(d_queries)), C.c_size_t(nq), int(k), int(nprobe), flt._h,
+                                                     C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
+                                                     C.c_void_p(int(stream)) if stream else None))
+
     def search_device(self, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0):
         """All arguments are raw device addresses (ints); enqueues on `stream` and returns immediately."""
         _check(lib().msvs_index_search_device(self._h, C.c_void_p(int(d_queries)), C.c_size_t(nq), int(k), int(nprobe),
@@ -486,6 +503,82 @@ class Index:
         m, dk, b = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
         _check(lib().msvs_index_resource_usage(self._h, C.byref(m), C.byref(dk), C.byref(b)))
         return m.value, dk.value, b.value
+
+
+class _Scalar(C.Structure):
+    _fields_ = [("i", C.c_int64), ("f", C.c_double)]
+
+
+_DTYPES = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1, np.dtype(np.uint32): 2, np.dtype(np.uint64): 3, np.dtype(np.int8): 4,
+           np.dtype(np.int16): 5, np.dtype(np.int32): 6, np.dtype(np.int64): 7, np.dtype(np.float32): 8, np.dtype(np.float64): 9}
+OPS = {"==": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "between": 6}
+FILTER_AND, FILTER_OR, FILTER_AND_NOT = 0, 1, 2
+
+
+class Filter:
+    """msvs_filter_t: a search filter (one bit per row offset of the part) resident on the device."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_bool(cls, alive):
+        bits = pack_bits(alive)
+        h = C.c_void_p()
+        _check(lib().msvs_filter_from_bits(_p(bits, C.c_uint64), C.c_size_t(len(alive)), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_offsets(cls, offsets, nbits):
+        """getFilterFromPipeline: the passing `_part_offset`s."""
+        off = np.ascontiguousarray(offsets, np.uint64)
+        h = C.c_void_p()
+        _check(lib().msvs_filter_from_offsets(_p(off, C.c_uint64), C.c_size_t(off.size), C.c_size_t(nbits), MEM_HOST, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_predicate(cls, column, op, lo, hi=0, device_ptr=None):
+        """`column OP lo` (OP in OPS; "between": lo <= x <= hi).  column: numpy array (uploaded), or pass its dtype-carrying
+        empty view plus device_ptr / len via (dtype, nrows) tuple for a column already on the device."""
+        if device_ptr is not None:
+            dt, n = column
+            ptr, mem = C.c_void_p(int(device_ptr)), MEM_DEVICE
+        else:
+            col = np.ascontiguousarray(column)
+            dt, n = col.dtype, col.size
+            ptr, mem = col.ctypes.data_as(C.c_void_p), MEM_HOST
+        isf = np.dtype(dt).kind == "f"
+        sl = _Scalar(0 if isf else int(lo), float(lo) if isf else 0.0)
+        sh = _Scalar(0 if isf else int(hi), float(hi) if isf else 0.0)
+        h = C.c_void_p()
+        lib().msvs_filter_from_predicate.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, _Scalar, _Scalar,
+                                                     C.POINTER(C.c_void_p)]
+        _check(lib().msvs_filter_from_predicate(ptr, _DTYPES[np.dtype(dt)], n, mem, OPS[op], sl, sh, C.byref(h)))
+        return cls(h)
+
+    def combine(self, other, mode=FILTER_AND):
+        _check(lib().msvs_filter_combine(self._h, other._h, int(mode)))
+        return self
+
+    def count(self):
+        a, n = C.c_uint64(0), C.c_size_t(0)
+        _check(lib().msvs_filter_count(self._h, C.byref(a), C.byref(n)))
+        return a.value, n.value
+
+    def to_bool(self):
+        alive, nbits = self.count()
+        words = np.zeros(max(1, (nbits + 63) // 64), np.uint64)
+        _check(lib().msvs_filter_to_bits(self._h, _p(words, C.c_uint64)))
+        return np.unpackbits(words.view(np.uint8), bitorder="little")[:nbits].astype(bool)
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.msvs_filter_free.argtypes = [C.c_void_p]
+            _lib.msvs_filter_free.restype = None
+            _lib.msvs_filter_free(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def bm25_stats():

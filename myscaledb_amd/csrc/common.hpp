@@ -152,6 +152,9 @@ struct Options
     double h16_ncb = 0;       // shadow pass: column blocks (32 queries each) per tile, 0 = planned
     double lat_path = 1;      // few-query IVFFLAT searches in two self-merging launches (latency_kernels.hpp): 0 off,
                               // 1 for 1-2 queries per call, 2 up to 4
+    double filter_compact_below = -1;  // filtered searches run over a compacted view when less than this fraction of the
+                                       // rows passes the filter (1: always, 0: never, < 0: by batch size,
+                                       // profiles/r02_filter.txt)
     double bm25_emit = 1;     // BM25 over long corpora: sample / cut / emit (1) or per-block top-k lists only (0)
     double bm25_cand_cap = 0; // BM25 candidate slots per query (0 = 2048; small values force the fallback)
 };

@@ -13,6 +13,7 @@
 #include "ivf_build_kernels.hpp"
 #include "h16_scan_kernels.hpp"
 #include "latency_kernels.hpp"
+#include "filter_kernels.hpp"
 
 namespace msvs
 {
@@ -60,10 +61,21 @@ static size_t flat_scratch_bytes(size_t n, size_t nq, uint32_t k, uint32_t ld)
     return flat_partial_keys(p, nq, k) * 8 + 1024;
 }
 
+/// A compacted view of an index for one search (filter_kernels.hpp): the rows a selective filter lets through.
+struct SearchView
+{
+    const int64_t * list_off; // [nlist + 1] view offsets of the lists (device)
+    const uint32_t * rowmap;  // view row -> stored row
+    const uint32_t * n_rows;  // device: rows in the view
+    size_t n_upper;           // host: an upper bound of it
+};
+
 static void flat_search_device(Scratch & scr, int metric, const float * d_rows, const uint32_t * d_row_ids, size_t n,
                                uint32_t ld, const float * d_q, size_t nq, uint32_t k, const uint64_t * d_alive,
-                               size_t nbits, MergeParams out, hipStream_t stream)
+                               size_t nbits, MergeParams out, hipStream_t stream, const SearchView * view = nullptr)
 {
+    if (view)
+        n = std::max<size_t>(1, std::min(n, view->n_upper));
     FlatPlan p = plan_flat(n, nq, ld / 4, k);
     uint64_t * partial = scr.take<uint64_t>(flat_partial_keys(p, nq, k));
     ScanParams a{};
@@ -77,6 +89,11 @@ static void flat_search_device(Scratch & scr, int metric, const float * d_rows, 
     a.k = k;
     a.nq = (uint32_t)nq;
     a.n_rows = (uint32_t)n;
+    if (view)
+    {
+        a.rowmap = view->rowmap;
+        a.n_rows_dev = view->n_rows;
+    }
     launch_flat_scan(scan_metric(metric), p, a, stream);
     out.partial = partial;
     out.n_lists = p.n_blocks;
@@ -1096,7 +1113,7 @@ struct IvfSearchPlan
     bool mfma() const { return nqg != 0; }
 };
 
-static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, uint32_t k)
+static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, uint32_t k, bool allow_pass = true)
 {
     IvfSearchPlan p{};
     const size_t pairs = nq * nprobe;
@@ -1105,7 +1122,7 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     // Matrix-core candidate pass: pays once ~4 queries share a list pass (the canonical scan is VALU-bound there);
     // needs finite, sane row norms for its error bound and k small enough for a 64-entry candidate list.
     {
-        const int mode = (int)options().ivf_pass; // experiment knob: 0 = never, 2 = whenever eligible
+        const int mode = allow_pass ? (int)options().ivf_pass : 0; // experiment knob: 0 = never, 2 = whenever eligible
         // row positions travel in the low word of the candidate keys: < 2^32 rows; NaN norms compare false
         const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f && ix.n <= 0xfffffff0ull;
         // the shadow pass keeps a whole query tile in LDS: at least one column block of 32 queries must fit
@@ -1663,7 +1680,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
 static void index_search_device_one(const msvs_index & ix, const float * d_queries, size_t nq, uint32_t k, size_t nprobe,
                                     const uint64_t * d_alive, size_t nbits, int64_t * d_ids, float * d_dis,
                                     hipStream_t stream, const int32_t * given_probes = nullptr,
-                                    int32_t * probes_only = nullptr);
+                                    int32_t * probes_only = nullptr, const SearchView * view = nullptr);
 
 /// The search proper: all pointers on the device, everything enqueued on `stream`.  Very large batches are cut into
 /// sub-batches of at most 2^21 (query, probe) pairs, stream-ordered one after the other: every scratch buffer of a search
@@ -1671,25 +1688,26 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
 static void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
                                 uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
                                 float * d_dis, hipStream_t stream, const int32_t * given_probes = nullptr,
-                                int32_t * probes_only = nullptr)
+                                int32_t * probes_only = nullptr, const SearchView * view = nullptr)
 {
     const size_t np_eff = ix.type == MSVS_INDEX_IVFFLAT ? std::max<size_t>(1, std::min(nprobe, std::max<size_t>(ix.nlist, 1))) : 1;
     const size_t sub = std::max<size_t>(256, ((size_t)1 << 21) / np_eff);
     if (nq <= sub)
         return index_search_device_one(ix, d_queries, nq, k, nprobe, d_alive, nbits, d_ids, d_dis, stream, given_probes,
-                                       probes_only);
+                                       probes_only, view);
     for (size_t q0 = 0; q0 < nq; q0 += sub)
     {
         const size_t m = std::min(sub, nq - q0);
         index_search_device_one(ix, d_queries + q0 * ix.dim, m, k, nprobe, d_alive, nbits, d_ids ? d_ids + q0 * k : nullptr,
                                 d_dis ? d_dis + q0 * k : nullptr, stream, given_probes ? given_probes + q0 * np_eff : nullptr,
-                                probes_only ? probes_only + q0 * np_eff : nullptr);
+                                probes_only ? probes_only + q0 * np_eff : nullptr, view);
     }
 }
 
 static void index_search_device_one(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
                                     uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
-                                    float * d_dis, hipStream_t stream, const int32_t * given_probes, int32_t * probes_only)
+                                    float * d_dis, hipStream_t stream, const int32_t * given_probes, int32_t * probes_only,
+                                    const SearchView * view)
 {
     if (!ix.ready)
         fail(MSVS_ERR_NOT_READY, "index is not ready");
@@ -1723,7 +1741,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     const int m = ix.metric == MSVS_METRIC_L2 ? MSVS_METRIC_L2 : MSVS_METRIC_IP;
     if (ix.type == MSVS_INDEX_FLAT)
     {
-        if (table_pass_eligible(ix.n, ix.xnorm.p, ix.xnorm_max, nq, k, options().flat_mfma))
+        if (!view && table_pass_eligible(ix.n, ix.xnorm.p, ix.xnorm_max, nq, k, options().flat_mfma))
         {
             // a batch against the whole table: matrix-core candidate pass + canonical re-rank (exact, certified)
             TablePass t{};
@@ -1743,7 +1761,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
             g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
             return;
         }
-        flat_search_device(scr, m, ix.vecs.p, ix.row_ids.p, ix.n, ld, dq, nq, k, d_alive, nbits, out, stream);
+        flat_search_device(scr, m, ix.vecs.p, ix.row_ids.p, ix.n, ld, dq, nq, k, d_alive, nbits, out, stream, view);
         return;
     }
     // 1. coarse quantiser: exact top-nprobe of the centroids (canonical arithmetic, so probes match the oracle)
@@ -1775,7 +1793,9 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     // 2. scan the probed lists
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");
-    const IvfSearchPlan pl = plan_ivf(ix, nq, nprobe, k);
+    // a compacted view is scanned canonically: the shadow / split-bf16 passes walk the stored 32-row blocks
+    const IvfSearchPlan pl = plan_ivf(ix, nq, nprobe, k, view == nullptr);
+    const int64_t * list_off = view ? view->list_off : ix.list_off.p;
     uint64_t * partial = scr.take<uint64_t>(pl.mfma() ? nq * (pl.h16 ? (size_t)pl.h_cap : big_cand_cap(nprobe, pl.seg_max))
                                                       : nq * nprobe * (size_t)pl.seg_max * k);
     ScanParams a{};
@@ -1790,7 +1810,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     a.nq = (uint32_t)nq;
     a.rows_per_block = pl.rpb;
     a.probes = d_probes;
-    a.list_off = ix.list_off.p;
+    a.list_off = list_off;
+    a.rowmap = view ? view->rowmap : nullptr;
     a.nprobe = (uint32_t)nprobe;
     a.seg_max = pl.seg_max;
     a.nlist = (uint32_t)ix.nlist;
@@ -1938,8 +1959,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         // group the (query, list) pairs by list, then one pass over each list segment per tile of T queries
         IvfPlanParams pp{};
         pp.probes = d_probes;
-        pp.list_off = ix.list_off.p;
-        pp.whole_off = ix.list_off.p;
+        pp.list_off = list_off;
+        pp.whole_off = list_off;
         pp.n_pairs = (uint32_t)(nq * nprobe);
         pp.nlist = (uint32_t)ix.nlist;
         pp.rows_per_block = pl.rpb;
@@ -1962,7 +1983,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     IvfMergeParams im{};
     im.partial = partial;
     im.probes = d_probes;
-    im.list_off = ix.list_off.p;
+    im.list_off = list_off;
     im.nprobe = (uint32_t)nprobe;
     im.seg_max = pl.seg_max;
     im.rows_per_block = pl.rpb;
@@ -2202,6 +2223,12 @@ extern "C" int msvs_index_search_device(const msvs_index_t * ix, const float * d
     });
 }
 
+namespace
+{
+void index_search_filtered(const msvs_index & ix, const float * d_queries, size_t nq, uint32_t k, size_t nprobe, const uint64_t * eff,
+                           size_t eff_bits, uint64_t alive_count, int64_t * d_ids, float * d_dis, hipStream_t stream);
+}
+
 extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
                                  const uint64_t * alive_bits, size_t nbits, int64_t * ids, float * dis)
 {
@@ -2250,7 +2277,15 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
             return;
         }
         MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
-        if ((size_t)k <= MSVS_MAX_K)
+        if ((size_t)k <= MSVS_MAX_K && filtered)
+        {
+            // the strategy (bit test / compacted view) goes by how many rows the caller's bitmap lets through
+            uint64_t alive_count = 0;
+            for (size_t w = 0; w < ceil_div(nbits, (size_t)64); w++)
+                alive_count += (uint64_t)__builtin_popcountll(alive_bits[w]);
+            index_search_filtered(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, alive_count, d_ids.p, d_dis.p, stream);
+        }
+        else if ((size_t)k <= MSVS_MAX_K)
             index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, d_ids.p, d_dis.p, stream);
         else
         {
@@ -2283,6 +2318,289 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         apply_row_ids_map(meta.get(), d_ids.p, nq * (size_t)k, stream);
         MSVS_HIP(hipMemcpyAsync(ids, d_ids.p, nq * (size_t)k * 8, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipMemcpyAsync(dis, d_dis.p, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+    });
+}
+
+// ------------------------------------------------------------------------------------------ filters
+
+struct msvs_filter
+{
+    DevBuf<uint64_t> bits;
+    size_t nbits = 0;
+    uint64_t count = 0; // passing rows (kept current by every operation: the search strategy reads it)
+};
+
+namespace
+{
+Scratch & view_for(hipStream_t stream)
+{
+    static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    return arenas[{dev, stream}];
+}
+
+void filter_recount(msvs_filter & f, hipStream_t stream)
+{
+    const size_t words = std::max<size_t>(1, ceil_div(f.nbits, (size_t)64));
+    Scratch & v = view_for(stream); // a counter word without a hipMalloc per filter
+    v.reserve(256, stream);
+    unsigned long long * c = v.take<unsigned long long>(1);
+    MSVS_HIP(hipMemsetAsync(c, 0, 8, stream));
+    hipLaunchKernelGGL(filter_count_kernel, dim3((unsigned)ceil_div(words, (size_t)256)), dim3(256), 0, stream, f.bits.p, words, f.nbits, c);
+    unsigned long long h = 0;
+    MSVS_HIP(hipMemcpyAsync(&h, c, 8, hipMemcpyDeviceToHost, stream));
+    MSVS_HIP(hipStreamSynchronize(stream));
+    f.count = h;
+}
+
+std::unique_ptr<msvs_filter> filter_alloc(size_t nbits, hipStream_t stream)
+{
+    std::unique_ptr<msvs_filter> f(new msvs_filter);
+    f->nbits = nbits;
+    const size_t words = std::max<size_t>(1, ceil_div(nbits, (size_t)64));
+    f->bits.alloc(words);
+    MSVS_HIP(hipMemsetAsync(f->bits.p, 0, words * 8, stream));
+    return f;
+}
+
+/// Build the compacted view of `ix` under the effective filter (everything enqueued on `stream`, scratch from view_for()).
+SearchView build_view(const msvs_index & ix, const uint64_t * d_alive, size_t nbits, size_t alive_upper, hipStream_t stream)
+{
+    const size_t n = ix.n, chunks = std::max<size_t>(1, ceil_div(n, (size_t)COMPACT_CHUNK));
+    const size_t upper = std::max<size_t>(1, std::min(n, alive_upper));
+    Scratch & v = view_for(stream);
+    v.reserve((chunks + 2) * 4 + (n + 2) * 4 + upper * 4 + (ix.nlist + 2) * 8 + 4096, stream);
+    CompactParams p{};
+    p.ids = ix.row_ids.p;
+    p.alive = d_alive;
+    p.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
+    p.n = (uint32_t)n;
+    p.chunk_cnt = v.take<uint32_t>(chunks + 1);
+    p.rank = v.take<uint32_t>(n + 1);
+    p.rowmap = v.take<uint32_t>(upper);
+    p.list_off = ix.type == MSVS_INDEX_IVFFLAT ? ix.list_off.p : nullptr;
+    p.nlist = (uint32_t)ix.nlist;
+    p.sel_off = v.take<int64_t>(ix.nlist + 1);
+    ProfileScope prof("filter_view", stream);
+    hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)chunks), dim3(BLOCK), 0, stream, p);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, p, (uint32_t)chunks);
+    hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)chunks), dim3(BLOCK), 0, stream, p);
+    if (p.list_off)
+        hipLaunchKernelGGL(compact_offsets_kernel, dim3((unsigned)ceil_div(ix.nlist + 1, (size_t)256)), dim3(256), 0, stream, p);
+    MSVS_HIP(hipGetLastError());
+    SearchView view{};
+    view.list_off = p.sel_off;
+    view.rowmap = p.rowmap;
+    view.n_rows = p.rank + n;
+    view.n_upper = upper;
+    return view;
+}
+
+/// The search of a filtered batch: selective filters go through the compacted view, the others through the bit test.
+/// alive_count: passing rows of the caller's filter (an upper bound of what passes the effective filter inside the index).
+void index_search_filtered(const msvs_index & ix, const float * d_queries, size_t nq, uint32_t k, size_t nprobe, const uint64_t * eff,
+                           size_t eff_bits, uint64_t alive_count, int64_t * d_ids, float * d_dis, hipStream_t stream)
+{
+    const double frac = ix.n ? (double)alive_count / (double)ix.n : 1.0;
+    double below = options().filter_compact_below;
+    if (below < 0)
+    {
+        // measured crossover (profiles/r02_filter.txt, 1M x 768): the view is scanned canonically, so it competes with the
+        // matrix-core candidate pass once many queries share a list pass -- 16 queries: wins below ~50 % passing,
+        // 256: below ~30 %, 4096: below ~3 %
+        const double per_list = ix.type == MSVS_INDEX_IVFFLAT ? (double)nq * (double)std::max<size_t>(nprobe, 1) / (double)std::max<size_t>(ix.nlist, 1)
+                                                               : (double)nq;
+        below = per_list < 2 ? 0.4 : (per_list < 16 ? 0.25 : 0.03);
+    }
+    // the view costs ~5 B per stored row: for one or two queries that is more than the probed lists themselves
+    const bool worth = nq * std::max<size_t>(nprobe, 1) * 4 >= ix.nlist || ix.type == MSVS_INDEX_FLAT;
+    if (eff && ix.n && (below >= 1.0 || (frac < below && worth)) && alive_count <= 0xfffffff0ull && ix.n <= 0xfffffff0ull)
+    {
+        const SearchView view = build_view(ix, eff, eff_bits, (size_t)alive_count, stream);
+        index_search_device(ix, d_queries, nq, k, nprobe, nullptr, 0, d_ids, d_dis, stream, nullptr, nullptr, &view);
+        return;
+    }
+    index_search_device(ix, d_queries, nq, k, nprobe, eff, eff_bits, d_ids, d_dis, stream);
+}
+}
+
+extern "C" int msvs_filter_from_bits(const uint64_t * bits, size_t nbits, msvs_filter_t ** out)
+{
+    return guarded([&] {
+        if (!out || (nbits && !bits))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
+        hipStream_t stream = thread_stream();
+        auto f = filter_alloc(nbits, stream);
+        if (nbits)
+            MSVS_HIP(hipMemcpyAsync(f->bits.p, bits, ceil_div(nbits, (size_t)64) * 8, hipMemcpyHostToDevice, stream));
+        filter_recount(*f, stream);
+        *out = f.release();
+    });
+}
+
+/// getFilterFromPipeline (MergeTreeSelectWithHybridSearchProcessor.cpp:905-934): one bit per passing `_part_offset`.
+extern "C" int msvs_filter_from_offsets(const uint64_t * part_offsets, size_t n, size_t nbits, int mem, msvs_filter_t ** out)
+{
+    return guarded([&] {
+        if (!out || (n && !part_offsets))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
+        hipStream_t stream = thread_stream();
+        auto f = filter_alloc(nbits, stream);
+        if (n)
+        {
+            const uint64_t * d_off = part_offsets;
+            DevBuf<uint64_t> tmp;
+            if (mem != MSVS_MEM_DEVICE)
+            {
+                tmp.alloc(n);
+                MSVS_HIP(hipMemcpyAsync(tmp.p, part_offsets, n * 8, hipMemcpyHostToDevice, stream));
+                d_off = tmp.p;
+            }
+            hipLaunchKernelGGL(filter_from_offsets_kernel, dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, d_off, n, nbits,
+                               reinterpret_cast<unsigned long long *>(f->bits.p));
+            MSVS_HIP(hipGetLastError());
+            filter_recount(*f, stream); // also orders tmp's release after the kernel
+        }
+        *out = f.release();
+    });
+}
+
+namespace
+{
+template <typename T>
+void launch_predicate(const void * col, size_t n, int mem, int op, T lo, T hi, msvs_filter & f, hipStream_t stream)
+{
+    const T * d_col = static_cast<const T *>(col);
+    DevBuf<T> tmp;
+    if (mem != MSVS_MEM_DEVICE)
+    {
+        tmp.alloc(std::max<size_t>(n, 1));
+        MSVS_HIP(hipMemcpyAsync(tmp.p, col, n * sizeof(T), hipMemcpyHostToDevice, stream));
+        d_col = tmp.p;
+    }
+    hipLaunchKernelGGL((filter_predicate_kernel<T>), dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, d_col, n, op, lo, hi,
+                       f.bits.p);
+    MSVS_HIP(hipGetLastError());
+    filter_recount(f, stream);
+}
+}
+
+/// A simple PREWHERE predicate `column OP constant` evaluated on the device: row i of the column is `_part_offset` i.
+extern "C" int msvs_filter_from_predicate(const void * column, int dtype, size_t nrows, int mem, int op, msvs_scalar_t lo,
+                                          msvs_scalar_t hi, msvs_filter_t ** out)
+{
+    return guarded([&] {
+        if (!out || (nrows && !column))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
+        if (op < MSVS_OP_EQ || op > MSVS_OP_BETWEEN)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "unknown comparison %d", op);
+        hipStream_t stream = thread_stream();
+        auto f = filter_alloc(nrows, stream);
+        if (nrows)
+            switch (dtype)
+            {
+                case MSVS_DT_UINT8: launch_predicate<uint8_t>(column, nrows, mem, op, (uint8_t)lo.i, (uint8_t)hi.i, *f, stream); break;
+                case MSVS_DT_UINT16: launch_predicate<uint16_t>(column, nrows, mem, op, (uint16_t)lo.i, (uint16_t)hi.i, *f, stream); break;
+                case MSVS_DT_UINT32: launch_predicate<uint32_t>(column, nrows, mem, op, (uint32_t)lo.i, (uint32_t)hi.i, *f, stream); break;
+                case MSVS_DT_UINT64: launch_predicate<uint64_t>(column, nrows, mem, op, (uint64_t)lo.i, (uint64_t)hi.i, *f, stream); break;
+                case MSVS_DT_INT8: launch_predicate<int8_t>(column, nrows, mem, op, (int8_t)lo.i, (int8_t)hi.i, *f, stream); break;
+                case MSVS_DT_INT16: launch_predicate<int16_t>(column, nrows, mem, op, (int16_t)lo.i, (int16_t)hi.i, *f, stream); break;
+                case MSVS_DT_INT32: launch_predicate<int32_t>(column, nrows, mem, op, (int32_t)lo.i, (int32_t)hi.i, *f, stream); break;
+                case MSVS_DT_INT64: launch_predicate<int64_t>(column, nrows, mem, op, lo.i, hi.i, *f, stream); break;
+                case MSVS_DT_FLOAT32: launch_predicate<float>(column, nrows, mem, op, (float)lo.f, (float)hi.f, *f, stream); break;
+                case MSVS_DT_FLOAT64: launch_predicate<double>(column, nrows, mem, op, lo.f, hi.f, *f, stream); break;
+                default: fail(MSVS_ERR_INVALID_ARGUMENT, "unknown column type %d", dtype);
+            }
+        *out = f.release();
+    });
+}
+
+extern "C" int msvs_filter_combine(msvs_filter_t * a, const msvs_filter_t * b, int mode)
+{
+    return guarded([&] {
+        if (!a || !b || mode < 0 || mode > 2)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null filter / unknown mode");
+        hipStream_t stream = thread_stream();
+        const size_t wa = std::max<size_t>(1, ceil_div(a->nbits, (size_t)64)), wb = ceil_div(b->nbits, (size_t)64);
+        hipLaunchKernelGGL(filter_combine_kernel, dim3((unsigned)ceil_div(wa, (size_t)256)), dim3(256), 0, stream, a->bits.p, wa, b->bits.p,
+                           wb, mode);
+        MSVS_HIP(hipGetLastError());
+        filter_recount(*a, stream);
+    });
+}
+
+extern "C" int msvs_filter_count(const msvs_filter_t * f, uint64_t * alive, size_t * nbits)
+{
+    return guarded([&] {
+        if (!f)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null filter");
+        if (alive)
+            *alive = f->count;
+        if (nbits)
+            *nbits = f->nbits;
+    });
+}
+
+extern "C" int msvs_filter_to_bits(const msvs_filter_t * f, uint64_t * bits_out)
+{
+    return guarded([&] {
+        if (!f || !bits_out)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
+        MSVS_HIP(hipMemcpy(bits_out, f->bits.p, std::max<size_t>(1, ceil_div(f->nbits, (size_t)64)) * 8, hipMemcpyDeviceToHost));
+    });
+}
+
+extern "C" void msvs_filter_free(msvs_filter_t * f) { delete f; }
+
+extern "C" int msvs_index_search_filter_device(const msvs_index_t * ix, const float * d_queries, size_t nq, int k, int nprobe,
+                                               const msvs_filter_t * filter, int64_t * d_ids, float * d_dis, void * hip_stream)
+{
+    return guarded([&] {
+        if (!ix || !filter || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/filter/buffer or negative k");
+        if (nq == 0 || k == 0)
+            return;
+        check_k((size_t)k);
+        hipStream_t stream = as_stream(hip_stream);
+        const auto meta = ix->get_meta();
+        size_t eff_bits = filter->nbits;
+        const uint64_t * eff = effective_filter(*ix, meta.get(), filter->bits.p, filter->nbits, &eff_bits, stream);
+        index_search_filtered(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, filter->count, d_ids, d_dis,
+                              stream);
+        apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
+    });
+}
+
+extern "C" int msvs_index_search_filter(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
+                                        const msvs_filter_t * filter, int64_t * ids, float * dis)
+{
+    return guarded([&] {
+        if (!ix || !filter || (nq && (!queries || !ids || !dis)) || k < 0)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/filter/buffer or negative k");
+        if (nq == 0 || k == 0)
+            return;
+        check_k((size_t)k);
+        auto p = parse_params(params);
+        for (const auto & kv : p)
+            if (kv.first != "nprobe")
+                fail(MSVS_ERR_INVALID_ARGUMENT, "unknown search parameter `%s`", kv.first.c_str());
+        const long nprobe = param_int(p, "nprobe", 1);
+        if (nprobe < 1)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "nprobe must be >= 1");
+        hipStream_t stream = thread_stream();
+        Scratch & stg = staging_for(stream);
+        stg.reserve(nq * ix->dim * 4 + nq * (size_t)k * 12 + 4096, stream);
+        float * dq = stg.take<float>(nq * ix->dim);
+        int64_t * d_ids = stg.take<int64_t>(nq * (size_t)k);
+        float * d_dis = stg.take<float>(nq * (size_t)k);
+        MSVS_HIP(hipMemcpyAsync(dq, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
+        const int rc = msvs_index_search_filter_device(ix, dq, nq, k, (int)nprobe, filter, d_ids, d_dis, stream);
+        if (rc != MSVS_OK)
+            fail(rc, "%s", msvs_last_error());
+        MSVS_HIP(hipMemcpyAsync(ids, d_ids, nq * (size_t)k * 8, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipMemcpyAsync(dis, d_dis, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipStreamSynchronize(stream));
     });
 }

@@ -213,6 +213,9 @@ struct ScanParams
 {
     const float4 * Y;       // base rows, ld4 float4 per row (zero padded to a multiple of 4 floats)
     const uint32_t * ids;   // nullable: id of stored row r (else r + id_base)
+    const uint32_t * rowmap; // nullable: the scan runs over a COMPACTED view -- view row r is stored row rowmap[r]
+                             // (the rows a selective filter lets through, filter_kernels.hpp); list offsets, row
+                             // ranges and segments are in view rows, Y / ids are indexed by the stored row
     const uint64_t * alive; // nullable filter bitmap indexed by id, LSB-first
     const float4 * Q;       // queries, ld4 float4 per row
     uint64_t * partial;     // output keys
@@ -223,6 +226,7 @@ struct ScanParams
     uint32_t nq;
     // FLAT front end
     uint32_t n_rows;
+    const uint32_t * n_rows_dev; // nullable: the row count lives on the device (a compacted view: n_rows is its upper bound)
     uint32_t rows_per_block;
     uint32_t n_blocks; // partial lists per query
     // IVF front end
@@ -293,7 +297,8 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
         bool ok = rv && g == 0;
         if (ok)
         {
-            id = a.ids ? a.ids[r] : r + a.id_base;
+            const uint32_t rs = a.rowmap ? a.rowmap[r] : r;
+            id = a.ids ? a.ids[rs] : rs + a.id_base;
             if (a.alive)
                 ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
         }
@@ -315,8 +320,8 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
     {
         const float4 * qrow = qs + g;
         auto load_rows = [&](uint32_t base, float4 * y) {
-            const uint32_t r = base + grp;
-            const float4 * yrow = a.Y + (size_t)(r < row_end ? r : row_end - 1) * ld4 + g;
+            const uint32_t r = base + grp, rc = r < row_end ? r : row_end - 1;
+            const float4 * yrow = a.Y + (size_t)(a.rowmap ? a.rowmap[rc] : rc) * ld4 + g;
 #pragma unroll
             for (int u = 0; u < 12; u++)
                 y[u] = yrow[u * 16];
@@ -358,7 +363,8 @@ __device__ __forceinline__ void scan_rows(const ScanParams & a, uint32_t row_beg
     {
         const uint32_t r = base + grp;
         const bool rv = r < row_end;
-        const float4 * yrow = a.Y + (size_t)(rv ? r : row_end - 1) * ld4 + g;
+        const uint32_t rc = rv ? r : row_end - 1;
+        const float4 * yrow = a.Y + (size_t)(a.rowmap ? a.rowmap[rc] : rc) * ld4 + g;
         const float4 * qrow = qs + g;
 
         float4 acc[T];
@@ -512,8 +518,9 @@ __global__ __launch_bounds__(BLOCK) void flat_scan_kernel(const ScanParams a)
     stage_queries<T>(a, qidx, qs);
     const uint32_t row_begin = blockIdx.x * a.rows_per_block;
     uint32_t row_end = row_begin + a.rows_per_block;
-    if (row_end > a.n_rows)
-        row_end = a.n_rows;
+    const uint32_t n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+    if (row_end > n_rows)
+        row_end = n_rows;
     scan_rows<METRIC, T, R>(a, row_begin < row_end ? row_begin : row_end, row_end, qs, lds_merge, out);
 }
 

@@ -605,6 +605,85 @@ def test_few_query_path_from_many_host_threads(opt):
     assert errors == []
 
 
+# ---------------------------------------------------------------------------------------- filters (PREWHERE -> bitmap, strategy)
+
+def test_filter_producers_match_numpy():
+    """msvs_filter_*: bitmap from row offsets (getFilterFromPipeline's loop), from `column OP constant` on the device for
+    every column type, combined with AND / OR / AND NOT; sizes that are not multiples of 64; NaN compares false."""
+    rng = np.random.default_rng(11)
+    for n in (1, 63, 64, 1000, 100_003):
+        off = np.unique(rng.integers(0, n, max(1, n // 3))).astype(np.uint64)
+        f = capi.Filter.from_offsets(off, n)
+        exp = np.zeros(n, bool)
+        exp[off.astype(np.int64)] = True
+        assert f.to_bool().tolist() == exp.tolist() and f.count() == (int(exp.sum()), n)
+        for dt in (np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16, np.int32, np.int64, np.float32, np.float64):
+            if np.dtype(dt).kind == "f":
+                col = rng.standard_normal(n).astype(dt) * 50
+                col[rng.integers(0, n, max(1, n // 50))] = np.nan
+            else:
+                info = np.iinfo(dt)
+                col = rng.integers(max(info.min, -100), min(info.max, 100), n).astype(dt)
+            lo, hi = (-3.5, 17.25) if np.dtype(dt).kind == "f" else (3, 40)
+            for op, fn in (("==", lambda c: c == lo), ("!=", lambda c: c != lo), ("<", lambda c: c < lo), ("<=", lambda c: c <= lo),
+                           (">", lambda c: c > lo), (">=", lambda c: c >= lo), ("between", lambda c: (c >= lo) & (c <= hi))):
+                with np.errstate(invalid="ignore"):
+                    want = fn(col.astype(np.float64) if np.dtype(dt).kind == "f" else col.astype(np.int64))
+                g = capi.Filter.from_predicate(col, op, lo, hi)
+                assert g.to_bool().tolist() == want.tolist(), (n, dt, op)
+                assert g.count()[0] == int(want.sum())
+        a = rng.random(n) < 0.5
+        b = rng.random(n) < 0.3
+        for mode, fn in ((capi.FILTER_AND, lambda: a & b), (capi.FILTER_OR, lambda: a | b), (capi.FILTER_AND_NOT, lambda: a & ~b)):
+            fa = capi.Filter.from_bool(a).combine(capi.Filter.from_bool(b), mode)
+            assert fa.to_bool().tolist() == fn().tolist() and fa.count()[0] == int(fn().sum())
+
+
+@pytest.mark.parametrize("kind,metric", [("ivf", capi.METRIC_L2), ("ivf", capi.METRIC_COSINE), ("flat", capi.METRIC_IP)])
+def test_filtered_search_strategies_agree_with_each_other_and_the_oracle(kind, metric, opt):
+    """A filtered search through the compacted view (filter_compact_below = 1: always), through the bit test (0: never)
+    and with the default crossover: identical results, equal to the oracle's filtered scan; with a delete bitmap on top;
+    selectivities from 0.1 % to 50 %, batches that take the one-query, the tiled and the candidate-pass paths."""
+    rng = np.random.default_rng(300 + metric)
+    n, d, nlist = 60000, 96, 64
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, 300)] + rng.standard_normal((300, d), dtype=np.float32)).astype(np.float32)
+    if kind == "ivf":
+        ix = build_ivf(x, metric, nlist)
+        params, nprobe = "nprobe=8", 8
+    else:
+        ix = capi.Index(capi.INDEX_FLAT, metric, d)
+        ix.add(x)
+        ix.build()
+        params, nprobe = "", 0
+    price = rng.integers(0, 1000, n).astype(np.int32)  # the PREWHERE column
+    deleted_alive = rng.random(n) < 0.9
+    for sel in (1, 50, 500):  # price < sel: 0.1 %, 5 %, 50 % of the rows
+        flt = capi.Filter.from_predicate(price, "<", sel)
+        alive = price < sel
+        assert flt.count()[0] == int(alive.sum())
+        for nq in (1, 16, 300):
+            for with_delete in (False, True):
+                ix.set_delete_bitmap(deleted_alive if with_delete else None)
+                eff = alive & deleted_alive if with_delete else alive
+                res = []
+                for below in ("1", "0", None):
+                    opt("filter_compact_below", below)
+                    res.append(ix.search_filter(q[:nq], 10, params, flt))
+                    res.append(ix.search(q[:nq], 10, params, alive=alive))
+                for r in res[1:]:
+                    same(r[0], r[1], res[0][0], res[0][1])
+                if nq <= 16:
+                    if kind == "ivf":
+                        oi, od, _ = oracle_on_exported(ix, q[:nq], nprobe, 10, metric, alive=eff)
+                    else:
+                        oi, od = o.knn(q[:nq], x, 10, OM[metric], alive=eff)
+                    same(res[0][0], res[0][1], oi, od)
+        flt.close()
+    ix.set_delete_bitmap(None)
+
+
 # ---------------------------------------------------------------------------------------- seam B: BM25
 
 def bm25_both(docs_texts, query, k, alive=None):
