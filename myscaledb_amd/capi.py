@@ -27,7 +27,7 @@ SYMBOLS = [
     "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
     "msvs_postings_create", "msvs_postings_create_fields", "msvs_postings_set_alive", "msvs_postings_free",
     "msvs_bm25_search", "msvs_bm25_search_batch", "msvs_bm25_search_batch_device", "msvs_bm25_stats",
-    "msvs_filter_from_bits", "msvs_filter_from_offsets", "msvs_filter_from_predicate", "msvs_filter_combine", "msvs_filter_count",
+    "msvs_release_scratch", "msvs_filter_from_bits", "msvs_filter_from_offsets", "msvs_filter_from_predicate", "msvs_filter_combine", "msvs_filter_count",
     "msvs_filter_to_bits", "msvs_filter_free", "msvs_index_search_filter", "msvs_index_search_filter_device", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
     "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_set_option", "msvs_index_serialize_io",
@@ -579,6 +579,12 @@ class Filter:
             self._h = None
 
     __del__ = close
+
+
+def release_scratch():
+    f = C.c_size_t(0)
+    _check(lib().msvs_release_scratch(C.byref(f)))
+    return f.value
 
 
 def bm25_stats():

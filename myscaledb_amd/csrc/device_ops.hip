@@ -16,7 +16,19 @@ const char * last_error_cstr() { return g_last_error.c_str(); }
 void Scratch::reserve(size_t bytes, hipStream_t stream)
 {
     used = 0;
-    bytes += 4096;
+    // bounded: an arena that has not needed a quarter of its capacity for 64 operations in a row (a full window after the large one) gives the rest back
+    // (one unusually large batch must not pin hundreds of MB per client thread for the life of the process)
+    recent_max = std::max(recent_max, bytes);
+    if (++ops >= 64)
+    {
+        if (buf.n > ((size_t)64 << 20) && recent_max * 4 < buf.n && bytes <= recent_max * 2)
+        {
+            MSVS_HIP(hipStreamSynchronize(stream));
+            buf.alloc(recent_max * 2);
+        }
+        ops = 0;
+        recent_max = 0;
+    }
     if (bytes <= buf.n)
         return;
     if (buf.p)
@@ -39,36 +51,40 @@ hipStream_t thread_stream()
     return s;
 }
 
-Scratch & scratch_for(hipStream_t stream)
+namespace
 {
-    static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
+/// Every arena of the calling host thread, keyed by (device, stream).
+struct ThreadArenas
+{
+    std::map<std::pair<int, hipStream_t>, Scratch> scratch, staging, aux, shard, view;
+};
+thread_local ThreadArenas t_arenas;
+
+Scratch & arena_in(std::map<std::pair<int, hipStream_t>, Scratch> & m, hipStream_t stream)
+{
     int dev = 0;
     MSVS_HIP(hipGetDevice(&dev));
-    return arenas[{dev, stream}];
+    return m[{dev, stream}];
+}
 }
 
-Scratch & aux_for(hipStream_t stream)
-{
-    static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
-    int dev = 0;
-    MSVS_HIP(hipGetDevice(&dev));
-    return arenas[{dev, stream}];
-}
+Scratch & scratch_for(hipStream_t stream) { return arena_in(t_arenas.scratch, stream); }
+Scratch & aux_for(hipStream_t stream) { return arena_in(t_arenas.aux, stream); }
+Scratch & shard_for(hipStream_t stream) { return arena_in(t_arenas.shard, stream); }
+Scratch & staging_for(hipStream_t stream) { return arena_in(t_arenas.staging, stream); }
+Scratch & view_for(hipStream_t stream) { return arena_in(t_arenas.view, stream); }
 
-Scratch & shard_for(hipStream_t stream)
+size_t release_thread_arenas()
 {
-    static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
-    int dev = 0;
-    MSVS_HIP(hipGetDevice(&dev));
-    return arenas[{dev, stream}];
-}
-
-Scratch & staging_for(hipStream_t stream)
-{
-    static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
-    int dev = 0;
-    MSVS_HIP(hipGetDevice(&dev));
-    return arenas[{dev, stream}];
+    size_t freed = 0;
+    (void)hipDeviceSynchronize(); // nothing enqueued may still use them
+    for (auto * m : {&t_arenas.scratch, &t_arenas.staging, &t_arenas.aux, &t_arenas.shard, &t_arenas.view})
+    {
+        for (auto & kv : *m)
+            freed += kv.second.buf.n;
+        m->clear();
+    }
+    return freed;
 }
 
 // ------------------------------------------------------------------------------------------ profiling
@@ -546,6 +562,7 @@ const OptionField g_option_fields[] = {
     {"cand_cap", &Options::cand_cap},       {"ivf_eps_scale", &Options::ivf_eps_scale},
     {"h16_nt", &Options::h16_nt},           {"h16_grid", &Options::h16_grid},
     {"h16_min_pairs", &Options::h16_min_pairs}, {"h16_ncb", &Options::h16_ncb},
+    {"h16_nocut", &Options::h16_nocut},
     {"lat_path", &Options::lat_path},         {"filter_compact_below", &Options::filter_compact_below},
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},
 };

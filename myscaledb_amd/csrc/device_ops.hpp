@@ -14,6 +14,8 @@ struct Scratch
 {
     DevBuf<unsigned char> buf;
     size_t used = 0;
+    size_t recent_max = 0; // largest reservation of the last `ops` operations (shrink policy, see reserve)
+    uint32_t ops = 0;
     void reset() { used = 0; }
     /// Reserve must be called once per operation with the total need BEFORE any take() (it may reallocate).
     void reserve(size_t bytes, hipStream_t stream);
@@ -42,6 +44,10 @@ Scratch & staging_for(hipStream_t stream);
 Scratch & aux_for(hipStream_t stream);
 /// ... and one for the exchange buffers of a sharded search (probe lists, packed partial top-k of every rank).
 Scratch & shard_for(hipStream_t stream);
+/// ... and one for the compacted view of a filtered search and small per-filter counters.
+Scratch & view_for(hipStream_t stream);
+/// Free every arena of the calling host thread (after a device synchronisation); returns the bytes released.
+size_t release_thread_arenas();
 
 /// Optional HIP-event timing of kernel launches (msvs_profile_* in the C-ABI); a no-op unless enabled.
 struct ProfileScope

@@ -644,7 +644,8 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint
         for (int u = 0; u < 4; u++)
             top.offer(key[u], m, lane);
     }
-    const uint32_t cut = top.thr == KEY_NONE ? 0xFFFFFFFFu : (uint32_t)(top.thr >> 32);
+    // target 0 (a test knob): no cut at all, every probed row becomes a candidate
+    const uint32_t cut = top.thr == KEY_NONE || target == 0 ? 0xFFFFFFFFu : (uint32_t)(top.thr >> 32);
     uint32_t count = 0;
     for (uint32_t base = 0; base < n; base += WAVE)
     {

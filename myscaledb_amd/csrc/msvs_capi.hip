@@ -1149,7 +1149,7 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 // cut (h16_sample_thr_kernel).  target = 25 k: m ~ 9 on lists of ~1000 rows; the certificate fails when
                 // fewer than k rows do (>= m of the k + m best rows fell into the sample: ~1e-6 there, and the floor m = 4
                 // is only reached when the sample is a small fraction of the probed rows)
-                p.h_mth = (uint32_t)std::max<size_t>(64, 25 * (size_t)k); // the target
+                p.h_mth = options().h16_nocut != 0 ? 0u : (uint32_t)std::max<size_t>(64, 25 * (size_t)k); // the target
                 // capacity: 8 x the target, and 2.5 x what the floor m = 4 leaves below the cut when every probed list is as
                 // long as the longest one (sample fraction 32 / max_list_len)
                 size_t cap = std::min<size_t>(std::max<size_t>(std::max<size_t>(1024, round_up(8 * (size_t)p.h_mth, 256)),
@@ -1520,6 +1520,18 @@ static uint32_t device_cu_count()
     return cus[dev] = (uint32_t)std::max(n, 1);
 }
 
+/// What the last shadow pass of this host thread left behind (tests: msvs_debug_h16_keys reads the kernel's OWN approximate
+/// keys out of the scratch arena; valid until the thread's next search on that stream).
+struct H16Last
+{
+    const uint64_t * partial = nullptr;
+    const uint32_t * qcnt = nullptr;
+    uint32_t cap = 0;
+    size_t nq = 0;
+    hipStream_t stream = nullptr;
+};
+static thread_local H16Last g_h16_last;
+
 /// List scan of a batch over the fp16 shadow: sample launch -> cut -> main launch -> candidate select -> canonical
 /// re-rank + certificate -> canonical fallback for the queries without one (h16_scan_kernels.hpp).
 static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq, uint32_t k,
@@ -1617,6 +1629,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             h16_dispatch<M_L2>(pl.h_ncb, nt, grid, lds, a, stream);
     }
     MSVS_HIP(hipGetLastError());
+    g_h16_last = H16Last{partial, qstate + nq, pl.h_cap, nq, stream};
     launch_cand_select(partial, qstate + nq, qstate, pl.h_cap, (uint32_t)nq, pl.kc, cand, bound, stream);
     RerankParams rp{};
     rp.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
@@ -2333,14 +2346,6 @@ struct msvs_filter
 
 namespace
 {
-Scratch & view_for(hipStream_t stream)
-{
-    static thread_local std::map<std::pair<int, hipStream_t>, Scratch> arenas;
-    int dev = 0;
-    MSVS_HIP(hipGetDevice(&dev));
-    return arenas[{dev, stream}];
-}
-
 void filter_recount(msvs_filter & f, hipStream_t stream)
 {
     const size_t words = std::max<size_t>(1, ceil_div(f.nbits, (size_t)64));
@@ -2778,6 +2783,17 @@ extern "C" int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks)
             *queries = g_prefilter_queries.load();
         if (fallbacks)
             *fallbacks = f;
+    });
+}
+
+/// Give the calling thread's scratch arenas back (they are grow-only per (thread, stream) otherwise, with a lazy shrink in
+/// Scratch::reserve): for hosts that park client threads.
+extern "C" int msvs_release_scratch(size_t * freed_bytes)
+{
+    return guarded([&] {
+        const size_t f = release_thread_arenas();
+        if (freed_bytes)
+            *freed_bytes = f;
     });
 }
 
@@ -3387,4 +3403,32 @@ extern "C" __attribute__((visibility("default"))) int msvs_lat_debug(unsigned lo
         if (out16)
             MSVS_HIP(hipMemcpy(out16, g_lat_dbg, 16 * 8, hipMemcpyDeviceToHost));
     });
+}
+
+/// Tests only (not in msvs.h): the candidate keys of this thread's last shadow pass -- (ordered approximate distance << 32 |
+/// stored row position) -- up to cap_out per query, and how many each query has.
+extern "C" __attribute__((visibility("default"))) int msvs_debug_h16_keys(uint64_t * keys_out, size_t cap_out, uint32_t * counts_out,
+                                                                         size_t nq)
+{
+    return guarded([&] {
+        const H16Last & h = g_h16_last;
+        if (!h.partial || nq != h.nq)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "no shadow pass of %zu queries on record", nq);
+        MSVS_HIP(hipStreamSynchronize(h.stream));
+        MSVS_HIP(hipMemcpy(counts_out, h.qcnt, nq * 4, hipMemcpyDeviceToHost));
+        const size_t take = std::min<size_t>(cap_out, h.cap);
+        MSVS_HIP(hipMemcpy2D(keys_out, cap_out * 8, h.partial, (size_t)h.cap * 8, take * 8, nq, hipMemcpyDeviceToHost));
+        g_h16_last = H16Last{}; // one fetch per pass: a later search that takes another path must not be mistaken for it
+    });
+}
+
+/// Tests only: the constants of the certificate's error model for the shadow pass at this dimension.
+extern "C" __attribute__((visibility("default"))) void msvs_debug_error_model_h16(size_t dim, double * c_dot, double * c_norm,
+                                                                                 double * c_canon)
+{
+    RerankParams rp{};
+    set_error_model_h16(rp, dim);
+    *c_dot = rp.c_dot;
+    *c_norm = rp.c_norm;
+    *c_canon = rp.c_canon;
 }

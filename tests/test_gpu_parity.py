@@ -605,6 +605,86 @@ def test_few_query_path_from_many_host_threads(opt):
     assert errors == []
 
 
+# ---------------------------------------------------------------------------------------- the certificate's premise, on hardware
+
+def _key_values(hi, ip):
+    o_ = (~hi if ip else hi).astype(np.uint32)
+    bits = np.where(o_ & np.uint32(0x80000000), o_ & np.uint32(0x7FFFFFFF), ~o_).astype(np.uint32)
+    return bits.view(np.float32)
+
+
+ADVERSARIAL = {
+    "gaussian": lambda r, n, d: r.standard_normal((n, d)),
+    "near_duplicates_of_the_queries": lambda r, n, d: np.tile(r.standard_normal((1, d)) * 30, (n, 1)) + r.standard_normal((n, d)) * 1e-3,
+    "wide_dynamic_range": lambda r, n, d: r.standard_normal((n, d)) * np.exp2(r.integers(-12, 12, (n, d))),
+    "one_sign_long_sums": lambda r, n, d: np.abs(r.standard_normal((n, d))) + 1.0,
+    "fp16_rounding_boundaries": lambda r, n, d: (r.integers(1024, 2048, (n, d)) * 2 + 1) * np.exp2(-11.0) * r.choice([-1.0, 1.0], (n, d)),
+    "sparse_spikes": lambda r, n, d: np.where(r.random((n, d)) < 0.02, r.standard_normal((n, d)) * 1e3, 0.0) + 1e-3,
+    "tiny_values": lambda r, n, d: r.standard_normal((n, d)) * 1e-6,
+}
+
+
+@pytest.mark.parametrize("name", sorted(ADVERSARIAL))
+@pytest.mark.parametrize("metric,d", [(capi.METRIC_L2, 768), (capi.METRIC_IP, 768), (capi.METRIC_L2, 1024), (capi.METRIC_L2, 100)])
+def test_mfma_accumulation_error_bound_on_hardware(name, metric, d, opt):
+    """The certificate (mfma_scan_kernels.hpp / h16_scan_kernels.hpp) rests on a per-pair bound of what the fp16-shadow
+    MFMA pass computes: |approximate - true| <= 2 c_dot |x||q| + c_norm (|x|^2 + |q|^2) for L2, c_dot |x||q| for IP, with
+    the constants of set_error_model_h16.  Round 1 only checked a numpy EMULATION of the arithmetic; this reads the
+    kernel's OWN approximate keys back (every probed row, h16_nocut) on adversarial inputs and measures the ratio."""
+    import ctypes as C
+
+    rng = np.random.default_rng(sorted(ADVERSARIAL).index(name) * 100 + metric * 10 + d)
+    n, nlist, nq = 2048, 4, 64
+    keys0 = np.zeros((nq, 1), np.uint64)
+    capi.lib().msvs_debug_h16_keys(keys0.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(1), np.zeros(nq, np.uint32).ctypes.data_as(
+        C.POINTER(C.c_uint32)), C.c_size_t(nq))  # drop the record of an earlier pass
+    x = ADVERSARIAL[name](rng, n, d).astype(np.float32)
+    q = ADVERSARIAL[name](rng, nq, d).astype(np.float32)
+    if name == "near_duplicates_of_the_queries":
+        q = (x[:nq] + rng.standard_normal((nq, d)).astype(np.float32) * 1e-3).astype(np.float32)
+    ix = build_ivf(x, metric, nlist)
+    opt("ivf_pass", "2")
+    opt("h16_nocut", "1")
+    opt("cand_cap", "16384")
+    p0 = capi.prefilter_stats()
+    ids, dis = ix.search(q, 10, "nprobe=%d" % nlist)
+    p1 = capi.prefilter_stats()
+    assert p1[0] - p0[0] == nq, "the shadow pass did not run"
+    cap = 4096
+    keys = np.zeros((nq, cap), np.uint64)
+    cnt = np.zeros(nq, np.uint32)
+    rc = capi.lib().msvs_debug_h16_keys(keys.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(cap), cnt.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        C.c_size_t(nq))
+    assert rc == 0, capi.lib().msvs_last_error()
+    assert (cnt == n).all(), "every row of every probed list is a candidate"  # nprobe = nlist, no cut
+    cd, cn, cc = C.c_double(), C.c_double(), C.c_double()
+    capi.lib().msvs_debug_error_model_h16.restype = None
+    capi.lib().msvs_debug_error_model_h16(C.c_size_t(d), C.byref(cd), C.byref(cn), C.byref(cc))
+    _, _, vecs, _ = ix.export()  # storage order: the low word of a key is a position here
+    ip = metric != capi.METRIC_L2
+    worst = 0.0
+    x64, q64 = vecs.astype(np.float64), q.astype(np.float64)
+    xn = np.sqrt((x64 * x64).sum(1))
+    for qi in range(nq):
+        kk = keys[qi, :n]
+        pos = (kk & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        approx = _key_values((kk >> np.uint64(32)).astype(np.uint32), ip).astype(np.float64)
+        qn = np.sqrt((q64[qi] * q64[qi]).sum())
+        if ip:
+            true = x64[pos] @ q64[qi]
+            eps = cd.value * xn[pos] * qn
+        else:
+            diff = x64[pos] - q64[qi]
+            true = (diff * diff).sum(1)
+            eps = 2 * cd.value * xn[pos] * qn + cn.value * (xn[pos] ** 2 + qn ** 2)
+        ratio = np.abs(approx - true) / (eps + 1e-300)
+        worst = max(worst, float(ratio.max()))
+    assert worst < 1.0, "approximate keys leave the certified band: max |approx - true| / eps = %.3f" % worst
+    # and the results are exact all the same
+    oi, od, _ = oracle_on_exported(ix, q, nlist, 10, metric)
+    same(ids, dis, oi, od)
+
+
 # ---------------------------------------------------------------------------------------- filters (PREWHERE -> bitmap, strategy)
 
 def test_filter_producers_match_numpy():
@@ -1249,3 +1329,26 @@ def test_knn_bin_matches_oracle(nbytes, ny, nx, k, metric):
     with pytest.raises(capi.MsvsError) as e:
         capi.knn_bin(x, y, k, capi.METRIC_L2)
     assert e.value.code == capi.ERR_NOT_IMPLEMENTED
+
+
+def test_scratch_arenas_shrink_and_release():
+    """Round-1 review: the per-(thread, stream) arenas were grow-only.  One large batch followed by small ones gives the
+    memory back (lazy shrink after a window of 64 small operations); msvs_release_scratch frees the thread's arenas at once."""
+    import torch
+
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((20000, 64), dtype=np.float32)
+    ix = build_ivf(x, capi.METRIC_L2, 32)
+    big = rng.standard_normal((60000, 64), dtype=np.float32)
+    capi.release_scratch()
+    free0 = torch.cuda.mem_get_info()[0]
+    i_big, d_big = ix.search(big, 100, "nprobe=32")  # hundreds of MB of partial lists
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held > (100 << 20)
+    for i in range(300):  # (8 queries: the general path, whose arena the large batch grew)
+        ix.search(big[8 * i:8 * i + 8], 10, "nprobe=4")
+    after = free0 - torch.cuda.mem_get_info()[0]
+    assert after < held // 2, (held, after)
+    assert capi.release_scratch() > 0
+    i2, d2 = ix.search(big[:50], 100, "nprobe=32")  # and everything still works afterwards
+    same(i2, d2, i_big[:50], d_big[:50])
