@@ -1,0 +1,165 @@
+// TextShim.cpp -- seam B of INTEGRATION.md as code: the TANTIVY::ffi_* functions the BM25 path of the host calls
+// (TantivyIndexStore.cpp:853-998), implemented on the postings export + device scorer (libmsvs_host.so: text_store.cpp,
+// libmsvs.so: bm25.hip) instead of the Rust library.  Compiled against shim/stubs/tantivy_search/tantivy_search.h, which
+// restates the generated header from its call sites.  An index "directory" is looked up as <index_path>/postings.mspost
+// (the export file written next to the tantivy files); readers are cached by path like the Rust side caches its
+// IndexReaderBridge (ffi_load_index_reader / ffi_free_index_reader).  Errors travel by value in .error, never as
+// exceptions -- the host turns them into TANTIVY_SEARCH_INTERNAL_ERROR (TantivyIndexStore.cpp:919-923).
+#include <tantivy_search/tantivy_search.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "../include/msvs_host.h"
+
+namespace
+{
+struct Reader
+{
+    msvs_text_index_t * ix = nullptr;
+    ~Reader() { msvs_text_index_free(ix); }
+};
+std::mutex g_mu;
+std::map<std::string, std::shared_ptr<Reader>> g_readers;
+
+std::shared_ptr<Reader> reader_of(const std::string & path, std::string & err)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_readers.find(path);
+    if (it != g_readers.end())
+        return it->second;
+    auto r = std::make_shared<Reader>();
+    if (msvs_text_index_load((path + "/postings.mspost").c_str(), &r->ix) != 0)
+    {
+        err = msvs_text_last_error();
+        return nullptr;
+    }
+    g_readers[path] = r;
+    return r;
+}
+
+template <typename R>
+R failed(const std::string & m)
+{
+    R r;
+    r.error.is_error = true;
+    r.error.message = m;
+    return r;
+}
+}
+
+namespace TANTIVY
+{
+FFIBoolResult ffi_load_index_reader(const std::string & index_path)
+{
+    std::string err;
+    if (!reader_of(index_path, err))
+        return failed<FFIBoolResult>(err);
+    FFIBoolResult r;
+    r.result = true;
+    return r;
+}
+
+FFIBoolResult ffi_free_index_reader(const std::string & index_path)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    FFIBoolResult r;
+    r.result = g_readers.erase(index_path) > 0;
+    return r;
+}
+
+FFIVecRowIdWithScoreResult ffi_bm25_search(const std::string & index_path, const std::string & sentence,
+                                           const std::vector<std::string> & column_names, uint32_t topk,
+                                           const std::vector<uint8_t> & u8_alive_bitmap, bool use_filter, bool enable_nlq,
+                                           bool operator_or, const Statistics & statistics)
+{
+    std::string err;
+    auto rd = reader_of(index_path, err);
+    if (!rd)
+        return failed<FFIVecRowIdWithScoreResult>(err);
+    std::vector<msvs_doc_freq_t> df(statistics.docs_freq.size());
+    for (size_t i = 0; i < df.size(); i++)
+        df[i] = {statistics.docs_freq[i].term_str.c_str(), statistics.docs_freq[i].field_id, statistics.docs_freq[i].doc_freq};
+    std::vector<msvs_field_tokens_t> tk(statistics.total_num_tokens.size());
+    for (size_t i = 0; i < tk.size(); i++)
+        tk[i] = {statistics.total_num_tokens[i].field_id, statistics.total_num_tokens[i].field_total_tokens};
+    msvs_bm25_stats_t st{df.data(), df.size(), tk.data(), tk.size(), statistics.total_num_docs};
+    std::vector<const char *> cols;
+    for (const auto & c : column_names)
+        cols.push_back(c.c_str());
+    std::vector<uint64_t> rows(topk);
+    std::vector<float> scores(topk);
+    uint32_t n = 0;
+    const int rc = msvs_text_index_bm25_search(rd->ix, sentence.c_str(), cols.empty() ? nullptr : cols.data(), cols.size(), topk,
+                                               u8_alive_bitmap.data(), u8_alive_bitmap.size(), use_filter ? 1 : 0, enable_nlq ? 1 : 0,
+                                               operator_or ? 1 : 0, &st, rows.data(), scores.data(), &n);
+    if (rc != 0)
+        return failed<FFIVecRowIdWithScoreResult>(msvs_text_last_error());
+    FFIVecRowIdWithScoreResult r;
+    r.result.resize(n);
+    for (uint32_t i = 0; i < n; i++)
+    {
+        r.result[i].row_id = rows[i];
+        r.result[i].score = scores[i];
+        r.result[i].doc_id = (uint32_t)rows[i]; // one segment per part: the row offset is the doc id
+    }
+    return r;
+}
+
+FFIVecDocWithFreqResult ffi_get_doc_freq(const std::string & index_path, const std::string & sentence)
+{
+    std::string err;
+    auto rd = reader_of(index_path, err);
+    if (!rd)
+        return failed<FFIVecDocWithFreqResult>(err);
+    std::vector<msvs_doc_freq_t> out(1024);
+    size_t n = 0;
+    if (msvs_text_index_doc_freq(rd->ix, sentence.c_str(), out.data(), out.size(), &n) != 0)
+        return failed<FFIVecDocWithFreqResult>(msvs_text_last_error());
+    FFIVecDocWithFreqResult r;
+    for (size_t i = 0; i < n && i < out.size(); i++)
+    {
+        DocWithFreq d;
+        d.term_str = std::string(out[i].term);
+        d.field_id = out[i].field_id;
+        d.doc_freq = out[i].doc_freq;
+        r.result.push_back(d);
+    }
+    return r;
+}
+
+FFIU64Result ffi_get_total_num_docs(const std::string & index_path)
+{
+    std::string err;
+    auto rd = reader_of(index_path, err);
+    if (!rd)
+        return failed<FFIU64Result>(err);
+    FFIU64Result r;
+    r.result = msvs_text_index_total_num_docs(rd->ix);
+    return r;
+}
+
+FFIU64Result ffi_get_indexed_doc_counts(const std::string & index_path) { return ffi_get_total_num_docs(index_path); }
+
+FFIFieldTokenNumsResult ffi_get_total_num_tokens(const std::string & index_path)
+{
+    std::string err;
+    auto rd = reader_of(index_path, err);
+    if (!rd)
+        return failed<FFIFieldTokenNumsResult>(err);
+    msvs_field_tokens_t out[8];
+    size_t n = 0;
+    if (msvs_text_index_total_num_tokens(rd->ix, out, 8, &n) != 0)
+        return failed<FFIFieldTokenNumsResult>(msvs_text_last_error());
+    FFIFieldTokenNumsResult r;
+    for (size_t i = 0; i < n && i < 8; i++)
+    {
+        FieldTokenNums f;
+        f.field_id = out[i].field_id;
+        f.field_total_tokens = out[i].field_total_tokens;
+        r.result.push_back(f);
+    }
+    return r;
+}
+}

@@ -61,3 +61,42 @@ def test_shim_end_to_end_matches_oracle(metric, typ):
             oi, od = o.knn_bin(bq, bx, k, m)
             assert (rd("bf_%s_ids" % tag, np.int64).reshape(nb_q, k) == oi).all()
             assert (rd("bf_%s_dis" % tag, np.float32).reshape(nb_q, k) == od).all()
+
+
+def test_text_shim_is_built_against_the_tantivy_stub():
+    lib = os.path.join(ROOT, "shim", "_build", "libmsvs_text_shim.so")
+    assert os.path.exists(lib) and os.path.exists(os.path.join(ROOT, "shim", "_build", "test_text_shim"))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", lib], text=True)
+    for sym in ("TANTIVY::ffi_bm25_search", "TANTIVY::ffi_get_doc_freq", "TANTIVY::ffi_get_total_num_docs",
+                "TANTIVY::ffi_get_total_num_tokens", "TANTIVY::ffi_load_index_reader"):
+        assert sym in out, sym
+
+
+@pytest.mark.gpu
+def test_text_shim_replays_the_two_part_bm25_golden():
+    """Seam B through the functions the host really calls (TANTIVY::ffi_*, shim/TextShim.cpp): the documents of
+    00041_mqvs_text_search_multiple_parts in two parts, statistics summed over the parts like BM25InfoInDataParts, one
+    ffi_bm25_search per part -> the golden hits; a filtered search; a missing index is an error VALUE."""
+    from golden_util import f32_of, load_goldens
+
+    g = load_goldens()["00041_two_parts"]
+    docs, n0 = g["docs"], g["part_sizes"][0]
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "docs.txt"), "w") as f:
+            for i, d_ in enumerate(docs):
+                f.write("%d\t%s\n" % (0 if i < n0 else 1, " ".join(d_["texts"]).replace("\n", " ").replace("\t", " ")))
+        with open(os.path.join(td, "query.txt"), "w") as f:
+            f.write(g["text_query"] + "\nor\n")
+        r = subprocess.run([os.path.join(ROOT, "shim", "_build", "test_text_shim"), td], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [ln.split() for ln in r.stdout.strip().split("\n")]
+        assert os.path.exists(os.path.join(td, "part0", "postings.mspost"))
+    hits = [(np.float32(ln[3]), docs[int(ln[2]) + (n0 if ln[1] == "1" else 0)]["id"]) for ln in lines if ln[0] == "hit"]
+    hits.sort(key=lambda h: (-float(h[0]), h[1]))
+    assert [h[1] for h in hits[:2]] == g["text_search_2parts"][0]
+    assert np.array([h[0] for h in hits[:2]], np.float32).tolist() == f32_of(g["text_search_2parts"][1]).tolist()
+    stats = [ln for ln in lines if ln[0] == "stats"][0]
+    assert int(stats[1]) == len(docs)
+    even = [ln for ln in lines if ln[0] == "even"]
+    assert all(int(ln[2]) % 2 == 0 for ln in even) and {(ln[1], ln[2]) for ln in even} <= {(ln[1], ln[2]) for ln in lines if ln[0] == "hit"}
+    assert ["missing_index_is_error", "1"] in lines
