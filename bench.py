@@ -393,12 +393,12 @@ def main():
         from oracle import oracle as o
         cent, off, vecs, lids = ix.export()
         cores = cpu_cores()
-        qh = q_all[:4096].cpu().numpy()
+        qh = q_all.cpu().numpy()  # n_pool x batch queries
         o.simd_ivf_search(cent, off, vecs, lids, qh[:cores], nprobe, k, o.METRIC_L2, cores)  # builds -march=native, warms up
         t1 = time.perf_counter()
         o.simd_ivf_search(cent, off, vecs, lids, qh[:4 * cores], nprobe, k, o.METRIC_L2, cores)
         per_round = max(time.perf_counter() - t1, 1e-3) / 4
-        nqs = int(min(4096, max(cores, cores * int(args.cpu_seconds / per_round))))
+        nqs = int(min(qh.shape[0], max(cores, cores * int(args.cpu_seconds / per_round))))
         t1 = time.perf_counter()
         si, _ = o.simd_ivf_search(cent, off, vecs, lids, qh[:nqs], nprobe, k, o.METRIC_L2, cores)
         cpu_s = time.perf_counter() - t1

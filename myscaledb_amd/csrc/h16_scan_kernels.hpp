@@ -12,12 +12,15 @@
 //     Lists are padded to whole blocks with zero rows (never offered).  +50 % index memory: 288 GB of HBM is what
 //     makes that the right trade (1M x 768: 3.07 GB f32 + 1.6 GB shadow).
 //   * PER SEARCH: the queries are rounded the same way once (h16_prep_queries_kernel: own power-of-two scale per
-//     query) into the LDS image of the A operand; the workgroup stages 64 reduction elements of its <= 128 queries per
-//     barrier, double buffered, XOR-swizzled so the ds_write_b128 of the stage and the ds_read_b128 of the operand
-//     reads are bank-conflict free.
+//     query) into the image of the A operand.  A work item is (list, tile of 32 * NCB probing queries): the tile is
+//     loaded ONCE into LDS ([chunk][query][8 x 16 B], XOR-swizzled so the ds_read_b128 operand reads are bank-conflict
+//     free) and stays there while the 8 wavefronts of the workgroup walk the list's blocks against it -- staging 64
+//     reduction elements of the queries per barrier instead (the first version) cost more than the rows and the MFMAs
+//     together (profiles/r02_h16_notes.txt).  Row chunks arrive through a 4-slot register ring per wavefront, chained
+//     across block boundaries, the prefetch issue pinned with sched_barrier.
 //   * ONE product per (row, query, step) instead of three: fp16 keeps 11 significant bits, so the single MFMA has
 //     error <= 2^-10 |x||q| where bf16 x 3 had 3.1 * 2^-16 -- larger, and still far below the spread of real
-//     distances (DESIGN.md section 4.3 has the numbers); the certificate of ivf_rerank_kernel takes the bound as a
+//     distances (tests/test_gpu_parity.py::test_mfma_accumulation_error_bound_on_hardware measures it); the certificate of ivf_rerank_kernel takes the bound as a
 //     parameter, so the returned ids / distance bits stay those of the canonical scan in every case.
 //   * NO selection inside the scan.  A first launch (SAMPLE) computes the approximate distance of block 0 of every
 //     probed list (32 rows per list, ~3 % of the rows) and writes them out; h16_sample_thr_kernel turns the m-th best
