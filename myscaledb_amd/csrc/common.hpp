@@ -149,6 +149,7 @@ struct Options
     double h16_nt = 0;        // shadow pass: non-temporal row loads
     double h16_grid = 0;      // shadow pass: grid size (0 = planned)
     double h16_min_pairs = 0.25; // shadow pass from this many (query, list) pairs per list on
+    double fb_cap = 0;        // queries per round of the canonical fallback (0 = by memory; small values: many rounds)
     double h16_nocut = 0;     // shadow pass: no sample cut, every probed row becomes a candidate (tests)
     double h16_ncb = 0;       // shadow pass: column blocks (32 queries each) per tile, 0 = planned
     double lat_path = 1;      // few-query IVFFLAT searches in two self-merging launches (latency_kernels.hpp): 0 off,

@@ -748,16 +748,17 @@ __global__ __launch_bounds__(BLOCK) void ivf_rerank_kernel(const RerankParams a)
     }
 }
 
-/// ivf_scan_kernel over a device-side list of queries: grid (seg_max, nprobe, Z); block z handles
-/// a.qmap[z], a.qmap[z + Z], ... up to *a.qcount (which is usually 0: then every block exits at once).
+/// ivf_scan_kernel over a device-side list of queries: grid (seg_max, nprobe, Z); block z handles the entries
+/// slot_base + z, + Z, ... of a.qmap inside this round's window (usually *a.qcount is 0: every block exits at once); the
+/// partial lists are indexed by the entry's position in the window, so the buffers hold slot_cap queries, not nq.
 template <int METRIC, int R>
 __global__ __launch_bounds__(BLOCK) void ivf_scan_subset_kernel(const ScanParams a)
 {
     const uint32_t s = blockIdx.x, p = blockIdx.y;
-    const uint32_t nf = *a.qcount;
+    const uint32_t nf = *a.qcount < a.slot_base + a.slot_cap ? *a.qcount : a.slot_base + a.slot_cap;
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
     uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16);
-    for (uint32_t f = blockIdx.z; f < nf; f += gridDim.z)
+    for (uint32_t f = a.slot_base + blockIdx.z; f < nf; f += gridDim.z)
     {
         const uint32_t q = a.qmap[f];
         const int32_t list = a.probes[(size_t)q * a.nprobe + p];
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(BLOCK) void ivf_scan_subset_kernel(const ScanParams
         if (lb >= le)
             continue;
         uint32_t qidx[1] = {q};
-        uint64_t * out[1] = {a.partial + (((size_t)q * a.nprobe + p) * a.seg_max + s) * a.k};
+        uint64_t * out[1] = {a.partial + (((size_t)(f - a.slot_base) * a.nprobe + p) * a.seg_max + s) * a.k};
         __syncthreads();
         stage_queries<1>(a, qidx, qs);
         scan_rows<METRIC, 1, R>(a, (uint32_t)lb, (uint32_t)le, qs, lds_merge, out);

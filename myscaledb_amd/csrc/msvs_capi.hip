@@ -1224,6 +1224,7 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
 }
 
 static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k);
+static size_t fallback_cap(size_t nq, size_t nprobe, size_t seg_max, uint32_t k);
 
 static size_t big_cand_cap(size_t nprobe, size_t slices_max)
 {
@@ -1246,7 +1247,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
             + nq * (size_t)p.kc * 8 + nq * 24 + 8192
-            + nq * nprobe * (size_t)p.seg_max1 * k * 8
+            + fallback_cap(nq, nprobe, p.seg_max1, k) * nprobe * (size_t)p.seg_max1 * k * 8
             + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8) + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
@@ -1288,8 +1289,8 @@ static uint32_t table_fallback_rpb(size_t n) { return (uint32_t)round_up(std::ma
 static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k)
 {
     const size_t nslices = ceil_div(std::max<size_t>(n, 1), (size_t)BG_ROWS);
-    return nq * (big_cand_cap(1, nslices) * 8 + 64 * 8 + 96)
-        + nq * ceil_div(std::max<size_t>(n, 1), (size_t)table_fallback_rpb(n)) * k * 8 + 65536;
+    const size_t segs = ceil_div(std::max<size_t>(n, 1), (size_t)table_fallback_rpb(n));
+    return nq * (big_cand_cap(1, nslices) * 8 + 64 * 8 + 96) + fallback_cap(nq, 1, segs, k) * segs * k * 8 + 65536;
 }
 
 /// Worth it once the (query tile) x (128-row slice) grid can occupy the chip (64 work items measured no better than
@@ -1301,6 +1302,28 @@ static bool table_pass_eligible(size_t n, const float * norms, float norm_max, s
     const size_t items = ceil_div(nq, (size_t)32) * ceil_div(n, (size_t)BG_ROWS); // at the smallest tile (32 queries)
     return mode != 0 && norms && norm_max < 1e30f /* false for NaN */ && k <= 40 && n >= 256 && n <= 0xfffffff0ull
         && ((items >= 256 && nq >= 16) || mode == 2);
+}
+
+/// The canonical fallback of a candidate pass: the queries on the device-side fail list are scanned and merged in ROUNDS of
+/// at most `cap` (their partial lists are indexed by the rank in the round), so the buffers are sized for `cap` queries
+/// instead of all nq -- normally nobody is on the list and every launch exits at once.
+static size_t fallback_cap(size_t nq, size_t nprobe, size_t seg_max, uint32_t k)
+{
+    const size_t per_query = std::max<size_t>(1, nprobe * seg_max * k * 8);
+    if (options().fb_cap >= 1) // test knob: several rounds on small batches
+        return std::min(nq, (size_t)options().fb_cap);
+    return std::min(nq, std::max<size_t>(64, ((size_t)256 << 20) / per_query));
+}
+
+static void run_fallback_rounds(int metric, ScanParams c, IvfMergeParams fm, size_t nq, size_t cap, uint32_t slots, hipStream_t stream)
+{
+    for (size_t base = 0; base < nq; base += cap)
+    {
+        c.slot_base = fm.slot_base = (uint32_t)base;
+        c.slot_cap = fm.slot_cap = (uint32_t)cap;
+        launch_ivf_scan_subset(metric, c, slots, stream);
+        launch_ivf_merge_subset(metric, fm, slots, stream);
+    }
 }
 
 static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq,
@@ -1326,7 +1349,8 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     uint64_t * bound = scr.take<uint64_t>(nq);
     uint32_t * failq = scr.take<uint32_t>(nq);
     const uint32_t rpb1 = table_fallback_rpb(t.n), seg_max1 = (uint32_t)ceil_div(t.n, (size_t)rpb1);
-    uint64_t * partial1 = scr.take<uint64_t>(nq * (size_t)seg_max1 * t.k);
+    const size_t fb_cap = fallback_cap(nq, 1, seg_max1, t.k);
+    uint64_t * partial1 = scr.take<uint64_t>(fb_cap * (size_t)seg_max1 * t.k);
     uint32_t * nfail = small + 2;
     MSVS_HIP(hipMemsetAsync(small, 0, 9 * sizeof(uint32_t), stream));
     MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
@@ -1433,7 +1457,6 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     c.qmap = failq;
     c.qcount = nfail;
     const uint32_t slots = (uint32_t)std::min<size_t>(nq, 8);
-    launch_ivf_scan_subset(scan_metric(m), c, slots, stream);
     IvfMergeParams fm{};
     fm.partial = partial1;
     fm.probes = probes0;
@@ -1448,7 +1471,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     fm.cosine = t.cosine;
     fm.qmap = failq;
     fm.qcount = nfail;
-    launch_ivf_merge_subset(scan_metric(m), fm, slots, stream);
+    run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, slots, stream);
 }
 
 /// Error model of the fp16 shadow pass (h16_scan_kernels.hpp), u = 2^-11:
@@ -1652,7 +1675,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
     g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
     // queries without a certificate: canonical scan, one query per block (normally zero of them)
-    uint64_t * partial1 = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max1 * k);
+    const size_t fb_cap = fallback_cap(nq, nprobe, pl.seg_max1, k);
+    uint64_t * partial1 = scr.take<uint64_t>(fb_cap * nprobe * (size_t)pl.seg_max1 * k);
     ScanParams c{};
     c.Y = rp.Y;
     c.ids = ix.row_ids.p;
@@ -1671,7 +1695,6 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     c.seg_max = pl.seg_max1;
     c.qmap = failq;
     c.qcount = nfail;
-    launch_ivf_scan_subset(scan_metric(m), c, pl.fb_slots, stream);
     IvfMergeParams fm{};
     fm.partial = partial1;
     fm.probes = d_probes;
@@ -1685,7 +1708,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     fm.cosine = ix.metric == MSVS_METRIC_COSINE;
     fm.qmap = failq;
     fm.qcount = nfail;
-    launch_ivf_merge_subset(scan_metric(m), fm, pl.fb_slots, stream);
+    run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, pl.fb_slots, stream);
 }
 
 /// given_probes (nullable): [nq][nprobe] list ids computed elsewhere (another rank's share of the coarse quantiser):
@@ -1927,7 +1950,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
         g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
         // queries without a certificate: canonical scan, one query per block (normally zero of them)
-        uint64_t * partial1 = scr.take<uint64_t>(nq * nprobe * (size_t)pl.seg_max1 * k);
+        const size_t fb_cap = fallback_cap(nq, nprobe, pl.seg_max1, k);
+        uint64_t * partial1 = scr.take<uint64_t>(fb_cap * nprobe * (size_t)pl.seg_max1 * k);
         ScanParams c = a;
         c.list_off = ix.list_off.p; // the fallback scans whole lists
         c.list_end = nullptr;
@@ -1937,7 +1961,6 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         c.seg_max = pl.seg_max1;
         c.qmap = failq;
         c.qcount = nfail;
-        launch_ivf_scan_subset(scan_metric(m), c, pl.fb_slots, stream);
         IvfMergeParams fm{};
         fm.partial = partial1;
         fm.probes = d_probes;
@@ -1951,7 +1974,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         fm.cosine = ix.metric == MSVS_METRIC_COSINE;
         fm.qmap = failq;
         fm.qcount = nfail;
-        launch_ivf_merge_subset(scan_metric(m), fm, pl.fb_slots, stream);
+        run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, pl.fb_slots, stream);
         return;
     }
     if (pl.T == 1)

@@ -246,6 +246,8 @@ struct ScanParams
     const float * xnorm;     // [n_rows] |x|^2
     const uint32_t * qmap;   // subset kernels: the queries to process ...
     const uint32_t * qcount; // ... and how many of them (device side)
+    uint32_t slot_base, slot_cap; // subset kernels: this round's window [slot_base, slot_base + slot_cap) of the fail list;
+                                  // the partial lists of entry f sit in slot f - slot_base
     uint32_t * qthr;         // big-tile candidate pass: per-query running cut (ordered distance word), see there
     uint32_t * qcnt;         // big-tile candidate pass: keys emitted so far per query (append cursor into `partial`)
     uint32_t cand_cap;       // ... whose row for query q is partial[q * cand_cap ...]
@@ -814,11 +816,13 @@ struct IvfMergeParams
     int32_t * out_probes;    // non-null: write [nq][k] int32 ids instead (the coarse quantiser's probe lists)
     const uint32_t * qmap;   // subset kernel: the queries to merge ...
     const uint32_t * qcount; // ... and how many of them (device side)
+    uint32_t slot_base, slot_cap; // subset kernel: the round's window of the fail list; partial is indexed by f - slot_base
 };
 
-/// Top-k of query q over the valid segments of its probed lists.  All BLOCK threads; uniform control flow.
+/// Top-k of query q over the valid segments of its probed lists, whose partial lists sit in slot `slot` of a.partial
+/// (the query itself, or its rank in a fail list).  All BLOCK threads; uniform control flow.
 template <int METRIC, int R>
-__device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const uint32_t q)
+__device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const uint32_t q, const uint32_t slot)
 {
     uint64_t * lds = reinterpret_cast<uint64_t *>(msvs_smem);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = a.k;
@@ -872,7 +876,7 @@ __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const 
             // one flat loop over the padded (probe, segment-slot, rank) space: every load is independent, so the
             // copy costs one memory latency instead of one per probe
             const uint32_t slots = a.seg_max * k, padded = a.nprobe * slots;
-            const uint64_t * src = a.partial + (size_t)q * padded;
+            const uint64_t * src = a.partial + (size_t)slot * padded;
             for (uint32_t i = tid; i < padded; i += BLOCK)
             {
                 const uint32_t p = i / slots, r = i - p * slots;
@@ -899,7 +903,7 @@ __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const 
             continue;
         const uint32_t len = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
         const uint32_t n = ((len + a.rows_per_block - 1) / a.rows_per_block) * k;
-        const uint64_t * src = a.partial + ((size_t)q * a.nprobe + p) * a.seg_max * k;
+        const uint64_t * src = a.partial + ((size_t)slot * a.nprobe + p) * a.seg_max * k;
         for (uint32_t base = 0; base < n; base += 4 * WAVE)
         {
             uint64_t key[4];
@@ -926,17 +930,18 @@ __device__ __forceinline__ void ivf_merge_query(const IvfMergeParams & a, const 
 template <int METRIC, int R>
 __global__ __launch_bounds__(BLOCK) void ivf_merge_kernel(const IvfMergeParams a)
 {
-    ivf_merge_query<METRIC, R>(a, blockIdx.x);
+    ivf_merge_query<METRIC, R>(a, blockIdx.x, blockIdx.x);
 }
 
 /// Block b merges queries a.qmap[b], a.qmap[b + gridDim.x], ... up to *a.qcount (usually 0).
 template <int METRIC, int R>
 __global__ __launch_bounds__(BLOCK) void ivf_merge_subset_kernel(const IvfMergeParams a)
 {
-    const uint32_t nf = *a.qcount;
-    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x)
+    // fail-list entries [slot_base, slot_base + slot_cap): one round of the fallback (its buffers hold slot_cap queries)
+    const uint32_t nf = *a.qcount < a.slot_base + a.slot_cap ? *a.qcount : a.slot_base + a.slot_cap;
+    for (uint32_t f = a.slot_base + blockIdx.x; f < nf; f += gridDim.x)
     {
-        ivf_merge_query<METRIC, R>(a, a.qmap[f]);
+        ivf_merge_query<METRIC, R>(a, a.qmap[f], f - a.slot_base);
         __syncthreads();
     }
 }

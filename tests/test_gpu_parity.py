@@ -218,6 +218,10 @@ def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, opt)
     opt("ivf_eps_scale", "1e12")  # no certificates: canonical fallback for every query
     ids, dis = ix.search(q, k)
     same(ids, dis, *expect())
+    opt("fb_cap", "5")  # ... in rounds of 5 queries (the fallback buffers hold `cap` queries, not nq)
+    ids, dis = ix.search(q, k)
+    same(ids, dis, *expect())
+    opt("fb_cap", None)
     opt("ivf_eps_scale", None)
     opt("ivf_nqg", "2")  # 256-query tiles
     ids, dis = ix.search(q, k)
@@ -308,6 +312,10 @@ def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, 
     same(ids, dis, oi, od)
     q2, f2 = capi.prefilter_stats()
     assert f2 - f1 == nq
+    opt("fb_cap", "7")  # the same in rounds of 7 queries
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    opt("fb_cap", None)
     opt("ivf_eps_scale", None)
     if not h16:
         # 256-query tiles (one 8-wavefront workgroup per CU): same answer
@@ -363,6 +371,10 @@ def test_coarse_quantiser_through_the_candidate_pass(metric, opt):
     opt("ivf_eps_scale", "1e12")  # every certificate fails: canonical fallbacks everywhere
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
+    opt("fb_cap", "3")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    opt("fb_cap", None)
     opt("ivf_eps_scale", None)
     opt("coarse_mfma", "0")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
