@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,c1,c3,c5,cpu")
     ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the C3 / C5 legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--test-single-device", action="store_true",
+                    help="N > 1 ranks all on cuda:0 with a gloo transport under msvs_shard_search_device: exercises the N > 1 "
+                         "code path of this script on a one-GPU box (not a measurement)")
     args = ap.parse_args()
     skip = set(x for x in args.skip.split(",") if x)
 
@@ -191,6 +194,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if args.test_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     capi.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -198,9 +203,13 @@ def main():
     comm = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
         from myscaledb_amd import sharded
-        comm = sharded.rccl_comm()  # RCCL communicator owned by libmsvs; torch only carried the unique id
+        if args.test_single_device:
+            dist.init_process_group("gloo")
+            comm = sharded.gloo_comm()
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+            comm = sharded.rccl_comm()  # RCCL communicator owned by libmsvs; torch only carried the unique id
 
     n, d, nlist, nprobe, k, B = args.rows, args.dim, args.nlist, args.nprobe, args.k, args.batch
     t_setup = time.time()
@@ -223,7 +232,12 @@ def main():
             t.build()
             cent.copy_(torch.from_numpy(t.export()[0]))
             t.close()
-        dist.broadcast(cent, 0)
+        if args.test_single_device:
+            c_ = cent.cpu()
+            dist.broadcast(c_, 0)
+            cent.copy_(c_)
+        else:
+            dist.broadcast(cent, 0)
         ix.set_centroids(cent.cpu().numpy())
     ix.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
     ix.build()
@@ -256,7 +270,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     qps = args.steps * B / elapsed
@@ -290,7 +304,7 @@ def main():
     # matrix-core work of the same launches: fp16 MFMA, 2 flop per (query, probed row, element padded to 64)
     mfma_tf = rows_model * 2 * ((d + 63) // 64 * 64) / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 and cand_pass else 0.0
     if world > 1:
-        t = torch.tensor([achieved, moved_gbs], device=dev, dtype=torch.float64)
+        t = torch.tensor([achieved, moved_gbs], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         achieved, moved_gbs = float(t[0].item()), float(t[1].item())
     roof = {

@@ -213,3 +213,24 @@ def test_rccl_transport_single_rank_roundtrip():
             fi, fd = ix.search(q, k, "nprobe=5" if typ == capi.INDEX_IVFFLAT else "")
             assert (oi.cpu().numpy() == fi).all() and (od.cpu().numpy() == fd).all()
     comm.close()
+
+
+@pytest.mark.gpu
+def test_bench_n_gt_1_code_path_runs_on_one_gpu():
+    """bench.py's N > 1 branch (sharded build, msvs_shard_search_device, max-over-ranks timing, rank-0 JSON line) with two
+    ranks sharing cuda:0 and a gloo transport (--test-single-device): the driver's multi-GPU run must not be the first
+    time this code executes."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29613", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rows", "200000", "--batch", "512", "--nlist", "256", "--test-single-device"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.split("\n") if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"].startswith("lists % 2")
