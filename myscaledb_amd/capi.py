@@ -644,11 +644,15 @@ class Postings:
                                             _p(cnt, C.c_uint32)))
         return [(rows[q, :cnt[q]].copy(), scores[q, :cnt[q]].copy()) for q in range(nq)]
 
+    def prepare_batch(self, queries, dfs, total_tokens, groups=None):
+        """The flat argument arrays of a batch, built once (a serving front end keeps them in this form anyway)."""
+        return (len(queries),) + self._batch_args(queries, dfs, groups, total_tokens)
+
     def bm25_search_batch_device(self, queries, dfs, total_docs, total_tokens, k, d_row_ids, d_scores, stream=0,
-                                 d_alive=0, nbits=0, groups=None, operator_or=True):
-        """Stream-ordered: int64 ids (-1 = no hit) / f32 scores into DEVICE buffers [nq, k] given by address."""
-        nq = len(queries)
-        qoff, qterms, qg, df, tokens = self._batch_args(queries, dfs, groups, total_tokens)
+                                 d_alive=0, nbits=0, groups=None, operator_or=True, prepared=None):
+        """Stream-ordered: int64 ids (-1 = no hit) / f32 scores into DEVICE buffers [nq, k] given by address.
+        prepared: the result of prepare_batch (queries / dfs / total_tokens / groups are then ignored)."""
+        nq, qoff, qterms, qg, df, tokens = prepared if prepared is not None else self.prepare_batch(queries, dfs, total_tokens, groups)
         _check(lib().msvs_bm25_search_batch_device(self._h, C.c_size_t(nq), _p(qoff, C.c_uint32), _p(qterms, C.c_uint32),
                                                    _p(qg, C.c_uint32), _p(df, C.c_uint64), C.c_uint64(int(total_docs)),
                                                    _p(tokens, C.c_uint64), 1 if operator_or else 0, C.c_void_p(d_alive),

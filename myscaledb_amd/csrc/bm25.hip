@@ -59,6 +59,58 @@ unsigned long long * bm25_fail_counter()
     return p;
 }
 
+/// Host staging of a batch's argument blob: a small ring of pinned buffers per (host thread, stream).  The copy to the
+/// device is truly asynchronous from pinned memory; a slot is reused only after the event recorded behind its copy has
+/// passed (four calls later: normally long ago).  hipLaunchHostFunc to free a heap blob cost ~0.3 ms per call.
+struct PinnedRing
+{
+    void * buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[4] = {0, 0, 0, 0};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int next = 0;
+    void * take(size_t bytes, int & slot)
+    {
+        slot = next;
+        next = (next + 1) & 3;
+        if (ev[slot])
+            MSVS_HIP(hipEventSynchronize(ev[slot]));
+        else
+            MSVS_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        if (cap[slot] < bytes)
+        {
+            if (buf[slot])
+                MSVS_HIP(hipHostFree(buf[slot]));
+            buf[slot] = nullptr;
+            cap[slot] = 0;
+            MSVS_HIP(hipHostMalloc(&buf[slot], bytes + bytes / 2 + 4096, hipHostMallocDefault));
+            cap[slot] = bytes + bytes / 2 + 4096;
+        }
+        return buf[slot];
+    }
+};
+PinnedRing & pinned_ring(hipStream_t stream)
+{
+    static thread_local std::map<std::pair<int, hipStream_t>, PinnedRing> rings;
+    int dev = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    return rings[{dev, stream}];
+}
+
+/// Resident workgroups of the wave scorer per CU: 8 B of LDS per document (+ 1 per text column) and wavefront.
+uint32_t bw_blocks_per_cu(bool one_field)
+{
+    const size_t per_block = (size_t)BW_WAVES * BW_DOCS * (8 + (one_field ? 1 : 4)) + 4096;
+    return (uint32_t)std::max<size_t>(1, (160 * 1024) / per_block);
+}
+
+uint32_t bm25_cu_count()
+{
+    int dev = 0, n = 0;
+    MSVS_HIP(hipGetDevice(&dev));
+    MSVS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    return (uint32_t)std::max(n, 1);
+}
+
 __global__ void and_words_kernel(const uint64_t * a, size_t na, const uint64_t * b, size_t nb, uint64_t * out, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,15 +216,16 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     const size_t o_qoff = 0, o_terms = o_qoff + (nq + 1) * 4, o_w = o_terms + nf1 * 4, o_cache = o_w + nf1 * 4,
                  o_full = o_cache + nc * 4, o_group = o_full + round_up(nq * 2, (size_t)4), o_field = o_group + nf1,
                  blob_bytes = round_up(o_field + nf1, (size_t)16);
-    auto * blob = new std::vector<unsigned char>(blob_bytes);
-    std::unique_ptr<std::vector<unsigned char>> blob_owner(blob);
-    uint32_t * h_qoff = reinterpret_cast<uint32_t *>(blob->data() + o_qoff);
-    uint32_t * h_terms = reinterpret_cast<uint32_t *>(blob->data() + o_terms);
-    float * weight = reinterpret_cast<float *>(blob->data() + o_w);
-    uint16_t * full = reinterpret_cast<uint16_t *>(blob->data() + o_full);
-    uint8_t * group = blob->data() + o_group;
-    uint8_t * field = blob->data() + o_field;
-    memcpy(blob->data() + o_cache, cache, nc * 4);
+    PinnedRing & ring = pinned_ring(stream);
+    int slot = 0;
+    unsigned char * blob = static_cast<unsigned char *>(ring.take(blob_bytes, slot));
+    uint32_t * h_qoff = reinterpret_cast<uint32_t *>(blob + o_qoff);
+    uint32_t * h_terms = reinterpret_cast<uint32_t *>(blob + o_terms);
+    float * weight = reinterpret_cast<float *>(blob + o_w);
+    uint16_t * full = reinterpret_cast<uint16_t *>(blob + o_full);
+    uint8_t * group = blob + o_group;
+    uint8_t * field = blob + o_field;
+    memcpy(blob + o_cache, cache, nc * 4);
     h_qoff[0] = 0;
     for (size_t q = 0; q < nq; q++)
     {
@@ -200,28 +253,32 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         }
         full[q] = m;
     }
-    const uint32_t n_blocks = (uint32_t)std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)BM25_DOCS));
-    // long corpora: sample -> cut -> emit -> select (+ exact fallback); short ones: per-block top-k lists, one merge
-    const bool emit = n_blocks >= 64 && options().bm25_emit != 0;
+    // two kernels share this flow: the wave-private streaming scorer (default) and the block scorer it replaced (knob)
+    const bool wave = options().bm25_wave != 0;
+    const uint32_t docs_per_block = wave ? BW_DOCS : BM25_DOCS;
+    const uint32_t n_blocks = (uint32_t)std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)docs_per_block));
+    // wave scorer: an item = spi consecutive sub-ranges of one query; enough items for ~4 per resident wavefront
+    const uint32_t spi = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (size_t)n_blocks * nq / 8192));
+    const uint32_t n_chunks = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi) : n_blocks;
+    // long corpora: sample -> cut -> emit -> select (+ exact fallback); short ones: per-chunk top-k lists, one merge
+    const bool emit = n_chunks >= (wave ? 32u : 64u) && ps.num_docs >= 500000 && options().bm25_emit != 0;
     const uint32_t cand_cap = options().bm25_cand_cap > 0 ? (uint32_t)std::min<double>(options().bm25_cand_cap, BM25_CAND_CAP) : BM25_CAND_CAP;
     unsigned long long * stat_fail = bm25_fail_counter();
-    const uint32_t n_sb = (uint32_t)ceil_div((size_t)n_blocks, (size_t)BM25_SAMPLE_STEP);
+    const uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks, (size_t)BM25_SAMPLE_STEP);
     // m-th best of the sample as the cut: about STEP * m documents pass, 4 sigma (STEP * sqrt(m)) above k
     const double rs = 2.0 + std::sqrt(4.0 + (double)k / BM25_SAMPLE_STEP);
     const uint32_t cut_m = (uint32_t)std::min<double>(64.0, std::ceil(rs * rs));
     Scratch & scr = scratch_for(stream);
-    scr.reserve(nq * (size_t)n_blocks * k * 8 + nf1 * (size_t)(n_blocks + 1) * 16 + blob_bytes
+    scr.reserve(nq * (size_t)n_chunks * k * 8 + nf1 * (size_t)(n_blocks + 1) * 16 + blob_bytes
                     + (emit ? nq * ((size_t)(n_sb + 1) * cut_m * 8 + (size_t)BM25_CAND_CAP * 8 + 16) : 0) + 65536,
                 stream);
     Bm25Params a{};
     unsigned char * d_blob = scr.take<unsigned char>(blob_bytes);
     int64_t * d_bounds = scr.take<int64_t>(nf1 * (n_blocks + 1));
     int64_t * d_bounds_hi = scr.take<int64_t>(nf1 * (n_blocks + 1));
-    uint64_t * partial = scr.take<uint64_t>(nq * (size_t)n_blocks * k);
-    MSVS_HIP(hipMemcpyAsync(d_blob, blob->data(), blob_bytes, hipMemcpyHostToDevice, stream));
-    // the blob lives until the copy has run (no host synchronisation on this path)
-    MSVS_HIP(hipLaunchHostFunc(stream, [](void * p) { delete static_cast<std::vector<unsigned char> *>(p); }, blob));
-    blob_owner.release();
+    uint64_t * partial = scr.take<uint64_t>(nq * (size_t)n_chunks * k);
+    MSVS_HIP(hipMemcpyAsync(d_blob, blob, blob_bytes, hipMemcpyHostToDevice, stream));
+    MSVS_HIP(hipEventRecord(ring.ev[slot], stream)); // the slot is free again once the copy has run
     a.post_off = ps.post_off.p;
     a.doc_ids = ps.doc_ids.p;
     a.tfs = ps.tfs.p;
@@ -245,36 +302,65 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     a.qfield = d_blob + o_field;
     a.bounds = d_bounds;
     a.bounds_hi = d_bounds_hi;
-    auto launch_topk = [&](const Bm25Params & p, dim3 grid) {
-        const size_t lds = (size_t)5 * p.kk * 8;
-        switch (r_for_k(p.kk))
+    const uint32_t cus = bm25_cu_count();
+    // TOPK over (a sample of) the chunks: lists of p.kk keys into p.partial, `lists` per slot
+    auto launch_topk = [&](Bm25Params p, uint32_t lists, uint32_t step, size_t slots_bound) {
+        if (wave)
         {
-            case 1:
-                hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 1>), grid, dim3(BLOCK), lds, stream, p);
-                break;
-            case 2:
-                hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 2>), grid, dim3(BLOCK), lds, stream, p);
-                break;
-            default:
-                hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 4>), grid, dim3(BLOCK), lds, stream, p);
-                break;
+            Bm25WParams w{};
+            w.p = p;
+            w.spi = spi;
+            w.n_chunks = n_chunks;
+            w.cstep = step;
+            w.n_items_c = lists;
+            w.lists = lists;
+            const bool nf1k = ps.num_fields == 1;
+            const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)lists * slots_bound, (size_t)BW_WAVES), (size_t)cus * bw_blocks_per_cu(nf1k)));
+            const int r = r_for_k(p.kk);
+#define MSVS_BM25W(RR, NF) hipLaunchKernelGGL((bm25w_kernel<BM25_TOPK, RR, NF>), dim3(grid), dim3(64 * BW_WAVES), 0, stream, w)
+            if (nf1k)
+            {
+                if (r == 1) MSVS_BM25W(1, 1); else if (r == 2) MSVS_BM25W(2, 1); else MSVS_BM25W(4, 1);
+            }
+            else
+            {
+                if (r == 1) MSVS_BM25W(1, 4); else if (r == 2) MSVS_BM25W(2, 4); else MSVS_BM25W(4, 4);
+            }
+#undef MSVS_BM25W
+        }
+        else
+        {
+            p.n_pad = lists;
+            p.bstep = step;
+            const size_t lds = (size_t)5 * p.kk * 8;
+            const dim3 grid(lists, (uint32_t)std::min<size_t>(slots_bound, std::max<size_t>(1, 2048 / lists)));
+            switch (r_for_k(p.kk))
+            {
+                case 1:
+                    hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 1>), grid, dim3(BLOCK), lds, stream, p);
+                    break;
+                case 2:
+                    hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 2>), grid, dim3(BLOCK), lds, stream, p);
+                    break;
+                default:
+                    hipLaunchKernelGGL((bm25_score_kernel<BM25_TOPK, 4>), grid, dim3(BLOCK), lds, stream, p);
+                    break;
+            }
         }
         MSVS_HIP(hipGetLastError());
     };
     ProfileScope prof("bm25_score", stream);
     if (n_flat)
         hipLaunchKernelGGL(bm25_bounds_kernel, dim3((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256)), dim3(256), 0,
-                           stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat);
+                           stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block);
     if (!emit)
     {
         a.partial = partial;
         a.kk = (uint32_t)k;
-        a.n_pad = n_blocks;
-        a.bstep = 1;
-        launch_topk(a, dim3(n_blocks, (uint32_t)std::min<size_t>(nq, std::max<size_t>(1, 2048 / n_blocks))));
+        launch_topk(a, n_chunks, 1, nq);
         MergeParams m{};
         m.partial = partial;
-        m.n_lists = n_blocks;
+        m.n_lists = n_chunks;
         m.k = (uint32_t)k;
         m.out_ids = d_ids;
         m.out_dis = d_scores;
@@ -287,13 +373,11 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     uint32_t * counters = scr.take<uint32_t>(2 * nq + 4); // ccnt[nq] | nfail | failq[nq]
     MSVS_HIP(hipMemsetAsync(counters, 0, (nq + 1) * 4, stream));
     uint32_t * ccnt = counters, * nfail = counters + nq, * failq = counters + nq + 1;
-    // 1. the sample: every 16th block, short lists
+    // 1. the sample: every 16th chunk, short lists
     Bm25Params sp = a;
     sp.partial = sample;
     sp.kk = cut_m;
-    sp.n_pad = n_sb;
-    sp.bstep = BM25_SAMPLE_STEP;
-    launch_topk(sp, dim3(n_sb, (uint32_t)std::min<size_t>(nq, std::max<size_t>(1, 2048 / n_sb))));
+    launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq);
     MergeParams m{};
     m.partial = sample;
     m.n_lists = n_sb;
@@ -301,16 +385,35 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     m.mode = 2;
     m.out_keys = cut_keys;
     launch_merge(M_IP, m, (uint32_t)nq, stream);
-    // 2. every block: emit what passes the cut
+    // 2. every chunk: emit what passes the cut
     Bm25Params ep = a;
-    ep.bstep = 1;
     ep.cut_keys = cut_keys;
     ep.cut_m = cut_m;
     ep.cand = cand;
     ep.ccnt = ccnt;
     ep.cand_cap = cand_cap;
-    hipLaunchKernelGGL((bm25_score_kernel<BM25_EMIT, 1>), dim3(n_blocks, (uint32_t)std::min<size_t>(nq, ceil_div((size_t)4096, (size_t)n_blocks))),
-                       dim3(BLOCK), 0, stream, ep);
+    if (wave)
+    {
+        Bm25WParams w{};
+        w.p = ep;
+        w.spi = spi;
+        w.n_chunks = n_chunks;
+        w.cstep = 1;
+        w.n_items_c = n_chunks;
+        w.lists = n_chunks;
+        const bool nf1k = ps.num_fields == 1;
+        const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)n_chunks * nq, (size_t)BW_WAVES), (size_t)cus * bw_blocks_per_cu(nf1k)));
+        if (nf1k)
+            hipLaunchKernelGGL((bm25w_kernel<BM25_EMIT, 1, 1>), dim3(grid), dim3(64 * BW_WAVES), 0, stream, w);
+        else
+            hipLaunchKernelGGL((bm25w_kernel<BM25_EMIT, 1, 4>), dim3(grid), dim3(64 * BW_WAVES), 0, stream, w);
+    }
+    else
+    {
+        ep.bstep = 1;
+        hipLaunchKernelGGL((bm25_score_kernel<BM25_EMIT, 1>), dim3(n_blocks, (uint32_t)std::min<size_t>(nq, ceil_div((size_t)4096, (size_t)n_blocks))),
+                           dim3(BLOCK), 0, stream, ep);
+    }
     // 3. select, or queue for the fallback
     const size_t lds_k = (size_t)5 * k * 8;
     switch (r_for_k((uint32_t)k))
@@ -332,23 +435,21 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     Bm25Params fp = a;
     fp.partial = partial;
     fp.kk = (uint32_t)k;
-    fp.n_pad = n_blocks;
-    fp.bstep = 1;
     fp.qsel = failq;
     fp.nsel = nfail;
-    launch_topk(fp, dim3(n_blocks, (uint32_t)std::min<size_t>(nq, 4)));
+    launch_topk(fp, n_chunks, 1, std::min<size_t>(nq, wave ? nq : 4));
     switch (r_for_k((uint32_t)k))
     {
         case 1:
-            hipLaunchKernelGGL((bm25_fb_merge_kernel<1>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_blocks, n_blocks,
+            hipLaunchKernelGGL((bm25_fb_merge_kernel<1>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_chunks, n_chunks,
                                (uint32_t)k, failq, nfail, d_ids, d_scores);
             break;
         case 2:
-            hipLaunchKernelGGL((bm25_fb_merge_kernel<2>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_blocks, n_blocks,
+            hipLaunchKernelGGL((bm25_fb_merge_kernel<2>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_chunks, n_chunks,
                                (uint32_t)k, failq, nfail, d_ids, d_scores);
             break;
         default:
-            hipLaunchKernelGGL((bm25_fb_merge_kernel<4>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_blocks, n_blocks,
+            hipLaunchKernelGGL((bm25_fb_merge_kernel<4>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, partial, n_chunks, n_chunks,
                                (uint32_t)k, failq, nfail, d_ids, d_scores);
             break;
     }
@@ -409,8 +510,10 @@ void bm25_batch_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
             eff_bits = res_bits;
         }
     }
-    const size_t n_blocks = std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)BM25_DOCS));
-    const size_t per_q = (n_blocks + 64) * k * 8 + (size_t)BM25_CAND_CAP * 8;
+    const size_t n_blocks = std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)BW_DOCS)); // an upper bound of the lists per query
+    // per query: candidate slots + ~4 terms of sub-range bounds (the per-chunk lists are ~8192 x k keys for the whole batch)
+    const size_t per_q = (size_t)BM25_CAND_CAP * 8 + 4 * 16 * (n_blocks + 1) + 64 * k * 8 + 64
+        + (options().bm25_wave != 0 ? 0 : ceil_div(ps.num_docs, (size_t)BM25_DOCS) * k * 8); // the block scorer: a list per block
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)256 << 20) / per_q));
     for (size_t q0 = 0; q0 < nq; q0 += chunk)
     {
@@ -522,3 +625,4 @@ extern "C" int msvs_bm25_stats(uint64_t * queries, uint64_t * fallbacks)
             *fallbacks = f;
     });
 }
+

@@ -83,7 +83,8 @@ struct Bm25Params
     uint32_t * ccnt;             // [nq], zeroed by the caller
 };
 
-static __global__ void bm25_bounds_kernel(const Bm25Params a, int64_t * bounds, int64_t * bounds_hi, uint32_t n_flat)
+static __global__ void bm25_bounds_kernel(const Bm25Params a, int64_t * bounds, int64_t * bounds_hi, uint32_t n_flat,
+                                          uint32_t docs_per_block)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nb1 = a.n_blocks + 1;
@@ -91,7 +92,7 @@ static __global__ void bm25_bounds_kernel(const Bm25Params a, int64_t * bounds, 
         return;
     const uint32_t j = (uint32_t)(i / nb1), b = (uint32_t)(i - (size_t)j * nb1);
     const uint32_t term = a.qterms[j];
-    const uint64_t target = (uint64_t)b * BM25_DOCS;
+    const uint64_t target = (uint64_t)b * docs_per_block;
     int64_t lo = a.post_off[term], hi = a.post_off[term + 1];
     while (lo < hi)
     {
@@ -426,6 +427,275 @@ __global__ __launch_bounds__(BLOCK) void bm25_score_kernel(const Bm25Params a)
         s += stride;
         if (s >= nslots)
             break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wave-private streaming scorer
+//
+// bm25_score_kernel above moves ~2 KB per (block, query) step through 4 wavefronts and 5 workgroup barriers: 12.7 us per
+// query at batch 64 over 10M documents whatever is prefetched.  Here the unit is ONE WAVEFRONT and there are no barriers:
+//   * a work item = (chunk of `spi` consecutive 2048-document sub-ranges, query); persistent wavefronts take items
+//     chunk-major (the 4 wavefronts of a block work on 4 queries of the same chunk: shared fieldnorm lines);
+//   * the wavefront owns f32 scores, u16 token-group masks and a touched list for 2048 documents in LDS (16 KB) plus
+//     the sub-range's fieldnorm bytes (2 KB per text column, loaded coalesced instead of gathered per posting);
+//   * per sub-range and term IN ORDER the slice of the posting list (bounds precomputed at sub-range granularity) is
+//     consumed 64 postings at a time: LDS ops of one wavefront execute in order, so term t + 1 sees term t's sums
+//     without any barrier; first-touched documents join the list through ballot + mbcnt, no atomics;
+//   * what the NEXT sub-range needs is in flight while this one is scored: its slice bounds are loaded two sub-ranges
+//     ahead (lane t = term t), its fieldnorm slice and the first 64 postings of its first four terms one ahead;
+//   * TOPK keeps one WaveTopK across the whole item (one sorted list per item), EMIT appends what passes the cut.
+// Measured (profiles/r02_bm25.txt): 10.0 us per query at batch 64 (block scorer 12.7), 7.9 at 256 (10.9), 2.9 at 1024.
+// Wall-clock stamps of one wavefront: 1.6 us per sub-range = prefetch issue 0.2 + terms 1.15 + touched 0.25 + waits 0.02:
+// the loads ARE hidden; what is left is instruction issue -- ~550 wavefront instructions per sub-range whatever the
+// lane use, and a mid-frequency term fills 20 of 64 lanes per 2048 documents.  Wider sub-ranges do not fit the LDS
+// (8 B per document); the next step is a sparse (hashed) accumulator instead of dense arrays.
+constexpr uint32_t BW_DOCS = 2048;
+constexpr uint32_t BW_WAVES = 4; // wavefronts per workgroup
+constexpr uint32_t BW_FNL = BW_DOCS / 64;   // fieldnorm bytes per lane and sub-range
+constexpr uint32_t BW_FNV = BW_FNL / 16;    // ... as 16-byte loads
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct Bm25WParams
+{
+    Bm25Params p;          // postings, batch, filter, cut / candidate buffers (bounds at BW_DOCS granularity: n_blocks = sub-ranges)
+    uint32_t spi;          // sub-ranges per item
+    uint32_t n_chunks;     // ceil(n_blocks / spi)
+    uint32_t cstep;        // TOPK sample: item chunk = index * cstep
+    uint32_t n_items_c;    // chunks this launch walks (n_chunks, or the sample's ceil(n_chunks / cstep))
+    uint32_t lists;        // TOPK: lists per slot in `partial` (= n_items_c)
+};
+
+template <int MODE, int R, int NF>
+__global__ __launch_bounds__(64 * BW_WAVES) void bm25w_kernel(const Bm25WParams a)
+{
+    __shared__ float score[BW_WAVES][BW_DOCS];
+    __shared__ uint16_t mask[BW_WAVES][BW_DOCS];
+    __shared__ uint16_t touched[BW_WAVES][BW_DOCS];
+    __shared__ __attribute__((aligned(16))) uint8_t fnw[BW_WAVES][NF][BW_DOCS];
+    __shared__ float cache[NF * 256];
+    const Bm25Params & p = a.p;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float * sc = score[wave];
+    uint16_t * mk = mask[wave];
+    uint16_t * tl = touched[wave];
+    for (uint32_t i = lane; i < BW_DOCS; i += 64)
+    {
+        sc[i] = 0.f;
+        mk[i] = 0;
+    }
+    for (uint32_t i = tid; i < p.num_fields * 256; i += 64 * BW_WAVES)
+        cache[i] = p.norm_cache[i];
+    __syncthreads(); // the only workgroup barrier: the fieldnorm cache
+    const uint32_t nslots = p.qsel ? *p.nsel : p.nq;
+    const uint32_t nb1 = p.n_blocks + 1;
+    const uint64_t n_items = (uint64_t)a.n_items_c * nslots;
+    const uint32_t waves_total = gridDim.x * BW_WAVES;
+    for (uint64_t item = (uint64_t)blockIdx.x * BW_WAVES + wave; item < n_items; item += waves_total)
+    {
+        const uint32_t ci = (uint32_t)(item / nslots), slot = (uint32_t)(item - (uint64_t)ci * nslots);
+        const uint32_t chunk = ci * a.cstep;
+        const uint32_t q = p.qsel ? p.qsel[slot] : slot;
+        const uint32_t j0 = p.qoff[q], nt = p.qoff[q + 1] - j0;
+        const uint16_t full = p.qfull[q];
+        float cut = 0.f;
+        if (MODE == BM25_EMIT)
+        {
+            const uint64_t ck = p.cut_keys[(size_t)q * p.cut_m + p.cut_m - 1];
+            cut = ck == KEY_NONE ? 0.f : key_value<M_IP>(ck); // fewer than m sample hits: everything passes
+        }
+        // lane t = term t of the query (<= 64 terms)
+        const uint32_t jt = j0 + (lane < nt ? lane : 0);
+        const float w_l = p.weight[jt];
+        const uint32_t bit_l = 1u << p.qgroup[jt], field_l = p.qfield[jt];
+        const uint32_t s_begin = chunk * a.spi, s_end = s_begin + a.spi < p.n_blocks ? s_begin + a.spi : p.n_blocks;
+        auto load_bounds = [&](uint32_t s, int64_t & b0, int64_t & b1) {
+            const uint32_t sx = s < p.n_blocks ? s : p.n_blocks - 1; // past the item: a valid address, never used
+            b0 = p.bounds[(size_t)jt * nb1 + sx];
+            b1 = p.bounds_hi[(size_t)jt * nb1 + sx];
+        };
+        struct Win // first 64 postings of terms 0..3 of a sub-range
+        {
+            uint32_t doc[4], tf[4];
+        };
+        auto load_win = [&](int64_t b0, Win & wd) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const int64_t pp = (int64_t)readlane64((uint64_t)b0, u) + lane; // lanes past the slice read on: valid memory, masked later
+                const uint64_t pc = (uint64_t)pp < p.last_posting ? (uint64_t)pp : p.last_posting;
+                wd.doc[u] = p.doc_ids[pc];
+                wd.tf[u] = p.tfs[pc];
+            }
+        };
+        u32x4 f_next[NF == 1 ? BW_FNV : 1];
+        auto load_fn = [&](uint32_t s) { // NF == 1: the sub-range's 2048 fieldnorm bytes, 32 per lane
+            const uint32_t base = s * BW_DOCS;
+            const size_t at = (size_t)base + lane * BW_FNL;
+            const size_t lim = p.num_docs >= BW_FNL + 16 ? (p.num_docs - BW_FNL) & ~(size_t)15 : 0; // the corpus' tail: a clamped,
+            const uint8_t * src = p.fieldnorm_ids + (at < lim ? at : lim); // aligned address (its bytes are re-read one by one)
+#pragma unroll
+            for (uint32_t v = 0; v < (NF == 1 ? BW_FNV : 1); v++)
+                f_next[v] = *reinterpret_cast<const u32x4 *>(src + 16 * v);
+        };
+        int64_t b0c, b1c, b0n, b1n;
+        load_bounds(s_begin, b0c, b1c);
+        load_bounds(s_begin + 1, b0n, b1n);
+        Win wc;
+        load_win(b0c, wc);
+        if (NF == 1)
+            load_fn(s_begin);
+        WaveTopK<R> top;
+        top.init();
+        for (uint32_t s = s_begin; s < s_end; s++)
+        {
+            const uint32_t base = s * BW_DOCS;
+            // ---- land what was prefetched for this sub-range, issue the prefetches for the next ones
+            if (NF == 1)
+            {
+                const size_t at = (size_t)base + lane * BW_FNL;
+                const size_t lim = p.num_docs >= BW_FNL + 16 ? (p.num_docs - BW_FNL) & ~(size_t)15 : 0;
+                if (at < lim)
+                {
+#pragma unroll
+                    for (uint32_t v = 0; v < (NF == 1 ? BW_FNV : 1); v++)
+                        *reinterpret_cast<u32x4 *>(&fnw[wave][0][lane * BW_FNL + 16 * v]) = f_next[v];
+                }
+                else
+                    for (uint32_t i = 0; i < BW_FNL; i++) // the last lanes of the corpus' last sub-range only
+                    {
+                        const size_t d = at + i;
+                        if (d < p.num_docs)
+                            fnw[wave][0][lane * BW_FNL + i] = p.fieldnorm_ids[d];
+                    }
+            }
+            else
+                for (uint32_t f = 0; f < p.num_fields; f++)
+                    for (uint32_t i = lane; i < BW_DOCS; i += 64)
+                        fnw[wave][f][i] = (size_t)base + i < p.num_docs ? p.fieldnorm_ids[(size_t)f * p.num_docs + base + i] : (uint8_t)0;
+            int64_t b0f, b1f;
+            load_bounds(s + 2, b0f, b1f);
+            Win wn;
+            load_win(b0n, wn);
+            if (NF == 1 && s + 1 < s_end)
+                load_fn(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- score the sub-range, term by term.  One posting = a chain of dependent LDS accesses (fieldnorm byte ->
+            // cache entry -> score read -> write, mask read -> write): ~1000 cycles per term when walked one term at a time.
+            // The lookups and the division of the first four terms' prefetched windows do not depend on each other: they
+            // are issued together; only the read-modify-writes stay in term order.
+            uint32_t ntouch = 0;
+            auto add = [&](bool live, uint32_t loc, float sv, uint32_t bit) {
+                bool fresh = false;
+                if (live)
+                {
+                    sc[loc] = __fadd_rn(sc[loc], sv);
+                    const uint16_t old = mk[loc];
+                    mk[loc] = old | (uint16_t)bit;
+                    fresh = old == 0;
+                }
+                const uint64_t fm = __ballot(fresh);
+                if (fresh)
+                    tl[ntouch + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = (uint16_t)loc;
+                ntouch += (uint32_t)__popcll(fm);
+            };
+            float sv4[4];
+            uint32_t loc4[4];
+            bool live4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const int64_t p0 = (int64_t)readlane64((uint64_t)b0c, u), p1 = (int64_t)readlane64((uint64_t)b1c, u);
+                live4[u] = (uint32_t)u < nt && p0 + lane < p1;
+                loc4[u] = live4[u] ? wc.doc[u] - base : 0u;
+            }
+            uint32_t fid4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const uint32_t field = (uint32_t)__builtin_amdgcn_readlane((int)field_l, u);
+                fid4[u] = fnw[wave][NF == 1 ? 0 : field][loc4[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const uint32_t field = (uint32_t)__builtin_amdgcn_readlane((int)field_l, u);
+                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w_l), u));
+                const float tff = (float)wc.tf[u];
+                sv4[u] = __fmul_rn(w, __fdiv_rn(tff, __fadd_rn(tff, cache[field * 256 + fid4[u]])));
+            }
+            for (uint32_t t = 0; t < nt; t++)
+            {
+                // t is wave-uniform: v_readlane with a scalar lane index, not a trip through the LDS crossbar
+                const int64_t p0 = (int64_t)readlane64((uint64_t)b0c, (int)t), p1 = (int64_t)readlane64((uint64_t)b1c, (int)t);
+                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w_l), (int)t));
+                const uint32_t bit = (uint32_t)__builtin_amdgcn_readlane((int)bit_l, (int)t),
+                               field = (uint32_t)__builtin_amdgcn_readlane((int)field_l, (int)t);
+                const float * fc = cache + field * 256;
+                const uint8_t * fb = fnw[wave][NF == 1 ? 0 : field];
+                int64_t pp = p0;
+                if (t < 4) // the prefetched window, already scored
+                {
+                    const bool lv = t == 0 ? live4[0] : (t == 1 ? live4[1] : (t == 2 ? live4[2] : live4[3]));
+                    const uint32_t lc = t == 0 ? loc4[0] : (t == 1 ? loc4[1] : (t == 2 ? loc4[2] : loc4[3]));
+                    const float sv = t == 0 ? sv4[0] : (t == 1 ? sv4[1] : (t == 2 ? sv4[2] : sv4[3]));
+                    if (p0 < p1)
+                        add(lv, lc, sv, bit);
+                    pp = p0 + 64;
+                }
+                for (; pp < p1; pp += 64) // long slices, and the terms past the fourth: plain loads
+                {
+                    const bool live = pp + lane < p1;
+                    const uint64_t pc = live ? (uint64_t)(pp + lane) : (uint64_t)p0;
+                    const uint32_t d = p.doc_ids[pc], f = p.tfs[pc];
+                    uint32_t loc = 0;
+                    float sv = 0.f;
+                    if (live)
+                    {
+                        loc = d - base;
+                        const float tff = (float)f;
+                        sv = __fmul_rn(w, __fdiv_rn(tff, __fadd_rn(tff, fc[fb[loc]])));
+                    }
+                    add(live, loc, sv, bit);
+                }
+            }
+            // ---- the documents this sub-range touched
+            for (uint32_t i0 = 0; i0 < ntouch; i0 += 64)
+            {
+                const uint32_t i = i0 + lane;
+                uint64_t key = KEY_NONE;
+                if (i < ntouch)
+                {
+                    const uint32_t loc = tl[i], docid = base + loc;
+                    const float sv = sc[loc];
+                    bool ok = (p.operator_or || mk[loc] == full) && (MODE != BM25_EMIT || sv >= cut);
+                    sc[loc] = 0.f;
+                    mk[loc] = 0;
+                    if (ok && p.alive)
+                        ok = docid < p.nbits && ((p.alive[docid >> 6] >> (docid & 63)) & 1);
+                    if (ok)
+                        key = make_key<M_IP>(sv, docid);
+                }
+                if (MODE == BM25_EMIT)
+                {
+                    if (key != KEY_NONE)
+                    {
+                        const uint32_t pos = atomicAdd(&p.ccnt[q], 1u);
+                        if (pos < p.cand_cap)
+                            p.cand[(size_t)q * BM25_CAND_CAP + pos] = key;
+                    }
+                }
+                else
+                    top.offer(key, p.kk, lane);
+            }
+            // ---- rotate
+            b0c = b0n;
+            b1c = b1n;
+            b0n = b0f;
+            b1n = b1f;
+            wc = wn;
+        }
+        if (MODE == BM25_TOPK)
+            top.store(p.partial + ((size_t)slot * a.lists + ci) * p.kk, p.kk, lane);
     }
 }
 

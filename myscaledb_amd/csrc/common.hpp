@@ -157,6 +157,7 @@ struct Options
     double filter_compact_below = -1;  // filtered searches run over a compacted view when less than this fraction of the
                                        // rows passes the filter (1: always, 0: never, < 0: by batch size,
                                        // profiles/r02_filter.txt)
+    double bm25_wave = 1;     // BM25: wave-private streaming scorer (1) or the barrier-synchronised block scorer (0)
     double bm25_emit = 1;     // BM25 over long corpora: sample / cut / emit (1) or per-block top-k lists only (0)
     double bm25_cand_cap = 0; // BM25 candidate slots per query (0 = 2048; small values force the fallback)
 };

