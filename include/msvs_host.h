@@ -74,6 +74,16 @@ MSVS_HOST_API size_t msvs_host_hybrid_search(int fusion_type, const float * vec_
                                              size_t topk, float * out_scores, uint64_t * out_parts,
                                              uint64_t * out_labels);
 
+/* HybridSearchFusionTransform::generate (src/VectorIndex/Processors/HybridSearchFusionTransform.cpp:22-182): the fusion step of
+ * a Distributed-table hybrid search on the initiator.  Rows = the merged shard results in pipeline order: distance rows
+ * (score_type 0) first, then bm25 rows (score_type 1), each with (shard_num, part_index, part_offset).  At most num_candidates
+ * rows of each kind take part.  Output: indices into the input rows + fused scores (every bm25 row in order, then the
+ * distance rows not among them); returns their number (<= 2 * num_candidates).  fusion_type: 0 = RRF, 1 = RSF. */
+MSVS_HOST_API size_t msvs_host_fusion_transform(int fusion_type, const float * score, const uint8_t * score_type,
+                                                const uint32_t * shard_num, const uint64_t * part_index, const uint64_t * part_offset,
+                                                size_t n_rows, uint64_t num_candidates, uint64_t fusion_k, float fusion_weight,
+                                                int vector_scan_direction, uint64_t * out_rows, float * out_scores);
+
 /* Canonical merge of per-shard top-k lists that share one id space (the multi-GPU exchange step when the merge is
  * done on the host): ids/dis [nparts][nq][k] -> [nq][k]; order (dist asc | desc for IP, id asc), -1 ids ignored. */
 MSVS_HOST_API int msvs_host_merge_topk(const int64_t * ids, const float * dis, size_t nparts, size_t nq, size_t k,

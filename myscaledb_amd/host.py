@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsvs_host.so")
 SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_host_total_topk",
            "msvs_host_hybrid_search", "msvs_host_merge_topk", "msvs_host_sum_bm25_stats",
            "msvs_host_vector_scan_without_index", "msvs_host_merge_search_result",
-           "msvs_host_generate_vector_dataset", "msvs_host_vector_scan_resident",
+           "msvs_host_generate_vector_dataset", "msvs_host_vector_scan_resident", "msvs_host_fusion_transform",
            "msvs_text_last_error", "msvs_text_index_create", "msvs_text_index_free", "msvs_text_index_add_doc",
            "msvs_text_index_commit", "msvs_text_index_save", "msvs_text_index_load", "msvs_text_index_total_num_docs",
            "msvs_text_index_total_num_tokens", "msvs_text_index_doc_freq", "msvs_text_index_set_alive",
@@ -31,6 +31,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.msvs_host_total_topk.restype = C.c_size_t
         _lib.msvs_host_hybrid_search.restype = C.c_size_t
+        _lib.msvs_host_fusion_transform.restype = C.c_size_t
         _lib.msvs_host_sum_bm25_stats.restype = None
         _lib.msvs_text_last_error.restype = C.c_char_p
         _lib.msvs_text_index_total_num_docs.restype = C.c_uint64
@@ -147,6 +148,23 @@ def hybrid_search(fusion_type, vec, txt, topk, fusion_k=60, fusion_weight=0.5, v
                                       C.c_float(fusion_weight), int(vector_scan_direction), C.c_size_t(topk),
                                       _p(os_, C.c_float), _p(op, C.c_uint64), _p(ol, C.c_uint64))
     return os_[:n], op[:n], ol[:n]
+
+
+def fusion_transform(fusion_type, score, score_type, shard_num, part_index, part_offset, num_candidates, fusion_k=60,
+                     fusion_weight=0.5, vector_scan_direction=1):
+    """HybridSearchFusionTransform::generate over the merged shard rows (distance rows first, then bm25 rows) ->
+    (indices into the rows, fused scores)."""
+    score = _f32(score)
+    st = np.ascontiguousarray(score_type, np.uint8)
+    sh = np.ascontiguousarray(shard_num, np.uint32)
+    pi, po = _u64(part_index), _u64(part_offset)
+    n = score.size
+    out_rows, out_scores = np.empty(2 * max(1, int(num_candidates)), np.uint64), np.empty(2 * max(1, int(num_candidates)), np.float32)
+    cnt = lib().msvs_host_fusion_transform(1 if fusion_type == "rsf" else 0, _p(score, C.c_float), _p(st, C.c_uint8), _p(sh, C.c_uint32),
+                                           _p(pi, C.c_uint64), _p(po, C.c_uint64), C.c_size_t(n), C.c_uint64(int(num_candidates)),
+                                           C.c_uint64(int(fusion_k)), C.c_float(fusion_weight), int(vector_scan_direction),
+                                           _p(out_rows, C.c_uint64), _p(out_scores, C.c_float))
+    return out_rows[:cnt].astype(np.int64), out_scores[:cnt]
 
 
 def merge_topk(ids, dis, metric):

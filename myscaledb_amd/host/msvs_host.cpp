@@ -461,6 +461,78 @@ ScoreWithPartIndexAndLabels MergeTreeHybridSearchManager::hybridSearch(
     return result;
 }
 
+std::vector<std::pair<size_t, float>> hybridSearchFusionTransform(const std::vector<FusionRow> & rows, uint64_t num_candidates,
+                                                                  const HybridSearchInfo & info)
+{
+    const size_t total_rows = rows.size();
+    // row ranges {start index, length}
+    std::pair<size_t, size_t> distance_row_range{0, 0}, bm25_row_range{0, 0};
+    for (size_t row = 0; row < total_rows; ++row)
+    {
+        if (rows[row].score_type == 0)
+            bm25_row_range.first++;
+        else
+            break;
+    }
+    bm25_row_range.second = std::min<size_t>(total_rows - bm25_row_range.first, num_candidates);
+    const int direction = info.vector_scan_direction;
+    if (direction == -1)
+    {
+        distance_row_range.first = 0;
+        distance_row_range.second = std::min<size_t>(bm25_row_range.first, num_candidates);
+    }
+    else if (direction == 1)
+    {
+        if (bm25_row_range.first >= num_candidates)
+        {
+            distance_row_range.first = bm25_row_range.first - num_candidates;
+            distance_row_range.second = num_candidates;
+        }
+        else if (bm25_row_range.first > 0)
+        {
+            distance_row_range.first = 0;
+            distance_row_range.second = bm25_row_range.first;
+        }
+    }
+    auto entry = [&](size_t row) {
+        ScoreWithPartIndexAndLabel e;
+        e.score = rows[row].score;
+        e.part_index = rows[row].part_index;
+        e.label_id = rows[row].part_offset;
+        e.shard_num = rows[row].shard_num;
+        return e;
+    };
+    ScoreWithPartIndexAndLabels bm25_score_dataset, distance_score_dataset;
+    for (size_t offset = 0; offset < distance_row_range.second; ++offset)
+        distance_score_dataset.push_back(entry(direction == -1 ? distance_row_range.first + offset
+                                                               : distance_row_range.first + distance_row_range.second - 1 - offset));
+    for (size_t offset = 0; offset < bm25_row_range.second; ++offset)
+        bm25_score_dataset.push_back(entry(bm25_row_range.first + offset));
+    std::map<std::tuple<uint32_t, uint64_t, uint64_t>, float> fusion_id_with_score;
+    if (info.fusion_type == "rsf")
+        RelativeScoreFusion(fusion_id_with_score, distance_score_dataset, bm25_score_dataset, info.fusion_weight, (int8_t)direction);
+    else
+        RankFusion(fusion_id_with_score, distance_score_dataset, bm25_score_dataset, (uint64_t)info.fusion_k);
+    std::vector<std::pair<size_t, float>> out;
+    for (size_t i = 0; i < bm25_row_range.second; ++i) // the bm25 rows keep their place, their score becomes the fused one
+    {
+        const size_t row = bm25_row_range.first + i;
+        const auto id = std::make_tuple(rows[row].shard_num, rows[row].part_index, rows[row].part_offset);
+        out.emplace_back(row, fusion_id_with_score[id]);
+        fusion_id_with_score.erase(id);
+    }
+    for (size_t offset = 0; offset < distance_row_range.second; ++offset) // then the distance rows that were not among them
+    {
+        const size_t row = distance_row_range.first + offset;
+        const auto id = std::make_tuple(rows[row].shard_num, rows[row].part_index, rows[row].part_offset);
+        auto it = fusion_id_with_score.find(id);
+        if (it != fusion_id_with_score.end())
+            out.emplace_back(row, it->second);
+    }
+    return out;
+}
+
+
 }
 
 // ================================================================================================ C entry points
@@ -621,6 +693,35 @@ extern "C" size_t msvs_host_hybrid_search(int fusion_type, const float * vec_sco
         out_scores[i] = r[i].score;
         out_parts[i] = r[i].part_index;
         out_labels[i] = r[i].label_id;
+    }
+    return r.size();
+}
+
+/* HybridSearchFusionTransform::generate over flat arrays; returns the number of output rows. */
+extern "C" size_t msvs_host_fusion_transform(int fusion_type, const float * score, const uint8_t * score_type, const uint32_t * shard_num,
+                                             const uint64_t * part_index, const uint64_t * part_offset, size_t n_rows,
+                                             uint64_t num_candidates, uint64_t fusion_k, float fusion_weight, int vector_scan_direction,
+                                             uint64_t * out_rows, float * out_scores)
+{
+    std::vector<DB::FusionRow> rows(n_rows);
+    for (size_t i = 0; i < n_rows; i++)
+    {
+        rows[i].score = score[i];
+        rows[i].score_type = score_type[i];
+        rows[i].shard_num = shard_num[i];
+        rows[i].part_index = part_index[i];
+        rows[i].part_offset = part_offset[i];
+    }
+    DB::HybridSearchInfo info;
+    info.fusion_type = fusion_type == 1 ? "rsf" : "rrf";
+    info.fusion_k = static_cast<int>(fusion_k);
+    info.fusion_weight = fusion_weight;
+    info.vector_scan_direction = vector_scan_direction;
+    const auto r = DB::hybridSearchFusionTransform(rows, num_candidates, info);
+    for (size_t i = 0; i < r.size(); i++)
+    {
+        out_rows[i] = r[i].first;
+        out_scores[i] = r[i].second;
     }
     return r.size();
 }

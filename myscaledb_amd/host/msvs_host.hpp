@@ -181,6 +181,21 @@ struct HybridSearchInfo
     int vector_scan_direction = 1;
 };
 
+/// HybridSearchFusionTransform::generate (src/VectorIndex/Processors/HybridSearchFusionTransform.cpp:22-182): the fusion step
+/// of a Distributed-table hybrid search on the initiator.  `rows` are the merged shard results in pipeline order -- the
+/// distance rows (score_type 0) first, then the bm25 rows (score_type 1).  At most num_candidates rows of each kind take part
+/// (direction 1: the LAST num_candidates distance rows, read backwards, i.e. best first).  Returns (index into rows, fused
+/// score): every bm25 row in order, then the distance rows that are not among them.
+struct FusionRow
+{
+    float score = 0;
+    uint8_t score_type = 0;
+    uint32_t shard_num = 0;
+    uint64_t part_index = 0, part_offset = 0;
+};
+std::vector<std::pair<size_t, float>> hybridSearchFusionTransform(const std::vector<FusionRow> & rows, uint64_t num_candidates,
+                                                                  const HybridSearchInfo & info);
+
 struct MergeTreeHybridSearchManager
 {
     static ScoreWithPartIndexAndLabels hybridSearch(const ScoreWithPartIndexAndLabels & vec_scan_result_with_part_index,

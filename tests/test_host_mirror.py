@@ -320,3 +320,40 @@ def test_index_meta_delete_bitmap_and_decoupled_part_row_ids(typ):
     got, dist = ix.search(q, 10, params, alive=flt_new)
     oi, od = o.knn(q, x, 10, o.METRIC_L2, alive=flt_new[row_ids_map] & (np.arange(n) % 3 != 0))
     assert (got == np.where(oi >= 0, row_ids_map[np.maximum(oi, 0)], -1)).all() and (dist == od).all()
+
+
+@pytest.mark.parametrize("kind", ["rrf", "rsf"])
+@pytest.mark.parametrize("direction", [1, -1])
+def test_distributed_fusion_transform_matches_the_oracle_fusion(kind, direction):
+    """HybridSearchFusionTransform (the initiator's fusion of a Distributed-table hybrid search): row-range selection
+    (last / first num_candidates distance rows by direction, first num_candidates bm25 rows), fusion keyed by
+    (shard, part, offset), output order = bm25 rows then the remaining distance rows; scores == the oracle's fusion."""
+    rng = np.random.default_rng(17 + direction)
+    n_dist, n_txt, nc = 37, 29, 20
+    ids = [(int(s), int(p), int(o)) for s, p, o in zip(rng.integers(1, 4, 200), rng.integers(0, 3, 200), rng.integers(0, 50, 200))]
+    ids = list(dict.fromkeys(ids))
+    d_ids, t_ids = ids[:n_dist], ids[20:20 + n_txt]  # 17 rows in both result sets
+    d_scores = np.sort(rng.random(n_dist).astype(np.float32))[::-1].copy()  # the pipeline sorts by score DESC
+    t_scores = np.sort(rng.random(n_txt).astype(np.float32) * 10)[::-1].copy()
+    score = np.concatenate([d_scores, t_scores])
+    stype = np.array([0] * n_dist + [1] * n_txt, np.uint8)
+    allid = d_ids + t_ids
+    rows, fused = host.fusion_transform(kind, score, stype, [i[0] for i in allid], [i[1] for i in allid], [i[2] for i in allid], nc,
+                                        fusion_k=60, fusion_weight=0.3, vector_scan_direction=direction)
+    # the oracle: best-first candidate lists, shard folded into the part number
+    if direction == 1:  # smaller is better: the LAST nc distance rows, read backwards
+        dsel = list(range(n_dist - 1, n_dist - 1 - nc, -1))
+    else:
+        dsel = list(range(nc))
+    tsel = list(range(n_dist, n_dist + nc))
+    key = lambda r: allid[r][0] * 1000 + allid[r][1]
+    vs = (score[dsel], np.array([key(r) for r in dsel], np.uint64), np.array([allid[r][2] for r in dsel], np.uint64))
+    ts = (score[tsel], np.array([key(r) for r in tsel], np.uint64), np.array([allid[r][2] for r in tsel], np.uint64))
+    os_, op, ol = o.hybrid_fusion(kind, vs, ts, 2 * nc, fusion_k=60, fusion_weight=0.3, vector_scan_direction=direction)
+    want = {(int(p), int(l)): np.float32(s) for s, p, l in zip(os_, op, ol)}
+    got = {(key(int(r)), allid[int(r)][2]): np.float32(f) for r, f in zip(rows, fused)}
+    assert got == want
+    # order: every bm25 candidate row first, in place; then the distance rows that are not among them, in stored order
+    assert rows[:nc].tolist() == tsel
+    rest = [r for r in sorted(dsel) if allid[r] not in {allid[t] for t in tsel}]
+    assert rows[nc:].tolist() == rest
