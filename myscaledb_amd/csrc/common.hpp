@@ -137,6 +137,7 @@ struct Options
 {
     double ivf_pass = 1;      // candidate pass of the list scan: 0 never, 1 from ~2 queries per list on, 2 whenever eligible
     double ivf_h16 = 1;       // 1: over the fp16 shadow (h16_scan_kernels.hpp); 0: split-bf16 over the f32 rows
+    double coarse_h16 = 1;    // coarse quantiser of batches through the centroid shadow (0: the split-bf16 table pass)
     double coarse_mfma = 1;   // same switch for the coarse quantiser ...
     double flat_mfma = 1;     // ... and for FLAT batches
     double ivf_nqg = 1;       // split-bf16 pass: 128- (1) or 256-query (2) tiles

@@ -556,6 +556,7 @@ struct OptionField
 const OptionField g_option_fields[] = {
     {"ivf_pass", &Options::ivf_pass},       {"ivf_mfma", &Options::ivf_pass} /* round-1 name */,
     {"ivf_h16", &Options::ivf_h16},         {"coarse_mfma", &Options::coarse_mfma},
+    {"coarse_h16", &Options::coarse_h16},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},
     {"ivf_t", &Options::ivf_t},             {"ivf_xcd", &Options::ivf_xcd},

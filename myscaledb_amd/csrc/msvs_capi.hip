@@ -519,6 +519,12 @@ struct msvs_index
     uint32_t h_nks = 0, h_nch = 0;
     float h_scale = 0.f, h_inv_scale = 0.f; // stored value = fp16(x * h_scale)
     bool shadow_ready = false;
+    // fp16 shadow of the CENTROID table (same scale, same block layout: ceil(nlist / 32) blocks) for the coarse quantiser of
+    // batches, and the G-lists-of-one-block view the sample kernel walks it through
+    DevBuf<uint4> c_shadow;
+    DevBuf<uint32_t> c_hoff;     // [G + 1]: block g
+    DevBuf<int64_t> c_list_off;  // [G + 1]: centroid 32 g (last: nlist)
+    bool c_shadow_ready = false;
     bool ready = false;
     // VIWithMeta (src/VectorIndex/Cache/VICacheObject.h:40-117): state that rides on a cached index.  Swapped under `meta_mu`
     // (setDeleteBitmap is an atomic_store in the reference); a search keeps its own shared_ptr while it runs.
@@ -697,6 +703,44 @@ static void index_build_shadow(msvs_index & ix, hipStream_t stream)
     MSVS_HIP(hipGetLastError());
     MSVS_HIP(hipStreamSynchronize(stream));
     ix.shadow_ready = true;
+    // the centroid table in the same form (one list of nlist rows = G blocks), if it fits the rows' scale
+    ix.c_shadow_ready = false;
+    {
+        MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
+        const size_t c4 = ix.nlist * (size_t)(ix.ld / 4);
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>(ceil_div(c4, (size_t)256), 4096)), dim3(256), 0, stream,
+                           reinterpret_cast<const float4 *>(ix.centroids.p), c4, mx.p);
+        MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+        float cmax;
+        memcpy(&cmax, &bits, 4);
+        if (!(cmax <= maxabs) || !(ix.cnorm_max < 1e30f)) // user-supplied centroids may be larger than any row: no shadow then
+            return;
+        const size_t G = ceil_div(ix.nlist, (size_t)H_ROWS);
+        std::vector<uint32_t> c_hoff(G + 1), one_hoff = {0u, (uint32_t)G};
+        std::vector<int64_t> c_off(G + 1), one_off = {0, (int64_t)ix.nlist};
+        for (size_t g = 0; g <= G; g++)
+        {
+            c_hoff[g] = (uint32_t)g;
+            c_off[g] = (int64_t)std::min(g * H_ROWS, ix.nlist);
+        }
+        DevBuf<uint32_t> d_one_hoff(2), d_cblk(G);
+        DevBuf<int64_t> d_one_off(2);
+        MSVS_HIP(hipMemsetAsync(d_cblk.p, 0, G * 4, stream)); // every block belongs to list 0
+        MSVS_HIP(hipMemcpyAsync(d_one_hoff.p, one_hoff.data(), 8, hipMemcpyHostToDevice, stream));
+        MSVS_HIP(hipMemcpyAsync(d_one_off.p, one_off.data(), 16, hipMemcpyHostToDevice, stream));
+        ix.c_hoff.alloc(G + 1);
+        ix.c_list_off.alloc(G + 1);
+        MSVS_HIP(hipMemcpyAsync(ix.c_hoff.p, c_hoff.data(), (G + 1) * 4, hipMemcpyHostToDevice, stream));
+        MSVS_HIP(hipMemcpyAsync(ix.c_list_off.p, c_off.data(), (G + 1) * 8, hipMemcpyHostToDevice, stream));
+        const size_t cpieces = G * (size_t)ix.h_nks * 64;
+        ix.c_shadow.alloc(cpieces);
+        hipLaunchKernelGGL(h16_build_kernel, dim3((unsigned)ceil_div(cpieces, (size_t)256)), dim3(256), 0, stream, ix.centroids.p, ix.ld,
+                           d_one_off.p, d_cblk.p, d_one_hoff.p, ix.h_nks, ix.h_scale, ix.c_shadow.p, (size_t)0, cpieces);
+        MSVS_HIP(hipGetLastError());
+        MSVS_HIP(hipStreamSynchronize(stream));
+        ix.c_shadow_ready = true;
+    }
 }
 
 /// Row norms for the approximate pass and its error bound; called once the final storage is in place.
@@ -1243,7 +1287,8 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe, ix.ld)
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
         + nq * nprobe * 4
-        + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768;
+        + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768
+        + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 8192 : 0);
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
             + nq * (size_t)p.kc * 8 + nq * 24 + 8192
@@ -1282,6 +1327,7 @@ struct TablePass
     float * out_dis;
     int cosine;
     const char * prof_name;
+    bool h16 = false; // the table is the centroid table and its fp16 shadow is usable: scan through h16_sample_kernel
 };
 
 static uint32_t table_fallback_rpb(size_t n) { return (uint32_t)round_up(std::max<size_t>(256, ceil_div(n, (size_t)256)), 16); }
@@ -1326,6 +1372,65 @@ static void run_fallback_rounds(int metric, ScanParams c, IvfMergeParams fm, siz
     }
 }
 
+static void set_error_model_h16(RerankParams & rp, size_t dim);
+static uint32_t device_cu_count();
+
+/// Second half of a table pass, whatever produced the candidates: canonical re-rank + certificate, then the canonical scan
+/// of the table for the queries on the fail list.
+static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, const ScanParams & a, size_t nq, const float * qnorm,
+                            const uint64_t * cand, const uint64_t * bound, uint32_t kc, uint32_t * failq, uint32_t * nfail,
+                            uint64_t * partial1, size_t fb_cap, uint32_t rpb1, uint32_t seg_max1, const int32_t * probes0,
+                            const int64_t * list_off, bool h16, hipStream_t stream)
+{
+    RerankParams rp{};
+    rp.Y = a.Y;
+    rp.ids = t.ids;
+    rp.Q = a.Q;
+    rp.qnorm = qnorm;
+    rp.cand = cand;
+    rp.bound = bound;
+    rp.kc = kc;
+    rp.k = t.k;
+    rp.ld4 = a.ld4;
+    rp.out_probes = t.out_probes;
+    rp.out_ids = t.out_ids;
+    rp.out_dis = t.out_dis;
+    rp.cosine = t.cosine;
+    if (h16)
+        set_error_model_h16(rp, ix.dim);
+    else
+        set_error_model(rp, ix.dim);
+    rp.xmax = t.norm_max;
+    rp.failq = failq;
+    rp.nfail = nfail;
+    rp.stat_fail = t.out_probes ? nullptr : prefilter_fail_counter(); // msvs_prefilter_stats counts result passes
+    launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
+    // queries without a certificate: canonical scan of the table
+    ScanParams c = a;
+    c.k = t.k;
+    c.partial = partial1;
+    c.rows_per_block = rpb1;
+    c.seg_max = seg_max1;
+    c.qmap = failq;
+    c.qcount = nfail;
+    const uint32_t slots = (uint32_t)std::min<size_t>(nq, 8);
+    IvfMergeParams fm{};
+    fm.partial = partial1;
+    fm.probes = probes0;
+    fm.list_off = list_off;
+    fm.nprobe = 1;
+    fm.seg_max = seg_max1;
+    fm.rows_per_block = rpb1;
+    fm.k = t.k;
+    fm.out_probes = t.out_probes;
+    fm.out_ids = t.out_ids;
+    fm.out_dis = t.out_dis;
+    fm.cosine = t.cosine;
+    fm.qmap = failq;
+    fm.qcount = nfail;
+    run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, slots, stream);
+}
+
 static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq,
                                  const TablePass & t, hipStream_t stream)
 {
@@ -1359,8 +1464,12 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     // plan 0: the whole table (also what the fallback scans)
     launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, tq, pairs, probes0, list_off, small, small + 3, stream);
     launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
-    float4 * qsplit = scr.take<float4>(nq * (size_t)ceil_div((size_t)ld / 4, (size_t)8) * 8);
-    launch_split_queries(dq, (uint32_t)nq, ld / 4, qsplit, stream);
+    float4 * qsplit = nullptr;
+    if (!t.h16)
+    {
+        qsplit = scr.take<float4>(nq * (size_t)ceil_div((size_t)ld / 4, (size_t)8) * 8);
+        launch_split_queries(dq, (uint32_t)nq, ld / 4, qsplit, stream);
+    }
     // A table too long for "16 keys per slice" to fit the candidate buffers is searched in two phases: a sample first,
     // whose m-th best candidate becomes the query's cut for the rest (sample_cut_kernel)
     const bool two_phase = (size_t)nslices * BG_SLICE_K > cap;
@@ -1403,6 +1512,50 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     a.Qsplit = qsplit;
     const size_t tiles = ceil_div(nq, (size_t)tq);
     ProfileScope prof(t.prof_name, stream);
+    if (t.h16)
+    {
+        // every approximate distance of the batch through the centroid shadow, then the kc best per query
+        const uint32_t G = (uint32_t)ceil_div(t.n, (size_t)H_ROWS), n_pad = G * H_ROWS;
+        uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8);
+        float2 * qinfo = scr.take<float2>(nq);
+        float * qn16 = scr.take<float>(nq);
+        uint32_t * sample = scr.take<uint32_t>(nq * (size_t)n_pad);
+        uint32_t * cpairs = scr.take<uint32_t>(nq * (size_t)G);
+        uint32_t * cpoff = scr.take<uint32_t>(G + 1);
+        uint32_t * cwoff = scr.take<uint32_t>(G + 1);
+        MSVS_HIP(hipMemcpyAsync(qn16, qnorm, nq * 4, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq, (uint32_t)nq, ld,
+                           ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qn16);
+        MSVS_HIP(hipMemsetAsync(sample, 0xFF, nq * (size_t)n_pad * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(coarse_plan_kernel, dim3((unsigned)ceil_div(std::max<size_t>(nq * (size_t)G, G + 1), (size_t)256)), dim3(256), 0,
+                           stream, (uint32_t)nq, G, cpairs, cpoff, cwoff);
+        H16Params h{};
+        h.H = ix.c_shadow.p;
+        h.hoff = ix.c_hoff.p;
+        h.nks = ix.h_nks;
+        h.nch = ix.h_nch;
+        h.Qh = qh;
+        h.qinfo = qinfo;
+        h.xnorm = t.norms;
+        h.list_off = ix.c_list_off.p;
+        h.pairs = cpairs;
+        h.pair_off = cpoff;
+        h.work_off = cwoff;
+        h.nlist = G;
+        h.nprobe = G;
+        h.sample_out = sample;
+        const uint32_t sgrid = device_cu_count() * 8;
+        if (scan_metric(m) == M_IP)
+            hipLaunchKernelGGL((h16_sample_kernel<M_IP>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
+        else
+            hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
+        hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
+                           n_pad, kc, cand, bound);
+        MSVS_HIP(hipGetLastError());
+        table_pass_tail(ix, m, t, a, nq, qn16, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true,
+                        stream);
+        return;
+    }
     if (two_phase)
     {
         ScanParams sa = a;
@@ -1428,50 +1581,8 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
                              (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 4096 / nqg), a, stream,
                              "table_scan", false);
     launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
-    RerankParams rp{};
-    rp.Y = a.Y;
-    rp.ids = t.ids;
-    rp.Q = a.Q;
-    rp.qnorm = qnorm;
-    rp.cand = cand;
-    rp.bound = bound;
-    rp.kc = kc;
-    rp.k = t.k;
-    rp.ld4 = ld / 4;
-    rp.out_probes = t.out_probes;
-    rp.out_ids = t.out_ids;
-    rp.out_dis = t.out_dis;
-    rp.cosine = t.cosine;
-    set_error_model(rp, ix.dim);
-    rp.xmax = t.norm_max;
-    rp.failq = failq;
-    rp.nfail = nfail;
-    rp.stat_fail = t.out_probes ? nullptr : prefilter_fail_counter(); // msvs_prefilter_stats counts result passes
-    launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
-    // queries without a certificate: canonical scan of the table
-    ScanParams c = a;
-    c.k = t.k;
-    c.partial = partial1;
-    c.rows_per_block = rpb1;
-    c.seg_max = seg_max1;
-    c.qmap = failq;
-    c.qcount = nfail;
-    const uint32_t slots = (uint32_t)std::min<size_t>(nq, 8);
-    IvfMergeParams fm{};
-    fm.partial = partial1;
-    fm.probes = probes0;
-    fm.list_off = list_off;
-    fm.nprobe = 1;
-    fm.seg_max = seg_max1;
-    fm.rows_per_block = rpb1;
-    fm.k = t.k;
-    fm.out_probes = t.out_probes;
-    fm.out_ids = t.out_ids;
-    fm.out_dis = t.out_dis;
-    fm.cosine = t.cosine;
-    fm.qmap = failq;
-    fm.qcount = nfail;
-    run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, slots, stream);
+    table_pass_tail(ix, m, t, a, nq, qnorm, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, false,
+                    stream);
 }
 
 /// Error model of the fp16 shadow pass (h16_scan_kernels.hpp), u = 2^-11:
@@ -1807,6 +1918,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     else if (table_pass_eligible(ix.nlist, ix.cnorm.p, ix.cnorm_max, nq, (uint32_t)nprobe, options().coarse_mfma))
     {
         TablePass t{};
+        // the centroid shadow: every approximate distance of the batch in one LDS-free MFMA launch (h16_scan_kernels.hpp)
+        t.h16 = ix.c_shadow_ready && options().coarse_h16 != 0 && nq * round_up(ix.nlist, (size_t)H_ROWS) * 4 <= ((size_t)128 << 20);
         t.rows = ix.centroids.p;
         t.norms = ix.cnorm.p;
         t.norm_max = ix.cnorm_max;

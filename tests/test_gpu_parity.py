@@ -349,12 +349,15 @@ def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, 
     assert capi.prefilter_stats()[0] == q2
 
 
+@pytest.mark.parametrize("h16", ["1", "0"])
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
-def test_coarse_quantiser_through_the_candidate_pass(metric, opt):
-    """nlist >= 256 and >= 512 queries: the top-nprobe centroids come from the matrix-core pass + canonical re-rank;
-    the probe SETS must equal the exact scan's, hence so must the final answer (with and without certificates)."""
+def test_coarse_quantiser_through_the_candidate_pass(metric, h16, opt):
+    """nlist >= 256 and >= 512 queries: the top-nprobe centroids come from the matrix-core pass (over the centroid
+    shadow, h16 = 1, or the split-bf16 table pass) + canonical re-rank; the probe SETS must equal the exact scan's,
+    hence so must the final answer (with and without certificates).  nlist = 330: the last 32-centroid block is partial."""
+    opt("coarse_h16", h16)
     rng = np.random.default_rng(2025)
-    n, d, nlist, nq, nprobe, k = 40000, 64, 320, 600, 12, 10
+    n, d, nlist, nq, nprobe, k = 40000, 64, 330, 600, 12, 10
     centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
     x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
     q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
