@@ -138,6 +138,9 @@ struct Options
     double ivf_pass = 1;      // candidate pass of the list scan: 0 never, 1 from ~2 queries per list on, 2 whenever eligible
     double ivf_h16 = 1;       // 1: over the fp16 shadow (h16_scan_kernels.hpp); 0: split-bf16 over the f32 rows
     double coarse_h16 = 1;    // coarse quantiser of batches through the centroid shadow (0: the split-bf16 table pass)
+    double wave_select = 1;   // candidate selection by the bitwise wave search (0: WaveTopK insertion kernels)
+    double plan_lds = 1;      // plan histogram / scatter aggregated in LDS per 2048 pairs (0: one global atomic per pair)
+    double fb_segs = 0;       // segments per list of the canonical fallback scan (0: automatic 4 / 16)
     double coarse_mfma = 1;   // same switch for the coarse quantiser ...
     double flat_mfma = 1;     // ... and for FLAT batches
     double ivf_nqg = 1;       // split-bf16 pass: 128- (1) or 256-query (2) tiles

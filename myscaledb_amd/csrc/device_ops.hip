@@ -294,10 +294,20 @@ void launch_ivf_plan(const IvfPlanParams & p, hipStream_t stream)
     if (p.n_pairs == 0)
         return;
     ProfileScope prof("ivf_plan", stream);
-    unsigned g = (unsigned)ceil_div(p.n_pairs, 256);
-    hipLaunchKernelGGL(ivf_hist_kernel, dim3(g), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
-    hipLaunchKernelGGL(ivf_scatter_kernel, dim3(g), dim3(256), 0, stream, p);
+    if (p.nlist <= PLAN_LDS_LISTS && options().plan_lds != 0)
+    {
+        unsigned g = (unsigned)ceil_div(p.n_pairs, PLAN_CHUNK);
+        hipLaunchKernelGGL(ivf_hist_lds_kernel, dim3(g), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(ivf_scatter_lds_kernel, dim3(g), dim3(256), 0, stream, p);
+    }
+    else
+    {
+        unsigned g = (unsigned)ceil_div(p.n_pairs, 256);
+        hipLaunchKernelGGL(ivf_hist_kernel, dim3(g), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(ivf_scatter_kernel, dim3(g), dim3(256), 0, stream, p);
+    }
     MSVS_HIP(hipGetLastError());
 }
 
@@ -463,8 +473,11 @@ void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint3
     if (nq == 0)
         return;
     ProfileScope prof("merge", stream);
-    hipLaunchKernelGGL(cand_select_kernel, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap,
-                       nq, kc, out, bound);
+    if (cap <= CAND_SELECT_WAVE_CAP && options().wave_select != 0)
+        hipLaunchKernelGGL(cand_select_wave_kernel, dim3((nq + 3) / 4), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out,
+                           bound);
+    else
+        hipLaunchKernelGGL(cand_select_kernel, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
     MSVS_HIP(hipGetLastError());
 }
 
@@ -556,7 +569,8 @@ struct OptionField
 const OptionField g_option_fields[] = {
     {"ivf_pass", &Options::ivf_pass},       {"ivf_mfma", &Options::ivf_pass} /* round-1 name */,
     {"ivf_h16", &Options::ivf_h16},         {"coarse_mfma", &Options::coarse_mfma},
-    {"coarse_h16", &Options::coarse_h16},
+    {"coarse_h16", &Options::coarse_h16},   {"wave_select", &Options::wave_select},
+    {"plan_lds", &Options::plan_lds},       {"fb_segs", &Options::fb_segs},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},
     {"ivf_t", &Options::ivf_t},             {"ivf_xcd", &Options::ivf_xcd},

@@ -695,15 +695,46 @@ static __global__ void coarse_plan_kernel(uint32_t nq, uint32_t G, uint32_t * pa
     }
 }
 
-/// One wavefront per query: the kc (<= 64) smallest of its n_pad sample words -> cand[q][kc] ascending keys
-/// (word << 32 | centroid); bound[q] = KEY_NONE (the certificate then uses the kc-th candidate as the cut).
+/// One wavefront per query: the kc (<= 64) smallest of its n_pad sample words -> cand[q][kc] keys
+/// (word << 32 | centroid), the largest value last; bound[q] = KEY_NONE (the certificate then uses that last
+/// candidate as the cut).  Up to 2048 centroids the words sit in registers and wave_select_words picks them
+/// (52 -> ~8 us for 4096 queries x 1024 centroids against inserting into a sorted wave list); beyond, the insertion loop.
+template <int NW>
+__device__ inline void coarse_select_wave(const uint32_t * src, uint32_t n_pad, uint32_t kc, uint64_t * out, uint32_t lane)
+{
+    uint32_t hi[NW], lo[NW];
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const uint32_t i = u * WAVE + lane;
+        hi[u] = i < n_pad ? src[i] : 0xFFFFFFFFu;
+        lo[u] = hi[u] == 0xFFFFFFFFu ? 0xFFFFFFFFu : i;
+    }
+    wave_select_words<NW>(hi, lo, kc, out, lane);
+}
+
 static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint32_t * sample, uint32_t nq, uint32_t n_pad, uint32_t kc,
-                                                                     uint64_t * cand, uint64_t * bound)
+                                                                     uint64_t * cand, uint64_t * bound, int wave_select)
 {
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq)
         return;
     const uint32_t * src = sample + (size_t)q * n_pad;
+    uint64_t * dst = cand + (size_t)q * kc;
+    if (lane == 0)
+        bound[q] = KEY_NONE;
+    if (wave_select && n_pad <= 32 * WAVE)
+    {
+        if (n_pad <= 4 * WAVE)
+            coarse_select_wave<4>(src, n_pad, kc, dst, lane);
+        else if (n_pad <= 8 * WAVE)
+            coarse_select_wave<8>(src, n_pad, kc, dst, lane);
+        else if (n_pad <= 16 * WAVE)
+            coarse_select_wave<16>(src, n_pad, kc, dst, lane);
+        else
+            coarse_select_wave<32>(src, n_pad, kc, dst, lane);
+        return;
+    }
     WaveTopK<1> top;
     top.init();
     for (uint32_t base = 0; base < n_pad; base += 4 * WAVE)
@@ -720,9 +751,7 @@ static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint3
         for (int u = 0; u < 4; u++)
             top.offer(key[u], kc, lane);
     }
-    top.store(cand + (size_t)q * kc, kc, lane);
-    if (lane == 0)
-        bound[q] = KEY_NONE;
+    top.store(dst, kc, lane);
 }
 
 }

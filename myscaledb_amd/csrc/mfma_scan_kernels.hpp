@@ -597,6 +597,94 @@ static __global__ void sample_cut_kernel(const uint64_t * cand, uint32_t kc, uin
         atomicMin(&qthr[q], (uint32_t)(key >> 32));
 }
 
+/// Wave-wide selection without insertion: the kc (<= 64) smallest of the wavefront's keys (NW per lane as
+/// (hi, lo) words; hi = 0xFFFFFFFF, lo = 0xFFFFFFFF = absent) by a bitwise search for H = the kc-th smallest HIGH word
+/// (32 rounds of NW compares + scalar popcounts: no cross-lane traffic, no serial inserts), then two ballot
+/// compactions: out[0..c) = the keys with hi < H (c < kc), out[c..kc) = keys with hi == H in (register, lane) order.
+/// out[kc-1] always holds a key whose high word is H = the largest approximate value among the candidates, which is all
+/// the certificate reads from it (ivf_rerank_kernel: `last`); the candidates are NOT sorted (the re-rank sorts the
+/// canonical keys).  Which of several rows with the same approximate value H are taken is arbitrary: the untaken
+/// ones are covered by the certificate's strict inequality, like any other row at the cut.
+template <int NW>
+__device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_t (&lo)[NW], uint32_t kc, uint64_t * out, uint32_t lane)
+{
+    uint32_t H = 0;
+#pragma unroll 1
+    for (int b = 31; b >= 0; b--)
+    {
+        const uint32_t c = H | (1u << b);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < NW; u++)
+            cnt += (uint32_t)__popcll(__ballot(hi[u] < c));
+        if (cnt < kc) // fewer than kc keys below c: the kc-th smallest is >= c
+            H = c;
+    }
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const bool take = hi[u] < H;
+        const uint64_t mask = __ballot(take);
+        if (take)
+            out[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))]
+                = (uint64_t)hi[u] << 32 | lo[u];
+        run += (uint32_t)__popcll(mask);
+    }
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const bool tie = hi[u] == H && run < kc;
+        const uint64_t mask = __ballot(tie);
+        const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (tie && pos < kc)
+            out[pos] = (uint64_t)hi[u] << 32 | lo[u];
+        run += (uint32_t)__popcll(mask);
+    }
+}
+
+template <int NW>
+__device__ inline void cand_select_wave(const uint64_t * src, uint32_t n, uint32_t kc, uint64_t * out, uint32_t lane)
+{
+    uint32_t hi[NW], lo[NW];
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const uint32_t i = u * WAVE + lane;
+        const uint64_t key = i < n ? src[i] : KEY_NONE;
+        hi[u] = (uint32_t)(key >> 32);
+        lo[u] = (uint32_t)key;
+    }
+    wave_select_words<NW>(hi, lo, kc, out, lane);
+}
+
+constexpr uint32_t CAND_SELECT_WAVE_CAP = 2048; // 32 keys per lane
+
+/// cand_select_kernel for buffers of at most CAND_SELECT_WAVE_CAP keys: ONE wavefront per query holds the whole
+/// buffer in registers (a query of the bench keeps ~250 keys below its cut: 4 per lane) and selects by
+/// wave_select_words.  out[q][kc]: the candidates, unsorted, KEY_NONE padded, the largest approximate value last.
+static __global__ __launch_bounds__(BLOCK) void cand_select_wave_kernel(const uint64_t * buf, const uint32_t * qcnt,
+                                                                         const uint32_t * qthr, uint32_t cap, uint32_t nq,
+                                                                         uint32_t kc, uint64_t * out, uint64_t * bound)
+{
+    const uint32_t q = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq)
+        return;
+    const uint32_t n = qcnt[q] < cap ? qcnt[q] : cap;
+    const uint64_t * src = buf + (size_t)q * cap;
+    uint64_t * dst = out + (size_t)q * kc;
+    if (n <= 4 * WAVE)
+        cand_select_wave<4>(src, n, kc, dst, lane);
+    else if (n <= 8 * WAVE)
+        cand_select_wave<8>(src, n, kc, dst, lane);
+    else if (n <= 16 * WAVE)
+        cand_select_wave<16>(src, n, kc, dst, lane);
+    else
+        cand_select_wave<32>(src, n, kc, dst, lane);
+    if (lane == 0) // an overflowed buffer dropped unknown keys: bound 0 = nothing can be certified
+        bound[q] = qcnt[q] > cap ? 0 : (qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32);
+}
+
 /// The kc (<= 64) best of the keys a query's slices appended (unsorted runs), ascending, one block per query (the
 /// 4 wavefronts take interleaved 256-key chunks, then a rank merge): out[q][kc] (KEY_NONE padded);
 /// bound[q] = the smallest key any slice may have cut (from qthr; KEY_NONE if none).
@@ -639,7 +727,7 @@ struct RerankParams
     const uint32_t * ids;  // id of stored row r
     const float4 * Q;      // queries
     const float * qnorm;   // |q|^2 (approximate)
-    const uint64_t * cand; // [nq][kc] ascending approximate keys, low word = row position
+    const uint64_t * cand; // [nq][kc] approximate keys (any order, the largest value LAST), low word = row position
     const uint64_t * bound; // nullable [nq]: smallest key any earlier stage may have dropped (KEY_NONE = none dropped)
     uint32_t kc, k, ld4;
     int64_t * out_ids; // [nq][k]

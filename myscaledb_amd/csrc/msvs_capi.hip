@@ -1224,7 +1224,12 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
             // lists are nq * nprobe * 4 * k keys whatever the longest list is (segments of 256 rows made that 84 x
             // larger on a skewed index, for a buffer that is reserved on every search; one block per list made a single
             // failing query cost 0.8 ms = 10 % of the bench step on average)
-            p.rpb1 = (uint32_t)round_up(std::max<size_t>(ceil_div(ix.max_list_len, (size_t)4), 16), 16);
+            // ... and SIXTEEN when their partial lists stay small (nprobe * 16 * k keys <= the merge's LDS fast path):
+            // one failing query of the bench step then costs ~25 us instead of ~100 (it is the tail of the whole step)
+            size_t segs = nprobe * 16 * (size_t)k <= 6144 ? 16 : 4;
+            if (options().fb_segs >= 1)
+                segs = (size_t)options().fb_segs;
+            p.rpb1 = (uint32_t)round_up(std::max<size_t>(ceil_div(ix.max_list_len, segs), 16), 16);
             p.seg_max1 = (uint32_t)std::max<size_t>(1, ceil_div(std::max<size_t>(ix.max_list_len, 1), (size_t)p.rpb1));
             p.fb_slots = (uint32_t)std::min<size_t>(nq, 8);
             return p;
@@ -1550,7 +1555,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         else
             hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
         hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
-                           n_pad, kc, cand, bound);
+                           n_pad, kc, cand, bound, options().wave_select != 0 ? 1 : 0);
         MSVS_HIP(hipGetLastError());
         table_pass_tail(ix, m, t, a, nq, qn16, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true,
                         stream);

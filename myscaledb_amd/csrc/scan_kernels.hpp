@@ -658,6 +658,70 @@ static __global__ void ivf_scatter_kernel(const IvfPlanParams p)
     }
 }
 
+// The same two passes with the per-pair atomics moved into LDS: a block takes PLAN_CHUNK consecutive pairs, counts them
+// per list in LDS, and touches global memory once per (block, non-empty list).  On the bench step (131 072 pairs over
+// 1024 lists, hot lists holding > 1000 pairs) the one-atomic-per-pair kernels spend 36 us each queueing on the hot
+// addresses; the scatter also hands every block ONE contiguous range per list (base from a single atomicAdd of the
+// block's count, rank inside the block from the LDS atomic).
+constexpr uint32_t PLAN_LDS_LISTS = 8192; // 32 KB of LDS counters
+constexpr uint32_t PLAN_CHUNK = 2048;     // pairs per block (8 per thread)
+
+static __device__ __forceinline__ bool plan_pair_list(const IvfPlanParams & p, uint32_t i, uint32_t end, int32_t & l)
+{
+    l = i < end ? p.probes[i] : -1;
+    return l >= 0 && (!p.whole_off || p.whole_off[l + 1] > p.whole_off[l]);
+}
+
+static __global__ __launch_bounds__(256) void ivf_hist_lds_kernel(const IvfPlanParams p)
+{
+    __shared__ uint32_t h[PLAN_LDS_LISTS];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t l = tid; l < p.nlist; l += 256)
+        h[l] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * PLAN_CHUNK, end = min(base + PLAN_CHUNK, p.n_pairs);
+#pragma unroll
+    for (uint32_t u = 0; u < PLAN_CHUNK / 256; u++)
+    {
+        int32_t l;
+        if (plan_pair_list(p, base + u * 256 + tid, end, l))
+            atomicAdd(&h[l], 1u);
+    }
+    __syncthreads();
+    for (uint32_t l = tid; l < p.nlist; l += 256)
+        if (h[l])
+            atomicAdd(&p.cnt[l], h[l]);
+}
+
+static __global__ __launch_bounds__(256) void ivf_scatter_lds_kernel(const IvfPlanParams p)
+{
+    __shared__ uint32_t h[PLAN_LDS_LISTS];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t l = tid; l < p.nlist; l += 256)
+        h[l] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * PLAN_CHUNK, end = min(base + PLAN_CHUNK, p.n_pairs);
+    int32_t list[PLAN_CHUNK / 256];
+    uint32_t rank[PLAN_CHUNK / 256];
+#pragma unroll
+    for (uint32_t u = 0; u < PLAN_CHUNK / 256; u++)
+    {
+        int32_t l;
+        const bool ok = plan_pair_list(p, base + u * 256 + tid, end, l);
+        list[u] = ok ? l : -1;
+        rank[u] = ok ? atomicAdd(&h[l], 1u) : 0;
+    }
+    __syncthreads();
+    for (uint32_t l = tid; l < p.nlist; l += 256) // count -> start of this block's range inside list l
+        if (h[l])
+            h[l] = p.pair_off[l] + atomicAdd(&p.fill[l], h[l]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < PLAN_CHUNK / 256; u++)
+        if (list[u] >= 0)
+            p.pairs[h[list[u]] + rank[u]] = base + u * 256 + tid;
+}
+
 /// grid: any size; block b handles work items b, b + gridDim.x, ...
 template <int METRIC, int T, int R>
 __global__ __launch_bounds__(BLOCK) void ivf_batched_scan_kernel(const ScanParams a)

@@ -384,6 +384,39 @@ def test_coarse_quantiser_through_the_candidate_pass(metric, h16, opt):
     same(ids, dis, oi, od)
 
 
+@pytest.mark.parametrize("knobs", [{}, {"wave_select": "0"}, {"plan_lds": "0"}, {"fb_segs": "4"}, {"fb_segs": "16"},
+                                   {"cand_cap": "3000"}])
+def test_selection_plan_and_fallback_variants_agree_with_the_oracle(knobs, opt):
+    """The bitwise wave selection (candidate buffers and centroid words held in registers), the LDS-aggregated plan and
+    the 16-segment fallback against their insertion / per-pair-atomic / 4-segment forms: the same exact answer.  Massive
+    duplicates (every approximate value shared by several rows) exercise the tie branch of the selection; cand_cap 3000
+    is above the register form's capacity (the insertion kernel serves it)."""
+    for name, v in knobs.items():
+        opt(name, v)
+    rng = np.random.default_rng(515)
+    n, d, nlist, nq, nprobe, k = 50000, 96, 300, 700, 16, 10
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    x[n // 2:] = x[: n - n // 2]  # every row twice: equal approximate AND canonical distances, ids break the ties
+    q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    for metric in (capi.METRIC_L2, capi.METRIC_IP):
+        ix = build_ivf(x, metric, nlist)
+        oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+        opt("coarse_mfma", "2")
+        q0, f0 = capi.prefilter_stats()
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+        assert capi.prefilter_stats()[0] > q0  # the candidate pass ran
+        opt("ivf_eps_scale", "1e12")  # every certificate fails: the fallback in its segments
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+        opt("ivf_eps_scale", None)
+        # k > 12: 64 candidates per query
+        oi, od, _ = oracle_on_exported(ix, q[:520], nprobe, 40, metric)
+        ids, dis = ix.search(q[:520], 40, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+
+
 def test_matrix_core_pass_with_massive_ties_and_unusable_norms():
     rng = np.random.default_rng(77)
     n, d, nlist, nq = 6000, 48, 4, 128
