@@ -228,6 +228,8 @@ MSVS_API int msvs_profile_reset(void);
  * were re-run through the canonical scan (`fallbacks`).  Results are identical either way; this is a speed metric.
  * Synchronises the device. */
 MSVS_API int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks);
+/* ... and of the coarse quantiser's candidate passes (whose output is the probe lists). */
+MSVS_API int msvs_coarse_stats(uint64_t * queries, uint64_t * fallbacks);
 /* Scratch memory is kept per (host thread, stream) and reused call after call; it shrinks by itself when a thread's
  * requests stay small for a window of 64 calls.  msvs_release_scratch frees the calling thread's arenas now (device synchronised). */
 MSVS_API int msvs_release_scratch(size_t * freed_bytes);

@@ -571,6 +571,7 @@ const OptionField g_option_fields[] = {
     {"ivf_h16", &Options::ivf_h16},         {"coarse_mfma", &Options::coarse_mfma},
     {"coarse_h16", &Options::coarse_h16},   {"wave_select", &Options::wave_select},
     {"plan_lds", &Options::plan_lds},       {"fb_segs", &Options::fb_segs},
+    {"h16_kc", &Options::h16_kc},           {"coarse_kc", &Options::coarse_kc},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},
     {"ivf_t", &Options::ivf_t},             {"ivf_xcd", &Options::ivf_xcd},

@@ -602,6 +602,80 @@ __global__ __launch_bounds__(BLOCK) void h16_sample_kernel(const H16Params a)
 /// (and pass the filter) and R = rows of the probed lists, clamped to [4, 64] -- lists of very different lengths
 /// (a sample block is 32 rows of ANY list) would otherwise let a query that probes the long lists overflow its buffer.
 /// Fewer than m sample rows: no cut (0xFFFFFFFF), everything is appended.
+/// The same for nprobe <= 64 (NW = nprobe / 2 words per lane): the sample words are read ONCE into registers, the cut is
+/// wave_kth_word of them, the rows below it are appended from the registers (27 -> ~8 us on the bench step).
+template <int NW>
+__device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t * qprobes, const int64_t * list_off, uint32_t nprobe,
+                                           uint32_t target, uint32_t * qthr, uint32_t * qcnt, uint64_t * dst, uint32_t cap,
+                                           uint32_t lane)
+{
+    const uint32_t n = nprobe * H_ROWS;
+    uint32_t word[NW];
+    int64_t lbeg[NW]; // start of the list word u belongs to (lane-dependent: i / 32)
+    uint64_t rows = 0;
+    uint32_t have = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const uint32_t i = u * WAVE + lane;
+        const int32_t l = i < n ? qprobes[i / H_ROWS] : -1;
+        word[u] = l >= 0 ? src[i] : 0xFFFFFFFFu;
+        lbeg[u] = l >= 0 ? list_off[l] : 0;
+        if (l >= 0 && (i & (H_ROWS - 1)) == 0)
+            rows += (uint64_t)(list_off[l + 1] - lbeg[u]);
+        have += word[u] != 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        rows += (uint64_t)__shfl_xor((int)(uint32_t)rows, o) | ((uint64_t)__shfl_xor((int)(uint32_t)(rows >> 32), o) << 32);
+        have += (uint32_t)__shfl_xor((int)have, o);
+    }
+    uint32_t m = rows ? (uint32_t)(((uint64_t)target * have + rows - 1) / rows) : 4u;
+    m = m < 4 ? 4 : (m > 64 ? 64 : m);
+    const uint32_t cut = target == 0 ? 0xFFFFFFFFu : wave_kth_word<NW>(word, m);
+    uint32_t count = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const bool take = word[u] < cut;
+        const uint64_t mask = __ballot(take);
+        if (take)
+        {
+            const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (pos < cap)
+                dst[pos] = (uint64_t)word[u] << 32 | (uint32_t)(lbeg[u] + (lane & (H_ROWS - 1)));
+        }
+        count += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0)
+    {
+        *qthr = cut;
+        *qcnt = count;
+    }
+}
+
+static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_wave_kernel(const uint32_t * sample, const int32_t * probes,
+                                                                            const int64_t * list_off, uint32_t nq, uint32_t nprobe,
+                                                                            uint32_t target, uint32_t * qthr, uint32_t * qcnt,
+                                                                            uint64_t * partial, uint32_t cap)
+{
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq)
+        return;
+    const uint32_t * src = sample + (size_t)q * nprobe * H_ROWS;
+    const int32_t * qp = probes + (size_t)q * nprobe;
+    uint64_t * dst = partial + (size_t)q * cap;
+    if (nprobe <= 8)
+        h16_sample_thr_wave<4>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane);
+    else if (nprobe <= 16)
+        h16_sample_thr_wave<8>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane);
+    else if (nprobe <= 32)
+        h16_sample_thr_wave<16>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane);
+    else
+        h16_sample_thr_wave<32>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane);
+}
+
 static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint32_t * sample, const int32_t * probes,
                                                                        const int64_t * list_off, uint32_t nq,
                                                                        uint32_t nprobe, uint32_t target, uint32_t * qthr,
@@ -678,6 +752,110 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint
 // of one block each, every query "probing" all of them, so the kernel writes ALL approximate centroid distances of the
 // batch (nq x nlist words) -- 6 GFLOP for 4096 x 1024 x 768, a few microseconds of MFMA, against 83 us for the split-bf16
 // table pass with its per-slice selection.  coarse_select_kernel then keeps the kc best per query for the canonical re-rank.
+
+/// The centroid table against the whole batch, two 32-centroid blocks x two 32-query blocks per wavefront (4 accumulators:
+/// every operand fragment loaded feeds two MFMAs, half the L2 traffic of one-tile items; h16_sample_kernel on the trivial
+/// plan took 44 us for 4096 x 1024 x 768, its operands being 96 KB per 32 x 32 tile).  No plan, no LDS: block g of the
+/// shadow = centroids [32 g, 32 g + 32), query block b = queries [32 b, 32 b + 32).  Writes EVERY word of
+/// sample_out[q][n_pad = 32 G] (0xFFFFFFFF for the padding rows of the last block): no memset.
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK, 1) void coarse_h16_kernel(const uint4 * H, uint32_t nch, const uint4 * Qh, const float2 * qinfo,
+                                                               const float * xnorm, uint32_t n_rows, uint32_t nq,
+                                                               uint32_t * sample_out)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
+    const uint32_t G = (n_rows + H_ROWS - 1) / H_ROWS, n_pad = G * H_ROWS, QB = (nq + 31) / 32;
+    const uint32_t G2 = (G + 1) / 2, QB2 = (QB + 1) / 2, total = G2 * QB2;
+    for (uint32_t w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4)
+    {
+        // consecutive wavefronts: the same two query blocks against successive centroid blocks
+        const uint32_t g2 = w % G2, q2 = w / G2;
+        const uint32_t gb[2] = {2 * g2, 2 * g2 + 1 < G ? 2 * g2 + 1 : 2 * g2};
+        const uint32_t qb[2] = {2 * q2, 2 * q2 + 1 < QB ? 2 * q2 + 1 : 2 * q2};
+        const u32x4 * ap[2];
+        const u32x4 * bp[2];
+        float2 qi[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+        {
+            const uint32_t q = qb[t] * 32 + r32 < nq ? qb[t] * 32 + r32 : nq - 1;
+            qi[t] = qinfo[q];
+            ap[t] = reinterpret_cast<const u32x4 *>(Qh) + (size_t)q * nch * 8 + h;
+            bp[t] = reinterpret_cast<const u32x4 *>(H) + (size_t)gb[t] * nch * 256 + lane;
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc[t][s][r] = 0.f;
+        u32x4 ar[2][2][4], br[2][2][4]; // [buffer][query block | centroid block][k step]
+        auto load = [&](const int b, const uint32_t c) {
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    ar[b][t][j] = ap[t][(size_t)c * 8 + 2 * j];
+                    br[b][t][j] = bp[t][(size_t)c * 256 + j * 64];
+                }
+        };
+        auto mul = [&](const int b) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int s = 0; s < 2; s++)
+                        acc[t][s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ar[b][t][j]),
+                                                                           __builtin_bit_cast(half8, br[b][s][j]), acc[t][s], 0, 0, 0);
+        };
+        load(0, 0);
+        const uint32_t last = nch - 1;
+        for (uint32_t c = 0; c < nch; c += 2)
+        {
+            load(1, c + 1 < last ? c + 1 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 >= nch)
+                break;
+            load(0, c + 2 < last ? c + 2 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+        {
+            if (s == 1 && gb[1] == gb[0])
+                break;
+            const uint32_t row = gb[s] * H_ROWS + r32;
+            const bool ok = row < n_rows;
+            const float xn = ok && METRIC == M_L2 ? xnorm[row] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+            {
+                if (t == 1 && qb[1] == qb[0])
+                    break;
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                {
+                    // accumulator register i = query (i & 3) + 8 (i >> 2) + 4 h of the block, row r32 (as in h16_sample_kernel)
+                    const int qidx = (i & 3) + 8 * (i >> 2) + 4 * (int)h;
+                    const float m2 = __shfl(qi[t].x, qidx), qn = __shfl(qi[t].y, qidx);
+                    const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2, acc[t][s][i], xn), qn) : __fmul_rn(m2, acc[t][s][i]);
+                    const uint64_t key = ok ? make_key<METRIC>(v, row) : KEY_NONE;
+                    const uint32_t q = qb[t] * 32 + (uint32_t)qidx;
+                    if (q < nq)
+                        sample_out[(size_t)q * n_pad + row] = (uint32_t)(key >> 32);
+                }
+            }
+        }
+    }
+}
 
 /// The trivial plan: pairs of list g = (query i, g) for every i; pair index = i * G + g.
 static __global__ void coarse_plan_kernel(uint32_t nq, uint32_t G, uint32_t * pairs, uint32_t * pair_off, uint32_t * work_off)

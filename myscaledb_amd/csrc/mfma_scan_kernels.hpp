@@ -605,8 +605,10 @@ static __global__ void sample_cut_kernel(const uint64_t * cand, uint32_t kc, uin
 /// the certificate reads from it (ivf_rerank_kernel: `last`); the candidates are NOT sorted (the re-rank sorts the
 /// canonical keys).  Which of several rows with the same approximate value H are taken is arbitrary: the untaken
 /// ones are covered by the certificate's strict inequality, like any other row at the cut.
+/// The kc-th smallest of the wavefront's words (NW per lane; 0xFFFFFFFF when there are fewer than kc below it): the
+/// largest H with count(word < H) < kc, built bit by bit from the top.
 template <int NW>
-__device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_t (&lo)[NW], uint32_t kc, uint64_t * out, uint32_t lane)
+__device__ inline uint32_t wave_kth_word(const uint32_t (&hi)[NW], uint32_t kc)
 {
     uint32_t H = 0;
 #pragma unroll 1
@@ -617,9 +619,16 @@ __device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_
 #pragma unroll
         for (int u = 0; u < NW; u++)
             cnt += (uint32_t)__popcll(__ballot(hi[u] < c));
-        if (cnt < kc) // fewer than kc keys below c: the kc-th smallest is >= c
+        if (cnt < kc) // fewer than kc words below c: the kc-th smallest is >= c
             H = c;
     }
+    return H;
+}
+
+template <int NW>
+__device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_t (&lo)[NW], uint32_t kc, uint64_t * out, uint32_t lane)
+{
+    const uint32_t H = wave_kth_word<NW>(hi, kc);
     uint32_t run = 0;
 #pragma unroll
     for (int u = 0; u < NW; u++)

@@ -776,7 +776,8 @@ static void index_finalize_norms(msvs_index & ix, hipStream_t stream)
     index_build_shadow(ix, stream);
 }
 
-/// Process-wide counters of the candidate pass: [0] = queries whose certificate failed (device side).
+/// Process-wide counters of the candidate passes (device side): [0] = result queries whose certificate failed, [1] = the
+/// same for the coarse quantiser's passes (probe lists).
 static unsigned long long * prefilter_fail_counter()
 {
     static std::map<int, unsigned long long *> per_device;
@@ -788,12 +789,12 @@ static unsigned long long * prefilter_fail_counter()
     if (it != per_device.end())
         return it->second;
     unsigned long long * p = nullptr;
-    MSVS_HIP(hipMalloc(&p, 8));
-    MSVS_HIP(hipMemset(p, 0, 8));
+    MSVS_HIP(hipMalloc(&p, 16));
+    MSVS_HIP(hipMemset(p, 0, 16));
     per_device[dev] = p;
     return p;
 }
-static std::atomic<unsigned long long> g_prefilter_queries{0};
+static std::atomic<unsigned long long> g_prefilter_queries{0}, g_coarse_queries{0};
 
 static void index_assign(const msvs_index & ix, const float * d_x, size_t n, int32_t * d_assign, hipStream_t stream)
 {
@@ -1210,6 +1211,8 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
             p.nqg = options().ivf_nqg == 2 ? 2 : 1;
             p.T = BG_TQ * p.nqg;
             p.kc = k <= 12 ? 32 : 64;
+            if (p.h16 && options().h16_kc >= k) // experiment knob: candidates per query of the shadow pass
+                p.kc = (uint32_t)std::min<double>(64, options().h16_kc);
             // work item = 1 slice of a list for a tile of <= 128 queries, a grid of 4096 blocks: with the selection cheap,
             // the finest granularity balances best (2 slices / 2048 blocks: +5-8 % step time at 1024 .. 16384 q/step)
             p.rpb = BG_ROWS;
@@ -1408,7 +1411,9 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
     rp.xmax = t.norm_max;
     rp.failq = failq;
     rp.nfail = nfail;
-    rp.stat_fail = t.out_probes ? nullptr : prefilter_fail_counter(); // msvs_prefilter_stats counts result passes
+    rp.stat_fail = prefilter_fail_counter() + (t.out_probes ? 1 : 0); // msvs_prefilter_stats / msvs_coarse_stats
+    if (t.out_probes)
+        g_coarse_queries.fetch_add(nq, std::memory_order_relaxed);
     launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
     // queries without a certificate: canonical scan of the table
     ScanParams c = a;
@@ -1439,7 +1444,10 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
 static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq,
                                  const TablePass & t, hipStream_t stream)
 {
-    const uint32_t ld = ix.ld, nrows = (uint32_t)t.n, kc = t.k <= 12 ? 32 : 64;
+    const uint32_t ld = ix.ld, nrows = (uint32_t)t.n;
+    uint32_t kc = t.k <= 12 ? 32 : 64;
+    if (t.h16 && options().coarse_kc >= t.k) // experiment knob: candidates per query of the centroid-shadow pass
+        kc = (uint32_t)std::min<double>(64, options().coarse_kc);
     const uint32_t nqg = options().ivf_nqg == 2 ? 2 : 1; // 256-query tiles: see plan_ivf
     // queries per tile: the full 128 when that still gives the chip >= 512 work items, else 64 or 32 (the rows are then
     // re-read by more tiles -- cheap for a table that lives in L2, like the centroids)
@@ -1531,29 +1539,45 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         MSVS_HIP(hipMemcpyAsync(qn16, qnorm, nq * 4, hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq, (uint32_t)nq, ld,
                            ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qn16);
-        MSVS_HIP(hipMemsetAsync(sample, 0xFF, nq * (size_t)n_pad * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(coarse_plan_kernel, dim3((unsigned)ceil_div(std::max<size_t>(nq * (size_t)G, G + 1), (size_t)256)), dim3(256), 0,
-                           stream, (uint32_t)nq, G, cpairs, cpoff, cwoff);
-        H16Params h{};
-        h.H = ix.c_shadow.p;
-        h.hoff = ix.c_hoff.p;
-        h.nks = ix.h_nks;
-        h.nch = ix.h_nch;
-        h.Qh = qh;
-        h.qinfo = qinfo;
-        h.xnorm = t.norms;
-        h.list_off = ix.c_list_off.p;
-        h.pairs = cpairs;
-        h.pair_off = cpoff;
-        h.work_off = cwoff;
-        h.nlist = G;
-        h.nprobe = G;
-        h.sample_out = sample;
-        const uint32_t sgrid = device_cu_count() * 8;
-        if (scan_metric(m) == M_IP)
-            hipLaunchKernelGGL((h16_sample_kernel<M_IP>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
+        if (options().coarse_h16 != 2)
+        {
+            // dedicated kernel: 2 x 2 blocks per wavefront, every word of `sample` written
+            const uint32_t items = (uint32_t)(ceil_div((size_t)G, (size_t)2) * ceil_div(ceil_div(nq, (size_t)32), (size_t)2));
+            const uint32_t cgrid = (uint32_t)std::min<size_t>(ceil_div((size_t)items, (size_t)4), (size_t)device_cu_count() * 2);
+            if (scan_metric(m) == M_IP)
+                hipLaunchKernelGGL((coarse_h16_kernel<M_IP>), dim3(cgrid), dim3(BLOCK), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo,
+                                   t.norms, (uint32_t)t.n, (uint32_t)nq, sample);
+            else
+                hipLaunchKernelGGL((coarse_h16_kernel<M_L2>), dim3(cgrid), dim3(BLOCK), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo,
+                                   t.norms, (uint32_t)t.n, (uint32_t)nq, sample);
+        }
         else
-            hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
+        {
+            // coarse_h16 = 2: h16_sample_kernel on the trivial plan (one 32 x 32 tile per wavefront)
+            MSVS_HIP(hipMemsetAsync(sample, 0xFF, nq * (size_t)n_pad * sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(coarse_plan_kernel, dim3((unsigned)ceil_div(std::max<size_t>(nq * (size_t)G, G + 1), (size_t)256)), dim3(256),
+                               0, stream, (uint32_t)nq, G, cpairs, cpoff, cwoff);
+            H16Params h{};
+            h.H = ix.c_shadow.p;
+            h.hoff = ix.c_hoff.p;
+            h.nks = ix.h_nks;
+            h.nch = ix.h_nch;
+            h.Qh = qh;
+            h.qinfo = qinfo;
+            h.xnorm = t.norms;
+            h.list_off = ix.c_list_off.p;
+            h.pairs = cpairs;
+            h.pair_off = cpoff;
+            h.work_off = cwoff;
+            h.nlist = G;
+            h.nprobe = G;
+            h.sample_out = sample;
+            const uint32_t sgrid = device_cu_count() * 8;
+            if (scan_metric(m) == M_IP)
+                hipLaunchKernelGGL((h16_sample_kernel<M_IP>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
+            else
+                hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
+        }
         hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
                            n_pad, kc, cand, bound, options().wave_select != 0 ? 1 : 0);
         MSVS_HIP(hipGetLastError());
@@ -1754,9 +1778,14 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             hipLaunchKernelGGL((h16_sample_kernel<M_IP>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
         else
             hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
-        hipLaunchKernelGGL(h16_sample_thr_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
-                           sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
-                           qstate + nq, partial, pl.h_cap);
+        if (nprobe <= 64 && options().wave_select != 0)
+            hipLaunchKernelGGL(h16_sample_thr_wave_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
+                               sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
+                               qstate + nq, partial, pl.h_cap);
+        else
+            hipLaunchKernelGGL(h16_sample_thr_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
+                               sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
+                               qstate + nq, partial, pl.h_cap);
     }
     {
         ProfileScope prof("ivf_scan", stream);
@@ -2922,6 +2951,21 @@ extern "C" int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks)
         MSVS_HIP(hipMemcpy(&f, p, 8, hipMemcpyDeviceToHost));
         if (queries)
             *queries = g_prefilter_queries.load();
+        if (fallbacks)
+            *fallbacks = f;
+    });
+}
+
+/// The same counters for the coarse quantiser's candidate passes (batches of >= 512 queries on nlist >= 256).
+extern "C" int msvs_coarse_stats(uint64_t * queries, uint64_t * fallbacks)
+{
+    return guarded([&] {
+        unsigned long long f = 0;
+        unsigned long long * p = prefilter_fail_counter();
+        MSVS_HIP(hipDeviceSynchronize());
+        MSVS_HIP(hipMemcpy(&f, p + 1, 8, hipMemcpyDeviceToHost));
+        if (queries)
+            *queries = g_coarse_queries.load();
         if (fallbacks)
             *fallbacks = f;
     });

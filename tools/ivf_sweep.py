@@ -17,7 +17,11 @@ from bench import make_data, make_queries  # noqa: E402
 
 dev = torch.device("cuda", 0)
 n, d, nlist, nprobe, k = int(os.environ.get("SWEEP_ROWS", 1_000_000)), 768, 1024, 32, 10
+IID = os.environ.get("SWEEP_IID") == "1"  # rows and queries iid N(0,1)^768 instead of the bench mixture
 model, x = make_data(n, d, 1234, dev)
+if IID:
+    g = torch.Generator(device=dev).manual_seed(1234)
+    x = torch.randn((n, d), device=dev, dtype=torch.float32, generator=g)
 ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=%d,kmeans_iters=10,train_sample=65536" % nlist)
 ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
 ix.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
@@ -29,6 +33,8 @@ FAMILIES = ("flat_scan", "coarse_pass", "merge", "ivf_plan", "ivf_prep", "ivf_sa
 
 def run(B, steps=20):
     q = make_queries(model, 8 * B, 4321, dev)
+    if IID:
+        q = torch.randn((8 * B, d), device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(4321))
     oi = torch.empty((B, k), device=dev, dtype=torch.int64)
     od = torch.empty((B, k), device=dev, dtype=torch.float32)
     for i in range(3):
@@ -48,9 +54,9 @@ for c in sys.argv[1:]:
     B = int(kv.pop("B"))
     for a, b in kv.items():
         capi.set_option(a, b)
-    f0 = capi.prefilter_stats()
+    f0, c0 = capi.prefilter_stats(), capi.coarse_stats()
     dt, ids = run(B)
-    f1 = capi.prefilter_stats()
+    f1, c1 = capi.prefilter_stats(), capi.coarse_stats()
     same = bool((ref.setdefault(B, ids) == ids).all())
     capi.profile_reset()
     capi.profile_enable(True)
@@ -64,5 +70,5 @@ for c in sys.argv[1:]:
     capi.profile_reset()
     for a in kv:
         capi.set_option(a, None)
-    print("B=%d %s : %.3f ms/step  %.0f QPS  same_ids=%s  prefilter(q,fallback)=%s  kernels ms/step %s"
-          % (B, kv, dt * 1e3, B / dt, same, (f1[0] - f0[0], f1[1] - f0[1]), fam), flush=True)
+    print("B=%d %s : %.3f ms/step  %.0f QPS  same_ids=%s  prefilter(q,fallback)=%s coarse(q,fallback)=%s  kernels ms/step %s"
+          % (B, kv, dt * 1e3, B / dt, same, (f1[0] - f0[0], f1[1] - f0[1]), (c1[0] - c0[0], c1[1] - c0[1]), fam), flush=True)
