@@ -153,6 +153,20 @@ MSVS_HOST_API int msvs_text_index_bm25_search_batch(const msvs_text_index_t * ix
                                                     int enable_nlq, int operator_or, const msvs_bm25_stats_t * stats,
                                                     uint64_t * row_ids, float * scores, uint32_t * n_out);
 
+/* Distributed BM25 statistics.  msvs_host_fts_index_statistics = the row ONE shard answers to
+ * ftsIndex(db, table, column, query_text): total docs, per-field token totals and per-(term, field) document frequencies summed
+ * over the shard's parts (ReadFromFtsIndex::initializePipeline, src/VectorIndex/Storages/StorageFtsIndex.cpp:150-213; a part
+ * without a committed text index -> MSVS_ERR_NOT_IMPLEMENTED like the reference's missing index file).
+ * msvs_host_fts_statistics_merge = the initiator's sum over the shards' rows (collectStatisticForBM25Calculation /
+ * parseBM25StaisiticsInfo, src/VectorIndex/Utils/CommonUtils.cpp:190-330).  The view of either result is what the shards pass as
+ * `stats` to msvs_text_index_bm25_search* (the "_fts_statistic_info" scalar); fields ordered by id, terms by (field_id, term). */
+typedef struct msvs_fts_stats msvs_fts_stats_t;
+MSVS_HOST_API int msvs_host_fts_index_statistics(const msvs_text_index_t * const * parts, size_t nparts, const char * query_text,
+                                                 msvs_fts_stats_t ** out);
+MSVS_HOST_API int msvs_host_fts_statistics_merge(const msvs_bm25_stats_t * const * rows, size_t nrows, msvs_fts_stats_t ** out);
+MSVS_HOST_API const msvs_bm25_stats_t * msvs_fts_stats_view(const msvs_fts_stats_t * st);
+MSVS_HOST_API void msvs_fts_stats_free(msvs_fts_stats_t * st);
+
 #ifdef __cplusplus
 }
 #endif

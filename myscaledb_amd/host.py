@@ -17,7 +17,8 @@ SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_h
            "msvs_text_last_error", "msvs_text_index_create", "msvs_text_index_free", "msvs_text_index_add_doc",
            "msvs_text_index_commit", "msvs_text_index_save", "msvs_text_index_load", "msvs_text_index_total_num_docs",
            "msvs_text_index_total_num_tokens", "msvs_text_index_doc_freq", "msvs_text_index_set_alive",
-           "msvs_text_index_bm25_search", "msvs_text_index_bm25_search_batch"]
+           "msvs_text_index_bm25_search", "msvs_text_index_bm25_search_batch", "msvs_host_fts_index_statistics",
+           "msvs_host_fts_statistics_merge", "msvs_fts_stats_view", "msvs_fts_stats_free"]
 
 _lib = None
 
@@ -38,6 +39,10 @@ def lib():
         _lib.msvs_text_index_total_num_docs.argtypes = [C.c_void_p]
         _lib.msvs_text_index_free.restype = None
         _lib.msvs_text_index_free.argtypes = [C.c_void_p]
+        _lib.msvs_fts_stats_view.restype = C.POINTER(_Stats)
+        _lib.msvs_fts_stats_view.argtypes = [C.c_void_p]
+        _lib.msvs_fts_stats_free.restype = None
+        _lib.msvs_fts_stats_free.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -260,6 +265,33 @@ class Statistics:
             for f, c in p.total_num_tokens:
                 tk[f] = tk.get(f, 0) + c
         return Statistics([(t, f, d) for (t, f), d in df.items()], list(tk.items()), n)
+
+
+def _stats_from_handle(h):
+    v = lib().msvs_fts_stats_view(h).contents
+    st = Statistics([(v.docs_freq[i].term.decode(), v.docs_freq[i].field_id, v.docs_freq[i].doc_freq) for i in range(v.n_docs_freq)],
+                    [(v.total_num_tokens[i].field_id, v.total_num_tokens[i].field_total_tokens) for i in range(v.n_fields)],
+                    v.total_num_docs)
+    lib().msvs_fts_stats_free(h)
+    return st
+
+
+def fts_index_statistics(parts, query_text):
+    """The row one shard answers to ftsIndex(db, table, column, query_text): its parts' statistics summed
+    (msvs_host_fts_index_statistics; StorageFtsIndex.cpp:150-213).  parts: TextIndexStore objects."""
+    arr = (C.c_void_p * max(1, len(parts)))(*[p._h for p in parts])
+    h = C.c_void_p()
+    _tcheck(lib().msvs_host_fts_index_statistics(arr, C.c_size_t(len(parts)), query_text.encode(), C.byref(h)))
+    return _stats_from_handle(h)
+
+
+def fts_statistics_merge(rows):
+    """The initiator's sum over the shards' rows (msvs_host_fts_statistics_merge; CommonUtils.cpp:190-330)."""
+    cs = [r._c() for r in rows]
+    arr = (C.POINTER(_Stats) * max(1, len(cs)))(*[C.pointer(c) for c in cs])
+    h = C.c_void_p()
+    _tcheck(lib().msvs_host_fts_statistics_merge(arr, C.c_size_t(len(cs)), C.byref(h)))
+    return _stats_from_handle(h)
 
 
 class TextIndexStore:

@@ -528,4 +528,93 @@ MSVS_HOST_API int msvs_text_index_bm25_search(const msvs_text_index_t * ix, cons
     return msvs_text_index_bm25_search_batch(ix, &sentence, 1, column_names, ncols, topk, u8_alive_bitmap, nbytes, use_filter,
                                              enable_nlq, operator_or, stats, row_ids, scores, n_out);
 }
+
+/* ------------------------------------------------------------------------------- distributed BM25 statistics (DFS)
+ * What a Distributed-table text / hybrid search does before any shard scores: the initiator runs
+ * ftsIndex(db, table, column, query_text) on every shard, each shard answers with ONE row summed over its parts
+ * (ReadFromFtsIndex::initializePipeline, src/VectorIndex/Storages/StorageFtsIndex.cpp:150-213), the initiator adds the rows up
+ * (collectStatisticForBM25Calculation / parseBM25StaisiticsInfo, src/VectorIndex/Utils/CommonUtils.cpp:190-330) and ships the
+ * result to the shards as the "_fts_statistic_info" scalar, which becomes the `statistics` argument of every ffi_bm25_search.
+ * Both sums keep the reference's container order: fields by id, terms by (field_id, term bytes). */
+struct msvs_fts_stats
+{
+    uint64_t total_docs = 0;
+    std::map<uint32_t, uint64_t> tokens;
+    std::map<std::pair<uint32_t, std::string>, uint64_t> terms;
+    std::vector<msvs_field_tokens_t> tokens_v;
+    std::vector<msvs_doc_freq_t> terms_v;
+    msvs_bm25_stats_t view{};
+    void finish()
+    {
+        for (const auto & kv : tokens)
+            tokens_v.push_back(msvs_field_tokens_t{kv.first, kv.second});
+        for (const auto & kv : terms)
+            terms_v.push_back(msvs_doc_freq_t{kv.first.second.c_str(), kv.first.first, kv.second}); // map nodes do not move
+        view.docs_freq = terms_v.data();
+        view.n_docs_freq = terms_v.size();
+        view.total_num_tokens = tokens_v.data();
+        view.n_fields = tokens_v.size();
+        view.total_num_docs = total_docs;
+    }
+};
+
+MSVS_HOST_API int msvs_host_fts_index_statistics(const msvs_text_index_t * const * parts, size_t nparts, const char * query_text,
+                                                 msvs_fts_stats_t ** out)
+{
+    return text_guarded([&] {
+        if (!out || !query_text || (nparts && !parts))
+            text_fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
+        std::unique_ptr<msvs_fts_stats> st(new msvs_fts_stats);
+        std::vector<std::string> toks;
+        tokenize(query_text, toks);
+        std::sort(toks.begin(), toks.end());
+        toks.erase(std::unique(toks.begin(), toks.end()), toks.end());
+        for (size_t p = 0; p < nparts; p++)
+        {
+            const msvs_text_index_t * ix = parts[p];
+            if (!ix || !ix->committed) // the reference: "Fts index file ... does not exist" (NOT_IMPLEMENTED)
+                text_fail(MSVS_ERR_NOT_IMPLEMENTED, "part " + std::to_string(p) + " has no committed text index");
+            st->total_docs += ix->num_docs;
+            for (size_t f = 0; f < ix->columns.size(); f++)
+                st->tokens[(uint32_t)f] += ix->total_tokens[f];
+            for (const auto & t : toks)
+                for (size_t f = 0; f < ix->columns.size(); f++)
+                {
+                    const int64_t id = ix->find_term((uint32_t)f, t);
+                    st->terms[std::make_pair((uint32_t)f, t)] += id < 0 ? 0 : (uint64_t)(ix->post_off[id + 1] - ix->post_off[id]);
+                }
+        }
+        st->finish();
+        *out = st.release();
+    });
+}
+
+MSVS_HOST_API int msvs_host_fts_statistics_merge(const msvs_bm25_stats_t * const * rows, size_t nrows, msvs_fts_stats_t ** out)
+{
+    return text_guarded([&] {
+        if (!out || (nrows && !rows))
+            text_fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
+        std::unique_ptr<msvs_fts_stats> st(new msvs_fts_stats);
+        for (size_t r = 0; r < nrows; r++)
+        {
+            const msvs_bm25_stats_t * row = rows[r];
+            if (!row || (row->n_fields && !row->total_num_tokens) || (row->n_docs_freq && !row->docs_freq))
+                text_fail(MSVS_ERR_INVALID_ARGUMENT, "malformed statistics row " + std::to_string(r));
+            st->total_docs += row->total_num_docs;
+            for (size_t i = 0; i < row->n_fields; i++)
+                st->tokens[row->total_num_tokens[i].field_id] += row->total_num_tokens[i].field_total_tokens;
+            for (size_t i = 0; i < row->n_docs_freq; i++)
+            {
+                if (!row->docs_freq[i].term)
+                    text_fail(MSVS_ERR_INVALID_ARGUMENT, "null term in statistics row " + std::to_string(r));
+                st->terms[std::make_pair(row->docs_freq[i].field_id, std::string(row->docs_freq[i].term))] += row->docs_freq[i].doc_freq;
+            }
+        }
+        st->finish();
+        *out = st.release();
+    });
+}
+
+MSVS_HOST_API const msvs_bm25_stats_t * msvs_fts_stats_view(const msvs_fts_stats_t * st) { return st ? &st->view : nullptr; }
+MSVS_HOST_API void msvs_fts_stats_free(msvs_fts_stats_t * st) { delete st; }
 }

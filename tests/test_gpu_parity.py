@@ -1020,6 +1020,43 @@ def build_store(docs, columns=("doc",)):
     return st
 
 
+def test_distributed_bm25_statistics_two_shards_of_two_parts():
+    """The DFS statistics path of a Distributed-table text search (StorageFtsIndex.cpp:150-213, CommonUtils.cpp:190-330):
+    every shard sums its parts (ftsIndex row), the initiator sums the shards' rows, the shards score with the merged
+    statistics -- and the union of their hits is what ONE index over all documents returns, score bits included."""
+    rng = np.random.default_rng(91)
+    vocab = ["w%02d" % i for i in range(60)]
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(3, 30)))) for _ in range(400)]
+    cuts = [0, 90, 200, 330, 400]  # shard 0 = parts 0, 1; shard 1 = parts 2, 3
+    parts = [build_store([{"doc": d} for d in docs[cuts[i]:cuts[i + 1]]]) for i in range(4)]
+    whole = build_store([{"doc": d} for d in docs])
+    query = "w03 w17 w41 nosuchword w03"
+    rows = [mhost.fts_index_statistics(parts[:2], query), mhost.fts_index_statistics(parts[2:], query)]
+    merged = mhost.fts_statistics_merge(rows)
+    ref = whole.statistics(query)
+    assert merged.total_num_docs == ref.total_num_docs == 400
+    assert merged.total_num_tokens == ref.total_num_tokens
+    assert sorted(merged.docs_freq) == sorted(ref.docs_freq)
+    assert merged.docs_freq == sorted(merged.docs_freq, key=lambda t: (t[1], t[0]))  # (field_id, term) order
+    assert ("nosuchword", 0, 0) in merged.docs_freq
+    # python-side sum of per-part statistics (BM25InfoInDataParts) agrees
+    py = mhost.Statistics.sum([p.statistics(query) for p in parts])
+    assert sorted(py.docs_freq) == sorted(merged.docs_freq) and dict(py.total_num_tokens) == dict(merged.total_num_tokens)
+    hits = []
+    for i, p in enumerate(parts):
+        r, sc = p.bm25_search(query, 10, statistics=merged)
+        hits += [(-float(x), int(rr) + cuts[i], x) for rr, x in zip(r, sc)]
+    hits.sort(key=lambda h: (h[0], h[1]))
+    r, sc = whole.bm25_search(query, 10, statistics=ref)
+    assert [h[1] for h in hits[:10]] == [int(x) for x in r]
+    assert np.array([h[2] for h in hits[:10]], np.float32).view(np.uint32).tolist() == sc.view(np.uint32).tolist()
+    # a part without a committed index: the reference's "Fts index file does not exist"
+    st = mhost.TextIndexStore(["doc"])
+    with pytest.raises(capi.MsvsError) as e:
+        mhost.fts_index_statistics([parts[0], st], query)
+    assert e.value.code == capi.ERR_NOT_IMPLEMENTED
+
+
 def test_text_store_replays_the_bm25_goldens(tmp_path):
     """Seam B end to end through the native host side (text_store.cpp: exporter -> export file -> loader -> device):
     the sentence goes in as a string like TantivyIndexStore::bm25Search's, the goldens of 00040 / 00041 come out."""

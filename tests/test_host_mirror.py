@@ -17,7 +17,7 @@ def test_host_library_exports_every_declared_symbol():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "include", "msvs_host.h")) as f:
-        decl = sorted(set(re.findall(r"MSVS_HOST_API\s+[\w\s\*]+?\b(msvs_(?:host|text)_\w+)\s*\(", f.read())))
+        decl = sorted(set(re.findall(r"MSVS_HOST_API\s+[\w\s\*]+?\b(msvs_(?:host|text|fts)_\w+)\s*\(", f.read())))
     assert decl == sorted(host.SYMBOLS)
     for s in decl:
         assert hasattr(host.lib(), s)
