@@ -264,7 +264,11 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     const bool emit = n_chunks >= (wave ? 32u : 64u) && ps.num_docs >= 500000 && options().bm25_emit != 0;
     const uint32_t cand_cap = options().bm25_cand_cap > 0 ? (uint32_t)std::min<double>(options().bm25_cand_cap, BM25_CAND_CAP) : BM25_CAND_CAP;
     unsigned long long * stat_fail = bm25_fail_counter();
-    const uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks, (size_t)BM25_SAMPLE_STEP);
+    // the sample (every 16th chunk) walks a FINER partition in the wave scorer: with the emit pass's chunks (38 sub-ranges at
+    // 64 queries over 10M documents) it was 576 items of 112 us each on 2048 resident wavefronts = one item's duration
+    const uint32_t spi_s = wave && options().bm25_fine_sample != 0 ? std::max<uint32_t>(1, spi / 8) : spi;
+    const uint32_t n_chunks_s = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi_s) : n_blocks;
+    const uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks_s, (size_t)BM25_SAMPLE_STEP);
     // m-th best of the sample as the cut: about STEP * m documents pass, 4 sigma (STEP * sqrt(m)) above k
     const double rs = 2.0 + std::sqrt(4.0 + (double)k / BM25_SAMPLE_STEP);
     const uint32_t cut_m = (uint32_t)std::min<double>(64.0, std::ceil(rs * rs));
@@ -304,13 +308,13 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     a.bounds_hi = d_bounds_hi;
     const uint32_t cus = bm25_cu_count();
     // TOPK over (a sample of) the chunks: lists of p.kk keys into p.partial, `lists` per slot
-    auto launch_topk = [&](Bm25Params p, uint32_t lists, uint32_t step, size_t slots_bound) {
+    auto launch_topk = [&](Bm25Params p, uint32_t lists, uint32_t step, size_t slots_bound, uint32_t item_spi, uint32_t item_chunks) {
         if (wave)
         {
             Bm25WParams w{};
             w.p = p;
-            w.spi = spi;
-            w.n_chunks = n_chunks;
+            w.spi = item_spi;
+            w.n_chunks = item_chunks;
             w.cstep = step;
             w.n_items_c = lists;
             w.lists = lists;
@@ -357,7 +361,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     {
         a.partial = partial;
         a.kk = (uint32_t)k;
-        launch_topk(a, n_chunks, 1, nq);
+        launch_topk(a, n_chunks, 1, nq, spi, n_chunks);
         MergeParams m{};
         m.partial = partial;
         m.n_lists = n_chunks;
@@ -377,7 +381,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     Bm25Params sp = a;
     sp.partial = sample;
     sp.kk = cut_m;
-    launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq);
+    launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq, spi_s, n_chunks_s);
     MergeParams m{};
     m.partial = sample;
     m.n_lists = n_sb;
@@ -437,7 +441,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     fp.kk = (uint32_t)k;
     fp.qsel = failq;
     fp.nsel = nfail;
-    launch_topk(fp, n_chunks, 1, std::min<size_t>(nq, wave ? nq : 4));
+    launch_topk(fp, n_chunks, 1, std::min<size_t>(nq, wave ? nq : 4), spi, n_chunks);
     switch (r_for_k((uint32_t)k))
     {
         case 1:

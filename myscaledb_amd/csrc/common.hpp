@@ -140,6 +140,7 @@ struct Options
     double coarse_h16 = 1;    // coarse quantiser of batches through the centroid shadow (0: the split-bf16 table pass)
     double wave_select = 1;   // candidate selection by the bitwise wave search (0: WaveTopK insertion kernels)
     double plan_lds = 1;      // plan histogram / scatter aggregated in LDS per 2048 pairs (0: one global atomic per pair)
+    double bm25_fine_sample = 1; // BM25 wave scorer: the sample pass walks items of spi / 8 sub-ranges (0: the emit pass's items)
     double h16_kc = 0;        // candidates re-ranked per query after the fp16-shadow list scan (0: 32 for k <= 12, else 64)
     double coarse_kc = 0;     // ... after the centroid-shadow pass
     double fb_segs = 0;       // segments per list of the canonical fallback scan (0: automatic 4 / 16)

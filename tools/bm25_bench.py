@@ -55,8 +55,9 @@ def main():
         capi.profile_reset()
         print("BM25 %d docs %d postings, batch %d x 3 terms, k=%d: %.3f ms/batch (%.1f us/query, %.0f q/s), score kernels %.3f ms; "
               "algorithmic %.1f MB/batch -> %.0f GB/s whole call, %.0f GB/s score kernels (%.3f of 8 TB/s)"
-              % (a.docs, n_post, B, a.k, dt * 1e3, dt / B * 1e6, B / dt, ms / max(cnt, 1), byts / 1e6, byts / dt / 1e9,
-                 byts / (ms / max(cnt, 1) * 1e-3) / 1e9, byts / (ms / max(cnt, 1) * 1e-3) / 8e12), flush=True)
+              % (a.docs, n_post, B, a.k, dt * 1e3, dt / B * 1e6, B / dt, ms / steps, byts / 1e6, byts / dt / 1e9,
+                 byts / (ms / steps * 1e-3) / 1e9, byts / (ms / steps * 1e-3) / 8e12), flush=True)  # per BATCH (a large
+        # batch runs as several chunks = several profile scopes: round 2's "2.9 us/query at 1024" divided by the scopes)
 
 
 if __name__ == "__main__":
