@@ -141,6 +141,7 @@ struct Options
     double wave_select = 1;   // candidate selection by the bitwise wave search (0: WaveTopK insertion kernels)
     double plan_lds = 1;      // plan histogram / scatter aggregated in LDS per 2048 pairs (0: one global atomic per pair)
     double bm25_fine_sample = 1; // BM25 wave scorer: the sample pass walks items of spi / 8 sub-ranges (0: the emit pass's items)
+    double lat_select = 1;    // few-query path: probe list by register selection in the last block of stage 1 (0: list merge)
     double h16_kc = 0;        // candidates re-ranked per query after the fp16-shadow list scan (0: 32 for k <= 12, else 64)
     double coarse_kc = 0;     // ... after the centroid-shadow pass
     double fb_segs = 0;       // segments per list of the canonical fallback scan (0: automatic 4 / 16)

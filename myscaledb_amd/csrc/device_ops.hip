@@ -572,7 +572,7 @@ const OptionField g_option_fields[] = {
     {"coarse_h16", &Options::coarse_h16},   {"wave_select", &Options::wave_select},
     {"plan_lds", &Options::plan_lds},       {"fb_segs", &Options::fb_segs},
     {"h16_kc", &Options::h16_kc},           {"coarse_kc", &Options::coarse_kc},
-    {"bm25_fine_sample", &Options::bm25_fine_sample},
+    {"bm25_fine_sample", &Options::bm25_fine_sample}, {"lat_select", &Options::lat_select},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},
     {"ivf_t", &Options::ivf_t},             {"ivf_xcd", &Options::ivf_xcd},

@@ -22,7 +22,7 @@
 // profiles/r02_latency.txt has the steps that led here.
 #pragma once
 
-#include "scan_kernels.hpp"
+#include "mfma_scan_kernels.hpp"
 
 #pragma clang fp contract(off)
 
@@ -54,6 +54,7 @@ struct LatParams
     int64_t * out_ids;  // [nq][k]
     float * out_dis;
     int cosine;
+    int reg_select;  // stage 1: probe list by the register selection (lat_select_probes) instead of the list merge
     uint32_t * done; // [2] arrival counters of the two stages; zero between calls
     uint32_t * flag; // nullable: host-visible completion word, set to `seq` after the results are written
     uint32_t seq;
@@ -206,6 +207,53 @@ __device__ __forceinline__ uint64_t * lat_merge_lists(const uint64_t * src, uint
     return merged;
 }
 
+/// The probe list of one query by ONE wavefront without any merge: all `total` (<= 64 NW) centroid keys of the query in
+/// registers (one batch of agent-scope loads), the np-th smallest distance word by wave_kth_word (32 rounds of NW compares,
+/// no LDS, no barrier), ties at that word broken exactly by a second search over the ids (the probes must be the
+/// oracle's: smallest (distance, id) first) -- 11.3 -> ~4 us for 1024 keys against popping 32 heads off 32 sorted
+/// lists.  The probes leave in arbitrary order (the list scan's result does not depend on it).
+template <int NW>
+__device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, uint32_t np, int32_t * probes, uint32_t lane)
+{
+    uint32_t hi[NW], lo[NW];
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const uint32_t i = u * WAVE + lane;
+        const uint64_t key = i < total ? lat_load_key(src + i) : KEY_NONE;
+        hi[u] = (uint32_t)(key >> 32);
+        lo[u] = (uint32_t)key;
+    }
+    const uint32_t H = wave_kth_word<NW>(hi, np);
+    uint32_t below = 0, ties = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        below += (uint32_t)__popcll(__ballot(hi[u] < H));
+        ties += (uint32_t)__popcll(__ballot(hi[u] == H));
+    }
+    uint32_t L = 0xFFFFFFFFu; // ties with id <= L are taken
+    if (below + ties > np)    // the tie group straddles the np-th place: its (np - below) smallest ids
+    {
+        uint32_t tl[NW];
+#pragma unroll
+        for (int u = 0; u < NW; u++)
+            tl[u] = hi[u] == H ? lo[u] : 0xFFFFFFFFu;
+        L = wave_kth_word<NW>(tl, np - below);
+    }
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const bool take = hi[u] < H || (hi[u] == H && lo[u] <= L);
+        const uint64_t mask = __ballot(take);
+        const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (take && pos < np)
+            probes[pos] = hi[u] == 0xFFFFFFFFu && lo[u] == 0xFFFFFFFFu ? -1 : (int32_t)lo[u];
+        run += (uint32_t)__popcll(mask);
+    }
+}
+
 /// dynamic LDS: ld4 * 16 + max(5 * nprobe * 8, lat_merge_lds(c_blocks, nprobe)) bytes
 template <int METRIC>
 __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
@@ -234,12 +282,32 @@ __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
     if (!lat_publish_and_arrive(s_list, p.c_partial + ((size_t)q * p.c_blocks + b) * np, np, p.done, gridDim.x * gridDim.y))
         return;
     const unsigned long long t2 = wall_clock64();
-    for (uint32_t qq = 0; qq < p.nq; qq++)
+    const uint32_t total = p.c_blocks * np;
+    if (total <= 32 * WAVE && p.reg_select)
     {
-        const uint64_t * merged = lat_merge_lists<true>(p.c_partial + (size_t)qq * p.c_blocks * np, p.c_blocks, p.c_blocks, np, lds_merge);
-        if (tid < np)
-            p.probes[(size_t)qq * np + tid] = merged[tid] == KEY_NONE ? -1 : (int32_t)(uint32_t)merged[tid];
+        // wavefront w takes queries w, w + 4, ...
+        for (uint32_t qq = tid >> 6; qq < p.nq; qq += BLOCK / WAVE)
+        {
+            const uint64_t * src = p.c_partial + (size_t)qq * total;
+            int32_t * dst = p.probes + (size_t)qq * np;
+            if (total <= 4 * WAVE)
+                lat_select_probes<4>(src, total, np, dst, tid & 63);
+            else if (total <= 8 * WAVE)
+                lat_select_probes<8>(src, total, np, dst, tid & 63);
+            else if (total <= 16 * WAVE)
+                lat_select_probes<16>(src, total, np, dst, tid & 63);
+            else
+                lat_select_probes<32>(src, total, np, dst, tid & 63);
+        }
+        __syncthreads();
     }
+    else
+        for (uint32_t qq = 0; qq < p.nq; qq++)
+        {
+            const uint64_t * merged = lat_merge_lists<true>(p.c_partial + (size_t)qq * p.c_blocks * np, p.c_blocks, p.c_blocks, np, lds_merge);
+            if (tid < np)
+                p.probes[(size_t)qq * np + tid] = merged[tid] == KEY_NONE ? -1 : (int32_t)(uint32_t)merged[tid];
+        }
     if (tid == 0)
         p.done[0] = 0;
     if (p.dbg && tid == 0)

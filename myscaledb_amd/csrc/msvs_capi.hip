@@ -2271,6 +2271,7 @@ void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, u
     p.c_rows = sh.c_rows;
     p.c_blocks = sh.c_blocks;
     p.items = sh.items;
+    p.reg_select = options().lat_select != 0 ? 1 : 0;
     const size_t grid_x = sh.grid_x;
     const size_t n_dq = LAT_MAX_Q * (size_t)ix.ld, n_cp = nq * (size_t)p.c_blocks * nprobe, n_part = nq * grid_x * k;
     const bool grow = c.dq.n < n_dq || c.c_partial.n < n_cp || c.partial.n < n_part || !c.done.p;

@@ -619,6 +619,28 @@ def test_few_query_path_equals_general_path_and_oracle(metric, d, opt):
             same(oi_t[:nq].cpu().numpy(), od_t[:nq].cpu().numpy(), hi, hd)
 
 
+@pytest.mark.parametrize("lat_select", ["1", "0"])
+def test_few_query_path_probe_ties_are_broken_by_centroid_id(lat_select, opt):
+    """A zero query under inner product is equally far from every centroid: the probe list is the nprobe smallest centroid
+    ids (the oracle's (distance, id) order) -- the register selection of the two-launch path resolves the tie group by a
+    second search over the ids; the list-merge form (lat_select = 0) by the order of its keys."""
+    opt("lat_select", lat_select)
+    rng = np.random.default_rng(808)
+    n, d, nlist = 20000, 64, 200
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    ix = build_ivf(x, capi.METRIC_IP, nlist)
+    q = np.zeros((2, d), np.float32)
+    q[1] = rng.standard_normal(d).astype(np.float32)
+    for nprobe in (1, 7, 32, 64):
+        opt("lat_path", "2")
+        ids, dis = ix.search(q, 10, "nprobe=%d" % nprobe)
+        opt("lat_path", "0")
+        gi, gd = ix.search(q, 10, "nprobe=%d" % nprobe)
+        same(ids, dis, gi, gd)
+        oi, od, _ = oracle_on_exported(ix, q, nprobe, 10, capi.METRIC_IP)
+        same(ids, dis, oi, od)
+
+
 def test_few_query_path_from_many_host_threads(opt):
     """Concurrent client threads (one non-blocking stream and one set of pinned buffers per host thread): every thread
     gets its own queries' results."""
