@@ -615,11 +615,13 @@ __device__ inline uint32_t wave_kth_word(const uint32_t (&hi)[NW], uint32_t kc)
     for (int b = 31; b >= 0; b--)
     {
         const uint32_t c = H | (1u << b);
+        // counted per lane on the VALU and summed once per round: a ballot + s_bcnt1 per register put 2 NW dependent
+        // scalar instructions (one scalar unit per CU, SGPR hazards after every v_cmp) into each round
         uint32_t cnt = 0;
 #pragma unroll
         for (int u = 0; u < NW; u++)
-            cnt += (uint32_t)__popcll(__ballot(hi[u] < c));
-        if (cnt < kc) // fewer than kc words below c: the kc-th smallest is >= c
+            cnt += hi[u] < c ? 1u : 0u;
+        if (wave_sum_u32(cnt) < kc) // fewer than kc words below c: the kc-th smallest is >= c
             H = c;
     }
     return H;

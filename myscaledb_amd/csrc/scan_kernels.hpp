@@ -816,6 +816,18 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return min(min(r0, r1), min(r2, r3));
 }
 
+/// Wave-wide sum of a u32, result uniform (the same butterfly: every step pairs disjoint groups).
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += dpp32<0xB1>(v);
+    v += dpp32<0x4E>(v);
+    v += dpp32<0x141>(v);
+    v += dpp32<0x140>(v);
+    const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16),
+                   r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    return r0 + r1 + r2 + r3;
+}
+
 /// Wave-wide minimum of a u64, result uniform: the minimum of the high words, then the minimum of the low words among
 /// the lanes that hold it (two 32-bit reductions of single-instruction steps instead of one chain of 64-bit
 /// compare-and-selects: this sits on the serial path of every heads-merge round).
