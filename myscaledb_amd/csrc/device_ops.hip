@@ -475,7 +475,7 @@ void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint3
     ProfileScope prof("merge", stream);
     if (cap <= CAND_SELECT_WAVE_CAP && options().wave_select != 0)
         hipLaunchKernelGGL(cand_select_wave_kernel, dim3((nq + 3) / 4), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out,
-                           bound);
+                           bound, options().wave_select == 3 ? 0 : 1);
     else
         hipLaunchKernelGGL(cand_select_kernel, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
     MSVS_HIP(hipGetLastError());

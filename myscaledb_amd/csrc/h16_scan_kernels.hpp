@@ -607,7 +607,7 @@ __global__ __launch_bounds__(BLOCK) void h16_sample_kernel(const H16Params a)
 template <int NW>
 __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t * qprobes, const int64_t * list_off, uint32_t nprobe,
                                            uint32_t target, uint32_t * qthr, uint32_t * qcnt, uint64_t * dst, uint32_t cap,
-                                           uint32_t lane)
+                                           uint32_t lane, uint32_t * hist)
 {
     const uint32_t n = nprobe * H_ROWS;
     uint32_t word[NW];
@@ -633,7 +633,7 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
     }
     uint32_t m = rows ? (uint32_t)(((uint64_t)target * have + rows - 1) / rows) : 4u;
     m = m < 4 ? 4 : (m > 64 ? 64 : m);
-    const uint32_t cut = target == 0 ? 0xFFFFFFFFu : wave_kth_word<NW>(word, m);
+    const uint32_t cut = target == 0 ? 0xFFFFFFFFu : wave_kth_word<NW>(word, m, hist, lane);
     uint32_t count = 0;
 #pragma unroll
     for (int u = 0; u < NW; u++)
@@ -658,22 +658,24 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
 static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_wave_kernel(const uint32_t * sample, const int32_t * probes,
                                                                             const int64_t * list_off, uint32_t nq, uint32_t nprobe,
                                                                             uint32_t target, uint32_t * qthr, uint32_t * qcnt,
-                                                                            uint64_t * partial, uint32_t cap)
+                                                                            uint64_t * partial, uint32_t cap, int radix)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq)
         return;
+    uint32_t * hist = radix ? s_hist[threadIdx.x >> 6] : nullptr;
     const uint32_t * src = sample + (size_t)q * nprobe * H_ROWS;
     const int32_t * qp = probes + (size_t)q * nprobe;
     uint64_t * dst = partial + (size_t)q * cap;
     if (nprobe <= 8)
-        h16_sample_thr_wave<4>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane);
+        h16_sample_thr_wave<4>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist);
     else if (nprobe <= 16)
-        h16_sample_thr_wave<8>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane);
+        h16_sample_thr_wave<8>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist);
     else if (nprobe <= 32)
-        h16_sample_thr_wave<16>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane);
+        h16_sample_thr_wave<16>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist);
     else
-        h16_sample_thr_wave<32>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane);
+        h16_sample_thr_wave<32>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist);
 }
 
 static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint32_t * sample, const int32_t * probes,
@@ -878,7 +880,7 @@ static __global__ void coarse_plan_kernel(uint32_t nq, uint32_t G, uint32_t * pa
 /// candidate as the cut).  Up to 2048 centroids the words sit in registers and wave_select_words picks them
 /// (52 -> ~8 us for 4096 queries x 1024 centroids against inserting into a sorted wave list); beyond, the insertion loop.
 template <int NW>
-__device__ inline void coarse_select_wave(const uint32_t * src, uint32_t n_pad, uint32_t kc, uint64_t * out, uint32_t lane)
+__device__ inline void coarse_select_wave(const uint32_t * src, uint32_t n_pad, uint32_t kc, uint64_t * out, uint32_t lane, uint32_t * hist)
 {
     uint32_t hi[NW], lo[NW];
 #pragma unroll
@@ -888,15 +890,17 @@ __device__ inline void coarse_select_wave(const uint32_t * src, uint32_t n_pad, 
         hi[u] = i < n_pad ? src[i] : 0xFFFFFFFFu;
         lo[u] = hi[u] == 0xFFFFFFFFu ? 0xFFFFFFFFu : i;
     }
-    wave_select_words<NW>(hi, lo, kc, out, lane);
+    wave_select_words<NW>(hi, lo, kc, out, lane, hist);
 }
 
 static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint32_t * sample, uint32_t nq, uint32_t n_pad, uint32_t kc,
                                                                      uint64_t * cand, uint64_t * bound, int wave_select)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq)
         return;
+    uint32_t * hist = wave_select == 3 ? nullptr : s_hist[threadIdx.x >> 6]; // 3: the bitwise search (experiments)
     const uint32_t * src = sample + (size_t)q * n_pad;
     uint64_t * dst = cand + (size_t)q * kc;
     if (lane == 0)
@@ -904,13 +908,13 @@ static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint3
     if (wave_select && n_pad <= 32 * WAVE)
     {
         if (n_pad <= 4 * WAVE)
-            coarse_select_wave<4>(src, n_pad, kc, dst, lane);
+            coarse_select_wave<4>(src, n_pad, kc, dst, lane, hist);
         else if (n_pad <= 8 * WAVE)
-            coarse_select_wave<8>(src, n_pad, kc, dst, lane);
+            coarse_select_wave<8>(src, n_pad, kc, dst, lane, hist);
         else if (n_pad <= 16 * WAVE)
-            coarse_select_wave<16>(src, n_pad, kc, dst, lane);
+            coarse_select_wave<16>(src, n_pad, kc, dst, lane, hist);
         else
-            coarse_select_wave<32>(src, n_pad, kc, dst, lane);
+            coarse_select_wave<32>(src, n_pad, kc, dst, lane, hist);
         return;
     }
     WaveTopK<1> top;

@@ -213,7 +213,7 @@ __device__ __forceinline__ uint64_t * lat_merge_lists(const uint64_t * src, uint
 /// oracle's: smallest (distance, id) first) -- 11.3 -> ~4 us for 1024 keys against popping 32 heads off 32 sorted
 /// lists.  The probes leave in arbitrary order (the list scan's result does not depend on it).
 template <int NW>
-__device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, uint32_t np, int32_t * probes, uint32_t lane)
+__device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, uint32_t np, int32_t * probes, uint32_t lane, uint32_t * hist)
 {
     uint32_t hi[NW], lo[NW];
 #pragma unroll
@@ -224,7 +224,7 @@ __device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, u
         hi[u] = (uint32_t)(key >> 32);
         lo[u] = (uint32_t)key;
     }
-    const uint32_t H = wave_kth_word<NW>(hi, np);
+    const uint32_t H = wave_kth_word<NW>(hi, np, hist, lane);
     uint32_t below = 0, ties = 0;
 #pragma unroll
     for (int u = 0; u < NW; u++)
@@ -239,7 +239,7 @@ __device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, u
 #pragma unroll
         for (int u = 0; u < NW; u++)
             tl[u] = hi[u] == H ? lo[u] : 0xFFFFFFFFu;
-        L = wave_kth_word<NW>(tl, np - below);
+        L = wave_kth_word<NW>(tl, np - below, hist, lane);
     }
     uint32_t run = 0;
 #pragma unroll
@@ -285,19 +285,21 @@ __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
     const uint32_t total = p.c_blocks * np;
     if (total <= 32 * WAVE && p.reg_select)
     {
+        __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
+        uint32_t * hist = p.reg_select == 3 ? nullptr : s_hist[tid >> 6];
         // wavefront w takes queries w, w + 4, ...
         for (uint32_t qq = tid >> 6; qq < p.nq; qq += BLOCK / WAVE)
         {
             const uint64_t * src = p.c_partial + (size_t)qq * total;
             int32_t * dst = p.probes + (size_t)qq * np;
             if (total <= 4 * WAVE)
-                lat_select_probes<4>(src, total, np, dst, tid & 63);
+                lat_select_probes<4>(src, total, np, dst, tid & 63, hist);
             else if (total <= 8 * WAVE)
-                lat_select_probes<8>(src, total, np, dst, tid & 63);
+                lat_select_probes<8>(src, total, np, dst, tid & 63, hist);
             else if (total <= 16 * WAVE)
-                lat_select_probes<16>(src, total, np, dst, tid & 63);
+                lat_select_probes<16>(src, total, np, dst, tid & 63, hist);
             else
-                lat_select_probes<32>(src, total, np, dst, tid & 63);
+                lat_select_probes<32>(src, total, np, dst, tid & 63, hist);
         }
         __syncthreads();
     }

@@ -606,17 +606,16 @@ static __global__ void sample_cut_kernel(const uint64_t * cand, uint32_t kc, uin
 /// canonical keys).  Which of several rows with the same approximate value H are taken is arbitrary: the untaken
 /// ones are covered by the certificate's strict inequality, like any other row at the cut.
 /// The kc-th smallest of the wavefront's words (NW per lane; 0xFFFFFFFF when there are fewer than kc below it): the
-/// largest H with count(word < H) < kc, built bit by bit from the top.
+/// largest H with count(word < H) < kc, built bit by bit from the top.  32 rounds of 2 NW + 12 instructions: the
+/// wavefronts of a SIMD share its VALU, so a kernel of 4 of them per SIMD spends 4 x 1400 x 4 clocks = 11 us in here.
 template <int NW>
-__device__ inline uint32_t wave_kth_word(const uint32_t (&hi)[NW], uint32_t kc)
+__device__ inline uint32_t wave_kth_word_bits(const uint32_t (&hi)[NW], uint32_t kc)
 {
     uint32_t H = 0;
 #pragma unroll 1
     for (int b = 31; b >= 0; b--)
     {
         const uint32_t c = H | (1u << b);
-        // counted per lane on the VALU and summed once per round: a ballot + s_bcnt1 per register put 2 NW dependent
-        // scalar instructions (one scalar unit per CU, SGPR hazards after every v_cmp) into each round
         uint32_t cnt = 0;
 #pragma unroll
         for (int u = 0; u < NW; u++)
@@ -627,10 +626,94 @@ __device__ inline uint32_t wave_kth_word(const uint32_t (&hi)[NW], uint32_t kc)
     return H;
 }
 
+/// The same value by a radix select through a wave-private 256-bin histogram in LDS (hist: 256 words owned by this
+/// wavefront): the bits the words do not all share (from the highest bit in which minimum and maximum differ) are fixed 8 at a
+/// time -- one LDS atomic per word still inside the current prefix, an in-register prefix sum over the bins (4 per
+/// lane), the bin that holds the rank.  Distances of one query differ in ~24 bits: 3 passes of ~5 NW + 60 instructions
+/// against 32 rounds.  LDS operations of one wavefront execute in program order: no barrier.
 template <int NW>
-__device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_t (&lo)[NW], uint32_t kc, uint64_t * out, uint32_t lane)
+__device__ inline uint32_t wave_kth_word_radix(const uint32_t (&hi)[NW], uint32_t kc, uint32_t * hist, uint32_t lane)
 {
-    const uint32_t H = wave_kth_word<NW>(hi, kc);
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u, real = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        mn = min(mn, hi[u]);
+        mx = max(mx, hi[u] == 0xFFFFFFFFu ? 0u : hi[u]);
+        real += hi[u] != 0xFFFFFFFFu ? 1u : 0u;
+    }
+    real = wave_sum_u32(real);
+    if (real < kc)
+        return 0xFFFFFFFFu;
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    if (mn >= mx) // all present words equal
+        return mn;
+    int hi_bit = 31 - __builtin_clz(mn ^ mx); // highest bit that is not common
+    uint32_t H = hi_bit == 31 ? 0u : mn & ~((2u << hi_bit) - 1u);
+    uint32_t need = kc; // rank (1-based) among the words that share the prefix above hi_bit
+#pragma unroll 1
+    while (hi_bit >= 0)
+    {
+        const int lo_bit = hi_bit >= 7 ? hi_bit - 7 : 0;
+        const uint32_t dmask = (1u << (hi_bit - lo_bit + 1)) - 1u;
+        *reinterpret_cast<uint4 *>(hist + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NW; u++)
+            if ((((hi[u] ^ H) >> hi_bit) >> 1) == 0) // shares the prefix (absent words that do sort last: never reached)
+                atomicAdd(hist + ((hi[u] >> lo_bit) & dmask), 1u);
+        __builtin_amdgcn_wave_barrier();
+        const uint4 b = *reinterpret_cast<const uint4 *>(hist + 4 * lane);
+        const uint32_t own = b.x + b.y + b.z + b.w;
+        uint32_t incl = own; // inclusive prefix sum over the lanes: inside the 16-lane rows by DPP, across them by readlane
+        incl += dpp32<0x111>(incl);
+        incl += dpp32<0x112>(incl);
+        incl += dpp32<0x114>(incl);
+        incl += dpp32<0x118>(incl);
+        const uint32_t r0 = __builtin_amdgcn_readlane((int)incl, 15), r1 = __builtin_amdgcn_readlane((int)incl, 31),
+                       r2 = __builtin_amdgcn_readlane((int)incl, 47);
+        incl += lane < 16 ? 0u : lane < 32 ? r0 : lane < 48 ? r0 + r1 : r0 + r1 + r2;
+        const uint64_t reach = __ballot(incl >= need);
+        const int L = __builtin_ctzll(reach); // reach != 0: need <= the words in the prefix group
+        uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)(incl - own), L);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b.x, L), b1 = (uint32_t)__builtin_amdgcn_readlane((int)b.y, L),
+                       b2 = (uint32_t)__builtin_amdgcn_readlane((int)b.z, L);
+        uint32_t digit = 4u * (uint32_t)L;
+        if (below + b0 < need)
+        {
+            below += b0;
+            digit++;
+            if (below + b1 < need)
+            {
+                below += b1;
+                digit++;
+                if (below + b2 < need)
+                {
+                    below += b2;
+                    digit++;
+                }
+            }
+        }
+        need -= below;
+        H |= digit << lo_bit;
+        hi_bit = lo_bit - 1;
+    }
+    return H;
+}
+
+/// hist != nullptr: the radix form (hist = 256 LDS words owned by the calling wavefront); else the bitwise search.
+template <int NW>
+__device__ inline uint32_t wave_kth_word(const uint32_t (&hi)[NW], uint32_t kc, uint32_t * hist, uint32_t lane)
+{
+    return hist ? wave_kth_word_radix<NW>(hi, kc, hist, lane) : wave_kth_word_bits<NW>(hi, kc);
+}
+
+template <int NW>
+__device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_t (&lo)[NW], uint32_t kc, uint64_t * out, uint32_t lane,
+                                         uint32_t * hist)
+{
+    const uint32_t H = wave_kth_word<NW>(hi, kc, hist, lane);
     uint32_t run = 0;
 #pragma unroll
     for (int u = 0; u < NW; u++)
@@ -655,7 +738,7 @@ __device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_
 }
 
 template <int NW>
-__device__ inline void cand_select_wave(const uint64_t * src, uint32_t n, uint32_t kc, uint64_t * out, uint32_t lane)
+__device__ inline void cand_select_wave(const uint64_t * src, uint32_t n, uint32_t kc, uint64_t * out, uint32_t lane, uint32_t * hist)
 {
     uint32_t hi[NW], lo[NW];
 #pragma unroll
@@ -666,7 +749,7 @@ __device__ inline void cand_select_wave(const uint64_t * src, uint32_t n, uint32
         hi[u] = (uint32_t)(key >> 32);
         lo[u] = (uint32_t)key;
     }
-    wave_select_words<NW>(hi, lo, kc, out, lane);
+    wave_select_words<NW>(hi, lo, kc, out, lane, hist);
 }
 
 constexpr uint32_t CAND_SELECT_WAVE_CAP = 2048; // 32 keys per lane
@@ -676,22 +759,24 @@ constexpr uint32_t CAND_SELECT_WAVE_CAP = 2048; // 32 keys per lane
 /// wave_select_words.  out[q][kc]: the candidates, unsorted, KEY_NONE padded, the largest approximate value last.
 static __global__ __launch_bounds__(BLOCK) void cand_select_wave_kernel(const uint64_t * buf, const uint32_t * qcnt,
                                                                          const uint32_t * qthr, uint32_t cap, uint32_t nq,
-                                                                         uint32_t kc, uint64_t * out, uint64_t * bound)
+                                                                         uint32_t kc, uint64_t * out, uint64_t * bound, int radix)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
     const uint32_t q = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq)
         return;
+    uint32_t * hist = radix ? s_hist[threadIdx.x >> 6] : nullptr;
     const uint32_t n = qcnt[q] < cap ? qcnt[q] : cap;
     const uint64_t * src = buf + (size_t)q * cap;
     uint64_t * dst = out + (size_t)q * kc;
     if (n <= 4 * WAVE)
-        cand_select_wave<4>(src, n, kc, dst, lane);
+        cand_select_wave<4>(src, n, kc, dst, lane, hist);
     else if (n <= 8 * WAVE)
-        cand_select_wave<8>(src, n, kc, dst, lane);
+        cand_select_wave<8>(src, n, kc, dst, lane, hist);
     else if (n <= 16 * WAVE)
-        cand_select_wave<16>(src, n, kc, dst, lane);
+        cand_select_wave<16>(src, n, kc, dst, lane, hist);
     else
-        cand_select_wave<32>(src, n, kc, dst, lane);
+        cand_select_wave<32>(src, n, kc, dst, lane, hist);
     if (lane == 0) // an overflowed buffer dropped unknown keys: bound 0 = nothing can be certified
         bound[q] = qcnt[q] > cap ? 0 : (qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32);
 }

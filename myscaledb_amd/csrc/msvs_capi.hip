@@ -1579,7 +1579,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
                 hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
         }
         hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
-                           n_pad, kc, cand, bound, options().wave_select != 0 ? 1 : 0);
+                           n_pad, kc, cand, bound, (int)options().wave_select);
         MSVS_HIP(hipGetLastError());
         table_pass_tail(ix, m, t, a, nq, qn16, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true,
                         stream);
@@ -1781,7 +1781,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         if (nprobe <= 64 && options().wave_select != 0)
             hipLaunchKernelGGL(h16_sample_thr_wave_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
                                sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
-                               qstate + nq, partial, pl.h_cap);
+                               qstate + nq, partial, pl.h_cap, options().wave_select == 3 ? 0 : 1);
         else
             hipLaunchKernelGGL(h16_sample_thr_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
                                sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
@@ -2271,7 +2271,7 @@ void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, u
     p.c_rows = sh.c_rows;
     p.c_blocks = sh.c_blocks;
     p.items = sh.items;
-    p.reg_select = options().lat_select != 0 ? 1 : 0;
+    p.reg_select = (int)options().lat_select; // 1: radix select, 3: bitwise search, 0: list merge
     const size_t grid_x = sh.grid_x;
     const size_t n_dq = LAT_MAX_Q * (size_t)ix.ld, n_cp = nq * (size_t)p.c_blocks * nprobe, n_part = nq * grid_x * k;
     const bool grow = c.dq.n < n_dq || c.c_partial.n < n_cp || c.partial.n < n_part || !c.done.p;

@@ -816,6 +816,18 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return min(min(r0, r1), min(r2, r3));
 }
 
+/// Wave-wide maximum of a u32, result uniform.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, dpp32<0xB1>(v));
+    v = max(v, dpp32<0x4E>(v));
+    v = max(v, dpp32<0x141>(v));
+    v = max(v, dpp32<0x140>(v));
+    const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16),
+                   r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
 /// Wave-wide sum of a u32, result uniform (the same butterfly: every step pairs disjoint groups).
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
