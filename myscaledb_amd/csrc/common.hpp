@@ -142,6 +142,9 @@ struct Options
     double plan_lds = 1;      // plan histogram / scatter aggregated in LDS per 2048 pairs (0: one global atomic per pair)
     double bm25_fine_sample = 1; // BM25 wave scorer: the sample pass walks items of spi / 8 sub-ranges (0: the emit pass's items)
     double lat_select = 1;    // few-query path: probe list by register selection in the last block of stage 1 (0: list merge)
+    double rerank_early = 1;  // re-rank of result passes: sorted candidates, skip those beyond the exact k-th of the first rounds +- eps
+    double rerank_groups = 16; // candidate rows in flight per re-rank block (32: 512-thread blocks, measured slower: 70 vs 47 us)
+    double rerank_stats = 0;  // experiments: count the candidates an early exit of the re-rank could skip (msvs_debug_rerank_stats)
     double h16_kc = 0;        // candidates re-ranked per query after the fp16-shadow list scan (0: 32 for k <= 12, else 64)
     double coarse_kc = 0;     // ... after the centroid-shadow pass
     double fb_segs = 0;       // segments per list of the canonical fallback scan (0: automatic 4 / 16)

@@ -475,7 +475,7 @@ void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint3
     ProfileScope prof("merge", stream);
     if (cap <= CAND_SELECT_WAVE_CAP && options().wave_select != 0)
         hipLaunchKernelGGL(cand_select_wave_kernel, dim3((nq + 3) / 4), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out,
-                           bound, options().wave_select == 3 ? 0 : 1);
+                           bound, options().wave_select == 3 ? 0 : 1, options().rerank_early != 0 ? 1 : 0);
     else
         hipLaunchKernelGGL(cand_select_kernel, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
     MSVS_HIP(hipGetLastError());
@@ -489,10 +489,17 @@ void launch_ivf_rerank(int metric, RerankParams a, uint32_t nq, hipStream_t stre
     if (lds > 64 * 1024)
         fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large for the re-rank block", a.ld4 * 4);
     ProfileScope prof("rerank", stream);
-    if (metric == M_IP)
-        hipLaunchKernelGGL((ivf_rerank_kernel<M_IP>), dim3(nq), dim3(BLOCK), lds, stream, a);
+    if (options().rerank_groups != 32)
+    {
+        if (metric == M_IP)
+            hipLaunchKernelGGL((ivf_rerank_kernel<M_IP, 16>), dim3(nq), dim3(256), lds, stream, a);
+        else
+            hipLaunchKernelGGL((ivf_rerank_kernel<M_L2, 16>), dim3(nq), dim3(256), lds, stream, a);
+    }
+    else if (metric == M_IP)
+        hipLaunchKernelGGL((ivf_rerank_kernel<M_IP, 32>), dim3(nq), dim3(512), lds, stream, a);
     else
-        hipLaunchKernelGGL((ivf_rerank_kernel<M_L2>), dim3(nq), dim3(BLOCK), lds, stream, a);
+        hipLaunchKernelGGL((ivf_rerank_kernel<M_L2, 32>), dim3(nq), dim3(512), lds, stream, a);
     MSVS_HIP(hipGetLastError());
 }
 
@@ -573,6 +580,8 @@ const OptionField g_option_fields[] = {
     {"plan_lds", &Options::plan_lds},       {"fb_segs", &Options::fb_segs},
     {"h16_kc", &Options::h16_kc},           {"coarse_kc", &Options::coarse_kc},
     {"bm25_fine_sample", &Options::bm25_fine_sample}, {"lat_select", &Options::lat_select},
+    {"rerank_stats", &Options::rerank_stats},   {"rerank_early", &Options::rerank_early},
+    {"rerank_groups", &Options::rerank_groups},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},
     {"ivf_t", &Options::ivf_t},             {"ivf_xcd", &Options::ivf_xcd},

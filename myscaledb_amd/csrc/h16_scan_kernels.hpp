@@ -880,7 +880,8 @@ static __global__ void coarse_plan_kernel(uint32_t nq, uint32_t G, uint32_t * pa
 /// candidate as the cut).  Up to 2048 centroids the words sit in registers and wave_select_words picks them
 /// (52 -> ~8 us for 4096 queries x 1024 centroids against inserting into a sorted wave list); beyond, the insertion loop.
 template <int NW>
-__device__ inline void coarse_select_wave(const uint32_t * src, uint32_t n_pad, uint32_t kc, uint64_t * out, uint32_t lane, uint32_t * hist)
+__device__ inline void coarse_select_wave(const uint32_t * src, uint32_t n_pad, uint32_t kc, uint64_t * out, uint32_t lane, uint32_t * hist,
+                                          uint64_t * stage)
 {
     uint32_t hi[NW], lo[NW];
 #pragma unroll
@@ -890,7 +891,7 @@ __device__ inline void coarse_select_wave(const uint32_t * src, uint32_t n_pad, 
         hi[u] = i < n_pad ? src[i] : 0xFFFFFFFFu;
         lo[u] = hi[u] == 0xFFFFFFFFu ? 0xFFFFFFFFu : i;
     }
-    wave_select_words<NW>(hi, lo, kc, out, lane, hist);
+    wave_select_words<NW>(hi, lo, kc, out, lane, hist, stage, false);
 }
 
 static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint32_t * sample, uint32_t nq, uint32_t n_pad, uint32_t kc,
@@ -900,7 +901,9 @@ static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint3
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq)
         return;
+    __shared__ uint64_t s_stage[BLOCK / WAVE][WAVE];
     uint32_t * hist = wave_select == 3 ? nullptr : s_hist[threadIdx.x >> 6]; // 3: the bitwise search (experiments)
+    uint64_t * stage = s_stage[threadIdx.x >> 6];
     const uint32_t * src = sample + (size_t)q * n_pad;
     uint64_t * dst = cand + (size_t)q * kc;
     if (lane == 0)
@@ -908,13 +911,13 @@ static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint3
     if (wave_select && n_pad <= 32 * WAVE)
     {
         if (n_pad <= 4 * WAVE)
-            coarse_select_wave<4>(src, n_pad, kc, dst, lane, hist);
+            coarse_select_wave<4>(src, n_pad, kc, dst, lane, hist, stage);
         else if (n_pad <= 8 * WAVE)
-            coarse_select_wave<8>(src, n_pad, kc, dst, lane, hist);
+            coarse_select_wave<8>(src, n_pad, kc, dst, lane, hist, stage);
         else if (n_pad <= 16 * WAVE)
-            coarse_select_wave<16>(src, n_pad, kc, dst, lane, hist);
+            coarse_select_wave<16>(src, n_pad, kc, dst, lane, hist, stage);
         else
-            coarse_select_wave<32>(src, n_pad, kc, dst, lane, hist);
+            coarse_select_wave<32>(src, n_pad, kc, dst, lane, hist, stage);
         return;
     }
     WaveTopK<1> top;

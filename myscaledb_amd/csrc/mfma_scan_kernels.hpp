@@ -711,9 +711,11 @@ __device__ inline uint32_t wave_kth_word(const uint32_t (&hi)[NW], uint32_t kc, 
 
 template <int NW>
 __device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_t (&lo)[NW], uint32_t kc, uint64_t * out, uint32_t lane,
-                                         uint32_t * hist)
+                                         uint32_t * hist, uint64_t * stage /* LDS [64], wave-private */, bool sort)
 {
     const uint32_t H = wave_kth_word<NW>(hi, kc, hist, lane);
+    stage[lane] = KEY_NONE;
+    __builtin_amdgcn_wave_barrier();
     uint32_t run = 0;
 #pragma unroll
     for (int u = 0; u < NW; u++)
@@ -721,7 +723,7 @@ __device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_
         const bool take = hi[u] < H;
         const uint64_t mask = __ballot(take);
         if (take)
-            out[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))]
+            stage[run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))]
                 = (uint64_t)hi[u] << 32 | lo[u];
         run += (uint32_t)__popcll(mask);
     }
@@ -732,13 +734,33 @@ __device__ inline void wave_select_words(const uint32_t (&hi)[NW], const uint32_
         const uint64_t mask = __ballot(tie);
         const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (tie && pos < kc)
-            out[pos] = (uint64_t)hi[u] << 32 | lo[u];
+            stage[pos] = (uint64_t)hi[u] << 32 | lo[u];
         run += (uint32_t)__popcll(mask);
     }
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t mine = stage[lane];
+    if (!sort) // only the largest value last (all the certificate reads)
+    {
+        if (lane < kc)
+            out[lane] = mine;
+        return;
+    }
+    // ascending order for the early exit of the re-rank: lane i ranks its key among the kc selected (keys are distinct except
+    // KEY_NONE padding, which ranks itself by its slot)
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < kc; j++)
+    {
+        const uint64_t other = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j) << 32
+            | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
+        rank += other < mine || (other == mine && j < lane) ? 1u : 0u;
+    }
+    if (lane < kc)
+        out[rank] = mine;
 }
 
 template <int NW>
-__device__ inline void cand_select_wave(const uint64_t * src, uint32_t n, uint32_t kc, uint64_t * out, uint32_t lane, uint32_t * hist)
+__device__ inline void cand_select_wave(const uint64_t * src, uint32_t n, uint32_t kc, uint64_t * out, uint32_t lane, uint32_t * hist,
+                                        uint64_t * stage, bool sort)
 {
     uint32_t hi[NW], lo[NW];
 #pragma unroll
@@ -749,34 +771,36 @@ __device__ inline void cand_select_wave(const uint64_t * src, uint32_t n, uint32
         hi[u] = (uint32_t)(key >> 32);
         lo[u] = (uint32_t)key;
     }
-    wave_select_words<NW>(hi, lo, kc, out, lane, hist);
+    wave_select_words<NW>(hi, lo, kc, out, lane, hist, stage, sort);
 }
 
 constexpr uint32_t CAND_SELECT_WAVE_CAP = 2048; // 32 keys per lane
 
 /// cand_select_kernel for buffers of at most CAND_SELECT_WAVE_CAP keys: ONE wavefront per query holds the whole
 /// buffer in registers (a query of the bench keeps ~250 keys below its cut: 4 per lane) and selects by
-/// wave_select_words.  out[q][kc]: the candidates, unsorted, KEY_NONE padded, the largest approximate value last.
+/// wave_select_words.  out[q][kc]: the candidates (ascending when `sort`, else only the largest value last), KEY_NONE padded.
 static __global__ __launch_bounds__(BLOCK) void cand_select_wave_kernel(const uint64_t * buf, const uint32_t * qcnt,
                                                                          const uint32_t * qthr, uint32_t cap, uint32_t nq,
-                                                                         uint32_t kc, uint64_t * out, uint64_t * bound, int radix)
+                                                                         uint32_t kc, uint64_t * out, uint64_t * bound, int radix, int sort)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
     const uint32_t q = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= nq)
         return;
+    __shared__ uint64_t s_stage[BLOCK / WAVE][WAVE];
     uint32_t * hist = radix ? s_hist[threadIdx.x >> 6] : nullptr;
+    uint64_t * stage = s_stage[threadIdx.x >> 6];
     const uint32_t n = qcnt[q] < cap ? qcnt[q] : cap;
     const uint64_t * src = buf + (size_t)q * cap;
     uint64_t * dst = out + (size_t)q * kc;
     if (n <= 4 * WAVE)
-        cand_select_wave<4>(src, n, kc, dst, lane, hist);
+        cand_select_wave<4>(src, n, kc, dst, lane, hist, stage, sort != 0);
     else if (n <= 8 * WAVE)
-        cand_select_wave<8>(src, n, kc, dst, lane, hist);
+        cand_select_wave<8>(src, n, kc, dst, lane, hist, stage, sort != 0);
     else if (n <= 16 * WAVE)
-        cand_select_wave<16>(src, n, kc, dst, lane, hist);
+        cand_select_wave<16>(src, n, kc, dst, lane, hist, stage, sort != 0);
     else
-        cand_select_wave<32>(src, n, kc, dst, lane, hist);
+        cand_select_wave<32>(src, n, kc, dst, lane, hist, stage, sort != 0);
     if (lane == 0) // an overflowed buffer dropped unknown keys: bound 0 = nothing can be certified
         bound[q] = qcnt[q] > cap ? 0 : (qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32);
 }
@@ -823,7 +847,7 @@ struct RerankParams
     const uint32_t * ids;  // id of stored row r
     const float4 * Q;      // queries
     const float * qnorm;   // |q|^2 (approximate)
-    const uint64_t * cand; // [nq][kc] approximate keys (any order, the largest value LAST), low word = row position
+    const uint64_t * cand; // [nq][kc] approximate keys, low word = row position; the largest value LAST (ascending for early_exit to pay)
     const uint64_t * bound; // nullable [nq]: smallest key any earlier stage may have dropped (KEY_NONE = none dropped)
     uint32_t kc, k, ld4;
     int64_t * out_ids; // [nq][k]
@@ -838,27 +862,83 @@ struct RerankParams
     uint32_t * failq; // queries whose certificate failed ...
     uint32_t * nfail; // ... and their count (zeroed by the caller)
     unsigned long long * stat_fail; // nullable: process-wide running total
+    unsigned long long * stat_skip; // nullable (experiments): [0] += candidates beyond e_k +- eps, [1] += candidates
+    int early_exit; // rounds after the first ceil(k / 16) skip candidates whose approximate value is beyond e_k +- eps
 };
 
-/// One block per query.  dynamic LDS: ld4*16 + 64*8 bytes.
+/// |approximate value - canonical value| <= eps for every row of the table and this query (sx, sq: upper bounds of |x|, |q|).
+/// L2: a = |x|^2 + |q|^2 - 2<x,q> with approximate norms and product; IP: a = <x,q>.
 template <int METRIC>
-__global__ __launch_bounds__(BLOCK) void ivf_rerank_kernel(const RerankParams a)
+__device__ __forceinline__ double rerank_eps(const RerankParams & a, double sx, double sq)
+{
+    return (METRIC == M_L2 ? 2.0 * a.c_dot * sx * sq + a.c_norm * (sx * sx + sq * sq) + (a.c_canon + 4e-7) * (sx + sq) * (sx + sq)
+                           : (a.c_dot + a.c_canon) * sx * sq)
+        + 1e-30;
+}
+
+/// One block of 16 G threads per query: G groups of 16 lanes, a group per candidate row and round.  G = 16; 32 (all
+/// candidates of a k <= 12 search in flight at once) measured SLOWER: 70 against 47 us per 4096 queries -- kept as a knob.
+/// dynamic LDS: ld4*16 + 64*8 bytes.
+template <int METRIC, int G>
+__global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a)
 {
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
     uint64_t * keys = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, g = tid & 15;
     const uint32_t q = blockIdx.x, ld4 = a.ld4, kc = a.kc;
-    for (uint32_t c = tid; c < ld4; c += BLOCK)
+    for (uint32_t c = tid; c < ld4; c += 16 * G)
         qs[c] = a.Q[(size_t)q * ld4 + c];
     if (tid < 64)
         keys[tid] = KEY_NONE;
     __syncthreads();
     const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
-    for (uint32_t c = grp; c < kc; c += 16)
+    // Early exit: the candidates arrive in ascending approximate order, G per round.  Once the first ceil(k / G) rounds
+    // have given an exact k-th distance e, a later candidate with approximate value a beyond e by more than the error
+    // bound (a - eps > e: its exact distance is > e >= the final k-th) cannot enter the result: its row is not read
+    // (valid whatever the order is; the order makes it effective).  List scan of the bench step: 57 % of the 32 candidates
+    // per query are never read (of 69 % that are not results), 45 -> 19 us; the coarse quantiser's table lives in L2 and
+    // gains nothing (measured), so the host leaves it off there and its candidates unsorted.
+    __shared__ double s_e, s_eps;
+    __shared__ int s_skip;
+    const uint32_t first = a.early_exit && kc % G == 0 ? (a.k + G - 1) / G * G : kc; // every group walks kc / G rounds: the barrier is uniform
+    for (uint32_t c = grp; c < kc; c += G)
     {
+        if (c - grp == first) // uniform over the block: the first rounds are complete
+        {
+            __syncthreads();
+            if (wave == 0)
+            {
+                WaveTopK<1> t0;
+                t0.init();
+                t0.offer(lane < first ? keys[lane] : KEY_NONE, a.k, lane);
+                const float qn = a.qnorm[q];
+                const bool usable = t0.thr != KEY_NONE && qn < 1e30f && a.xmax < 1e30f;
+                if (lane == 0)
+                {
+                    s_skip = usable ? 1 : 0;
+                    if (usable)
+                    {
+                        const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
+                        s_e = (double)key_value<METRIC>(t0.thr);
+                        s_eps = rerank_eps<METRIC>(a, sx, sq);
+                    }
+                }
+            }
+            __syncthreads();
+        }
         const uint64_t ck = a.cand[(size_t)q * kc + c]; // uniform over the 16 lanes that own candidate c
         if (ck == KEY_NONE)
             continue;
+        if (c - grp >= first && s_skip)
+        {
+            const double aj = (double)key_value<METRIC>(ck);
+            if (METRIC == M_L2 ? (aj - s_eps > s_e) : (aj + s_eps < s_e))
+            {
+                if (a.stat_skip && g == 0) // experiments: rows really skipped (slot 6 = result passes, 7 = coarse passes)
+                    atomicAdd(a.stat_skip + (a.out_probes ? 3 : 4), 1ull);
+                continue;
+            }
+        }
         const uint32_t pos = (uint32_t)ck;
         const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
         const float4 * qrow = qs + g;
@@ -916,12 +996,20 @@ __global__ __launch_bounds__(BLOCK) void ivf_rerank_kernel(const RerankParams a)
         {
             const double al = (double)key_value<METRIC>(last), e = (double)key_value<METRIC>(ek);
             const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
-            // L2: a = |x|^2 + |q|^2 - 2<x,q> with approximate norms and product; IP: a = <x,q>
-            const double eps = (METRIC == M_L2 ? 2.0 * a.c_dot * sx * sq + a.c_norm * (sx * sx + sq * sq)
-                                        + (a.c_canon + 4e-7) * (sx + sq) * (sx + sq)
-                                               : (a.c_dot + a.c_canon) * sx * sq)
-                + 1e-30;
+            const double eps = rerank_eps<METRIC>(a, sx, sq);
             ok = METRIC == M_L2 ? (al - eps > e) : (al + eps < e);
+            if (a.stat_skip) // experiment: how many candidates an early exit could have skipped (approximate value beyond e_k +- eps)
+            {
+                const uint64_t ck = lane < kc ? a.cand[(size_t)q * kc + lane] : KEY_NONE;
+                const double aj = (double)key_value<METRIC>(ck);
+                const bool skippable = ck != KEY_NONE && (METRIC == M_L2 ? (aj - eps > e) : (aj + eps < e));
+                const uint32_t ns = (uint32_t)__popcll(__ballot(skippable)), nc = (uint32_t)__popcll(__ballot(ck != KEY_NONE));
+                if (lane == 0)
+                {
+                    atomicAdd(a.stat_skip, (unsigned long long)ns);
+                    atomicAdd(a.stat_skip + 1, (unsigned long long)nc);
+                }
+            }
         }
     }
     if (!ok && lane == 0)

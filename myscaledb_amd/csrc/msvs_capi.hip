@@ -789,8 +789,8 @@ static unsigned long long * prefilter_fail_counter()
     if (it != per_device.end())
         return it->second;
     unsigned long long * p = nullptr;
-    MSVS_HIP(hipMalloc(&p, 16));
-    MSVS_HIP(hipMemset(p, 0, 16));
+    MSVS_HIP(hipMalloc(&p, 64));
+    MSVS_HIP(hipMemset(p, 0, 64));
     per_device[dev] = p;
     return p;
 }
@@ -1411,7 +1411,9 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
     rp.xmax = t.norm_max;
     rp.failq = failq;
     rp.nfail = nfail;
+    rp.early_exit = options().rerank_early != 0 && !t.out_probes ? 1 : 0; // result passes only: the centroid table gains nothing
     rp.stat_fail = prefilter_fail_counter() + (t.out_probes ? 1 : 0); // msvs_prefilter_stats / msvs_coarse_stats
+    rp.stat_skip = options().rerank_stats != 0 ? prefilter_fail_counter() + (t.out_probes ? 4 : 2) : nullptr;
     if (t.out_probes)
         g_coarse_queries.fetch_add(nq, std::memory_order_relaxed);
     launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
@@ -1816,7 +1818,9 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     rp.xmax = ix.xnorm_max;
     rp.failq = failq;
     rp.nfail = nfail;
+    rp.early_exit = options().rerank_early != 0 ? 1 : 0;
     rp.stat_fail = prefilter_fail_counter();
+    rp.stat_skip = options().rerank_stats != 0 ? prefilter_fail_counter() + 2 : nullptr;
     launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
     g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
     // queries without a certificate: canonical scan, one query per block (normally zero of them)
@@ -2093,6 +2097,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         rp.xmax = ix.xnorm_max;
         rp.failq = failq;
         rp.nfail = nfail;
+        rp.early_exit = options().rerank_early != 0 ? 1 : 0;
         rp.stat_fail = prefilter_fail_counter();
         launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
         g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
@@ -2954,6 +2959,19 @@ extern "C" int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks)
             *queries = g_prefilter_queries.load();
         if (fallbacks)
             *fallbacks = f;
+    });
+}
+
+/// Experiments (option rerank_stats = 1): out[0..3] = candidates an early exit could have skipped / candidates re-ranked, for the
+/// result passes and for the coarse quantiser's passes; out[4], out[5] = rows really skipped (result / coarse passes).
+extern "C" __attribute__((visibility("default"))) int msvs_debug_rerank_stats(uint64_t * out)
+{
+    return guarded([&] {
+        unsigned long long v[6];
+        MSVS_HIP(hipDeviceSynchronize());
+        MSVS_HIP(hipMemcpy(v, prefilter_fail_counter() + 2, 48, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 6; i++)
+            out[i] = v[i];
     });
 }
 

@@ -384,11 +384,12 @@ def test_coarse_quantiser_through_the_candidate_pass(metric, h16, opt):
     same(ids, dis, oi, od)
 
 
-@pytest.mark.parametrize("knobs", [{}, {"wave_select": "0"}, {"plan_lds": "0"}, {"fb_segs": "4"}, {"fb_segs": "16"},
-                                   {"cand_cap": "3000"}])
+@pytest.mark.parametrize("knobs", [{}, {"wave_select": "0"}, {"wave_select": "3"}, {"plan_lds": "0"}, {"fb_segs": "4"}, {"fb_segs": "16"},
+                                   {"cand_cap": "3000"}, {"rerank_early": "0"}, {"rerank_groups": "32"}])
 def test_selection_plan_and_fallback_variants_agree_with_the_oracle(knobs, opt):
-    """The bitwise wave selection (candidate buffers and centroid words held in registers), the LDS-aggregated plan and
-    the 16-segment fallback against their insertion / per-pair-atomic / 4-segment forms: the same exact answer.  Massive
+    """The radix / bitwise (3) wave selection (candidate buffers and centroid words held in registers), the LDS-aggregated
+    plan, the 16-segment fallback and the early exit of the re-rank (64 candidates: the second half is skipped when beyond the
+    exact k-th of the first) against their insertion / per-pair-atomic / 4-segment / evaluate-everything forms: the same exact answer.  Massive
     duplicates (every approximate value shared by several rows) exercise the tie branch of the selection; cand_cap 3000
     is above the register form's capacity (the insertion kernel serves it)."""
     for name, v in knobs.items():

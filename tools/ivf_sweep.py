@@ -70,5 +70,12 @@ for c in sys.argv[1:]:
     capi.profile_reset()
     for a in kv:
         capi.set_option(a, None)
+    if kv.get("rerank_stats") == "1":
+        import ctypes as C
+        import numpy as np
+        st = np.zeros(6, np.uint64)
+        capi.lib().msvs_debug_rerank_stats(st.ctypes.data_as(C.POINTER(C.c_uint64)))
+        print("   re-rank candidates beyond e_k +- eps (cumulative): lists %d of %d, coarse %d of %d; rows skipped: lists %d, coarse %d"
+              % tuple(int(x) for x in st))
     print("B=%d %s : %.3f ms/step  %.0f QPS  same_ids=%s  prefilter(q,fallback)=%s coarse(q,fallback)=%s  kernels ms/step %s"
           % (B, kv, dt * 1e3, B / dt, same, (f1[0] - f0[0], f1[1] - f0[1]), (c1[0] - c0[0], c1[1] - c0[1]), fam), flush=True)
