@@ -896,7 +896,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
     // have given an exact k-th distance e, a later candidate with approximate value a beyond e by more than the error
     // bound (a - eps > e: its exact distance is > e >= the final k-th) cannot enter the result: its row is not read
     // (valid whatever the order is; the order makes it effective).  List scan of the bench step: 57 % of the 32 candidates
-    // per query are never read (of 69 % that are not results), 45 -> 19 us; the coarse quantiser's table lives in L2 and
+    // per query are never read (of 69 % that are not results), 75 -> 50 us; the coarse quantiser's table lives in L2 and
     // gains nothing (measured), so the host leaves it off there and its candidates unsorted.
     __shared__ double s_e, s_eps;
     __shared__ int s_skip;
