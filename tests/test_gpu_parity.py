@@ -366,14 +366,18 @@ def test_coarse_quantiser_through_the_candidate_pass(metric, h16, opt):
     opt("coarse_mfma", "2")  # whenever eligible (by default only from ~128 tile x slice items on)
     capi.profile_reset()
     capi.profile_enable(True)
+    c0 = capi.coarse_stats()
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     capi.profile_enable(False)
     assert capi.profile_get("coarse_pass")[0] == 1  # the pass is the one that ran
     capi.profile_reset()
     same(ids, dis, oi, od)
+    c1 = capi.coarse_stats()
+    assert c1[0] - c0[0] == nq and c1[1] - c0[1] <= nq // 20  # msvs_coarse_stats: queries through the pass, few fallbacks
     opt("ivf_eps_scale", "1e12")  # every certificate fails: canonical fallbacks everywhere
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
+    assert capi.coarse_stats()[1] - c1[1] == nq
     opt("fb_cap", "3")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
