@@ -230,6 +230,12 @@ MSVS_API int msvs_profile_reset(void);
 MSVS_API int msvs_prefilter_stats(uint64_t * queries, uint64_t * fallbacks);
 /* ... and of the coarse quantiser's candidate passes (whose output is the probe lists). */
 MSVS_API int msvs_coarse_stats(uint64_t * queries, uint64_t * fallbacks);
+/* msvs_index_search from many host threads (the reference: one query per thread, up to ScanThreadLimiter of them,
+ * MergeTreeVSManager.cpp:973): up to 8 unfiltered calls of <= 4 queries run directly; callers beyond that queue, and the next call
+ * to finish hands its slot to the first waiter together with every waiter that asks for the same k and parameters -- one batched
+ * search serves them all (same bits: every path is exact).  Counters: calls through this front end, batches of several callers,
+ * queries served by such batches.  Option "combine" = the number of direct calls (0: off). */
+MSVS_API int msvs_combine_stats(uint64_t * calls, uint64_t * batches, uint64_t * batched_queries);
 /* Scratch memory is kept per (host thread, stream) and reused call after call; it shrinks by itself when a thread's
  * requests stay small for a window of 64 calls.  msvs_release_scratch frees the calling thread's arenas now (device synchronised). */
 MSVS_API int msvs_release_scratch(size_t * freed_bytes);

@@ -11,6 +11,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "msvs.h" /* msvs_index_t */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -152,6 +154,14 @@ MSVS_HOST_API int msvs_text_index_bm25_search_batch(const msvs_text_index_t * ix
                                                     const uint8_t * u8_alive_bitmap, size_t nbytes, int use_filter,
                                                     int enable_nlq, int operator_or, const msvs_bm25_stats_t * stats,
                                                     uint64_t * row_ids, float * scores, uint32_t * n_out);
+
+/* Measurement / test driver for the reference's calling pattern (MergeTreeVSManager.cpp:973: up to ScanThreadLimiter-many host
+ * threads, one query per VectorIndex::search call): `threads` native threads, thread t searching queries t, t + threads, ...
+ * `calls_per_thread` times through msvs_index_search.  seconds: wall time; lat_us (nullable, [threads * calls_per_thread]):
+ * per-call latencies; ids / dis (nullable, [n_queries][k]): each query's last result. */
+MSVS_HOST_API int msvs_host_concurrent_search(const msvs_index_t * ix, const float * queries, size_t n_queries, size_t dim, int threads,
+                                              size_t calls_per_thread, int k, const char * params, double * seconds, float * lat_us,
+                                              int64_t * ids, float * dis);
 
 /* Distributed BM25 statistics.  msvs_host_fts_index_statistics = the row ONE shard answers to
  * ftsIndex(db, table, column, query_text): total docs, per-field token totals and per-(term, field) document frequencies summed

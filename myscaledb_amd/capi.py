@@ -30,7 +30,7 @@ SYMBOLS = [
     "msvs_release_scratch", "msvs_filter_from_bits", "msvs_filter_from_offsets", "msvs_filter_from_predicate", "msvs_filter_combine", "msvs_filter_count",
     "msvs_filter_to_bits", "msvs_filter_free", "msvs_index_search_filter", "msvs_index_search_filter_device", "msvs_index_scanned_rows",
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
-    "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_coarse_stats", "msvs_set_option", "msvs_index_serialize_io",
+    "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_coarse_stats", "msvs_combine_stats", "msvs_set_option", "msvs_index_serialize_io",
     "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
     "msvs_cache_create", "msvs_cache_free", "msvs_block_upload", "msvs_block_lookup", "msvs_block_release",
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
@@ -132,6 +132,13 @@ def prefilter_stats():
     q, f = C.c_uint64(0), C.c_uint64(0)
     _check(lib().msvs_prefilter_stats(C.byref(q), C.byref(f)))
     return q.value, f.value
+
+
+def combine_stats():
+    """-> (calls, batches, batched queries) of msvs_index_search's combining front end (msvs_combine_stats)."""
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _check(lib().msvs_combine_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def coarse_stats():

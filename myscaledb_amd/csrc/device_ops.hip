@@ -581,7 +581,8 @@ const OptionField g_option_fields[] = {
     {"h16_kc", &Options::h16_kc},           {"coarse_kc", &Options::coarse_kc},
     {"bm25_fine_sample", &Options::bm25_fine_sample}, {"lat_select", &Options::lat_select},
     {"rerank_stats", &Options::rerank_stats},   {"rerank_early", &Options::rerank_early},
-    {"rerank_groups", &Options::rerank_groups},
+    {"rerank_groups", &Options::rerank_groups}, {"combine", &Options::combine},
+    {"combine_batches", &Options::combine_batches},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},
     {"ivf_t", &Options::ivf_t},             {"ivf_xcd", &Options::ivf_xcd},

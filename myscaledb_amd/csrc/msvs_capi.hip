@@ -251,6 +251,8 @@ extern "C" int msvs_normalize_f32(float * x, size_t n, size_t d)
 
 #include <list>
 #include <unordered_map>
+#include <condition_variable>
+#include <deque>
 
 struct msvs_block
 {
@@ -852,7 +854,16 @@ extern "C" int msvs_index_create(int index_type, int metric, size_t dim, const c
     });
 }
 
-extern "C" void msvs_index_free(msvs_index_t * index) { delete index; }
+namespace
+{
+void combiner_forget(const msvs_index * ix); // the per-index queue of concurrent host callers (below)
+}
+extern "C" void msvs_index_free(msvs_index_t * index)
+{
+    if (index)
+        combiner_forget(index);
+    delete index;
+}
 
 extern "C" int msvs_index_set_centroids(msvs_index_t * ix, const float * centroids, size_t nlist, int mem)
 {
@@ -2418,8 +2429,8 @@ void index_search_filtered(const msvs_index & ix, const float * d_queries, size_
                            size_t eff_bits, uint64_t alive_count, int64_t * d_ids, float * d_dis, hipStream_t stream);
 }
 
-extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
-                                 const uint64_t * alive_bits, size_t nbits, int64_t * ids, float * dis)
+static int index_search_host_call(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
+                                  const uint64_t * alive_bits, size_t nbits, int64_t * ids, float * dis)
 {
     return guarded([&] {
         if (!ix || (nq && (!queries || !ids || !dis)) || k < 0)
@@ -2509,6 +2520,201 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
         MSVS_HIP(hipMemcpyAsync(dis, d_dis.p, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipStreamSynchronize(stream));
     });
+}
+
+// ------------------------------------------------------------------------------------------ combining concurrent callers
+//
+// The reference's host calls VectorIndex::search from up to ScanThreadLimiter-many threads, one query each
+// (MergeTreeVSManager.cpp:973).  One query is a whole-GPU job of ~55 us here, so beyond a handful of concurrent callers the
+// calls only queue behind each other on the device (64 threads: 26 k QPS), while ONE batched search of 64 queries takes
+// 0.37 ms (170 k QPS).  So: up to `combine` (8) single calls run directly, each on its thread's stream, exactly as
+// before, as long as nobody waits; callers beyond that wait in a queue, and the next call to finish while no batch is in
+// flight hands the lead to the first waiter together with EVERY compatible waiter's query (same k, same parameter string,
+// no filter) -- that thread runs them as one batch and distributes the rows; while a batch runs, new callers queue up for
+// the next one.  No timer, no extra latency for a lone caller; results are the same bits either way (every path is
+// exact).  msvs_combine_stats counts the batches.
+namespace
+{
+struct CombineReq
+{
+    const float * q;
+    size_t nq;
+    int k;
+    std::string params;
+    int64_t * ids;
+    float * dis;
+    int status = 0;
+    std::string err;
+    int state = 0; // 0 waiting, 1 leader of `batch`, 2 served
+    std::vector<CombineReq *> batch;
+    std::condition_variable cv;
+};
+struct Combiner
+{
+    std::mutex mu;
+    std::deque<CombineReq *> queue;
+    int active = 0;  // leaders running (single calls and batches)
+    int batches = 0; // ... of which batches of several callers
+};
+std::mutex g_comb_mu;
+std::unordered_map<const msvs_index *, std::shared_ptr<Combiner>> g_comb;
+std::atomic<unsigned long long> g_comb_calls{0}, g_comb_batches{0}, g_comb_batched{0};
+constexpr size_t COMBINE_MAX_QUERIES = 1024;
+
+std::shared_ptr<Combiner> combiner_of(const msvs_index * ix)
+{
+    std::lock_guard<std::mutex> lk(g_comb_mu);
+    auto & c = g_comb[ix];
+    if (!c)
+        c = std::make_shared<Combiner>();
+    return c;
+}
+void combiner_forget(const msvs_index * ix)
+{
+    std::lock_guard<std::mutex> lk(g_comb_mu);
+    g_comb.erase(ix);
+}
+
+/// Runs the leader's batch: one request = the plain call into its own buffers; several = one gathered search.
+void combine_run(const msvs_index * ix, CombineReq & lead)
+{
+    auto & b = lead.batch;
+    if (b.size() == 1)
+    {
+        lead.status = index_search_host_call(ix, lead.q, lead.nq, lead.k, lead.params.c_str(), nullptr, 0, lead.ids, lead.dis);
+        if (lead.status)
+            lead.err = msvs_last_error();
+        return;
+    }
+    size_t total = 0;
+    for (auto * r : b)
+        total += r->nq;
+    const size_t d = ix->dim, k = (size_t)lead.k;
+    static thread_local std::vector<float> qbuf, dbuf;
+    static thread_local std::vector<int64_t> ibuf;
+    qbuf.resize(total * d);
+    ibuf.resize(total * k);
+    dbuf.resize(total * k);
+    size_t at = 0;
+    for (auto * r : b)
+    {
+        memcpy(qbuf.data() + at * d, r->q, r->nq * d * 4);
+        at += r->nq;
+    }
+    const int rc = index_search_host_call(ix, qbuf.data(), total, lead.k, lead.params.c_str(), nullptr, 0, ibuf.data(), dbuf.data());
+    const std::string err = rc ? msvs_last_error() : "";
+    at = 0;
+    for (auto * r : b)
+    {
+        if (!rc)
+        {
+            memcpy(r->ids, ibuf.data() + at * k, r->nq * k * 8);
+            memcpy(r->dis, dbuf.data() + at * k, r->nq * k * 4);
+        }
+        r->status = rc;
+        r->err = err;
+        at += r->nq;
+    }
+    g_comb_batches.fetch_add(1, std::memory_order_relaxed);
+    g_comb_batched.fetch_add(total, std::memory_order_relaxed);
+}
+
+int combined_search(const msvs_index * ix, const float * queries, size_t nq, int k, const char * params, int64_t * ids, float * dis)
+{
+    const int max_direct = (int)options().combine;
+    auto comb = combiner_of(ix); // keeps the combiner alive across a concurrent msvs_index_free (which is a caller bug anyway)
+    Combiner & c = *comb;
+    CombineReq me;
+    me.q = queries;
+    me.nq = nq;
+    me.k = k;
+    me.params = params ? params : "";
+    me.ids = ids;
+    me.dis = dis;
+    g_comb_calls.fetch_add(1, std::memory_order_relaxed);
+    std::unique_lock<std::mutex> lk(c.mu);
+    // direct while nobody waits and no batch is in flight (a batch uses the whole device well; single calls next to it
+    // would only slow it down and keep the next batch small)
+    const int max_batches = std::max(1, (int)options().combine_batches);
+    if (c.active == 0 || (c.active < max_direct && c.queue.empty() && c.batches == 0))
+    {
+        c.active++;
+        me.batch.assign(1, &me);
+    }
+    else
+    {
+        c.queue.push_back(&me);
+        me.cv.wait(lk, [&] { return me.state != 0; });
+        if (me.state == 2)
+        {
+            lk.unlock();
+            if (me.status)
+                set_last_error(me.err);
+            return me.status;
+        }
+    }
+    lk.unlock();
+    combine_run(ix, me); // never throws: the C entry underneath translates
+    lk.lock();
+    for (auto * r : me.batch)
+        if (r != &me)
+        {
+            r->state = 2;
+            r->cv.notify_one();
+        }
+    c.active--;
+    if (me.batch.size() > 1)
+        c.batches--;
+    if (!c.queue.empty() && c.batches < max_batches)
+    {
+        // the first waiter leads next, with every compatible waiter's queries (waiters with another k / parameter string
+        // follow when this batch is done)
+        c.active++;
+        CombineReq * next = c.queue.front();
+        c.queue.pop_front();
+        next->batch.assign(1, next);
+        size_t total = next->nq;
+        for (auto it = c.queue.begin(); it != c.queue.end() && total < COMBINE_MAX_QUERIES;)
+            if ((*it)->k == next->k && (*it)->params == next->params && total + (*it)->nq <= COMBINE_MAX_QUERIES)
+            {
+                total += (*it)->nq;
+                next->batch.push_back(*it);
+                it = c.queue.erase(it);
+            }
+            else
+                ++it;
+        if (next->batch.size() > 1)
+            c.batches++;
+        next->state = 1;
+        next->cv.notify_one();
+    }
+    lk.unlock();
+    if (me.status)
+        set_last_error(me.err);
+    return me.status;
+}
+}
+
+extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
+                                 const uint64_t * alive_bits, size_t nbits, int64_t * ids, float * dis)
+{
+    // few unfiltered queries on a ready index: through the combiner (anything else, and every argument error, directly)
+    if (options().combine >= 1 && ix && ix->ready && nq >= 1 && nq <= 4 && !alive_bits && queries && ids && dis && k >= 1
+        && (size_t)k <= MSVS_MAX_K)
+        return combined_search(ix, queries, nq, k, params, ids, dis);
+    return index_search_host_call(ix, queries, nq, k, params, alive_bits, nbits, ids, dis);
+}
+
+/// calls that went through the combiner, batches of more than one caller, queries served by such batches
+extern "C" int msvs_combine_stats(uint64_t * calls, uint64_t * batches, uint64_t * batched_queries)
+{
+    if (calls)
+        *calls = g_comb_calls.load();
+    if (batches)
+        *batches = g_comb_batches.load();
+    if (batched_queries)
+        *batched_queries = g_comb_batched.load();
+    return MSVS_OK;
 }
 
 // ------------------------------------------------------------------------------------------ filters

@@ -18,7 +18,7 @@ SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_h
            "msvs_text_index_commit", "msvs_text_index_save", "msvs_text_index_load", "msvs_text_index_total_num_docs",
            "msvs_text_index_total_num_tokens", "msvs_text_index_doc_freq", "msvs_text_index_set_alive",
            "msvs_text_index_bm25_search", "msvs_text_index_bm25_search_batch", "msvs_host_fts_index_statistics",
-           "msvs_host_fts_statistics_merge", "msvs_fts_stats_view", "msvs_fts_stats_free"]
+           "msvs_host_fts_statistics_merge", "msvs_fts_stats_view", "msvs_fts_stats_free", "msvs_host_concurrent_search"]
 
 _lib = None
 
@@ -265,6 +265,23 @@ class Statistics:
             for f, c in p.total_num_tokens:
                 tk[f] = tk.get(f, 0) + c
         return Statistics([(t, f, d) for (t, f), d in df.items()], list(tk.items()), n)
+
+
+def concurrent_search(index, queries, threads, calls_per_thread, k, params=""):
+    """msvs_host_concurrent_search: native threads, one query per msvs_index_search call.
+    -> (seconds, per-call latencies in us [threads * calls], ids [nq, k], dis [nq, k] of each query's last call)."""
+    q = np.ascontiguousarray(queries, np.float32)
+    nq, d = q.shape
+    sec = C.c_double(0)
+    lat = np.zeros(threads * calls_per_thread, np.float32)
+    ids = np.full((nq, k), -2, np.int64)
+    dis = np.zeros((nq, k), np.float32)
+    rc = lib().msvs_host_concurrent_search(index._h, _p(q, C.c_float), C.c_size_t(nq), C.c_size_t(d), int(threads),
+                                           C.c_size_t(calls_per_thread), int(k), params.encode(), C.byref(sec), _p(lat, C.c_float),
+                                           _p(ids, C.c_int64), _p(dis, C.c_float))
+    if rc != 0:
+        raise capi.MsvsError(rc, capi.last_error())
+    return sec.value, lat, ids, dis
 
 
 def _stats_from_handle(h):

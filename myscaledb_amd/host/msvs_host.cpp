@@ -776,3 +776,48 @@ extern "C" void msvs_host_sum_bm25_stats(const uint64_t * per_part, size_t npart
         for (size_t j = 0; j < w; j++)
             out[j] += per_part[p * w + j];
 }
+
+/* Measurement / test driver for the reference's calling pattern (MergeTreeVSManager.cpp:973: up to ScanThreadLimiter-many host
+ * threads, ONE query per VectorIndex::search call): `threads` native threads, thread t searching queries t, t + threads, ...
+ * (wrapping) `calls_per_thread` times through msvs_index_search.  seconds = wall time of the whole run; lat_us (nullable,
+ * [threads * calls_per_thread]) every call's latency; ids / dis (nullable, [n_queries][k]) the rows of each query's last call. */
+#include <chrono>
+#include <thread>
+extern "C" int msvs_host_concurrent_search(const msvs_index_t * ix, const float * queries, size_t n_queries, size_t dim, int threads,
+                                           size_t calls_per_thread, int k, const char * params, double * seconds, float * lat_us,
+                                           int64_t * ids, float * dis)
+{
+    if (!ix || !queries || n_queries == 0 || threads < 1 || k < 1 || !seconds)
+        return MSVS_ERR_INVALID_ARGUMENT;
+    std::vector<int> rc((size_t)threads, 0);
+    std::vector<std::thread> pool;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([&, t] {
+            std::vector<int64_t> li((size_t)k);
+            std::vector<float> ld((size_t)k);
+            for (size_t c = 0; c < calls_per_thread; c++)
+            {
+                const size_t qi = ((size_t)t + c * (size_t)threads) % n_queries;
+                const auto a = std::chrono::steady_clock::now();
+                const int r = msvs_index_search(ix, queries + qi * dim, 1, k, params, nullptr, 0, ids ? ids + qi * (size_t)k : li.data(),
+                                                dis ? dis + qi * (size_t)k : ld.data());
+                const auto b = std::chrono::steady_clock::now();
+                if (lat_us)
+                    lat_us[(size_t)t * calls_per_thread + c] = std::chrono::duration<float, std::micro>(b - a).count();
+                if (r)
+                {
+                    rc[(size_t)t] = r;
+                    return;
+                }
+            }
+        });
+    for (auto & th : pool)
+        th.join();
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int r : rc)
+        if (r)
+            return r;
+    return MSVS_OK;
+}
+

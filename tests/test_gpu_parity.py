@@ -680,6 +680,65 @@ def test_few_query_path_from_many_host_threads(opt):
     assert errors == []
 
 
+def test_concurrent_single_query_callers_are_combined_into_batches(opt):
+    """msvs_index_search from 48 host threads, one query per call (the reference's calling pattern): callers beyond the 8
+    direct ones are served by batches (msvs_combine_stats), every caller gets exactly the rows of its own query, whatever
+    batch it landed in; different k / parameters never share a batch; an argument error reaches every caller of the batch
+    in its own thread (msvs_last_error is thread-local); combine = 0 is the plain path."""
+    import threading
+
+    rng = np.random.default_rng(31)
+    n, d, nlist = 40000, 96, 128
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((384, d), dtype=np.float32)
+    ix = build_ivf(x, capi.METRIC_L2, nlist)
+    opt("combine", "0")
+    exp = {(10, 8): ix.search(q, 10, "nprobe=8"), (5, 16): ix.search(q, 5, "nprobe=16")}
+    # native threads: real concurrency (python threads hold the GIL between calls and rarely have 8 calls in flight)
+    opt("combine", None)
+    c0 = capi.combine_stats()
+    sec, lat, ci, cd = mhost.concurrent_search(ix, q, 48, 40, 10, "nprobe=8")
+    same(ci, cd, *exp[(10, 8)])
+    c1 = capi.combine_stats()
+    assert c1[0] - c0[0] == 48 * 40
+    assert c1[1] > c0[1] and c1[2] - c0[2] >= 2 * (c1[1] - c0[1])  # batches of several callers were formed
+    # python threads with ONE direct slot: everybody else is served by batches; mixed k / parameters; errors
+    opt("combine", "1")
+    c0 = capi.combine_stats()
+    errors = []
+
+    def worker(t):
+        try:
+            k, nprobe = (10, 8) if t % 3 else (5, 16)
+            ei, ed = exp[(k, nprobe)]
+            for rep in range(4):
+                for j in range(t, 384, 48):
+                    i1, d1 = ix.search(q[j:j + 1], k, "nprobe=%d" % nprobe)
+                    if not ((i1 == ei[j:j + 1]).all() and (d1.view(np.uint32) == ed[j:j + 1].view(np.uint32)).all()):
+                        errors.append((t, j))
+            try:
+                ix.search(q[t:t + 1], 10, "bogus=1")
+                errors.append((t, "no error for a bad parameter"))
+            except capi.MsvsError as e:
+                if e.code != capi.ERR_INVALID_ARGUMENT or "bogus" not in str(e):
+                    errors.append((t, repr(e)))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(48)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
+    c1 = capi.combine_stats()
+    assert c1[0] - c0[0] == 48 * (4 * 8 + 1)
+    assert c1[1] > c0[1] and c1[2] - c0[2] >= 2 * (c1[1] - c0[1])  # batches of several callers were formed
+    # two- and four-query calls take part too
+    i2, d2 = ix.search(q[:4], 10, "nprobe=8")
+    same(i2, d2, exp[(10, 8)][0][:4], exp[(10, 8)][1][:4])
+
+
 # ---------------------------------------------------------------------------------------- the certificate's premise, on hardware
 
 def _key_values(hi, ip):
