@@ -370,8 +370,8 @@ def main():
         # spend ~30 us per call under the GIL and cannot keep more than a few calls in flight: 26 k QPS whatever the library
         # does).  Callers beyond 8 in flight are served in batches by msvs_index_search's combining front end.
         import myscaledb_amd.host as mhost
-        for c in (8, 64):
-            per = 10000 // c
+        for c in (1, 8, 64):
+            per = 10000 // c if c > 1 else 4000
             b0 = capi.combine_stats()
             sec, al, _, _ = mhost.concurrent_search(ix, qh, c, per, k, sp)
             b1 = capi.combine_stats()
