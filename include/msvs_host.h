@@ -76,6 +76,14 @@ MSVS_HOST_API size_t msvs_host_hybrid_search(int fusion_type, const float * vec_
                                              size_t topk, float * out_scores, uint64_t * out_parts,
                                              uint64_t * out_labels);
 
+/* The same fusion for a batch of queries straight from the device searches' output arrays (one part): query q's vector rows are
+ * vec_dis / vec_ids[q * kv ...] (an id < 0 ends the list, like the host's `> -1` unpack, MergeTreeVSManager.cpp:1110-1140), its text
+ * rows txt_scores / txt_ids[q * kt ...]; out_scores / out_labels[q * topk ...], n_out[q] rows each. */
+MSVS_HOST_API int msvs_host_hybrid_search_batch(int fusion_type, const float * vec_dis, const int64_t * vec_ids, size_t kv,
+                                                const float * txt_scores, const int64_t * txt_ids, size_t kt, size_t nq,
+                                                uint64_t fusion_k, float fusion_weight, int vector_scan_direction, size_t topk,
+                                                float * out_scores, uint64_t * out_labels, uint32_t * n_out);
+
 /* HybridSearchFusionTransform::generate (src/VectorIndex/Processors/HybridSearchFusionTransform.cpp:22-182): the fusion step of
  * a Distributed-table hybrid search on the initiator.  Rows = the merged shard results in pipeline order: distance rows
  * (score_type 0) first, then bm25 rows (score_type 1), each with (shard_num, part_index, part_offset).  At most num_candidates

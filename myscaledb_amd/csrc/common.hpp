@@ -147,6 +147,7 @@ struct Options
     double rerank_stats = 0;  // experiments: count the candidates an early exit of the re-rank could skip (msvs_debug_rerank_stats)
     double combine = 8;       // msvs_index_search: single-query callers beyond this many in flight are batched by the next finisher (0: off)
     double combine_batches = 1; // ... and at most this many combined batches in flight
+    double h16_k128 = 1;      // shadow pass for 40 < k <= 128 with 256 candidates (0: the canonical scan as before)
     double h16_kc = 0;        // candidates re-ranked per query after the fp16-shadow list scan (0: 32 for k <= 12, else 64)
     double coarse_kc = 0;     // ... after the centroid-shadow pass
     double fb_segs = 0;       // segments per list of the canonical fallback scan (0: automatic 4 / 16)

@@ -473,11 +473,13 @@ void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint3
     if (nq == 0)
         return;
     ProfileScope prof("merge", stream);
-    if (cap <= CAND_SELECT_WAVE_CAP && options().wave_select != 0)
+    if (cap <= CAND_SELECT_WAVE_CAP && kc <= 64 && options().wave_select != 0)
         hipLaunchKernelGGL(cand_select_wave_kernel, dim3((nq + 3) / 4), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out,
                            bound, options().wave_select == 3 ? 0 : 1, options().rerank_early != 0 ? 1 : 0);
+    else if (kc <= 64)
+        hipLaunchKernelGGL(cand_select_kernel<1>, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
     else
-        hipLaunchKernelGGL(cand_select_kernel, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
+        hipLaunchKernelGGL(cand_select_kernel<4>, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
     MSVS_HIP(hipGetLastError());
 }
 
@@ -485,21 +487,31 @@ void launch_ivf_rerank(int metric, RerankParams a, uint32_t nq, hipStream_t stre
 {
     if (nq == 0)
         return;
-    const size_t lds = (size_t)a.ld4 * 16 + 64 * 8;
+    if (a.kc > 256 || a.k > a.kc)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "re-rank of %u candidates for k = %u", a.kc, a.k);
+    const size_t lds = (size_t)a.ld4 * 16 + (a.kc <= 64 ? 64 : 256) * 8;
     if (lds > 64 * 1024)
         fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large for the re-rank block", a.ld4 * 4);
     ProfileScope prof("rerank", stream);
-    if (options().rerank_groups != 32)
+    const bool ip = metric == M_IP;
+    if (a.kc > 64) // 256 candidates (40 < k <= 128)
     {
-        if (metric == M_IP)
-            hipLaunchKernelGGL((ivf_rerank_kernel<M_IP, 16>), dim3(nq), dim3(256), lds, stream, a);
+        if (ip)
+            hipLaunchKernelGGL((ivf_rerank_kernel<M_IP, 16, 4>), dim3(nq), dim3(256), lds, stream, a);
         else
-            hipLaunchKernelGGL((ivf_rerank_kernel<M_L2, 16>), dim3(nq), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((ivf_rerank_kernel<M_L2, 16, 4>), dim3(nq), dim3(256), lds, stream, a);
     }
-    else if (metric == M_IP)
-        hipLaunchKernelGGL((ivf_rerank_kernel<M_IP, 32>), dim3(nq), dim3(512), lds, stream, a);
+    else if (options().rerank_groups != 32)
+    {
+        if (ip)
+            hipLaunchKernelGGL((ivf_rerank_kernel<M_IP, 16, 1>), dim3(nq), dim3(256), lds, stream, a);
+        else
+            hipLaunchKernelGGL((ivf_rerank_kernel<M_L2, 16, 1>), dim3(nq), dim3(256), lds, stream, a);
+    }
+    else if (ip)
+        hipLaunchKernelGGL((ivf_rerank_kernel<M_IP, 32, 1>), dim3(nq), dim3(512), lds, stream, a);
     else
-        hipLaunchKernelGGL((ivf_rerank_kernel<M_L2, 32>), dim3(nq), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((ivf_rerank_kernel<M_L2, 32, 1>), dim3(nq), dim3(512), lds, stream, a);
     MSVS_HIP(hipGetLastError());
 }
 
@@ -581,7 +593,7 @@ const OptionField g_option_fields[] = {
     {"h16_kc", &Options::h16_kc},           {"coarse_kc", &Options::coarse_kc},
     {"bm25_fine_sample", &Options::bm25_fine_sample}, {"lat_select", &Options::lat_select},
     {"rerank_stats", &Options::rerank_stats},   {"rerank_early", &Options::rerank_early},
-    {"rerank_groups", &Options::rerank_groups}, {"combine", &Options::combine},
+    {"rerank_groups", &Options::rerank_groups}, {"combine", &Options::combine},           {"h16_k128", &Options::h16_k128},
     {"combine_batches", &Options::combine_batches},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},

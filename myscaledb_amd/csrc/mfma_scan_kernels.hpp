@@ -805,18 +805,19 @@ static __global__ __launch_bounds__(BLOCK) void cand_select_wave_kernel(const ui
         bound[q] = qcnt[q] > cap ? 0 : (qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32);
 }
 
-/// The kc (<= 64) best of the keys a query's slices appended (unsorted runs), ascending, one block per query (the
+/// The kc (<= 64 R) best of the keys a query's slices appended (unsorted runs), ascending, one block per query (the
 /// 4 wavefronts take interleaved 256-key chunks, then a rank merge): out[q][kc] (KEY_NONE padded);
 /// bound[q] = the smallest key any slice may have cut (from qthr; KEY_NONE if none).
+template <int R> // kc <= 64 R
 static __global__ __launch_bounds__(BLOCK) void cand_select_kernel(const uint64_t * buf, const uint32_t * qcnt,
                                                                     const uint32_t * qthr, uint32_t cap, uint32_t nq,
                                                                     uint32_t kc, uint64_t * out, uint64_t * bound)
 {
-    __shared__ uint64_t lds[5 * 64];
+    __shared__ uint64_t lds[5 * 64 * R];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
     const uint32_t n = qcnt[q] < cap ? qcnt[q] : cap;
     const uint64_t * src = buf + (size_t)q * cap;
-    WaveTopK<1> top;
+    WaveTopK<R> top;
     top.init();
     for (uint32_t base = wave * 4 * WAVE; base < n; base += 4 * 4 * WAVE)
     {
@@ -878,8 +879,8 @@ __device__ __forceinline__ double rerank_eps(const RerankParams & a, double sx, 
 
 /// One block of 16 G threads per query: G groups of 16 lanes, a group per candidate row and round.  G = 16; 32 (all
 /// candidates of a k <= 12 search in flight at once) measured SLOWER: 70 against 47 us per 4096 queries -- kept as a knob.
-/// dynamic LDS: ld4*16 + 64*8 bytes.
-template <int METRIC, int G>
+/// dynamic LDS: ld4*16 + 64*R*8 bytes.
+template <int METRIC, int G, int R> // R: kc <= 64 R (256 candidates for 40 < k <= 128)
 __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a)
 {
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
@@ -888,8 +889,8 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
     const uint32_t q = blockIdx.x, ld4 = a.ld4, kc = a.kc;
     for (uint32_t c = tid; c < ld4; c += 16 * G)
         qs[c] = a.Q[(size_t)q * ld4 + c];
-    if (tid < 64)
-        keys[tid] = KEY_NONE;
+    for (uint32_t c = tid; c < 64 * R; c += 16 * G)
+        keys[c] = KEY_NONE;
     __syncthreads();
     const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
     // Early exit: the candidates arrive in ascending approximate order, G per round.  Once the first ceil(k / G) rounds
@@ -908,9 +909,11 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
             __syncthreads();
             if (wave == 0)
             {
-                WaveTopK<1> t0;
+                WaveTopK<R> t0;
                 t0.init();
-                t0.offer(lane < first ? keys[lane] : KEY_NONE, a.k, lane);
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    t0.offer(r * 64 + lane < first ? keys[r * 64 + lane] : KEY_NONE, a.k, lane);
                 const float qn = a.qnorm[q];
                 const bool usable = t0.thr != KEY_NONE && qn < 1e30f && a.xmax < 1e30f;
                 if (lane == 0)
@@ -964,22 +967,26 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
     __syncthreads();
     if (wave != 0)
         return;
-    WaveTopK<1> top;
+    WaveTopK<R> top;
     top.init();
-    top.offer(lane < kc ? keys[lane] : KEY_NONE, a.k, lane);
-    if (lane < a.k)
-    {
-        const uint64_t key = top.v[0];
-        const size_t o = (size_t)q * a.k + lane;
-        if (a.out_probes)
-            a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
-        else
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        top.offer(r * 64 + lane < kc ? keys[r * 64 + lane] : KEY_NONE, a.k, lane);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (r * 64 + lane < a.k)
         {
-            a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
-            const float v = key_value<METRIC>(key);
-            a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+            const uint64_t key = top.v[r];
+            const size_t o = (size_t)q * a.k + r * 64 + lane;
+            if (a.out_probes)
+                a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
+            else
+            {
+                a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
+                const float v = key_value<METRIC>(key);
+                a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+            }
         }
-    }
     // certificate (see the header comment): `last` = the smallest approximate key a non-candidate row can have; a
     // candidate list that is not full (and no truncated slice) holds every probed row
     uint64_t last = a.cand[(size_t)q * kc + kc - 1];

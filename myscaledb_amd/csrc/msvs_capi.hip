@@ -1180,9 +1180,11 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     {
         const int mode = allow_pass ? (int)options().ivf_pass : 0; // experiment knob: 0 = never, 2 = whenever eligible
         // row positions travel in the low word of the candidate keys: < 2^32 rows; NaN norms compare false
-        const bool eligible = k <= 40 && ix.xnorm.p && ix.xnorm_max < 1e30f && ix.n <= 0xfffffff0ull;
         // the shadow pass keeps a whole query tile in LDS: at least one column block of 32 queries must fit
         const bool h16 = ix.shadow_ready && options().ivf_h16 != 0 && h16_lds_bytes(1, ix.h_nch) <= 160 * 1024;
+        // k <= 40: 64 candidates; the shadow pass also serves 40 < k <= 128 with 256 (hybrid searches take a vector top-100)
+        const bool eligible = (k <= 40 || (h16 && k <= 128 && options().h16_k128 != 0)) && ix.xnorm.p && ix.xnorm_max < 1e30f
+            && ix.n <= 0xfffffff0ull;
         const double min_pairs = h16 ? options().h16_min_pairs : 4.0;
         if (mode != 0 && eligible && ((double)pairs >= min_pairs * (double)nlist || mode >= 2))
         {
@@ -1221,9 +1223,9 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
             // (4096 q/step: 1.92 vs 1.70 ms, 16384: 6.01 vs 5.89 ms): kept as a knob only
             p.nqg = options().ivf_nqg == 2 ? 2 : 1;
             p.T = BG_TQ * p.nqg;
-            p.kc = k <= 12 ? 32 : 64;
+            p.kc = k <= 12 ? 32 : k <= 40 ? 64 : 256;
             if (p.h16 && options().h16_kc >= k) // experiment knob: candidates per query of the shadow pass
-                p.kc = (uint32_t)std::min<double>(64, options().h16_kc);
+                p.kc = (uint32_t)std::min<double>(k <= 40 ? 64 : 256, options().h16_kc);
             // work item = 1 slice of a list for a tile of <= 128 queries, a grid of 4096 blocks: with the selection cheap,
             // the finest granularity balances best (2 slices / 2048 blocks: +5-8 % step time at 1024 .. 16384 q/step)
             p.rpb = BG_ROWS;

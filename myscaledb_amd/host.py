@@ -18,7 +18,8 @@ SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_h
            "msvs_text_index_commit", "msvs_text_index_save", "msvs_text_index_load", "msvs_text_index_total_num_docs",
            "msvs_text_index_total_num_tokens", "msvs_text_index_doc_freq", "msvs_text_index_set_alive",
            "msvs_text_index_bm25_search", "msvs_text_index_bm25_search_batch", "msvs_host_fts_index_statistics",
-           "msvs_host_fts_statistics_merge", "msvs_fts_stats_view", "msvs_fts_stats_free", "msvs_host_concurrent_search"]
+           "msvs_host_fts_statistics_merge", "msvs_fts_stats_view", "msvs_fts_stats_free", "msvs_host_concurrent_search",
+           "msvs_host_hybrid_search_batch"]
 
 _lib = None
 
@@ -153,6 +154,24 @@ def hybrid_search(fusion_type, vec, txt, topk, fusion_k=60, fusion_weight=0.5, v
                                       C.c_float(fusion_weight), int(vector_scan_direction), C.c_size_t(topk),
                                       _p(os_, C.c_float), _p(op, C.c_uint64), _p(ol, C.c_uint64))
     return os_[:n], op[:n], ol[:n]
+
+
+def hybrid_search_batch(fusion_type, vec_dis, vec_ids, txt_scores, txt_ids, topk, fusion_k=60, fusion_weight=0.5,
+                        vector_scan_direction=1):
+    """msvs_host_hybrid_search_batch: [nq, kv] vector rows + [nq, kt] text rows (ids < 0 = no row) -> (scores [nq, topk],
+    labels [nq, topk], counts [nq])."""
+    vd, vi = _f32(vec_dis), np.ascontiguousarray(vec_ids, np.int64)
+    ts, ti = _f32(txt_scores), np.ascontiguousarray(txt_ids, np.int64)
+    nq, kv = vi.shape
+    kt = ti.shape[1]
+    os_, ol, cnt = np.zeros((nq, topk), np.float32), np.zeros((nq, topk), np.uint64), np.zeros(nq, np.uint32)
+    rc = lib().msvs_host_hybrid_search_batch(1 if fusion_type == "rsf" else 0, _p(vd, C.c_float), _p(vi, C.c_int64), C.c_size_t(kv),
+                                             _p(ts, C.c_float), _p(ti, C.c_int64), C.c_size_t(kt), C.c_size_t(nq),
+                                             C.c_uint64(int(fusion_k)), C.c_float(fusion_weight), int(vector_scan_direction),
+                                             C.c_size_t(topk), _p(os_, C.c_float), _p(ol, C.c_uint64), _p(cnt, C.c_uint32))
+    if rc != 0:
+        raise capi.MsvsError(rc, "msvs_host_hybrid_search_batch: invalid argument")
+    return os_, ol, cnt
 
 
 def fusion_transform(fusion_type, score, score_type, shard_num, part_index, part_offset, num_candidates, fusion_k=60,

@@ -697,6 +697,48 @@ extern "C" size_t msvs_host_hybrid_search(int fusion_type, const float * vec_sco
     return r.size();
 }
 
+/* The same fusion for a BATCH of queries straight from the device searches' output arrays: query q's vector rows are
+ * vec_dis / vec_ids[q * kv ...] (id < 0 ends the list, like the host's `> -1` unpack), its text rows txt_scores / txt_ids[q * kt ...];
+ * one part (part index 0).  out_*[q * topk ...], n_out[q] rows each. */
+extern "C" int msvs_host_hybrid_search_batch(int fusion_type, const float * vec_dis, const int64_t * vec_ids, size_t kv,
+                                             const float * txt_scores, const int64_t * txt_ids, size_t kt, size_t nq, uint64_t fusion_k,
+                                             float fusion_weight, int vector_scan_direction, size_t topk, float * out_scores,
+                                             uint64_t * out_labels, uint32_t * n_out)
+{
+    if ((nq && (!vec_dis || !vec_ids || !txt_scores || !txt_ids || !out_scores || !out_labels || !n_out)) || topk == 0)
+        return MSVS_ERR_INVALID_ARGUMENT;
+    DB::HybridSearchInfo info;
+    info.fusion_type = fusion_type == 1 ? "rsf" : "rrf";
+    info.fusion_k = static_cast<int>(fusion_k);
+    info.fusion_weight = fusion_weight;
+    info.topk = static_cast<int>(topk);
+    info.vector_scan_direction = vector_scan_direction;
+    std::vector<uint64_t> parts(std::max(kv, kt), 0), lab;
+    for (size_t q = 0; q < nq; q++)
+    {
+        size_t nv = 0, nt = 0;
+        while (nv < kv && vec_ids[q * kv + nv] > -1)
+            nv++;
+        while (nt < kt && txt_ids[q * kt + nt] > -1)
+            nt++;
+        lab.resize(nv + nt);
+        for (size_t i = 0; i < nv; i++)
+            lab[i] = (uint64_t)vec_ids[q * kv + i];
+        for (size_t i = 0; i < nt; i++)
+            lab[nv + i] = (uint64_t)txt_ids[q * kt + i];
+        auto r = DB::MergeTreeHybridSearchManager::hybridSearch(make_list(vec_dis + q * kv, parts.data(), lab.data(), nv),
+                                                                make_list(txt_scores + q * kt, parts.data(), lab.data() + nv, nt), info);
+        const size_t n = std::min(r.size(), topk);
+        for (size_t i = 0; i < n; i++)
+        {
+            out_scores[q * topk + i] = r[i].score;
+            out_labels[q * topk + i] = r[i].label_id;
+        }
+        n_out[q] = (uint32_t)n;
+    }
+    return MSVS_OK;
+}
+
 /* HybridSearchFusionTransform::generate over flat arrays; returns the number of output rows. */
 extern "C" size_t msvs_host_fusion_transform(int fusion_type, const float * score, const uint8_t * score_type, const uint32_t * shard_num,
                                              const uint64_t * part_index, const uint64_t * part_offset, size_t n_rows,

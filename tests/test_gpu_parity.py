@@ -422,6 +422,48 @@ def test_selection_plan_and_fallback_variants_agree_with_the_oracle(knobs, opt):
         same(ids, dis, oi, od)
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_COSINE])
+def test_shadow_pass_serves_k_up_to_128_with_256_candidates(metric, opt):
+    """40 < k <= 128 (a hybrid search takes the vector top-100): the fp16-shadow pass with 256 candidates per query, the
+    insertion select with four registers per lane, the re-rank's four-register top-k and its early exit after the first
+    ceil(k / 16) rounds; forced certificate failures (canonical fallback with k = 100); h16_k128 = 0 = the canonical scan."""
+    rng = np.random.default_rng(4100)
+    n, d, nlist, nq, nprobe = 60000, 64, 64, 320, 8
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, metric, nlist)
+    for k in (41, 100, 128):
+        oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+        q0, f0 = capi.prefilter_stats()
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+        q1, f1 = capi.prefilter_stats()
+        assert q1 - q0 == nq and f1 - f0 <= nq // 10  # the candidate pass ran, few fallbacks
+        if k == 100:
+            opt("ivf_eps_scale", "1e12")
+            ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+            same(ids, dis, oi, od)
+            assert capi.prefilter_stats()[1] - f1 == nq
+            opt("ivf_eps_scale", None)
+            opt("rerank_early", "0")
+            ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+            same(ids, dis, oi, od)
+            opt("rerank_early", None)
+            opt("h16_k128", "0")
+            q2 = capi.prefilter_stats()[0]
+            ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+            same(ids, dis, oi, od)
+            assert capi.prefilter_stats()[0] == q2  # canonical path
+            opt("h16_k128", None)
+    # k = 129: beyond the pass
+    q2 = capi.prefilter_stats()[0]
+    oi, od, _ = oracle_on_exported(ix, q[:40], nprobe, 129, metric)
+    ids, dis = ix.search(q[:40], 129, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    assert capi.prefilter_stats()[0] == q2
+
+
 def test_matrix_core_pass_with_massive_ties_and_unusable_norms():
     rng = np.random.default_rng(77)
     n, d, nlist, nq = 6000, 48, 4, 128

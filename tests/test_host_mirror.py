@@ -357,3 +357,28 @@ def test_distributed_fusion_transform_matches_the_oracle_fusion(kind, direction)
     assert rows[:nc].tolist() == tsel
     rest = [r for r in sorted(dsel) if allid[r] not in {allid[t] for t in tsel}]
     assert rows[nc:].tolist() == rest
+
+
+def test_hybrid_search_batch_equals_the_per_query_fusion():
+    """msvs_host_hybrid_search_batch over the device searches' [nq, k] output arrays (ids < 0 = no row) against
+    msvs_host_hybrid_search query by query, RRF and RSF."""
+    rng = np.random.default_rng(12)
+    nq, kv, kt = 9, 20, 15
+    vd = np.sort(rng.random((nq, kv)).astype(np.float32), axis=1)
+    vi = np.stack([rng.permutation(60)[:kv] for _ in range(nq)]).astype(np.int64)
+    td = -np.sort(-rng.random((nq, kt)).astype(np.float32) * 10, axis=1)
+    ti = np.stack([rng.permutation(60)[:kt] for _ in range(nq)]).astype(np.int64)
+    vi[3, 12:] = -1  # short lists
+    ti[5, 4:] = -1
+    ti[7, :] = -1
+    z = np.zeros(max(kv, kt), np.uint64)
+    for fusion in ("rrf", "rsf"):
+        bs, bl, bn = host.hybrid_search_batch(fusion, vd, vi, td, ti, 10, fusion_k=60, fusion_weight=0.3)
+        for q in range(nq):
+            nv, nt = int((vi[q] >= 0).sum()), int((ti[q] >= 0).sum())
+            s1, _, l1 = host.hybrid_search(fusion, (vd[q][:nv], z[:nv], vi[q][:nv].astype(np.uint64)),
+                                           (td[q][:nt], z[:nt], ti[q][:nt].astype(np.uint64)), 10, fusion_k=60, fusion_weight=0.3)
+            assert bn[q] == len(l1)
+            assert bl[q][:bn[q]].tolist() == l1.tolist()
+            assert bs[q][:bn[q]].view(np.uint32).tolist() == s1.view(np.uint32).tolist()
+
