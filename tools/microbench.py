@@ -88,7 +88,7 @@ def ivf_cosine_case(n, d, nlist, batch, nprobe, k, dev, metric=capi.METRIC_COSIN
     f1 = capi.prefilter_stats()
     print("%s IVFFLAT %s %dx%d nlist=%d batch=%d nprobe=%d k=%d : build %.1f s, %.3f ms/batch  %.0f QPS ; rows/query %.0f ; "
           "union %.2f GB -> %.0f GB/s, per-query model %.2f GB ; candidate pass (queries, fallbacks) per batch = (%d, %d)"
-          % (name, "cosine" if metric == capi.METRIC_COSINE else "L2", n, d, nlist, batch, nprobe, k, build_s, dt * 1e3,
+          % (name, {capi.METRIC_COSINE: "cosine", capi.METRIC_IP: "IP"}.get(metric, "L2"), n, d, nlist, batch, nprobe, k, build_s, dt * 1e3,
              batch / dt, rows / batch, uniq * rb / 1e9, uniq * rb / dt / 1e9, rows * rb / 1e9, f1[0] - f0[0],
              f1[1] - f0[1]), flush=True)
     ix.close()
@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--big-rows", type=int, default=0,
                     help="C4s: IVFFLAT L2 on this many rows x 768 (nlist = rows / 2048, nprobe 64, 4096 queries per batch); "
                          "needs ~3 x rows x 3 KB of HBM during the build")
+    ap.add_argument("--c4-rows", type=int, default=0,
+                    help="C4 shard shape: IVFFLAT inner product on this many rows x 1536 (nlist = rows / 1536, nprobe 64), batches "
+                         "of 64 / 1024 / 4096 -- one GPU's share of BASELINE config 4 is 12.5M rows")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     capi.set_device(0)
@@ -167,6 +170,10 @@ def main():
     if a.big_rows:
         nl = max(1024, a.big_rows // 2048)
         ivf_cosine_case(a.big_rows, 768, nl, 4096, 64, 10, dev, metric=capi.METRIC_L2, name="C4s", blobs=nl)
+    if a.c4_rows:
+        nl = max(1024, a.c4_rows // 1536)
+        for b in (4096, 1024, 64):
+            ivf_cosine_case(a.c4_rows, 1536, nl, b, 64, 10, dev, metric=capi.METRIC_IP, name="C4-shard", blobs=nl)
     if "c5h" not in a.skip and "c5" not in a.skip:
         hybrid_case(a.rows, 768, 4096, 32, 200_000, dev)
     if "c5" not in a.skip:
