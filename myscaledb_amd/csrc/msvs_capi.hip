@@ -2656,7 +2656,18 @@ int combined_search(const msvs_index * ix, const float * queries, size_t nq, int
         }
     }
     lk.unlock();
-    combine_run(ix, me); // never throws: the C entry underneath translates
+    try
+    {
+        combine_run(ix, me); // the C entry underneath translates its own exceptions; what is left is the gather's allocation
+    }
+    catch (...)
+    {
+        for (auto * r : me.batch)
+        {
+            r->status = MSVS_ERR_OOM;
+            r->err = "host allocation failed while combining concurrent searches";
+        }
+    }
     lk.lock();
     for (auto * r : me.batch)
         if (r != &me)
