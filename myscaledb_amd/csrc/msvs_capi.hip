@@ -2664,7 +2664,7 @@ int combined_search(const msvs_index * ix, const float * queries, size_t nq, int
     {
         for (auto * r : me.batch)
         {
-            r->status = MSVS_ERR_OOM;
+            r->status = MSVS_ERR_OUT_OF_MEMORY;
             r->err = "host allocation failed while combining concurrent searches";
         }
     }
