@@ -371,14 +371,44 @@ def test_hybrid_search_batch_equals_the_per_query_fusion():
     vi[3, 12:] = -1  # short lists
     ti[5, 4:] = -1
     ti[7, :] = -1
+    # ties: equal scores inside a list, the same label at the same ranks of both lists, a label twice in one list
+    vd[1] = np.repeat(np.arange(kv // 4, dtype=np.float32), 4)[:kv]
+    td[1] = 3.0
+    ti[1, :kt] = vi[1, :kt]
+    vi[2, 5] = vi[2, 1]
+    ti[2, 3] = ti[2, 0]
+    vd[4] = 0.5  # all distances equal: normalised scores are all 1
     z = np.zeros(max(kv, kt), np.uint64)
-    for fusion in ("rrf", "rsf"):
-        bs, bl, bn = host.hybrid_search_batch(fusion, vd, vi, td, ti, 10, fusion_k=60, fusion_weight=0.3)
+    for fusion, direction in (("rrf", 1), ("rsf", 1), ("rsf", -1)):
+        bs, bl, bn = host.hybrid_search_batch(fusion, vd, vi, td, ti, 10, fusion_k=60, fusion_weight=0.3, vector_scan_direction=direction)
         for q in range(nq):
             nv, nt = int((vi[q] >= 0).sum()), int((ti[q] >= 0).sum())
             s1, _, l1 = host.hybrid_search(fusion, (vd[q][:nv], z[:nv], vi[q][:nv].astype(np.uint64)),
-                                           (td[q][:nt], z[:nt], ti[q][:nt].astype(np.uint64)), 10, fusion_k=60, fusion_weight=0.3)
+                                           (td[q][:nt], z[:nt], ti[q][:nt].astype(np.uint64)), 10, fusion_k=60, fusion_weight=0.3,
+                                           vector_scan_direction=direction)
             assert bn[q] == len(l1)
             assert bl[q][:bn[q]].tolist() == l1.tolist()
+            assert bs[q][:bn[q]].view(np.uint32).tolist() == s1.view(np.uint32).tolist()
+
+
+def test_hybrid_search_batch_random_ties_against_the_map_based_fusion():
+    """Quantised scores and a small label range: many equal fused scores, most labels in both lists."""
+    rng = np.random.default_rng(77)
+    nq, kv, kt = 120, 12, 9
+    vd = np.sort(np.round(rng.random((nq, kv)) * 4) / 4, axis=1).astype(np.float32)
+    td = -np.sort(-np.round(rng.random((nq, kt)) * 3), axis=1).astype(np.float32)
+    vi = np.stack([rng.permutation(16)[:kv] for _ in range(nq)]).astype(np.int64)
+    ti = np.stack([rng.permutation(16)[:kt] for _ in range(nq)]).astype(np.int64)
+    for q in range(0, nq, 7):
+        vi[q, rng.integers(3, kv):] = -1
+    z = np.zeros(max(kv, kt), np.uint64)
+    for fusion, direction, w in (("rrf", 1, 0.5), ("rsf", 1, 0.5), ("rsf", -1, 0.25)):
+        bs, bl, bn = host.hybrid_search_batch(fusion, vd, vi, td, ti, 7, fusion_k=3, fusion_weight=w, vector_scan_direction=direction)
+        for q in range(nq):
+            nv, nt = int((vi[q] >= 0).sum()), int((ti[q] >= 0).sum())
+            s1, _, l1 = host.hybrid_search(fusion, (vd[q][:nv], z[:nv], vi[q][:nv].astype(np.uint64)),
+                                           (td[q][:nt], z[:nt], ti[q][:nt].astype(np.uint64)), 7, fusion_k=3, fusion_weight=w,
+                                           vector_scan_direction=direction)
+            assert bn[q] == len(l1) and bl[q][:bn[q]].tolist() == l1.tolist(), (fusion, q)
             assert bs[q][:bn[q]].view(np.uint32).tolist() == s1.view(np.uint32).tolist()
 
