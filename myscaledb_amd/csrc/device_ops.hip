@@ -478,6 +478,8 @@ void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint3
                            bound, options().wave_select == 3 ? 0 : 1, options().rerank_early != 0 ? 1 : 0);
     else if (kc <= 64)
         hipLaunchKernelGGL(cand_select_kernel<1>, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
+    else if (options().wave_select != 0)
+        hipLaunchKernelGGL(cand_select_block_kernel, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
     else
         hipLaunchKernelGGL(cand_select_kernel<4>, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
     MSVS_HIP(hipGetLastError());

@@ -842,6 +842,98 @@ static __global__ __launch_bounds__(BLOCK) void cand_select_kernel(const uint64_
         bound[q] = qcnt[q] > cap ? 0 : (qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32);
 }
 
+/// The kc (<= 256) best of a query's candidate buffer by a BLOCK-wide radix select (one block per query, any buffer
+/// size): four passes over the high words -- an LDS histogram of the current byte among the keys still inside the
+/// prefix, a 256-thread prefix sum, the bin that holds the kc-th -- then the keys below the value and the ties are
+/// collected in LDS and ranked against each other, so out[q][kc] is ascending (KEY_NONE padded).  The insertion kernel
+/// above needs ~kc (1 + ln(n / kc)) serial list insertions per wavefront: 1.03 ms per 4096 queries at kc = 256,
+/// n ~ 2500 (k = 100), against ~0.03 ms here.
+static __global__ __launch_bounds__(BLOCK) void cand_select_block_kernel(const uint64_t * buf, const uint32_t * qcnt,
+                                                                          const uint32_t * qthr, uint32_t cap, uint32_t nq,
+                                                                          uint32_t kc, uint64_t * out, uint64_t * bound)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wsum[BLOCK / WAVE];
+    __shared__ uint32_t s_digit, s_below, s_cnt;
+    __shared__ uint64_t sel[256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    const uint32_t n = qcnt[q] < cap ? qcnt[q] : cap;
+    const uint64_t * src = buf + (size_t)q * cap;
+    const bool all = n <= kc; // every key is a candidate
+    uint32_t H = 0, need = kc;
+    if (!all)
+        for (int shift = 24; shift >= 0; shift -= 8)
+        {
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t pmask = shift == 24 ? 0u : ~0u << (shift + 8); // the bits fixed so far
+            for (uint32_t i = tid; i < n; i += BLOCK)
+            {
+                const uint32_t hi = (uint32_t)(src[i] >> 32);
+                if ((hi & pmask) == H)
+                    atomicAdd(&hist[(hi >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            const uint32_t own = hist[tid]; // thread t owns bin t: inclusive prefix sum over the block
+            uint32_t incl = own;
+            incl += dpp32<0x111>(incl);
+            incl += dpp32<0x112>(incl);
+            incl += dpp32<0x114>(incl);
+            incl += dpp32<0x118>(incl);
+            const uint32_t r0 = __builtin_amdgcn_readlane((int)incl, 15), r1 = __builtin_amdgcn_readlane((int)incl, 31),
+                           r2 = __builtin_amdgcn_readlane((int)incl, 47);
+            incl += lane < 16 ? 0u : lane < 32 ? r0 : lane < 48 ? r0 + r1 : r0 + r1 + r2;
+            if (lane == 63)
+                wsum[wave] = incl;
+            __syncthreads();
+            for (uint32_t w = 0; w < wave; w++)
+                incl += wsum[w];
+            if (incl - own < need && need <= incl) // exactly one bin holds the rank
+            {
+                s_digit = tid;
+                s_below = incl - own;
+            }
+            __syncthreads();
+            H |= s_digit << shift;
+            need -= s_below;
+            __syncthreads();
+        }
+    if (tid == 0)
+        s_cnt = 0;
+    sel[tid] = KEY_NONE;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += BLOCK) // below the kc-th value: fewer than kc keys
+    {
+        const uint64_t key = src[i];
+        if (all || (uint32_t)(key >> 32) < H)
+            sel[atomicAdd(&s_cnt, 1u)] = key;
+    }
+    __syncthreads();
+    if (!all)
+        for (uint32_t i = tid; i < n; i += BLOCK) // at the value: as many as there is room for
+        {
+            const uint64_t key = src[i];
+            if ((uint32_t)(key >> 32) == H)
+            {
+                const uint32_t pos = atomicAdd(&s_cnt, 1u);
+                if (pos < kc)
+                    sel[pos] = key;
+            }
+        }
+    __syncthreads();
+    const uint64_t mine = sel[tid];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < 256; j++)
+    {
+        const uint64_t other = sel[j];
+        rank += other < mine || (other == mine && j < tid) ? 1u : 0u;
+    }
+    if (rank < kc)
+        out[(size_t)q * kc + rank] = mine;
+    if (tid == 0) // an overflowed buffer dropped unknown keys: bound 0 = nothing can be certified
+        bound[q] = qcnt[q] > cap ? 0 : (qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32);
+}
+
 struct RerankParams
 {
     const float4 * Y;      // rows, ld4 float4 each
@@ -901,30 +993,35 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
     // gains nothing (measured), so the host leaves it off there and its candidates unsorted.
     __shared__ double s_e, s_eps;
     __shared__ int s_skip;
+    __shared__ uint64_t s_ek;
     const uint32_t first = a.early_exit && kc % G == 0 ? (a.k + G - 1) / G * G : kc; // every group walks kc / G rounds: the barrier is uniform
     for (uint32_t c = grp; c < kc; c += G)
     {
         if (c - grp == first) // uniform over the block: the first rounds are complete
         {
             __syncthreads();
-            if (wave == 0)
+            // the exact k-th key among the first rounds' results: every key ranks itself (keys are distinct up to duplicates
+            // of a row, which rank by their slot); a sorted-list insertion per key took 17 us per block at kc = 256
+            for (uint32_t i = tid; i < first; i += 16 * G)
             {
-                WaveTopK<R> t0;
-                t0.init();
-#pragma unroll
-                for (int r = 0; r < R; r++)
-                    t0.offer(r * 64 + lane < first ? keys[r * 64 + lane] : KEY_NONE, a.k, lane);
+                const uint64_t mine = keys[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < first; j++)
+                    rank += keys[j] < mine || (keys[j] == mine && j < i) ? 1u : 0u;
+                if (rank == a.k - 1)
+                    s_ek = mine;
+            }
+            __syncthreads();
+            if (tid == 0)
+            {
                 const float qn = a.qnorm[q];
-                const bool usable = t0.thr != KEY_NONE && qn < 1e30f && a.xmax < 1e30f;
-                if (lane == 0)
+                const bool usable = s_ek != KEY_NONE && qn < 1e30f && a.xmax < 1e30f;
+                s_skip = usable ? 1 : 0;
+                if (usable)
                 {
-                    s_skip = usable ? 1 : 0;
-                    if (usable)
-                    {
-                        const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
-                        s_e = (double)key_value<METRIC>(t0.thr);
-                        s_eps = rerank_eps<METRIC>(a, sx, sq);
-                    }
+                    const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
+                    s_e = (double)key_value<METRIC>(s_ek);
+                    s_eps = rerank_eps<METRIC>(a, sx, sq);
                 }
             }
             __syncthreads();
@@ -965,28 +1062,31 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
             keys[c] = make_key<METRIC>(s, a.ids ? a.ids[pos] : pos);
     }
     __syncthreads();
-    if (wave != 0)
-        return;
-    WaveTopK<R> top;
-    top.init();
-#pragma unroll
-    for (int r = 0; r < R; r++)
-        top.offer(r * 64 + lane < kc ? keys[r * 64 + lane] : KEY_NONE, a.k, lane);
-#pragma unroll
-    for (int r = 0; r < R; r++)
-        if (r * 64 + lane < a.k)
+    // exact top-k of the evaluated candidates: every key ranks itself among the 64 R slots (skipped / absent = KEY_NONE)
+    for (uint32_t i = tid; i < 64 * R; i += 16 * G)
+    {
+        const uint64_t mine = keys[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < 64 * R; j++)
+            rank += keys[j] < mine || (keys[j] == mine && j < i) ? 1u : 0u;
+        if (rank < a.k)
         {
-            const uint64_t key = top.v[r];
-            const size_t o = (size_t)q * a.k + r * 64 + lane;
+            const size_t o = (size_t)q * a.k + rank;
             if (a.out_probes)
-                a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
+                a.out_probes[o] = mine == KEY_NONE ? -1 : (int32_t)(uint32_t)mine;
             else
             {
-                a.out_ids[o] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
-                const float v = key_value<METRIC>(key);
+                a.out_ids[o] = mine == KEY_NONE ? -1 : (int64_t)(uint32_t)mine;
+                const float v = key_value<METRIC>(mine);
                 a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
             }
+            if (rank == a.k - 1)
+                s_ek = mine;
         }
+    }
+    __syncthreads();
+    if (wave != 0)
+        return;
     // certificate (see the header comment): `last` = the smallest approximate key a non-candidate row can have; a
     // candidate list that is not full (and no truncated slice) holds every probed row
     uint64_t last = a.cand[(size_t)q * kc + kc - 1];
@@ -995,7 +1095,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
     bool ok = true;
     if (last != KEY_NONE)
     {
-        const uint64_t ek = top.thr;
+        const uint64_t ek = s_ek;
         const float qn = a.qnorm[q];
         if (ek == KEY_NONE || !(qn < 1e30f) || !(a.xmax < 1e30f))
             ok = false;

@@ -1207,7 +1207,10 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 // cut (h16_sample_thr_kernel).  target = 25 k: m ~ 9 on lists of ~1000 rows; the certificate fails when
                 // fewer than k rows do (>= m of the k + m best rows fell into the sample: ~1e-6 there, and the floor m = 4
                 // is only reached when the sample is a small fraction of the probed rows)
-                p.h_mth = options().h16_nocut != 0 ? 0u : (uint32_t)std::max<size_t>(64, 25 * (size_t)k); // the target
+                // ... k > 40 (256 candidates re-ranked): 10 k, at least what k = 40 gets -- the sample's rank noise is relative
+                p.h_mth = options().h16_nocut != 0 ? 0u
+                                                    : (uint32_t)(k <= 40 ? std::max<size_t>(64, 25 * (size_t)k)
+                                                                         : std::max<size_t>(1000, 10 * (size_t)k)); // the target
                 // capacity: 8 x the target, and 2.5 x what the floor m = 4 leaves below the cut when every probed list is as
                 // long as the longest one (sample fraction 32 / max_list_len)
                 size_t cap = std::min<size_t>(std::max<size_t>(std::max<size_t>(1024, round_up(8 * (size_t)p.h_mth, 256)),

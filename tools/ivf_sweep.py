@@ -16,7 +16,7 @@ import myscaledb_amd.capi as capi  # noqa: E402
 from bench import make_data, make_queries  # noqa: E402
 
 dev = torch.device("cuda", 0)
-n, d, nlist, nprobe, k = int(os.environ.get("SWEEP_ROWS", 1_000_000)), 768, 1024, 32, 10
+n, d, nlist, nprobe, k = int(os.environ.get("SWEEP_ROWS", 1_000_000)), 768, 1024, 32, int(os.environ.get("SWEEP_K", 10))
 IID = os.environ.get("SWEEP_IID") == "1"  # rows and queries iid N(0,1)^768 instead of the bench mixture
 model, x = make_data(n, d, 1234, dev)
 if IID:
