@@ -1211,6 +1211,8 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 p.h_mth = options().h16_nocut != 0 ? 0u
                                                     : (uint32_t)(k <= 40 ? std::max<size_t>(64, 25 * (size_t)k)
                                                                          : std::max<size_t>(1000, 10 * (size_t)k)); // the target
+                if (options().h16_target >= 1 && options().h16_nocut == 0) // experiment knob
+                    p.h_mth = (uint32_t)options().h16_target;
                 // capacity: 8 x the target, and 2.5 x what the floor m = 4 leaves below the cut when every probed list is as
                 // long as the longest one (sample fraction 32 / max_list_len)
                 size_t cap = std::min<size_t>(std::max<size_t>(std::max<size_t>(1024, round_up(8 * (size_t)p.h_mth, 256)),
