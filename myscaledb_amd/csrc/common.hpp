@@ -148,6 +148,8 @@ struct Options
     double combine = 8;       // msvs_index_search: single-query callers beyond this many in flight are batched by the next finisher (0: off)
     double combine_batches = 1; // ... and at most this many combined batches in flight
     double h16_k128 = 1;      // shadow pass for 40 < k <= 128 with 256 candidates (0: the canonical scan as before)
+    double h16_cut_floor = 0; // experiment: the sample cut kept >= 2.2 eps beyond the third best sample row (measured: 10 -> 4
+                              // fallbacks per 94 208 queries on the mixture, but 2 -> 8 and +3 % step time on iid gaussians: off)
     double h16_target = 0;    // rows of a query's probed lists the sample cut aims to keep (0: 25 k, 10 k beyond k = 40)
     double h16_kc = 0;        // candidates re-ranked per query after the fp16-shadow list scan (0: 32 for k <= 12, else 64)
     double coarse_kc = 0;     // ... after the centroid-shadow pass

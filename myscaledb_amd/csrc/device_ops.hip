@@ -596,7 +596,7 @@ const OptionField g_option_fields[] = {
     {"bm25_fine_sample", &Options::bm25_fine_sample}, {"lat_select", &Options::lat_select},
     {"rerank_stats", &Options::rerank_stats},   {"rerank_early", &Options::rerank_early},
     {"rerank_groups", &Options::rerank_groups}, {"combine", &Options::combine},           {"h16_k128", &Options::h16_k128},
-    {"h16_target", &Options::h16_target},
+    {"h16_target", &Options::h16_target},       {"h16_cut_floor", &Options::h16_cut_floor},
     {"combine_batches", &Options::combine_batches},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},

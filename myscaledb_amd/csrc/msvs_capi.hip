@@ -1799,9 +1799,23 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         else
             hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
         if (nprobe <= 64 && options().wave_select != 0)
+        {
+            H16CutFloor fl{};
+            if (options().h16_cut_floor != 0)
+            {
+                RerankParams em{};
+                set_error_model_h16(em, ix.dim);
+                fl.qnorm = qnorm;
+                fl.xmax = ix.xnorm_max;
+                fl.c_dot = em.c_dot;
+                fl.c_norm = em.c_norm;
+                fl.c_canon = em.c_canon;
+                fl.ip = scan_metric(m) == M_IP ? 1 : 0;
+            }
             hipLaunchKernelGGL(h16_sample_thr_wave_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
                                sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
-                               qstate + nq, partial, pl.h_cap, options().wave_select == 3 ? 0 : 1);
+                               qstate + nq, partial, pl.h_cap, options().wave_select == 3 ? 0 : 1, fl);
+        }
         else
             hipLaunchKernelGGL(h16_sample_thr_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
                                sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
