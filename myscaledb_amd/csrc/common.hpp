@@ -150,6 +150,8 @@ struct Options
     double h16_k128 = 1;      // shadow pass for 40 < k <= 128 with 256 candidates (0: the canonical scan as before)
     double h16_cut_floor = 0; // experiment: the sample cut kept >= 2.2 eps beyond the third best sample row (measured: 10 -> 4
                               // fallbacks per 94 208 queries on the mixture, but 2 -> 8 and +3 % step time on iid gaussians: off)
+    double coarse_h16_min_q = 192; // coarse quantiser through the centroid shadow from this many queries on (0: only with 128-query
+                                   // tiles, ~1000 queries); measured on nlist 1024: 512 queries -6 %, 256 -2.6 %, 64 +10 % (ten launches)
     double h16_target = 0;    // rows of a query's probed lists the sample cut aims to keep (0: 25 k, 10 k beyond k = 40)
     double h16_kc = 0;        // candidates re-ranked per query after the fp16-shadow list scan (0: 32 for k <= 12, else 64)
     double coarse_kc = 0;     // ... after the centroid-shadow pass

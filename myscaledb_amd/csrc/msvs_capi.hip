@@ -1376,6 +1376,15 @@ static bool table_pass_eligible(size_t n, const float * norms, float norm_max, s
         && ((items >= 256 && nq >= 16) || mode == 2);
 }
 
+/// The coarse quantiser through the centroid shadow needs no 128-query tiles: it pays from ~200 queries on (its ten
+/// launches cost ~85 us whatever the batch; the canonical centroid scan + merge of 64 / 256 / 512 queries 54 / 95 / 120 us).
+static bool coarse_shadow_eligible(const msvs_index & ix, size_t nq, size_t nprobe)
+{
+    return options().coarse_mfma != 0 && options().coarse_h16 != 0 && ix.c_shadow_ready && ix.cnorm.p && ix.cnorm_max < 1e30f
+        && nprobe <= 40 && ix.nlist >= 256 && options().coarse_h16_min_q >= 1 && nq >= (size_t)options().coarse_h16_min_q
+        && nq * round_up(ix.nlist, (size_t)H_ROWS) * 4 <= ((size_t)128 << 20);
+}
+
 /// The canonical fallback of a candidate pass: the queries on the device-side fail list are scanned and merged in ROUNDS of
 /// at most `cap` (their partial lists are indexed by the rank in the round), so the buffers are sized for `cap` queries
 /// instead of all nq -- normally nobody is on the list and every launch exits at once.
@@ -1985,7 +1994,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     int32_t * d_probes = probes_only ? probes_only : scr.take<int32_t>(nq * nprobe);
     if (given_probes)
         MSVS_HIP(hipMemcpyAsync(d_probes, given_probes, nq * nprobe * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-    else if (table_pass_eligible(ix.nlist, ix.cnorm.p, ix.cnorm_max, nq, (uint32_t)nprobe, options().coarse_mfma))
+    else if (table_pass_eligible(ix.nlist, ix.cnorm.p, ix.cnorm_max, nq, (uint32_t)nprobe, options().coarse_mfma)
+             || coarse_shadow_eligible(ix, nq, nprobe))
     {
         TablePass t{};
         // the centroid shadow: every approximate distance of the batch in one LDS-free MFMA launch (h16_scan_kernels.hpp)
