@@ -207,9 +207,20 @@ def main():
         if args.test_single_device:
             dist.init_process_group("gloo")
             comm = sharded.gloo_comm()
+            comm_kind = "gloo transport on host copies (test)"
         else:
             dist.init_process_group("nccl", device_id=dev)
-            comm = sharded.rccl_comm()  # RCCL communicator owned by libmsvs; torch only carried the unique id
+            try:
+                comm = sharded.rccl_comm()  # RCCL communicator owned by libmsvs; torch only carried the unique id
+                comm_kind = "RCCL communicator owned by libmsvs (msvs_comm_init)"
+            except Exception as e:  # noqa: BLE001 -- keep the N > 1 run alive; every rank takes the same branch or the all-reduce below fails
+                sys.stderr.write("rank %d: msvs_comm_init failed (%r): all-gathers through torch.distributed\n" % (rank, e))
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm = sharded.torch_comm()
+                comm_kind = "torch.distributed all_gather_into_tensor callback (msvs_comm_init_custom)"
 
     n, d, nlist, nprobe, k, B = args.rows, args.dim, args.nlist, args.nprobe, args.k, args.batch
     t_setup = time.time()
@@ -627,8 +638,8 @@ def main():
             "config": {"workload": "IVFFLAT nlist=%d, %dx%d f32, L2, nprobe=%d, top-%d, batch %d queries/step "
                                    "(BASELINE.json configs[1])" % (nlist, n, d, nprobe, k, B),
                        "rows": n, "dim": d, "nlist": nlist, "nprobe": nprobe, "k": k, "batch": B,
-                       "parallelism": ("lists %% %d, coarse quantiser by query, probe + packed top-k all-gathers (RCCL inside "
-                                       "libmsvs)" % world) if world > 1 else "single GPU",
+                       "parallelism": ("lists %% %d, coarse quantiser by query, probe + packed top-k all-gathers; transport: %s"
+                                       % (world, comm_kind)) if world > 1 else "single GPU",
                        "data_model": "1024-blob gaussian mixture in a 32-d latent space embedded in R^768 + 0.05 noise, seeds 99/1234/4321"},
             "recall_at_10": None if recall is None else round(recall, 4),
             "p50_ms_batch1": extra.get("latency", {}).get("p50_us", 0) / 1e3 if "latency" in extra and "p50_us" in extra["latency"] else None,

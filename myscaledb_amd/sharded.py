@@ -123,6 +123,28 @@ def rccl_comm(group=None):
     return capi.Comm(world, rank, id=box[0])
 
 
+def torch_comm(group=None):
+    """Fallback transport for bench.py: the all-gather of msvs_shard_search_device done by torch.distributed's own NCCL
+    (= RCCL) process group on device staging tensors, ordered on the caller's stream (the calls are issued from the thread
+    that owns torch's current stream).  Used only when libmsvs could not create its own communicator."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    stage = {}
+
+    def all_gather(d_send, d_recv, nbytes, stream):
+        if nbytes not in stage:
+            stage[nbytes] = (torch.empty(nbytes, dtype=torch.uint8, device="cuda"),
+                             torch.empty(nbytes * world, dtype=torch.uint8, device="cuda"))
+        snd, rcv = stage[nbytes]
+        if hip.hipMemcpyAsync(C.c_void_p(snd.data_ptr()), C.c_void_p(d_send), nbytes, 3, C.c_void_p(stream)) != 0:  # device -> device
+            return 1
+        dist.all_gather_into_tensor(rcv, snd, group=group)
+        return hip.hipMemcpyAsync(C.c_void_p(d_recv), C.c_void_p(rcv.data_ptr()), nbytes * world, 3, C.c_void_p(stream))
+
+    return capi.Comm(world, rank, all_gather=all_gather)
+
+
 def gloo_comm(group=None):
     """The same communicator with the all-gather done by torch.distributed on HOST copies (gloo): lets two processes
     that share one GPU run the product's sharded search in tests.  Ordered after the stream's work by a device sync."""

@@ -216,6 +216,46 @@ def test_rccl_transport_single_rank_roundtrip():
 
 
 @pytest.mark.gpu
+def test_torch_distributed_fallback_transport_single_rank():
+    """sharded.torch_comm (bench.py's fallback when libmsvs cannot create its own communicator): the all-gathers of the
+    sharded search through torch.distributed's NCCL = RCCL process group on the caller's stream, with the one rank a 1-GPU
+    box can host: == the plain search."""
+    import subprocess
+    import sys
+
+    code = """
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import myscaledb_amd.capi as capi
+from myscaledb_amd import sharded
+capi.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+comm = sharded.torch_comm()
+rng = np.random.default_rng(5)
+n, d, k = 8000, 32, 10
+x = rng.standard_normal((n, d), dtype=np.float32)
+ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=16")
+ix.train(x); ix.add(x); ix.build()
+stream = torch.cuda.current_stream().cuda_stream
+for nq in (3, 200):
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    dq = torch.from_numpy(q).cuda()
+    oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    od = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    ix.shard_search_device(comm, dq.data_ptr(), nq, k, 5, oi.data_ptr(), od.data_ptr(), stream)
+    torch.cuda.synchronize()
+    fi, fd = ix.search(q, k, "nprobe=5")
+    assert (oi.cpu().numpy() == fi).all() and (od.cpu().numpy() == fd).all()
+comm.close()
+dist.destroy_process_group()
+print("torch_comm ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "torch_comm ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_bench_n_gt_1_code_path_runs_on_one_gpu():
     """bench.py's N > 1 branch (sharded build, msvs_shard_search_device, max-over-ranks timing, rank-0 JSON line) with two
     ranks sharing cuda:0 and a gloo transport (--test-single-device): the driver's multi-GPU run must not be the first
