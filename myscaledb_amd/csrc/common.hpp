@@ -152,6 +152,7 @@ struct Options
                               // fallbacks per 94 208 queries on the mixture, but 2 -> 8 and +3 % step time on iid gaussians: off)
     double coarse_h16_min_q = 192; // coarse quantiser through the centroid shadow from this many queries on (0: only with 128-query
                                    // tiles, ~1000 queries); measured on nlist 1024: 512 queries -6 %, 256 -2.6 %, 64 +10 % (ten launches)
+    double h16_sample_nqb = 1; // column blocks (32 queries) per item of the sample launch (2: measured slower, 80 vs 73 us: 240 VGPRs)
     double h16_target = 0;    // rows of a query's probed lists the sample cut aims to keep (0: 25 k, 10 k beyond k = 40)
     double h16_kc = 0;        // candidates re-ranked per query after the fp16-shadow list scan (0: 32 for k <= 12, else 64)
     double coarse_kc = 0;     // ... after the centroid-shadow pass

@@ -597,7 +597,7 @@ const OptionField g_option_fields[] = {
     {"rerank_stats", &Options::rerank_stats},   {"rerank_early", &Options::rerank_early},
     {"rerank_groups", &Options::rerank_groups}, {"combine", &Options::combine},           {"h16_k128", &Options::h16_k128},
     {"h16_target", &Options::h16_target},       {"h16_cut_floor", &Options::h16_cut_floor},
-    {"coarse_h16_min_q", &Options::coarse_h16_min_q},
+    {"coarse_h16_min_q", &Options::coarse_h16_min_q}, {"h16_sample_nqb", &Options::h16_sample_nqb},
     {"combine_batches", &Options::combine_batches},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},

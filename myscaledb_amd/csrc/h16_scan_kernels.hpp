@@ -506,7 +506,10 @@ __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
 /// query q's image; the four steps of a chunk use up the 128-byte line).  The plan behind pair_off / work_off is built
 /// with T = 32 over the row range [list_off, list_off + 32).  Writes the 32 x 32 ordered distance words of the item
 /// to a.sample_out[pair][row].
-template <int METRIC>
+/// NQB = 2 (knob h16_sample_nqb, off): an item is TWO column blocks (64 probing queries; the plan is built with T = 64), every
+/// row fragment feeds two MFMAs, a quarter less operand traffic -- measured SLOWER (80 against 73 us per 4096-query step: 240
+/// VGPRs, and half of the second blocks are empty).  A short second block repeats the item's last pair and stores nothing.
+template <int METRIC, int NQB>
 __global__ __launch_bounds__(BLOCK) void h16_sample_kernel(const H16Params a)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
@@ -525,13 +528,21 @@ __global__ __launch_bounds__(BLOCK) void h16_sample_kernel(const H16Params a)
         const uint32_t l = lo;
         const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
         const uint32_t pe = a.pair_off[l + 1];
-        const uint32_t pb = a.pair_off[l] + (w - a.work_off[l]) * 32;
-        const uint32_t nvalid = pe - pb < 32u ? pe - pb : 32u;
-        // this lane's query (A operand row r32); short tiles repeat their last pair
-        const uint32_t qp = a.pairs[pb + (r32 < nvalid ? r32 : nvalid - 1)];
-        const uint32_t q = qp / a.nprobe;
-        const float2 qi = a.qinfo[q];
-        const u32x4 * const ap = reinterpret_cast<const u32x4 *>(a.Qh) + (size_t)q * nch * 8 + h;
+        const uint32_t pb = a.pair_off[l] + (w - a.work_off[l]) * 32 * NQB;
+        const uint32_t nvalid = pe - pb < 32u * NQB ? pe - pb : 32u * NQB;
+        // this lane's queries (A operand row r32 of each column block); short tiles repeat their last pair
+        uint32_t qp[NQB];
+        float2 qi[NQB];
+        const u32x4 * ap[NQB];
+#pragma unroll
+        for (int b = 0; b < NQB; b++)
+        {
+            const uint32_t slot = 32u * b + r32;
+            qp[b] = a.pairs[pb + (slot < nvalid ? slot : nvalid - 1)];
+            const uint32_t q = qp[b] / a.nprobe;
+            qi[b] = a.qinfo[q];
+            ap[b] = reinterpret_cast<const u32x4 *>(a.Qh) + (size_t)q * nch * 8 + h;
+        }
         const u32x4 * const bp = reinterpret_cast<const u32x4 *>(a.H) + (size_t)a.hoff[l] * nch * 256 + lane;
         const int64_t row = lbeg + r32;
         bool ok = row < lend;
@@ -546,18 +557,30 @@ __global__ __launch_bounds__(BLOCK) void h16_sample_kernel(const H16Params a)
                 ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
             }
         }
-        f32x16 acc;
+        f32x16 acc[NQB];
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-            acc[r] = 0.f;
-        u32x4 ar[2][4], br[2][4];
+        for (int b = 0; b < NQB; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                acc[b][r] = 0.f;
+        u32x4 ar[2][NQB][4], br[2][4];
         auto load = [&](const int s, const uint32_t c) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
-                ar[s][j] = ap[(size_t)c * 8 + 2 * j];
+#pragma unroll
+                for (int b = 0; b < NQB; b++)
+                    ar[s][b][j] = ap[b][(size_t)c * 8 + 2 * j];
                 br[s][j] = bp[(size_t)c * 256 + j * 64];
             }
+        };
+        auto mul = [&](const int s) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int b = 0; b < NQB; b++)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ar[s][b][j]),
+                                                                    __builtin_bit_cast(half8, br[s][j]), acc[b], 0, 0, 0);
         };
         load(0, 0);
         const uint32_t last = nch - 1;
@@ -565,34 +588,30 @@ __global__ __launch_bounds__(BLOCK) void h16_sample_kernel(const H16Params a)
         {
             load(1, c + 1 < last ? c + 1 : last);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ar[0][j]),
-                                                             __builtin_bit_cast(half8, br[0][j]), acc, 0, 0, 0);
+            mul(0);
             __builtin_amdgcn_sched_barrier(0);
             if (c + 1 >= nch)
                 break;
             load(0, c + 2 < last ? c + 2 : last);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ar[1][j]),
-                                                             __builtin_bit_cast(half8, br[1][j]), acc, 0, 0, 0);
+            mul(1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // accumulator register i = query (i & 3) + 8 (i >> 2) + 4 h of the tile, row r32: the query's constants live in the
-        // lane that fed it as A operand
+        // accumulator register i = query (i & 3) + 8 (i >> 2) + 4 h of the column block, row r32: the query's constants live
+        // in the lane that fed it as A operand
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-        {
-            const int qidx = (i & 3) + 8 * (i >> 2) + 4 * (int)h; // lanes qidx and qidx + 32 hold the same query
-            const float m2 = __shfl(qi.x, qidx), qn = __shfl(qi.y, qidx);
-            const uint32_t pair = (uint32_t)__shfl((int)qp, qidx);
-            const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2, acc[i], xn), qn) : __fmul_rn(m2, acc[i]);
-            const uint64_t key = ok ? make_key<METRIC>(v, (uint32_t)row) : KEY_NONE;
-            if ((uint32_t)qidx < nvalid)
-                a.sample_out[(size_t)pair * H_ROWS + r32] = (uint32_t)(key >> 32);
-        }
+        for (int b = 0; b < NQB; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+            {
+                const int qidx = (i & 3) + 8 * (i >> 2) + 4 * (int)h; // lanes qidx and qidx + 32 hold the same query
+                const float m2 = __shfl(qi[b].x, qidx), qn = __shfl(qi[b].y, qidx);
+                const uint32_t pair = (uint32_t)__shfl((int)qp[b], qidx);
+                const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2, acc[b][i], xn), qn) : __fmul_rn(m2, acc[b][i]);
+                const uint64_t key = ok ? make_key<METRIC>(v, (uint32_t)row) : KEY_NONE;
+                if (32u * b + (uint32_t)qidx < nvalid)
+                    a.sample_out[(size_t)pair * H_ROWS + r32] = (uint32_t)(key >> 32);
+            }
     }
 }
 

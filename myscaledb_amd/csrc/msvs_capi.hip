@@ -1603,9 +1603,9 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
             h.sample_out = sample;
             const uint32_t sgrid = device_cu_count() * 8;
             if (scan_metric(m) == M_IP)
-                hipLaunchKernelGGL((h16_sample_kernel<M_IP>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
+                hipLaunchKernelGGL((h16_sample_kernel<M_IP, 1>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
             else
-                hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
+                hipLaunchKernelGGL((h16_sample_kernel<M_L2, 1>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
         }
         hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
                            n_pad, kc, cand, bound, (int)options().wave_select);
@@ -1754,7 +1754,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     IvfPlanParams pa = pp; // the sample launch: block 0 of every probed list, tiles of 32 queries (small workgroups)
     pa.list_off = ix.list_off.p;
     pa.list_end = ix.list_mid32.p;
-    pa.T = 32;
+    const uint32_t sample_nqb = options().h16_sample_nqb == 2 ? 2u : 1u; // column blocks of 32 queries per sample item
+    pa.T = 32 * sample_nqb;
     pa.work_off = scr.take<uint32_t>(ix.nlist + 1);
     launch_ivf_plan_rescan(pa, stream);
     float * qnorm = scr.take<float>(nq);
@@ -1803,10 +1804,17 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         ProfileScope prof("ivf_sample_scan", stream);
         a.work_off = pa.work_off;
         const uint32_t sgrid = device_cu_count() * 8; // one wavefront per (list, 32-query column block), grid-stride
-        if (scan_metric(m) == M_IP)
-            hipLaunchKernelGGL((h16_sample_kernel<M_IP>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
+        if (sample_nqb == 2)
+        {
+            if (scan_metric(m) == M_IP)
+                hipLaunchKernelGGL((h16_sample_kernel<M_IP, 2>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
+            else
+                hipLaunchKernelGGL((h16_sample_kernel<M_L2, 2>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
+        }
+        else if (scan_metric(m) == M_IP)
+            hipLaunchKernelGGL((h16_sample_kernel<M_IP, 1>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
         else
-            hipLaunchKernelGGL((h16_sample_kernel<M_L2>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
+            hipLaunchKernelGGL((h16_sample_kernel<M_L2, 1>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
         if (nprobe <= 64 && options().wave_select != 0)
         {
             H16CutFloor fl{};
