@@ -39,3 +39,27 @@ def test_product_never_imports_the_oracle():
                     assert not bad.search(src), fn
                     for name in so_name.findall(src):
                         assert any(t in name for t in ("librccl", "libmsvs", "libamdhip64")), (fn, name)
+
+
+def test_public_headers_compile_as_c99_and_cxx17(tmp_path):
+    """The drop-in boundary is a C ABI: include/msvs.h and include/msvs_host.h must be consumable by a C compiler (no C++
+    constructs, no torch types) and by the host's C++17."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = '#include "include/msvs.h"\n#include "include/msvs_host.h"\nint main(void) { return 0; }\n'
+    c = tmp_path / "abi.c"
+    c.write_text(src)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", root, str(c)], check=True)
+    cpp = tmp_path / "abi.cpp"
+    cpp.write_text(src)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", root, str(cpp)], check=True)
+
+
+def test_concurrent_search_driver_rejects_bad_arguments():
+    import ctypes as C
+    import myscaledb_amd.host as host
+    sec = C.c_double(0)
+    assert host.lib().msvs_host_concurrent_search(None, None, C.c_size_t(0), C.c_size_t(4), 1, C.c_size_t(1), 1, b"", C.byref(sec),
+                                                  None, None, None) != 0
+
