@@ -221,6 +221,16 @@ extern "C" int msvs_knn_f32_filtered(const float * x, const float * y, size_t d,
     return guarded([&] { knn_host(x, y, d, k, nx, ny, metric, alive_bits, ids, dis); });
 }
 
+static void normalize_device_rows(float * d_x, size_t n, uint32_t d, uint32_t ld, hipStream_t stream)
+{
+    if (n == 0)
+        return;
+    if ((size_t)d * 4 > 60 * 1024) // the row is staged in LDS
+        fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large to normalise on the device", d);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(normalize_rows_grid(n)), dim3(WAVE), (size_t)d * 4, stream, d_x, n, d, ld);
+    MSVS_HIP(hipGetLastError());
+}
+
 extern "C" int msvs_normalize_f32(float * x, size_t n, size_t d)
 {
     return guarded([&] {
@@ -233,9 +243,7 @@ extern "C" int msvs_normalize_f32(float * x, size_t n, size_t d)
         scr.reserve(n * d * 4 + 4096, stream);
         float * dx = scr.take<float>(n * d);
         MSVS_HIP(hipMemcpyAsync(dx, x, n * d * 4, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, dx, n,
-                           (uint32_t)d, (uint32_t)d);
-        MSVS_HIP(hipGetLastError());
+        normalize_device_rows(dx, n, (uint32_t)d, (uint32_t)d, stream);
         MSVS_HIP(hipMemcpyAsync(x, dx, n * d * 4, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipStreamSynchronize(stream));
     });
@@ -383,9 +391,7 @@ extern "C" int msvs_block_upload(msvs_cache_t * c, const char * key, uint64_t ma
         upload_rows(b->rows.p, rows, n, (uint32_t)d, b->ld, MSVS_MEM_HOST, stream);
         if (normalize && n)
         {
-            hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, b->rows.p, n,
-                               (uint32_t)d, b->ld);
-            MSVS_HIP(hipGetLastError());
+            normalize_device_rows(b->rows.p, n, (uint32_t)d, b->ld, stream);
         }
         MSVS_HIP(hipStreamSynchronize(stream));
         std::lock_guard<std::mutex> lk(c->mu);
@@ -814,13 +820,6 @@ static void index_assign(const msvs_index & ix, const float * d_x, size_t n, int
     MSVS_HIP(hipStreamSynchronize(stream));
 }
 
-static void normalize_device_rows(float * d_x, size_t n, uint32_t d, uint32_t ld, hipStream_t stream)
-{
-    if (n == 0)
-        return;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, d_x, n, d, ld);
-    MSVS_HIP(hipGetLastError());
-}
 
 extern "C" int msvs_index_create(int index_type, int metric, size_t dim, const char * params, msvs_index_t ** out)
 {
