@@ -71,6 +71,7 @@ struct H16Params
     // sample launch
     uint32_t * sample_out;    // [nq * nprobe][32] ordered distance word of row r of block 0 (0xFFFFFFFF = no row)
     uint32_t * sched;         // [8] work-queue cursors of this launch (zeroed by the caller)
+    uint32_t dbg;             // experiments (option h16_dbg; results are WRONG with any bit set): 1 no MFMA work, 2 no epilogue, 4 no norms
 };
 
 /// Largest |element| of a table as float bits (NaN compares largest); max_bits zeroed by the caller.

@@ -12,6 +12,7 @@
 #include "device_ops.hpp"
 #include "ivf_build_kernels.hpp"
 #include "h16_scan_kernels.hpp"
+#include "h16r_scan_kernels.hpp"
 #include "latency_kernels.hpp"
 #include "filter_kernels.hpp"
 
@@ -1165,6 +1166,7 @@ struct IvfSearchPlan
     uint32_t h_mth;    // ... the number of rows per query its cut aims to leave below it (h16_sample_thr_kernel)
     uint32_t h_cap;    // ... and its candidate-buffer capacity per query
     uint32_t h_ncb;    // ... and its query tile: 32 * h_ncb queries resident in LDS
+    uint32_t h_ks;     // ... or, != 0: the tile lives in REGISTERS (h16r_scan_kernels.hpp), the reduction dimension in h_ks parts
     bool mfma() const { return nqg != 0; }
 };
 
@@ -1199,6 +1201,12 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 while (ncb > 1 && h16_lds_bytes(ncb, ix.h_nch) > 160 * 1024)
                     ncb--;
                 p.h_ncb = ncb;
+                // queries in registers, rows through LDS: 256 / 128 queries per pass over a list (d <= 768 / 1536) where LDS holds
+                // 32 * ncb -- taken when the lists are probed by more queries than that (twice the average, as above)
+                const uint32_t ks = (uint32_t)ceil_div(ix.h_nch, (size_t)HR_CPP);
+                const int reg = (int)options().h16_reg;
+                if (reg != 0 && ks <= 2 && (reg >= 2 || 2 * ceil_div(pairs, nlist) > 32 * (size_t)ncb))
+                    p.h_ks = ks;
             }
             {
                 // sample = block 0 (<= 32 rows) of every probed list; the cut of a query = its m-th best sample row with
@@ -1318,7 +1326,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
             + nq * (size_t)p.kc * 8 + nq * 24 + 8192
             + fallback_cap(nq, nprobe, p.seg_max1, k) * nprobe * (size_t)p.seg_max1 * k * 8
-            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8) + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
+            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8) + HR_CPP * 128 + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
     return need;
@@ -1696,6 +1704,29 @@ static void h16_dispatch(uint32_t ncb, bool nt, uint32_t grid, size_t lds, const
     }
 }
 
+static uint32_t device_cu_count();
+
+template <int METRIC, int KS>
+static void h16r_launch(const H16Params & a, hipStream_t stream)
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&h16r_scan_kernel<METRIC, KS, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    // persistent workgroups, one per CU (the ring and the stages take the LDS)
+    const uint32_t grid = options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count();
+    hipLaunchKernelGGL((h16r_scan_kernel<METRIC, KS, 1>), dim3(grid), dim3(512), h16r_lds_bytes(KS), stream, a);
+}
+
+static void h16r_dispatch(int metric, uint32_t ks, const H16Params & a, hipStream_t stream)
+{
+    if (metric == M_IP)
+        ks == 1 ? h16r_launch<M_IP, 1>(a, stream) : h16r_launch<M_IP, 2>(a, stream);
+    else
+        ks == 1 ? h16r_launch<M_L2, 1>(a, stream) : h16r_launch<M_L2, 2>(a, stream);
+}
+
 static uint32_t device_cu_count()
 {
     static std::mutex mu;
@@ -1739,7 +1770,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.n_pairs = (uint32_t)(nq * nprobe);
     pp.nlist = (uint32_t)ix.nlist;
     pp.rows_per_block = 0x7fffffffu; // one segment per non-empty row range
-    pp.T = 32 * pl.h_ncb;
+    const bool reg_tile = pl.h_ks != 0 && !d_alive; // filtered searches keep the LDS-resident tile (the register kernel has no bit test)
+    pp.T = reg_tile ? 32 * (8 / pl.h_ks) : 32 * pl.h_ncb;
     uint32_t * counters = scr.take<uint32_t>(2 * ix.nlist + 1 + 16);
     pp.cnt = counters;
     pp.fill = counters + ix.nlist;
@@ -1759,7 +1791,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     launch_ivf_plan_rescan(pa, stream);
     float * qnorm = scr.take<float>(nq);
     launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
-    uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8);
+    uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + HR_CPP * 8); // + what the register kernel may read past the last image
     float2 * qinfo = scr.take<float2>(nq);
     uint32_t * sample = scr.take<uint32_t>(nq * nprobe * H_ROWS);
     uint32_t * qstate = scr.take<uint32_t>(2 * nq);
@@ -1794,6 +1826,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     a.partial = partial;
     a.cand_cap = pl.h_cap;
     a.sample_out = sample;
+    a.dbg = (uint32_t)options().h16_dbg;
     // persistent workgroups pulling work items from per-XCD queues: one per CU (the tile takes most of the LDS)
     const size_t lds = h16_lds_bytes(pl.h_ncb, ix.h_nch);
     const uint32_t per_cu = (uint32_t)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
@@ -1841,7 +1874,9 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         ProfileScope prof("ivf_scan", stream);
         a.work_off = pp.work_off;
         a.sched = sched + 8;
-        if (scan_metric(m) == M_IP)
+        if (reg_tile)
+            h16r_dispatch(scan_metric(m), pl.h_ks, a, stream);
+        else if (scan_metric(m) == M_IP)
             h16_dispatch<M_IP>(pl.h_ncb, nt, grid, lds, a, stream);
         else
             h16_dispatch<M_L2>(pl.h_ncb, nt, grid, lds, a, stream);

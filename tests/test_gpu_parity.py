@@ -349,6 +349,77 @@ def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, 
     assert capi.prefilter_stats()[0] == q2
 
 
+def h16_keys(nq, cap=4096):
+    """Candidate keys (approximate distance word << 32 | stored row position) and counts of this thread's last shadow pass."""
+    import ctypes as C
+
+    keys = np.zeros((nq, cap), np.uint64)
+    cnt = np.zeros(nq, np.uint32)
+    rc = capi.lib().msvs_debug_h16_keys(keys.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(cap), cnt.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        C.c_size_t(nq))
+    assert rc == 0, capi.lib().msvs_last_error()
+    return keys, cnt
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(40000, 768, 16, 900, 4, 10),    # 12 chunks: 11 in registers + the LDS-resident one
+                                                   (30000, 704, 8, 300, 8, 10),     # 11 chunks: registers only
+                                                   (30000, 100, 8, 2100, 8, 40),    # 2 chunks; > 256 queries per list: several tiles
+                                                   (20000, 20, 8, 129, 3, 1),       # one (short) chunk
+                                                   (3000, 64, 4, 100, 4, 12),       # lists of ~750 rows, few queries
+                                                   (12000, 1536, 4, 300, 2, 10),    # 24 chunks: two parts of 12
+                                                   (12000, 1000, 6, 200, 3, 10),    # 16 chunks: two parts of 8
+                                                   (9000, 1400, 3, 150, 3, 5),      # 22 chunks: parts of 11
+                                                   (2000, 200, 40, 700, 5, 10)])    # lists of ~50 rows: one or two blocks beyond the sample
+def test_register_tile_list_scan_matches_oracle(metric, n, d, nlist, nq, nprobe, k, opt):
+    """h16r_scan_kernel: the query tile in registers (256 / 128 queries per pass over a list), the rows through an LDS ring
+    filled by LDS-DMA, survivors staged in LDS.  Forced (h16_reg = 2) on shapes covering one and two parts of the reduction
+    dimension, the LDS-resident 12th chunk, short lists, several tiles per list, no cut at all (every probed row is appended: the
+    stage flushes all the time), tiny candidate buffers (overflow -> fallback) and failing certificates.  Always the canonical
+    answer, bit for bit; and the candidate SETS equal those of the LDS-tile kernel when there is one part (same MFMA chain)."""
+    rng = np.random.default_rng(n + d + nlist + 11)
+    centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+    x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, metric, nlist)
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+    opt("ivf_pass", "2")
+    opt("h16_reg", "2")
+    q0, f0 = capi.prefilter_stats()
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    q1, f1 = capi.prefilter_stats()
+    assert q1 - q0 == nq and f1 - f0 <= nq // 4  # the candidate pass ran and certified (almost) everybody
+    keys_r, cnt_r = h16_keys(nq)
+    opt("h16_reg", "0")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    keys_l, cnt_l = h16_keys(nq)
+    assert (cnt_r == cnt_l).all()
+    if d <= 768:  # one part: the very same approximate values, hence the same survivors (appended in another order)
+        for i in range(0, nq, max(1, nq // 16)):
+            if cnt_r[i] <= keys_r.shape[1]:
+                assert sorted(keys_r[i][: cnt_r[i]].tolist()) == sorted(keys_l[i][: cnt_l[i]].tolist())
+    opt("h16_reg", "2")
+    opt("h16_nocut", "1")  # every probed row a candidate
+    ids, dis = ix.search(q[:64], k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi[:64], od[:64])
+    opt("h16_nocut", None)
+    opt("cand_cap", "64")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    opt("cand_cap", None)
+    opt("ivf_eps_scale", "1e12")
+    ids, dis = ix.search(q[:100], k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi[:100], od[:100])
+    opt("ivf_eps_scale", None)
+    # a filter: the register kernel has no bit test, the LDS-tile kernel serves it -- same answer
+    alive = rng.random(n) < 0.5
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=alive)
+    oa, oda, _ = oracle_on_exported(ix, q, nprobe, k, metric, alive=alive)
+    same(ids, dis, oa, oda)
+
+
 @pytest.mark.parametrize("h16", ["1", "0"])
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
 def test_coarse_quantiser_through_the_candidate_pass(metric, h16, opt):
