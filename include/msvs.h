@@ -111,6 +111,10 @@ MSVS_API int msvs_block_upload(msvs_cache_t * cache, const char * part_key, uint
                                size_t d, int normalize, msvs_block_t ** out);
 MSVS_API int msvs_block_lookup(msvs_cache_t * cache, const char * part_key, uint64_t mark, msvs_block_t ** out);
 MSVS_API void msvs_block_release(msvs_block_t * block);
+/* Shape and stored form of a resident block (rows, dimension, 1 = rows were normalised at upload); any out pointer may be NULL.
+ * A caller that finds a block by key checks these against what it is about to search: a block uploaded for Cosine holds
+ * normalised rows and must not serve an L2 / IP search of the same part (msvs_host.cpp keys the two forms apart as well). */
+MSVS_API int msvs_block_info(const msvs_block_t * block, size_t * n, size_t * d, int * normalized);
 MSVS_API int msvs_cache_evict(msvs_cache_t * cache, const char * key_prefix, size_t * evicted);
 MSVS_API int msvs_cache_stats(msvs_cache_t * cache, size_t * bytes, size_t * blocks, uint64_t * hits, uint64_t * misses,
                               uint64_t * evictions);

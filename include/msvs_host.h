@@ -149,6 +149,9 @@ MSVS_HOST_API int msvs_text_index_doc_freq(const msvs_text_index_t * ix, const c
                                            size_t * n);
 /* The part's lightweight-delete bitmap in the reference's byte form (bit j of byte i = row 8 i + j,
  * MergeTreeTextSearchManager.cpp:199-255), kept resident on the device; NULL clears. */
+/* Tokens of `text` under the default tokenizer chain (SimpleTokenizer on Unicode alphanumerics, RemoveLong(40), LowerCaser),
+ * '\n'-separated; *n_needed = bytes incl. NUL (buf may be NULL / too small: call again). */
+MSVS_HOST_API int msvs_text_tokenize(const char * text, char * buf, size_t cap, size_t * n_needed);
 MSVS_HOST_API int msvs_text_index_set_alive(msvs_text_index_t * ix, const uint8_t * u8_alive_bitmap, size_t nbytes);
 /* TANTIVY::ffi_bm25_search(index_path, sentence, column_names, topk, u8_alive_bitmap, use_filter, enable_nlq, operator_or,
  * statistics) (call sites TantivyIndexStore.cpp:908-917, 939-948) and its batched form.  Outputs [nq][topk], n_out[q] hits

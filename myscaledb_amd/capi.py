@@ -32,7 +32,7 @@ SYMBOLS = [
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
     "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_coarse_stats", "msvs_combine_stats", "msvs_set_option", "msvs_index_serialize_io",
     "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
-    "msvs_cache_create", "msvs_cache_free", "msvs_block_upload", "msvs_block_lookup", "msvs_block_release",
+    "msvs_cache_create", "msvs_cache_free", "msvs_block_upload", "msvs_block_lookup", "msvs_block_release", "msvs_block_info",
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
     "msvs_index_set_merged_maps", "msvs_comm_unique_id", "msvs_comm_init", "msvs_comm_init_custom",
     "msvs_comm_free", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device",

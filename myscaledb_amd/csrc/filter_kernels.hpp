@@ -109,6 +109,7 @@ struct CompactParams
     uint32_t * chunk_cnt;   // [chunks + 1]: passing rows per chunk, then (after the scan) the exclusive prefix; [chunks] = total
     uint32_t * rank;        // [n + 1]: passing rows before stored row r; rank[n] = total
     uint32_t * rowmap;      // [total] stored row of view row v
+    uint32_t rowmap_cap;    // its capacity (writes beyond it are dropped: never past the buffer, whatever the caller promised)
     const int64_t * list_off; // [nlist + 1] (FLAT: nullptr)
     uint32_t nlist;
     int64_t * sel_off;      // [nlist + 1] view offsets of the lists
@@ -202,7 +203,7 @@ static __global__ __launch_bounds__(BLOCK) void compact_fill_kernel(const Compac
             all += s_wave[w];
         if (r < p.n)
             p.rank[r] = before + in_wave;
-        if (pass)
+        if (pass && before + in_wave < p.rowmap_cap)
             p.rowmap[before + in_wave] = r;
         running += all;
         __syncthreads();

@@ -146,7 +146,6 @@ __global__ __launch_bounds__(512) void h16r_scan_kernel(const H16Params a)
         const uint32_t nvalid = pe - pb < TQ ? pe - pb : TQ;
         const uint32_t hb_list = a.hoff[l];
         const uint32_t nblk = a.hoff[l + 1] - hb_list;
-        const uint32_t P = nblk > 1 ? (nblk - 1) * NPP : 0; // phases of the item: blocks 1 .. nblk - 1 (block 0 = the sample)
         const bool active = 32 * qb < nvalid;
 
         // ---- the row stream: stage after stage of blocks 1 .. nblk - 1; src = this wavefront's piece of the next stage to load
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(512) void h16r_scan_kernel(const H16Params a)
             cnt = 0;
         };
 
-        uint32_t s = 0, c_off = 0; // phase, LDS offset of the slot being multiplied
+        uint32_t c_off = 0; // LDS offset of the slot being multiplied
         const uint32_t sbv0 = lane * 16 + kp * 8192;
 #pragma unroll 1
         for (uint32_t blk = 1; blk < nblk; blk++)
@@ -305,7 +304,6 @@ __global__ __launch_bounds__(512) void h16r_scan_kernel(const H16Params a)
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                s++;
                 c_off ^= SB;
             }
             if (METRIC == M_L2)

@@ -437,8 +437,9 @@ __global__ __launch_bounds__(BLOCK) void lat_scan_kernel(const LatParams p)
     {
         __builtin_amdgcn_s_waitcnt(0); // results acknowledged before the word the host polls
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) // release at system scope: the result stores of the whole block (ordered before this by the barrier) are
+                      // visible to the host thread that acquires the word
+            __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

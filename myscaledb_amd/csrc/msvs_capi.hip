@@ -415,6 +415,20 @@ extern "C" int msvs_block_upload(msvs_cache_t * c, const char * key, uint64_t ma
     });
 }
 
+extern "C" int msvs_block_info(const msvs_block_t * b, size_t * n, size_t * d, int * normalized)
+{
+    return guarded([&] {
+        if (!b)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null block");
+        if (n)
+            *n = b->n;
+        if (d)
+            *d = b->d;
+        if (normalized)
+            *normalized = b->normalized;
+    });
+}
+
 extern "C" void msvs_block_release(msvs_block_t * b)
 {
     if (!b)
@@ -509,6 +523,9 @@ struct msvs_index
     // final storage
     DevBuf<float> vecs;       // n x ld, list-major (IVF) / id order (FLAT)
     DevBuf<uint32_t> row_ids; // n
+    int64_t last_id = -1;        // largest label so far while the labels arrive strictly ascending
+    bool ids_may_repeat = false; // labels were given by the caller and are not known to be distinct (add does not forbid duplicates):
+                                 // a filter's population count then does not bound the rows that pass it (build_view)
     DevBuf<int64_t> list_off; // nlist + 1
     std::vector<int64_t> h_list_off;
     size_t n = 0;
@@ -1004,10 +1021,23 @@ extern "C" int msvs_index_add(msvs_index_t * ix, const float * x, const int64_t 
                 MSVS_HIP(hipMemcpy(ch.ids.data(), ids, n * 8, hipMemcpyDeviceToHost));
             else
                 memcpy(ch.ids.data(), ids, n * 8);
+            // distinct as long as every chunk is strictly ascending and starts above everything before it (what a part's row
+            // offsets look like); anything else may repeat a label
+            for (size_t i = 0; i < n && !ix->ids_may_repeat; i++)
+            {
+                if (ch.ids[i] <= ix->last_id)
+                    ix->ids_may_repeat = true;
+                ix->last_id = ch.ids[i];
+            }
         }
         else
+        {
             for (size_t i = 0; i < n; i++)
                 ch.ids[i] = (int64_t)(ix->staged + i);
+            if ((int64_t)ix->staged <= ix->last_id)
+                ix->ids_may_repeat = true;
+            ix->last_id = (int64_t)(ix->staged + n - 1);
+        }
         for (size_t i = 0; i < n; i++)
             if (ch.ids[i] < 0 || ch.ids[i] > 0xfffffff0ll)
                 fail(MSVS_ERR_ID_RANGE, "id %lld does not fit the u32 label range", (long long)ch.ids[i]);
@@ -2270,7 +2300,7 @@ struct LatCtx
             MSVS_HIP(hipHostFree(pinned));
         pinned = nullptr;
         pinned_bytes = 0;
-        MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), bytes, hipHostMallocDefault));
+        MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), bytes, hipHostMallocCoherent)); // fine-grained whatever HIP_HOST_COHERENT says
         pinned_bytes = bytes;
         memset(pinned, 0, bytes);
     }
@@ -2435,7 +2465,8 @@ void lat_search_host(const msvs_index & ix, const float * queries, size_t nq, ui
     int64_t * h_ids = reinterpret_cast<int64_t *>(c.pinned + o_ids);
     float * h_dis = reinterpret_cast<float *>(c.pinned + o_dis);
     lat_launch(ix, c, hq, nq, k, nprobe, d_alive, nbits, h_ids, h_dis, const_cast<uint32_t *>(flag), seq, stream);
-    for (uint64_t spins = 1; *flag != seq; spins++)
+    // acquire: the copies of the results below are ordered after the word (a volatile read alone orders nothing for the compiler)
+    for (uint64_t spins = 1; __atomic_load_n(const_cast<const uint32_t *>(flag), __ATOMIC_ACQUIRE) != seq; spins++)
     {
         __builtin_ia32_pause();
         if ((spins & 0xfff) == 0) // a failed launch never sets the word: look at the stream now and then
@@ -2819,7 +2850,8 @@ std::unique_ptr<msvs_filter> filter_alloc(size_t nbits, hipStream_t stream)
 SearchView build_view(const msvs_index & ix, const uint64_t * d_alive, size_t nbits, size_t alive_upper, hipStream_t stream)
 {
     const size_t n = ix.n, chunks = std::max<size_t>(1, ceil_div(n, (size_t)COMPACT_CHUNK));
-    const size_t upper = std::max<size_t>(1, std::min(n, alive_upper));
+    // rows that can pass: the filter's population count -- unless labels may repeat (three rows with label 5 pass one bit)
+    const size_t upper = std::max<size_t>(1, ix.ids_may_repeat ? n : std::min(n, alive_upper));
     Scratch & v = view_for(stream);
     v.reserve((chunks + 2) * 4 + (n + 2) * 4 + upper * 4 + (ix.nlist + 2) * 8 + 4096, stream);
     CompactParams p{};
@@ -2830,6 +2862,7 @@ SearchView build_view(const msvs_index & ix, const uint64_t * d_alive, size_t nb
     p.chunk_cnt = v.take<uint32_t>(chunks + 1);
     p.rank = v.take<uint32_t>(n + 1);
     p.rowmap = v.take<uint32_t>(upper);
+    p.rowmap_cap = (uint32_t)upper;
     p.list_off = ix.type == MSVS_INDEX_IVFFLAT ? ix.list_off.p : nullptr;
     p.nlist = (uint32_t)ix.nlist;
     p.sel_off = v.take<int64_t>(ix.nlist + 1);
@@ -3533,6 +3566,9 @@ extern "C" int msvs_index_load_io(const msvs_io_t * io, msvs_index_t ** out)
             ix->row_ids.alloc(std::max<size_t>(n, 1));
             if (n)
                 MSVS_HIP(hipMemcpy(ix->row_ids.p, h32.data(), n * 4, hipMemcpyHostToDevice));
+            // list-major storage order says nothing about the labels: distinct or not is decided by looking (once per load)
+            std::sort(h32.begin(), h32.end());
+            ix->ids_may_repeat = std::adjacent_find(h32.begin(), h32.end()) != h32.end();
         }
         index_finalize_norms(*ix, nullptr);
         MSVS_HIP(hipDeviceSynchronize());

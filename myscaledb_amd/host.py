@@ -19,7 +19,7 @@ SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_h
            "msvs_text_index_total_num_tokens", "msvs_text_index_doc_freq", "msvs_text_index_set_alive",
            "msvs_text_index_bm25_search", "msvs_text_index_bm25_search_batch", "msvs_host_fts_index_statistics",
            "msvs_host_fts_statistics_merge", "msvs_fts_stats_view", "msvs_fts_stats_free", "msvs_host_concurrent_search",
-           "msvs_host_hybrid_search_batch"]
+           "msvs_host_hybrid_search_batch", "msvs_text_tokenize"]
 
 _lib = None
 
@@ -36,6 +36,7 @@ def lib():
         _lib.msvs_host_fusion_transform.restype = C.c_size_t
         _lib.msvs_host_sum_bm25_stats.restype = None
         _lib.msvs_text_last_error.restype = C.c_char_p
+        _lib.msvs_text_tokenize.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _lib.msvs_text_index_total_num_docs.restype = C.c_uint64
         _lib.msvs_text_index_total_num_docs.argtypes = [C.c_void_p]
         _lib.msvs_text_index_free.restype = None
@@ -403,3 +404,18 @@ class TextIndexStore:
 
     def bm25_search(self, sentence, topk, statistics=None, column_names=None, alive=None, enable_nlq=False, operator_or=True):
         return self.bm25_search_batch([sentence], topk, statistics, column_names, alive, enable_nlq, operator_or)[0]
+
+
+def tokenize(text):
+    """Tokens of `text` (str) under the text store's default tokenizer chain (msvs_text_tokenize)."""
+    raw = text.encode("utf-8", errors="surrogatepass") if isinstance(text, str) else bytes(text)
+    need = C.c_size_t(0)
+    buf = C.create_string_buffer(max(64, 2 * len(raw) + 8))
+    rc = lib().msvs_text_tokenize(raw, buf, len(buf), C.byref(need))
+    if rc != 0:
+        raise RuntimeError(lib().msvs_text_last_error().decode())
+    if need.value > len(buf):
+        buf = C.create_string_buffer(need.value)
+        lib().msvs_text_tokenize(raw, buf, len(buf), C.byref(need))
+    s = buf.value.decode("utf-8")
+    return s.split("\n") if s else []

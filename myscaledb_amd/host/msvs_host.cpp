@@ -265,11 +265,29 @@ VectorScanResult MergeTreeVSManager::vectorScanWithoutIndexResident(msvs_cache_t
         qd.normalize();
     }
     std::vector<float> block;
+    // normalised (Cosine) and raw (L2 / IP) copies of a part are different blocks; msvs_cache_evict(part_key) drops both
+    const std::string form_key = part_key + (metric == VIMetric::Cosine ? "/cos" : "/raw");
     for (size_t mark_start = 0, mark = 0; mark_start < total_rows; mark_start += index_granularity, mark++)
     {
         const size_t mark_end = std::min(total_rows, mark_start + index_granularity), block_rows = mark_end - mark_start;
         msvs_block_t * blk = nullptr;
-        VectorIndex::throwIfError(msvs_block_lookup(cache, part_key.c_str(), mark, &blk));
+        VectorIndex::throwIfError(msvs_block_lookup(cache, form_key.c_str(), mark, &blk));
+        if (blk)
+        {
+            // a hit must be the block this search would have uploaded: same rows, same dimension, same stored form (a per-query
+            // metric setting may search one part under Cosine and under L2: the two forms live under different keys, and a block
+            // whose shape no longer matches the mark means the part changed without an eviction)
+            size_t bn = 0, bd = 0;
+            int bnorm = 0;
+            const int irc = msvs_block_info(blk, &bn, &bd, &bnorm);
+            if (irc != 0 || bn != block_rows || bd != dim || bnorm != (metric == VIMetric::Cosine ? 1 : 0))
+            {
+                msvs_block_release(blk);
+                VectorIndex::throwIfError(irc);
+                throw VectorIndex::VIException(MSVS_ERR_INVALID_ARGUMENT, "resident block of `" + part_key + "` mark " + std::to_string(mark)
+                                                                          + " does not match the part (rows / dimension / stored form): evict the part first");
+            }
+        }
         if (!blk)
         {
             // the dense block of the mark exactly as the scan builds it: rows without a vector padded with FLT_MAX
@@ -280,7 +298,7 @@ VectorScanResult MergeTreeVSManager::vectorScanWithoutIndexResident(msvs_cache_t
                 if (e - b == dim)
                     std::copy(column.data + b, column.data + e, block.begin() + (r - mark_start) * dim);
             }
-            VectorIndex::throwIfError(msvs_block_upload(cache, part_key.c_str(), mark, block.data(), block_rows, dim,
+            VectorIndex::throwIfError(msvs_block_upload(cache, form_key.c_str(), mark, block.data(), block_rows, dim,
                                                         metric == VIMetric::Cosine ? 1 : 0, &blk));
         }
         // rows the search may return: not lightweight-deleted; with a filter only the passing rows that carry a vector

@@ -26,6 +26,7 @@
 
 #include "../../include/msvs_host.h"
 #include "msvs_host.hpp"
+#include "unicode_tables.hpp"
 
 namespace
 {
@@ -59,6 +60,66 @@ int text_guarded(F && f)
     }
 }
 
+/// The default tokenizer chain of a tantivy_search `fts` index: SimpleTokenizer (split on every code point that is not
+/// alphanumeric), RemoveLongFilter(40 bytes), LowerCaser (ASCII fast path, char::to_lowercase otherwise).  The Unicode
+/// properties come from unicode_tables.hpp (generated, tools/gen_unicode_tables.py; known difference: combining marks with
+/// the Other_Alphabetic property split a token here).  Malformed UTF-8 bytes are separators.
+static bool uni_alnum(uint32_t cp)
+{
+    size_t lo = 0, hi = sizeof(msvs_unicode::kAlnum) / sizeof(msvs_unicode::kAlnum[0]);
+    while (lo < hi)
+    {
+        const size_t mid = (lo + hi) / 2;
+        if (cp > msvs_unicode::kAlnum[mid].hi)
+            lo = mid + 1;
+        else if (cp < msvs_unicode::kAlnum[mid].lo)
+            hi = mid;
+        else
+            return true;
+    }
+    return false;
+}
+
+static uint32_t uni_lower(uint32_t cp)
+{
+    size_t lo = 0, hi = sizeof(msvs_unicode::kLower) / sizeof(msvs_unicode::kLower[0]);
+    while (lo < hi)
+    {
+        const size_t mid = (lo + hi) / 2;
+        if (cp > msvs_unicode::kLower[mid].from)
+            lo = mid + 1;
+        else if (cp < msvs_unicode::kLower[mid].from)
+            hi = mid;
+        else
+            return msvs_unicode::kLower[mid].to;
+    }
+    return cp;
+}
+
+static void put_utf8(std::string & s, uint32_t cp)
+{
+    if (cp < 0x80)
+        s.push_back((char)cp);
+    else if (cp < 0x800)
+    {
+        s.push_back((char)(0xC0 | (cp >> 6)));
+        s.push_back((char)(0x80 | (cp & 0x3F)));
+    }
+    else if (cp < 0x10000)
+    {
+        s.push_back((char)(0xE0 | (cp >> 12)));
+        s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+        s.push_back((char)(0x80 | (cp & 0x3F)));
+    }
+    else
+    {
+        s.push_back((char)(0xF0 | (cp >> 18)));
+        s.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+        s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+        s.push_back((char)(0x80 | (cp & 0x3F)));
+    }
+}
+
 void tokenize(const char * text, std::vector<std::string> & out)
 {
     std::string cur;
@@ -67,13 +128,49 @@ void tokenize(const char * text, std::vector<std::string> & out)
             out.push_back(cur);
         cur.clear();
     };
-    for (const unsigned char * p = reinterpret_cast<const unsigned char *>(text); *p; p++)
+    const unsigned char * p = reinterpret_cast<const unsigned char *>(text);
+    while (*p)
     {
         const unsigned char c = *p;
-        if ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || c >= 0x80)
-            cur.push_back((char)c);
-        else if (c >= 'A' && c <= 'Z')
-            cur.push_back((char)(c - 'A' + 'a'));
+        if (c < 0x80)
+        {
+            p++;
+            if ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z'))
+                cur.push_back((char)c);
+            else if (c >= 'A' && c <= 'Z')
+                cur.push_back((char)(c - 'A' + 'a'));
+            else
+                flush();
+            continue;
+        }
+        // one UTF-8 sequence (shortest form, no surrogates); anything else is a separator byte
+        uint32_t cp = 0;
+        int len = 0;
+        if ((c & 0xE0) == 0xC0)
+            cp = c & 0x1F, len = 2;
+        else if ((c & 0xF0) == 0xE0)
+            cp = c & 0x0F, len = 3;
+        else if ((c & 0xF8) == 0xF0)
+            cp = c & 0x07, len = 4;
+        bool ok = len != 0;
+        for (int i = 1; ok && i < len; i++)
+        {
+            if ((p[i] & 0xC0) != 0x80) // also stops at the terminating NUL
+                ok = false;
+            else
+                cp = cp << 6 | (p[i] & 0x3F);
+        }
+        if (ok && ((len == 2 && cp < 0x80) || (len == 3 && cp < 0x800) || (len == 4 && (cp < 0x10000 || cp > 0x10FFFF)) || (cp >= 0xD800 && cp <= 0xDFFF)))
+            ok = false;
+        if (!ok)
+        {
+            p++;
+            flush();
+            continue;
+        }
+        p += len;
+        if (uni_alnum(cp))
+            put_utf8(cur, uni_lower(cp));
         else
             flush();
     }
@@ -408,6 +505,28 @@ MSVS_HOST_API int msvs_text_index_doc_freq(const msvs_text_index_t * ix, const c
     });
 }
 
+/* The tokens of a text under the index's (default) tokenizer, '\n'-separated into buf; *n_needed = bytes needed including the NUL
+ * (call again with a larger buffer when it exceeds cap).  Tests compare it with a Python restatement on non-ASCII text. */
+MSVS_HOST_API int msvs_text_tokenize(const char * text, char * buf, size_t cap, size_t * n_needed)
+{
+    return text_guarded([&] {
+        if (!text || !n_needed)
+            text_fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<std::string> toks;
+        tokenize(text, toks);
+        std::string joined;
+        for (size_t i = 0; i < toks.size(); i++)
+        {
+            if (i)
+                joined.push_back('\n');
+            joined += toks[i];
+        }
+        *n_needed = joined.size() + 1;
+        if (buf && cap >= joined.size() + 1)
+            memcpy(buf, joined.c_str(), joined.size() + 1);
+    });
+}
+
 MSVS_HOST_API int msvs_text_index_set_alive(msvs_text_index_t * ix, const uint8_t * u8_alive_bitmap, size_t nbytes)
 {
     return text_guarded([&] {
@@ -508,6 +627,13 @@ MSVS_HOST_API int msvs_text_index_bm25_search_batch(const msvs_text_index_t * ix
             qoff[q + 1] = (uint32_t)qterms.size();
         }
         std::vector<uint64_t> words;
+        if (use_filter && (!u8_alive_bitmap || nbytes == 0))
+        {
+            // a filter was asked for and it is empty: no row passes (NOT "no filter")
+            for (size_t q = 0; q < nq; q++)
+                n_out[q] = 0;
+            return;
+        }
         const bool filter = use_filter && u8_alive_bitmap;
         if (filter)
         {

@@ -113,10 +113,17 @@ FFIVecDocWithFreqResult ffi_get_doc_freq(const std::string & index_path, const s
     auto rd = reader_of(index_path, err);
     if (!rd)
         return failed<FFIVecDocWithFreqResult>(err);
-    std::vector<msvs_doc_freq_t> out(1024);
+    // every (token, column) pair of the sentence: the callee reports how many there are; a second call takes them all
+    std::vector<msvs_doc_freq_t> out(256);
     size_t n = 0;
     if (msvs_text_index_doc_freq(rd->ix, sentence.c_str(), out.data(), out.size(), &n) != 0)
         return failed<FFIVecDocWithFreqResult>(msvs_text_last_error());
+    if (n > out.size())
+    {
+        out.resize(n);
+        if (msvs_text_index_doc_freq(rd->ix, sentence.c_str(), out.data(), out.size(), &n) != 0)
+            return failed<FFIVecDocWithFreqResult>(msvs_text_last_error());
+    }
     FFIVecDocWithFreqResult r;
     for (size_t i = 0; i < n && i < out.size(); i++)
     {
@@ -148,12 +155,18 @@ FFIFieldTokenNumsResult ffi_get_total_num_tokens(const std::string & index_path)
     auto rd = reader_of(index_path, err);
     if (!rd)
         return failed<FFIFieldTokenNumsResult>(err);
-    msvs_field_tokens_t out[8];
+    std::vector<msvs_field_tokens_t> out(8);
     size_t n = 0;
-    if (msvs_text_index_total_num_tokens(rd->ix, out, 8, &n) != 0)
+    if (msvs_text_index_total_num_tokens(rd->ix, out.data(), out.size(), &n) != 0)
         return failed<FFIFieldTokenNumsResult>(msvs_text_last_error());
+    if (n > out.size()) // more than eight text columns: take them all
+    {
+        out.resize(n);
+        if (msvs_text_index_total_num_tokens(rd->ix, out.data(), out.size(), &n) != 0)
+            return failed<FFIFieldTokenNumsResult>(msvs_text_last_error());
+    }
     FFIFieldTokenNumsResult r;
-    for (size_t i = 0; i < n && i < 8; i++)
+    for (size_t i = 0; i < n && i < out.size(); i++)
     {
         FieldTokenNums f;
         f.field_id = out[i].field_id;

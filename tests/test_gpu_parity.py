@@ -1011,6 +1011,39 @@ def test_filtered_search_strategies_agree_with_each_other_and_the_oracle(kind, m
     ix.set_delete_bitmap(None)
 
 
+@pytest.mark.parametrize("kind", ["ivf", "flat"])
+def test_compacted_view_with_repeated_labels_does_not_overrun(kind, opt):
+    """msvs_index_add does not forbid repeated labels: three rows with label 5 pass a filter with ONE bit set, so the filter's
+    population count is no bound on the rows of the compacted view (its row map was sized by it and written without a bound).
+    Both strategies must return the same rows as the oracle, and nothing past the row map may be written."""
+    rng = np.random.default_rng(55)
+    n, d, nlist = 6000, 32, 16
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    labels = (np.arange(n) // 3).astype(np.int64)  # every label three times
+    q = rng.standard_normal((20, d), dtype=np.float32)
+    if kind == "ivf":
+        ix = build_ivf(x, capi.METRIC_L2, nlist, ids=labels)
+        params = "nprobe=%d" % nlist
+    else:
+        ix = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
+        ix.add(x, labels)
+        ix.build()
+        params = ""
+    alive = np.zeros(n // 3, bool)
+    alive[rng.integers(0, n // 3, 40)] = True  # 40 bits -> 120 passing rows
+    flt = capi.Filter.from_bool(alive)
+    # the oracle on the rows themselves: a row passes when its label's bit is set; results carry the labels
+    row_alive = alive[labels]
+    oi, od = o.knn(q, x, 10, o.METRIC_L2, alive=row_alive)
+    oi = np.where(oi >= 0, labels[np.maximum(oi, 0)], -1)
+    for below in ("1", "0"):
+        opt("filter_compact_below", below)
+        ids, dis = ix.search_filter(q, 10, params, flt)
+        assert (dis.view(np.uint32) == od.view(np.uint32)).all()
+        assert (ids == oi).all()
+    flt.close()
+
+
 # ---------------------------------------------------------------------------------------- seam B: BM25
 
 def bm25_both(docs_texts, query, k, alive=None):

@@ -264,6 +264,62 @@ def test_resident_cache_lru_pins_and_eviction():
 
 
 @pytest.mark.gpu
+def test_resident_blocks_of_one_part_under_two_metrics_do_not_mix():
+    """A per-query metric setting may search the same part under Cosine (block stored normalised) and under L2 / IP (stored
+    raw): the two forms are different cache entries, each search gets its own, and both match the non-resident scan."""
+    rng = np.random.default_rng(12)
+    n, d, gran = 700, 24, 256
+    vecs = (rng.standard_normal((n, d)) * rng.uniform(0.2, 5.0, (n, 1))).astype(np.float32)
+    q = rng.standard_normal((1, d)).astype(np.float32)
+    rows = [v for v in vecs]
+    cache = capi.Cache(64 << 20)
+    marks = -(-n // gran)
+    for metric in (capi.METRIC_COSINE, capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE):
+        ref = host.vector_scan_without_index(rows, d, gran, q[0].tolist(), 7, metric)
+        got = host.vector_scan_without_index(rows, d, gran, q[0].tolist(), 7, metric, cache=cache, part_key="p_1_1_0")
+        assert got[0].tolist() == ref[0].tolist() and got[2].tolist() == ref[2].tolist()
+    assert cache.stats()["blocks"] == 2 * marks  # one normalised and one raw copy per mark
+    assert cache.evict("p_1_1_0") == 2 * marks
+    # a stale block under the key of a part whose mark has another size now is an error, not a silent wrong answer
+    h = cache.upload("q_1_1_0/raw", 0, vecs[:100])
+    cache.release(h)
+    with pytest.raises(Exception):
+        host.vector_scan_without_index(rows, d, gran, q[0].tolist(), 7, capi.METRIC_L2, cache=cache, part_key="q_1_1_0")
+    cache.close()
+
+
+def test_default_tokenizer_on_non_ascii_text_matches_a_python_restatement():
+    """SimpleTokenizer splits on code points that are not alphanumeric, LowerCaser lowercases beyond ASCII, RemoveLong drops
+    tokens of 40 bytes or more: checked against Python's unicodedata on text with Unicode punctuation, NBSP, CJK, Cyrillic,
+    Greek, full-width digits, an over-long token and malformed UTF-8."""
+    import unicodedata
+
+    def py_tokens(text):
+        out, cur = [], ""
+        for ch in text:
+            c = unicodedata.category(ch)
+            if c[0] == "L" or c in ("Nd", "Nl", "No"):
+                lo = ch.lower()
+                cur += lo[0] if lo != ch else ch
+            else:
+                if cur and len(cur.encode("utf-8")) < 40:
+                    out.append(cur)
+                cur = ""
+        if cur and len(cur.encode("utf-8")) < 40:
+            out.append(cur)
+        return out
+
+    texts = ["History's LESSONS \u2014 r\u00e9sum\u00e9\u00a0na\u00efve caf\u00c9, \u00dcBER-stra\u00dfe",
+             "\u5317\u4eac\uff0c\u4e0a\u6d77\u3002\u6771\u4eac\u30bf\u30ef\u30fc 2024\u5e74", "\u041c\u043e\u0441\u043a\u0432\u0410 \u2013 \u0391\u0398\u0397\u039d\u0391 \u03c3\u03c4\u03b7\u03bd",
+             "\uff11\uff12\uff13 abc\u00b2 x\u2082 \u2167 \u00bd", "a" * 39 + " " + "b" * 40 + " \u00e9" * 3 + " " + "\u00e9" * 20,
+             "", "   \u3000\u2003 ", "\U0001d400\U0001d401 emoji \U0001f600 done"]
+    for t in texts:
+        assert host.tokenize(t) == py_tokens(t), t
+    # malformed sequences are separators: a lone continuation byte, a truncated 3-byte sequence, an overlong encoding
+    assert host.tokenize(b"ab\x80cd \xe4\xb8 ef \xc0\xafgh") == ["ab", "cd", "ef", "gh"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("typ", [capi.INDEX_FLAT, capi.INDEX_IVFFLAT])
 def test_index_meta_delete_bitmap_and_decoupled_part_row_ids(typ):
     """VIWithMeta on a cached index: resident delete bitmap (goldens 00016 / 00032) and the row-id maps of a decoupled
