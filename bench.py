@@ -2,29 +2,37 @@
 """bench.py -- headline benchmark of the MI355X vector-search hot path (BASELINE.json).
 
 Metric   : QPS (+ p50 latency) at recall@10 >= 0.95, 1M x 768-d f32, L2, top-10.
-Workload : BASELINE.json configs[1] -- IVFFLAT nlist=1024, nprobe=32, on synthetic data of that shape.
+Workload : BASELINE.json configs[1] -- IVFFLAT nlist=1024, nprobe=32, on synthetic data of that shape; the coarse quantiser is
+           trained as SURVEY 8d says (k-means, 20 iterations on a 256 k sample, seed 7).
 A "step" : one batch of `--batch` queries through the search entry point (coarse quantiser + list scan + exact re-rank /
            top-k merge), queries / index / outputs resident in HBM, enqueued on torch's current stream.
 N = 1    : msvs_index_search_device.
 N > 1    : msvs_shard_search_device (one process per GPU; libmsvs owns the RCCL communicator): lists sharded
            list_id % N, the coarse quantiser sharded BY QUERY, one all-gather of the probe lists, local list scans, one
            all-gather of the packed partial top-k, canonical merge.  Total work is fixed => "strong".
+           `python bench.py --gpus N` without a launcher spawns its N ranks itself (torch.distributed.run on 127.0.0.1).
 
 Data: there is no network, so vectors are synthetic.  The headline uses a 1024-blob gaussian mixture of low intrinsic
-dimension embedded in R^768 (see _latent_model: what an IVF index is built for); the `iid` leg repeats it on iid N(0,1)
-rows and queries (SURVEY 8d's first data model), where no IVF index reaches recall 0.95 at nprobe 32 -- both are reported.
+dimension embedded in R^768 (_latent_model: what an IVF index is built for).  SURVEY 8d's own two data models are separate
+legs, each with an nprobe sweep that locates recall@10 >= 0.95 and a timed run AT that operating point: `iid` (rows and
+queries iid N(0,1)) and `blobs03` (1024 gaussian blobs, sigma 0.3, in R^768).
 
 Prints ONE JSON line on rank 0 (driver contract) with these extra objects:
-  roofline      -- the dominant kernel (the list scan: h16_sample_kernel + h16_scan_kernel, two launches per step).
+  roofline      -- the dominant kernel (the list scan: h16_sample_kernel + h16_scan_kernel, two launches per step).  `frac` prices
+                   the bytes the launches HAVE TO READ (the fp16 shadow + norms of the union of the probed rows); the f32-equivalent
+                   rate of SURVEY 8d's formula is a side field (it credits bytes that never move); `whole_step_frac` = the same
+                   bytes over the whole step.
   cpu_baseline  -- the SIMD CPU restatement (oracle/simd_baseline.c, built -march=native on this machine) on a bounded sample,
                    plus a bit-for-bit check of >= 256 bench queries against the parity oracle.
   other_batches -- the same index at 1 / 16 / 64 / 256 / 1024 queries per step.
   latency       -- SURVEY 8d's protocol through the host-pointer C-ABI (query in, ids + distances out): p50 / p99 of
                    single-query calls, QPS at 1 / 8 / 64 concurrent host threads.
-  iid           -- the headline on iid gaussian data.
-  other_configs -- BASELINE configs C1 (FLAT 10k x 128), C3 (10M x 768 cosine, batches of 64), C5 (hybrid: vector top-100
-                   + BM25 top-100 over 10M documents + RRF), each with its own bytes/s figure.
-Every leg but the headline is skipped by --headline-only (profiler runs) and N > 1.
+  iid, blobs03  -- SURVEY 8d's data models at their recall >= 0.95 operating points.
+  other_configs -- BASELINE configs C1 (FLAT 10k x 128), C3 (10M x 768 cosine, batches of 64), C4 (one GPU's share of
+                   100M x 1536 inner product: 12.5M rows, 2048 of the 16384 lists, 8 of the 64 probes), C5 (hybrid: vector top-100
+                   + BM25 top-100 over 10M documents + RRF), each with its own bytes/s figure and an oracle check.
+Every leg but the headline is skipped by --headline-only (profiler runs); --only LEG[,LEG] runs the named legs only; N > 1 runs
+the headline and the sharded C4 family (12.5M rows, 2048 lists, 8 probes PER RANK: at N = 8 that is BASELINE configs[3]).
 """
 import argparse
 import json
@@ -69,6 +77,20 @@ def _sample(model, n, g, device, chunk=65536, out=None):
     return x
 
 
+def _sample_of_blobs(model, n, g, device, first, stride, out, chunk=65536):
+    """Rows of the blobs first, first + stride, first + 2 stride, ... only (one rank's share of a list_id % world sharding
+    when the coarse centroids are the blob centres)."""
+    centres, proj = model
+    d = proj.shape[1]
+    mine = (centres.shape[0] - first + stride - 1) // stride
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        z = first + stride * torch.randint(0, mine, (hi - lo,), generator=g, device=device)
+        lat = centres[z] + torch.randn((hi - lo, LATENT_DIM), generator=g, device=device, dtype=torch.float32)
+        out[lo:hi] = lat @ proj + 0.05 * torch.randn((hi - lo, d), generator=g, device=device, dtype=torch.float32)
+    return out
+
+
 def make_data(n, d, seed, device, blobs=N_BLOBS):
     model = _latent_model(d, 99, device, blobs)
     g = torch.Generator(device=device).manual_seed(seed)
@@ -103,6 +125,40 @@ def build_postings(n_docs, vocab):
     fn_ids = (np.searchsorted(np.array(table, np.int64), lens, side="right") - 1).astype(np.uint8)
     ps = capi.Postings(post_off, doc, tf.astype(np.uint32), fn_ids)
     return ps, np.diff(post_off), total, len(doc)
+
+
+def ivf_params(nlist, n_train, extra=""):
+    """k-means 20 iterations on a 256 k sample, seed 7 (the sample never exceeds the rows it is drawn from)."""
+    return "ncentroids=%d,kmeans_iters=20,train_sample=%d,seed=7%s" % (nlist, min(n_train, 262144), extra)
+
+
+def oracle_on_index_lists(ix, q, nprobe, k, metric, threads=8):
+    """The parity oracle on what the queries touch, for an index too large to export whole: probes from the oracle's exact scan
+    of the exported centroids, then the oracle's exact scan of the rows of the probed lists, exported list by list from the
+    index's own storage (msvs_index_export_list).  Test infrastructure: only the check legs of this script and tests/ call it."""
+    from oracle import oracle as o
+    om = {capi.METRIC_L2: o.METRIC_L2, capi.METRIC_IP: o.METRIC_IP, capi.METRIC_COSINE: o.METRIC_IP}[metric]
+    cent, off, _, _ = ix.export(with_vecs=False)
+    qn = o.normalize_rows(q) if metric == capi.METRIC_COSINE else q
+    probes, _ = o.knn(qn, cent, nprobe, om)
+    cache = {}
+    out_i, out_d = [], []
+    for qi in range(q.shape[0]):
+        vs, ls = [], []
+        for l in probes[qi]:
+            if l < 0 or off[l + 1] == off[l]:
+                continue
+            if int(l) not in cache:
+                if len(cache) > 256:
+                    cache.clear()
+                cache[int(l)] = ix.export_list(int(l), int(off[l + 1] - off[l]))
+            vs.append(cache[int(l)][0])
+            ls.append(cache[int(l)][1])
+        sub, rows = np.concatenate(vs), np.concatenate(ls)
+        i1, d1 = o.knn(qn[qi:qi + 1], sub, k, om, labels=rows)
+        out_i.append(i1[0])
+        out_d.append((np.float32(1) - d1[0]).astype(np.float32) if metric == capi.METRIC_COSINE else d1[0])
+    return np.stack(out_i), np.stack(out_d)
 
 
 def cpu_cores():
@@ -180,7 +236,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps + the roofline pass (profiler runs)")
-    ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,c1,c3,c5,cpu")
+    ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,blobs03,c1,c3,c4,c5,cpu")
+    ap.add_argument("--only", default="", help="comma list of legs to run (the others are skipped; the headline always runs)")
+    ap.add_argument("--c4-rows", type=int, default=12_500_000, help="rows per GPU of the C4 leg (100M / 8)")
     ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the C3 / C5 legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--test-single-device", action="store_true",
@@ -188,12 +246,25 @@ def main():
                          "code path of this script on a one-GPU box (not a measurement)")
     args = ap.parse_args()
     skip = set(x for x in args.skip.split(",") if x)
+    ALL_LEGS = ("other_batches", "latency", "iid", "blobs03", "c1", "c3", "c4", "c5", "cpu")
+    if args.only:
+        skip |= set(ALL_LEGS) - set(x for x in args.only.split(",") if x)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched without torch.distributed.run: spawn the N ranks ourselves (one process per GPU) and pass the JSON line through
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.test_single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -229,8 +300,7 @@ def main():
     q_all = make_queries(model, n_pool * B, 4321, dev)
 
     # ---- build: rank 0 trains the coarse quantiser, everyone adopts the same centroids, keeps its own lists
-    params = "ncentroids=%d,kmeans_iters=10,train_sample=%d,shard_rank=%d,shard_world=%d" % (
-        nlist, min(n, nlist * 64), rank, world)
+    params = ivf_params(nlist, n, ",shard_rank=%d,shard_world=%d" % (rank, world))
     ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, params)
     if world == 1:
         ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
@@ -318,27 +388,85 @@ def main():
         t = torch.tensor([achieved, moved_gbs], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         achieved, moved_gbs = float(t[0].item()), float(t[1].item())
+    step_ms = elapsed / args.steps * 1e3
     roof = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "bound": "hbm", "achieved": round(moved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(moved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
         "kernel": "h16_scan_kernel + h16_sample_kernel (fp16-shadow MFMA candidate pass of the list scan; exact f32 re-rank + "
                   "certificate follow)" if cand_pass else "ivf_batched_scan_kernel / ivf_scan_kernel (canonical f32 scan)",
         "launch_ms": round(scan_ms, 4), "launches_per_step": 2 if fam["ivf_sample_scan"] else 1,
-        "bytes_per_launch": int(bytes_alg), "moved_bytes_per_launch": int(bytes_moved),
-        "moved_gbs": round(moved_gbs, 1), "moved_frac": round(moved_gbs / HBM_PEAK_GBS, 4),
+        "bytes_per_launch": int(bytes_moved),
+        "whole_step_gbs": round(bytes_moved / (step_ms * 1e-3) / 1e9, 1),
+        "whole_step_frac": round(bytes_moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "non_scan_ms_per_step": round(step_ms - scan_ms, 4),
+        "f32_equiv_bytes_per_launch": int(bytes_alg), "f32_equiv_gbs": round(achieved, 1),
+        "f32_equiv_frac": round(achieved / HBM_PEAK_GBS, 4),
         "mfma_tflops": round(mfma_tf, 1), "mfma_frac_of_2500": round(mfma_tf / 2500.0, 4),
         "per_query_model_gbs": round(rows_model * (4 * d + 4) / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else None,
         "prefilter": [pf1[0] - pf0[0], pf1[1] - pf0[1]],
         "step_kernels_ms": {f: round(v, 4) for f, v in fam.items() if v},
-        "note": "achieved = union of the step's probed rows x (4d+4) B (SURVEY 8d algorithmic bytes) / (sample + main "
-                "launch time, HIP events); moved_* = the same rows x (2d+8) B, what the fp16-shadow pass has to read; traffic = "
-                "FETCH_SIZE/WRITE_SIZE of both launches from rocprofv3 --pmc (profiles/); prefilter = (queries through the "
-                "candidate pass, queries that needed the canonical fallback) during the profiled steps; per_query_model_gbs "
-                "exceeds HBM speed because one pass over a list serves every query of the step that probes it",
+        "note": "achieved / frac = the bytes the two launches have to read -- union of the step's probed rows x (2d + 8) B: the fp16 "
+                "shadow row, its f32 norm and its id -- / (sample + main launch time, HIP events on the launch stream); "
+                "whole_step_* = the same bytes over the whole step; f32_equiv_* = the same rows x (4d + 4) B (SURVEY 8d's "
+                "per-row figure: credits bytes that never move, can exceed 1); traffic = FETCH_SIZE (x2, gfx950) + WRITE_SIZE of both "
+                "launches from rocprofv3 --pmc (profiles/); prefilter = (queries through the candidate pass, queries that needed "
+                "the canonical fallback) during the profiled steps; per_query_model_gbs exceeds HBM speed because one pass over "
+                "a list serves every query of the step that probes it",
     }
 
     extra = {}
     solo = world == 1 and not args.headline_only
+
+    # ---- N > 1: BASELINE configs[3] as a weak-scaling family -- 12.5M rows, 2048 lists and 8 probes PER RANK of one logical
+    # IVFFLAT index (N = 8: 100M x 1536, nlist 16384, nprobe 64, lists list_id % 8).  Every rank is shown every row of the
+    # index (generated on its device, chunk by chunk) and keeps the rows of its lists; the coarse centroids are the blob centres
+    # of the data model (identical on every rank: nothing to train or broadcast).
+    def c4_sharded():
+        d4, nl_g, npb = 1536, 2048 * world, 8 * world
+        total_rows = args.c4_rows * world
+        mdl = _latent_model(d4, 99, dev, nl_g)
+        cent = (mdl[0] @ mdl[1]).contiguous()
+        six = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_IP, d4, "ncentroids=%d,shard_rank=%d,shard_world=%d" % (nl_g, rank, world))
+        six.set_centroids(cent.cpu().numpy())
+        t1 = time.time()
+        chunk = 500_000
+        buf = torch.empty((chunk, d4), device=dev, dtype=torch.float32)
+        g = torch.Generator(device=dev).manual_seed(1234)  # the same rows in the same order on every rank
+        for lo in range(0, total_rows, chunk):
+            m = min(chunk, total_rows - lo)
+            _sample(mdl, m, g, dev, out=buf)
+            six.add(buf.data_ptr(), n=m, mem=capi.MEM_DEVICE)
+        del buf
+        six.build()
+        torch.cuda.synchronize()
+        build_s = time.time() - t1
+        res = {"workload": "IVFFLAT %d x %d f32 inner product, nlist %d, nprobe %d, lists list_id %% %d, top-%d; weak scaling family "
+                           "(12.5M rows, 2048 lists, 8 probes per rank)" % (total_rows, d4, nl_g, npb, world, k),
+               "rows_on_rank0": six.num_data, "build_s": round(build_s, 1), "scaling": "weak", "batches": {}}
+        for bq in (4096, 1024):
+            qs = make_queries(mdl, 4 * bq, 4321, dev)
+            o_i = torch.empty((bq, k), device=dev, dtype=torch.int64)
+            o_d = torch.empty((bq, k), device=dev, dtype=torch.float32)
+
+            def sstep(i):
+                six.shard_search_device(comm, qs[(i % 4) * bq:(i % 4 + 1) * bq].data_ptr(), bq, k, npb, o_i.data_ptr(), o_d.data_ptr(), stream)
+            for i in range(3):
+                sstep(i)
+            fence()
+            t2 = time.perf_counter()
+            for i in range(10):
+                sstep(i)
+            fence()
+            el = time.perf_counter() - t2
+            tt = torch.tensor([el], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+            res["batches"][str(bq)] = {"qps": round(10 * bq / el, 1), "ms_per_batch": round(el / 10 * 1e3, 4)}
+        six.close()
+        return res
+
+    if world > 1 and not args.headline_only and "c4" not in skip:
+        leg("c4_sharded", c4_sharded, extra)
 
     # ---- the same index at other step sizes (20 timed steps each)
     def other_batches():
@@ -445,39 +573,78 @@ def main():
         leg("cpu", cpu_baseline, tmp)
         cpu = tmp["cpu"]
 
-    # ---- the headline on iid gaussian data (SURVEY 8d's first data model)
-    def iid():
+    # ---- SURVEY 8d's own data models, each at ITS recall@10 >= 0.95 operating point (nprobe sweep), same index parameters
+    def operating_point(kind):
         g = torch.Generator(device=dev).manual_seed(1234)
-        xi = torch.randn((n, d), generator=g, device=dev, dtype=torch.float32)
-        g = torch.Generator(device=dev).manual_seed(4321)
-        qi = torch.randn((2 * B, d), generator=g, device=dev, dtype=torch.float32)
-        iix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=%d,kmeans_iters=10,train_sample=%d" % (nlist, min(n, nlist * 64)))
+        gq = torch.Generator(device=dev).manual_seed(4321)
+        if kind == "iid":
+            xi = torch.randn((n, d), generator=g, device=dev, dtype=torch.float32)
+            qi = torch.randn((2 * B, d), generator=gq, device=dev, dtype=torch.float32)
+            data = "rows and queries iid N(0,1)^%d, seeds 1234 / 4321 (torch generators on the GPU)" % d
+        else:
+            gc = torch.Generator(device=dev).manual_seed(99)
+            centres = torch.randn((1024, d), generator=gc, device=dev, dtype=torch.float32)
+            xi = torch.empty((n, d), device=dev, dtype=torch.float32)
+            for lo in range(0, n, 131072):
+                hi = min(n, lo + 131072)
+                z = torch.randint(0, 1024, (hi - lo,), generator=g, device=dev)
+                xi[lo:hi] = centres[z] + 0.3 * torch.randn((hi - lo, d), generator=g, device=dev, dtype=torch.float32)
+            z = torch.randint(0, 1024, (2 * B,), generator=gq, device=dev)
+            qi = centres[z] + 0.3 * torch.randn((2 * B, d), generator=gq, device=dev, dtype=torch.float32)
+            data = "1024 gaussian blobs (centres N(0,1)^%d, seed 99), sigma 0.3, rows seed 1234, queries seed 4321" % d
+        t1 = time.time()
+        iix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, ivf_params(nlist, n))
         iix.train(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
         iix.add(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
         iix.build()
-
-        def istep(i):
-            iix.search_device(qi[(i % 2) * B:(i % 2 + 1) * B].data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
-        p0 = capi.prefilter_stats()
-        dt = timed(istep, 20)
-        p1 = capi.prefilter_stats()
+        torch.cuda.synchronize()
+        build_s = time.time() - t1
         fl = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
         fl.add(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
         fl.build()
-        qh = qi[:500].cpu().numpy()
+        del xi
+        qh = qi[:1000].cpu().numpy()
         gt, _ = fl.search(qh, k)
-        res = {"qps": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "batch": B,
-               "candidate_pass_queries": p1[0] - p0[0], "fallback_queries": p1[1] - p0[1],
-               "data": "rows and queries iid N(0,1)^768, seeds 1234 / 4321 (torch generators on the GPU)"}
-        for npb in (nprobe, 128, 256):
-            got, _ = iix.search(qh, k, "nprobe=%d" % npb)
-            res["recall_at_%d_nprobe_%d" % (k, npb)] = round(recall_at_k(got, gt, k), 4)
         fl.close()
+        res = {"data": data, "batch": B, "build_s": round(build_s, 1), "lists": iix.list_stats(), "recall_at_%d" % k: {}}
+        op = None
+        for npb in (8, 16, 32, 64, 128, 256, 512):
+            if npb > nlist:
+                break
+            got, _ = iix.search(qh, k, "nprobe=%d" % npb)
+            r = recall_at_k(got, gt, k)
+            res["recall_at_%d" % k]["nprobe_%d" % npb] = round(r, 4)
+            if r >= 0.95:
+                op = npb
+                break
+
+        def run_at(npb):
+            def istep(i):
+                iix.search_device(qi[(i % 2) * B:(i % 2 + 1) * B].data_ptr(), B, k, npb, out_ids.data_ptr(), out_dis.data_ptr(), stream)
+            p0 = capi.prefilter_stats()
+            dt = timed(istep, 20)
+            p1 = capi.prefilter_stats()
+            fo = profiled(istep, 4, STEP_FAMILIES)
+            uni = sum(iix.scanned_rows(qi[j * B:(j + 1) * B].cpu().numpy(), npb)[2] for j in range(2)) / 2
+            sc = fo["ivf_scan"] + fo["ivf_sample_scan"]
+            mv = uni * (2 * d + 8)
+            return {"nprobe": npb, "qps": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "list_scan_ms": round(sc, 4),
+                    "union_rows_per_step": int(uni), "roofline_frac": round(mv / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
+                    "whole_step_frac": round(mv / dt / 1e9 / HBM_PEAK_GBS, 4),
+                    "candidate_pass_queries": p1[0] - p0[0], "fallback_queries": p1[1] - p0[1]}
+        if op is not None:
+            res["at_recall_0.95"] = run_at(op)
+        else:
+            res["at_recall_0.95"] = {"error": "recall@%d < 0.95 up to nprobe 512" % k}
+        if op != nprobe:
+            res["at_config_nprobe"] = run_at(nprobe)
         iix.close()
         return res
 
     if solo and "iid" not in skip:
-        leg("iid", iid, extra)
+        leg("iid", lambda: operating_point("iid"), extra)
+    if solo and "blobs03" not in skip:
+        leg("blobs03", lambda: operating_point("blobs03"), extra)
 
     # ---- other BASELINE configurations
     other_cfg = {}
@@ -550,6 +717,66 @@ def main():
                 "whole_step_hbm_frac_algorithmic": round(uni * (4 * d + 4) / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "step_kernels_ms": {f: round(v, 4) for f, v in f3.items() if v}}
 
+    def c4():
+        """One GPU's share of BASELINE configs[3] (IVFFLAT 100M x 1536 f32, inner product, nlist 16384, nprobe 64, lists
+        list_id % 8): 12.5M rows in 2048 lists, every query probing 8 of them -- the work msvs_shard_search_device leaves on a
+        rank (its coarse quantiser covers nq / 8 queries x 16384 centroids = nq x 2048 here).  The sharded family itself runs
+        under --gpus N."""
+        nb, d4, nl, npb = args.c4_rows, 1536, 2048, 8
+        mdl = _latent_model(d4, 99, dev, nl)
+        g = torch.Generator(device=dev).manual_seed(1234)
+        cix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_IP, d4, ivf_params(nl, nb))
+        t1 = time.time()
+        xs = _sample(mdl, min(nb, 262144), g, dev)
+        cix.train(xs.data_ptr(), n=xs.shape[0], mem=capi.MEM_DEVICE)
+        del xs
+        chunk = 500_000
+        buf = torch.empty((chunk, d4), device=dev, dtype=torch.float32)
+        g = torch.Generator(device=dev).manual_seed(1234)
+        for lo in range(0, nb, chunk):
+            m = min(chunk, nb - lo)
+            _sample(mdl, m, g, dev, out=buf)
+            cix.add(buf.data_ptr(), n=m, mem=capi.MEM_DEVICE)
+        del buf
+        cix.build()
+        torch.cuda.synchronize()
+        build_s = time.time() - t1
+        res = {"workload": "one GPU of 8: IVFFLAT %d x %d f32 inner product, %d lists (16384 / 8), %d probes per query (64 / 8), top-%d"
+                           % (nb, d4, nl, npb, k), "build_s": round(build_s, 1), "lists": cix.list_stats(), "batches": {}}
+        for bq in (4096, 1024, 64):
+            qs = make_queries(mdl, 4 * bq, 4321, dev)
+            o_i = torch.empty((bq, k), device=dev, dtype=torch.int64)
+            o_d = torch.empty((bq, k), device=dev, dtype=torch.float32)
+
+            def cstep(i):
+                cix.search_device(qs[(i % 4) * bq:(i % 4 + 1) * bq].data_ptr(), bq, k, npb, o_i.data_ptr(), o_d.data_ptr(), stream)
+            p0 = capi.prefilter_stats()
+            dt = timed(cstep, 12)
+            p1 = capi.prefilter_stats()
+            f4 = profiled(cstep, 4, STEP_FAMILIES)
+            uni = sum(cix.scanned_rows(qs[j * bq:(j + 1) * bq].cpu().numpy(), npb)[2] for j in range(4)) / 4
+            sc = f4["ivf_scan"] + f4["ivf_sample_scan"]
+            mv = uni * (2 * d4 + 8)
+            res["batches"][str(bq)] = {
+                "qps": round(bq / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "list_scan_ms": round(sc, 4),
+                "union_rows_per_batch": int(uni), "roofline_frac": round(mv / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
+                "roofline_gbs": round(mv / (sc * 1e-3) / 1e9, 1) if sc else None,
+                "whole_step_frac": round(mv / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "candidate_pass_queries": p1[0] - p0[0], "fallback_queries": p1[1] - p0[1],
+                "step_kernels_ms": {f: round(v, 4) for f, v in f4.items() if v}}
+            if bq == 64:
+                # 64 queries of a batch against the parity oracle on the lists they probe (exported from the index's own storage)
+                cstep(0)
+                torch.cuda.synchronize()
+                t2 = time.time()
+                ei, ed = oracle_on_index_lists(cix, qs[:bq].cpu().numpy(), npb, k, capi.METRIC_IP, threads=cpu_cores())
+                gi, gd = o_i.cpu().numpy(), o_d.cpu().numpy()
+                res["oracle_check"] = {"queries": bq, "ids_and_distances_bit_identical":
+                                       bool((ei == gi).all() and (ed.view(np.uint32) == gd.view(np.uint32)).all()),
+                                       "seconds": round(time.time() - t2, 1)}
+        cix.close()
+        return res
+
     def c5():
         """Hybrid (configs[4]): per query vector top-100 + BM25 top-100 over the same rows + RRF(k=60) -> top-10, in
         batches of 64 (device entries for both searches, fusion in libmsvs_host.so), and the BM25 scorer alone."""
@@ -621,13 +848,18 @@ def main():
     if solo and "c1" not in skip:
         leg("C1", c1, other_cfg)
     if solo and not ({"c3", "c5"} <= skip):
-        del x  # the 10M-row legs want the memory
+        x = None  # the 10M-row legs want the memory
         torch.cuda.empty_cache()
         leg("C3", c3, other_cfg)
         if "c5" not in skip and "index" in big:
             leg("C5", c5, other_cfg)
         if "index" in big:
             big["index"].close()
+            big.clear()
+    if solo and "c4" not in skip:
+        x = None
+        torch.cuda.empty_cache()
+        leg("C4", c4, other_cfg)
 
     if rank == 0:
         out = {
@@ -648,6 +880,8 @@ def main():
             "other_batches": extra.get("other_batches"),
             "latency": extra.get("latency"),
             "iid": extra.get("iid"),
+            "blobs03": extra.get("blobs03"),
+            "c4_sharded": extra.get("c4_sharded"),
             "other_configs": other_cfg or None,
             "setup_s": round(setup_s, 1),
         }

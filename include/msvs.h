@@ -184,6 +184,17 @@ MSVS_API int msvs_index_set_merged_maps(msvs_index_t * index, const uint64_t * r
 MSVS_API int msvs_index_export(const msvs_index_t * index, float * centroids, int64_t * list_off, float * vecs,
                                int64_t * ids);
 
+/* One inverted list of a built IVFFLAT index: its rows (len * dim f32, as stored: cosine indexes hold normalised rows) and
+ * labels (len i64), len = list_off[list + 1] - list_off[list] of msvs_index_export.  Lets a checker redo what a few queries
+ * touch on an index too large to export whole (12.5M x 1536 = 77 GB).  Either output may be NULL. */
+MSVS_API int msvs_index_export_list(const msvs_index_t * index, size_t list, float * vecs, int64_t * ids);
+
+/* Balance of the inverted lists of a built IVFFLAT index: list count, shortest / longest list, and Faiss' imbalance factor
+ * nlist * sum(len^2) / n^2 (1 = uniform; the expected number of rows a probe meets is imbalance * n / nlist); train_empty =
+ * empty clusters the last k-means iteration had to re-seed (0 for loaded indexes / caller-given centroids).  Any out may be NULL. */
+MSVS_API int msvs_index_list_stats(const msvs_index_t * index, size_t * nlist, size_t * min_len, size_t * max_len, double * imbalance,
+                                   size_t * train_empty);
+
 /* Serialisation through caller-supplied streams -- the form the reference's library uses: Search::VectorIndex::serialize
  * (IndexDataFileWriter<OS>*) / saveDataID / load(IndexDataFileReader<IS>*) / loadDataID open every file of the index
  * through the host's opener, a VectorIndexWriter / VectorIndexReader over IDisk (local disk or S3 alike):
@@ -268,6 +279,11 @@ MSVS_API int msvs_comm_unique_id(void * id_out /* MSVS_COMM_ID_BYTES */);
 MSVS_API int msvs_comm_init(const void * id, int nranks, int rank, msvs_comm_t ** out);
 MSVS_API int msvs_comm_init_custom(int nranks, int rank, msvs_allgather_fn all_gather, void * ctx, msvs_comm_t ** out);
 MSVS_API void msvs_comm_free(msvs_comm_t * comm);
+/* Sum of n u64 counters over the ranks, in place in HOST memory, every rank gets the sums -- the one exchange step of a sharded
+ * BM25 search: (total documents, total tokens per column, document frequency per query term), what BM25InfoInDataParts /
+ * the ftsIndex table function add up over parts and shards (BM25InfoInDataParts.cpp:40-93, StorageFtsIndex.cpp:150-213).
+ * Runs on the communicator's all-gather (RCCL or the caller's), ordered on hip_stream, and returns when the sums are there. */
+MSVS_API int msvs_comm_all_reduce_u64(const msvs_comm_t * comm, uint64_t * values, size_t n, void * hip_stream);
 MSVS_API int msvs_comm_rank(const msvs_comm_t * comm);
 MSVS_API int msvs_comm_size(const msvs_comm_t * comm);
 MSVS_API int msvs_shard_search_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries,

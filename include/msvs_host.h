@@ -48,6 +48,7 @@ MSVS_HOST_API int msvs_host_vector_scan_without_index(const uint64_t * offsets, 
  * (key = part_key / mark index), later queries only send their vectors; filters and lightweight deletes travel as row
  * bitmaps over the resident block.  Results are identical to msvs_host_vector_scan_without_index. */
 struct msvs_cache;
+struct msvs_comm;
 MSVS_HOST_API int msvs_host_vector_scan_resident(struct msvs_cache * cache, const char * part_key, const uint64_t * offsets,
                                                  const float * data, size_t rows, size_t dim, size_t index_granularity,
                                                  const float * queries, size_t nq, int k, int metric, int is_batch,
@@ -111,6 +112,11 @@ MSVS_HOST_API int msvs_host_generate_vector_dataset(const void * values, int is_
 /* BM25InfoInDataParts-style statistics reduction (src/VectorIndex/Common/BM25InfoInDataParts.cpp:40-93):
  * element-wise sums of per-part (total_docs, total_tokens, df[n_terms]) vectors laid out [nparts][2 + n_terms]. */
 MSVS_HOST_API void msvs_host_sum_bm25_stats(const uint64_t * per_part, size_t nparts, size_t n_terms, uint64_t * out);
+/* The same sum across the GPUs of a sharded table: this rank's (total_docs, total_tokens, df[n_terms]) in `stats` [2 + n_terms]
+ * (already summed over its own parts) becomes the table-wide vector on every rank -- one msvs_comm_all_reduce_u64 on the
+ * communicator of the vector searches.  What the initiator of a Distributed query does with the shards' ftsIndex rows
+ * (StorageFtsIndex.cpp:150-213) before any shard scores a document. */
+MSVS_HOST_API int msvs_host_all_reduce_bm25_stats(const struct msvs_comm * comm, uint64_t * stats, size_t n_terms, void * hip_stream);
 
 /* ---------------------------------------------------------------------------------------------- seam B host side
  * A part's text index as the device scorer consumes it (myscaledb_amd/host/text_store.cpp): the search-side interface

@@ -24,7 +24,7 @@ SYMBOLS = [
     "msvs_knn_f32", "msvs_normalize_f32", "msvs_index_create", "msvs_index_free", "msvs_index_train",
     "msvs_index_set_centroids", "msvs_index_add", "msvs_index_build", "msvs_index_ready", "msvs_index_num_data",
     "msvs_index_num_lists", "msvs_index_memory_usage", "msvs_index_search", "msvs_index_search_device",
-    "msvs_index_export", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
+    "msvs_index_export", "msvs_index_export_list", "msvs_index_list_stats", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
     "msvs_postings_create", "msvs_postings_create_fields", "msvs_postings_set_alive", "msvs_postings_free",
     "msvs_bm25_search", "msvs_bm25_search_batch", "msvs_bm25_search_batch_device", "msvs_bm25_stats",
     "msvs_release_scratch", "msvs_filter_from_bits", "msvs_filter_from_offsets", "msvs_filter_from_predicate", "msvs_filter_combine", "msvs_filter_count",
@@ -35,7 +35,7 @@ SYMBOLS = [
     "msvs_cache_create", "msvs_cache_free", "msvs_block_upload", "msvs_block_lookup", "msvs_block_release", "msvs_block_info",
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
     "msvs_index_set_merged_maps", "msvs_comm_unique_id", "msvs_comm_init", "msvs_comm_init_custom",
-    "msvs_comm_free", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device",
+    "msvs_comm_free", "msvs_comm_all_reduce_u64", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device",
 ]
 
 
@@ -398,6 +398,20 @@ class Index:
 
     def build(self):
         _check(lib().msvs_index_build(self._h))
+
+    def export_list(self, l, length):
+        """(vecs [length, dim] f32, ids [length] i64) of inverted list l (length from export(with_vecs=False)'s offsets)."""
+        vecs = np.empty((length, self.dim), np.float32)
+        ids = np.empty(length, np.int64)
+        _check(lib().msvs_index_export_list(self._h, C.c_size_t(l), _p(vecs, C.c_float), _p(ids, C.c_int64)))
+        return vecs, ids
+
+    def list_stats(self):
+        """{nlist, min_len, max_len, imbalance (nlist * sum(len^2) / n^2), train_empty} of a built IVFFLAT index."""
+        nl, mn, mx, te = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        imb = C.c_double()
+        _check(lib().msvs_index_list_stats(self._h, C.byref(nl), C.byref(mn), C.byref(mx), C.byref(imb), C.byref(te)))
+        return {"nlist": nl.value, "min_len": mn.value, "max_len": mx.value, "imbalance": imb.value, "train_empty": te.value}
 
     @property
     def ready(self):

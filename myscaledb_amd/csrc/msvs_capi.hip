@@ -504,6 +504,7 @@ struct msvs_index
     // build parameters
     size_t ncentroids = 1024;
     int kmeans_iters = 10;
+    size_t train_empty_last = 0; // empty clusters the last k-means iteration re-seeded (diagnostics)
     size_t train_sample = 0;
     uint64_t seed = 1234;
     int shard_rank = 0, shard_world = 1;
@@ -993,6 +994,47 @@ extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, in
                                d_off.p, d_members.p, ix->centroids.p);
             MSVS_HIP(hipGetLastError());
             MSVS_HIP(hipStreamSynchronize(stream));
+            // Empty clusters are re-seeded the way Faiss' Clustering does (split_clusters; the library behind the reference's
+            // IVF indexes bundles it: BruteForceSearch.h:17,32): an empty cluster takes the centroid of a cluster drawn with
+            // probability ~ (size - 1), the two copies are pushed apart by a relative 1/1024 with alternating sign per dimension,
+            // and the donor's members count as split in halves for the next draw.  Without it a cluster that loses its members
+            // stays where it is for good (round 2: half of the lists <= 10 rows on iid data).
+            size_t nempty = 0;
+            for (size_t j = 0; j < nlist; j++)
+                nempty += off[j + 1] == off[j];
+            if (nempty && ns > nlist)
+            {
+                std::vector<float> hc(nlist * ld);
+                MSVS_HIP(hipMemcpy(hc.data(), ix->centroids.p, nlist * ld * 4, hipMemcpyDeviceToHost));
+                std::vector<double> sz(nlist);
+                for (size_t j = 0; j < nlist; j++)
+                    sz[j] = (double)(off[j + 1] - off[j]);
+                std::mt19937_64 srng(ix->seed * 1315423911ull + (uint64_t)it);
+                std::uniform_real_distribution<double> uni(0.0, 1.0);
+                const double denom = (double)(ns - nlist);
+                for (size_t ci = 0; ci < nlist; ci++)
+                {
+                    if (sz[ci] != 0)
+                        continue;
+                    size_t cj = 0;
+                    for (size_t guard = 0; guard < 64 * nlist; guard++, cj = (cj + 1) % nlist)
+                        if (uni(srng) < (sz[cj] - 1.0) / denom)
+                            break;
+                    if (sz[cj] < 2)
+                        continue; // nothing left to split (more clusters than distinct points)
+                    const float eps = 1.f / 1024.f;
+                    for (uint32_t c = 0; c < d; c++)
+                    {
+                        const float v = hc[cj * ld + c];
+                        hc[ci * ld + c] = v * (c % 2 == 0 ? 1 + eps : 1 - eps);
+                        hc[cj * ld + c] = v * (c % 2 == 0 ? 1 - eps : 1 + eps);
+                    }
+                    sz[ci] = std::floor(sz[cj] / 2);
+                    sz[cj] -= sz[ci];
+                }
+                MSVS_HIP(hipMemcpy(ix->centroids.p, hc.data(), nlist * ld * 4, hipMemcpyHostToDevice));
+            }
+            ix->train_empty_last = nempty;
         }
     });
 }
@@ -1049,10 +1091,45 @@ extern "C" int msvs_index_add(msvs_index_t * ix, const float * x, const int64_t 
             index_assign(*ix, ch.x.p, n, d_assign.p, stream);
             ch.assign.resize(n);
             MSVS_HIP(hipMemcpy(ch.assign.data(), d_assign.p, n * 4, hipMemcpyDeviceToHost));
+            if (ix->shard_world > 1)
+            {
+                // a shard keeps the rows of ITS lists only, and drops the others NOW: a rank that is shown all 100M rows of an
+                // 8-way sharded index stages 12.5M of them, not 100M (the labels were taken from the global staging order above)
+                std::vector<uint32_t> keep;
+                keep.reserve(n / (size_t)ix->shard_world + 16);
+                for (size_t i = 0; i < n; i++)
+                    if (ch.assign[i] % ix->shard_world == ix->shard_rank)
+                        keep.push_back((uint32_t)i);
+                if (keep.size() < n)
+                {
+                    const size_t m = keep.size();
+                    DevBuf<float> kept(std::max<size_t>(m, 1) * ld);
+                    if (m)
+                    {
+                        DevBuf<uint32_t> d_keep(m);
+                        MSVS_HIP(hipMemcpyAsync(d_keep.p, keep.data(), m * 4, hipMemcpyHostToDevice, stream));
+                        const size_t total = m * (ld / 4);
+                        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(total, (size_t)256)), dim3(256), 0, stream,
+                                           reinterpret_cast<const float4 *>(ch.x.p), reinterpret_cast<float4 *>(kept.p), d_keep.p, m, ld / 4);
+                        MSVS_HIP(hipGetLastError());
+                        MSVS_HIP(hipStreamSynchronize(stream));
+                    }
+                    for (size_t j = 0; j < m; j++)
+                    {
+                        ch.ids[j] = ch.ids[keep[j]];
+                        ch.assign[j] = ch.assign[keep[j]];
+                    }
+                    ch.ids.resize(m);
+                    ch.assign.resize(m);
+                    ch.x = std::move(kept);
+                    ch.n = m;
+                }
+            }
         }
         MSVS_HIP(hipStreamSynchronize(stream));
         ix->staged += n;
-        ix->chunks.push_back(std::move(ch));
+        if (ch.n)
+            ix->chunks.push_back(std::move(ch));
     });
 }
 
@@ -1077,7 +1154,12 @@ extern "C" int msvs_index_build(msvs_index_t * ix)
             uint32_t row;
         };
         std::vector<Ref> refs;
-        refs.reserve(ix->staged);
+        {
+            size_t held = 0;
+            for (const auto & ch : ix->chunks)
+                held += ch.n;
+            refs.reserve(held);
+        }
         for (size_t c = 0; c < ix->chunks.size(); c++)
         {
             const auto & ch = ix->chunks[c];
@@ -3339,6 +3421,57 @@ extern "C" int msvs_index_export(const msvs_index_t * ix, float * centroids, int
     });
 }
 
+extern "C" int msvs_index_export_list(const msvs_index_t * ix, size_t list, float * vecs, int64_t * ids)
+{
+    return guarded([&] {
+        if (!ix || !ix->ready || ix->type != MSVS_INDEX_IVFFLAT)
+            fail(MSVS_ERR_NOT_READY, "not a built IVFFLAT index");
+        if (list >= ix->nlist)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "list %zu of %zu", list, ix->nlist);
+        const size_t b = (size_t)ix->h_list_off[list], len = (size_t)ix->h_list_off[list + 1] - b, d = ix->dim, ld = ix->ld;
+        if (!len)
+            return;
+        if (vecs)
+            MSVS_HIP(hipMemcpy2D(vecs, d * 4, ix->vecs.p + b * ld, ld * 4, d * 4, len, hipMemcpyDeviceToHost));
+        if (ids)
+        {
+            std::vector<uint32_t> h(len);
+            MSVS_HIP(hipMemcpy(h.data(), ix->row_ids.p + b, len * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < len; i++)
+                ids[i] = (int64_t)h[i];
+        }
+    });
+}
+
+extern "C" int msvs_index_list_stats(const msvs_index_t * ix, size_t * nlist, size_t * min_len, size_t * max_len, double * imbalance,
+                                     size_t * train_empty)
+{
+    return guarded([&] {
+        if (!ix || !ix->ready)
+            fail(MSVS_ERR_NOT_READY, "index is not ready");
+        size_t mn = ~(size_t)0, mx = 0;
+        double sq = 0;
+        const size_t nl = ix->type == MSVS_INDEX_IVFFLAT ? ix->nlist : 0;
+        for (size_t l = 0; l < nl; l++)
+        {
+            const size_t len = (size_t)(ix->h_list_off[l + 1] - ix->h_list_off[l]);
+            mn = std::min(mn, len);
+            mx = std::max(mx, len);
+            sq += (double)len * (double)len;
+        }
+        if (nlist)
+            *nlist = nl;
+        if (min_len)
+            *min_len = nl ? mn : 0;
+        if (max_len)
+            *max_len = mx;
+        if (imbalance)
+            *imbalance = nl && ix->n ? (double)nl * sq / ((double)ix->n * (double)ix->n) : 1.0;
+        if (train_empty)
+            *train_empty = ix->train_empty_last;
+    });
+}
+
 // ------------------------------------------------------------------------------------------- serialisation
 
 // The index is a set of NAMED files written / read through caller-supplied stream callbacks (msvs_io_t), which is how
@@ -3833,6 +3966,34 @@ extern "C" void msvs_comm_free(msvs_comm_t * c)
     if (c->nccl)
         (void)rccl().CommDestroy(c->nccl);
     delete c;
+}
+
+extern "C" int msvs_comm_all_reduce_u64(const msvs_comm_t * comm, uint64_t * values, size_t n, void * hip_stream)
+{
+    return guarded([&] {
+        if (!comm || (n && !values))
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null communicator / values");
+        if (n == 0 || (comm->nranks == 1 && !comm->nccl))
+            return;
+        // a few dozen counters (BM25: documents, tokens per column, document frequency per query term): one all-gather of
+        // every rank's vector on the communicator the searches use, summed locally -- the same transport whatever it is
+        // (RCCL or the caller's), no second collective type to support
+        hipStream_t stream = as_stream(hip_stream);
+        const size_t W = (size_t)comm->nranks, bytes = n * 8;
+        DevBuf<unsigned char> buf(W * bytes);
+        MSVS_HIP(hipMemcpyAsync(buf.p + (size_t)comm->rank * bytes, values, bytes, hipMemcpyHostToDevice, stream));
+        comm->all_gather(buf.p, bytes, stream);
+        std::vector<uint64_t> all(W * n);
+        MSVS_HIP(hipMemcpyAsync(all.data(), buf.p, W * bytes, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < n; i++)
+        {
+            uint64_t sum = 0;
+            for (size_t r = 0; r < W; r++)
+                sum += all[r * n + i];
+            values[i] = sum;
+        }
+    });
 }
 
 extern "C" int msvs_comm_rank(const msvs_comm_t * c) { return c ? c->rank : -1; }

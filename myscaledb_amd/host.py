@@ -19,7 +19,8 @@ SYMBOLS = ["msvs_host_search_without_index", "msvs_host_search_wrapper", "msvs_h
            "msvs_text_index_total_num_tokens", "msvs_text_index_doc_freq", "msvs_text_index_set_alive",
            "msvs_text_index_bm25_search", "msvs_text_index_bm25_search_batch", "msvs_host_fts_index_statistics",
            "msvs_host_fts_statistics_merge", "msvs_fts_stats_view", "msvs_fts_stats_free", "msvs_host_concurrent_search",
-           "msvs_host_hybrid_search_batch", "msvs_text_tokenize"]
+           "msvs_host_hybrid_search_batch", "msvs_text_tokenize",
+           "msvs_host_all_reduce_bm25_stats"]
 
 _lib = None
 
@@ -419,3 +420,14 @@ def tokenize(text):
         lib().msvs_text_tokenize(raw, buf, len(buf), C.byref(need))
     s = buf.value.decode("utf-8")
     return s.split("\n") if s else []
+
+
+def all_reduce_bm25_stats(comm, total_docs, total_tokens, df, stream=None):
+    """(N, total tokens, df per term) summed over the ranks of a capi.Comm (msvs_host_all_reduce_bm25_stats)."""
+    v = np.array([int(total_docs), int(total_tokens)] + [int(x) for x in df], np.uint64)
+    rc = lib().msvs_host_all_reduce_bm25_stats(comm._h, v.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(len(df)),
+                                               C.c_void_p(stream) if stream else None)
+    if rc != 0:
+        raise capi.MsvsError(rc, capi.lib().msvs_last_error().decode())
+    out = [int(x) for x in v]
+    return out[0], out[1], out[2:]

@@ -897,6 +897,13 @@ extern "C" void msvs_host_sum_bm25_stats(const uint64_t * per_part, size_t npart
             out[j] += per_part[p * w + j];
 }
 
+extern "C" int msvs_host_all_reduce_bm25_stats(const struct msvs_comm * comm, uint64_t * stats, size_t n_terms, void * hip_stream)
+{
+    if (!comm || !stats)
+        return MSVS_ERR_INVALID_ARGUMENT;
+    return msvs_comm_all_reduce_u64(comm, stats, 2 + n_terms, hip_stream);
+}
+
 /* Measurement / test driver for the reference's calling pattern (MergeTreeVSManager.cpp:973: up to ScanThreadLimiter-many host
  * threads, ONE query per VectorIndex::search call): `threads` native threads, thread t searching queries t, t + threads, ...
  * (wrapping) `calls_per_thread` times through msvs_index_search.  seconds = wall time of the whole run; lat_us (nullable,

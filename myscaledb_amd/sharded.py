@@ -18,29 +18,24 @@ from . import capi
 
 def exchange_and_merge(local_ids, local_dis, metric, group=None, stream=None):
     """local_ids int64 [nq,k], local_dis float32 [nq,k] (same device on every rank) -> merged (ids, dis) on all ranks.
-    metric: capi.METRIC_L2 (ascending; also for cosine distances) or capi.METRIC_IP (descending)."""
+    metric: capi.METRIC_L2 (ascending; also for cosine distances) or capi.METRIC_IP (descending).
+    ONE collective either way: the partial lists travel as one packed buffer {ids | dis} per rank (PackedExchange on the
+    GPU; on host tensors -- the gloo tests -- one all_gather of the packed bytes, merged by libmsvs_host.so)."""
     world = dist.get_world_size(group)
     nq, k = local_ids.shape
-    g_ids = torch.empty((world, nq, k), dtype=torch.int64, device=local_ids.device)
-    g_dis = torch.empty((world, nq, k), dtype=torch.float32, device=local_dis.device)
     if local_ids.is_cuda:
-        dist.all_gather_into_tensor(g_ids, local_ids.contiguous(), group=group)
-        dist.all_gather_into_tensor(g_dis, local_dis.contiguous(), group=group)
-        out_ids = torch.empty((nq, k), dtype=torch.int64, device=local_ids.device)
-        out_dis = torch.empty((nq, k), dtype=torch.float32, device=local_ids.device)
-        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        capi._check(capi.lib().msvs_merge_topk_device(
-            C.c_void_p(g_ids.data_ptr()), C.c_void_p(g_dis.data_ptr()), C.c_size_t(world), C.c_size_t(nq),
-            C.c_size_t(k), int(metric), C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_dis.data_ptr()),
-            C.c_void_p(s) if s else None))
-        return out_ids, out_dis
-    # host tensors (gloo): all_gather into lists, merge with the host mirror
+        px = PackedExchange(nq, k, local_ids.device, group)
+        px.ids.copy_(local_ids)
+        px.dis.copy_(local_dis)
+        oi, od = px.run(metric, stream)
+        return oi.clone(), od.clone()
     from . import host
-    il = [torch.empty_like(local_ids) for _ in range(world)]
-    dl = [torch.empty_like(local_dis) for _ in range(world)]
-    dist.all_gather(il, local_ids.contiguous(), group=group)
-    dist.all_gather(dl, local_dis.contiguous(), group=group)
-    oi, od = host.merge_topk(torch.stack(il).numpy(), torch.stack(dl).numpy(), metric)
+    packed = torch.cat([local_ids.contiguous().view(torch.uint8).reshape(-1), local_dis.contiguous().view(torch.uint8).reshape(-1)])
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(parts, packed, group=group)
+    il = torch.stack([p_[:nq * k * 8].view(torch.int64).view(nq, k) for p_ in parts])
+    dl = torch.stack([p_[nq * k * 8:].view(torch.float32).view(nq, k) for p_ in parts])
+    oi, od = host.merge_topk(il.numpy(), dl.numpy(), metric)
     return torch.from_numpy(oi), torch.from_numpy(od)
 
 
@@ -73,8 +68,13 @@ class PackedExchange:
         return self.out_ids, self.out_dis
 
 
-def all_reduce_bm25_stats(total_docs, total_tokens, df, group=None, device="cpu"):
-    """Sum (N, total tokens, df[terms]) over the ranks: the one exchange step of sharded BM25."""
+def all_reduce_bm25_stats(total_docs, total_tokens, df, group=None, device="cpu", comm=None):
+    """Sum (N, total tokens, df[terms]) over the ranks: the one exchange step of sharded BM25.  With a libmsvs communicator
+    (capi.Comm) the sum runs through the C-ABI the C++ host would call (msvs_host_all_reduce_bm25_stats ->
+    msvs_comm_all_reduce_u64); without one (CPU tests over gloo) through torch.distributed."""
+    if comm is not None:
+        from . import host
+        return host.all_reduce_bm25_stats(comm, total_docs, total_tokens, df)
     t = torch.tensor([int(total_docs), int(total_tokens)] + [int(x) for x in df], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     v = t.cpu().tolist()

@@ -14,7 +14,7 @@ import torch
 
 import myscaledb_amd.capi as capi
 import myscaledb_amd.host as mhost
-from bench import _latent_model, _sample, build_postings, make_data, make_queries
+from bench import _latent_model, _sample, build_postings, ivf_params, make_data, make_queries, oracle_on_index_lists
 from oracle import oracle as o
 
 pytestmark = pytest.mark.gpu
@@ -103,7 +103,10 @@ def test_c3_10m_x_768_cosine_batch_64(ten_million, opt):
     ci, cd = ix.search(q, k, "nprobe=%d" % nprobe)
     same(ci, cd, ids, dis)
     opt("ivf_pass", None)
-    # the oracle on what 6 of the queries touch
+    # the oracle on what EVERY query of the batch touches (rows exported list by list from the index's own storage)
+    ei, ed = oracle_on_index_lists(ix, q, nprobe, k, capi.METRIC_COSINE, threads=16)
+    same(ids, dis, ei, ed)
+    # ... and, for six of them, on the rows gathered from the source table by id: the storage holds what was added
     cent, off, _, lids = ix.export(with_vecs=False)
     ei, ed = oracle_on_probed_lists(ix, x, q[:6], nprobe, k, capi.METRIC_COSINE, cent, off, lids)
     same(ids[:6], dis[:6], ei, ed)
@@ -129,7 +132,7 @@ def test_c5_10m_documents_bm25_batch_vector_top100_rrf(ten_million):
     vi, vd = ix.search(q_dev.cpu().numpy(), 100, "nprobe=%d" % nprobe)
     assert (vi >= 0).all()
     import ctypes as C
-    for qi in (0, 9, 33, 63):
+    for qi in range(bq):  # every query of the batch
         sr, ss = ps.bm25_search(terms[qi], dfs[qi], n, total, 100)
         assert sr.tolist() == got[qi][0].tolist() and (ss.view(np.uint32) == got[qi][1].view(np.uint32)).all()
         assert (np.diff(ss) <= 0).all() and len(sr) == 100
@@ -171,7 +174,7 @@ def test_c5_bm25_10m_against_the_oracle_scorer():
     alive = rng.random(n) < 0.5
     for al in (None, alive):
         got = ps.bm25_search_batch(terms, dfs, n, total, 100, alive=al)
-        for qi in (0, 5, 17, 40):
+        for qi in (range(64) if al is None else (0, 5, 17, 40)):  # the whole batch against the oracle's scorer; a sample under the filter
             er, es = o.bm25_search(post_off, doc, tf, fn, terms[qi], dfs[qi], n, total, 100, alive=al)
             assert got[qi][0].tolist() == er.tolist()
             assert (got[qi][1].view(np.uint32) == es.view(np.uint32)).all()
@@ -210,3 +213,54 @@ def test_c4_shape_ivfflat_ip_1536_eight_shards():
         sh.close()
     mi, md = capi.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), capi.METRIC_IP)
     same(mi, md, fi, fd)
+
+
+def test_c4_one_gpu_share_12m5_rows_1536_ip_against_the_oracle():
+    """One GPU's share of BASELINE config 4 at FULL size: 12.5M rows x 1536, inner product, 2048 lists (16384 / 8), 8 probes per
+    query (64 / 8) -- bench.py's C4 leg.  A 1024-query batch through the candidate pass; 64 of its queries against the parity
+    oracle on the lists they probe (exported from the index's own 77 GB of rows list by list); whole-batch properties; a query
+    alone == inside the batch; and the register-tile kernel (two parts of the reduction dimension) returns the same bits."""
+    n, d, nlist, nprobe, k = 12_500_000, 1536, 2048, 8, 10
+    dev = torch.device("cuda", 0)
+    model = _latent_model(d, 99, dev, nlist)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_IP, d, ivf_params(nlist, n))
+    xs = _sample(model, 262144, g, dev)
+    ix.train(xs.data_ptr(), n=xs.shape[0], mem=capi.MEM_DEVICE)
+    del xs
+    buf = torch.empty((500_000, d), device=dev, dtype=torch.float32)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    for lo in range(0, n, 500_000):
+        _sample(model, 500_000, g, dev, out=buf)
+        ix.add(buf.data_ptr(), n=500_000, mem=capi.MEM_DEVICE)
+    del buf
+    ix.build()
+    assert ix.num_data == n
+    st = ix.list_stats()
+    assert st["nlist"] == nlist and st["min_len"] > 0
+    B = 1024
+    q_dev = make_queries(model, B, 4321, dev)
+    oi = torch.empty((B, k), device=dev, dtype=torch.int64)
+    od = torch.empty((B, k), device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    p0 = capi.prefilter_stats()
+    ix.search_device(q_dev.data_ptr(), B, k, nprobe, oi.data_ptr(), od.data_ptr(), stream)
+    torch.cuda.synchronize()
+    p1 = capi.prefilter_stats()
+    assert p1[0] - p0[0] == B and p1[1] - p0[1] <= B // 50  # the candidate pass ran and certified (almost) everybody
+    ids, dis = oi.cpu().numpy(), od.cpu().numpy()
+    assert (np.diff(dis, axis=1) <= 0).all()  # inner product: descending
+    assert all(len(set(r)) == k for r in ids.tolist()) and ids.min() >= 0 and ids.max() < n
+    q = q_dev.cpu().numpy()
+    ei, ed = oracle_on_index_lists(ix, q[:64], nprobe, k, capi.METRIC_IP, threads=16)
+    same(ids[:64], dis[:64], ei, ed)
+    i1, d1 = ix.search(q[70:71], k, "nprobe=%d" % nprobe)
+    same(i1, d1, ids[70:71], dis[70:71])
+    capi.set_option("h16_reg", "2")
+    try:
+        ix.search_device(q_dev.data_ptr(), B, k, nprobe, oi.data_ptr(), od.data_ptr(), stream)
+        torch.cuda.synchronize()
+    finally:
+        capi.set_option("h16_reg", None)
+    same(oi.cpu().numpy(), od.cpu().numpy(), ids, dis)
+    ix.close()
