@@ -172,6 +172,7 @@ struct Options
     double fb_cap = 0;        // queries per round of the canonical fallback (0 = by memory; small values: many rounds)
     double h16_nocut = 0;     // shadow pass: no sample cut, every probed row becomes a candidate (tests)
     double h16_ncb = 0;       // shadow pass: column blocks (32 queries each) per tile, 0 = planned
+    double rerank_second = 1; // queries whose first certificate fails get their whole candidate buffer re-ranked before the canonical scan
     double h16_dbg = 0;       // experiments: ablation bits of h16r_scan_kernel (wrong results)
     double h16_reg = 0;       // shadow pass with the queries in registers and the rows through LDS (h16r_scan_kernels.hpp): 0 never
                               // (measured: at par or slower than the LDS-tile kernel, profiles/r03_h16r_notes.txt), 1 when the average

@@ -517,6 +517,22 @@ void launch_ivf_rerank(int metric, RerankParams a, uint32_t nq, hipStream_t stre
     MSVS_HIP(hipGetLastError());
 }
 
+void launch_ivf_rerank_all(int metric, const RerankParams & a, const RerankAllParams & b, uint32_t nq, hipStream_t stream)
+{
+    if (nq == 0)
+        return;
+    if (a.k > RA_KMAX)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "second-chance re-rank for k = %u", a.k);
+    const size_t lds = (size_t)a.ld4 * 16 + (2 * RA_KMAX + RA_CHUNK) * 8;
+    ProfileScope prof("rerank", stream);
+    const uint32_t grid = std::min<uint32_t>(nq, 2048); // usually nobody is on the list: every block exits at once
+    if (metric == M_IP)
+        hipLaunchKernelGGL((ivf_rerank_all_kernel<M_IP>), dim3(grid), dim3(256), lds, stream, a, b);
+    else
+        hipLaunchKernelGGL((ivf_rerank_all_kernel<M_L2>), dim3(grid), dim3(256), lds, stream, a, b);
+    MSVS_HIP(hipGetLastError());
+}
+
 template <int METRIC>
 static void ivf_subset_dispatch(const ScanParams & a, uint32_t z, hipStream_t stream)
 {
@@ -605,7 +621,7 @@ const OptionField g_option_fields[] = {
     {"cand_cap", &Options::cand_cap},       {"ivf_eps_scale", &Options::ivf_eps_scale},
     {"h16_nt", &Options::h16_nt},           {"h16_grid", &Options::h16_grid},
     {"h16_min_pairs", &Options::h16_min_pairs}, {"h16_ncb", &Options::h16_ncb},
-    {"h16_nocut", &Options::h16_nocut},     {"fb_cap", &Options::fb_cap},           {"h16_reg", &Options::h16_reg},       {"h16_dbg", &Options::h16_dbg},
+    {"h16_nocut", &Options::h16_nocut},     {"fb_cap", &Options::fb_cap},           {"h16_reg", &Options::h16_reg},       {"h16_dbg", &Options::h16_dbg},       {"rerank_second", &Options::rerank_second},
     {"lat_path", &Options::lat_path},         {"filter_compact_below", &Options::filter_compact_below},
     {"bm25_wave", &Options::bm25_wave},
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},

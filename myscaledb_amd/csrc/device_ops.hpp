@@ -122,6 +122,8 @@ void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint3
 
 /// Canonical re-rank of the candidates + certificate; failing queries are appended to a.failq.
 void launch_ivf_rerank(int metric, RerankParams a, uint32_t nq, hipStream_t stream);
+/// Second chance of the queries on a.failq-style list b.failq_in: re-rank of their whole candidate buffers (mfma_scan_kernels.hpp).
+void launch_ivf_rerank_all(int metric, const RerankParams & a, const RerankAllParams & b, uint32_t nq, hipStream_t stream);
 
 /// Canonical scan / merge of the queries listed in (a.qmap, *a.qcount) with `z` block slots per (segment, probe).
 void launch_ivf_scan_subset(int metric, ScanParams a, uint32_t z, hipStream_t stream);

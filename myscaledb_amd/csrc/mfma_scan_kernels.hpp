@@ -1127,6 +1127,149 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
     }
 }
 
+/// SECOND CHANCE of a query whose certificate failed: the canonical distance of EVERY row in its candidate buffer (everything the
+/// pass kept below the query's cut: a few hundred rows, not the kc best of them), exact top-k by ranking, certificate against
+/// the cut itself -- the smallest approximate value a row outside the buffer can have.  The first certificate compares the
+/// k-th exact distance with the kc-th approximate one (32 candidates for k <= 12): on data whose distances concentrate
+/// (1024 blobs, sigma 0.3, in R^768: the 10th and the 32nd neighbour are 3 eps apart) a sixth of the queries fail it, and the
+/// canonical scan of all their probed lists costs 20 x the step.  Here the margin is cut - e_k (rank ~250 against rank k);
+/// only a query that fails this one too, or whose buffer overflowed, goes to the canonical scan (failq_out).
+/// One block of 256 threads per failed query (grid-stride over *nfail_in), 16 lanes per candidate row as in ivf_rerank_kernel.
+/// dynamic LDS: ld4 * 16 + (2 * RA_KMAX + RA_CHUNK) * 8 bytes.
+constexpr uint32_t RA_KMAX = 128, RA_CHUNK = 256;
+struct RerankAllParams
+{
+    const uint64_t * partial; // [nq][cap] candidate keys (approximate word << 32 | row position)
+    const uint32_t * qcnt;    // [nq] candidates appended (may exceed cap: overflow)
+    const uint32_t * qthr;    // [nq] the cut (0xFFFFFFFF = none: every probed row is a candidate)
+    uint32_t cap;
+    const uint32_t * failq_in;
+    const uint32_t * nfail_in;
+    uint32_t * failq_out;
+    uint32_t * nfail_out; // zeroed by the caller
+    unsigned long long * stat_fail;
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams a, const RerankAllParams b)
+{
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * best = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16); // [RA_KMAX] running exact top-k, ascending
+    uint64_t * chunk = best + RA_KMAX;                                              // [RA_CHUNK] this round's exact keys
+    uint64_t * tmp = chunk + RA_CHUNK;                                              // [RA_KMAX]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, g = tid & 15;
+    const uint32_t ld4 = a.ld4, k = a.k;
+    const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
+    const uint32_t nf = *b.nfail_in;
+    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x)
+    {
+        const uint32_t q = b.failq_in[f];
+        const uint32_t cnt = b.qcnt[q];
+        bool ok = cnt <= b.cap; // an overflowed buffer dropped rows below the cut: nothing to certify
+        __syncthreads();        // the previous query is done with the LDS arrays
+        if (ok)
+        {
+            for (uint32_t c = tid; c < ld4; c += 256)
+                qs[c] = a.Q[(size_t)q * ld4 + c];
+            for (uint32_t c = tid; c < RA_KMAX; c += 256)
+                best[c] = tmp[c] = KEY_NONE;
+            __syncthreads();
+            for (uint32_t base = 0; base < cnt; base += RA_CHUNK)
+            {
+                for (uint32_t c = grp; c < RA_CHUNK; c += 16)
+                {
+                    uint64_t key = KEY_NONE;
+                    if (base + c < cnt) // uniform over the 16 lanes of the group
+                    {
+                        const uint32_t pos = (uint32_t)b.partial[(size_t)q * b.cap + base + c];
+                        const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
+                        const float4 * qrow = qs + g;
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        uint32_t j = 0;
+                        for (; j + 4 <= jfull; j += 4)
+                        {
+                            const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16], y3 = yrow[(j + 3) * 16];
+                            canonical_update<METRIC>(acc, qrow[j * 16], y0);
+                            canonical_update<METRIC>(acc, qrow[(j + 1) * 16], y1);
+                            canonical_update<METRIC>(acc, qrow[(j + 2) * 16], y2);
+                            canonical_update<METRIC>(acc, qrow[(j + 3) * 16], y3);
+                        }
+                        for (; j < jfull; j++)
+                            canonical_update<METRIC>(acc, qrow[j * 16], yrow[j * 16]);
+                        if (g < jtail)
+                            canonical_update<METRIC>(acc, qrow[jfull * 16], yrow[jfull * 16]);
+                        float s = __fadd_rn(__fadd_rn(acc.x, acc.y), __fadd_rn(acc.z, acc.w));
+                        s = row16_tree_sum(s);
+                        key = make_key<METRIC>(s, a.ids ? a.ids[pos] : pos);
+                    }
+                    if (g == 0)
+                        chunk[c] = key;
+                }
+                __syncthreads();
+                // the k best of (running k, this chunk): every key ranks itself among the RA_KMAX + RA_CHUNK slots
+                for (uint32_t i = tid; i < RA_KMAX + RA_CHUNK; i += 256)
+                {
+                    const uint64_t mine = best[i]; // best and chunk are contiguous
+                    if (mine == KEY_NONE)
+                        continue;
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < RA_KMAX + RA_CHUNK; j++)
+                        rank += best[j] < mine || (best[j] == mine && j < i) ? 1u : 0u;
+                    if (rank < RA_KMAX)
+                        tmp[rank] = mine;
+                }
+                __syncthreads();
+                for (uint32_t c = tid; c < RA_KMAX; c += 256) // ranks nobody took stay KEY_NONE
+                {
+                    best[c] = tmp[c];
+                    tmp[c] = KEY_NONE;
+                }
+                __syncthreads();
+            }
+            // certificate against the cut
+            if (tid == 0)
+            {
+                const uint32_t cutw = b.qthr[q];
+                bool good = true;
+                if (cutw != 0xFFFFFFFFu)
+                {
+                    const uint64_t ek = best[k - 1];
+                    const float qn = a.qnorm[q];
+                    if (ek == KEY_NONE || !(qn < 1e30f) || !(a.xmax < 1e30f))
+                        good = false;
+                    else
+                    {
+                        const double al = (double)key_value<METRIC>((uint64_t)cutw << 32), e = (double)key_value<METRIC>(ek);
+                        const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
+                        const double eps = rerank_eps<METRIC>(a, sx, sq);
+                        good = METRIC == M_L2 ? (al - eps > e) : (al + eps < e);
+                    }
+                }
+                *reinterpret_cast<volatile uint32_t *>(tmp) = good ? 1u : 0u;
+            }
+            __syncthreads();
+            ok = *reinterpret_cast<volatile uint32_t *>(tmp) != 0;
+            if (ok)
+                for (uint32_t r = tid; r < k; r += 256)
+                {
+                    const uint64_t mine = best[r];
+                    const size_t o = (size_t)q * k + r;
+                    a.out_ids[o] = mine == KEY_NONE ? -1 : (int64_t)(uint32_t)mine;
+                    const float v = key_value<METRIC>(mine);
+                    a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+                }
+        }
+        if (!ok && tid == 0)
+        {
+            b.failq_out[atomicAdd(b.nfail_out, 1u)] = q;
+            if (b.stat_fail)
+                atomicAdd(b.stat_fail, 1ull);
+        }
+        (void)lane;
+        (void)wave;
+    }
+}
+
 /// ivf_scan_kernel over a device-side list of queries: grid (seg_max, nprobe, Z); block z handles the entries
 /// slot_base + z, + Z, ... of a.qmap inside this round's window (usually *a.qcount is 0: every block exits at once); the
 /// partial lists are indexed by the entry's position in the window, so the buffers hold slot_cap queries, not nq.

@@ -1440,7 +1440,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
             + nq * (size_t)p.kc * 8 + nq * 24 + 8192
             + fallback_cap(nq, nprobe, p.seg_max1, k) * nprobe * (size_t)p.seg_max1 * k * 8
-            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8) + HR_CPP * 128 + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
+            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8 + 4) + HR_CPP * 128 + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
     return need;
@@ -1863,15 +1863,16 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.rows_per_block = 0x7fffffffu; // one segment per non-empty row range
     const bool reg_tile = pl.h_ks != 0 && !d_alive; // filtered searches keep the LDS-resident tile (the register kernel has no bit test)
     pp.T = reg_tile ? 32 * (8 / pl.h_ks) : 32 * pl.h_ncb;
-    uint32_t * counters = scr.take<uint32_t>(2 * ix.nlist + 1 + 16);
+    uint32_t * counters = scr.take<uint32_t>(2 * ix.nlist + 2 + 16);
     pp.cnt = counters;
     pp.fill = counters + ix.nlist;
     uint32_t * nfail = counters + 2 * ix.nlist;
     uint32_t * sched = nfail + 1; // 8 work-queue cursors per launch
+    uint32_t * nfail2 = sched + 16; // queries still without a certificate after the second chance
     pp.pair_off = scr.take<uint32_t>(ix.nlist + 1);
     pp.work_off = scr.take<uint32_t>(ix.nlist + 1);
     pp.pairs = scr.take<uint32_t>(nq * nprobe);
-    MSVS_HIP(hipMemsetAsync(counters, 0, (2 * ix.nlist + 1 + 16) * sizeof(uint32_t), stream));
+    MSVS_HIP(hipMemsetAsync(counters, 0, (2 * ix.nlist + 2 + 16) * sizeof(uint32_t), stream));
     launch_ivf_plan(pp, stream);
     IvfPlanParams pa = pp; // the sample launch: block 0 of every probed list, tiles of 32 queries (small workgroups)
     pa.list_off = ix.list_off.p;
@@ -1993,10 +1994,30 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     rp.failq = failq;
     rp.nfail = nfail;
     rp.early_exit = options().rerank_early != 0 ? 1 : 0;
-    rp.stat_fail = prefilter_fail_counter();
+    const bool second = options().rerank_second != 0 && k <= RA_KMAX;
+    rp.stat_fail = second ? nullptr : prefilter_fail_counter(); // the statistic counts queries that reach the canonical scan
     rp.stat_skip = options().rerank_stats != 0 ? prefilter_fail_counter() + 2 : nullptr;
     launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
     g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
+    // second chance of the queries without a certificate: every row of their candidate buffers, certified against the cut
+    uint32_t * failq2 = failq;
+    uint32_t * nfail_final = nfail;
+    if (second)
+    {
+        failq2 = scr.take<uint32_t>(nq);
+        nfail_final = nfail2;
+        RerankAllParams ra{};
+        ra.partial = partial;
+        ra.qcnt = qstate + nq;
+        ra.qthr = qstate;
+        ra.cap = pl.h_cap;
+        ra.failq_in = failq;
+        ra.nfail_in = nfail;
+        ra.failq_out = failq2;
+        ra.nfail_out = nfail2;
+        ra.stat_fail = prefilter_fail_counter();
+        launch_ivf_rerank_all(scan_metric(m), rp, ra, (uint32_t)nq, stream);
+    }
     // queries without a certificate: canonical scan, one query per block (normally zero of them)
     const size_t fb_cap = fallback_cap(nq, nprobe, pl.seg_max1, k);
     uint64_t * partial1 = scr.take<uint64_t>(fb_cap * nprobe * (size_t)pl.seg_max1 * k);
@@ -2016,8 +2037,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     c.partial = partial1;
     c.rows_per_block = pl.rpb1;
     c.seg_max = pl.seg_max1;
-    c.qmap = failq;
-    c.qcount = nfail;
+    c.qmap = failq2;
+    c.qcount = nfail_final;
     IvfMergeParams fm{};
     fm.partial = partial1;
     fm.probes = d_probes;
@@ -2029,8 +2050,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     fm.out_ids = d_ids;
     fm.out_dis = d_dis;
     fm.cosine = ix.metric == MSVS_METRIC_COSINE;
-    fm.qmap = failq;
-    fm.qcount = nfail;
+    fm.qmap = failq2;
+    fm.qcount = nfail_final;
     run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, pl.fb_slots, stream);
 }
 

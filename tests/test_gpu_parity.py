@@ -535,6 +535,44 @@ def test_shadow_pass_serves_k_up_to_128_with_256_candidates(metric, opt):
     assert capi.prefilter_stats()[0] == q2
 
 
+def test_second_chance_rerank_of_the_whole_candidate_buffer(opt):
+    """Distances that concentrate (gaussian blobs of sigma 0.3 in a few hundred dimensions: the 10th and the 32nd neighbour of a
+    query are a couple of error bounds apart) fail the first certificate -- k-th exact distance against the kc-th approximate
+    one -- for a good share of the queries.  The second chance re-ranks every row of a failed query's candidate buffer and
+    certifies against the cut: almost nobody is left for the canonical scan, and the answer is the canonical one either way."""
+    rng = np.random.default_rng(303)
+    n, d, blobs, nq, nprobe, k = 100000, 768, 96, 400, 4, 10
+    centres = rng.standard_normal((blobs, d), dtype=np.float32)
+    x = (centres[rng.integers(0, blobs, n)] + 0.3 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centres[rng.integers(0, blobs, nq)] + 0.3 * rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    ix = build_ivf(x, capi.METRIC_L2, blobs)
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, capi.METRIC_L2)
+    opt("ivf_pass", "2")
+    opt("rerank_second", "0")
+    q0, f0 = capi.prefilter_stats()
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    q1, f1 = capi.prefilter_stats()
+    assert q1 - q0 == nq
+    first_stage_failures = f1 - f0
+    opt("rerank_second", None)
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    q2, f2 = capi.prefilter_stats()
+    assert q2 - q1 == nq
+    assert first_stage_failures >= nq // 50, "the data no longer provokes first-stage failures: the test tests nothing"
+    assert f2 - f1 <= first_stage_failures // 5
+    # overflowing buffers cannot be certified by the second chance either: canonical scan, same answer
+    opt("cand_cap", "64")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    opt("cand_cap", None)
+    # k = 100 through the 256-candidate form
+    oi, od, _ = oracle_on_exported(ix, q[:200], nprobe, 100, capi.METRIC_L2)
+    ids, dis = ix.search(q[:200], 100, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+
+
 def test_matrix_core_pass_with_massive_ties_and_unusable_norms():
     rng = np.random.default_rng(77)
     n, d, nlist, nq = 6000, 48, 4, 128
