@@ -999,16 +999,20 @@ extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, in
             // probability ~ (size - 1), the two copies are pushed apart by a relative 1/1024 with alternating sign per dimension,
             // and the donor's members count as split in halves for the next draw.  Without it a cluster that loses its members
             // stays where it is for good (round 2: half of the lists <= 10 rows on iid data).
+            // ... "empty" here includes the nearly empty: a cluster holding less than 1/16 of the average is a centroid that
+            // fits a handful of sample points (on unstructured data it ends with a list of one or two rows); it is re-seeded
+            // like an empty one, except in the last iteration (its members would be left without their mean)
+            const size_t tiny = it + 1 < ix->kmeans_iters ? ns / nlist / 16 : 0;
             size_t nempty = 0;
             for (size_t j = 0; j < nlist; j++)
-                nempty += off[j + 1] == off[j];
+                nempty += (size_t)(off[j + 1] - off[j]) <= tiny;
             if (nempty && ns > nlist)
             {
                 std::vector<float> hc(nlist * ld);
                 MSVS_HIP(hipMemcpy(hc.data(), ix->centroids.p, nlist * ld * 4, hipMemcpyDeviceToHost));
                 std::vector<double> sz(nlist);
                 for (size_t j = 0; j < nlist; j++)
-                    sz[j] = (double)(off[j + 1] - off[j]);
+                    sz[j] = (size_t)(off[j + 1] - off[j]) <= tiny ? 0.0 : (double)(off[j + 1] - off[j]);
                 std::mt19937_64 srng(ix->seed * 1315423911ull + (uint64_t)it);
                 std::uniform_real_distribution<double> uni(0.0, 1.0);
                 const double denom = (double)(ns - nlist);

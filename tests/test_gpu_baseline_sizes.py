@@ -264,3 +264,24 @@ def test_c4_one_gpu_share_12m5_rows_1536_ip_against_the_oracle():
         capi.set_option("h16_reg", None)
     same(oi.cpu().numpy(), od.cpu().numpy(), ids, dis)
     ix.close()
+
+
+def test_trainer_on_iid_rows_leaves_no_dead_lists():
+    """k-means with SURVEY 8d's parameters (20 iterations, 256 k sample, seed 7) on iid N(0,1)^768 rows -- nothing to find, the
+    centroids fit sample noise: round 2's trainer (empty clusters left where they were) ended with half of the 1024 lists at
+    <= 10 rows and a tenth above 4600.  Re-seeding empty and nearly empty clusters (Faiss' split_clusters): every list alive,
+    imbalance factor nlist * sum(len^2) / n^2 <= 1.5; the lists are still a permutation of the input."""
+    n, d, nlist = 1_000_000, 768, 1024
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    x = torch.randn((n, d), generator=g, device=dev, dtype=torch.float32)
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, ivf_params(nlist, n))
+    ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+    ix.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+    ix.build()
+    st = ix.list_stats()
+    assert st["nlist"] == nlist and st["min_len"] > 10 and st["imbalance"] <= 1.5, st
+    _, off, _, lids = ix.export(with_vecs=False)
+    assert off[0] == 0 and off[-1] == n and (np.diff(off) >= 0).all()
+    assert (np.sort(lids) == np.arange(n)).all()
+    ix.close()
