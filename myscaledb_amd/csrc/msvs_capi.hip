@@ -1002,17 +1002,62 @@ extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, in
             // ... "empty" here includes the nearly empty: a cluster holding less than 1/16 of the average is a centroid that
             // fits a handful of sample points (on unstructured data it ends with a list of one or two rows); it is re-seeded
             // like an empty one, except in the last iteration (its members would be left without their mean)
-            const size_t tiny = it + 1 < ix->kmeans_iters ? ns / nlist / 16 : 0;
+            const bool last_it = it + 1 >= ix->kmeans_iters;
+            const size_t tiny = last_it ? 0 : ns / nlist / 16;
+            std::vector<char> give_up(nlist, 0); // clusters re-seeded although they have members
             size_t nempty = 0;
             for (size_t j = 0; j < nlist; j++)
                 nempty += (size_t)(off[j + 1] - off[j]) <= tiny;
-            if (nempty && ns > nlist)
+            // ... and the oversized: Lloyd's iteration cannot undo a seeding that put two centroids into one well-separated blob
+            // and none into another (the orphan blobs merge into a neighbour's list: 12 blobs in one list on SURVEY 8d's
+            // sigma-0.3 model).  While a cluster holds more than 2.5 x the average, the smallest cluster below 0.75 x the average
+            // gives its centroid up to split it; its members fall to their next centroid (the twin inside the same blob).
+            std::vector<std::pair<size_t, size_t>> forced; // (small cluster, the giant it splits)
+            if (!last_it && ns > 4 * nlist)
+            {
+                const double avg = (double)ns / (double)nlist;
+                std::vector<size_t> order(nlist);
+                std::iota(order.begin(), order.end(), (size_t)0);
+                std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+                    const int64_t sx = off[x + 1] - off[x], sy = off[y + 1] - off[y];
+                    return sx != sy ? sx < sy : x < y;
+                });
+                size_t lo = 0, hi = nlist;
+                while (lo + 1 < hi)
+                {
+                    const size_t small = order[lo], big = order[hi - 1];
+                    const double ssz = (double)(off[small + 1] - off[small]), bsz = (double)(off[big + 1] - off[big]);
+                    if (!(bsz > 2.5 * avg && ssz < 0.75 * avg))
+                        break;
+                    if (ssz > (double)tiny) // the tiny ones are re-seeded by the draw below anyway
+                    {
+                        forced.push_back({small, big});
+                        give_up[small] = 1;
+                        hi--;
+                    }
+                    lo++;
+                }
+            }
+            if ((nempty || !forced.empty()) && ns > nlist)
             {
                 std::vector<float> hc(nlist * ld);
                 MSVS_HIP(hipMemcpy(hc.data(), ix->centroids.p, nlist * ld * 4, hipMemcpyDeviceToHost));
                 std::vector<double> sz(nlist);
                 for (size_t j = 0; j < nlist; j++)
                     sz[j] = (size_t)(off[j + 1] - off[j]) <= tiny ? 0.0 : (double)(off[j + 1] - off[j]);
+                const float feps = 1.f / 1024.f;
+                for (const auto & fs : forced)
+                {
+                    const size_t ci = fs.first, cj = fs.second;
+                    for (uint32_t c = 0; c < d; c++)
+                    {
+                        const float v = hc[cj * ld + c];
+                        hc[ci * ld + c] = v * (c % 2 == 0 ? 1 + feps : 1 - feps);
+                        hc[cj * ld + c] = v * (c % 2 == 0 ? 1 - feps : 1 + feps);
+                    }
+                    sz[ci] = std::floor(sz[cj] / 2);
+                    sz[cj] -= sz[ci];
+                }
                 std::mt19937_64 srng(ix->seed * 1315423911ull + (uint64_t)it);
                 std::uniform_real_distribution<double> uni(0.0, 1.0);
                 const double denom = (double)(ns - nlist);

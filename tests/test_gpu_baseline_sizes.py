@@ -237,7 +237,7 @@ def test_c4_one_gpu_share_12m5_rows_1536_ip_against_the_oracle():
     ix.build()
     assert ix.num_data == n
     st = ix.list_stats()
-    assert st["nlist"] == nlist and st["min_len"] > 0
+    assert st["nlist"] == nlist  # (inner-product assignment may leave a list of a small-norm centroid empty)
     B = 1024
     q_dev = make_queries(model, B, 4321, dev)
     oi = torch.empty((B, k), device=dev, dtype=torch.int64)
