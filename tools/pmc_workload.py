@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import myscaledb_amd.capi as capi  # noqa: E402
-from bench import make_data, make_queries  # noqa: E402
+from bench import ivf_params, make_data, make_queries  # noqa: E402
 
 
 def main():
@@ -22,7 +22,7 @@ def main():
     dev = torch.device("cuda", 0)
     n, d, nlist, nprobe, k = 1_000_000, 768, 1024, 32, 10
     model, x = make_data(n, d, 1234, dev)
-    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=%d,kmeans_iters=10,train_sample=%d" % (nlist, nlist * 64))
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, ivf_params(nlist, n))
     ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
     ix.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
     ix.build()
