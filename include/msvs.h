@@ -93,6 +93,23 @@ MSVS_API int msvs_normalize_f32(float * x, size_t n, size_t d);
 MSVS_API int msvs_knn_bin(const uint8_t * x, const uint8_t * y, size_t nbytes, size_t k, size_t nx, size_t ny,
                           int metric, const uint64_t * alive_bits, int64_t * ids, float * dis);
 
+/* Seam A1 for BinaryVector -- Search::VectorIndex<IS, OS, Bitmap, DataType::BinaryVector> (VICommon.h:142-143; the host creates
+ * it at VIWithDataPart.cpp:431-446 and searches it at :928-935; index types BinaryFLAT / BinaryMSTG, goldens 00038): an
+ * exhaustive Hamming / Jaccard scan (msvs_knn_bin's arithmetic) over rows kept RESIDENT on the device.  rows: n * nbytes
+ * (a FixedString(N) column, 8 bits per byte); ids: the rows' labels (part row offsets; NULL = staging order); alive_bits:
+ * nullable LSB-first bitmap over LABELS (nbits of them).  Files "data_bin" / "id_list" through the caller's stream openers like
+ * the float index.  Results ascending by (distance, label), unfilled slots id -1 / FLT_MAX. */
+typedef struct msvs_bin_index msvs_bin_index_t;
+MSVS_API int msvs_bin_index_create(size_t nbytes, int metric, msvs_bin_index_t ** out);
+MSVS_API void msvs_bin_index_free(msvs_bin_index_t * index);
+MSVS_API int msvs_bin_index_add(msvs_bin_index_t * index, const uint8_t * rows, const int64_t * ids, size_t n);
+MSVS_API size_t msvs_bin_index_num_data(const msvs_bin_index_t * index);
+MSVS_API int msvs_bin_index_search(const msvs_bin_index_t * index, const uint8_t * x, size_t nx, size_t k, const uint64_t * alive_bits,
+                                   size_t nbits, int64_t * ids, float * dis);
+struct msvs_io;
+MSVS_API int msvs_bin_index_serialize_io(const msvs_bin_index_t * index, const struct msvs_io * io);
+MSVS_API int msvs_bin_index_load_io(const struct msvs_io * io, msvs_bin_index_t ** out);
+
 /* Resident blocks for the brute-force path: the GPU analogue of VICacheManager / VIWithMeta
  * (src/VectorIndex/Cache/VICacheObject.h:40-162) for the dense block a mark of a part turns into
  * (MergeTreeVSManager.cpp:1380-1392).  msvs_knn_f32 moves that block over PCIe on every query; here it is uploaded

@@ -32,7 +32,8 @@ SYMBOLS = [
     "msvs_profile_enable", "msvs_profile_get", "msvs_profile_reset", "msvs_merge_topk_device_strided",
     "msvs_knn_f32_filtered", "msvs_prefilter_stats", "msvs_coarse_stats", "msvs_combine_stats", "msvs_set_option", "msvs_index_serialize_io",
     "msvs_index_load_io", "msvs_index_version", "msvs_index_resource_usage", "msvs_knn_bin",
-    "msvs_cache_create", "msvs_cache_free", "msvs_block_upload", "msvs_block_lookup", "msvs_block_release", "msvs_block_info",
+    "msvs_cache_create", "msvs_cache_free", "msvs_block_upload", "msvs_block_lookup", "msvs_block_release", "msvs_block_info", "msvs_bin_index_create", "msvs_bin_index_free",
+    "msvs_bin_index_add", "msvs_bin_index_num_data", "msvs_bin_index_search", "msvs_bin_index_serialize_io", "msvs_bin_index_load_io",
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
     "msvs_index_set_merged_maps", "msvs_comm_unique_id", "msvs_comm_init", "msvs_comm_init_custom",
     "msvs_comm_free", "msvs_comm_all_reduce_u64", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device",
@@ -181,6 +182,46 @@ def knn_bin(x, y, k, metric, alive=None):
                               C.c_size_t(y.shape[0]), int(metric), _p(bits, C.c_uint64), _p(ids, C.c_int64),
                               _p(dis, C.c_float)))
     return ids, dis
+
+
+class BinIndex:
+    """msvs_bin_index_t: BinaryFLAT over rows resident on the device (labels = ids given at add, filter indexed by label)."""
+
+    def __init__(self, nbytes, metric):
+        self._h = C.c_void_p()
+        self.nbytes = int(nbytes)
+        _check(lib().msvs_bin_index_create(C.c_size_t(nbytes), int(metric), C.byref(self._h)))
+
+    def add(self, rows, ids=None):
+        rows = np.ascontiguousarray(rows, np.uint8).reshape(-1, self.nbytes)
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, np.int64)
+            idp = _p(ids, C.c_int64)
+        _check(lib().msvs_bin_index_add(self._h, _p(rows, C.c_uint8), idp, C.c_size_t(rows.shape[0])))
+
+    @property
+    def num_data(self):
+        lib().msvs_bin_index_num_data.restype = C.c_size_t
+        return lib().msvs_bin_index_num_data(self._h)
+
+    def search(self, x, k, alive=None):
+        x = np.ascontiguousarray(x, np.uint8).reshape(-1, self.nbytes)
+        ids = np.empty((x.shape[0], k), np.int64)
+        dis = np.empty((x.shape[0], k), np.float32)
+        bits = None if alive is None else pack_bits(alive)
+        _check(lib().msvs_bin_index_search(self._h, _p(x, C.c_uint8), C.c_size_t(x.shape[0]), C.c_size_t(k), _p(bits, C.c_uint64),
+                                           C.c_size_t(0 if alive is None else len(alive)), _p(ids, C.c_int64), _p(dis, C.c_float)))
+        return ids, dis
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.msvs_bin_index_free.argtypes = [C.c_void_p]
+            _lib.msvs_bin_index_free.restype = None
+            _lib.msvs_bin_index_free(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def normalize(x):

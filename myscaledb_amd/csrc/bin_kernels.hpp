@@ -26,7 +26,8 @@ struct BinParams
 {
     const uint4 * Y;        // rows, ld16 uint4 per row (zero padded)
     const uint4 * Q;        // queries, same stride
-    const uint64_t * alive; // nullable filter bitmap over rows
+    const uint64_t * alive; // nullable filter bitmap over the rows' labels
+    const uint32_t * labels; // nullable: label of row r (else r); results carry labels, ties break by label
     uint32_t nbits;
     uint32_t ld16;
     uint32_t n_rows, rows_per_block, n_blocks, k, nq;
@@ -76,10 +77,11 @@ __global__ __launch_bounds__(BLOCK) void bin_scan_kernel(const BinParams a)
                 c1 += (uint32_t)__shfl_xor((int)c1, o);
         }
         bool ok = rv && g == 0;
+        const uint32_t id = ok && a.labels ? a.labels[r] : r;
         if (ok && a.alive)
-            ok = r < a.nbits && ((a.alive[r >> 6] >> (r & 63)) & 1);
+            ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
         const float v = METRIC == B_HAMMING ? (float)c0 : (c1 == 0 ? 1.0f : __fdiv_rn((float)(c1 - c0), (float)c1));
-        top.offer(ok ? make_key<M_L2>(v, r) : KEY_NONE, k, lane);
+        top.offer(ok ? make_key<M_L2>(v, id) : KEY_NONE, k, lane);
     }
     top.store(lds_merge + wave * k, k, lane);
     __syncthreads();

@@ -13,6 +13,7 @@
 #include "ivf_build_kernels.hpp"
 #include "h16_scan_kernels.hpp"
 #include "h16r_scan_kernels.hpp"
+#include "io_stream.hpp"
 #include "latency_kernels.hpp"
 #include "filter_kernels.hpp"
 
@@ -3565,59 +3566,6 @@ struct DataHeader
     uint64_t dim, nlist, n;
 };
 constexpr uint32_t DATA_VERSION = 2;
-constexpr size_t IO_CHUNK = (size_t)64 << 20;
-
-struct IoStream
-{
-    const msvs_io_t * io;
-    void * h;
-    const char * name;
-    IoStream(const msvs_io_t * io_, const char * name_, int write) : io(io_), h(nullptr), name(name_)
-    {
-        if (!io || !io->open || !io->close || (write ? !io->write : !io->read))
-            msvs::fail(MSVS_ERR_INVALID_ARGUMENT, "msvs_io_t lacks a callback");
-        h = io->open(io->ctx, name, write);
-        if (!h)
-            msvs::fail(MSVS_ERR_IO, "cannot open index file `%s` for %s", name, write ? "writing" : "reading");
-    }
-    ~IoStream()
-    {
-        if (h)
-            (void)io->close(io->ctx, h);
-    }
-    void write(const void * p, size_t n)
-    {
-        const char * c = static_cast<const char *>(p);
-        while (n)
-        {
-            const size_t m = std::min(n, IO_CHUNK);
-            if (io->write(io->ctx, h, c, m) != (int64_t)m)
-                msvs::fail(MSVS_ERR_IO, "short write to index file `%s`", name);
-            c += m;
-            n -= m;
-        }
-    }
-    void read(void * p, size_t n)
-    {
-        char * c = static_cast<char *>(p);
-        while (n)
-        {
-            const int64_t got = io->read(io->ctx, h, c, std::min(n, IO_CHUNK));
-            if (got <= 0)
-                msvs::fail(MSVS_ERR_IO, "index file `%s` is truncated", name);
-            c += got;
-            n -= (size_t)got;
-        }
-    }
-    void finish()
-    {
-        void * t = h;
-        h = nullptr;
-        if (io->close(io->ctx, t) != 0)
-            msvs::fail(MSVS_ERR_IO, "closing index file `%s` failed", name);
-    }
-};
-
 /// stdio implementation behind the path convenience calls: file NAME of the set is <prefix>-NAME.vidx3
 struct StdioCtx
 {

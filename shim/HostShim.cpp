@@ -6,6 +6,7 @@
 // the host already converts to VIException (VICommon.h:75-104, VIWithDataPart.cpp:948-956).
 //
 //   seam A1  Search::VectorIndex<IS, OS, Bitmap, FloatVector>   -> MsvsVectorIndex            (FLAT, IVFFLAT, MSTG*)
+//            Search::VectorIndex<IS, OS, Bitmap, BinaryVector>  -> MsvsBinaryIndex            (BinaryFLAT, BinaryMSTG*)
 //   seam A2  faiss::knn_L2sqr / knn_inner_product / hammings_knn_mc / jaccard_knn -> msvs_knn_f32 / msvs_knn_bin
 //   (* MSTG is proprietary and absent: its partition scan is served by IVFFLAT with the same metric)
 #include <SearchIndex/VectorIndex.h>
@@ -238,6 +239,117 @@ private:
     msvs_index_t * ix = nullptr;
 };
 
+/// Search::VectorIndex<IS, OS, Bitmap, BinaryVector> (VICommon.h:142-143 BinaryVI; created at VIWithDataPart.cpp:431-446,
+/// searched at :928-935): BinaryFLAT and the scan stage of BinaryMSTG as an exhaustive Hamming / Jaccard scan over rows kept
+/// resident on the device (msvs_bin_index_*).  Element = bool with one BYTE carrying 8 bits (VIPartReader.h:143-150): a dataset
+/// of `dimension` bits is dimension / 8 bytes per row.
+template <typename IS, typename OS, typename Bitmap>
+class MsvsBinaryIndex final : public Search::VectorIndex<IS, OS, Bitmap, Search::DataType::BinaryVector>
+{
+public:
+    using Reader = Search::IndexSourceDataReader<bool>;
+
+    MsvsBinaryIndex(Search::IndexType type_, Search::Metric metric_, size_t dim_bits, size_t total_vec_)
+        : type(type_), metric(metric_), dim(dim_bits), total_vec(total_vec_)
+    {
+        if (type != Search::IndexType::BinaryFLAT && type != Search::IndexType::BinaryMSTG)
+            throw Search::SearchIndexException(MSVS_ERR_NOT_IMPLEMENTED,
+                                               "index type " + Search::enumToString(type) + " is not a binary index served by libmsvs");
+        if (dim == 0 || dim % 8 != 0)
+            throw Search::SearchIndexException(MSVS_ERR_INVALID_ARGUMENT, "BinaryVector dimension must be a multiple of 8");
+        check(msvs_bin_index_create(dim / 8, msvs_metric_of(metric), &ix));
+    }
+    ~MsvsBinaryIndex() override { msvs_bin_index_free(ix); }
+
+    void setTrainDataChunkSize(size_t) override {}
+    void setAddDataChunkSize(size_t bytes) override { add_chunk = bytes; }
+
+    void build(Reader * reader, int /*num_threads*/, std::function<bool()> check_cancelled) override
+    {
+        const size_t row_bytes = dim / 8;
+        const size_t rows_per = std::max<size_t>(1, (add_chunk ? add_chunk : ((size_t)64 << 20)) / row_bytes);
+        while (!reader->eof())
+        {
+            if (check_cancelled && check_cancelled())
+                throw Search::SearchIndexException(MSVS_ERR_DEVICE, "Cancelled building vector index");
+            auto chunk = reader->readData(rows_per);
+            if (!chunk)
+                break;
+            check(msvs_bin_index_add(ix, reinterpret_cast<const uint8_t *>(chunk->getData()), chunk->getDataID(), chunk->numData()));
+        }
+        built = true;
+    }
+
+    std::shared_ptr<Search::SearchResult> search(std::shared_ptr<Search::DataSet<bool>> queries, int32_t k, Search::Parameters &,
+                                                 bool /*first_stage_only*/, Bitmap * filter) override
+    {
+        auto res = Search::SearchResult::createTopKHolder(queries->numData(), k);
+        std::vector<uint64_t> words;
+        size_t nbits = 0;
+        if (filter)
+        {
+            nbits = filter->get_size();
+            words.assign((nbits + 63) / 64 + 1, 0);
+            memcpy(words.data(), filter->get_bitmap(), filter->byte_size());
+        }
+        check(msvs_bin_index_search(ix, reinterpret_cast<const uint8_t *>(queries->getData()), (size_t)queries->numData(), (size_t)k,
+                                    filter ? words.data() : nullptr, nbits, res->getResultIndices(), res->getResultDistances()));
+        return res;
+    }
+    std::shared_ptr<Search::SearchResult> computeTopDistanceSubset(std::shared_ptr<Search::DataSet<bool>>,
+                                                                   std::shared_ptr<Search::SearchResult> first_stage, int32_t) override
+    {
+        return first_stage;
+    }
+    bool supportTwoStageSearch() const override { return false; }
+
+    void serialize(Search::IndexDataFileWriter<OS> * writer) override
+    {
+        StreamIO<IS, OS> s;
+        s.writer = writer;
+        const msvs_io_t io = s.io();
+        check(msvs_bin_index_serialize_io(ix, &io));
+        for (auto & o : s.outs)
+            o->close();
+    }
+    void saveDataID(Search::IndexDataFileWriter<OS> *) override {}
+    void load(Search::IndexDataFileReader<IS> * reader, std::function<bool()> check_expired) override
+    {
+        if (check_expired && check_expired())
+            throw Search::SearchIndexException(MSVS_ERR_IO, "index files expired before load");
+        StreamIO<IS, OS> s;
+        s.reader = reader;
+        const msvs_io_t io = s.io();
+        msvs_bin_index_t * loaded = nullptr;
+        check(msvs_bin_index_load_io(&io, &loaded));
+        msvs_bin_index_free(ix);
+        ix = loaded;
+        built = true;
+    }
+    void loadDataID(Search::IndexDataFileReader<IS> *) override {}
+
+    bool ready() const override { return built; }
+    size_t numData() const override { return msvs_bin_index_num_data(ix); }
+    Search::IndexResourceUsage getResourceUsage() const override
+    {
+        Search::IndexResourceUsage u;
+        const size_t n = built ? numData() : total_vec, row = dim / 8;
+        u.memory_usage_bytes = n * ((row + 15) / 16 * 16 + 4);
+        u.disk_usage_bytes = built ? 48 + n * row + 8 + n * 8 : 0;
+        u.build_memory_usage_bytes = 2 * n * row + n * 8;
+        return u;
+    }
+    Search::IndexVersion getVersion() const override { return Search::IndexVersion{msvs_index_version()}; }
+
+private:
+    Search::IndexType type;
+    Search::Metric metric;
+    size_t dim, total_vec;
+    size_t add_chunk = 0;
+    bool built = false;
+    msvs_bin_index_t * ix = nullptr;
+};
+
 }
 
 namespace Search
@@ -293,8 +405,10 @@ std::shared_ptr<VectorIndex<IS, OS, Bitmap, T>> createVectorIndex(const std::str
                                                                   size_t /*max_threads*/, const std::string & /*cache_prefix*/,
                                                                   std::function<bool()> /*check_cancelled*/)
 {
-    static_assert(T == DataType::FloatVector, "binary indexes: brute force only (msvs_knn_bin)");
-    return std::make_shared<MsvsVectorIndex<IS, OS, Bitmap>>(type, metric, dimension, total_vec, params);
+    if constexpr (T == DataType::FloatVector)
+        return std::make_shared<MsvsVectorIndex<IS, OS, Bitmap>>(type, metric, dimension, total_vec, params);
+    else
+        return std::make_shared<MsvsBinaryIndex<IS, OS, Bitmap>>(type, metric, dimension, total_vec);
 }
 
 // the instantiation the host uses (VICommon.h:142-143)
@@ -304,6 +418,16 @@ createVectorIndex<AbstractIStream, AbstractOStream, DenseBitmap, DataType::Float
                                                                                        size_t, const std::string &,
                                                                                        std::function<bool()>);
 
+}
+
+namespace Search
+{
+// ... and the second one (VICommon.h:142-143 BinaryVI; VIWithDataPart.cpp:431-446)
+template std::shared_ptr<VectorIndex<AbstractIStream, AbstractOStream, DenseBitmap, DataType::BinaryVector>>
+createVectorIndex<AbstractIStream, AbstractOStream, DenseBitmap, DataType::BinaryVector>(const std::string &, IndexType, Metric,
+                                                                                        size_t, size_t, const Parameters &,
+                                                                                        size_t, const std::string &,
+                                                                                        std::function<bool()>);
 }
 
 // ------------------------------------------------------------------------------------------------ seam A2

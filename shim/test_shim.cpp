@@ -2,7 +2,7 @@
 // (call-site pattern of VIWithDataPart.cpp:415-446 create, VIWithDataPart.h:332-337 build, VIWithDataPart.cpp:461-479
 // serialize, :688-700 load, :922-926 search; BruteForceSearch.h:80-104 brute force), on inputs written by
 // tests/test_shim.py, and writes the results back for the comparison with the oracle.
-//   usage: test_shim <dir>     reads  <dir>/{meta.txt, x.bin, q.bin, alive.bin, bx.bin, bq.bin}
+//   usage: test_shim <dir>     reads  <dir>/{meta.txt, x.bin, q.bin, alive.bin, bx.bin, bq.bin, balive.bin}
 //                              writes <dir>/{out_*.bin, files.txt}
 #include <SearchIndex/VectorIndex.h>
 #include <faiss/utils/distances.h>
@@ -259,6 +259,87 @@ int main(int argc, char ** argv)
             jaccard_knn(bq.data(), bx.data(), nb_q, nb_rows, k, nb_bytes, dis.data(), ids.data(), nullptr);
             dump(dir + "/bf_jac_ids.bin", ids.data(), ids.size());
             dump(dir + "/bf_jac_dis.bin", dis.data(), dis.size());
+        }
+        // ---- seam A1 for BinaryVector (VIWithDataPart.cpp:431-446 create, :928-935 search): BinaryFLAT over the same binary rows,
+        // built from FixedString chunks with ids, serialised, loaded, searched with and without a filter bitmap
+        {
+            using BinaryVI = Search::VectorIndex<IS, OS, Bitmap, Search::DataType::BinaryVector>;
+            auto bx = slurp<uint8_t>(dir + "/bx.bin");
+            auto bq = slurp<uint8_t>(dir + "/bq.bin");
+            auto balive = slurp<uint8_t>(dir + "/balive.bin");
+            class BinReader : public Search::IndexSourceDataReader<bool>
+            {
+            public:
+                BinReader(const std::vector<uint8_t> & x_, size_t n_, size_t nbytes_) : x(x_), n(n_), nbytes(nbytes_) {}
+                size_t numDataRead() const override { return pos; }
+                size_t dataDimension() const override { return nbytes * 8; }
+                bool eof() override { return pos == n; }
+                void seekg(std::streamsize, std::ios::seekdir) override { throw std::runtime_error("seekg() is not implemented"); }
+                std::shared_ptr<DataChunk> sampleData(size_t) override { return nullptr; }
+
+            protected:
+                std::shared_ptr<DataChunk> readDataImpl(size_t m) override
+                {
+                    m = std::min(m, n - pos);
+                    if (m == 0)
+                        return nullptr;
+                    bool * data = new bool[m * nbytes]; // one byte = 8 bits (VIPartReader.h:262-266)
+                    Search::idx_t * ids = new Search::idx_t[m];
+                    memcpy(data, x.data() + pos * nbytes, m * nbytes);
+                    for (size_t i = 0; i < m; i++)
+                        ids[i] = (Search::idx_t)(pos + i);
+                    auto chunk = std::make_shared<DataChunk>(data, m, nbytes * 8, [=]() { delete[] data; });
+                    chunk->setDataID(ids, [=]() { delete[] ids; });
+                    pos += m;
+                    return chunk;
+                }
+
+            private:
+                const std::vector<uint8_t> & x;
+                size_t n, nbytes, pos = 0;
+            };
+            auto cancel2 = []() { return false; };
+            for (const char * mname : {"Hamming", "Jaccard"})
+            {
+                const auto bmetric = Search::getMetricType(mname, Search::DataType::BinaryVector);
+                const auto btype = Search::getVectorIndexType("BinaryFLAT", Search::DataType::BinaryVector);
+                Search::Parameters bdes;
+                std::shared_ptr<BinaryVI> bindex = Search::createVectorIndex<IS, OS, Bitmap, Search::DataType::BinaryVector>(
+                    "b1", btype, bmetric, nb_bytes * 8, nb_rows, bdes, 8, "cache/", cancel2);
+                bindex->setAddDataChunkSize(nb_bytes * 700); // several chunks
+                BinReader breader(bx, nb_rows, nb_bytes);
+                bindex->build(&breader, 4, cancel2);
+                if (!bindex->ready() || bindex->numData() != nb_rows)
+                    throw std::runtime_error("binary build did not produce a ready index");
+                g_disk.clear();
+                auto bw = Search::IndexDataFileWriter<OS>(
+                    "part/b1-", [&](const std::string & name, std::ios::openmode) { return std::make_shared<MemWriter>(name); });
+                bindex->serialize(&bw);
+                bindex->saveDataID(&bw);
+                auto bloaded = Search::createVectorIndex<IS, OS, Bitmap, Search::DataType::BinaryVector>("b1", btype, bmetric, nb_bytes * 8,
+                                                                                                        nb_rows, bdes, 8, "cache/", cancel2);
+                auto br = Search::IndexDataFileReader<IS>(
+                    "part/b1-", [&](const std::string & name, std::ios::openmode) { return std::make_shared<MemReader>(name); });
+                bloaded->load(&br, []() { return false; });
+                bloaded->loadDataID(&br);
+                if (bloaded->numData() != nb_rows)
+                    throw std::runtime_error("binary load: numData mismatch");
+                bindex.reset();
+                auto bqueries = std::make_shared<Search::DataSet<bool>>(reinterpret_cast<bool *>(bq.data()), (int64_t)nb_q,
+                                                                        (int64_t)(nb_bytes * 8));
+                Search::Parameters bsp;
+                auto b1 = bloaded->search(bqueries, (int32_t)k, bsp, false, nullptr);
+                const std::string tag = mname[0] == 'H' ? "ham" : "jac";
+                dump(dir + "/bi_" + tag + "_ids.bin", b1->getResultIndices(), nb_q * k);
+                dump(dir + "/bi_" + tag + "_dis.bin", b1->getResultDistances(), nb_q * k);
+                auto bfilter = std::make_shared<Bitmap>(nb_rows);
+                for (size_t i = 0; i < nb_rows; i++)
+                    if (balive[i])
+                        bfilter->set(i);
+                auto b2 = bloaded->search(bqueries, (int32_t)k, bsp, false, bfilter.get());
+                dump(dir + "/bi_" + tag + "_ids_f.bin", b2->getResultIndices(), nb_q * k);
+                dump(dir + "/bi_" + tag + "_dis_f.bin", b2->getResultDistances(), nb_q * k);
+            }
         }
     }
     catch (const std::exception & e)

@@ -1668,6 +1668,30 @@ def test_binary_vector_goldens_on_gpu(case):
         alive = np.arange(c["rows"]) >= c["lwd_deleted_below"]
         ids, dis = capi.knn_bin(np.array([c["query"]], np.uint8), y, 10, metric, alive=alive)
         assert ids[0].tolist() == c["lwd_ids"] and dis[0].tolist() == f32_of(c["lwd_dists"]).tolist()
+    # the same through the BinaryFLAT index object (rows resident, added in two chunks with their row offsets as labels; the
+    # goldens of 00038 are produced with index types BinaryFLAT / BinaryMSTG)
+    bix = capi.BinIndex(c["nbytes"], metric)
+    half = c["rows"] // 2
+    bix.add(y[:half], n[:half])
+    bix.add(y[half:], n[half:])
+    assert bix.num_data == c["rows"]
+    ids, dis = bix.search(np.array([c["query"]], np.uint8), c["k"])
+    assert ids[0].tolist() == c["ids"] and dis[0].tolist() == f32_of(c["dists"]).tolist()
+    ids, dis = bix.search(np.array(c["batch_queries"], np.uint8), c["batch_k"])
+    for q in range(3):
+        assert ids[q].tolist() == c["batch_ids"][q] and dis[q].tolist() == f32_of(c["batch_dists"][q]).tolist()
+    alive = eval_filter(c["filter"], np.arange(c["rows"]))
+    ids, dis = bix.search(np.array([c["query"]], np.uint8), c["k"], alive=alive)
+    assert ids[0, :m].tolist() == c["filter_ids"] and ids[0, m] == -1
+    # labels that are not the storage order (a decoupled part's row ids): the filter and the results speak labels
+    rng = np.random.default_rng(38)
+    perm = rng.permutation(c["rows"])
+    bix2 = capi.BinIndex(c["nbytes"], metric)
+    bix2.add(y[perm], n[perm])
+    ids, dis = bix2.search(np.array([c["query"]], np.uint8), c["k"], alive=alive)
+    assert ids[0, :m].tolist() == c["filter_ids"] and dis[0, :m].tolist() == f32_of(c["filter_dists"]).tolist()
+    bix.close()
+    bix2.close()
 
 
 @pytest.mark.parametrize("nbytes,ny,nx,k", [(4, 1024, 3, 10), (16, 5000, 2, 64), (32, 100000, 5, 10), (100, 20000, 1, 200),

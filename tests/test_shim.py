@@ -21,6 +21,9 @@ def test_shim_is_built_against_the_stub_headers():
     for sym in ("faiss::knn_L2sqr", "faiss::knn_inner_product", "faiss::hammings_knn_mc", "jaccard_knn",
                 "Search::createVectorIndex", "Search::getMetricType"):
         assert sym in out, sym
+    # both instantiations the host links against (VICommon.h:142-143): FloatVector = (Search::DataType)0, BinaryVector = 1
+    made = [ln for ln in out.split("\n") if "Search::createVectorIndex<" in ln]
+    assert any("(Search::DataType)0" in ln for ln in made) and any("(Search::DataType)1" in ln for ln in made), made
 
 
 @pytest.mark.gpu
@@ -37,7 +40,8 @@ def test_shim_end_to_end_matches_oracle(metric, typ):
     with tempfile.TemporaryDirectory() as td:
         with open(os.path.join(td, "meta.txt"), "w") as f:
             f.write("%d %d %d %d %d %s %s %d %d %d\n" % (n, d, nq, k, nlist, metric, typ, nb_rows, nb_bytes, nb_q))
-        for name, a in (("x", x), ("q", q), ("alive", alive.astype(np.uint8)), ("bx", bx), ("bq", bq)):
+        balive = rng.random(nb_rows) < 0.4
+        for name, a in (("x", x), ("q", q), ("alive", alive.astype(np.uint8)), ("bx", bx), ("bq", bq), ("balive", balive.astype(np.uint8))):
             a.tofile(os.path.join(td, name + ".bin"))
         r = subprocess.run([EXE, td], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -61,6 +65,12 @@ def test_shim_end_to_end_matches_oracle(metric, typ):
             oi, od = o.knn_bin(bq, bx, k, m)
             assert (rd("bf_%s_ids" % tag, np.int64).reshape(nb_q, k) == oi).all()
             assert (rd("bf_%s_dis" % tag, np.float32).reshape(nb_q, k) == od).all()
+            # the BinaryFLAT index object (createVectorIndex<..., BinaryVector>: build from chunks, serialise, load, search)
+            assert (rd("bi_%s_ids" % tag, np.int64).reshape(nb_q, k) == oi).all()
+            assert (rd("bi_%s_dis" % tag, np.float32).reshape(nb_q, k) == od).all()
+            fi, fd = o.knn_bin(bq, bx, k, m, alive=balive)
+            assert (rd("bi_%s_ids_f" % tag, np.int64).reshape(nb_q, k) == fi).all()
+            assert (rd("bi_%s_dis_f" % tag, np.float32).reshape(nb_q, k) == fd).all()
 
 
 def test_text_shim_is_built_against_the_tantivy_stub():
