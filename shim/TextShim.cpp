@@ -5,6 +5,12 @@
 // (the export file written next to the tantivy files); readers are cached by path like the Rust side caches its
 // IndexReaderBridge (ffi_load_index_reader / ffi_free_index_reader).  Errors travel by value in .error, never as
 // exceptions -- the host turns them into TANTIVY_SEARCH_INTERNAL_ERROR (TantivyIndexStore.cpp:919-923).
+//
+// The writer side is a TEE (TantivyIndexStore.cpp:713 create, :742 index, :824 commit, :792 free): the same four calls
+// the part writer already makes build the postings export next to whatever else the directory holds, so no host code
+// changes to get <index_path>/postings.mspost written.  Built with -DMSVS_TANTIVY_FORWARD_NS=<ns> every writer call is
+// ALSO forwarded to <ns>::ffi_* (the Rust crate's bridge regenerated under another namespace, for a build that keeps
+// tantivy's own files for the boolean FTS functions); without it this library stands alone.
 #include <tantivy_search/tantivy_search.h>
 
 #include <map>
@@ -22,6 +28,21 @@ struct Reader
 };
 std::mutex g_mu;
 std::map<std::string, std::shared_ptr<Reader>> g_readers;
+
+struct Writer
+{
+    msvs_text_index_t * ix = nullptr;
+    std::mutex mu; // the part writer is single-threaded per index; this only keeps a stray concurrent commit honest
+    ~Writer() { msvs_text_index_free(ix); }
+};
+std::map<std::string, std::shared_ptr<Writer>> g_writers;
+
+std::shared_ptr<Writer> writer_of(const std::string & path)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_writers.find(path);
+    return it == g_writers.end() ? nullptr : it->second;
+}
 
 std::shared_ptr<Reader> reader_of(const std::string & path, std::string & err)
 {
@@ -49,8 +70,112 @@ R failed(const std::string & m)
 }
 }
 
+#ifdef MSVS_TANTIVY_FORWARD_NS
+namespace MSVS_TANTIVY_FORWARD_NS
+{
+TANTIVY::FFIBoolResult ffi_create_index_with_parameter(const std::string &, const std::vector<std::string> &, const std::string &);
+TANTIVY::FFIBoolResult ffi_index_multi_column_docs(const std::string &, uint64_t, const std::vector<std::string> &,
+                                                   const std::vector<std::string> &);
+TANTIVY::FFIBoolResult ffi_index_writer_commit(const std::string &);
+TANTIVY::FFIBoolResult ffi_free_index_writer(const std::string &);
+}
+#define MSVS_TEE(call) \
+    do \
+    { \
+        TANTIVY::FFIBoolResult fw = MSVS_TANTIVY_FORWARD_NS::call; \
+        if (fw.error.is_error || !fw.result) \
+            return fw; \
+    } while (0)
+#else
+#define MSVS_TEE(call) \
+    do \
+    { \
+    } while (0)
+#endif
+
 namespace TANTIVY
 {
+// ---- the writer side: TantivyIndexStore::getTantivyIndexWriter / indexMultiColumnDoc / commitTantivyIndex / freeTantivyIndexWriter
+FFIBoolResult ffi_create_index_with_parameter(const std::string & index_path, const std::vector<std::string> & column_names,
+                                              const std::string & index_json_parameter)
+{
+    MSVS_TEE(ffi_create_index_with_parameter(index_path, column_names, index_json_parameter));
+    // index_json_parameter ({"<column>": {"tokenizer": {"type": "<name>", ...}}}, MergeTreeIndexTantivy.cpp:795) picks a
+    // tokenizer per column; the export implements tantivy's default chain only, and a column on another tokenizer must
+    // fail here rather than score differently later
+    for (size_t at = index_json_parameter.find("\"type\""); at != std::string::npos; at = index_json_parameter.find("\"type\"", at + 6))
+    {
+        const size_t q0 = index_json_parameter.find('"', index_json_parameter.find(':', at + 6));
+        const size_t q1 = q0 == std::string::npos ? q0 : index_json_parameter.find('"', q0 + 1);
+        if (q1 == std::string::npos || index_json_parameter.substr(q0 + 1, q1 - q0 - 1) != "default")
+            return failed<FFIBoolResult>("msvs text export: only tantivy's default tokenizer chain is implemented, got " + index_json_parameter);
+    }
+    std::vector<const char *> cols;
+    for (const auto & c : column_names)
+        cols.push_back(c.c_str());
+    auto w = std::make_shared<Writer>();
+    if (msvs_text_index_create(cols.empty() ? nullptr : cols.data(), cols.size(), &w->ix) != 0)
+        return failed<FFIBoolResult>(msvs_text_last_error());
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_writers[index_path] = w; // like the Rust side: creating again over a live writer replaces it
+    g_readers.erase(index_path); // a reader of the previous contents would be stale
+    FFIBoolResult r;
+    r.result = true;
+    return r;
+}
+
+FFIBoolResult ffi_index_multi_column_docs(const std::string & index_path, uint64_t row_id, const std::vector<std::string> & column_names,
+                                          const std::vector<std::string> & docs)
+{
+    MSVS_TEE(ffi_index_multi_column_docs(index_path, row_id, column_names, docs));
+    auto w = writer_of(index_path);
+    if (!w)
+        return failed<FFIBoolResult>("msvs text export: no index writer for " + index_path);
+    if (column_names.size() != docs.size())
+        return failed<FFIBoolResult>("msvs text export: column_names and docs differ in length");
+    std::vector<const char *> cols, texts;
+    for (size_t i = 0; i < docs.size(); i++)
+    {
+        cols.push_back(column_names[i].c_str());
+        texts.push_back(docs[i].c_str());
+    }
+    std::lock_guard<std::mutex> lk(w->mu);
+    if (msvs_text_index_add_doc(w->ix, row_id, cols.data(), texts.data(), docs.size()) != 0)
+        return failed<FFIBoolResult>(msvs_text_last_error());
+    FFIBoolResult r;
+    r.result = true;
+    return r;
+}
+
+FFIBoolResult ffi_index_writer_commit(const std::string & index_path)
+{
+    MSVS_TEE(ffi_index_writer_commit(index_path));
+    auto w = writer_of(index_path);
+    if (!w)
+        return failed<FFIBoolResult>("msvs text export: no index writer for " + index_path);
+    std::lock_guard<std::mutex> lk(w->mu);
+    if (msvs_text_index_commit(w->ix) != 0 || msvs_text_index_save(w->ix, (index_path + "/postings.mspost").c_str()) != 0)
+        return failed<FFIBoolResult>(msvs_text_last_error());
+    {
+        std::lock_guard<std::mutex> lk2(g_mu);
+        g_readers.erase(index_path); // the next ffi_load_index_reader sees what was just committed
+    }
+    FFIBoolResult r;
+    r.result = true;
+    return r;
+}
+
+FFIBoolResult ffi_free_index_writer(const std::string & index_path)
+{
+    MSVS_TEE(ffi_free_index_writer(index_path));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_writers.erase(index_path); // freeing a writer that is not there is not an error (freeTantivyIndexWriter is idempotent)
+    FFIBoolResult r;
+    r.result = true;
+    return r;
+}
+
+// ---- the reader side
 FFIBoolResult ffi_load_index_reader(const std::string & index_path)
 {
     std::string err;

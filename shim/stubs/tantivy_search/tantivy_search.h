@@ -1,6 +1,7 @@
 // Stub of the C++ header the tantivy_search crate generates (contrib/tantivy-search is an un-vendored submodule):
 // only what the BM25 path of the host uses, reconstructed from the call sites
 //   src/Storages/MergeTree/TantivyIndexStore.cpp:853-998   (ffi_* calls and the {result, error{is_error, message}} wrappers)
+//   src/Storages/MergeTree/TantivyIndexStore.cpp:713,742,792,824   (the writer: create / index docs / free / commit)
 //   src/VectorIndex/Storages/MergeTreeTextSearchManager.cpp:183-267   (RowIdWithScore::row_id / score)
 //   src/VectorIndex/Common/BM25InfoInDataParts.cpp:40-93    (DocWithFreq{term_str, field_id, doc_freq}, FieldTokenNums)
 //   src/VectorIndex/Utils/ReadWithHybridSearch.cpp:204-206,279-291   (Statistics{docs_freq, total_num_tokens, total_num_docs})
@@ -69,6 +70,12 @@ struct FFIFieldTokenNumsResult
     FFIError error;
 };
 
+FFIBoolResult ffi_create_index_with_parameter(const std::string & index_path, const std::vector<std::string> & column_names,
+                                              const std::string & index_json_parameter);
+FFIBoolResult ffi_index_multi_column_docs(const std::string & index_path, uint64_t row_id, const std::vector<std::string> & column_names,
+                                          const std::vector<std::string> & docs);
+FFIBoolResult ffi_index_writer_commit(const std::string & index_path);
+FFIBoolResult ffi_free_index_writer(const std::string & index_path);
 FFIBoolResult ffi_load_index_reader(const std::string & index_path);
 FFIBoolResult ffi_free_index_reader(const std::string & index_path);
 FFIVecRowIdWithScoreResult ffi_bm25_search(const std::string & index_path, const std::string & sentence,

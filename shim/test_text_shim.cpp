@@ -31,28 +31,41 @@ int main(int argc, char ** argv)
     std::string query, op;
     std::getline(qf, query);
     std::getline(qf, op); // "or" / "and"
-    const char * col = "doc";
-    // the exporter side (stands where ffi_index_multi_column_docs / ffi_index_writer_commit stand)
+    const std::string col = "doc";
+    // the part writer's side, through the calls TantivyIndexStore makes (getTantivyIndexWriter :713, indexMultiColumnDoc
+    // :742, commitTantivyIndex :824, freeTantivyIndexWriter :792); the shim tees them into <dir>/postings.mspost
     for (auto & kv : parts)
     {
-        msvs_text_index_t * w = nullptr;
-        if (msvs_text_index_create(&col, 1, &w) != 0)
-            return 3;
-        for (size_t r = 0; r < kv.second.size(); r++)
-        {
-            const char * text = kv.second[r].c_str();
-            if (msvs_text_index_add_doc(w, r, &col, &text, 1) != 0)
-                return 4;
-        }
         const std::string pdir = dir + "/part" + std::to_string(kv.first);
         mkdir(pdir.c_str(), 0755);
-        if (msvs_text_index_commit(w) != 0 || msvs_text_index_save(w, (pdir + "/postings.mspost").c_str()) != 0)
+        auto made = TANTIVY::ffi_create_index_with_parameter(pdir, {col}, "{}");
+        if (made.error.is_error || !made.result)
         {
-            std::cerr << msvs_text_last_error() << "\n";
+            std::cerr << std::string(made.error.message) << "\n";
+            return 3;
+        }
+        for (size_t r = 0; r < kv.second.size(); r++)
+        {
+            auto st = TANTIVY::ffi_index_multi_column_docs(pdir, r, {col}, {kv.second[r]});
+            if (st.error.is_error || !st.result)
+                return 4;
+        }
+        auto done = TANTIVY::ffi_index_writer_commit(pdir);
+        if (done.error.is_error || !done.result)
+        {
+            std::cerr << std::string(done.error.message) << "\n";
             return 5;
         }
-        msvs_text_index_free(w);
+        if (!TANTIVY::ffi_free_index_writer(pdir).result)
+            return 5;
     }
+    // misuse is an error VALUE: indexing into a writer that was freed, a tokenizer the export does not implement
+    std::printf("freed_writer_is_error %d\n", TANTIVY::ffi_index_multi_column_docs(dir + "/part0", 0, {col}, {"x"}).error.is_error ? 1 : 0);
+    std::printf("other_tokenizer_is_error %d\n",
+                TANTIVY::ffi_create_index_with_parameter(dir + "/nope", {col}, "{\"doc\": {\"tokenizer\": {\"type\": \"ngram\"}}}").error.is_error ? 1 : 0);
+    std::printf("default_tokenizer_is_fine %d\n",
+                TANTIVY::ffi_create_index_with_parameter(dir + "/nope", {col}, "{\"doc\": {\"tokenizer\": {\"type\": \"default\"}}}").result ? 1 : 0);
+    TANTIVY::ffi_free_index_writer(dir + "/nope");
     // the host side: statistics over the parts, then one search per part
     TANTIVY::Statistics stats;
     std::map<std::pair<uint32_t, std::string>, uint64_t> df;

@@ -78,15 +78,22 @@ def test_text_shim_is_built_against_the_tantivy_stub():
     assert os.path.exists(lib) and os.path.exists(os.path.join(ROOT, "shim", "_build", "test_text_shim"))
     out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", lib], text=True)
     for sym in ("TANTIVY::ffi_bm25_search", "TANTIVY::ffi_get_doc_freq", "TANTIVY::ffi_get_total_num_docs",
-                "TANTIVY::ffi_get_total_num_tokens", "TANTIVY::ffi_load_index_reader"):
+                "TANTIVY::ffi_get_total_num_tokens", "TANTIVY::ffi_load_index_reader",
+                # the writer-side tee (TantivyIndexStore.cpp:713,742,792,824)
+                "TANTIVY::ffi_create_index_with_parameter", "TANTIVY::ffi_index_multi_column_docs",
+                "TANTIVY::ffi_index_writer_commit", "TANTIVY::ffi_free_index_writer"):
         assert sym in out, sym
+    # the forwarding build (writer calls also go to the crate's bridge under another namespace) compiles
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Istubs", "-DMSVS_TANTIVY_FORWARD_NS=TANTIVY_RS", "TextShim.cpp"],
+                          cwd=os.path.join(ROOT, "shim"))
 
 
 @pytest.mark.gpu
 def test_text_shim_replays_the_two_part_bm25_golden():
     """Seam B through the functions the host really calls (TANTIVY::ffi_*, shim/TextShim.cpp): the documents of
-    00041_mqvs_text_search_multiple_parts in two parts, statistics summed over the parts like BM25InfoInDataParts, one
-    ffi_bm25_search per part -> the golden hits; a filtered search; a missing index is an error VALUE."""
+    00041_mqvs_text_search_multiple_parts in two parts, each BUILT through ffi_create_index_with_parameter /
+    ffi_index_multi_column_docs / ffi_index_writer_commit / ffi_free_index_writer, statistics summed over the parts like
+    BM25InfoInDataParts, one ffi_bm25_search per part -> the golden hits; a filtered search; misuse is an error VALUE."""
     from golden_util import f32_of, load_goldens
 
     g = load_goldens()["00041_two_parts"]
@@ -110,3 +117,5 @@ def test_text_shim_replays_the_two_part_bm25_golden():
     even = [ln for ln in lines if ln[0] == "even"]
     assert all(int(ln[2]) % 2 == 0 for ln in even) and {(ln[1], ln[2]) for ln in even} <= {(ln[1], ln[2]) for ln in lines if ln[0] == "hit"}
     assert ["missing_index_is_error", "1"] in lines
+    assert ["freed_writer_is_error", "1"] in lines and ["other_tokenizer_is_error", "1"] in lines
+    assert ["default_tokenizer_is_fine", "1"] in lines
