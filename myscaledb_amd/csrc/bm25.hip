@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "bm25_kernels.hpp"
+#include "bm25p_kernels.hpp"
 #include "device_ops.hpp"
 
 using namespace msvs;
@@ -212,10 +213,77 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
 {
     const size_t f0 = qoff[0], n_flat = qoff[nq] - f0, nf1 = std::max<size_t>(n_flat, 1), nc = ps.num_fields * 256;
     const float K1 = 1.2f;
-    // one host blob -> one copy: [qoff u32][qterms u32][weight f32][cache f32][full u16][group u8][field u8]
+    // two kernels share this flow: the wave-private streaming scorer (default) and the block scorer it replaced (knob)
+    const bool wave = options().bm25_wave != 0;
+    // ... and, for batches of sparse terms, the posting-as-unit scorer (bm25p_kernels.hpp).  Its sub-range size follows the
+    // densest query of the batch (postings of all its terms per document): that query's windows (<= BP_CAP postings) are
+    // single sub-ranges, sparser queries take several per window.  Frequent terms (over 1/8 posting per document) keep the dense accumulator,
+    // which they fill.
+    bool posting = wave && options().bm25_posting != 0;
+    static thread_local std::vector<uint64_t> q_postings;
+    uint64_t all_postings = 0;
+    uint32_t sub_docs = BW_DOCS;
+    if (posting)
+    {
+        double rho = 0;
+        q_postings.assign(nq, 0);
+        for (size_t q = 0; q < nq; q++)
+        {
+            uint64_t sum = 0;
+            for (size_t j = qoff[q]; j < qoff[q + 1] && qoff[q + 1] >= qoff[q]; j++)
+            {
+                if (qterms[j] >= ps.num_terms)
+                    fail(MSVS_ERR_INVALID_ARGUMENT, "query term id %u out of range", qterms[j]);
+                sum += (uint64_t)(ps.h_post_off[qterms[j] + 1] - ps.h_post_off[qterms[j]]);
+            }
+            q_postings[q] = sum;
+            all_postings += sum;
+            rho = std::max(rho, (double)sum / (double)std::max<size_t>(ps.num_docs, 1));
+        }
+        if (rho > 0.125 && options().bm25_posting != 2) // 2: always (tests: every sub-range of a frequent term is split)
+            posting = false;
+        else
+        {
+            // the densest query's windows are single sub-ranges filled to ~3/4 of the cap; sparser queries take several
+            sub_docs = (uint32_t)std::min<double>(BP_MAX_DOCS, std::max<double>(BP_MIN_DOCS, std::floor(0.75 * BP_CAP / std::max(rho, 1e-9))));
+            if (options().bm25_sub_docs >= 16)
+                sub_docs = (uint32_t)options().bm25_sub_docs;
+        }
+    }
+    const uint32_t docs_per_block = posting ? sub_docs : (wave ? BW_DOCS : BM25_DOCS);
+    const uint32_t n_blocks = (uint32_t)std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)docs_per_block));
+    // wave scorer: an item = spi consecutive sub-ranges of one query; enough items for ~4 per resident wavefront
+    const uint32_t spi = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (size_t)n_blocks * nq / 8192));
+    const uint32_t n_chunks = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi) : n_blocks;
+    // long corpora: sample -> cut -> emit -> select (+ exact fallback); short ones: per-chunk top-k lists, one merge
+    const bool emit = n_chunks >= (wave ? 32u : 64u) && ps.num_docs >= 500000 && options().bm25_emit != 0;
+    const uint32_t cand_cap = options().bm25_cand_cap > 0 ? (uint32_t)std::min<double>(options().bm25_cand_cap, BM25_CAND_CAP) : BM25_CAND_CAP;
+    unsigned long long * stat_fail = bm25_fail_counter();
+    // posting scorer, EMIT pass: items of about equal postings (a uniform spread of a term over the documents assumed), twice
+    // as many as resident wavefronts -- the launch walks them with a static stride
+    const uint32_t cus = bm25_cu_count();
+    const double per_item = std::max(800.0, (double)all_postings / (2.0 * cus * 16));
+    auto spi_of = [&](size_t q) -> uint32_t {
+        if (q_postings[q] == 0)
+            return n_blocks;
+        return (uint32_t)std::min<double>(n_blocks, std::max(1.0, std::floor(per_item * n_blocks / (double)q_postings[q])));
+    };
+    size_t n_items_e = 0;
+    if (posting && emit)
+        for (size_t q = 0; q < nq; q++)
+            n_items_e += ceil_div((size_t)n_blocks, (size_t)spi_of(q));
+    // the sample (every 16th chunk) walks a FINER partition in the wave scorer: with the emit pass's chunks (38 sub-ranges at
+    // 64 queries over 10M documents) it was 576 items of 112 us each on 2048 resident wavefronts = one item's duration
+    const uint32_t spi_s = wave && options().bm25_fine_sample != 0 ? std::max<uint32_t>(1, spi / 8) : spi;
+    const uint32_t n_chunks_s = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi_s) : n_blocks;
+    const uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks_s, (size_t)BM25_SAMPLE_STEP);
+    // m-th best of the sample as the cut: about STEP * m documents pass, 4 sigma (STEP * sqrt(m)) above k
+    const double rs = 2.0 + std::sqrt(4.0 + (double)k / BM25_SAMPLE_STEP);
+    const uint32_t cut_m = (uint32_t)std::min<double>(64.0, std::ceil(rs * rs));
+    // one host blob -> one copy: [qoff u32][qterms u32][weight f32][cache f32][full u16][group u8][field u8][emit items 3 x u32]
     const size_t o_qoff = 0, o_terms = o_qoff + (nq + 1) * 4, o_w = o_terms + nf1 * 4, o_cache = o_w + nf1 * 4,
                  o_full = o_cache + nc * 4, o_group = o_full + round_up(nq * 2, (size_t)4), o_field = o_group + nf1,
-                 blob_bytes = round_up(o_field + nf1, (size_t)16);
+                 o_items = round_up(o_field + nf1, (size_t)16), blob_bytes = round_up(o_items + n_items_e * 12, (size_t)16);
     PinnedRing & ring = pinned_ring(stream);
     int slot = 0;
     unsigned char * blob = static_cast<unsigned char *>(ring.take(blob_bytes, slot));
@@ -253,28 +321,23 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         }
         full[q] = m;
     }
-    // two kernels share this flow: the wave-private streaming scorer (default) and the block scorer it replaced (knob)
-    const bool wave = options().bm25_wave != 0;
-    const uint32_t docs_per_block = wave ? BW_DOCS : BM25_DOCS;
-    const uint32_t n_blocks = (uint32_t)std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)docs_per_block));
-    // wave scorer: an item = spi consecutive sub-ranges of one query; enough items for ~4 per resident wavefront
-    const uint32_t spi = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (size_t)n_blocks * nq / 8192));
-    const uint32_t n_chunks = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi) : n_blocks;
-    // long corpora: sample -> cut -> emit -> select (+ exact fallback); short ones: per-chunk top-k lists, one merge
-    const bool emit = n_chunks >= (wave ? 32u : 64u) && ps.num_docs >= 500000 && options().bm25_emit != 0;
-    const uint32_t cand_cap = options().bm25_cand_cap > 0 ? (uint32_t)std::min<double>(options().bm25_cand_cap, BM25_CAND_CAP) : BM25_CAND_CAP;
-    unsigned long long * stat_fail = bm25_fail_counter();
-    // the sample (every 16th chunk) walks a FINER partition in the wave scorer: with the emit pass's chunks (38 sub-ranges at
-    // 64 queries over 10M documents) it was 576 items of 112 us each on 2048 resident wavefronts = one item's duration
-    const uint32_t spi_s = wave && options().bm25_fine_sample != 0 ? std::max<uint32_t>(1, spi / 8) : spi;
-    const uint32_t n_chunks_s = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi_s) : n_blocks;
-    const uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks_s, (size_t)BM25_SAMPLE_STEP);
-    // m-th best of the sample as the cut: about STEP * m documents pass, 4 sigma (STEP * sqrt(m)) above k
-    const double rs = 2.0 + std::sqrt(4.0 + (double)k / BM25_SAMPLE_STEP);
-    const uint32_t cut_m = (uint32_t)std::min<double>(64.0, std::ceil(rs * rs));
+    {
+        uint32_t * it = reinterpret_cast<uint32_t *>(blob + o_items);
+        if (n_items_e)
+            for (size_t q = 0; q < nq; q++)
+            {
+                const uint32_t sq = spi_of(q);
+                for (uint32_t b = 0; b < n_blocks; b += sq, it += 3)
+                {
+                    it[0] = (uint32_t)q;
+                    it[1] = b;
+                    it[2] = std::min<uint32_t>(n_blocks, b + sq);
+                }
+            }
+    }
     Scratch & scr = scratch_for(stream);
     scr.reserve(nq * (size_t)n_chunks * k * 8 + nf1 * (size_t)(n_blocks + 1) * 16 + blob_bytes
-                    + (emit ? nq * ((size_t)(n_sb + 1) * cut_m * 8 + (size_t)BM25_CAND_CAP * 8 + 16) : 0) + 65536,
+                    + (emit ? nq * ((size_t)(n_sb + 1) * cut_m * 8 + (size_t)BM25_CAND_CAP * 8 + 16) : 0) + nq * 8 + 256 + 65536,
                 stream);
     Bm25Params a{};
     unsigned char * d_blob = scr.take<unsigned char>(blob_bytes);
@@ -306,7 +369,6 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     a.qfield = d_blob + o_field;
     a.bounds = d_bounds;
     a.bounds_hi = d_bounds_hi;
-    const uint32_t cus = bm25_cu_count();
     // TOPK over (a sample of) the chunks: lists of p.kk keys into p.partial, `lists` per slot
     auto launch_topk = [&](Bm25Params p, uint32_t lists, uint32_t step, size_t slots_bound, uint32_t item_spi, uint32_t item_chunks) {
         if (wave)
@@ -318,9 +380,23 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
             w.cstep = step;
             w.n_items_c = lists;
             w.lists = lists;
+            w.sub_docs = docs_per_block;
+            w.dbg = (uint32_t)options().bm25_dbg;
             const bool nf1k = ps.num_fields == 1;
-            const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)lists * slots_bound, (size_t)BW_WAVES), (size_t)cus * bw_blocks_per_cu(nf1k)));
             const int r = r_for_k(p.kk);
+            if (posting)
+            {
+                const unsigned pgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)lists * slots_bound, (size_t)BP_WAVES), (size_t)cus * 4));
+                if (r == 1)
+                    hipLaunchKernelGGL((bm25p_kernel<BM25_TOPK, 1>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, w);
+                else if (r == 2)
+                    hipLaunchKernelGGL((bm25p_kernel<BM25_TOPK, 2>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, w);
+                else
+                    hipLaunchKernelGGL((bm25p_kernel<BM25_TOPK, 4>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, w);
+                MSVS_HIP(hipGetLastError());
+                return;
+            }
+            const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)lists * slots_bound, (size_t)BW_WAVES), (size_t)cus * bw_blocks_per_cu(nf1k)));
 #define MSVS_BM25W(RR, NF) hipLaunchKernelGGL((bm25w_kernel<BM25_TOPK, RR, NF>), dim3(grid), dim3(64 * BW_WAVES), 0, stream, w)
             if (nf1k)
             {
@@ -405,9 +481,16 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         w.cstep = 1;
         w.n_items_c = n_chunks;
         w.lists = n_chunks;
+        w.sub_docs = docs_per_block;
+        w.dbg = (uint32_t)options().bm25_dbg;
+        w.items = posting ? reinterpret_cast<const uint32_t *>(d_blob + o_items) : nullptr;
+        w.n_items_tab = (uint32_t)n_items_e;
         const bool nf1k = ps.num_fields == 1;
         const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)n_chunks * nq, (size_t)BW_WAVES), (size_t)cus * bw_blocks_per_cu(nf1k)));
-        if (nf1k)
+        if (posting)
+            hipLaunchKernelGGL((bm25p_kernel<BM25_EMIT, 1>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)n_chunks * nq, (size_t)BP_WAVES), (size_t)cus * 4))),
+                               dim3(64 * BP_WAVES), 0, stream, w);
+        else if (nf1k)
             hipLaunchKernelGGL((bm25w_kernel<BM25_EMIT, 1, 1>), dim3(grid), dim3(64 * BW_WAVES), 0, stream, w);
         else
             hipLaunchKernelGGL((bm25w_kernel<BM25_EMIT, 1, 4>), dim3(grid), dim3(64 * BW_WAVES), 0, stream, w);
@@ -420,21 +503,8 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     }
     // 3. select, or queue for the fallback
     const size_t lds_k = (size_t)5 * k * 8;
-    switch (r_for_k((uint32_t)k))
-    {
-        case 1:
-            hipLaunchKernelGGL((bm25_select_kernel<1>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, cand, ccnt, cand_cap, cut_keys,
-                               cut_m, (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
-            break;
-        case 2:
-            hipLaunchKernelGGL((bm25_select_kernel<2>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, cand, ccnt, cand_cap, cut_keys,
-                               cut_m, (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
-            break;
-        default:
-            hipLaunchKernelGGL((bm25_select_kernel<4>), dim3((unsigned)nq), dim3(BLOCK), lds_k, stream, cand, ccnt, cand_cap, cut_keys,
-                               cut_m, (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
-            break;
-    }
+    hipLaunchKernelGGL(bm25_select_kernel, dim3((unsigned)nq), dim3(BM25_SELECT_THREADS), 0, stream, cand, ccnt, cand_cap, cut_keys, cut_m,
+                       (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
     // 4. the exact fallback over the queue (empty launches when nobody queued)
     Bm25Params fp = a;
     fp.partial = partial;
@@ -514,7 +584,7 @@ void bm25_batch_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
             eff_bits = res_bits;
         }
     }
-    const size_t n_blocks = std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)BW_DOCS)); // an upper bound of the lists per query
+    const size_t n_blocks = std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)(options().bm25_posting != 0 ? BP_MIN_DOCS : BW_DOCS))); // an upper bound of the lists per query
     // per query: candidate slots + ~4 terms of sub-range bounds (the per-chunk lists are ~8192 x k keys for the whole batch)
     const size_t per_q = (size_t)BM25_CAND_CAP * 8 + 4 * 16 * (n_blocks + 1) + 64 * k * 8 + 64
         + (options().bm25_wave != 0 ? 0 : ceil_div(ps.num_docs, (size_t)BM25_DOCS) * k * 8); // the block scorer: a list per block

@@ -463,6 +463,10 @@ struct Bm25WParams
     uint32_t cstep;        // TOPK sample: item chunk = index * cstep
     uint32_t n_items_c;    // chunks this launch walks (n_chunks, or the sample's ceil(n_chunks / cstep))
     uint32_t lists;        // TOPK: lists per slot in `partial` (= n_items_c)
+    const uint32_t * items; // bm25p_kernel EMIT: [n_items_tab][3] = query, first sub-range, end sub-range (nullptr: (chunk, query) items)
+    uint32_t n_items_tab;
+    uint32_t dbg;          // experiment masks of bm25p_kernel (option bm25_dbg; results are wrong with any bit set)
+    uint32_t sub_docs;     // documents per sub-range (BW_DOCS for bm25w_kernel; chosen per batch for bm25p_kernel)
 };
 
 template <int MODE, int R, int NF>
@@ -699,16 +703,19 @@ __global__ __launch_bounds__(64 * BW_WAVES) void bm25w_kernel(const Bm25WParams 
     }
 }
 
-/// One block per query: top-k of its candidates -> results; a query whose candidates cannot prove its top-k (list
-/// overflowed, or a real cut let fewer than k through) joins the fallback queue instead.
-template <int R>
-__global__ __launch_bounds__(BLOCK) void bm25_select_kernel(const uint64_t * cand, const uint32_t * ccnt, uint32_t cand_cap,
-                                                            const uint64_t * cut_keys, uint32_t cut_m, uint32_t k, int64_t * out_ids,
-                                                            float * out_scores, uint32_t * failq, uint32_t * nfail,
-                                                            unsigned long long * stat_fail)
+/// One block of 1024 threads per query: top-k of its candidates -> results; a query whose candidates cannot prove its top-k
+/// (list overflowed, or a real cut let fewer than k through) joins the fallback queue instead.
+/// Selection by RANK: the <= 2048 candidate keys go to LDS and every thread counts the keys below its own (a key holds the
+/// document id: no two are equal); rank < k is the output position.  cnt^2 / 1024 broadcast LDS reads and compares per
+/// thread -- ~5 us at the usual 500-1000 candidates, where four wavefronts feeding WaveTopK insertions took 33 us.
+constexpr uint32_t BM25_SELECT_THREADS = 1024;
+static __global__ __launch_bounds__(BM25_SELECT_THREADS) void bm25_select_kernel(const uint64_t * cand, const uint32_t * ccnt, uint32_t cand_cap,
+                                                                                 const uint64_t * cut_keys, uint32_t cut_m, uint32_t k,
+                                                                                 int64_t * out_ids, float * out_scores, uint32_t * failq,
+                                                                                 uint32_t * nfail, unsigned long long * stat_fail)
 {
-    uint64_t * lds = reinterpret_cast<uint64_t *>(msvs_smem);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) uint64_t keys[BM25_CAND_CAP + 2];
+    const uint32_t tid = threadIdx.x, q = blockIdx.x;
     const uint32_t cnt = ccnt[q];
     const bool real_cut = cut_keys[(size_t)q * cut_m + cut_m - 1] != KEY_NONE;
     if (cnt > cand_cap || (real_cut && cnt < k))
@@ -721,30 +728,28 @@ __global__ __launch_bounds__(BLOCK) void bm25_select_kernel(const uint64_t * can
         return;
     }
     const uint64_t * src = cand + (size_t)q * BM25_CAND_CAP;
-    WaveTopK<R> top;
-    top.init();
-    for (uint32_t b = 0; b < cnt; b += 4 * BLOCK)
+    for (uint32_t i = tid; i < cnt + 2; i += BM25_SELECT_THREADS)
+        keys[i] = i < cnt ? src[i] : KEY_NONE; // two pad keys: the count loop reads pairs
+    for (uint32_t i = cnt + tid; i < k; i += BM25_SELECT_THREADS) // fewer candidates than k: the tail is "no hit"
     {
-        uint64_t key[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-        {
-            const uint32_t i = b + u * BLOCK + tid;
-            key[u] = i < cnt ? src[i] : KEY_NONE;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            top.offer(key[u], k, lane);
+        out_ids[(size_t)q * k + i] = -1;
+        out_scores[(size_t)q * k + i] = key_value<M_IP>(KEY_NONE);
     }
-    top.store(lds + wave * k, k, lane);
     __syncthreads();
-    uint64_t * merged = lds + 4 * k;
-    block_rank_merge(lds, k, merged, k, tid);
-    for (uint32_t i = tid; i < k; i += BLOCK)
+    for (uint32_t i = tid; i < cnt; i += BM25_SELECT_THREADS)
     {
-        const uint64_t key = merged[i];
-        out_ids[(size_t)q * k + i] = key == KEY_NONE ? -1 : (int64_t)(uint32_t)key;
-        out_scores[(size_t)q * k + i] = key_value<M_IP>(key);
+        const uint64_t mine = keys[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < cnt; j += 2)
+        {
+            const uint64_t k0 = keys[j], k1 = keys[j + 1]; // the same address in every lane: one broadcast read of 16 bytes
+            rank += (k0 < mine ? 1u : 0u) + (k1 < mine ? 1u : 0u); // the pad keys are KEY_NONE: never below a candidate
+        }
+        if (rank < k)
+        {
+            out_ids[(size_t)q * k + rank] = (int64_t)(uint32_t)mine;
+            out_scores[(size_t)q * k + rank] = key_value<M_IP>(mine);
+        }
     }
 }
 

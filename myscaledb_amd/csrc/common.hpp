@@ -183,6 +183,9 @@ struct Options
                                        // rows passes the filter (1: always, 0: never, < 0: by batch size,
                                        // profiles/r02_filter.txt)
     double bm25_wave = 1;     // BM25: wave-private streaming scorer (1) or the barrier-synchronised block scorer (0)
+    double bm25_posting = 1;  // BM25: posting-as-unit scorer (bm25p_kernel) for batches of sparse terms; 0: always the dense accumulator, 2: always the posting scorer
+    double bm25_dbg = 0;      // BM25 posting scorer: experiment masks (1 no owner search, 2 no fieldnorm gather, 4 no output, 8 windows only)
+    double bm25_sub_docs = 0; // BM25 posting scorer: documents per sub-range (0: from the batch's posting density)
     double bm25_emit = 1;     // BM25 over long corpora: sample / cut / emit (1) or per-block top-k lists only (0)
     double bm25_cand_cap = 0; // BM25 candidate slots per query (0 = 2048; small values force the fallback)
 };

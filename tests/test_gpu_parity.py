@@ -1127,12 +1127,19 @@ def test_bm25_synthetic_corpus_matches_oracle():
         assert (got[1].view(np.uint32) == exp[1].view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("wave", ["1", "0"])
+def bm25_scorer(opt, which):
+    """"p": the posting-as-unit scorer forced (frequent terms take its split path), "w": the wave-private dense accumulator,
+    "0": the block scorer it replaced.  (The default routes a batch to "p" or "w" by its posting density.)"""
+    opt("bm25_wave", "0" if which == "0" else "1")
+    opt("bm25_posting", "2" if which == "p" else "0")
+
+
+@pytest.mark.parametrize("wave", ["p", "w", "0"])
 @pytest.mark.parametrize("mode", ["emit", "lists", "forced_fallback"])
 def test_bm25_many_doc_blocks(mode, wave, opt):
     """>= 64 document blocks (here 700k documents = 86 blocks): sample -> cut -> emit -> select; the same with the
     candidate list too small for any query (every query takes the exact fallback); and per-block lists only."""
-    opt("bm25_wave", wave)  # the wave-private streaming scorer / the block scorer it replaced
+    bm25_scorer(opt, wave)
     if mode == "lists":
         opt("bm25_emit", "0")
     if mode == "forced_fallback":
@@ -1194,11 +1201,11 @@ def synthetic_postings(rng, n_docs, vocab, mean_len, num_fields=1):
     return post_off, np.concatenate(docs), np.concatenate(tfs), np.stack(fns), term_field, np.asarray(tokens, np.uint64)
 
 
-@pytest.mark.parametrize("wave", ["1", "0"])
+@pytest.mark.parametrize("wave", ["p", "w", "0"])
 def test_bm25_batch_equals_single_queries_and_oracle(wave, opt):
     """msvs_bm25_search_batch: every query of a batch == the one-query entry point == the oracle, bit for bit; the
     resident alive bitmap (msvs_postings_set_alive) ANDs with the per-call one."""
-    opt("bm25_wave", wave)
+    bm25_scorer(opt, wave)
     rng = np.random.default_rng(91)
     n_docs, vocab = 300_000, 2000
     post_off, doc, tf, fn, _, tokens = synthetic_postings(rng, n_docs, vocab, 14)
@@ -1245,12 +1252,12 @@ def test_bm25_batch_equals_single_queries_and_oracle(wave, opt):
         assert (od[qi].cpu().numpy()[:len(gr)].view(np.uint32) == gs.view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("wave", ["1", "0"])
+@pytest.mark.parametrize("wave", ["p", "w", "0"])
 @pytest.mark.parametrize("num_fields", [1, 3])
 def test_bm25_and_operator_and_text_columns(num_fields, wave, opt):
     """operator_or = false (every token must match, in any column) and an index over several text columns: one term
     per (column, token), one token group per query token -- against the oracle's restatement."""
-    opt("bm25_wave", wave)
+    bm25_scorer(opt, wave)
     rng = np.random.default_rng(92 + num_fields)
     n_docs, vocab = 120_000, 400
     post_off, doc, tf, fn, term_field, tokens = synthetic_postings(rng, n_docs, vocab, 6, num_fields)
@@ -1274,6 +1281,52 @@ def test_bm25_and_operator_and_text_columns(num_fields, wave, opt):
                 assert (gs.view(np.uint32) == es.view(np.uint32)).all()
                 n_hits += len(gr)
             assert n_hits > 0
+
+
+@pytest.mark.parametrize("sub_docs", ["0", "8192", "512"])
+def test_bm25_posting_scorer_windows_duplicates_and_density_routing(sub_docs, opt):
+    """The default routing: a batch of sparse terms goes to the posting-as-unit scorer (bm25p_kernel), whatever sub-range
+    size it cuts its windows from; terms repeated inside a query, terms sharing most of their documents, 40-term queries
+    and empty posting lists -- every hit and score bit == the oracle's dense term-order accumulation."""
+    opt("bm25_sub_docs", sub_docs)
+    rng = np.random.default_rng(123)
+    n_docs, vocab = 600_000, 4000
+    # terms 0..39: ~0.25 % of the documents each (the 40-term query stays under 1/8 posting per document), term 1 = half of
+    # term 0's documents plus a few (shared documents);
+    # the rest: rare.  Term vocab - 1 has no postings at all.
+    lists = []
+    base = np.sort(rng.choice(n_docs, 1800, replace=False)).astype(np.uint32)
+    lists.append(base)
+    lists.append(np.unique(np.concatenate([base[::2], rng.choice(n_docs, 600, replace=False).astype(np.uint32)])))
+    for t in range(2, 40):
+        lists.append(np.sort(rng.choice(n_docs, int(rng.integers(1000, 2000)), replace=False)).astype(np.uint32))
+    for t in range(40, vocab - 1):
+        lists.append(np.sort(rng.choice(n_docs, int(rng.integers(1, 400)), replace=False)).astype(np.uint32))
+    lists.append(np.zeros(0, np.uint32))
+    post_off = np.zeros(vocab + 1, np.int64)
+    np.cumsum([len(x) for x in lists], out=post_off[1:])
+    doc = np.concatenate(lists)
+    tf = rng.integers(1, 6, len(doc)).astype(np.uint32)
+    lens = np.maximum(1, rng.poisson(20, n_docs))
+    fn = np.array([o.fieldnorm_id(int(n)) for n in range(int(lens.max()) + 1)], np.uint8)[lens]
+    total_tokens = int(lens.sum())
+    ps = capi.Postings(post_off, doc, tf, fn)
+    df_all = np.diff(post_off)
+    queries = [[0, 1], [1, 0, 1], [5, 5, 5], [3, 900, 17], [vocab - 1, 7], [vocab - 1], list(range(40)), [2000, 2001, 2002, 2003],
+               [39, 38, 0, 1500]]
+    queries += [list(rng.choice(vocab - 1, rng.integers(1, 5), replace=False)) for _ in range(55)]
+    dfs = [[int(df_all[t]) for t in q] for q in queries]
+    alive = rng.random(n_docs) < 0.5
+    q0, f0 = capi.bm25_stats()
+    for k in (10, 100):
+        for al in (None, alive):
+            got = ps.bm25_search_batch(queries, dfs, n_docs, total_tokens, k, alive=al)
+            for q, dfq, (gr, gs) in zip(queries, dfs, got):
+                er, es = o.bm25_search(post_off, doc, tf, fn, q, dfq, n_docs, total_tokens, k, alive=al)
+                assert gr.tolist() == er.tolist(), q
+                assert (gs.view(np.uint32) == es.view(np.uint32)).all(), q
+    q1, f1 = capi.bm25_stats()
+    assert q1 - q0 == 4 * len(queries) and f1 - f0 <= 8  # the sample/emit path, a rare exact fallback
 
 
 def build_store(docs, columns=("doc",)):
