@@ -371,24 +371,48 @@ __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25p_kernel(const Bm25WPara
                     if (r * 64 + lane < tot)
                         *reinterpret_cast<uint2 *>(&bm[2 * ((doc_r[r] & (BP_SLOTS - 1)) >> 5)]) = make_uint2(0u, 0u);
             }
-            // ---- the unshared records leave at once
-            uint32_t nfl = 0;
+            // ---- the unshared records leave at once.  EMIT: few records of a window pass the cut, most windows have none:
+            // the tests are collected as bits first and the rows nobody passes in are skipped
+            uint32_t passbits = 0;
 #pragma unroll
             for (uint32_t r = 0; r < BP_RMAX; r++)
             {
                 if (r >= nr)
                     break;
-                const uint32_t docid = doc_r[r];
-                bool ok = !(a.dbg & 4) && r * 64 + lane < tot && !((flags >> r) & 1u) && (p.operator_or || (tfb[t_r[r]] >> 8) == full)
+                const bool ok = !(a.dbg & 4) && r * 64 + lane < tot && !((flags >> r) & 1u) && (p.operator_or || (tfb[t_r[r]] >> 8) == full)
                     && (MODE != BM25_EMIT || s_r[r] >= cut);
-                if (ok && p.alive)
-                    ok = docid < p.nbits && ((p.alive[docid >> 6] >> (docid & 63)) & 1);
-                out_one(ok, make_key<M_IP>(s_r[r], docid));
-                const bool fl = (flags >> r) & 1u;
-                const uint64_t fm = __ballot(fl);
-                if (fl)
-                    flist[nfl + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = (uint16_t)(r * 64 + lane);
-                nfl += (uint32_t)__popcll(fm);
+                passbits |= (ok ? 1u : 0u) << r;
+            }
+            if (MODE == BM25_TOPK || __ballot(passbits != 0))
+            {
+#pragma unroll
+                for (uint32_t r = 0; r < BP_RMAX; r++)
+                {
+                    if (r >= nr)
+                        break;
+                    bool ok = (passbits >> r) & 1u;
+                    if (MODE == BM25_EMIT && !__ballot(ok))
+                        continue;
+                    const uint32_t docid = doc_r[r];
+                    if (ok && p.alive)
+                        ok = docid < p.nbits && ((p.alive[docid >> 6] >> (docid & 63)) & 1);
+                    out_one(ok, make_key<M_IP>(s_r[r], docid));
+                }
+            }
+            uint32_t nfl = 0;
+            if (__ballot(flags != 0))
+            {
+#pragma unroll
+                for (uint32_t r = 0; r < BP_RMAX; r++)
+                {
+                    if (r >= nr)
+                        break;
+                    const bool fl = (flags >> r) & 1u;
+                    const uint64_t fm = __ballot(fl);
+                    if (fl)
+                        flist[nfl + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = (uint16_t)(r * 64 + lane);
+                    nfl += (uint32_t)__popcll(fm);
+                }
             }
             // ---- the shared ones (and the hash's false alarms), one per lane: the record is the OWNER of its document when no
             // earlier term has it; the owner adds the later terms' partials in term order

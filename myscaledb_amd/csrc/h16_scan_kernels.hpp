@@ -130,14 +130,53 @@ static __global__ void h16_build_kernel(const float * vecs, uint32_t ld, const i
 }
 
 /// Queries -> fp16 image + per-query constants; one wavefront per query.
-/// qnorm[q] (|q|^2, already computed) is overwritten with +inf when the query cannot be represented (NaN / inf /
-/// a scale outside 2^+-100): the certificate then fails and the canonical fallback serves the query.
+/// qnorm[q] = |q|^2: taken as given, or (compute_norm) computed here with row_sqnorm16_kernel's arithmetic -- 16 lanes,
+/// fma chains, the DPP row tree -- so one launch serves where there were three (norms, a copy of them, this).  It is
+/// overwritten with +inf when the query cannot be represented (NaN / inf / a scale outside 2^+-100): the certificate then
+/// fails and the canonical fallback serves the query.
+/// The small set-up work of a search that would otherwise be launches of its own rides along (aux, all nullable): the
+/// one-list plan of a table pass (every query "probes" list 0 = rows [0, row_end): single_list_plan_kernel) and the zeroing of
+/// the search's counters.
+struct H16PrepAux
+{
+    uint32_t * pairs = nullptr;   // [nq] = 0 .. nq - 1
+    int32_t * probes0 = nullptr;  // [nq] = 0
+    int64_t * list_off = nullptr; // [2]
+    uint32_t * pair_off = nullptr, * work_off = nullptr; // [2] each
+    uint32_t * nfail = nullptr;   // the pass's fail counter = 0
+    uint32_t row_end = 0, rows_per_block = 1, tq = 1;
+    uint32_t * zero[2] = {nullptr, nullptr}; // two regions of 32-bit words to clear ...
+    uint32_t nzero[2] = {0, 0};              // ... and their lengths
+};
+
 static __global__ void h16_prep_queries_kernel(const float * Q, uint32_t nq, uint32_t ld, uint32_t nch,
-                                               float inv_sx, int ip, uint4 * Qh, float2 * qinfo, float * qnorm)
+                                               float inv_sx, int ip, uint4 * Qh, float2 * qinfo, float * qnorm, int compute_norm,
+                                               const H16PrepAux aux)
 {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    {
+        const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+        for (int z = 0; z < 2; z++)
+            for (uint32_t i = gid; i < aux.nzero[z]; i += gsz)
+                aux.zero[z][i] = 0;
+        if (aux.pairs && gid == 0)
+        {
+            aux.list_off[0] = 0;
+            aux.list_off[1] = aux.row_end;
+            aux.pair_off[0] = 0;
+            aux.pair_off[1] = nq;
+            aux.work_off[0] = 0;
+            aux.work_off[1] = ((nq + aux.tq - 1) / aux.tq) * ((aux.row_end + aux.rows_per_block - 1) / aux.rows_per_block);
+            *aux.nfail = 0;
+        }
+    }
     if (q >= nq)
         return;
+    if (aux.pairs && lane == 0)
+    {
+        aux.pairs[q] = q;
+        aux.probes0[q] = 0;
+    }
     const float * src = Q + (size_t)q * ld;
     uint32_t m = 0;
     for (uint32_t e = lane * 4; e < ld; e += 256)
@@ -172,12 +211,28 @@ static __global__ void h16_prep_queries_kernel(const float * Q, uint32_t nq, uin
         Qh[(size_t)q * nch * 8 + p] = make_uint4(pack_h2(v0.x * sq, v0.y * sq), pack_h2(v0.z * sq, v0.w * sq),
                                                  pack_h2(v1.x * sq, v1.y * sq), pack_h2(v1.z * sq, v1.w * sq));
     }
+    float qn = 0.f;
+    if (compute_norm)
+    {
+        if (lane < 16)
+            for (uint32_t c = lane; c < ld / 4; c += 16)
+            {
+                const float4 v = *reinterpret_cast<const float4 *>(src + 4 * c);
+                qn = fmaf(v.x, v.x, qn);
+                qn = fmaf(v.y, v.y, qn);
+                qn = fmaf(v.z, v.z, qn);
+                qn = fmaf(v.w, v.w, qn);
+            }
+        qn = row16_tree_sum(qn);
+    }
     if (lane == 0)
     {
+        if (!compute_norm)
+            qn = qnorm[q];
         const float unscale = inv_sx * inv_sq; // powers of two: exact
-        qinfo[q] = ip ? make_float2(unscale, 0.f) : make_float2(-2.f * unscale, qnorm[q]);
-        if (bad)
-            qnorm[q] = __uint_as_float(0x7f800000u);
+        qinfo[q] = ip ? make_float2(unscale, 0.f) : make_float2(-2.f * unscale, qn);
+        if (bad || compute_norm)
+            qnorm[q] = bad ? __uint_as_float(0x7f800000u) : qn;
     }
 }
 
@@ -685,10 +740,18 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
     {
         const uint32_t i = u * WAVE + lane;
         const int32_t l = i < n ? qprobes[i / H_ROWS] : -1;
-        word[u] = l >= 0 ? src[i] : 0xFFFFFFFFu;
         lbeg[u] = l >= 0 ? list_off[l] : 0;
+        // the list's length: loaded by the first lane of the pair's 32, which also tells the others whether the list has rows
+        // at all -- an empty list has no sample item and its 32 words were never written
+        uint32_t len = 0;
         if (l >= 0 && (i & (H_ROWS - 1)) == 0)
-            rows += (uint64_t)(list_off[l + 1] - lbeg[u]);
+        {
+            const uint64_t len64 = (uint64_t)(list_off[l + 1] - lbeg[u]);
+            rows += len64;
+            len = len64 ? 1u : 0u;
+        }
+        len = (uint32_t)__shfl((int)len, (int)(lane & ~(H_ROWS - 1)));
+        word[u] = len ? src[i] : 0xFFFFFFFFu;
         have += word[u] != 0xFFFFFFFFu;
     }
 #pragma unroll
@@ -764,9 +827,14 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint
         if (l >= 0)
             rows += (uint64_t)(list_off[l + 1] - list_off[l]);
     }
+    // a pair whose list is empty has no sample item: its words were never written
+    auto word_of = [&](uint32_t i) -> uint32_t {
+        const int32_t l = probes[(size_t)q * nprobe + i / H_ROWS];
+        return l >= 0 && list_off[l + 1] > list_off[l] ? src[i] : 0xFFFFFFFFu;
+    };
     uint32_t have = 0;
     for (uint32_t i = lane; i < n; i += 64)
-        have += probes[(size_t)q * nprobe + i / H_ROWS] >= 0 && src[i] != 0xFFFFFFFFu;
+        have += word_of(i) != 0xFFFFFFFFu;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1)
     {
@@ -784,7 +852,7 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint
         for (int u = 0; u < 4; u++)
         {
             const uint32_t i = base + u * WAVE + lane;
-            const uint32_t word = i < n && probes[(size_t)q * nprobe + i / H_ROWS] >= 0 ? src[i] : 0xFFFFFFFFu;
+            const uint32_t word = i < n ? word_of(i) : 0xFFFFFFFFu;
             key[u] = word == 0xFFFFFFFFu ? KEY_NONE : ((uint64_t)word << 32 | i);
         }
 #pragma unroll
@@ -798,7 +866,7 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint
     {
         const uint32_t i = base + lane;
         const int32_t l = i < n ? probes[(size_t)q * nprobe + i / H_ROWS] : -1;
-        const uint32_t word = l >= 0 ? src[i] : 0xFFFFFFFFu;
+        const uint32_t word = i < n ? word_of(i) : 0xFFFFFFFFu;
         const bool take = word < cut; // 0xFFFFFFFF (no row) is never below a cut
         const uint64_t mask = __ballot(take);
         if (take)

@@ -1485,6 +1485,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
         + nq * nprobe * 4
         + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768
+        + (2 * ix.nlist + 18) * 4 + HR_CPP * 128 + 1024 // the list scan's counters taken up front, the padded query images
         + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 8192 : 0);
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
@@ -1509,6 +1510,17 @@ static void set_error_model(RerankParams & rp, size_t dim)
 /// (single_list_plan_kernel); 16 candidates per (query, 128-row slice) -> 32 / 64 per query -> canonical re-rank ->
 /// exact top-k with the same certificate / canonical fallback as the list scan (mfma_scan_kernels.hpp).
 /// Used for the coarse quantiser (table = centroids, result = probe lists) and for FLAT indexes (table = all rows).
+/// The queries of a search as the fp16 shadow passes want them (h16_prep_queries_kernel): the coarse pass over the centroid
+/// shadow and the list scan use the same images, scale and norms -- prepared once per search.
+struct H16Queries
+{
+    uint4 * qh = nullptr;
+    float2 * qinfo = nullptr;
+    float * qnorm = nullptr;
+    uint32_t * counters = nullptr; // in: the list scan's counters, to be zeroed along the way (cleared flag: qh != nullptr)
+    uint32_t n_counters = 0;
+};
+
 struct TablePass
 {
     const float * rows;    // n x ld
@@ -1525,6 +1537,7 @@ struct TablePass
     int cosine;
     const char * prof_name;
     bool h16 = false; // the table is the centroid table and its fp16 shadow is usable: scan through h16_sample_kernel
+    H16Queries * h16_out = nullptr; // h16: where the pass leaves the queries' fp16 images for the list scan that follows
 };
 
 static uint32_t table_fallback_rpb(size_t n) { return (uint32_t)round_up(std::max<size_t>(256, ceil_div(n, (size_t)256)), 16); }
@@ -1670,16 +1683,19 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     const size_t fb_cap = fallback_cap(nq, 1, seg_max1, t.k);
     uint64_t * partial1 = scr.take<uint64_t>(fb_cap * (size_t)seg_max1 * t.k);
     uint32_t * nfail = small + 2;
-    MSVS_HIP(hipMemsetAsync(small, 0, 9 * sizeof(uint32_t), stream));
-    MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
-    MSVS_HIP(hipMemsetAsync(qstate + nq, 0, nq * sizeof(uint32_t), stream));
     const uint32_t rpb = BG_ROWS; // work item = 1 slice (see plan_ivf)
-    // plan 0: the whole table (also what the fallback scans)
-    launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, tq, pairs, probes0, list_off, small, small + 3, stream);
-    launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
+    if (!t.h16) // (the centroid-shadow pass keeps no per-query cut / count, and its query preparation kernel does the rest)
+    {
+        MSVS_HIP(hipMemsetAsync(small, 0, 9 * sizeof(uint32_t), stream));
+        MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
+        MSVS_HIP(hipMemsetAsync(qstate + nq, 0, nq * sizeof(uint32_t), stream));
+        // plan 0: the whole table (also what the fallback scans)
+        launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, tq, pairs, probes0, list_off, small, small + 3, stream);
+    }
     float4 * qsplit = nullptr;
     if (!t.h16)
     {
+        launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
         qsplit = scr.take<float4>(nq * (size_t)ceil_div((size_t)ld / 4, (size_t)8) * 8);
         launch_split_queries(dq, (uint32_t)nq, ld / 4, qsplit, stream);
     }
@@ -1729,16 +1745,38 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     {
         // every approximate distance of the batch through the centroid shadow, then the kc best per query
         const uint32_t G = (uint32_t)ceil_div(t.n, (size_t)H_ROWS), n_pad = G * H_ROWS;
-        uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8);
+        uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + HR_CPP * 8); // + what the register-tile list scan may read past the end
         float2 * qinfo = scr.take<float2>(nq);
-        float * qn16 = scr.take<float>(nq);
+        float * qn16 = qnorm; // computed by the preparation kernel itself
         uint32_t * sample = scr.take<uint32_t>(nq * (size_t)n_pad);
         uint32_t * cpairs = scr.take<uint32_t>(nq * (size_t)G);
         uint32_t * cpoff = scr.take<uint32_t>(G + 1);
         uint32_t * cwoff = scr.take<uint32_t>(G + 1);
-        MSVS_HIP(hipMemcpyAsync(qn16, qnorm, nq * 4, hipMemcpyDeviceToDevice, stream));
+        // one launch: norms, fp16 images, the one-list plan of this pass (what its fallback scans), its fail counter, and the
+        // zeroed counters of the list scan that follows
+        H16PrepAux aux{};
+        aux.pairs = pairs;
+        aux.probes0 = probes0;
+        aux.list_off = list_off;
+        aux.pair_off = small;
+        aux.work_off = small + 3;
+        aux.nfail = nfail;
+        aux.row_end = nrows;
+        aux.rows_per_block = rpb;
+        aux.tq = tq;
+        if (t.h16_out && t.h16_out->counters)
+        {
+            aux.zero[0] = t.h16_out->counters;
+            aux.nzero[0] = t.h16_out->n_counters;
+        }
         hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq, (uint32_t)nq, ld,
-                           ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qn16);
+                           ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qn16, 1, aux);
+        if (t.h16_out)
+        {
+            t.h16_out->qh = qh;
+            t.h16_out->qinfo = qinfo;
+            t.h16_out->qnorm = qn16;
+        }
         if (options().coarse_h16 != 2)
         {
             // dedicated kernel: 2 x 2 blocks per wavefront, every word of `sample` written
@@ -1899,7 +1937,8 @@ static thread_local H16Last g_h16_last;
 /// re-rank + certificate -> canonical fallback for the queries without one (h16_scan_kernels.hpp).
 static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq, uint32_t k,
                           size_t nprobe, const IvfSearchPlan & pl, const int32_t * d_probes, const uint64_t * d_alive,
-                          size_t nbits, uint64_t * partial, int64_t * d_ids, float * d_dis, hipStream_t stream)
+                          size_t nbits, uint64_t * partial, int64_t * d_ids, float * d_dis, hipStream_t stream,
+                          const H16Queries & prepared)
 {
     const uint32_t ld = ix.ld;
     // work item = (list, tile of 32 * h_ncb probing queries); main launch: rows [list_off + 32, end), sample launch: block 0
@@ -1913,7 +1952,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.rows_per_block = 0x7fffffffu; // one segment per non-empty row range
     const bool reg_tile = pl.h_ks != 0 && !d_alive; // filtered searches keep the LDS-resident tile (the register kernel has no bit test)
     pp.T = reg_tile ? 32 * (8 / pl.h_ks) : 32 * pl.h_ncb;
-    uint32_t * counters = scr.take<uint32_t>(2 * ix.nlist + 2 + 16);
+    const bool zeroed = prepared.qh && prepared.counters && prepared.n_counters >= 2 * ix.nlist + 2 + 16;
+    uint32_t * counters = zeroed ? prepared.counters : scr.take<uint32_t>(2 * ix.nlist + 2 + 16);
     pp.cnt = counters;
     pp.fill = counters + ix.nlist;
     uint32_t * nfail = counters + 2 * ix.nlist;
@@ -1922,30 +1962,35 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.pair_off = scr.take<uint32_t>(ix.nlist + 1);
     pp.work_off = scr.take<uint32_t>(ix.nlist + 1);
     pp.pairs = scr.take<uint32_t>(nq * nprobe);
-    MSVS_HIP(hipMemsetAsync(counters, 0, (2 * ix.nlist + 2 + 16) * sizeof(uint32_t), stream));
-    launch_ivf_plan(pp, stream);
-    IvfPlanParams pa = pp; // the sample launch: block 0 of every probed list, tiles of 32 queries (small workgroups)
-    pa.list_off = ix.list_off.p;
-    pa.list_end = ix.list_mid32.p;
+    if (!zeroed)
+        MSVS_HIP(hipMemsetAsync(counters, 0, (2 * ix.nlist + 2 + 16) * sizeof(uint32_t), stream));
+    // ... and the sample launch's partition of the same pairs: block 0 of every probed list, tiles of 32 queries (small
+    // workgroups) -- one scan launch computes both
     const uint32_t sample_nqb = options().h16_sample_nqb == 2 ? 2u : 1u; // column blocks of 32 queries per sample item
-    pa.T = 32 * sample_nqb;
-    pa.work_off = scr.take<uint32_t>(ix.nlist + 1);
-    launch_ivf_plan_rescan(pa, stream);
-    float * qnorm = scr.take<float>(nq);
-    launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
-    uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + HR_CPP * 8); // + what the register kernel may read past the last image
-    float2 * qinfo = scr.take<float2>(nq);
+    pp.list_off2 = ix.list_off.p;
+    pp.list_end2 = ix.list_mid32.p;
+    pp.T2 = 32 * sample_nqb;
+    pp.work_off2 = scr.take<uint32_t>(ix.nlist + 1);
+    launch_ivf_plan(pp, stream);
+    IvfPlanParams pa = pp;
+    pa.work_off = pp.work_off2;
+    // the queries' fp16 images: the coarse pass over the centroid shadow left them behind, or they are made here
+    float * qnorm = prepared.qh ? prepared.qnorm : scr.take<float>(nq);
+    uint4 * qh = prepared.qh ? prepared.qh : scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + HR_CPP * 8); // + what the register kernel may read past the last image
+    float2 * qinfo = prepared.qh ? prepared.qinfo : scr.take<float2>(nq);
     uint32_t * sample = scr.take<uint32_t>(nq * nprobe * H_ROWS);
     uint32_t * qstate = scr.take<uint32_t>(2 * nq);
     uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
     uint64_t * bound = scr.take<uint64_t>(nq);
     uint32_t * failq = scr.take<uint32_t>(nq);
+    if (!prepared.qh)
     {
         ProfileScope prof("ivf_prep", stream);
         hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq,
-                           (uint32_t)nq, ld, ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm);
-        MSVS_HIP(hipMemsetAsync(sample, 0xFF, nq * nprobe * H_ROWS * sizeof(uint32_t), stream));
+                           (uint32_t)nq, ld, ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, H16PrepAux{});
     }
+    // (no fill of `sample`: the sample launch writes all 32 words of every pair whose list has rows, and the cut kernels
+    // take a pair whose list is empty as 32 missing rows)
     H16Params a{};
     a.H = ix.shadow.p;
     a.hoff = ix.hoff.p;
@@ -2195,6 +2240,9 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         return;
     }
     // 1. coarse quantiser: exact top-nprobe of the centroids (canonical arithmetic, so probes match the oracle)
+    H16Queries prepared{};
+    prepared.n_counters = (uint32_t)(2 * ix.nlist + 2 + 16); // the shadow list scan's counters (h16_list_scan)
+    prepared.counters = scr.take<uint32_t>(prepared.n_counters);
     int32_t * d_probes = probes_only ? probes_only : scr.take<int32_t>(nq * nprobe);
     if (given_probes)
         MSVS_HIP(hipMemcpyAsync(d_probes, given_probes, nq * nprobe * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
@@ -2210,6 +2258,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         t.n = ix.nlist;
         t.k = (uint32_t)nprobe;
         t.out_probes = d_probes;
+        t.h16_out = &prepared;
         t.prof_name = "coarse_pass";
         table_candidate_pass(ix, scr, m, dq, nq, t, stream);
     }
@@ -2250,7 +2299,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     a.nlist = (uint32_t)ix.nlist;
     if (pl.mfma() && pl.h16)
     {
-        h16_list_scan(ix, scr, m, dq, nq, k, nprobe, pl, d_probes, d_alive, nbits, partial, d_ids, d_dis, stream);
+        h16_list_scan(ix, scr, m, dq, nq, k, nprobe, pl, d_probes, d_alive, nbits, partial, d_ids, d_dis, stream, prepared);
         return;
     }
     if (pl.mfma())

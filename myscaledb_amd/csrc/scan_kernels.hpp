@@ -576,6 +576,12 @@ struct IvfPlanParams
     uint32_t * pair_off; // [nlist+1] exclusive scan of cnt
     uint32_t * work_off; // [nlist+1] exclusive scan of ceil(cnt/T) * ceil(len/rows_per_block)
     uint32_t * pairs;    // [n_pairs] pair indices grouped by list
+    // optional second work partition of the SAME pairs over another row range (the sample launch of the shadow scan: block 0
+    // of every list, tiles of T2 queries), computed by the same scan launch
+    const int64_t * list_off2 = nullptr;
+    const int64_t * list_end2 = nullptr;
+    uint32_t T2 = 0;
+    uint32_t * work_off2 = nullptr; // [nlist+1]
 };
 
 static __global__ void ivf_hist_kernel(const IvfPlanParams p)
@@ -589,54 +595,66 @@ static __global__ void ivf_hist_kernel(const IvfPlanParams p)
     }
 }
 
-/// One block of 1024 threads: the two exclusive scans over the lists.
+/// One block of 1024 threads: the exclusive scans over the lists (pairs, work items, and the second partition's work items).
 static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPlanParams p)
 {
     __shared__ uint32_t sp[2][1024];
     __shared__ uint32_t sw[2][1024];
-    __shared__ uint32_t carry[2];
+    __shared__ uint32_t sv[2][1024];
+    __shared__ uint32_t carry[3];
     const uint32_t tid = threadIdx.x;
-    if (tid < 2)
+    if (tid < 3)
         carry[tid] = 0;
     __syncthreads();
     for (uint32_t base = 0; base < p.nlist; base += 1024)
     {
         const uint32_t l = base + tid;
-        uint32_t c = 0, w = 0;
+        uint32_t c = 0, w = 0, v = 0;
         if (l < p.nlist)
         {
             c = p.cnt[l];
             uint32_t len = (uint32_t)((p.list_end ? p.list_end[l] : p.list_off[l + 1]) - p.list_off[l]);
             w = ((c + p.T - 1) / p.T) * ((len + p.rows_per_block - 1) / p.rows_per_block);
+            if (p.work_off2)
+            {
+                const uint32_t len2 = (uint32_t)((p.list_end2 ? p.list_end2[l] : p.list_off2[l + 1]) - p.list_off2[l]);
+                v = ((c + p.T2 - 1) / p.T2) * ((len2 + p.rows_per_block - 1) / p.rows_per_block);
+            }
         }
         int cur = 0;
         sp[0][tid] = c;
         sw[0][tid] = w;
+        sv[0][tid] = v;
         __syncthreads();
         for (uint32_t d = 1; d < 1024; d <<= 1)
         {
-            uint32_t vp = sp[cur][tid], vw = sw[cur][tid];
+            uint32_t vp = sp[cur][tid], vw = sw[cur][tid], vv = sv[cur][tid];
             if (tid >= d)
             {
                 vp += sp[cur][tid - d];
                 vw += sw[cur][tid - d];
+                vv += sv[cur][tid - d];
             }
             sp[cur ^ 1][tid] = vp;
             sw[cur ^ 1][tid] = vw;
+            sv[cur ^ 1][tid] = vv;
             cur ^= 1;
             __syncthreads();
         }
-        const uint32_t cp = carry[0], cw = carry[1];
+        const uint32_t cp = carry[0], cw = carry[1], cv = carry[2];
         if (l < p.nlist)
         {
             p.pair_off[l] = cp + sp[cur][tid] - c;
             p.work_off[l] = cw + sw[cur][tid] - w;
+            if (p.work_off2)
+                p.work_off2[l] = cv + sv[cur][tid] - v;
         }
         __syncthreads();
         if (tid == 1023)
         {
             carry[0] = cp + sp[cur][1023];
             carry[1] = cw + sw[cur][1023];
+            carry[2] = cv + sv[cur][1023];
         }
         __syncthreads();
     }
@@ -644,6 +662,8 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
     {
         p.pair_off[p.nlist] = carry[0];
         p.work_off[p.nlist] = carry[1];
+        if (p.work_off2)
+            p.work_off2[p.nlist] = carry[2];
     }
 }
 
