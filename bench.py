@@ -809,34 +809,50 @@ def main():
             sets.append((terms, dfs_, ps.prepare_batch(terms, dfs_, total)))
         z = np.zeros(100, np.uint64)
 
-        def hybrid(i):
+        f_s = torch.empty((bq, 10), device=dev, dtype=torch.float32)
+        f_l = torch.empty((bq, 10), device=dev, dtype=torch.int64)
+        f_n = torch.empty((bq,), device=dev, dtype=torch.int32)
+
+        def searches(i):
             terms, dfs, prep = sets[i % 4]
             cix.search_device(qs[(i % 4) * bq:(i % 4 + 1) * bq].data_ptr(), bq, 100, npb, v_i.data_ptr(), v_d.data_ptr(), stream)
             ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), stream, prepared=prep)
+
+        def hybrid(i):
+            """Both searches and the fusion on the device (msvs_hybrid_fuse_device), the 64 x 10 fused rows read back."""
+            searches(i)
+            capi.hybrid_fuse_device("rrf", v_d.data_ptr(), v_i.data_ptr(), 100, t_d.data_ptr(), t_i.data_ptr(), 100, bq, 10,
+                                    f_s.data_ptr(), f_l.data_ptr(), f_n.data_ptr(), stream, fusion_k=60)
+            return f_s.cpu().numpy(), f_l.cpu().numpy(), f_n.cpu().numpy()
+
+        def hybrid_host(i):
+            """The round-2 form: results to the host, fusion in libmsvs_host.so (msvs_host_hybrid_search_batch)."""
+            searches(i)
             torch.cuda.synchronize()
-            ta = time.perf_counter()
             vi, vd, ti, td = v_i.cpu().numpy(), v_d.cpu().numpy(), t_i.cpu().numpy(), t_d.cpu().numpy()
-            tb = time.perf_counter()
-            r = mhost.hybrid_search_batch("rrf", vd, vi, td, ti, 10, fusion_k=60)  # one C++ loop over the batch
-            if os.environ.get("C5_DEBUG"):
-                print("c5 split: d2h %.3f ms fusion %.3f ms" % ((tb - ta) * 1e3, (time.perf_counter() - tb) * 1e3), file=sys.stderr)
-            return r
+            return mhost.hybrid_search_batch("rrf", vd, vi, td, ti, 10, fusion_k=60)  # one C++ loop over the batch
         for i in range(2):
             fused = hybrid(i)
-        # the batched fusion returns what the per-query entry returns
-        terms0, dfs0, prep0 = sets[1]
+        # the device fusion returns what the host's batched fusion and its per-query entry return
+        fused_h = hybrid_host(1)
+        assert fused[2].tolist() == fused_h[2].tolist() and fused[1].tolist() == fused_h[1].astype(np.int64).tolist()
+        assert (fused[0].view(np.uint32) == fused_h[0].view(np.uint32)).all()
         vi0, vd0, ti0, td0 = v_i.cpu().numpy(), v_d.cpu().numpy(), t_i.cpu().numpy(), t_d.cpu().numpy()
         for qq in (0, 17, 63):
             nt = int((ti0[qq] >= 0).sum())
             s1, _, l1 = mhost.hybrid_search("rrf", (vd0[qq], z, vi0[qq].astype(np.uint64)),
                                             (td0[qq][:nt], z[:nt], ti0[qq][:nt].astype(np.uint64)), 10, fusion_k=60)
             assert l1.tolist() == fused[1][qq][:len(l1)].tolist() and s1.tolist() == fused[0][qq][:len(s1)].tolist()
-        per = []
+        per, per_h = [], []
         for i in range(12):
             t1 = time.perf_counter()
             hybrid(i)
             per.append(time.perf_counter() - t1)
-        dt = float(np.median(per))  # one call in ~10 takes tens of ms on the host side (scheduling of the fusion thread): median
+        for i in range(6):
+            t1 = time.perf_counter()
+            hybrid_host(i)
+            per_h.append(time.perf_counter() - t1)
+        dt = float(np.median(per))  # one call in ~10 takes tens of ms on the host side: median
 
         def bstep(i):
             terms, dfs, prep = sets[i % 4]
@@ -849,6 +865,8 @@ def main():
                             "batches of 64" % (nb, n_post),
                 "hybrid_qps": round(bq / dt, 1), "hybrid_ms_per_query": round(dt / bq * 1e3, 4),
                 "hybrid_ms_per_batch_median_mean_max": [round(dt * 1e3, 3), round(float(np.mean(per)) * 1e3, 3), round(max(per) * 1e3, 3)],
+                "fusion": "on the device (msvs_hybrid_fuse_device), 64 x 10 fused rows read back; == the host fusion bit for bit",
+                "host_fusion_ms_per_batch_median": round(float(np.median(per_h)) * 1e3, 3),
                 "bm25_batch64": {"ms_per_batch": round(dtb * 1e3, 4), "us_per_query": round(dtb / bq * 1e6, 2),
                                  "algorithmic_mb_per_batch": round(byts / 1e6, 1),
                                  "gbs": round(byts / dtb / 1e9, 1), "hbm_frac": round(byts / dtb / 1e9 / HBM_PEAK_GBS, 4),

@@ -321,6 +321,19 @@ MSVS_API int msvs_merge_topk_device_strided(const int64_t * d_ids, size_t ids_pa
                                             size_t dis_part_stride, size_t nparts, size_t nq, size_t k, int metric,
                                             int64_t * d_out_ids, float * d_out_dis, void * hip_stream);
 
+/* Fusion step of a hybrid search for a batch, on the device: RankFusion / RelativeScoreFusion / computeNormalizedScore
+ * (src/VectorIndex/Utils/HybridSearchUtils.cpp:164-300) as MergeTreeHybridSearchManager::hybridSearch applies them to ONE
+ * part's vector and text results.  Inputs are the device searches' output arrays: query q's vector rows d_vec_dis /
+ * d_vec_ids[q * kv ...] (best first; the first id < 0 ends the list), its text rows d_txt_scores / d_txt_ids[q * kt ...];
+ * kv, kt <= 256.  fusion_type: 0 = RRF (score = sum of 1 / (fusion_k + rank), fusion_k 0 = 60), 1 = RSF (fusion_weight *
+ * normalised text score + (1 - fusion_weight) * normalised vector score, vector_scan_direction -1: larger is better).
+ * Outputs [nq][topk]: fused scores descending, ties by ascending label; label -1 / score 0 past d_n_out[q] rows.  Same
+ * arithmetic, same order, same bits as msvs_host_hybrid_search_batch (include/msvs_host.h).  Stream-ordered, no host sync. */
+MSVS_API int msvs_hybrid_fuse_device(int fusion_type, const float * d_vec_dis, const int64_t * d_vec_ids, size_t kv,
+                                     const float * d_txt_scores, const int64_t * d_txt_ids, size_t kt, size_t nq,
+                                     uint64_t fusion_k, float fusion_weight, int vector_scan_direction, size_t topk,
+                                     float * d_out_scores, int64_t * d_out_labels, uint32_t * d_n_out, void * hip_stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Seam B -- BM25 posting-list scorer.  Replaces the scoring inside
  *   TANTIVY::ffi_bm25_search(index_path, sentence, column_names, topk, alive_bitmap, use_filter, enable_nlq,

@@ -37,6 +37,7 @@ SYMBOLS = [
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
     "msvs_index_set_merged_maps", "msvs_comm_unique_id", "msvs_comm_init", "msvs_comm_init_custom",
     "msvs_comm_free", "msvs_comm_all_reduce_u64", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device",
+    "msvs_hybrid_fuse_device",
 ]
 
 
@@ -654,6 +655,17 @@ def release_scratch():
     f = C.c_size_t(0)
     _check(lib().msvs_release_scratch(C.byref(f)))
     return f.value
+
+
+def hybrid_fuse_device(fusion, d_vec_dis, d_vec_ids, kv, d_txt_scores, d_txt_ids, kt, nq, topk, d_out_scores, d_out_labels, d_n_out,
+                       stream=0, fusion_k=60, fusion_weight=0.5, vector_scan_direction=1):
+    """msvs_hybrid_fuse_device: RRF ("rrf") / RSF ("rsf") fusion of a batch's vector and text result lists, all device
+    pointers (ints), stream-ordered.  Outputs [nq][topk] f32 scores, i64 labels (-1 past n_out[q]), u32 n_out."""
+    _check(lib().msvs_hybrid_fuse_device(C.c_int(1 if fusion == "rsf" else 0), C.c_void_p(d_vec_dis), C.c_void_p(d_vec_ids),
+                                         C.c_size_t(kv), C.c_void_p(d_txt_scores), C.c_void_p(d_txt_ids), C.c_size_t(kt),
+                                         C.c_size_t(nq), C.c_uint64(fusion_k), C.c_float(fusion_weight), C.c_int(vector_scan_direction),
+                                         C.c_size_t(topk), C.c_void_p(d_out_scores), C.c_void_p(d_out_labels), C.c_void_p(d_n_out),
+                                         C.c_void_p(stream)))
 
 
 def bm25_stats():

@@ -1329,6 +1329,55 @@ def test_bm25_posting_scorer_windows_duplicates_and_density_routing(sub_docs, op
     assert q1 - q0 == 4 * len(queries) and f1 - f0 <= 8  # the sample/emit path, a rare exact fallback
 
 
+@pytest.mark.parametrize("fusion", ["rrf", "rsf"])
+def test_device_fusion_of_a_hybrid_batch_equals_the_host_fusion(fusion):
+    """msvs_hybrid_fuse_device == msvs_host_hybrid_search_batch (the flat-array form of hybridSearch + RankFusion /
+    RelativeScoreFusion, itself held against the map-based mirror in test_host_mirror.py): labels, order and score BITS, for
+    lists that overlap a little, a lot, not at all, short lists (ids -1), equal scores (RSF: all-equal lists normalise to 1)."""
+    import torch
+
+    rng = np.random.default_rng(77 if fusion == "rrf" else 78)
+    nq, kv, kt, topk = 37, 100, 100, 10
+    vi = np.full((nq, kv), -1, np.int64)
+    ti = np.full((nq, kt), -1, np.int64)
+    vd = np.zeros((nq, kv), np.float32)
+    td = np.zeros((nq, kt), np.float32)
+    for q in range(nq):
+        nv = int(rng.integers(0, kv + 1)) if q % 5 else kv
+        nt = int(rng.integers(0, kt + 1)) if q % 7 else kt
+        pool = rng.choice(5000, 260, replace=False)
+        share = [0.0, 0.1, 0.9, 1.0][q % 4]
+        v = pool[:nv]
+        t_take = np.where(rng.random(nt) < share, 1, 0)
+        t = np.array([pool[j] if (t_take[j] and j < nv) else pool[130 + j] for j in range(nt)], np.int64)
+        vi[q, :nv], ti[q, :nt] = v, t
+        vd[q, :nv] = np.sort(rng.random(nv).astype(np.float32))            # distances ascending
+        td[q, :nt] = -np.sort(-rng.random(nt).astype(np.float32) * 20)      # scores descending
+        if q % 6 == 1 and nt:
+            td[q, :nt] = np.float32(3.25)                                   # all equal
+        if q % 6 == 2 and nv > 3:
+            vd[q, 1:4] = vd[q, 1]                                           # ties inside a list
+    for direction, weight, fk in ((1, 0.5, 60), (-1, 0.3, 7)):
+        exp = mhost.hybrid_search_batch(fusion, vd, vi, td, ti, topk, fusion_k=fk, fusion_weight=weight, vector_scan_direction=direction)
+        g = lambda a: torch.from_numpy(a).cuda()
+        dvd, dvi, dtd, dti = g(vd), g(vi), g(td), g(ti)
+        os_ = torch.empty((nq, topk), device="cuda", dtype=torch.float32)
+        ol = torch.empty((nq, topk), device="cuda", dtype=torch.int64)
+        on = torch.empty((nq,), device="cuda", dtype=torch.int32)
+        capi.hybrid_fuse_device(fusion, dvd.data_ptr(), dvi.data_ptr(), kv, dtd.data_ptr(), dti.data_ptr(), kt, nq, topk,
+                                os_.data_ptr(), ol.data_ptr(), on.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                                fusion_k=fk, fusion_weight=weight, vector_scan_direction=direction)
+        torch.cuda.synchronize()
+        hs, hl, hn = os_.cpu().numpy(), ol.cpu().numpy(), on.cpu().numpy()
+        es, el, ec = exp
+        for q in range(nq):
+            n = int(ec[q])
+            assert int(hn[q]) == n, q
+            assert hl[q, :n].tolist() == [int(x) for x in el[q, :n]], q
+            assert (hs[q, :n].view(np.uint32) == es[q, :n].view(np.uint32)).all(), q
+            assert (hl[q, n:] == -1).all()
+
+
 def build_store(docs, columns=("doc",)):
     """docs: list of {column: text | [texts]}; row id = position."""
     st = mhost.TextIndexStore(list(columns))
