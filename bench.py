@@ -813,10 +813,14 @@ def main():
         f_l = torch.empty((bq, 10), device=dev, dtype=torch.int64)
         f_n = torch.empty((bq,), device=dev, dtype=torch.int32)
 
+        side = torch.cuda.Stream(device=dev)  # the BM25 scorer (small, issue-bound kernels) runs beside the HBM-bound list scan
+
         def searches(i):
             terms, dfs, prep = sets[i % 4]
+            side.wait_stream(torch.cuda.current_stream())
+            ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), side.cuda_stream, prepared=prep)
             cix.search_device(qs[(i % 4) * bq:(i % 4 + 1) * bq].data_ptr(), bq, 100, npb, v_i.data_ptr(), v_d.data_ptr(), stream)
-            ps.bm25_search_batch_device(terms, dfs, nb, total, 100, t_i.data_ptr(), t_d.data_ptr(), stream, prepared=prep)
+            torch.cuda.current_stream().wait_stream(side)
 
         def hybrid(i):
             """Both searches and the fusion on the device (msvs_hybrid_fuse_device), the 64 x 10 fused rows read back."""
@@ -865,7 +869,7 @@ def main():
                             "batches of 64" % (nb, n_post),
                 "hybrid_qps": round(bq / dt, 1), "hybrid_ms_per_query": round(dt / bq * 1e3, 4),
                 "hybrid_ms_per_batch_median_mean_max": [round(dt * 1e3, 3), round(float(np.mean(per)) * 1e3, 3), round(max(per) * 1e3, 3)],
-                "fusion": "on the device (msvs_hybrid_fuse_device), 64 x 10 fused rows read back; == the host fusion bit for bit",
+                "fusion": "on the device (msvs_hybrid_fuse_device), 64 x 10 fused rows read back; == the host fusion bit for bit; the BM25 scorer runs on a second stream beside the vector search",
                 "host_fusion_ms_per_batch_median": round(float(np.median(per_h)) * 1e3, 3),
                 "bm25_batch64": {"ms_per_batch": round(dtb * 1e3, 4), "us_per_query": round(dtb / bq * 1e6, 2),
                                  "algorithmic_mb_per_batch": round(byts / 1e6, 1),
