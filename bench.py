@@ -602,7 +602,6 @@ def main():
         fl = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
         fl.add(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
         fl.build()
-        del xi
         qh = qi[:1000].cpu().numpy()
         gt, _ = fl.search(qh, k)
         res = {"data": data, "batch": B, "build_s": round(build_s, 1), "lists": iix.list_stats(), "recall_at_%d" % k: {}}
@@ -633,18 +632,48 @@ def main():
                     "candidate_pass_queries": p1[0] - p0[0], "fallback_queries": p1[1] - p0[1],
                     "step_kernels_ms": {f: round(v, 4) for f, v in fo.items() if v}}
         if op is not None:
+            del xi
             res["at_recall_0.95"] = run_at(op)
         else:
+            # ... or, twice as fast, through the list scan's fp16 shadow: an IVFFLAT index of 256 lists with ALL of them probed
+            # is an exhaustive scan too (every row is in some list; results exact as always), and its candidate pass reads
+            # 2 bytes per element where the FLAT table pass reads 4
+            eix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, ivf_params(256, n))
+            eix.train(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+            eix.add(xi.data_ptr(), n=n, mem=capi.MEM_DEVICE)
+            eix.build()
+            del xi
+            got, _ = eix.search(qh, k, "nprobe=256")
+            r_e = recall_at_k(got, gt, k)
+
+            def estep(i):
+                eix.search_device(qi[(i % 2) * B:(i % 2 + 1) * B].data_ptr(), B, k, 256, out_ids.data_ptr(), out_dis.data_ptr(), stream)
+            p0 = capi.prefilter_stats()
+            dte = timed(estep, 5, warmup=2)
+            p1 = capi.prefilter_stats()
+            fe = profiled(estep, 2, STEP_FAMILIES)
+            tiles = -(-B // 96)
+            sce = fe["ivf_scan"] + fe["ivf_sample_scan"]
+            res["exhaustive_ivf256"] = {"method": "IVFFLAT nlist 256, nprobe 256: every list probed by every query (fp16-shadow candidate pass, canonical re-rank, certificate)",
+                                        "recall": round(r_e, 4), "qps": round(B / dte, 1), "ms_per_step": round(dte * 1e3, 4),
+                                        "list_scan_ms": round(sce, 4), "shadow_passes_per_step": tiles,
+                                        "l2_to_cu_frac": round(tiles * n * (2 * d + 8) / (sce * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sce else None,
+                                        "roofline_frac": round(n * (2 * d + 8) / (sce * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sce else None,
+                                        "candidate_pass_queries": p1[0] - p0[0], "fallback_queries": p1[1] - p0[1],
+                                        "step_kernels_ms": {f: round(v, 4) for f, v in fe.items() if v}, "lists": eix.list_stats()}
+            eix.close()
             # no structure for an IVF index to use (recall ~ 1.5 x the fraction of the rows scanned): the operating point is the
             # exhaustive scan of the same rows, batched through the FLAT index's candidate pass (recall 1.0 by construction)
             def fstep(i):
                 fl.search_device(qi[(i % 2) * B:(i % 2 + 1) * B].data_ptr(), B, k, 0, out_ids.data_ptr(), out_dis.data_ptr(), stream)
             dtf = timed(fstep, 5, warmup=2)
             passes = -(-B // 128)
-            res["at_recall_0.95"] = {"method": "exhaustive FLAT scan (IVFFLAT stays below recall 0.95 up to nprobe 256 of %d)" % nlist,
-                                     "recall": 1.0, "qps": round(B / dtf, 1), "ms_per_step": round(dtf * 1e3, 4),
-                                     "f32_table_passes_per_step": passes,
-                                     "whole_step_frac": round(passes * n * d * 4 / dtf / 1e9 / HBM_PEAK_GBS, 4)}
+            res["exhaustive_flat"] = {"method": "exhaustive FLAT scan (IVFFLAT nlist %d stays below recall 0.95 up to nprobe 256)" % nlist,
+                                      "recall": 1.0, "qps": round(B / dtf, 1), "ms_per_step": round(dtf * 1e3, 4),
+                                      "f32_table_passes_per_step": passes,
+                                      "whole_step_frac": round(passes * n * d * 4 / dtf / 1e9 / HBM_PEAK_GBS, 4)}
+            best = "exhaustive_ivf256" if res["exhaustive_ivf256"]["recall"] >= 0.95 and res["exhaustive_ivf256"]["qps"] > res["exhaustive_flat"]["qps"] else "exhaustive_flat"
+            res["at_recall_0.95"] = dict(res[best], chosen=best)
         if op != nprobe:
             res["at_config_nprobe"] = run_at(nprobe)
         fl.close()
