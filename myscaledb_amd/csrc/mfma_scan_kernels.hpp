@@ -957,6 +957,8 @@ struct RerankParams
     unsigned long long * stat_fail; // nullable: process-wide running total
     unsigned long long * stat_skip; // nullable (experiments): [0] += candidates beyond e_k +- eps, [1] += candidates
     int early_exit; // rounds after the first ceil(k / 16) skip candidates whose approximate value is beyond e_k +- eps
+    uint64_t * ek_out; // nullable [nq]: a query WITHOUT a certificate leaves the k-th exact key of the candidates it evaluated here
+                       // (KEY_NONE: fewer than k) -- an upper bound of its true k-th distance for the second chance
 };
 
 /// |approximate value - canonical value| <= eps for every row of the table and this query (sx, sq: upper bounds of |x|, |q|).
@@ -1122,6 +1124,8 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
     if (!ok && lane == 0)
     {
         a.failq[atomicAdd(a.nfail, 1u)] = q;
+        if (a.ek_out)
+            a.ek_out[q] = s_ek;
         if (a.stat_fail)
             atomicAdd(a.stat_fail, 1ull);
     }
@@ -1134,6 +1138,9 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
 /// (1024 blobs, sigma 0.3, in R^768: the 10th and the 32nd neighbour are 3 eps apart) a sixth of the queries fail it, and the
 /// canonical scan of all their probed lists costs 20 x the step.  Here the margin is cut - e_k (rank ~250 against rank k);
 /// only a query that fails this one too, or whose buffer overflowed, goes to the canonical scan (failq_out).
+/// Not every row of the buffer is evaluated: the first stage found k rows, so their k-th exact distance E0 (ek_in) bounds the
+/// true k-th from above, and a row whose approximate value lies beyond E0 by more than eps has an exact distance > E0 -- it
+/// cannot enter the result and its 3 KB are not read (on the sigma-0.3 blobs at nprobe 2 most of the ~250 rows of a buffer).
 /// One block of 256 threads per failed query (grid-stride over *nfail_in), 16 lanes per candidate row as in ivf_rerank_kernel.
 /// dynamic LDS: ld4 * 16 + (2 * RA_KMAX + RA_CHUNK) * 8 bytes.
 constexpr uint32_t RA_KMAX = 128, RA_CHUNK = 256;
@@ -1148,6 +1155,7 @@ struct RerankAllParams
     uint32_t * failq_out;
     uint32_t * nfail_out; // zeroed by the caller
     unsigned long long * stat_fail;
+    const uint64_t * ek_in; // nullable [nq]: RerankParams::ek_out of the first stage
 };
 
 template <int METRIC>
@@ -1169,6 +1177,16 @@ __global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams 
         __syncthreads();        // the previous query is done with the LDS arrays
         if (ok)
         {
+            // rows that cannot beat the first stage's k-th exact distance are skipped
+            const uint64_t hint = b.ek_in ? b.ek_in[q] : KEY_NONE;
+            const float qn0 = a.qnorm[q];
+            const bool have_hint = hint != KEY_NONE && qn0 < 1e30f && a.xmax < 1e30f;
+            double e0 = 0.0, eps0 = 0.0;
+            if (have_hint)
+            {
+                e0 = (double)key_value<METRIC>(hint);
+                eps0 = rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn0 * 1.001));
+            }
             for (uint32_t c = tid; c < ld4; c += 256)
                 qs[c] = a.Q[(size_t)q * ld4 + c];
             for (uint32_t c = tid; c < RA_KMAX; c += 256)
@@ -1179,9 +1197,20 @@ __global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams 
                 for (uint32_t c = grp; c < RA_CHUNK; c += 16)
                 {
                     uint64_t key = KEY_NONE;
-                    if (base + c < cnt) // uniform over the 16 lanes of the group
+                    bool take = base + c < cnt; // uniform over the 16 lanes of the group
+                    uint64_t pk = 0;
+                    if (take)
                     {
-                        const uint32_t pos = (uint32_t)b.partial[(size_t)q * b.cap + base + c];
+                        pk = b.partial[(size_t)q * b.cap + base + c];
+                        if (have_hint)
+                        {
+                            const double aj = (double)key_value<METRIC>(pk & 0xFFFFFFFF00000000ull);
+                            take = METRIC == M_L2 ? !(aj - eps0 > e0) : !(aj + eps0 < e0);
+                        }
+                    }
+                    if (take)
+                    {
+                        const uint32_t pos = (uint32_t)pk;
                         const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
                         const float4 * qrow = qs + g;
                         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);

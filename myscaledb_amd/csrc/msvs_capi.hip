@@ -1489,7 +1489,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 8192 : 0);
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
-            + nq * (size_t)p.kc * 8 + nq * 24 + 8192
+            + nq * (size_t)p.kc * 8 + nq * 32 + 8192
             + fallback_cap(nq, nprobe, p.seg_max1, k) * nprobe * (size_t)p.seg_max1 * k * 8
             + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8 + 4) + HR_CPP * 128 + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
     else
@@ -2090,6 +2090,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     rp.nfail = nfail;
     rp.early_exit = options().rerank_early != 0 ? 1 : 0;
     const bool second = options().rerank_second != 0 && k <= RA_KMAX;
+    uint64_t * ek_hint = second && options().rerank_hint != 0 ? scr.take<uint64_t>(nq) : nullptr; // written for failing queries only
+    rp.ek_out = ek_hint;
     rp.stat_fail = second ? nullptr : prefilter_fail_counter(); // the statistic counts queries that reach the canonical scan
     rp.stat_skip = options().rerank_stats != 0 ? prefilter_fail_counter() + 2 : nullptr;
     launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
@@ -2111,6 +2113,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         ra.failq_out = failq2;
         ra.nfail_out = nfail2;
         ra.stat_fail = prefilter_fail_counter();
+        ra.ek_in = ek_hint;
         launch_ivf_rerank_all(scan_metric(m), rp, ra, (uint32_t)nq, stream);
     }
     // queries without a certificate: canonical scan, one query per block (normally zero of them)

@@ -562,6 +562,17 @@ def test_second_chance_rerank_of_the_whole_candidate_buffer(opt):
     assert q2 - q1 == nq
     assert first_stage_failures >= nq // 50, "the data no longer provokes first-stage failures: the test tests nothing"
     assert f2 - f1 <= first_stage_failures // 5
+    # ... the same without the first stage's k-th distance as a skip bound (every row of the buffer evaluated), and for inner product
+    opt("rerank_hint", "0")
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    q3, f3 = capi.prefilter_stats()
+    assert f3 - f2 == f2 - f1  # the bound only saves row reads: the same queries get their certificate
+    opt("rerank_hint", None)
+    ixp = build_ivf(x, capi.METRIC_IP, blobs)
+    opi, opd, _ = oracle_on_exported(ixp, q[:200], nprobe, k, capi.METRIC_IP)
+    ids, dis = ixp.search(q[:200], k, "nprobe=%d" % nprobe)
+    same(ids, dis, opi, opd)
     # overflowing buffers cannot be certified by the second chance either: canonical scan, same answer
     opt("cand_cap", "64")
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
