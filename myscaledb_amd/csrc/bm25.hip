@@ -274,16 +274,43 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
             n_items_e += ceil_div((size_t)n_blocks, (size_t)spi_of(q));
     // the sample (every 16th chunk) walks a FINER partition in the wave scorer: with the emit pass's chunks (38 sub-ranges at
     // 64 queries over 10M documents) it was 576 items of 112 us each on 2048 resident wavefronts = one item's duration
-    const uint32_t spi_s = wave && options().bm25_fine_sample != 0 ? std::max<uint32_t>(1, spi / 8) : spi;
+    // (posting scorer: no finer than one item per resident wavefront -- a sample item costs ~30 us whatever it holds, and 5248
+    // items on 4096 wavefront slots were two rounds of them)
+    const uint32_t spi_s = wave && options().bm25_fine_sample != 0
+        ? std::max<uint32_t>(std::max<uint32_t>(1, spi / 8),
+                             posting ? (uint32_t)ceil_div((size_t)n_blocks * nq, (size_t)BM25_SAMPLE_STEP * cus * 16) : 1u)
+        : spi;
     const uint32_t n_chunks_s = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi_s) : n_blocks;
-    const uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks_s, (size_t)BM25_SAMPLE_STEP);
+    uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks_s, (size_t)BM25_SAMPLE_STEP);
+    // posting scorer: the sample's items hold equal postings too (every 16th chunk of a PER-QUERY chunking: one window each,
+    // one item per resident wavefront at most) -- with the same chunks for every query the launch lasted as long as the densest
+    // query's items, 50 us
+    const double per_item_s = std::max(384.0, (double)all_postings / BM25_SAMPLE_STEP / (cus * 16.0));
+    auto spi_s_of = [&](size_t q) -> uint32_t {
+        if (q_postings[q] == 0)
+            return n_blocks;
+        return (uint32_t)std::min<double>(n_blocks, std::max(1.0, std::floor(per_item_s * n_blocks / (double)q_postings[q])));
+    };
+    size_t n_items_s = 0;
+    if (posting && emit)
+    {
+        uint32_t lists_s = 1;
+        for (size_t q = 0; q < nq; q++)
+        {
+            const size_t ns = ceil_div(ceil_div((size_t)n_blocks, (size_t)spi_s_of(q)), (size_t)BM25_SAMPLE_STEP);
+            n_items_s += ns;
+            lists_s = std::max<uint32_t>(lists_s, (uint32_t)ns);
+        }
+        n_sb = lists_s; // lists per query in the sample buffer (unused ones stay KEY_NONE)
+    }
     // m-th best of the sample as the cut: about STEP * m documents pass, 4 sigma (STEP * sqrt(m)) above k
     const double rs = 2.0 + std::sqrt(4.0 + (double)k / BM25_SAMPLE_STEP);
     const uint32_t cut_m = (uint32_t)std::min<double>(64.0, std::ceil(rs * rs));
-    // one host blob -> one copy: [qoff u32][qterms u32][weight f32][cache f32][full u16][group u8][field u8][emit items 3 x u32]
+    // one host blob -> one copy: [qoff u32][qterms u32][weight f32][cache f32][full u16][group u8][field u8][emit items 4 x u32][sample items 4 x u32]
     const size_t o_qoff = 0, o_terms = o_qoff + (nq + 1) * 4, o_w = o_terms + nf1 * 4, o_cache = o_w + nf1 * 4,
                  o_full = o_cache + nc * 4, o_group = o_full + round_up(nq * 2, (size_t)4), o_field = o_group + nf1,
-                 o_items = round_up(o_field + nf1, (size_t)16), blob_bytes = round_up(o_items + n_items_e * 12, (size_t)16);
+                 o_items = round_up(o_field + nf1, (size_t)16), o_items_s = o_items + n_items_e * 16,
+                 blob_bytes = round_up(o_items_s + n_items_s * 16, (size_t)16);
     PinnedRing & ring = pinned_ring(stream);
     int slot = 0;
     unsigned char * blob = static_cast<unsigned char *>(ring.take(blob_bytes, slot));
@@ -327,11 +354,26 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
             for (size_t q = 0; q < nq; q++)
             {
                 const uint32_t sq = spi_of(q);
-                for (uint32_t b = 0; b < n_blocks; b += sq, it += 3)
+                for (uint32_t b = 0; b < n_blocks; b += sq, it += 4)
                 {
                     it[0] = (uint32_t)q;
                     it[1] = b;
                     it[2] = std::min<uint32_t>(n_blocks, b + sq);
+                    it[3] = 0;
+                }
+            }
+        it = reinterpret_cast<uint32_t *>(blob + o_items_s);
+        if (n_items_s)
+            for (size_t q = 0; q < nq; q++)
+            {
+                const uint32_t sq = spi_s_of(q);
+                uint32_t li = 0;
+                for (uint64_t b = 0; b < n_blocks; b += (uint64_t)sq * BM25_SAMPLE_STEP, it += 4, li++)
+                {
+                    it[0] = (uint32_t)q;
+                    it[1] = (uint32_t)b;
+                    it[2] = (uint32_t)std::min<uint64_t>(n_blocks, b + sq);
+                    it[3] = li;
                 }
             }
     }
@@ -370,7 +412,8 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     a.bounds = d_bounds;
     a.bounds_hi = d_bounds_hi;
     // TOPK over (a sample of) the chunks: lists of p.kk keys into p.partial, `lists` per slot
-    auto launch_topk = [&](Bm25Params p, uint32_t lists, uint32_t step, size_t slots_bound, uint32_t item_spi, uint32_t item_chunks) {
+    auto launch_topk = [&](Bm25Params p, uint32_t lists, uint32_t step, size_t slots_bound, uint32_t item_spi, uint32_t item_chunks,
+                           const uint32_t * items = nullptr, size_t n_items_tab = 0) {
         if (wave)
         {
             Bm25WParams w{};
@@ -386,7 +429,10 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
             const int r = r_for_k(p.kk);
             if (posting)
             {
-                const unsigned pgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)lists * slots_bound, (size_t)BP_WAVES), (size_t)cus * 4));
+                w.items = items;
+                w.n_items_tab = (uint32_t)n_items_tab;
+                const size_t n_it = items ? n_items_tab : (size_t)lists * slots_bound;
+                const unsigned pgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div(n_it, (size_t)BP_WAVES), (size_t)cus * 4));
                 if (r == 1)
                     hipLaunchKernelGGL((bm25p_kernel<BM25_TOPK, 1>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, w);
                 else if (r == 2)
@@ -457,7 +503,13 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     Bm25Params sp = a;
     sp.partial = sample;
     sp.kk = cut_m;
-    launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq, spi_s, n_chunks_s);
+    if (n_items_s)
+    {
+        MSVS_HIP(hipMemsetAsync(sample, 0xFF, nq * (size_t)n_sb * cut_m * 8, stream)); // a query with fewer items leaves lists unused
+        launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq, spi_s, n_chunks_s, reinterpret_cast<const uint32_t *>(d_blob + o_items_s), n_items_s);
+    }
+    else
+        launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq, spi_s, n_chunks_s);
     MergeParams m{};
     m.partial = sample;
     m.n_lists = n_sb;

@@ -463,7 +463,7 @@ struct Bm25WParams
     uint32_t cstep;        // TOPK sample: item chunk = index * cstep
     uint32_t n_items_c;    // chunks this launch walks (n_chunks, or the sample's ceil(n_chunks / cstep))
     uint32_t lists;        // TOPK: lists per slot in `partial` (= n_items_c)
-    const uint32_t * items; // bm25p_kernel EMIT: [n_items_tab][3] = query, first sub-range, end sub-range (nullptr: (chunk, query) items)
+    const uint32_t * items; // bm25p_kernel: [n_items_tab][4] = query, first sub-range, end sub-range, list index (nullptr: (chunk, query) items)
     uint32_t n_items_tab;
     uint32_t dbg;          // experiment masks of bm25p_kernel (option bm25_dbg; results are wrong with any bit set)
     uint32_t sub_docs;     // documents per sub-range (BW_DOCS for bm25w_kernel; chosen per batch for bm25p_kernel)

@@ -128,9 +128,10 @@ __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25p_kernel(const Bm25WPara
     // wavefront would see the SAME query for the whole launch, and a query of frequent terms holds six times the postings of
     // a query of rare ones (the launch lasted six times its average wavefront; handing items out through global atomics is
     // worse: device-scope atomics of 4096 wavefronts on one line serialise beyond the XCDs' L2s, ~100 us per turn).  So:
-    //   EMIT walks a host-built item table (a.items: query, first sub-range, end) whose items hold about the same number of
-    //   postings whatever the query -- long document ranges for rare terms, short ones for frequent terms;
-    //   TOPK keeps (chunk, query) items -- its lists are addressed that way -- and rotates the query with the chunk.
+    //   the EMIT and the SAMPLE launch walk a host-built item table (a.items: query, first sub-range, end, list index) whose
+    //   items hold about the same number of postings whatever the query -- long document ranges for rare terms, short ones
+    //   for frequent terms;
+    //   the other TOPK launches keep (chunk, query) items and rotate the query with the chunk.
     const uint32_t waves_total = gridDim.x * BP_WAVES;
     const uint64_t n_items = a.items ? (uint64_t)a.n_items_tab : n_items_u;
     for (uint64_t item = (uint64_t)blockIdx.x * BP_WAVES + wave; item < n_items; item += waves_total)
@@ -138,9 +139,11 @@ __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25p_kernel(const Bm25WPara
         uint32_t ci = 0, slot, s_begin, s_end;
         if (a.items)
         {
-            slot = a.items[3 * item];
-            s_begin = a.items[3 * item + 1];
-            s_end = a.items[3 * item + 2];
+            const uint4 e = reinterpret_cast<const uint4 *>(a.items)[item];
+            slot = e.x;
+            s_begin = e.y;
+            s_end = e.z;
+            ci = e.w; // TOPK: which of the query's lists the item fills
         }
         else
         {
@@ -379,9 +382,37 @@ __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25p_kernel(const Bm25WPara
             {
                 if (r >= nr)
                     break;
-                const bool ok = !(a.dbg & 4) && r * 64 + lane < tot && !((flags >> r) & 1u) && (p.operator_or || (tfb[t_r[r]] >> 8) == full)
+                bool ok = !(a.dbg & 4) && r * 64 + lane < tot && !((flags >> r) & 1u) && (p.operator_or || (tfb[t_r[r]] >> 8) == full)
                     && (MODE != BM25_EMIT || s_r[r] >= cut);
+                if (MODE == BM25_TOPK && ok && p.alive) // (EMIT tests the few records that pass the cut below)
+                    ok = doc_r[r] < p.nbits && ((p.alive[doc_r[r] >> 6] >> (doc_r[r] & 63)) & 1);
                 passbits |= (ok ? 1u : 0u) << r;
+            }
+            // TOPK, the item's list not full yet: offering a window's ~400 records one by one costs ~100 list insertions.  The
+            // kk-th largest of the 64 lanes' BEST scores is a floor -- kk records at or above it exist -- and what lies below
+            // it cannot be among the window's kk best: ~30 insertions instead
+            if (MODE == BM25_TOPK && top.thr == KEY_NONE)
+            {
+                float best = -1.f; // scores are >= 0
+#pragma unroll
+                for (uint32_t r = 0; r < BP_RMAX; r++)
+                    if (r < nr && ((passbits >> r) & 1u))
+                        best = fmaxf(best, s_r[r]);
+                if ((uint32_t)__popcll(__ballot(best >= 0.f)) >= p.kk)
+                {
+                    uint32_t rank = 0;
+                    for (int j = 0; j < 64; j++)
+                    {
+                        const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), j));
+                        rank += (sj > best || (sj == best && (uint32_t)j < lane)) ? 1u : 0u;
+                    }
+                    const uint64_t at = __ballot(rank == p.kk - 1);
+                    const float floor_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), __builtin_ctzll(at)));
+#pragma unroll
+                    for (uint32_t r = 0; r < BP_RMAX; r++)
+                        if (r < nr && s_r[r] < floor_s)
+                            passbits &= ~(1u << r);
+                }
             }
             if (MODE == BM25_TOPK || __ballot(passbits != 0))
             {
@@ -394,7 +425,7 @@ __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25p_kernel(const Bm25WPara
                     if (MODE == BM25_EMIT && !__ballot(ok))
                         continue;
                     const uint32_t docid = doc_r[r];
-                    if (ok && p.alive)
+                    if (MODE == BM25_EMIT && ok && p.alive)
                         ok = docid < p.nbits && ((p.alive[docid >> 6] >> (docid & 63)) & 1);
                     out_one(ok, make_key<M_IP>(s_r[r], docid));
                 }
