@@ -286,10 +286,13 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     // one item per resident wavefront at most) -- with the same chunks for every query the launch lasted as long as the densest
     // query's items, 50 us
     const double per_item_s = std::max(384.0, (double)all_postings / BM25_SAMPLE_STEP / (cus * 16.0));
+    // ... at least 64 chunks per query whatever its terms: the sample must stay 1 / 16 of the documents (a rare term whose one
+    // chunk is the whole corpus would make the cut the m-th best of ALL documents: m < k pass, the query takes the fallback)
+    const uint32_t spi_s_cap = std::max<uint32_t>(1, n_blocks / 64);
     auto spi_s_of = [&](size_t q) -> uint32_t {
         if (q_postings[q] == 0)
-            return n_blocks;
-        return (uint32_t)std::min<double>(n_blocks, std::max(1.0, std::floor(per_item_s * n_blocks / (double)q_postings[q])));
+            return spi_s_cap;
+        return (uint32_t)std::min<double>(spi_s_cap, std::max(1.0, std::floor(per_item_s * n_blocks / (double)q_postings[q])));
     };
     size_t n_items_s = 0;
     if (posting && emit)
@@ -476,9 +479,16 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         MSVS_HIP(hipGetLastError());
     };
     ProfileScope prof("bm25_score", stream);
+    // the buffers of the sample / emit path, taken here so that the bounds launch can fill them on its way
+    uint64_t * sample = emit ? scr.take<uint64_t>(nq * (size_t)n_sb * cut_m) : nullptr;
+    uint64_t * cut_keys = emit ? scr.take<uint64_t>(nq * (size_t)cut_m) : nullptr;
+    uint64_t * cand = emit ? scr.take<uint64_t>(nq * (size_t)BM25_CAND_CAP) : nullptr;
+    uint32_t * counters = emit ? scr.take<uint32_t>(2 * nq + 4) : nullptr; // ccnt[nq] | nfail | failq[nq]
+    const bool fills_ride = emit && n_flat != 0;
     if (n_flat)
         hipLaunchKernelGGL(bm25_bounds_kernel, dim3((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256)), dim3(256), 0,
-                           stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block);
+                           stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block, counters, fills_ride ? nq + 1 : (size_t)0,
+                           sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0);
     if (!emit)
     {
         a.partial = partial;
@@ -493,11 +503,8 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         launch_merge(M_IP, m, (uint32_t)nq, stream);
         return;
     }
-    uint64_t * sample = scr.take<uint64_t>(nq * (size_t)n_sb * cut_m);
-    uint64_t * cut_keys = scr.take<uint64_t>(nq * (size_t)cut_m);
-    uint64_t * cand = scr.take<uint64_t>(nq * (size_t)BM25_CAND_CAP);
-    uint32_t * counters = scr.take<uint32_t>(2 * nq + 4); // ccnt[nq] | nfail | failq[nq]
-    MSVS_HIP(hipMemsetAsync(counters, 0, (nq + 1) * 4, stream));
+    if (!fills_ride)
+        MSVS_HIP(hipMemsetAsync(counters, 0, (nq + 1) * 4, stream));
     uint32_t * ccnt = counters, * nfail = counters + nq, * failq = counters + nq + 1;
     // 1. the sample: every 16th chunk, short lists
     Bm25Params sp = a;
@@ -505,7 +512,8 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     sp.kk = cut_m;
     if (n_items_s)
     {
-        MSVS_HIP(hipMemsetAsync(sample, 0xFF, nq * (size_t)n_sb * cut_m * 8, stream)); // a query with fewer items leaves lists unused
+        if (!fills_ride)
+            MSVS_HIP(hipMemsetAsync(sample, 0xFF, nq * (size_t)n_sb * cut_m * 8, stream)); // a query with fewer items leaves lists unused
         launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq, spi_s, n_chunks_s, reinterpret_cast<const uint32_t *>(d_blob + o_items_s), n_items_s);
     }
     else

@@ -83,10 +83,19 @@ struct Bm25Params
     uint32_t * ccnt;             // [nq], zeroed by the caller
 };
 
+/// The fills of the batch ride along (nullable): `zero` = the candidate counters + fail counter, `ones` = the sample's
+/// per-query lists (KEY_NONE = all bits set) -- two launches less in front of the sample pass.
 static __global__ void bm25_bounds_kernel(const Bm25Params a, int64_t * bounds, int64_t * bounds_hi, uint32_t n_flat,
-                                          uint32_t docs_per_block)
+                                          uint32_t docs_per_block, uint32_t * zero, size_t n_zero, uint64_t * ones, size_t n_ones)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        const size_t gsz = (size_t)gridDim.x * blockDim.x;
+        for (size_t j = i; j < n_zero; j += gsz)
+            zero[j] = 0;
+        for (size_t j = i; j < n_ones; j += gsz)
+            ones[j] = KEY_NONE;
+    }
     const uint32_t nb1 = a.n_blocks + 1;
     if (i >= (size_t)n_flat * nb1)
         return;
