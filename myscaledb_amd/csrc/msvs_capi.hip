@@ -2,6 +2,12 @@
 // top-k merge.  Everything computes on the GPU; there is no CPU fallback.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <list>
+#include <map>
+#include <string>
+#include <vector>
 #include <cmath>
 #include <mutex>
 #include <cstdio>
@@ -10,6 +16,7 @@
 #include <random>
 
 #include "device_ops.hpp"
+#include "index_internal.hpp"
 #include "ivf_build_kernels.hpp"
 #include "h16_scan_kernels.hpp"
 #include "h16r_scan_kernels.hpp"
@@ -21,12 +28,10 @@ namespace msvs
 {
 const char * last_error_cstr();
 
-static inline int scan_metric(int metric) { return metric == MSVS_METRIC_L2 ? M_L2 : M_IP; }
 
-static inline hipStream_t as_stream(void * s) { return reinterpret_cast<hipStream_t>(s); }
 
 /// Copy n rows of d floats (host or device) into a device buffer with row stride ld (zero padded).
-static void upload_rows(float * dst, const float * src, size_t n, uint32_t d, uint32_t ld, int mem, hipStream_t stream)
+void upload_rows(float * dst, const float * src, size_t n, uint32_t d, uint32_t ld, int mem, hipStream_t stream)
 {
     if (n == 0)
         return;
@@ -36,45 +41,21 @@ static void upload_rows(float * dst, const float * src, size_t n, uint32_t d, ui
                               mem == MSVS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
 }
 
-static inline uint32_t padded_dim(size_t d) { return (uint32_t)round_up(d, 4); }
 
-/// Clear the filter bits of the (non-negative) ids just returned, so the next round of a large-k search skips them.
-static __global__ void clear_bits_kernel(uint64_t * bits, const int64_t * ids, uint32_t n)
-{
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-    {
-        const int64_t id = ids[i];
-        if (id >= 0)
-            atomicAnd(reinterpret_cast<unsigned long long *>(bits + (id >> 6)), ~(1ull << (id & 63)));
-    }
-}
 
-static void check_k(size_t k)
-{
-    if (k > MSVS_MAX_K)
-        fail(MSVS_ERR_UNSUPPORTED_K, "k = %zu exceeds the device top-k limit %d", k, MSVS_MAX_K);
-}
 
 /// Exhaustive top-k of device queries (nq x ld) against device rows (n x ld) -> device ids/dis.
 /// `scr` must have been reserved by the caller for flat_scratch_bytes().
-static size_t flat_scratch_bytes(size_t n, size_t nq, uint32_t k, uint32_t ld)
+size_t flat_scratch_bytes(size_t n, size_t nq, uint32_t k, uint32_t ld)
 {
     FlatPlan p = plan_flat(n, nq, ld / 4, k);
     return flat_partial_keys(p, nq, k) * 8 + 1024;
 }
 
-/// A compacted view of an index for one search (filter_kernels.hpp): the rows a selective filter lets through.
-struct SearchView
-{
-    const int64_t * list_off; // [nlist + 1] view offsets of the lists (device)
-    const uint32_t * rowmap;  // view row -> stored row
-    const uint32_t * n_rows;  // device: rows in the view
-    size_t n_upper;           // host: an upper bound of it
-};
 
-static void flat_search_device(Scratch & scr, int metric, const float * d_rows, const uint32_t * d_row_ids, size_t n,
-                               uint32_t ld, const float * d_q, size_t nq, uint32_t k, const uint64_t * d_alive,
-                               size_t nbits, MergeParams out, hipStream_t stream, const SearchView * view = nullptr)
+void flat_search_device(Scratch & scr, int metric, const float * d_rows, const uint32_t * d_row_ids, size_t n, uint32_t ld,
+                        const float * d_q, size_t nq, uint32_t k, const uint64_t * d_alive, size_t nbits, MergeParams out,
+                        hipStream_t stream, const SearchView * view)
 {
     if (view)
         n = std::max<size_t>(1, std::min(n, view->n_upper));
@@ -131,450 +112,7 @@ extern "C" int msvs_device_synchronize(void)
     return guarded([&] { MSVS_HIP(hipDeviceSynchronize()); });
 }
 
-// =========================================================================================== seam A2
-
-namespace msvs
-{
-/// Shared body of msvs_knn_f32 / msvs_knn_f32_filtered: host buffers in, host buffers out.
-/// d_resident (nullable): the base rows already in HBM (row stride = padded_dim(d) floats, zero padded) -- a block of
-/// the resident cache (msvs_block_t); y is then ignored and nothing but the queries crosses PCIe.
-static void knn_host(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny, int metric,
-                     const uint64_t * alive_bits, int64_t * ids, float * dis, const float * d_resident = nullptr)
-{
-    if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
-        fail(MSVS_ERR_NOT_IMPLEMENTED, "Metric not implemented in brute force search for Float32 Vector");
-    if (nx == 0 || k == 0)
-        return;
-    if (!x || !ids || !dis || (ny && !y && !d_resident) || d == 0)
-        fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer or zero dimension");
-    if (k > MSVS_MAX_K_ROUNDS)
-        fail(MSVS_ERR_UNSUPPORTED_K, "k = %zu exceeds the limit %d", k, MSVS_MAX_K_ROUNDS);
-    if (ny > 0xfffffff0ull)
-        fail(MSVS_ERR_ID_RANGE, "ny exceeds the u32 id range");
-    hipStream_t stream = thread_stream();
-    const uint32_t ld = padded_dim(d);
-    const uint32_t kpass = (uint32_t)std::min<size_t>(k, MSVS_MAX_K);
-    const size_t bw = ceil_div(std::max<size_t>(ny, 1), 64);
-    const bool rounds = k > MSVS_MAX_K;
-    Scratch & scr = scratch_for(stream);
-    size_t need = (nx + (d_resident ? 0 : ny)) * (size_t)ld * 4 + nx * k * 12 + bw * 8
-        + flat_scratch_bytes(ny, rounds ? 1 : nx, kpass, ld) + 16384;
-    scr.reserve(need, stream);
-    float * dq = scr.take<float>(nx * ld);
-    const float * dy = d_resident;
-    if (!d_resident)
-    {
-        float * up = scr.take<float>(std::max<size_t>(ny, 1) * ld);
-        upload_rows(up, y, ny, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
-        dy = up;
-    }
-    int64_t * d_ids = scr.take<int64_t>(nx * k);
-    float * d_dis = scr.take<float>(nx * k);
-    uint64_t * bm = (alive_bits || rounds) ? scr.take<uint64_t>(bw) : nullptr;
-    const size_t mark = scr.used; // everything taken after this point is per-pass scratch
-    upload_rows(dq, x, nx, (uint32_t)d, ld, MSVS_MEM_HOST, stream);
-    auto load_filter = [&]() {
-        if (alive_bits)
-            MSVS_HIP(hipMemcpyAsync(bm, alive_bits, bw * 8, hipMemcpyHostToDevice, stream));
-        else if (bm)
-            MSVS_HIP(hipMemsetAsync(bm, 0xFF, bw * 8, stream));
-    };
-    MergeParams out{};
-    if (!rounds)
-    {
-        load_filter();
-        out.out_ids = d_ids;
-        out.out_dis = d_dis;
-        flat_search_device(scr, metric, dy, nullptr, ny, ld, dq, nx, (uint32_t)k, bm, ny, out, stream);
-    }
-    else
-    {
-        // rounds of MSVS_MAX_K per query, excluding what was already returned (see msvs_index_search)
-        for (size_t q = 0; q < nx; q++)
-        {
-            load_filter();
-            for (size_t done = 0; done < k; done += MSVS_MAX_K)
-            {
-                const uint32_t kr = (uint32_t)std::min<size_t>(MSVS_MAX_K, k - done);
-                scr.used = mark;
-                out.out_ids = d_ids + q * k + done;
-                out.out_dis = d_dis + q * k + done;
-                flat_search_device(scr, metric, dy, nullptr, ny, ld, dq + q * ld, 1, kr, bm, ny, out, stream);
-                hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(256), 0, stream, bm, out.out_ids, kr);
-                MSVS_HIP(hipGetLastError());
-            }
-        }
-    }
-    MSVS_HIP(hipMemcpyAsync(ids, d_ids, nx * k * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    MSVS_HIP(hipMemcpyAsync(dis, d_dis, nx * k * sizeof(float), hipMemcpyDeviceToHost, stream));
-    MSVS_HIP(hipStreamSynchronize(stream));
-}
-}
-
-extern "C" int msvs_knn_f32(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny, int metric,
-                            int64_t * ids, float * dis)
-{
-    return guarded([&] { knn_host(x, y, d, k, nx, ny, metric, nullptr, ids, dis); });
-}
-
-extern "C" int msvs_knn_f32_filtered(const float * x, const float * y, size_t d, size_t k, size_t nx, size_t ny,
-                                     int metric, const uint64_t * alive_bits, int64_t * ids, float * dis)
-{
-    return guarded([&] { knn_host(x, y, d, k, nx, ny, metric, alive_bits, ids, dis); });
-}
-
-static void normalize_device_rows(float * d_x, size_t n, uint32_t d, uint32_t ld, hipStream_t stream)
-{
-    if (n == 0)
-        return;
-    if ((size_t)d * 4 > 60 * 1024) // the row is staged in LDS
-        fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large to normalise on the device", d);
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3(normalize_rows_grid(n)), dim3(WAVE), (size_t)d * 4, stream, d_x, n, d, ld);
-    MSVS_HIP(hipGetLastError());
-}
-
-extern "C" int msvs_normalize_f32(float * x, size_t n, size_t d)
-{
-    return guarded([&] {
-        if (n == 0)
-            return;
-        if (!x || d == 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer or zero dimension");
-        hipStream_t stream = nullptr;
-        Scratch & scr = scratch_for(stream);
-        scr.reserve(n * d * 4 + 4096, stream);
-        float * dx = scr.take<float>(n * d);
-        MSVS_HIP(hipMemcpyAsync(dx, x, n * d * 4, hipMemcpyHostToDevice, stream));
-        normalize_device_rows(dx, n, (uint32_t)d, (uint32_t)d, stream);
-        MSVS_HIP(hipMemcpyAsync(x, dx, n * d * 4, hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipStreamSynchronize(stream));
-    });
-}
-
-// =========================================================================================== resident blocks (f1)
-//
-// The GPU analogue of the reference's VICacheManager / VIWithMeta for the BRUTE-FORCE path: the
-// dense block a mark of a part turns into (MergeTreeVSManager.cpp:1380-1392) is uploaded once, keyed by
-// (part key, mark), and stays in HBM in an LRU bounded by bytes; later queries against the same part send only the
-// query vectors over PCIe.  Blocks are immutable; lightweight deletes arrive per search as the row_exists bitmap, like in
-// the reference.  A part that is dropped or mutated is evicted by key prefix (CacheKey: table path / part name, VICacheObject.h:119-162).
-
-#include <list>
-#include <unordered_map>
-#include <condition_variable>
-#include <deque>
-
-struct msvs_block
-{
-    msvs_cache_t * owner = nullptr;
-    std::string key;
-    DevBuf<float> rows; // n x ld, zero padded; normalised when `normalized`
-    size_t n = 0, d = 0;
-    uint32_t ld = 0;
-    int normalized = 0;
-    int pins = 0;
-    bool doomed = false; // evicted while pinned: freed at the last release
-    std::list<msvs_block *>::iterator pos;
-    size_t bytes() const { return rows.bytes(); }
-};
-
-struct msvs_cache
-{
-    std::mutex mu;
-    size_t capacity = 0, used = 0;
-    std::list<msvs_block *> lru; // front = most recently used
-    std::unordered_map<std::string, msvs_block *> map;
-    uint64_t hits = 0, misses = 0, evictions = 0;
-    int device = 0;
-
-    static std::string full_key(const char * key, uint64_t mark) { return std::string(key ? key : "") + "#" + std::to_string(mark); }
-    void drop_locked(msvs_block * b)
-    {
-        map.erase(b->key);
-        lru.erase(b->pos);
-        used -= b->bytes();
-        evictions++;
-        if (b->pins == 0)
-            delete b;
-        else
-            b->doomed = true;
-    }
-    void make_room_locked(size_t need)
-    {
-        // least recently used first; pinned blocks stay (the bound is soft while searches hold more than the capacity)
-        std::vector<msvs_block *> victims;
-        size_t freed = 0;
-        for (auto it = lru.rbegin(); it != lru.rend() && used - freed + need > capacity; ++it)
-            if ((*it)->pins == 0)
-            {
-                victims.push_back(*it);
-                freed += (*it)->bytes();
-            }
-        for (msvs_block * b : victims)
-            drop_locked(b);
-    }
-};
-
-extern "C" int msvs_cache_create(size_t capacity_bytes, msvs_cache_t ** out)
-{
-    return guarded([&] {
-        if (!out)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "out is null");
-        std::unique_ptr<msvs_cache> c(new msvs_cache);
-        c->capacity = capacity_bytes;
-        MSVS_HIP(hipGetDevice(&c->device));
-        *out = c.release();
-    });
-}
-
-extern "C" void msvs_cache_free(msvs_cache_t * c)
-{
-    if (!c)
-        return;
-    for (msvs_block * b : c->lru)
-        delete b;
-    delete c;
-}
-
-extern "C" int msvs_block_lookup(msvs_cache_t * c, const char * key, uint64_t mark, msvs_block_t ** out)
-{
-    return guarded([&] {
-        if (!c || !out)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null cache / out");
-        *out = nullptr;
-        std::lock_guard<std::mutex> lk(c->mu);
-        auto it = c->map.find(msvs_cache::full_key(key, mark));
-        if (it == c->map.end())
-        {
-            c->misses++;
-            return;
-        }
-        msvs_block * b = it->second;
-        c->lru.splice(c->lru.begin(), c->lru, b->pos);
-        b->pins++;
-        c->hits++;
-        *out = b;
-    });
-}
-
-extern "C" int msvs_block_upload(msvs_cache_t * c, const char * key, uint64_t mark, const float * rows, size_t n, size_t d,
-                                 int normalize, msvs_block_t ** out)
-{
-    return guarded([&] {
-        if (!c || !out || (n && !rows) || d == 0 || d > 8192)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null cache / rows / out or bad dimension");
-        if (n > 0xfffffff0ull)
-            fail(MSVS_ERR_ID_RANGE, "block exceeds the u32 row range");
-        *out = nullptr;
-        const std::string fk = msvs_cache::full_key(key, mark);
-        {
-            std::lock_guard<std::mutex> lk(c->mu);
-            auto it = c->map.find(fk);
-            if (it != c->map.end()) // another thread was faster: the resident copy wins
-            {
-                msvs_block * b = it->second;
-                if (b->n != n || b->d != d || b->normalized != (normalize ? 1 : 0))
-                    fail(MSVS_ERR_INVALID_ARGUMENT, "block `%s` is resident with another shape", fk.c_str());
-                c->lru.splice(c->lru.begin(), c->lru, b->pos);
-                b->pins++;
-                *out = b;
-                return;
-            }
-        }
-        std::unique_ptr<msvs_block> b(new msvs_block);
-        b->owner = c;
-        b->key = fk;
-        b->n = n;
-        b->d = d;
-        b->ld = padded_dim(d);
-        b->normalized = normalize ? 1 : 0;
-        b->rows.alloc(std::max<size_t>(n, 1) * b->ld);
-        hipStream_t stream = nullptr;
-        upload_rows(b->rows.p, rows, n, (uint32_t)d, b->ld, MSVS_MEM_HOST, stream);
-        if (normalize && n)
-        {
-            normalize_device_rows(b->rows.p, n, (uint32_t)d, b->ld, stream);
-        }
-        MSVS_HIP(hipStreamSynchronize(stream));
-        std::lock_guard<std::mutex> lk(c->mu);
-        auto it = c->map.find(fk);
-        if (it != c->map.end())
-        {
-            msvs_block * e = it->second;
-            c->lru.splice(c->lru.begin(), c->lru, e->pos);
-            e->pins++;
-            *out = e;
-            return; // b is dropped
-        }
-        c->make_room_locked(b->bytes());
-        c->lru.push_front(b.get());
-        b->pos = c->lru.begin();
-        b->pins = 1;
-        c->used += b->bytes();
-        c->map[fk] = b.get();
-        *out = b.release();
-    });
-}
-
-extern "C" int msvs_block_info(const msvs_block_t * b, size_t * n, size_t * d, int * normalized)
-{
-    return guarded([&] {
-        if (!b)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null block");
-        if (n)
-            *n = b->n;
-        if (d)
-            *d = b->d;
-        if (normalized)
-            *normalized = b->normalized;
-    });
-}
-
-extern "C" void msvs_block_release(msvs_block_t * b)
-{
-    if (!b)
-        return;
-    msvs_cache_t * c = b->owner;
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (--b->pins == 0 && b->doomed)
-        delete b;
-}
-
-extern "C" int msvs_cache_evict(msvs_cache_t * c, const char * key_prefix, size_t * evicted)
-{
-    return guarded([&] {
-        if (!c)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null cache");
-        const std::string pre = key_prefix ? key_prefix : "";
-        size_t cnt = 0;
-        std::lock_guard<std::mutex> lk(c->mu);
-        for (auto it = c->lru.begin(); it != c->lru.end();)
-        {
-            msvs_block * b = *it;
-            ++it;
-            if (b->key.compare(0, pre.size(), pre) == 0)
-            {
-                c->drop_locked(b);
-                cnt++;
-            }
-        }
-        if (evicted)
-            *evicted = cnt;
-    });
-}
-
-extern "C" int msvs_cache_stats(msvs_cache_t * c, size_t * bytes, size_t * blocks, uint64_t * hits, uint64_t * misses,
-                                uint64_t * evictions)
-{
-    return guarded([&] {
-        if (!c)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null cache");
-        std::lock_guard<std::mutex> lk(c->mu);
-        if (bytes)
-            *bytes = c->used;
-        if (blocks)
-            *blocks = c->map.size();
-        if (hits)
-            *hits = c->hits;
-        if (misses)
-            *misses = c->misses;
-        if (evictions)
-            *evictions = c->evictions;
-    });
-}
-
-extern "C" int msvs_knn_resident(const msvs_block_t * b, const float * x, size_t k, size_t nx, int metric,
-                                 const uint64_t * alive_bits, int64_t * ids, float * dis)
-{
-    return guarded([&] {
-        if (!b)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null block");
-        knn_host(x, nullptr, b->d, k, nx, b->n, metric, alive_bits, ids, dis, b->rows.p);
-    });
-}
-
 // =========================================================================================== seam A1
-
-struct msvs_index
-{
-    int type = MSVS_INDEX_FLAT;
-    int metric = MSVS_METRIC_L2;
-    size_t dim = 0;
-    uint32_t ld = 0;
-    int device = 0;
-    // build parameters
-    size_t ncentroids = 1024;
-    int kmeans_iters = 10;
-    size_t train_empty_last = 0; // empty clusters the last k-means iteration re-seeded (diagnostics)
-    size_t train_sample = 0;
-    uint64_t seed = 1234;
-    int shard_rank = 0, shard_world = 1;
-    // coarse quantiser (IVFFLAT)
-    size_t nlist = 0;
-    DevBuf<float> centroids; // nlist x ld
-    // staging (between add and build)
-    struct Chunk
-    {
-        DevBuf<float> x; // n x ld (normalised for cosine)
-        std::vector<int64_t> ids;
-        std::vector<int32_t> assign;
-        size_t n = 0;
-    };
-    std::vector<Chunk> chunks;
-    size_t staged = 0;
-    // final storage
-    DevBuf<float> vecs;       // n x ld, list-major (IVF) / id order (FLAT)
-    DevBuf<uint32_t> row_ids; // n
-    int64_t last_id = -1;        // largest label so far while the labels arrive strictly ascending
-    bool ids_may_repeat = false; // labels were given by the caller and are not known to be distinct (add does not forbid duplicates):
-                                 // a filter's population count then does not bound the rows that pass it (build_view)
-    DevBuf<int64_t> list_off; // nlist + 1
-    std::vector<int64_t> h_list_off;
-    size_t n = 0;
-    size_t max_list_len = 0;
-    uint64_t max_id = 0; // largest stored row id (size of the id space the filter bitmaps range over)
-    // matrix-core candidate pass (mfma_scan_kernels.hpp): |x|^2 of every stored row and their maximum
-    DevBuf<float> xnorm;
-    float xnorm_max = 0.f;
-    DevBuf<float> cnorm; // same for the centroids (the coarse quantiser goes through the same pass)
-    float cnorm_max = 0.f;
-    DevBuf<int64_t> list_mid; // nlist: end of the SAMPLE slice of list l = min(list_off[l] + 128, list_off[l+1])
-    // fp16 shadow of the lists (h16_scan_kernels.hpp): the list scan of batched searches reads this instead of vecs
-    int want_shadow = 1;        // build parameter `shadow=0|1`
-    DevBuf<uint4> shadow;       // blocks of 32 rows in MFMA operand order
-    DevBuf<uint32_t> hoff;      // nlist + 1: first block of list l
-    DevBuf<int64_t> list_mid32; // nlist: end of block 0 of list l = min(list_off[l] + 32, list_off[l+1])
-    uint32_t h_nks = 0, h_nch = 0;
-    float h_scale = 0.f, h_inv_scale = 0.f; // stored value = fp16(x * h_scale)
-    bool shadow_ready = false;
-    // fp16 shadow of the CENTROID table (same scale, same block layout: ceil(nlist / 32) blocks) for the coarse quantiser of
-    // batches, and the G-lists-of-one-block view the sample kernel walks it through
-    DevBuf<uint4> c_shadow;
-    DevBuf<uint32_t> c_hoff;     // [G + 1]: block g
-    DevBuf<int64_t> c_list_off;  // [G + 1]: centroid 32 g (last: nlist)
-    bool c_shadow_ready = false;
-    bool ready = false;
-    // VIWithMeta (src/VectorIndex/Cache/VICacheObject.h:40-117): state that rides on a cached index.  Swapped under `meta_mu`
-    // (setDeleteBitmap is an atomic_store in the reference); a search keeps its own shared_ptr while it runs.
-    struct Meta
-    {
-        DevBuf<uint64_t> delete_alive; // 1 = not deleted, over the index labels; empty = nothing deleted
-        size_t delete_nbits = 0;
-        DevBuf<uint64_t> row_ids_map;  // decoupled part: label -> row of the merged part (transferToNewRowIds)
-        size_t row_ids_n = 0;
-        DevBuf<uint64_t> inv_row_ids;  // merged-part row -> label of its source part ...
-        DevBuf<uint8_t> inv_sources;   // ... and which source part (getRealBitmap keeps those of own_id)
-        size_t inv_n = 0;
-        uint32_t own_id = 0;
-    };
-    mutable std::mutex meta_mu;
-    std::shared_ptr<Meta> meta;
-    std::shared_ptr<Meta> get_meta() const
-    {
-        std::lock_guard<std::mutex> lk(meta_mu);
-        return meta;
-    }
-};
 
 static __global__ void and_bits_kernel(const uint64_t * a, size_t na, const uint64_t * b, size_t nb, uint64_t * out, size_t n)
 {
@@ -608,10 +146,12 @@ static __global__ void remap_ids_kernel(int64_t * ids, size_t n, const uint64_t 
         ids[i] = (int64_t)map[ids[i]];
 }
 
+namespace msvs
+{
 /// The filter a search really runs with: (per-search filter, converted to label space for a decoupled part) AND the resident
 /// delete bitmap.  Returns the device pointer (nullptr = no filter) and its valid bits; scratch from aux_for(stream).
-static const uint64_t * effective_filter(const msvs_index & ix, const msvs_index::Meta * meta, const uint64_t * d_alive,
-                                         size_t nbits, size_t * eff_nbits, hipStream_t stream)
+const uint64_t * effective_filter(const msvs_index & ix, const msvs_index::Meta * meta, const uint64_t * d_alive,
+                                  size_t nbits, size_t * eff_nbits, hipStream_t stream)
 {
     *eff_nbits = nbits;
     if (!meta)
@@ -658,13 +198,14 @@ static const uint64_t * effective_filter(const msvs_index & ix, const msvs_index
     return cur;
 }
 
-static void apply_row_ids_map(const msvs_index::Meta * meta, int64_t * d_ids, size_t n, hipStream_t stream)
+void apply_row_ids_map(const msvs_index::Meta * meta, int64_t * d_ids, size_t n, hipStream_t stream)
 {
     if (!meta || !meta->row_ids_n || !n)
         return;
     hipLaunchKernelGGL(remap_ids_kernel, dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, d_ids, n,
                        meta->row_ids_map.p, meta->row_ids_n);
     MSVS_HIP(hipGetLastError());
+}
 }
 
 /// The fp16 shadow of an IVF index (see h16_scan_kernels.hpp); called once the final storage and the norms are in place.
@@ -772,8 +313,10 @@ static void index_build_shadow(msvs_index & ix, hipStream_t stream)
     }
 }
 
+namespace msvs
+{
 /// Row norms for the approximate pass and its error bound; called once the final storage is in place.
-static void index_finalize_norms(msvs_index & ix, hipStream_t stream)
+void index_finalize_norms(msvs_index & ix, hipStream_t stream)
 {
     ix.xnorm.alloc(std::max<size_t>(ix.n, 1));
     ix.xnorm_max = 0.f;
@@ -803,6 +346,7 @@ static void index_finalize_norms(msvs_index & ix, hipStream_t stream)
     MSVS_HIP(hipStreamSynchronize(stream));
     memcpy(&ix.xnorm_max, &bits, 4); // NaN / inf / huge values switch the candidate pass off (see plan_ivf)
     index_build_shadow(ix, stream);
+}
 }
 
 /// Process-wide counters of the candidate passes (device side): [0] = result queries whose certificate failed, [1] = the
@@ -2163,10 +1707,9 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
 /// The search proper: all pointers on the device, everything enqueued on `stream`.  Very large batches are cut into
 /// sub-batches of at most 2^21 (query, probe) pairs, stream-ordered one after the other: every scratch buffer of a search
 /// is proportional to the pairs of ONE sub-batch, so the per-(thread, stream) arena stays bounded (~0.5 GB) whatever nq.
-static void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
-                                uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
-                                float * d_dis, hipStream_t stream, const int32_t * given_probes = nullptr,
-                                int32_t * probes_only = nullptr, const SearchView * view = nullptr)
+void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq, uint32_t k, size_t nprobe,
+                         const uint64_t * d_alive, size_t nbits, int64_t * d_ids, float * d_dis, hipStream_t stream,
+                         const int32_t * given_probes, int32_t * probes_only, const SearchView * view)
 {
     const size_t np_eff = ix.type == MSVS_INDEX_IVFFLAT ? std::max<size_t>(1, std::min(nprobe, std::max<size_t>(ix.nlist, 1))) : 1;
     const size_t sub = std::max<size_t>(256, ((size_t)1 << 21) / np_eff);
@@ -2711,13 +2254,10 @@ extern "C" int msvs_index_search_device(const msvs_index_t * ix, const float * d
     });
 }
 
-namespace
-{
-void index_search_filtered(const msvs_index & ix, const float * d_queries, size_t nq, uint32_t k, size_t nprobe, const uint64_t * eff,
-                           size_t eff_bits, uint64_t alive_count, int64_t * d_ids, float * d_dis, hipStream_t stream);
-}
 
-static int index_search_host_call(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
+namespace msvs
+{
+int index_search_host_call(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
                                   const uint64_t * alive_bits, size_t nbits, int64_t * ids, float * dis)
 {
     return guarded([&] {
@@ -2808,6 +2348,7 @@ static int index_search_host_call(const msvs_index_t * ix, const float * queries
         MSVS_HIP(hipMemcpyAsync(dis, d_dis.p, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
         MSVS_HIP(hipStreamSynchronize(stream));
     });
+}
 }
 
 // ------------------------------------------------------------------------------------------ combining concurrent callers
@@ -3016,322 +2557,6 @@ extern "C" int msvs_combine_stats(uint64_t * calls, uint64_t * batches, uint64_t
     return MSVS_OK;
 }
 
-// ------------------------------------------------------------------------------------------ filters
-
-struct msvs_filter
-{
-    DevBuf<uint64_t> bits;
-    size_t nbits = 0;
-    uint64_t count = 0; // passing rows (kept current by every operation: the search strategy reads it)
-};
-
-namespace
-{
-void filter_recount(msvs_filter & f, hipStream_t stream)
-{
-    const size_t words = std::max<size_t>(1, ceil_div(f.nbits, (size_t)64));
-    Scratch & v = view_for(stream); // a counter word without a hipMalloc per filter
-    v.reserve(256, stream);
-    unsigned long long * c = v.take<unsigned long long>(1);
-    MSVS_HIP(hipMemsetAsync(c, 0, 8, stream));
-    hipLaunchKernelGGL(filter_count_kernel, dim3((unsigned)ceil_div(words, (size_t)256)), dim3(256), 0, stream, f.bits.p, words, f.nbits, c);
-    unsigned long long h = 0;
-    MSVS_HIP(hipMemcpyAsync(&h, c, 8, hipMemcpyDeviceToHost, stream));
-    MSVS_HIP(hipStreamSynchronize(stream));
-    f.count = h;
-}
-
-std::unique_ptr<msvs_filter> filter_alloc(size_t nbits, hipStream_t stream)
-{
-    std::unique_ptr<msvs_filter> f(new msvs_filter);
-    f->nbits = nbits;
-    const size_t words = std::max<size_t>(1, ceil_div(nbits, (size_t)64));
-    f->bits.alloc(words);
-    MSVS_HIP(hipMemsetAsync(f->bits.p, 0, words * 8, stream));
-    return f;
-}
-
-/// Build the compacted view of `ix` under the effective filter (everything enqueued on `stream`, scratch from view_for()).
-SearchView build_view(const msvs_index & ix, const uint64_t * d_alive, size_t nbits, size_t alive_upper, hipStream_t stream)
-{
-    const size_t n = ix.n, chunks = std::max<size_t>(1, ceil_div(n, (size_t)COMPACT_CHUNK));
-    // rows that can pass: the filter's population count -- unless labels may repeat (three rows with label 5 pass one bit)
-    const size_t upper = std::max<size_t>(1, ix.ids_may_repeat ? n : std::min(n, alive_upper));
-    Scratch & v = view_for(stream);
-    v.reserve((chunks + 2) * 4 + (n + 2) * 4 + upper * 4 + (ix.nlist + 2) * 8 + 4096, stream);
-    CompactParams p{};
-    p.ids = ix.row_ids.p;
-    p.alive = d_alive;
-    p.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
-    p.n = (uint32_t)n;
-    p.chunk_cnt = v.take<uint32_t>(chunks + 1);
-    p.rank = v.take<uint32_t>(n + 1);
-    p.rowmap = v.take<uint32_t>(upper);
-    p.rowmap_cap = (uint32_t)upper;
-    p.list_off = ix.type == MSVS_INDEX_IVFFLAT ? ix.list_off.p : nullptr;
-    p.nlist = (uint32_t)ix.nlist;
-    p.sel_off = v.take<int64_t>(ix.nlist + 1);
-    ProfileScope prof("filter_view", stream);
-    hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)chunks), dim3(BLOCK), 0, stream, p);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, p, (uint32_t)chunks);
-    hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)chunks), dim3(BLOCK), 0, stream, p);
-    if (p.list_off)
-        hipLaunchKernelGGL(compact_offsets_kernel, dim3((unsigned)ceil_div(ix.nlist + 1, (size_t)256)), dim3(256), 0, stream, p);
-    MSVS_HIP(hipGetLastError());
-    SearchView view{};
-    view.list_off = p.sel_off;
-    view.rowmap = p.rowmap;
-    view.n_rows = p.rank + n;
-    view.n_upper = upper;
-    return view;
-}
-
-/// The search of a filtered batch: selective filters go through the compacted view, the others through the bit test.
-/// alive_count: passing rows of the caller's filter (an upper bound of what passes the effective filter inside the index).
-void index_search_filtered(const msvs_index & ix, const float * d_queries, size_t nq, uint32_t k, size_t nprobe, const uint64_t * eff,
-                           size_t eff_bits, uint64_t alive_count, int64_t * d_ids, float * d_dis, hipStream_t stream)
-{
-    const double frac = ix.n ? (double)alive_count / (double)ix.n : 1.0;
-    double below = options().filter_compact_below;
-    if (below < 0)
-    {
-        // measured crossover (profiles/r02_filter.txt, 1M x 768): the view is scanned canonically, so it competes with the
-        // matrix-core candidate pass once many queries share a list pass -- 16 queries: wins below ~50 % passing,
-        // 256: below ~30 %, 4096: below ~3 %
-        const double per_list = ix.type == MSVS_INDEX_IVFFLAT ? (double)nq * (double)std::max<size_t>(nprobe, 1) / (double)std::max<size_t>(ix.nlist, 1)
-                                                               : (double)nq;
-        below = per_list < 2 ? 0.4 : (per_list < 16 ? 0.25 : 0.03);
-    }
-    // the view costs ~5 B per stored row: for one or two queries that is more than the probed lists themselves
-    const bool worth = nq * std::max<size_t>(nprobe, 1) * 4 >= ix.nlist || ix.type == MSVS_INDEX_FLAT;
-    if (eff && ix.n && (below >= 1.0 || (frac < below && worth)) && alive_count <= 0xfffffff0ull && ix.n <= 0xfffffff0ull)
-    {
-        const SearchView view = build_view(ix, eff, eff_bits, (size_t)alive_count, stream);
-        index_search_device(ix, d_queries, nq, k, nprobe, nullptr, 0, d_ids, d_dis, stream, nullptr, nullptr, &view);
-        return;
-    }
-    index_search_device(ix, d_queries, nq, k, nprobe, eff, eff_bits, d_ids, d_dis, stream);
-}
-}
-
-extern "C" int msvs_filter_from_bits(const uint64_t * bits, size_t nbits, msvs_filter_t ** out)
-{
-    return guarded([&] {
-        if (!out || (nbits && !bits))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
-        hipStream_t stream = thread_stream();
-        auto f = filter_alloc(nbits, stream);
-        if (nbits)
-            MSVS_HIP(hipMemcpyAsync(f->bits.p, bits, ceil_div(nbits, (size_t)64) * 8, hipMemcpyHostToDevice, stream));
-        filter_recount(*f, stream);
-        *out = f.release();
-    });
-}
-
-/// getFilterFromPipeline (MergeTreeSelectWithHybridSearchProcessor.cpp:905-934): one bit per passing `_part_offset`.
-extern "C" int msvs_filter_from_offsets(const uint64_t * part_offsets, size_t n, size_t nbits, int mem, msvs_filter_t ** out)
-{
-    return guarded([&] {
-        if (!out || (n && !part_offsets))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
-        hipStream_t stream = thread_stream();
-        auto f = filter_alloc(nbits, stream);
-        if (n)
-        {
-            const uint64_t * d_off = part_offsets;
-            DevBuf<uint64_t> tmp;
-            if (mem != MSVS_MEM_DEVICE)
-            {
-                tmp.alloc(n);
-                MSVS_HIP(hipMemcpyAsync(tmp.p, part_offsets, n * 8, hipMemcpyHostToDevice, stream));
-                d_off = tmp.p;
-            }
-            hipLaunchKernelGGL(filter_from_offsets_kernel, dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, d_off, n, nbits,
-                               reinterpret_cast<unsigned long long *>(f->bits.p));
-            MSVS_HIP(hipGetLastError());
-            filter_recount(*f, stream); // also orders tmp's release after the kernel
-        }
-        *out = f.release();
-    });
-}
-
-namespace
-{
-template <typename T>
-void launch_predicate(const void * col, size_t n, int mem, int op, T lo, T hi, msvs_filter & f, hipStream_t stream)
-{
-    const T * d_col = static_cast<const T *>(col);
-    DevBuf<T> tmp;
-    if (mem != MSVS_MEM_DEVICE)
-    {
-        tmp.alloc(std::max<size_t>(n, 1));
-        MSVS_HIP(hipMemcpyAsync(tmp.p, col, n * sizeof(T), hipMemcpyHostToDevice, stream));
-        d_col = tmp.p;
-    }
-    hipLaunchKernelGGL((filter_predicate_kernel<T>), dim3((unsigned)ceil_div(n, (size_t)256)), dim3(256), 0, stream, d_col, n, op, lo, hi,
-                       f.bits.p);
-    MSVS_HIP(hipGetLastError());
-    filter_recount(f, stream);
-}
-}
-
-/// A simple PREWHERE predicate `column OP constant` evaluated on the device: row i of the column is `_part_offset` i.
-extern "C" int msvs_filter_from_predicate(const void * column, int dtype, size_t nrows, int mem, int op, msvs_scalar_t lo,
-                                          msvs_scalar_t hi, msvs_filter_t ** out)
-{
-    return guarded([&] {
-        if (!out || (nrows && !column))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
-        if (op < MSVS_OP_EQ || op > MSVS_OP_BETWEEN)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "unknown comparison %d", op);
-        hipStream_t stream = thread_stream();
-        auto f = filter_alloc(nrows, stream);
-        if (nrows)
-            switch (dtype)
-            {
-                case MSVS_DT_UINT8: launch_predicate<uint8_t>(column, nrows, mem, op, (uint8_t)lo.i, (uint8_t)hi.i, *f, stream); break;
-                case MSVS_DT_UINT16: launch_predicate<uint16_t>(column, nrows, mem, op, (uint16_t)lo.i, (uint16_t)hi.i, *f, stream); break;
-                case MSVS_DT_UINT32: launch_predicate<uint32_t>(column, nrows, mem, op, (uint32_t)lo.i, (uint32_t)hi.i, *f, stream); break;
-                case MSVS_DT_UINT64: launch_predicate<uint64_t>(column, nrows, mem, op, (uint64_t)lo.i, (uint64_t)hi.i, *f, stream); break;
-                case MSVS_DT_INT8: launch_predicate<int8_t>(column, nrows, mem, op, (int8_t)lo.i, (int8_t)hi.i, *f, stream); break;
-                case MSVS_DT_INT16: launch_predicate<int16_t>(column, nrows, mem, op, (int16_t)lo.i, (int16_t)hi.i, *f, stream); break;
-                case MSVS_DT_INT32: launch_predicate<int32_t>(column, nrows, mem, op, (int32_t)lo.i, (int32_t)hi.i, *f, stream); break;
-                case MSVS_DT_INT64: launch_predicate<int64_t>(column, nrows, mem, op, lo.i, hi.i, *f, stream); break;
-                case MSVS_DT_FLOAT32: launch_predicate<float>(column, nrows, mem, op, (float)lo.f, (float)hi.f, *f, stream); break;
-                case MSVS_DT_FLOAT64: launch_predicate<double>(column, nrows, mem, op, lo.f, hi.f, *f, stream); break;
-                default: fail(MSVS_ERR_INVALID_ARGUMENT, "unknown column type %d", dtype);
-            }
-        *out = f.release();
-    });
-}
-
-extern "C" int msvs_filter_combine(msvs_filter_t * a, const msvs_filter_t * b, int mode)
-{
-    return guarded([&] {
-        if (!a || !b || mode < 0 || mode > 2)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null filter / unknown mode");
-        hipStream_t stream = thread_stream();
-        const size_t wa = std::max<size_t>(1, ceil_div(a->nbits, (size_t)64)), wb = ceil_div(b->nbits, (size_t)64);
-        hipLaunchKernelGGL(filter_combine_kernel, dim3((unsigned)ceil_div(wa, (size_t)256)), dim3(256), 0, stream, a->bits.p, wa, b->bits.p,
-                           wb, mode);
-        MSVS_HIP(hipGetLastError());
-        filter_recount(*a, stream);
-    });
-}
-
-extern "C" int msvs_filter_count(const msvs_filter_t * f, uint64_t * alive, size_t * nbits)
-{
-    return guarded([&] {
-        if (!f)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null filter");
-        if (alive)
-            *alive = f->count;
-        if (nbits)
-            *nbits = f->nbits;
-    });
-}
-
-extern "C" int msvs_filter_to_bits(const msvs_filter_t * f, uint64_t * bits_out)
-{
-    return guarded([&] {
-        if (!f || !bits_out)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
-        MSVS_HIP(hipMemcpy(bits_out, f->bits.p, std::max<size_t>(1, ceil_div(f->nbits, (size_t)64)) * 8, hipMemcpyDeviceToHost));
-    });
-}
-
-extern "C" void msvs_filter_free(msvs_filter_t * f) { delete f; }
-
-extern "C" int msvs_index_search_filter_device(const msvs_index_t * ix, const float * d_queries, size_t nq, int k, int nprobe,
-                                               const msvs_filter_t * filter, int64_t * d_ids, float * d_dis, void * hip_stream)
-{
-    return guarded([&] {
-        if (!ix || !filter || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/filter/buffer or negative k");
-        if (nq == 0 || k == 0)
-            return;
-        check_k((size_t)k);
-        hipStream_t stream = as_stream(hip_stream);
-        const auto meta = ix->get_meta();
-        size_t eff_bits = filter->nbits;
-        const uint64_t * eff = effective_filter(*ix, meta.get(), filter->bits.p, filter->nbits, &eff_bits, stream);
-        index_search_filtered(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, filter->count, d_ids, d_dis,
-                              stream);
-        apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
-    });
-}
-
-extern "C" int msvs_index_search_filter(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
-                                        const msvs_filter_t * filter, int64_t * ids, float * dis)
-{
-    return guarded([&] {
-        if (!ix || !filter || (nq && (!queries || !ids || !dis)) || k < 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/filter/buffer or negative k");
-        if (nq == 0 || k == 0)
-            return;
-        check_k((size_t)k);
-        auto p = parse_params(params);
-        for (const auto & kv : p)
-            if (kv.first != "nprobe")
-                fail(MSVS_ERR_INVALID_ARGUMENT, "unknown search parameter `%s`", kv.first.c_str());
-        const long nprobe = param_int(p, "nprobe", 1);
-        if (nprobe < 1)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "nprobe must be >= 1");
-        hipStream_t stream = thread_stream();
-        Scratch & stg = staging_for(stream);
-        stg.reserve(nq * ix->dim * 4 + nq * (size_t)k * 12 + 4096, stream);
-        float * dq = stg.take<float>(nq * ix->dim);
-        int64_t * d_ids = stg.take<int64_t>(nq * (size_t)k);
-        float * d_dis = stg.take<float>(nq * (size_t)k);
-        MSVS_HIP(hipMemcpyAsync(dq, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
-        const int rc = msvs_index_search_filter_device(ix, dq, nq, k, (int)nprobe, filter, d_ids, d_dis, stream);
-        if (rc != MSVS_OK)
-            fail(rc, "%s", msvs_last_error());
-        MSVS_HIP(hipMemcpyAsync(ids, d_ids, nq * (size_t)k * 8, hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipMemcpyAsync(dis, d_dis, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipStreamSynchronize(stream));
-    });
-}
-
-/// VIWithMeta::setDeleteBitmap (VICacheObject.h:100-102): the lightweight-delete state of a cached index, resident in HBM
-/// and swapped atomically; every search ANDs it into its filter (VIWithDataPart.cpp:903-908).  alive_bits NULL clears it.
-extern "C" int msvs_index_set_delete_bitmap(msvs_index_t * ix, const uint64_t * alive_bits, size_t nbits)
-{
-    return guarded([&] {
-        if (!ix)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
-        auto cur = ix->get_meta();
-        auto next = std::make_shared<msvs_index::Meta>();
-        if (alive_bits)
-        {
-            const size_t words = std::max<size_t>(1, ceil_div(nbits, (size_t)64));
-            next->delete_alive.alloc(words);
-            MSVS_HIP(hipMemset(next->delete_alive.p, 0, words * 8));
-            if (nbits)
-                MSVS_HIP(hipMemcpy(next->delete_alive.p, alive_bits, ceil_div(nbits, (size_t)64) * 8, hipMemcpyHostToDevice));
-            next->delete_nbits = nbits;
-        }
-        if (cur) // the maps are immutable once set: share them by copying device to device
-        {
-            auto dup = [](auto & dst, const auto & src) {
-                if (src.n)
-                {
-                    dst.alloc(src.n);
-                    MSVS_HIP(hipMemcpy(dst.p, src.p, src.bytes(), hipMemcpyDeviceToDevice));
-                }
-            };
-            dup(next->row_ids_map, cur->row_ids_map);
-            dup(next->inv_row_ids, cur->inv_row_ids);
-            dup(next->inv_sources, cur->inv_sources);
-            next->row_ids_n = cur->row_ids_n;
-            next->inv_n = cur->inv_n;
-            next->own_id = cur->own_id;
-        }
-        std::lock_guard<std::mutex> lk(ix->meta_mu);
-        ix->meta = next;
-    });
-}
-
 /// The row-id maps of a decoupled part (SegmentId::getMergedMaps, VIWithDataPart.cpp:722): once set, a search takes its
 /// filter in the MERGED part's row space (getRealBitmap) and reports the MERGED part's rows (transferToNewRowIds).
 extern "C" int msvs_index_set_merged_maps(msvs_index_t * ix, const uint64_t * row_ids_map, size_t n_old,
@@ -3521,614 +2746,6 @@ extern "C" int msvs_profile_reset(void)
     return guarded([&] { profile_reset(); });
 }
 
-extern "C" int msvs_index_export(const msvs_index_t * ix, float * centroids, int64_t * list_off, float * vecs,
-                                 int64_t * ids)
-{
-    return guarded([&] {
-        if (!ix || !ix->ready)
-            fail(MSVS_ERR_NOT_READY, "index is not ready");
-        const size_t d = ix->dim, ld = ix->ld;
-        if (centroids && ix->type == MSVS_INDEX_IVFFLAT)
-            MSVS_HIP(hipMemcpy2D(centroids, d * 4, ix->centroids.p, ld * 4, d * 4, ix->nlist, hipMemcpyDeviceToHost));
-        if (list_off)
-            memcpy(list_off, ix->h_list_off.data(), ix->h_list_off.size() * 8);
-        if (vecs && ix->n)
-            MSVS_HIP(hipMemcpy2D(vecs, d * 4, ix->vecs.p, ld * 4, d * 4, ix->n, hipMemcpyDeviceToHost));
-        if (ids && ix->n)
-        {
-            std::vector<uint32_t> h(ix->n);
-            MSVS_HIP(hipMemcpy(h.data(), ix->row_ids.p, ix->n * 4, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < ix->n; i++)
-                ids[i] = (int64_t)h[i];
-        }
-    });
-}
-
-extern "C" int msvs_index_export_list(const msvs_index_t * ix, size_t list, float * vecs, int64_t * ids)
-{
-    return guarded([&] {
-        if (!ix || !ix->ready || ix->type != MSVS_INDEX_IVFFLAT)
-            fail(MSVS_ERR_NOT_READY, "not a built IVFFLAT index");
-        if (list >= ix->nlist)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "list %zu of %zu", list, ix->nlist);
-        const size_t b = (size_t)ix->h_list_off[list], len = (size_t)ix->h_list_off[list + 1] - b, d = ix->dim, ld = ix->ld;
-        if (!len)
-            return;
-        if (vecs)
-            MSVS_HIP(hipMemcpy2D(vecs, d * 4, ix->vecs.p + b * ld, ld * 4, d * 4, len, hipMemcpyDeviceToHost));
-        if (ids)
-        {
-            std::vector<uint32_t> h(len);
-            MSVS_HIP(hipMemcpy(h.data(), ix->row_ids.p + b, len * 4, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < len; i++)
-                ids[i] = (int64_t)h[i];
-        }
-    });
-}
-
-extern "C" int msvs_index_list_stats(const msvs_index_t * ix, size_t * nlist, size_t * min_len, size_t * max_len, double * imbalance,
-                                     size_t * train_empty)
-{
-    return guarded([&] {
-        if (!ix || !ix->ready)
-            fail(MSVS_ERR_NOT_READY, "index is not ready");
-        size_t mn = ~(size_t)0, mx = 0;
-        double sq = 0;
-        const size_t nl = ix->type == MSVS_INDEX_IVFFLAT ? ix->nlist : 0;
-        for (size_t l = 0; l < nl; l++)
-        {
-            const size_t len = (size_t)(ix->h_list_off[l + 1] - ix->h_list_off[l]);
-            mn = std::min(mn, len);
-            mx = std::max(mx, len);
-            sq += (double)len * (double)len;
-        }
-        if (nlist)
-            *nlist = nl;
-        if (min_len)
-            *min_len = nl ? mn : 0;
-        if (max_len)
-            *max_len = mx;
-        if (imbalance)
-            *imbalance = nl && ix->n ? (double)nl * sq / ((double)ix->n * (double)ix->n) : 1.0;
-        if (train_empty)
-            *train_empty = ix->train_empty_last;
-    });
-}
-
-// ------------------------------------------------------------------------------------------- serialisation
-
-// The index is a set of NAMED files written / read through caller-supplied stream callbacks (msvs_io_t), which is how
-// the reference's library does it: Search::IndexDataFileWriter<OS>(path_prefix, opener) opens every file of the set through
-// the host's opener -- a VectorIndexWriter over IDisk::writeFile, local disk or S3 alike (VectorIndexIO.h:25-166,
-// VIWithDataPart.cpp:461-473, :688-700).  Files (the shim turns NAME into <index_name>-NAME.vidx3):
-//   data_bin : DataHeader, centroids [nlist][dim] f32 (IVFFLAT), list offsets [nlist + 1] i64, rows [n][dim] f32
-//              list-major (cosine: normalised)              -- serialize() / load()
-//   id_list  : u64 n, ids [n] i64 in storage order          -- saveDataID() / loadDataID()
-// The fp16 shadow and the norms are derived data and are rebuilt at load.
-
-namespace
-{
-struct DataHeader
-{
-    char magic[8]; // "MSVSIDX2"
-    uint32_t version;
-    int32_t type, metric;
-    uint32_t shard_rank, shard_world;
-    uint32_t reserved;
-    uint64_t dim, nlist, n;
-};
-constexpr uint32_t DATA_VERSION = 2;
-/// stdio implementation behind the path convenience calls: file NAME of the set is <prefix>-NAME.vidx3
-struct StdioCtx
-{
-    std::string prefix;
-};
-void * stdio_open(void * ctx, const char * name, int write)
-{
-    const std::string path = static_cast<StdioCtx *>(ctx)->prefix + "-" + name + ".vidx3";
-    return fopen(path.c_str(), write ? "wb" : "rb");
-}
-int64_t stdio_write(void *, void * s, const void * p, size_t n) { return (int64_t)fwrite(p, 1, n, static_cast<FILE *>(s)); }
-int64_t stdio_read(void *, void * s, void * p, size_t n) { return (int64_t)fread(p, 1, n, static_cast<FILE *>(s)); }
-int stdio_close(void *, void * s) { return fclose(static_cast<FILE *>(s)); }
-msvs_io_t stdio_io(StdioCtx * c) { return msvs_io_t{c, stdio_open, stdio_write, stdio_read, stdio_close}; }
-}
-
-extern "C" int msvs_index_serialize_io(const msvs_index_t * ix, const msvs_io_t * io)
-{
-    return guarded([&] {
-        if (!ix || !ix->ready)
-            fail(MSVS_ERR_NOT_READY, "index is not ready");
-        const size_t nlist = msvs_index_num_lists(ix), d = ix->dim, ld = ix->ld;
-        {
-            IoStream f(io, "data_bin", 1);
-            DataHeader h{};
-            memcpy(h.magic, "MSVSIDX2", 8);
-            h.version = DATA_VERSION;
-            h.type = ix->type;
-            h.metric = ix->metric;
-            h.shard_rank = (uint32_t)ix->shard_rank;
-            h.shard_world = (uint32_t)ix->shard_world;
-            h.dim = d;
-            h.nlist = nlist;
-            h.n = ix->n;
-            f.write(&h, sizeof(h));
-            if (ix->type == MSVS_INDEX_IVFFLAT)
-            {
-                std::vector<float> cent(nlist * d);
-                MSVS_HIP(hipMemcpy2D(cent.data(), d * 4, ix->centroids.p, ld * 4, d * 4, nlist, hipMemcpyDeviceToHost));
-                f.write(cent.data(), cent.size() * 4);
-            }
-            f.write(ix->h_list_off.data(), (nlist + 1) * 8);
-            // rows in chunks: a 77 GB shard never sits in host memory at once
-            const size_t rows_per = std::max<size_t>(1, IO_CHUNK / (d * 4));
-            std::vector<float> buf(std::min(rows_per, std::max<size_t>(ix->n, 1)) * d);
-            for (size_t r0 = 0; r0 < ix->n; r0 += rows_per)
-            {
-                const size_t m = std::min(rows_per, ix->n - r0);
-                MSVS_HIP(hipMemcpy2D(buf.data(), d * 4, ix->vecs.p + r0 * ld, ld * 4, d * 4, m, hipMemcpyDeviceToHost));
-                f.write(buf.data(), m * d * 4);
-            }
-            f.finish();
-        }
-        {
-            IoStream f(io, "id_list", 1);
-            const uint64_t n = ix->n;
-            f.write(&n, 8);
-            std::vector<uint32_t> h32(ix->n);
-            if (ix->n)
-                MSVS_HIP(hipMemcpy(h32.data(), ix->row_ids.p, ix->n * 4, hipMemcpyDeviceToHost));
-            std::vector<int64_t> ids(h32.begin(), h32.end());
-            f.write(ids.data(), ids.size() * 8);
-            f.finish();
-        }
-    });
-}
-
-extern "C" int msvs_index_load_io(const msvs_io_t * io, msvs_index_t ** out)
-{
-    return guarded([&] {
-        if (!out)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "out is null");
-        *out = nullptr;
-        std::unique_ptr<msvs_index> ix(new msvs_index);
-        MSVS_HIP(hipGetDevice(&ix->device));
-        size_t nlist = 0, n = 0, d = 0;
-        {
-            IoStream f(io, "data_bin", 0);
-            DataHeader h{};
-            f.read(&h, sizeof(h));
-            // nothing of the file is trusted: a corrupt header must not turn into out-of-bounds device reads or TB allocations
-            if (memcmp(h.magic, "MSVSIDX2", 8) != 0 || h.version != DATA_VERSION)
-                fail(MSVS_ERR_IO, "not an msvs index (data_bin: bad magic / version)");
-            if ((h.type != MSVS_INDEX_FLAT && h.type != MSVS_INDEX_IVFFLAT)
-                || (h.metric != MSVS_METRIC_L2 && h.metric != MSVS_METRIC_IP && h.metric != MSVS_METRIC_COSINE)
-                || h.dim == 0 || h.dim > 8192 || h.nlist == 0 || h.nlist > 0x7fffffffull || h.n > 0xfffffff0ull
-                || (h.type == MSVS_INDEX_FLAT && h.nlist != 1) || h.shard_world == 0 || h.shard_rank >= h.shard_world)
-                fail(MSVS_ERR_IO, "corrupt msvs index header");
-            ix->type = h.type;
-            ix->metric = h.metric;
-            ix->dim = d = h.dim;
-            ix->ld = padded_dim(d);
-            ix->shard_rank = (int)h.shard_rank;
-            ix->shard_world = (int)h.shard_world;
-            nlist = h.nlist;
-            n = h.n;
-            const uint32_t ld = ix->ld;
-            if (ix->type == MSVS_INDEX_IVFFLAT)
-            {
-                std::vector<float> cent(nlist * d);
-                f.read(cent.data(), cent.size() * 4);
-                ix->nlist = nlist;
-                ix->centroids.alloc(nlist * ld);
-                upload_rows(ix->centroids.p, cent.data(), nlist, (uint32_t)d, ld, MSVS_MEM_HOST, nullptr);
-                MSVS_HIP(hipStreamSynchronize(nullptr));
-            }
-            std::vector<int64_t> off(nlist + 1);
-            f.read(off.data(), off.size() * 8);
-            bool ok = off[0] == 0 && off[nlist] == (int64_t)n;
-            for (size_t l = 0; ok && l < nlist; l++)
-                ok = off[l + 1] >= off[l];
-            if (!ok)
-                fail(MSVS_ERR_IO, "corrupt msvs index: list offsets are not a partition of the rows");
-            ix->n = n;
-            ix->h_list_off = off;
-            ix->max_list_len = 0;
-            for (size_t l = 0; l < nlist; l++)
-                ix->max_list_len = std::max<size_t>(ix->max_list_len, (size_t)(off[l + 1] - off[l]));
-            ix->vecs.alloc(std::max<size_t>(n, 1) * ld);
-            ix->list_off.alloc(nlist + 1);
-            MSVS_HIP(hipMemcpy(ix->list_off.p, off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
-            const size_t rows_per = std::max<size_t>(1, IO_CHUNK / (d * 4));
-            std::vector<float> buf(std::min(rows_per, std::max<size_t>(n, 1)) * d);
-            for (size_t r0 = 0; r0 < n; r0 += rows_per)
-            {
-                const size_t m = std::min(rows_per, n - r0);
-                f.read(buf.data(), m * d * 4); // a short file fails here, before anything is searched
-                upload_rows(ix->vecs.p + r0 * ld, buf.data(), m, (uint32_t)d, ld, MSVS_MEM_HOST, nullptr);
-                MSVS_HIP(hipStreamSynchronize(nullptr));
-            }
-        }
-        {
-            IoStream f(io, "id_list", 0);
-            uint64_t nid = 0;
-            f.read(&nid, 8);
-            if (nid != n)
-                fail(MSVS_ERR_IO, "corrupt msvs index: id_list holds %llu ids for %zu rows", (unsigned long long)nid, n);
-            std::vector<int64_t> ids(n);
-            f.read(ids.data(), n * 8);
-            std::vector<uint32_t> h32(n);
-            ix->max_id = 0;
-            for (size_t i = 0; i < n; i++)
-            {
-                if (ids[i] < 0 || ids[i] > 0xfffffff0ll)
-                    fail(MSVS_ERR_IO, "corrupt msvs index: row id %lld outside the u32 row-offset range", (long long)ids[i]);
-                h32[i] = (uint32_t)ids[i];
-                ix->max_id = std::max<uint64_t>(ix->max_id, (uint64_t)ids[i]);
-            }
-            ix->row_ids.alloc(std::max<size_t>(n, 1));
-            if (n)
-                MSVS_HIP(hipMemcpy(ix->row_ids.p, h32.data(), n * 4, hipMemcpyHostToDevice));
-            // list-major storage order says nothing about the labels: distinct or not is decided by looking (once per load)
-            std::sort(h32.begin(), h32.end());
-            ix->ids_may_repeat = std::adjacent_find(h32.begin(), h32.end()) != h32.end();
-        }
-        index_finalize_norms(*ix, nullptr);
-        MSVS_HIP(hipDeviceSynchronize());
-        ix->ready = true;
-        *out = ix.release();
-    });
-}
-
-/// Convenience over stdio: the file set <path_prefix>-data_bin.vidx3, <path_prefix>-id_list.vidx3.
-extern "C" int msvs_index_serialize(const msvs_index_t * ix, const char * path_prefix)
-{
-    if (!path_prefix)
-        return guarded([] { fail(MSVS_ERR_INVALID_ARGUMENT, "null path"); });
-    StdioCtx c{path_prefix};
-    const msvs_io_t io = stdio_io(&c);
-    return msvs_index_serialize_io(ix, &io);
-}
-
-extern "C" int msvs_index_load(const char * path_prefix, msvs_index_t ** out)
-{
-    if (!path_prefix)
-        return guarded([] { fail(MSVS_ERR_INVALID_ARGUMENT, "null path"); });
-    StdioCtx c{path_prefix};
-    const msvs_io_t io = stdio_io(&c);
-    return msvs_index_load_io(&io, out);
-}
-
-/// Search::VectorIndex::getVersion().toString() -- what VIMetadata records as `version:` and hands back as the
-/// `load_index_version` parameter at load (VIWithDataPart.cpp:485, :645).
-extern "C" const char * msvs_index_version(void) { return "msvs-2"; }
-
-/// Search::VectorIndex::getResourceUsage() (VIWithDataPart.cpp:368-385, :486-488): bytes resident in HBM, bytes of the
-/// serialised file set, and the peak of the build (staging chunks + final storage).
-extern "C" int msvs_index_resource_usage(const msvs_index_t * ix, size_t * memory_usage_bytes, size_t * disk_usage_bytes,
-                                         size_t * build_memory_usage_bytes)
-{
-    return guarded([&] {
-        if (!ix)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
-        const size_t n = ix->ready ? ix->n : ix->staged, nlist = msvs_index_num_lists(ix);
-        const size_t disk = sizeof(DataHeader) + (ix->type == MSVS_INDEX_IVFFLAT ? nlist * ix->dim * 4 : 0) + (nlist + 1) * 8
-            + n * ix->dim * 4 + 8 + n * 8;
-        if (memory_usage_bytes)
-            *memory_usage_bytes = msvs_index_memory_usage(ix);
-        if (disk_usage_bytes)
-            *disk_usage_bytes = disk;
-        if (build_memory_usage_bytes)
-            *build_memory_usage_bytes = 2 * n * (size_t)ix->ld * 4 + n * 6 * ix->dim / 4 + n * 24;
-    });
-}
-
-// =========================================================================================== merge
-
-namespace msvs
-{
-static void merge_topk_device(const int64_t * d_ids, size_t ids_stride, const float * d_dis, size_t dis_stride,
-                              size_t nparts, size_t nq, size_t k, int metric, int64_t * d_out_ids, float * d_out_dis,
-                              hipStream_t stream)
-{
-    if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP)
-        fail(MSVS_ERR_NOT_IMPLEMENTED, "merge supports L2 / IP ordering (cosine distances are ascending: use L2)");
-    if (nq == 0 || k == 0)
-        return;
-    check_k(k);
-    Scratch & scr = scratch_for(stream);
-    const size_t total = nparts * nq * k;
-    scr.reserve(total * 8 + 8192, stream);
-    uint64_t * keys_q = scr.take<uint64_t>(total); // [nq][nparts][k]
-    if (metric == MSVS_METRIC_IP)
-        hipLaunchKernelGGL((pack_keys_kernel<M_IP>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, d_ids,
-                           ids_stride, d_dis, dis_stride, keys_q, (uint32_t)nparts, (uint32_t)nq, (uint32_t)k);
-    else
-        hipLaunchKernelGGL((pack_keys_kernel<M_L2>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, d_ids,
-                           ids_stride, d_dis, dis_stride, keys_q, (uint32_t)nparts, (uint32_t)nq, (uint32_t)k);
-    MSVS_HIP(hipGetLastError());
-    MergeParams m{};
-    m.partial = keys_q;
-    m.n_lists = (uint32_t)nparts;
-    m.k = (uint32_t)k;
-    m.out_ids = d_out_ids;
-    m.out_dis = d_out_dis;
-    launch_merge(scan_metric(metric), m, (uint32_t)nq, stream);
-}
-}
-
-extern "C" int msvs_merge_topk_device(const int64_t * d_ids, const float * d_dis, size_t nparts, size_t nq, size_t k,
-                                      int metric, int64_t * d_out_ids, float * d_out_dis, void * hip_stream)
-{
-    return guarded([&] {
-        if (nparts && nq && k && (!d_ids || !d_dis || !d_out_ids || !d_out_dis))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
-        merge_topk_device(d_ids, nq * k, d_dis, nq * k, nparts, nq, k, metric, d_out_ids, d_out_dis,
-                          as_stream(hip_stream));
-    });
-}
-
-extern "C" int msvs_merge_topk_device_strided(const int64_t * d_ids, size_t ids_part_stride, const float * d_dis,
-                                              size_t dis_part_stride, size_t nparts, size_t nq, size_t k, int metric,
-                                              int64_t * d_out_ids, float * d_out_dis, void * hip_stream)
-{
-    return guarded([&] {
-        if (nparts && nq && k && (!d_ids || !d_dis || !d_out_ids || !d_out_dis))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
-        if (ids_part_stride < nq * k || dis_part_stride < nq * k)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "part stride smaller than nq * k");
-        merge_topk_device(d_ids, ids_part_stride, d_dis, dis_part_stride, nparts, nq, k, metric, d_out_ids, d_out_dis,
-                          as_stream(hip_stream));
-    });
-}
-
-extern "C" int msvs_merge_topk(const int64_t * ids, const float * dis, size_t nparts, size_t nq, size_t k, int metric,
-                               int64_t * out_ids, float * out_dis)
-{
-    return guarded([&] {
-        if (nparts == 0 || nq == 0 || k == 0)
-            return;
-        if (!ids || !dis || !out_ids || !out_dis)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
-        const size_t total = nparts * nq * k;
-        DevBuf<int64_t> d_ids(total), d_oi(nq * k);
-        DevBuf<float> d_dis(total), d_od(nq * k);
-        MSVS_HIP(hipMemcpy(d_ids.p, ids, total * 8, hipMemcpyHostToDevice));
-        MSVS_HIP(hipMemcpy(d_dis.p, dis, total * 4, hipMemcpyHostToDevice));
-        merge_topk_device(d_ids.p, nq * k, d_dis.p, nq * k, nparts, nq, k, metric, d_oi.p, d_od.p, nullptr);
-        MSVS_HIP(hipMemcpy(out_ids, d_oi.p, nq * k * 8, hipMemcpyDeviceToHost));
-        MSVS_HIP(hipMemcpy(out_dis, d_od.p, nq * k * 4, hipMemcpyDeviceToHost));
-    });
-}
-
-// =========================================================================================== multi-GPU
-//
-// One process per GPU, lists sharded list_id % world (index params shard_rank / shard_world; FLAT: row ranges), centroids
-// replicated.  A sharded search is ONE call on ONE stream that owns its communicator -- RCCL over xGMI, straight from
-// rccl.h, no Python in the data path:
-//   1. the coarse quantiser is sharded BY QUERY: rank r ranks the centroids for queries [r c, (r + 1) c), c = ceil(nq / W),
-//      and ONE all-gather of c * nprobe int32 per rank gives every rank the probe lists of the whole batch -- nothing of
-//      the per-step work is replicated (round 1 ran coarse quantiser, plan and selection on every rank: Amdahl ~3x at 8);
-//   2. every rank scans its LOCAL probed lists for the whole batch (pairs that point at lists it does not own are dropped
-//      by the plan), exact local top-k straight into its slot of the packed exchange buffer {ids i64 | dis f32}[nq][k];
-//   3. ONE all-gather of nq * k * 12 B per rank, then the canonical W-way merge in place (identical on every rank) --
-//      the device-side getTotalTopSearchResultImpl (MergeTreeBaseSearchManager.cpp:207-299).
-// RCCL is resolved with dlopen at first use (the host process -- ClickHouse, or PyTorch in the bench -- may already carry
-// its own librccl: the loader then hands back that one instead of a second copy).
-#include <dlfcn.h>
-#include <rccl/rccl.h>
-
-namespace
-{
-struct RcclApi
-{
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    const char * (*GetErrorString)(ncclResult_t) = nullptr;
-};
-
-const RcclApi & rccl()
-{
-    static RcclApi api;
-    static std::once_flag once;
-    static std::string err;
-    std::call_once(once, [] {
-        void * h = nullptr;
-        for (const char * name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
-                break;
-        if (!h)
-        {
-            err = std::string("cannot load librccl: ") + dlerror();
-            return;
-        }
-        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
-        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather)
-            err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
-    });
-    if (!err.empty())
-        msvs::fail(MSVS_ERR_DEVICE, "%s", err.c_str());
-    return api;
-}
-
-void nccl_check(ncclResult_t r, const char * what)
-{
-    if (r != ncclSuccess)
-        msvs::fail(MSVS_ERR_DEVICE, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
-}
-}
-
-struct msvs_comm
-{
-    int nranks = 1, rank = 0;
-    ncclComm_t nccl = nullptr;
-    msvs_allgather_fn custom = nullptr;
-    void * ctx = nullptr;
-    /// every rank contributes `bytes` at d_buf + rank * bytes; afterwards d_buf holds all nranks slots (in place)
-    void all_gather(unsigned char * d_buf, size_t bytes, hipStream_t stream) const
-    {
-        if ((nranks == 1 && !nccl) || bytes == 0)
-            return;
-        if (custom)
-        {
-            if (custom(ctx, d_buf + (size_t)rank * bytes, d_buf, bytes, stream) != 0)
-                msvs::fail(MSVS_ERR_DEVICE, "the caller-supplied all-gather failed");
-            return;
-        }
-        nccl_check(rccl().AllGather(d_buf + (size_t)rank * bytes, d_buf, bytes, ncclInt8, nccl, stream), "ncclAllGather");
-    }
-};
-
-extern "C" int msvs_comm_unique_id(void * id_out)
-{
-    return guarded([&] {
-        static_assert(MSVS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
-        if (!id_out)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null id buffer");
-        ncclUniqueId id;
-        nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
-        memcpy(id_out, &id, sizeof(id));
-    });
-}
-
-extern "C" int msvs_comm_init(const void * id, int nranks, int rank, msvs_comm_t ** out)
-{
-    return guarded([&] {
-        if (!out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "bad communicator arguments");
-        std::unique_ptr<msvs_comm> c(new msvs_comm);
-        c->nranks = nranks;
-        c->rank = rank;
-        if (nranks > 1 || id) // a single rank WITH an id still gets a real RCCL communicator (self-test of the transport)
-        {
-            ncclUniqueId uid;
-            memcpy(&uid, id, sizeof(uid));
-            nccl_check(rccl().CommInitRank(&c->nccl, nranks, uid, rank), "ncclCommInitRank"); // on the current device
-        }
-        *out = c.release();
-    });
-}
-
-extern "C" int msvs_comm_init_custom(int nranks, int rank, msvs_allgather_fn all_gather, void * ctx, msvs_comm_t ** out)
-{
-    return guarded([&] {
-        if (!out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !all_gather))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "bad communicator arguments");
-        std::unique_ptr<msvs_comm> c(new msvs_comm);
-        c->nranks = nranks;
-        c->rank = rank;
-        c->custom = all_gather;
-        c->ctx = ctx;
-        *out = c.release();
-    });
-}
-
-extern "C" void msvs_comm_free(msvs_comm_t * c)
-{
-    if (!c)
-        return;
-    if (c->nccl)
-        (void)rccl().CommDestroy(c->nccl);
-    delete c;
-}
-
-extern "C" int msvs_comm_all_reduce_u64(const msvs_comm_t * comm, uint64_t * values, size_t n, void * hip_stream)
-{
-    return guarded([&] {
-        if (!comm || (n && !values))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null communicator / values");
-        if (n == 0 || (comm->nranks == 1 && !comm->nccl))
-            return;
-        // a few dozen counters (BM25: documents, tokens per column, document frequency per query term): one all-gather of
-        // every rank's vector on the communicator the searches use, summed locally -- the same transport whatever it is
-        // (RCCL or the caller's), no second collective type to support
-        hipStream_t stream = as_stream(hip_stream);
-        const size_t W = (size_t)comm->nranks, bytes = n * 8;
-        DevBuf<unsigned char> buf(W * bytes);
-        MSVS_HIP(hipMemcpyAsync(buf.p + (size_t)comm->rank * bytes, values, bytes, hipMemcpyHostToDevice, stream));
-        comm->all_gather(buf.p, bytes, stream);
-        std::vector<uint64_t> all(W * n);
-        MSVS_HIP(hipMemcpyAsync(all.data(), buf.p, W * bytes, hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipStreamSynchronize(stream));
-        for (size_t i = 0; i < n; i++)
-        {
-            uint64_t sum = 0;
-            for (size_t r = 0; r < W; r++)
-                sum += all[r * n + i];
-            values[i] = sum;
-        }
-    });
-}
-
-extern "C" int msvs_comm_rank(const msvs_comm_t * c) { return c ? c->rank : -1; }
-extern "C" int msvs_comm_size(const msvs_comm_t * c) { return c ? c->nranks : 0; }
-
-extern "C" int msvs_shard_search_device(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq,
-                                        int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
-                                        float * d_dis, void * hip_stream)
-{
-    return guarded([&] {
-        if (!ix || !comm || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index / communicator / buffer or negative k");
-        if (comm->nranks != ix->shard_world || comm->rank != ix->shard_rank)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "the index is shard %d of %d but the communicator is rank %d of %d", ix->shard_rank,
-                 ix->shard_world, comm->rank, comm->nranks);
-        hipStream_t stream = as_stream(hip_stream);
-        if (nq == 0 || k == 0)
-            return;
-        const auto meta = ix->get_meta();
-        size_t eff_bits = nbits;
-        const uint64_t * eff = effective_filter(*ix, meta.get(), d_alive_bits, nbits, &eff_bits, stream);
-        const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank;
-        if (W == 1 && !comm->nccl)
-        {
-            index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids, d_dis, stream);
-            apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
-            return;
-        }
-        const size_t part = round_up(nq * (size_t)k * 12, 16); // one rank's {ids | dis}
-        const bool ivf = ix->type == MSVS_INDEX_IVFFLAT;
-        const size_t np = ivf ? std::min<size_t>(std::max(nprobe, 1), ix->nlist) : 0;
-        const size_t chunk = ceil_div(nq, W);
-        Scratch & sh = shard_for(stream);
-        sh.reserve(W * part + W * chunk * np * 4 + 4096, stream);
-        unsigned char * packed = sh.take<unsigned char>(W * part);
-        int64_t * my_ids = reinterpret_cast<int64_t *>(packed + r * part);
-        float * my_dis = reinterpret_cast<float *>(packed + r * part + nq * (size_t)k * 8);
-        if (ivf)
-        {
-            int32_t * probes = sh.take<int32_t>(W * chunk * np);
-            int32_t * mine = probes + r * chunk * np;
-            const size_t q0 = std::min(nq, r * chunk), m = std::min(chunk, nq - q0);
-            MSVS_HIP(hipMemsetAsync(mine, 0xFF, chunk * np * 4, stream)); // queries past nq: no probes
-            if (m)
-                index_search_device(*ix, d_queries + q0 * ix->dim, m, 1, np, nullptr, 0, nullptr, nullptr, stream, nullptr, mine);
-            {
-                ProfileScope prof("shard_exchange", stream);
-                comm->all_gather(reinterpret_cast<unsigned char *>(probes), chunk * np * 4, stream);
-            }
-            index_search_device(*ix, d_queries, nq, (uint32_t)k, np, eff, eff_bits, my_ids, my_dis, stream, probes, nullptr);
-        }
-        else
-            index_search_device(*ix, d_queries, nq, (uint32_t)k, 0, eff, eff_bits, my_ids, my_dis, stream);
-        {
-            ProfileScope prof("shard_exchange", stream);
-            comm->all_gather(packed, part, stream);
-        }
-        // cosine distances leave the search as 1 - ip: ascending like L2
-        const int order = ix->metric == MSVS_METRIC_IP ? MSVS_METRIC_IP : MSVS_METRIC_L2;
-        merge_topk_device(reinterpret_cast<const int64_t *>(packed), part / 8,
-                          reinterpret_cast<const float *>(packed + nq * (size_t)k * 8), part / 4, W, nq, (size_t)k, order, d_ids,
-                          d_dis, stream);
-        apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
-    });
-}
 
 /// Experiments only (not in msvs.h): wall-clock stamps (100 MHz) of the last blocks of the two few-query launches.
 extern "C" __attribute__((visibility("default"))) int msvs_lat_debug(unsigned long long * out16)
