@@ -124,6 +124,9 @@ void normalize_device_rows(float * d_x, size_t n, uint32_t d, uint32_t ld, hipSt
 void upload_rows(float * dst, const float * src, size_t n, uint32_t d, uint32_t ld, int mem, hipStream_t stream);
 /// Row norms for the approximate pass and its error bound, then the fp16 shadows; called once the final storage is in place.
 void index_finalize_norms(msvs_index & ix, hipStream_t stream);
+uint32_t device_cu_count();
+/// The per-index queue of concurrent host callers forgets an index that is being freed (msvs_capi.hip).
+void combiner_forget(const msvs_index * ix);
 /// The search proper: all pointers on the device, everything enqueued on `stream` (msvs_capi.hip).  given_probes (nullable):
 /// [nq][nprobe] list ids computed elsewhere (another rank's share of the coarse quantiser): step 1 is skipped.  probes_only
 /// (nullable): run ONLY step 1 and leave the probe lists there.

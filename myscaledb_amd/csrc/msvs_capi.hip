@@ -208,147 +208,6 @@ void apply_row_ids_map(const msvs_index::Meta * meta, int64_t * d_ids, size_t n,
 }
 }
 
-/// The fp16 shadow of an IVF index (see h16_scan_kernels.hpp); called once the final storage and the norms are in place.
-static void index_build_shadow(msvs_index & ix, hipStream_t stream)
-{
-    ix.shadow_ready = false;
-    if (ix.type != MSVS_INDEX_IVFFLAT || !ix.want_shadow || ix.n == 0 || ix.nlist == 0 || !(ix.xnorm_max < 1e30f)
-        || ix.n > 0xfffffff0ull)
-        return;
-    DevBuf<uint32_t> mx(1);
-    MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
-    const size_t n4 = ix.n * (size_t)(ix.ld / 4);
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>(ceil_div(n4, (size_t)256), 4096)), dim3(256), 0,
-                       stream, reinterpret_cast<const float4 *>(ix.vecs.p), n4, mx.p);
-    MSVS_HIP(hipGetLastError());
-    uint32_t bits = 0;
-    MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
-    MSVS_HIP(hipStreamSynchronize(stream));
-    float maxabs;
-    memcpy(&maxabs, &bits, 4);
-    if (!(maxabs < 3.0e38f))
-        return;
-    int ex = 0;
-    if (maxabs > 0.f)
-        (void)frexpf(maxabs, &ex); // maxabs < 2^ex  =>  |x| * 2^(14 - ex) < 2^14: no fp16 overflow
-    const int sh = 14 - ex;
-    if (sh > 100 || sh < -100)
-        return; // the error model assumes the fp16 subnormal quantum is <= 2^-38 max|x|
-    ix.h_scale = ldexpf(1.f, sh);
-    ix.h_inv_scale = ldexpf(1.f, -sh);
-    ix.h_nch = (uint32_t)ceil_div(ix.dim, (size_t)H_CHUNK);
-    ix.h_nks = 4 * ix.h_nch; // whole chunks: the scan's inner loop has no tail
-    std::vector<uint32_t> hoff(ix.nlist + 1, 0);
-    std::vector<int64_t> mid(ix.nlist);
-    for (size_t l = 0; l < ix.nlist; l++)
-    {
-        const size_t len = (size_t)(ix.h_list_off[l + 1] - ix.h_list_off[l]);
-        const size_t nb = hoff[l] + ceil_div(len, (size_t)H_ROWS);
-        if (nb > 0xfffffff0ull)
-            return;
-        hoff[l + 1] = (uint32_t)nb;
-        mid[l] = std::min<int64_t>(ix.h_list_off[l] + H_ROWS, ix.h_list_off[l + 1]);
-    }
-    const size_t nblocks = hoff[ix.nlist];
-    std::vector<uint32_t> blk_list(nblocks);
-    for (size_t l = 0; l < ix.nlist; l++)
-        std::fill(blk_list.begin() + hoff[l], blk_list.begin() + hoff[l + 1], (uint32_t)l);
-    DevBuf<uint32_t> d_blk(std::max<size_t>(nblocks, 1));
-    ix.hoff.alloc(ix.nlist + 1);
-    ix.list_mid32.alloc(ix.nlist);
-    const size_t npieces = nblocks * (size_t)ix.h_nks * 64;
-    ix.shadow.alloc(npieces + 32768); // + 512 KiB: h16r_scan_kernel's load ring runs a few stages past the end of a list
-    MSVS_HIP(hipMemsetAsync(ix.shadow.p + npieces, 0, 32768 * sizeof(uint4), stream));
-    MSVS_HIP(hipMemcpyAsync(d_blk.p, blk_list.data(), nblocks * 4, hipMemcpyHostToDevice, stream));
-    MSVS_HIP(hipMemcpyAsync(ix.hoff.p, hoff.data(), (ix.nlist + 1) * 4, hipMemcpyHostToDevice, stream));
-    MSVS_HIP(hipMemcpyAsync(ix.list_mid32.p, mid.data(), ix.nlist * 8, hipMemcpyHostToDevice, stream));
-    const size_t per_launch = (size_t)1 << 30; // pieces per launch (grid dimension limit)
-    for (size_t p0 = 0; p0 < npieces; p0 += per_launch)
-    {
-        const size_t m = std::min(per_launch, npieces - p0);
-        // p0 is a multiple of 2^30 pieces; the kernel indexes from the start of the shadow, so shift the base
-        hipLaunchKernelGGL(h16_build_kernel, dim3((unsigned)ceil_div(m, (size_t)256)), dim3(256), 0, stream, ix.vecs.p,
-                           ix.ld, ix.list_off.p, d_blk.p, ix.hoff.p, ix.h_nks, ix.h_scale, ix.shadow.p, p0, m);
-    }
-    MSVS_HIP(hipGetLastError());
-    MSVS_HIP(hipStreamSynchronize(stream));
-    ix.shadow_ready = true;
-    // the centroid table in the same form (one list of nlist rows = G blocks), if it fits the rows' scale
-    ix.c_shadow_ready = false;
-    {
-        MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
-        const size_t c4 = ix.nlist * (size_t)(ix.ld / 4);
-        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>(ceil_div(c4, (size_t)256), 4096)), dim3(256), 0, stream,
-                           reinterpret_cast<const float4 *>(ix.centroids.p), c4, mx.p);
-        MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipStreamSynchronize(stream));
-        float cmax;
-        memcpy(&cmax, &bits, 4);
-        if (!(cmax <= maxabs) || !(ix.cnorm_max < 1e30f)) // user-supplied centroids may be larger than any row: no shadow then
-            return;
-        const size_t G = ceil_div(ix.nlist, (size_t)H_ROWS);
-        std::vector<uint32_t> c_hoff(G + 1), one_hoff = {0u, (uint32_t)G};
-        std::vector<int64_t> c_off(G + 1), one_off = {0, (int64_t)ix.nlist};
-        for (size_t g = 0; g <= G; g++)
-        {
-            c_hoff[g] = (uint32_t)g;
-            c_off[g] = (int64_t)std::min(g * H_ROWS, ix.nlist);
-        }
-        DevBuf<uint32_t> d_one_hoff(2), d_cblk(G);
-        DevBuf<int64_t> d_one_off(2);
-        MSVS_HIP(hipMemsetAsync(d_cblk.p, 0, G * 4, stream)); // every block belongs to list 0
-        MSVS_HIP(hipMemcpyAsync(d_one_hoff.p, one_hoff.data(), 8, hipMemcpyHostToDevice, stream));
-        MSVS_HIP(hipMemcpyAsync(d_one_off.p, one_off.data(), 16, hipMemcpyHostToDevice, stream));
-        ix.c_hoff.alloc(G + 1);
-        ix.c_list_off.alloc(G + 1);
-        MSVS_HIP(hipMemcpyAsync(ix.c_hoff.p, c_hoff.data(), (G + 1) * 4, hipMemcpyHostToDevice, stream));
-        MSVS_HIP(hipMemcpyAsync(ix.c_list_off.p, c_off.data(), (G + 1) * 8, hipMemcpyHostToDevice, stream));
-        const size_t cpieces = G * (size_t)ix.h_nks * 64;
-        ix.c_shadow.alloc(cpieces);
-        hipLaunchKernelGGL(h16_build_kernel, dim3((unsigned)ceil_div(cpieces, (size_t)256)), dim3(256), 0, stream, ix.centroids.p, ix.ld,
-                           d_one_off.p, d_cblk.p, d_one_hoff.p, ix.h_nks, ix.h_scale, ix.c_shadow.p, (size_t)0, cpieces);
-        MSVS_HIP(hipGetLastError());
-        MSVS_HIP(hipStreamSynchronize(stream));
-        ix.c_shadow_ready = true;
-    }
-}
-
-namespace msvs
-{
-/// Row norms for the approximate pass and its error bound; called once the final storage is in place.
-void index_finalize_norms(msvs_index & ix, hipStream_t stream)
-{
-    ix.xnorm.alloc(std::max<size_t>(ix.n, 1));
-    ix.xnorm_max = 0.f;
-    DevBuf<uint32_t> mx(1);
-    if (ix.type == MSVS_INDEX_IVFFLAT && ix.nlist)
-    {
-        std::vector<int64_t> mid(ix.nlist);
-        for (size_t l = 0; l < ix.nlist; l++)
-            mid[l] = std::min<int64_t>(ix.h_list_off[l] + BG_ROWS, ix.h_list_off[l + 1]);
-        ix.list_mid.alloc(ix.nlist);
-        MSVS_HIP(hipMemcpyAsync(ix.list_mid.p, mid.data(), ix.nlist * 8, hipMemcpyHostToDevice, stream));
-        MSVS_HIP(hipStreamSynchronize(stream));
-        ix.cnorm.alloc(ix.nlist);
-        MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
-        launch_row_sqnorm(ix.centroids.p, ix.cnorm.p, ix.nlist, ix.ld / 4, mx.p, stream);
-        uint32_t cb = 0;
-        MSVS_HIP(hipMemcpyAsync(&cb, mx.p, 4, hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipStreamSynchronize(stream));
-        memcpy(&ix.cnorm_max, &cb, 4);
-    }
-    if (ix.n == 0)
-        return;
-    MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
-    launch_row_sqnorm(ix.vecs.p, ix.xnorm.p, ix.n, ix.ld / 4, mx.p, stream);
-    uint32_t bits = 0;
-    MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
-    MSVS_HIP(hipStreamSynchronize(stream));
-    memcpy(&ix.xnorm_max, &bits, 4); // NaN / inf / huge values switch the candidate pass off (see plan_ivf)
-    index_build_shadow(ix, stream);
-}
-}
-
 /// Process-wide counters of the candidate passes (device side): [0] = result queries whose certificate failed, [1] = the
 /// same for the coarse quantiser's passes (probe lists).
 static unsigned long long * prefilter_fail_counter()
@@ -368,489 +227,6 @@ static unsigned long long * prefilter_fail_counter()
     return p;
 }
 static std::atomic<unsigned long long> g_prefilter_queries{0}, g_coarse_queries{0};
-
-static void index_assign(const msvs_index & ix, const float * d_x, size_t n, int32_t * d_assign, hipStream_t stream)
-{
-    DevBuf<float> cnorm(ix.nlist);
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)ceil_div(ix.nlist, 256)), dim3(256), 0, stream,
-                       ix.centroids.p, cnorm.p, (uint32_t)ix.nlist, (uint32_t)ix.dim, ix.ld);
-    unsigned grid = (unsigned)ceil_div(n, AS_TN);
-    if (ix.metric == MSVS_METRIC_L2)
-        hipLaunchKernelGGL((assign_kernel<false>), dim3(grid), dim3(256), 0, stream, d_x, n, ix.centroids.p, cnorm.p,
-                           (uint32_t)ix.nlist, (uint32_t)ix.dim, ix.ld, d_assign, (float *)nullptr);
-    else
-        hipLaunchKernelGGL((assign_kernel<true>), dim3(grid), dim3(256), 0, stream, d_x, n, ix.centroids.p, cnorm.p,
-                           (uint32_t)ix.nlist, (uint32_t)ix.dim, ix.ld, d_assign, (float *)nullptr);
-    MSVS_HIP(hipGetLastError());
-    MSVS_HIP(hipStreamSynchronize(stream));
-}
-
-
-extern "C" int msvs_index_create(int index_type, int metric, size_t dim, const char * params, msvs_index_t ** out)
-{
-    return guarded([&] {
-        if (!out)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "out is null");
-        *out = nullptr;
-        if (index_type != MSVS_INDEX_FLAT && index_type != MSVS_INDEX_IVFFLAT)
-            fail(MSVS_ERR_NOT_IMPLEMENTED, "index type %d is not implemented", index_type);
-        if (metric != MSVS_METRIC_L2 && metric != MSVS_METRIC_IP && metric != MSVS_METRIC_COSINE)
-            fail(MSVS_ERR_NOT_IMPLEMENTED, "metric %d is not implemented for Float32 vectors", metric);
-        if (dim == 0 || dim > 8192)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %zu out of range [1, 8192]", dim);
-        auto p = parse_params(params);
-        std::unique_ptr<msvs_index> ix(new msvs_index);
-        ix->type = index_type;
-        ix->metric = metric;
-        ix->dim = dim;
-        ix->ld = padded_dim(dim);
-        MSVS_HIP(hipGetDevice(&ix->device));
-        ix->ncentroids = (size_t)param_int(p, "ncentroids", 1024);
-        ix->kmeans_iters = (int)param_int(p, "kmeans_iters", 10);
-        ix->train_sample = (size_t)param_int(p, "train_sample", 0);
-        ix->seed = (uint64_t)param_int(p, "seed", 1234);
-        ix->shard_rank = (int)param_int(p, "shard_rank", 0);
-        ix->shard_world = (int)param_int(p, "shard_world", 1);
-        ix->want_shadow = (int)param_int(p, "shadow", 1);
-        if (ix->ncentroids == 0 || ix->shard_world < 1 || ix->shard_rank < 0 || ix->shard_rank >= ix->shard_world)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "bad ncentroids / shard parameters");
-        *out = ix.release();
-    });
-}
-
-namespace
-{
-void combiner_forget(const msvs_index * ix); // the per-index queue of concurrent host callers (below)
-}
-extern "C" void msvs_index_free(msvs_index_t * index)
-{
-    if (index)
-        combiner_forget(index);
-    delete index;
-}
-
-extern "C" int msvs_index_set_centroids(msvs_index_t * ix, const float * centroids, size_t nlist, int mem)
-{
-    return guarded([&] {
-        if (!ix || !centroids || nlist == 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/centroids");
-        if (ix->type != MSVS_INDEX_IVFFLAT)
-            return;
-        if (ix->staged || ix->ready)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "centroids must be set before data is added");
-        ix->nlist = nlist;
-        ix->centroids.alloc(nlist * ix->ld);
-        upload_rows(ix->centroids.p, centroids, nlist, (uint32_t)ix->dim, ix->ld, mem, nullptr);
-        MSVS_HIP(hipStreamSynchronize(nullptr));
-    });
-}
-
-extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, int mem)
-{
-    return guarded([&] {
-        if (!ix || (n && !x))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/data");
-        if (ix->type != MSVS_INDEX_IVFFLAT)
-            return;
-        if (ix->staged || ix->ready)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "train must precede add");
-        if (n == 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "no training data");
-        hipStream_t stream = nullptr;
-        const uint32_t d = (uint32_t)ix->dim, ld = ix->ld;
-        size_t nlist = std::min(ix->ncentroids, n);
-        size_t ns = ix->train_sample ? ix->train_sample : nlist * 64;
-        ns = std::min(ns, n);
-        // deterministic sample: a seeded partial Fisher-Yates over row indices
-        std::mt19937_64 rng(ix->seed);
-        std::vector<uint32_t> perm(n);
-        std::iota(perm.begin(), perm.end(), 0u);
-        for (size_t i = 0; i < ns; i++)
-        {
-            size_t j = i + (size_t)(rng() % (n - i));
-            std::swap(perm[i], perm[j]);
-        }
-        perm.resize(ns);
-        // stage the sample on the device (rows padded to ld)
-        DevBuf<float> xs(ns * ld);
-        {
-            DevBuf<uint32_t> d_idx(ns);
-            MSVS_HIP(hipMemcpyAsync(d_idx.p, perm.data(), ns * 4, hipMemcpyHostToDevice, stream));
-            if (mem == MSVS_MEM_DEVICE && ld == d)
-            {
-                size_t total = ns * (ld / 4);
-                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
-                                   reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(xs.p), d_idx.p, ns,
-                                   ld / 4);
-                MSVS_HIP(hipGetLastError());
-            }
-            else
-            {
-                // host data (or odd dimension): gather on the host, then upload
-                std::vector<float> hx;
-                const float * src = x;
-                if (mem == MSVS_MEM_DEVICE)
-                {
-                    hx.resize(n * d);
-                    MSVS_HIP(hipMemcpy(hx.data(), x, n * d * 4, hipMemcpyDeviceToHost));
-                    src = hx.data();
-                }
-                std::vector<float> g(ns * d);
-                for (size_t i = 0; i < ns; i++)
-                    memcpy(&g[i * d], src + (size_t)perm[i] * d, d * 4);
-                upload_rows(xs.p, g.data(), ns, d, ld, MSVS_MEM_HOST, stream);
-                MSVS_HIP(hipStreamSynchronize(stream));
-            }
-            MSVS_HIP(hipStreamSynchronize(stream));
-        }
-        if (ix->metric == MSVS_METRIC_COSINE)
-            normalize_device_rows(xs.p, ns, d, ld, stream);
-        // init: the first nlist sampled rows
-        ix->nlist = nlist;
-        ix->centroids.alloc(nlist * ld);
-        MSVS_HIP(hipMemcpyAsync(ix->centroids.p, xs.p, nlist * ld * 4, hipMemcpyDeviceToDevice, stream));
-        DevBuf<int32_t> d_assign(ns);
-        DevBuf<int64_t> d_off(nlist + 1);
-        DevBuf<uint32_t> d_members(ns);
-        std::vector<int32_t> h_assign(ns);
-        std::vector<int64_t> off(nlist + 1);
-        std::vector<uint32_t> members(ns);
-        for (int it = 0; it < ix->kmeans_iters; it++)
-        {
-            // Lloyd step: L2 assignment (IP/cosine indexes train on L2 too, like Faiss' default clustering)
-            msvs_index tmp_view;
-            (void)tmp_view;
-            int saved = ix->metric;
-            ix->metric = MSVS_METRIC_L2;
-            index_assign(*ix, xs.p, ns, d_assign.p, stream);
-            ix->metric = saved;
-            MSVS_HIP(hipMemcpy(h_assign.data(), d_assign.p, ns * 4, hipMemcpyDeviceToHost));
-            std::fill(off.begin(), off.end(), 0);
-            for (size_t i = 0; i < ns; i++)
-                off[h_assign[i] + 1]++;
-            for (size_t j = 0; j < nlist; j++)
-                off[j + 1] += off[j];
-            std::vector<int64_t> cur(off.begin(), off.end() - 1);
-            for (size_t i = 0; i < ns; i++)
-                members[cur[h_assign[i]]++] = (uint32_t)i;
-            MSVS_HIP(hipMemcpyAsync(d_off.p, off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, stream));
-            MSVS_HIP(hipMemcpyAsync(d_members.p, members.data(), ns * 4, hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)nlist), dim3(256), 0, stream, xs.p, d, ld,
-                               d_off.p, d_members.p, ix->centroids.p);
-            MSVS_HIP(hipGetLastError());
-            MSVS_HIP(hipStreamSynchronize(stream));
-            // Empty clusters are re-seeded the way Faiss' Clustering does (split_clusters; the library behind the reference's
-            // IVF indexes bundles it: BruteForceSearch.h:17,32): an empty cluster takes the centroid of a cluster drawn with
-            // probability ~ (size - 1), the two copies are pushed apart by a relative 1/1024 with alternating sign per dimension,
-            // and the donor's members count as split in halves for the next draw.  Without it a cluster that loses its members
-            // stays where it is for good (round 2: half of the lists <= 10 rows on iid data).
-            // ... "empty" here includes the nearly empty: a cluster holding less than 1/16 of the average is a centroid that
-            // fits a handful of sample points (on unstructured data it ends with a list of one or two rows); it is re-seeded
-            // like an empty one, except in the last iteration (its members would be left without their mean)
-            const bool last_it = it + 1 >= ix->kmeans_iters;
-            const size_t tiny = last_it ? 0 : ns / nlist / 16;
-            std::vector<char> give_up(nlist, 0); // clusters re-seeded although they have members
-            size_t nempty = 0;
-            for (size_t j = 0; j < nlist; j++)
-                nempty += (size_t)(off[j + 1] - off[j]) <= tiny;
-            // ... and the oversized: Lloyd's iteration cannot undo a seeding that put two centroids into one well-separated blob
-            // and none into another (the orphan blobs merge into a neighbour's list: 12 blobs in one list on SURVEY 8d's
-            // sigma-0.3 model).  While a cluster holds more than 2.5 x the average, the smallest cluster below 0.75 x the average
-            // gives its centroid up to split it; its members fall to their next centroid (the twin inside the same blob).
-            std::vector<std::pair<size_t, size_t>> forced; // (small cluster, the giant it splits)
-            if (!last_it && ns > 4 * nlist)
-            {
-                const double avg = (double)ns / (double)nlist;
-                std::vector<size_t> order(nlist);
-                std::iota(order.begin(), order.end(), (size_t)0);
-                std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
-                    const int64_t sx = off[x + 1] - off[x], sy = off[y + 1] - off[y];
-                    return sx != sy ? sx < sy : x < y;
-                });
-                size_t lo = 0, hi = nlist;
-                while (lo + 1 < hi)
-                {
-                    const size_t small = order[lo], big = order[hi - 1];
-                    const double ssz = (double)(off[small + 1] - off[small]), bsz = (double)(off[big + 1] - off[big]);
-                    if (!(bsz > 2.5 * avg && ssz < 0.75 * avg))
-                        break;
-                    if (ssz > (double)tiny) // the tiny ones are re-seeded by the draw below anyway
-                    {
-                        forced.push_back({small, big});
-                        give_up[small] = 1;
-                        hi--;
-                    }
-                    lo++;
-                }
-            }
-            if ((nempty || !forced.empty()) && ns > nlist)
-            {
-                std::vector<float> hc(nlist * ld);
-                MSVS_HIP(hipMemcpy(hc.data(), ix->centroids.p, nlist * ld * 4, hipMemcpyDeviceToHost));
-                std::vector<double> sz(nlist);
-                for (size_t j = 0; j < nlist; j++)
-                    sz[j] = (size_t)(off[j + 1] - off[j]) <= tiny ? 0.0 : (double)(off[j + 1] - off[j]);
-                const float feps = 1.f / 1024.f;
-                for (const auto & fs : forced)
-                {
-                    const size_t ci = fs.first, cj = fs.second;
-                    for (uint32_t c = 0; c < d; c++)
-                    {
-                        const float v = hc[cj * ld + c];
-                        hc[ci * ld + c] = v * (c % 2 == 0 ? 1 + feps : 1 - feps);
-                        hc[cj * ld + c] = v * (c % 2 == 0 ? 1 - feps : 1 + feps);
-                    }
-                    sz[ci] = std::floor(sz[cj] / 2);
-                    sz[cj] -= sz[ci];
-                }
-                std::mt19937_64 srng(ix->seed * 1315423911ull + (uint64_t)it);
-                std::uniform_real_distribution<double> uni(0.0, 1.0);
-                const double denom = (double)(ns - nlist);
-                for (size_t ci = 0; ci < nlist; ci++)
-                {
-                    if (sz[ci] != 0)
-                        continue;
-                    size_t cj = 0;
-                    for (size_t guard = 0; guard < 64 * nlist; guard++, cj = (cj + 1) % nlist)
-                        if (uni(srng) < (sz[cj] - 1.0) / denom)
-                            break;
-                    if (sz[cj] < 2)
-                        continue; // nothing left to split (more clusters than distinct points)
-                    const float eps = 1.f / 1024.f;
-                    for (uint32_t c = 0; c < d; c++)
-                    {
-                        const float v = hc[cj * ld + c];
-                        hc[ci * ld + c] = v * (c % 2 == 0 ? 1 + eps : 1 - eps);
-                        hc[cj * ld + c] = v * (c % 2 == 0 ? 1 - eps : 1 + eps);
-                    }
-                    sz[ci] = std::floor(sz[cj] / 2);
-                    sz[cj] -= sz[ci];
-                }
-                MSVS_HIP(hipMemcpy(ix->centroids.p, hc.data(), nlist * ld * 4, hipMemcpyHostToDevice));
-            }
-            ix->train_empty_last = nempty;
-        }
-    });
-}
-
-extern "C" int msvs_index_add(msvs_index_t * ix, const float * x, const int64_t * ids, size_t n, int mem)
-{
-    return guarded([&] {
-        if (!ix || (n && !x))
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/data");
-        if (ix->ready)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "index already built");
-        if (n == 0)
-            return;
-        if (ix->type == MSVS_INDEX_IVFFLAT && ix->nlist == 0)
-            fail(MSVS_ERR_NOT_READY, "IVFFLAT index must be trained (or given centroids) before add");
-        hipStream_t stream = nullptr;
-        const uint32_t d = (uint32_t)ix->dim, ld = ix->ld;
-        msvs_index::Chunk ch;
-        ch.n = n;
-        ch.x.alloc(n * ld);
-        upload_rows(ch.x.p, x, n, d, ld, mem, stream);
-        ch.ids.resize(n);
-        if (ids)
-        {
-            if (mem == MSVS_MEM_DEVICE)
-                MSVS_HIP(hipMemcpy(ch.ids.data(), ids, n * 8, hipMemcpyDeviceToHost));
-            else
-                memcpy(ch.ids.data(), ids, n * 8);
-            // distinct as long as every chunk is strictly ascending and starts above everything before it (what a part's row
-            // offsets look like); anything else may repeat a label
-            for (size_t i = 0; i < n && !ix->ids_may_repeat; i++)
-            {
-                if (ch.ids[i] <= ix->last_id)
-                    ix->ids_may_repeat = true;
-                ix->last_id = ch.ids[i];
-            }
-        }
-        else
-        {
-            for (size_t i = 0; i < n; i++)
-                ch.ids[i] = (int64_t)(ix->staged + i);
-            if ((int64_t)ix->staged <= ix->last_id)
-                ix->ids_may_repeat = true;
-            ix->last_id = (int64_t)(ix->staged + n - 1);
-        }
-        for (size_t i = 0; i < n; i++)
-            if (ch.ids[i] < 0 || ch.ids[i] > 0xfffffff0ll)
-                fail(MSVS_ERR_ID_RANGE, "id %lld does not fit the u32 label range", (long long)ch.ids[i]);
-        if (ix->metric == MSVS_METRIC_COSINE)
-            normalize_device_rows(ch.x.p, n, d, ld, stream);
-        if (ix->type == MSVS_INDEX_IVFFLAT)
-        {
-            DevBuf<int32_t> d_assign(n);
-            index_assign(*ix, ch.x.p, n, d_assign.p, stream);
-            ch.assign.resize(n);
-            MSVS_HIP(hipMemcpy(ch.assign.data(), d_assign.p, n * 4, hipMemcpyDeviceToHost));
-            if (ix->shard_world > 1)
-            {
-                // a shard keeps the rows of ITS lists only, and drops the others NOW: a rank that is shown all 100M rows of an
-                // 8-way sharded index stages 12.5M of them, not 100M (the labels were taken from the global staging order above)
-                std::vector<uint32_t> keep;
-                keep.reserve(n / (size_t)ix->shard_world + 16);
-                for (size_t i = 0; i < n; i++)
-                    if (ch.assign[i] % ix->shard_world == ix->shard_rank)
-                        keep.push_back((uint32_t)i);
-                if (keep.size() < n)
-                {
-                    const size_t m = keep.size();
-                    DevBuf<float> kept(std::max<size_t>(m, 1) * ld);
-                    if (m)
-                    {
-                        DevBuf<uint32_t> d_keep(m);
-                        MSVS_HIP(hipMemcpyAsync(d_keep.p, keep.data(), m * 4, hipMemcpyHostToDevice, stream));
-                        const size_t total = m * (ld / 4);
-                        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(total, (size_t)256)), dim3(256), 0, stream,
-                                           reinterpret_cast<const float4 *>(ch.x.p), reinterpret_cast<float4 *>(kept.p), d_keep.p, m, ld / 4);
-                        MSVS_HIP(hipGetLastError());
-                        MSVS_HIP(hipStreamSynchronize(stream));
-                    }
-                    for (size_t j = 0; j < m; j++)
-                    {
-                        ch.ids[j] = ch.ids[keep[j]];
-                        ch.assign[j] = ch.assign[keep[j]];
-                    }
-                    ch.ids.resize(m);
-                    ch.assign.resize(m);
-                    ch.x = std::move(kept);
-                    ch.n = m;
-                }
-            }
-        }
-        MSVS_HIP(hipStreamSynchronize(stream));
-        ix->staged += n;
-        if (ch.n)
-            ix->chunks.push_back(std::move(ch));
-    });
-}
-
-extern "C" int msvs_index_build(msvs_index_t * ix)
-{
-    return guarded([&] {
-        if (!ix)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
-        if (ix->ready)
-            return;
-        hipStream_t stream = nullptr;
-        const uint32_t ld = ix->ld;
-        const size_t nlist = ix->type == MSVS_INDEX_IVFFLAT ? ix->nlist : 1;
-        if (ix->type == MSVS_INDEX_IVFFLAT && nlist == 0)
-            fail(MSVS_ERR_NOT_READY, "IVFFLAT index has no centroids");
-        // rows kept on this shard, ordered by (list, id)
-        struct Ref
-        {
-            int32_t list;
-            uint32_t id;
-            uint32_t chunk;
-            uint32_t row;
-        };
-        std::vector<Ref> refs;
-        {
-            size_t held = 0;
-            for (const auto & ch : ix->chunks)
-                held += ch.n;
-            refs.reserve(held);
-        }
-        for (size_t c = 0; c < ix->chunks.size(); c++)
-        {
-            const auto & ch = ix->chunks[c];
-            for (size_t i = 0; i < ch.n; i++)
-            {
-                int32_t l = ix->type == MSVS_INDEX_IVFFLAT ? ch.assign[i] : 0;
-                if (ix->type == MSVS_INDEX_IVFFLAT && ix->shard_world > 1 && l % ix->shard_world != ix->shard_rank)
-                    continue;
-                if (ix->type == MSVS_INDEX_FLAT && ix->shard_world > 1)
-                {
-                    // FLAT shards by contiguous id ranges of the staged order
-                    size_t g = 0;
-                    for (size_t cc = 0; cc < c; cc++)
-                        g += ix->chunks[cc].n;
-                    g += i;
-                    size_t per = ceil_div(ix->staged, (size_t)ix->shard_world);
-                    if (g / per != (size_t)ix->shard_rank)
-                        continue;
-                }
-                refs.push_back({l, (uint32_t)ch.ids[i], (uint32_t)c, (uint32_t)i});
-            }
-        }
-        std::stable_sort(refs.begin(), refs.end(), [](const Ref & a, const Ref & b) {
-            return a.list != b.list ? a.list < b.list : a.id < b.id;
-        });
-        const size_t n = refs.size();
-        ix->n = n;
-        ix->h_list_off.assign(nlist + 1, 0);
-        ix->max_id = 0;
-        for (const auto & r : refs)
-        {
-            ix->h_list_off[r.list + 1]++;
-            ix->max_id = std::max<uint64_t>(ix->max_id, r.id);
-        }
-        ix->max_list_len = 0;
-        for (size_t l = 0; l < nlist; l++)
-        {
-            ix->max_list_len = std::max<size_t>(ix->max_list_len, (size_t)ix->h_list_off[l + 1]);
-            ix->h_list_off[l + 1] += ix->h_list_off[l];
-        }
-        ix->vecs.alloc(std::max<size_t>(n, 1) * ld);
-        ix->row_ids.alloc(std::max<size_t>(n, 1));
-        ix->list_off.alloc(nlist + 1);
-        std::vector<uint32_t> h_ids(n);
-        std::vector<std::vector<uint32_t>> pos(ix->chunks.size());
-        std::vector<std::vector<uint32_t>> src(ix->chunks.size());
-        for (size_t p = 0; p < n; p++)
-        {
-            h_ids[p] = refs[p].id;
-            pos[refs[p].chunk].push_back((uint32_t)p);
-            src[refs[p].chunk].push_back(refs[p].row);
-        }
-        for (size_t c = 0; c < ix->chunks.size(); c++)
-        {
-            size_t m = pos[c].size();
-            if (m)
-            {
-                // gather the kept rows of the chunk, then scatter them to their list-major positions
-                DevBuf<uint32_t> d_src(m), d_pos(m);
-                DevBuf<float> tmp(m * ld);
-                MSVS_HIP(hipMemcpyAsync(d_src.p, src[c].data(), m * 4, hipMemcpyHostToDevice, stream));
-                MSVS_HIP(hipMemcpyAsync(d_pos.p, pos[c].data(), m * 4, hipMemcpyHostToDevice, stream));
-                size_t total = m * (ld / 4);
-                hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
-                                   reinterpret_cast<const float4 *>(ix->chunks[c].x.p),
-                                   reinterpret_cast<float4 *>(tmp.p), d_src.p, m, ld / 4);
-                hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
-                                   reinterpret_cast<const float4 *>(tmp.p), reinterpret_cast<float4 *>(ix->vecs.p),
-                                   d_pos.p, m, ld / 4);
-                MSVS_HIP(hipGetLastError());
-                MSVS_HIP(hipStreamSynchronize(stream));
-            }
-            ix->chunks[c].x.release();
-        }
-        if (n)
-            MSVS_HIP(hipMemcpy(ix->row_ids.p, h_ids.data(), n * 4, hipMemcpyHostToDevice));
-        MSVS_HIP(hipMemcpy(ix->list_off.p, ix->h_list_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice));
-        ix->chunks.clear();
-        index_finalize_norms(*ix, stream);
-        MSVS_HIP(hipDeviceSynchronize()); // searches run on other (per-thread, non-blocking) streams
-        ix->ready = true;
-    });
-}
-
-extern "C" int msvs_index_ready(const msvs_index_t * ix) { return ix && ix->ready ? 1 : 0; }
-extern "C" size_t msvs_index_num_data(const msvs_index_t * ix) { return ix ? (ix->ready ? ix->n : ix->staged) : 0; }
-extern "C" size_t msvs_index_num_lists(const msvs_index_t * ix)
-{
-    return ix ? (ix->type == MSVS_INDEX_IVFFLAT ? ix->nlist : 1) : 0;
-}
-extern "C" size_t msvs_index_memory_usage(const msvs_index_t * ix)
-{
-    return ix ? ix->vecs.bytes() + ix->row_ids.bytes() + ix->centroids.bytes() + ix->list_off.bytes()
-            + ix->xnorm.bytes() + ix->cnorm.bytes() + ix->list_mid.bytes() + ix->shadow.bytes() + ix->hoff.bytes()
-            + ix->list_mid32.bytes()
-              : 0;
-}
 
 namespace msvs
 {
@@ -1136,7 +512,6 @@ static void run_fallback_rounds(int metric, ScanParams c, IvfMergeParams fm, siz
 }
 
 static void set_error_model_h16(RerankParams & rp, size_t dim);
-static uint32_t device_cu_count();
 
 /// Second half of a table pass, whatever produced the candidates: canonical re-rank + certificate, then the canonical scan
 /// of the table for the queries on the fail list.
@@ -1450,7 +825,7 @@ static void h16_dispatch(uint32_t ncb, bool nt, uint32_t grid, size_t lds, const
     }
 }
 
-static uint32_t device_cu_count()
+uint32_t device_cu_count()
 {
     static std::mutex mu;
     static std::map<int, uint32_t> cus;
@@ -2025,538 +1400,6 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
 
 }
 
-// ------------------------------------------------------------------------------------------ few-query path
-
-namespace
-{
-/// Buffers of the two-launch search (latency_kernels.hpp) of one (host thread, stream): grow-only, reused call after call.
-struct LatCtx
-{
-    DevBuf<float> dq;
-    DevBuf<int32_t> probes;
-    DevBuf<uint64_t> c_partial, partial;
-    DevBuf<uint32_t> done;
-    // host side (pinned, device-visible): queries in, results + completion word out
-    unsigned char * pinned = nullptr;
-    size_t pinned_bytes = 0;
-    uint32_t seq = 0;
-    void need_pinned(size_t bytes)
-    {
-        if (bytes <= pinned_bytes)
-            return;
-        if (pinned)
-            MSVS_HIP(hipHostFree(pinned));
-        pinned = nullptr;
-        pinned_bytes = 0;
-        MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), bytes, hipHostMallocCoherent)); // fine-grained whatever HIP_HOST_COHERENT says
-        pinned_bytes = bytes;
-        memset(pinned, 0, bytes);
-    }
-};
-
-LatCtx & lat_ctx(hipStream_t stream)
-{
-    static thread_local std::map<std::pair<int, hipStream_t>, LatCtx> ctxs;
-    int dev = 0;
-    MSVS_HIP(hipGetDevice(&dev));
-    return ctxs[{dev, stream}];
-}
-
-unsigned long long * g_lat_dbg = nullptr; // experiments: msvs_lat_debug()
-
-struct LatShape
-{
-    uint32_t c_rows, c_blocks, items, grid_x;
-    size_t lds1, lds2;
-};
-
-LatShape lat_shape(const msvs_index & ix, size_t nq, size_t k, size_t nprobe)
-{
-    LatShape s{};
-    // stage 1: 32 centroids per block, more when all blocks' lists would not fit the LDS of a stage-2 block
-    s.c_rows = (uint32_t)(32 * ceil_div(ix.nlist * nprobe, (size_t)32 * HEADS_CAP));
-    s.c_blocks = (uint32_t)ceil_div(ix.nlist, (size_t)s.c_rows);
-    // work items per query: the grid (items + nprobe) is exactly 2 blocks per CU over the whole call -- a CU streams
-    // ~22 KB/us whatever runs on it, so one CU with a third block sets the time of the launch (27 us against 19)
-    s.items = (uint32_t)std::max<size_t>(nprobe, 2 * (size_t)device_cu_count() / nq > nprobe ? 2 * (size_t)device_cu_count() / nq - nprobe : nprobe);
-    s.grid_x = s.items + (uint32_t)nprobe;
-    s.lds1 = (size_t)ix.ld * 4 + std::max((size_t)5 * nprobe * 8, lat_merge_lds(s.c_blocks, (uint32_t)nprobe));
-    s.lds2 = (size_t)ix.ld * 4 + std::max((size_t)5 * k * 8, lat_merge_lds(s.grid_x, (uint32_t)k));
-    return s;
-}
-
-bool lat_eligible(const msvs_index & ix, size_t nq, size_t k, size_t nprobe)
-{
-    // beyond two queries per call the general path's batched kernels are as fast (201 vs 195 us at 4 queries)
-    if (options().lat_path == 0 || ix.type != MSVS_INDEX_IVFFLAT || !ix.ready || ix.n == 0 || nq < 1
-        || nq > std::min<size_t>(LAT_MAX_Q, options().lat_path >= 2 ? LAT_MAX_Q : 2) || k < 1
-        || k > LAT_MAX_K)
-        return false;
-    nprobe = std::min<size_t>(std::max<size_t>(nprobe, 1), ix.nlist);
-    if (nprobe > LAT_MAX_K)
-        return false;
-    const LatShape s = lat_shape(ix, nq, k, nprobe);
-    return s.lds1 <= SCAN_LDS_BUDGET && s.lds2 <= SCAN_LDS_BUDGET;
-}
-
-/// Enqueue the two launches.  Q: nq scan-ready rows of ix.ld floats (device or pinned host memory).
-void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, uint32_t k, size_t nprobe, const uint64_t * d_alive,
-                size_t nbits, int64_t * out_ids, float * out_dis, uint32_t * flag, uint32_t seq, hipStream_t stream)
-{
-    nprobe = std::min<size_t>(std::max<size_t>(nprobe, 1), ix.nlist);
-    const uint32_t ld4 = ix.ld / 4;
-    LatParams p{};
-    p.Q = reinterpret_cast<const float4 *>(Q);
-    p.nq = (uint32_t)nq;
-    p.ld4 = ld4;
-    p.k = k;
-    p.nprobe = (uint32_t)nprobe;
-    p.nlist = (uint32_t)ix.nlist;
-    p.C = reinterpret_cast<const float4 *>(ix.centroids.p);
-    const LatShape sh = lat_shape(ix, nq, k, nprobe);
-    p.c_rows = sh.c_rows;
-    p.c_blocks = sh.c_blocks;
-    p.items = sh.items;
-    p.reg_select = (int)options().lat_select; // 1: radix select, 3: bitwise search, 0: list merge
-    const size_t grid_x = sh.grid_x;
-    const size_t n_dq = LAT_MAX_Q * (size_t)ix.ld, n_cp = nq * (size_t)p.c_blocks * nprobe, n_part = nq * grid_x * k;
-    const bool grow = c.dq.n < n_dq || c.c_partial.n < n_cp || c.partial.n < n_part || !c.done.p;
-    if (grow)
-    {
-        MSVS_HIP(hipStreamSynchronize(stream)); // an earlier call on this stream may still use the old buffers
-        if (c.dq.n < n_dq)
-            c.dq.alloc(n_dq);
-        if (!c.probes.p)
-            c.probes.alloc(LAT_MAX_Q * LAT_MAX_K);
-        if (c.c_partial.n < n_cp)
-            c.c_partial.alloc(n_cp + n_cp / 2);
-        if (c.partial.n < n_part)
-            c.partial.alloc(n_part + n_part / 2);
-        if (!c.done.p)
-        {
-            c.done.alloc(2);
-            MSVS_HIP(hipMemset(c.done.p, 0, 8));
-            MSVS_HIP(hipDeviceSynchronize());
-        }
-    }
-    p.dq = reinterpret_cast<float4 *>(c.dq.p);
-    p.c_partial = c.c_partial.p;
-    p.probes = c.probes.p;
-    p.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
-    p.ids = ix.row_ids.p;
-    p.list_off = ix.list_off.p;
-    p.alive = d_alive;
-    p.nbits = (uint32_t)std::min<size_t>(nbits, 0xffffffffu);
-    p.partial = c.partial.p;
-    p.out_ids = out_ids;
-    p.out_dis = out_dis;
-    p.cosine = ix.metric == MSVS_METRIC_COSINE;
-    p.done = c.done.p;
-    p.flag = flag;
-    p.seq = seq;
-    p.dbg = g_lat_dbg;
-    const size_t lds1 = sh.lds1, lds2 = sh.lds2;
-    const dim3 g1(p.c_blocks, (unsigned)nq), g2((unsigned)grid_x, (unsigned)nq);
-    ProfileScope prof("lat_search", stream);
-    if (ix.metric == MSVS_METRIC_L2)
-    {
-        hipLaunchKernelGGL((lat_coarse_kernel<M_L2>), g1, dim3(BLOCK), lds1, stream, p);
-        hipLaunchKernelGGL((lat_scan_kernel<M_L2>), g2, dim3(BLOCK), lds2, stream, p);
-    }
-    else
-    {
-        hipLaunchKernelGGL((lat_coarse_kernel<M_IP>), g1, dim3(BLOCK), lds1, stream, p);
-        hipLaunchKernelGGL((lat_scan_kernel<M_IP>), g2, dim3(BLOCK), lds2, stream, p);
-    }
-    MSVS_HIP(hipGetLastError());
-}
-
-/// VectorDataset::normalize() of one row on the host: the arithmetic of normalize_rows_kernel (strictly sequential f32
-/// sum of squares, IEEE sqrt and divide), so a query prepared here equals one prepared on the device bit for bit.
-void normalize_row_host(float * p, uint32_t d)
-{
-    volatile float sum = 0.f;
-    for (uint32_t j = 0; j < d; j++)
-    {
-        volatile float sq = p[j] * p[j];
-        sum = sum + sq;
-    }
-    if (sum < 1.1920928955078125e-7f)
-        return;
-    const float s = sqrtf(sum);
-    for (uint32_t j = 0; j < d; j++)
-        p[j] = p[j] / s;
-}
-
-/// Host-pointer search of a few queries: queries go in through pinned memory the kernels read directly, results and a
-/// completion word come back the same way (no memcpy calls, no stream synchronisation: the host thread spins on the
-/// word).  d_alive: the effective filter, already on the device and ordered on `stream`.
-void lat_search_host(const msvs_index & ix, const float * queries, size_t nq, uint32_t k, size_t nprobe, const uint64_t * d_alive,
-                     size_t nbits, int64_t * ids, float * dis, hipStream_t stream)
-{
-    LatCtx & c = lat_ctx(stream);
-    const size_t ld = ix.ld, o_ids = round_up(LAT_MAX_Q * ld * 4, (size_t)256), o_dis = o_ids + LAT_MAX_Q * LAT_MAX_K * 8,
-                 o_flag = o_dis + LAT_MAX_Q * LAT_MAX_K * 4;
-    c.need_pinned(o_flag + 256);
-    float * hq = reinterpret_cast<float *>(c.pinned);
-    for (size_t q = 0; q < nq; q++)
-    {
-        float * row = hq + q * ld;
-        memcpy(row, queries + q * ix.dim, ix.dim * 4);
-        for (size_t j = ix.dim; j < ld; j++)
-            row[j] = 0.f;
-        if (ix.metric == MSVS_METRIC_COSINE)
-            normalize_row_host(row, (uint32_t)ix.dim);
-    }
-    volatile uint32_t * flag = reinterpret_cast<volatile uint32_t *>(c.pinned + o_flag);
-    const uint32_t seq = ++c.seq ? c.seq : ++c.seq; // never 0: the word starts at 0
-    int64_t * h_ids = reinterpret_cast<int64_t *>(c.pinned + o_ids);
-    float * h_dis = reinterpret_cast<float *>(c.pinned + o_dis);
-    lat_launch(ix, c, hq, nq, k, nprobe, d_alive, nbits, h_ids, h_dis, const_cast<uint32_t *>(flag), seq, stream);
-    // acquire: the copies of the results below are ordered after the word (a volatile read alone orders nothing for the compiler)
-    for (uint64_t spins = 1; __atomic_load_n(const_cast<const uint32_t *>(flag), __ATOMIC_ACQUIRE) != seq; spins++)
-    {
-        __builtin_ia32_pause();
-        if ((spins & 0xfff) == 0) // a failed launch never sets the word: look at the stream now and then
-        {
-            const hipError_t e = hipStreamQuery(stream);
-            if (e == hipSuccess)
-                break;
-            if (e != hipErrorNotReady)
-                fail(MSVS_ERR_DEVICE, "few-query search: %s", hipGetErrorString(e));
-        }
-    }
-    if (*flag != seq)
-        MSVS_HIP(hipStreamSynchronize(stream));
-    memcpy(ids, h_ids, nq * k * 8);
-    memcpy(dis, h_dis, nq * k * 4);
-}
-}
-
-extern "C" int msvs_index_search_device(const msvs_index_t * ix, const float * d_queries, size_t nq, int k, int nprobe,
-                                        const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids, float * d_dis,
-                                        void * hip_stream)
-{
-    return guarded([&] {
-        if (!ix || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/buffer or negative k");
-        const auto meta = ix->get_meta();
-        size_t eff_bits = nbits;
-        const uint64_t * eff = effective_filter(*ix, meta.get(), d_alive_bits, nbits, &eff_bits, as_stream(hip_stream));
-        if (k > 0 && lat_eligible(*ix, nq, (size_t)k, (size_t)std::max(nprobe, 0)) && ix->ld == ix->dim && ix->metric != MSVS_METRIC_COSINE)
-            // a few scan-ready queries: two launches (latency_kernels.hpp)
-            lat_launch(*ix, lat_ctx(as_stream(hip_stream)), d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids,
-                       d_dis, nullptr, 0, as_stream(hip_stream));
-        else
-            index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids, d_dis,
-                                as_stream(hip_stream));
-        apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, as_stream(hip_stream));
-    });
-}
-
-
-namespace msvs
-{
-int index_search_host_call(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
-                                  const uint64_t * alive_bits, size_t nbits, int64_t * ids, float * dis)
-{
-    return guarded([&] {
-        if (!ix || (nq && (!queries || !ids || !dis)) || k < 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index/buffer or negative k");
-        if (!ix->ready)
-            fail(MSVS_ERR_NOT_READY, "index is not ready");
-        if (nq == 0 || k == 0)
-            return;
-        if ((size_t)k > MSVS_MAX_K_ROUNDS)
-            fail(MSVS_ERR_UNSUPPORTED_K, "k = %d exceeds the limit %d", k, MSVS_MAX_K_ROUNDS);
-        auto p = parse_params(params);
-        for (const auto & kv : p)
-            if (kv.first != "nprobe")
-                fail(MSVS_ERR_INVALID_ARGUMENT, "unknown search parameter `%s`", kv.first.c_str());
-        long nprobe = param_int(p, "nprobe", 1);
-        if (nprobe < 1)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "nprobe must be >= 1");
-        hipStream_t stream = thread_stream();
-        // a filter that is PRESENT with zero valid bits means "no row passes" (not "no filter"): it still travels as one
-        // zero word with nbits = 0, and every id fails the `id < nbits` test
-        const bool filtered = alive_bits != nullptr;
-        const size_t words = filtered ? std::max<size_t>(1, ceil_div(nbits, 64)) : 0;
-        // host staging lives in its own arena (scratch_for() belongs to the device-level search underneath)
-        Scratch & stg = staging_for(stream);
-        stg.reserve(nq * ix->dim * 4 + nq * (size_t)k * 12 + words * 8 + 4096, stream);
-        const DevView<float> dq{stg.take<float>(nq * ix->dim)};
-        const DevView<int64_t> d_ids{stg.take<int64_t>(nq * (size_t)k)};
-        const DevView<float> d_dis{stg.take<float>(nq * (size_t)k)};
-        const DevView<uint64_t> d_alive{words ? stg.take<uint64_t>(words) : nullptr};
-        if (filtered)
-        {
-            MSVS_HIP(hipMemsetAsync(d_alive.p, 0, words * 8, stream));
-            if (nbits)
-                MSVS_HIP(hipMemcpyAsync(d_alive.p, alive_bits, ceil_div(nbits, 64) * 8, hipMemcpyHostToDevice, stream));
-        }
-        const auto meta = ix->get_meta();
-        size_t eff_bits = nbits;
-        const uint64_t * eff = effective_filter(*ix, meta.get(), words ? d_alive.p : nullptr, nbits, &eff_bits, stream);
-        const bool eff_filtered = eff != nullptr;
-        if (lat_eligible(*ix, nq, (size_t)k, (size_t)nprobe) && !(meta && meta->row_ids_n))
-        {
-            // a few queries: two launches, queries and results through pinned memory (no copies, no stream sync)
-            lat_search_host(*ix, queries, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, ids, dis, stream);
-            return;
-        }
-        MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
-        if ((size_t)k <= MSVS_MAX_K && filtered)
-        {
-            // the strategy (bit test / compacted view) goes by how many rows the caller's bitmap lets through
-            uint64_t alive_count = 0;
-            for (size_t w = 0; w < ceil_div(nbits, (size_t)64); w++)
-                alive_count += (uint64_t)__builtin_popcountll(alive_bits[w]);
-            index_search_filtered(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, alive_count, d_ids.p, d_dis.p, stream);
-        }
-        else if ((size_t)k <= MSVS_MAX_K)
-            index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, d_ids.p, d_dis.p, stream);
-        else
-        {
-            // k beyond one wavefront top-k pass: rounds of MSVS_MAX_K per query, each round excluding the rows already
-            // returned through a private copy of the filter bitmap (exact: round r returns ranks 256r .. 256r+255)
-            const size_t idspace = std::max<size_t>(eff_filtered ? eff_bits : 0, (size_t)ix->max_id + 1);
-            const size_t bw = ceil_div(idspace, 64);
-            DevBuf<uint64_t> bm(bw);
-            for (size_t q = 0; q < nq; q++)
-            {
-                if (eff_filtered)
-                {
-                    MSVS_HIP(hipMemsetAsync(bm.p, 0, bw * 8, stream));
-                    MSVS_HIP(hipMemcpyAsync(bm.p, eff, std::max<size_t>(1, ceil_div(eff_bits, (size_t)64)) * 8,
-                                            hipMemcpyDeviceToDevice, stream));
-                }
-                else
-                    MSVS_HIP(hipMemsetAsync(bm.p, 0xFF, bw * 8, stream));
-                for (size_t done = 0; done < (size_t)k; done += MSVS_MAX_K)
-                {
-                    const uint32_t kr = (uint32_t)std::min<size_t>(MSVS_MAX_K, (size_t)k - done);
-                    int64_t * oi = d_ids.p + q * (size_t)k + done;
-                    index_search_device(*ix, dq.p + q * ix->dim, 1, kr, (size_t)nprobe, bm.p, eff_filtered ? eff_bits : idspace,
-                                        oi, d_dis.p + q * (size_t)k + done, stream);
-                    hipLaunchKernelGGL(clear_bits_kernel, dim3(1), dim3(256), 0, stream, bm.p, oi, kr);
-                    MSVS_HIP(hipGetLastError());
-                }
-            }
-        }
-        apply_row_ids_map(meta.get(), d_ids.p, nq * (size_t)k, stream);
-        MSVS_HIP(hipMemcpyAsync(ids, d_ids.p, nq * (size_t)k * 8, hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipMemcpyAsync(dis, d_dis.p, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream));
-        MSVS_HIP(hipStreamSynchronize(stream));
-    });
-}
-}
-
-// ------------------------------------------------------------------------------------------ combining concurrent callers
-//
-// The reference's host calls VectorIndex::search from up to ScanThreadLimiter-many threads, one query each
-// (MergeTreeVSManager.cpp:973).  One query is a whole-GPU job of ~55 us here, so beyond a handful of concurrent callers the
-// calls only queue behind each other on the device (64 threads: 26 k QPS), while ONE batched search of 64 queries takes
-// 0.37 ms (170 k QPS).  So: up to `combine` (8) single calls run directly, each on its thread's stream, exactly as
-// before, as long as nobody waits; callers beyond that wait in a queue, and the next call to finish while no batch is in
-// flight hands the lead to the first waiter together with EVERY compatible waiter's query (same k, same parameter string,
-// no filter) -- that thread runs them as one batch and distributes the rows; while a batch runs, new callers queue up for
-// the next one.  No timer, no extra latency for a lone caller; results are the same bits either way (every path is
-// exact).  msvs_combine_stats counts the batches.
-namespace
-{
-struct CombineReq
-{
-    const float * q;
-    size_t nq;
-    int k;
-    std::string params;
-    int64_t * ids;
-    float * dis;
-    int status = 0;
-    std::string err;
-    int state = 0; // 0 waiting, 1 leader of `batch`, 2 served
-    std::vector<CombineReq *> batch;
-    std::condition_variable cv;
-};
-struct Combiner
-{
-    std::mutex mu;
-    std::deque<CombineReq *> queue;
-    int active = 0;  // leaders running (single calls and batches)
-    int batches = 0; // ... of which batches of several callers
-};
-std::mutex g_comb_mu;
-std::unordered_map<const msvs_index *, std::shared_ptr<Combiner>> g_comb;
-std::atomic<unsigned long long> g_comb_calls{0}, g_comb_batches{0}, g_comb_batched{0};
-constexpr size_t COMBINE_MAX_QUERIES = 1024;
-
-std::shared_ptr<Combiner> combiner_of(const msvs_index * ix)
-{
-    std::lock_guard<std::mutex> lk(g_comb_mu);
-    auto & c = g_comb[ix];
-    if (!c)
-        c = std::make_shared<Combiner>();
-    return c;
-}
-void combiner_forget(const msvs_index * ix)
-{
-    std::lock_guard<std::mutex> lk(g_comb_mu);
-    g_comb.erase(ix);
-}
-
-/// Runs the leader's batch: one request = the plain call into its own buffers; several = one gathered search.
-void combine_run(const msvs_index * ix, CombineReq & lead)
-{
-    auto & b = lead.batch;
-    if (b.size() == 1)
-    {
-        lead.status = index_search_host_call(ix, lead.q, lead.nq, lead.k, lead.params.c_str(), nullptr, 0, lead.ids, lead.dis);
-        if (lead.status)
-            lead.err = msvs_last_error();
-        return;
-    }
-    size_t total = 0;
-    for (auto * r : b)
-        total += r->nq;
-    const size_t d = ix->dim, k = (size_t)lead.k;
-    static thread_local std::vector<float> qbuf, dbuf;
-    static thread_local std::vector<int64_t> ibuf;
-    qbuf.resize(total * d);
-    ibuf.resize(total * k);
-    dbuf.resize(total * k);
-    size_t at = 0;
-    for (auto * r : b)
-    {
-        memcpy(qbuf.data() + at * d, r->q, r->nq * d * 4);
-        at += r->nq;
-    }
-    const int rc = index_search_host_call(ix, qbuf.data(), total, lead.k, lead.params.c_str(), nullptr, 0, ibuf.data(), dbuf.data());
-    const std::string err = rc ? msvs_last_error() : "";
-    at = 0;
-    for (auto * r : b)
-    {
-        if (!rc)
-        {
-            memcpy(r->ids, ibuf.data() + at * k, r->nq * k * 8);
-            memcpy(r->dis, dbuf.data() + at * k, r->nq * k * 4);
-        }
-        r->status = rc;
-        r->err = err;
-        at += r->nq;
-    }
-    g_comb_batches.fetch_add(1, std::memory_order_relaxed);
-    g_comb_batched.fetch_add(total, std::memory_order_relaxed);
-}
-
-int combined_search(const msvs_index * ix, const float * queries, size_t nq, int k, const char * params, int64_t * ids, float * dis)
-{
-    const int max_direct = (int)options().combine;
-    auto comb = combiner_of(ix); // keeps the combiner alive across a concurrent msvs_index_free (which is a caller bug anyway)
-    Combiner & c = *comb;
-    CombineReq me;
-    me.q = queries;
-    me.nq = nq;
-    me.k = k;
-    me.params = params ? params : "";
-    me.ids = ids;
-    me.dis = dis;
-    g_comb_calls.fetch_add(1, std::memory_order_relaxed);
-    std::unique_lock<std::mutex> lk(c.mu);
-    // direct while nobody waits and no batch is in flight (a batch uses the whole device well; single calls next to it
-    // would only slow it down and keep the next batch small)
-    const int max_batches = std::max(1, (int)options().combine_batches);
-    if (c.active == 0 || (c.active < max_direct && c.queue.empty() && c.batches == 0))
-    {
-        c.active++;
-        me.batch.assign(1, &me);
-    }
-    else
-    {
-        c.queue.push_back(&me);
-        me.cv.wait(lk, [&] { return me.state != 0; });
-        if (me.state == 2)
-        {
-            lk.unlock();
-            if (me.status)
-                set_last_error(me.err);
-            return me.status;
-        }
-    }
-    lk.unlock();
-    try
-    {
-        combine_run(ix, me); // the C entry underneath translates its own exceptions; what is left is the gather's allocation
-    }
-    catch (...)
-    {
-        for (auto * r : me.batch)
-        {
-            r->status = MSVS_ERR_OUT_OF_MEMORY;
-            r->err = "host allocation failed while combining concurrent searches";
-        }
-    }
-    lk.lock();
-    for (auto * r : me.batch)
-        if (r != &me)
-        {
-            r->state = 2;
-            r->cv.notify_one();
-        }
-    c.active--;
-    if (me.batch.size() > 1)
-        c.batches--;
-    if (!c.queue.empty() && c.batches < max_batches)
-    {
-        // the first waiter leads next, with every compatible waiter's queries (waiters with another k / parameter string
-        // follow when this batch is done)
-        c.active++;
-        CombineReq * next = c.queue.front();
-        c.queue.pop_front();
-        next->batch.assign(1, next);
-        size_t total = next->nq;
-        for (auto it = c.queue.begin(); it != c.queue.end() && total < COMBINE_MAX_QUERIES;)
-            if ((*it)->k == next->k && (*it)->params == next->params && total + (*it)->nq <= COMBINE_MAX_QUERIES)
-            {
-                total += (*it)->nq;
-                next->batch.push_back(*it);
-                it = c.queue.erase(it);
-            }
-            else
-                ++it;
-        if (next->batch.size() > 1)
-            c.batches++;
-        next->state = 1;
-        next->cv.notify_one();
-    }
-    lk.unlock();
-    if (me.status)
-        set_last_error(me.err);
-    return me.status;
-}
-}
-
-extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries, size_t nq, int k, const char * params,
-                                 const uint64_t * alive_bits, size_t nbits, int64_t * ids, float * dis)
-{
-    // few unfiltered queries on a ready index: through the combiner (anything else, and every argument error, directly)
-    if (options().combine >= 1 && ix && ix->ready && nq >= 1 && nq <= 4 && !alive_bits && queries && ids && dis && k >= 1
-        && (size_t)k <= MSVS_MAX_K)
-        return combined_search(ix, queries, nq, k, params, ids, dis);
-    return index_search_host_call(ix, queries, nq, k, params, alive_bits, nbits, ids, dis);
-}
-
-/// calls that went through the combiner, batches of more than one caller, queries served by such batches
-extern "C" int msvs_combine_stats(uint64_t * calls, uint64_t * batches, uint64_t * batched_queries)
-{
-    if (calls)
-        *calls = g_comb_calls.load();
-    if (batches)
-        *batches = g_comb_batches.load();
-    if (batched_queries)
-        *batched_queries = g_comb_batched.load();
-    return MSVS_OK;
-}
-
 /// The row-id maps of a decoupled part (SegmentId::getMergedMaps, VIWithDataPart.cpp:722): once set, a search takes its
 /// filter in the MERGED part's row space (getRealBitmap) and reports the MERGED part's rows (transferToNewRowIds).
 extern "C" int msvs_index_set_merged_maps(msvs_index_t * ix, const uint64_t * row_ids_map, size_t n_old,
@@ -2747,20 +1590,6 @@ extern "C" int msvs_profile_reset(void)
 }
 
 
-/// Experiments only (not in msvs.h): wall-clock stamps (100 MHz) of the last blocks of the two few-query launches.
-extern "C" __attribute__((visibility("default"))) int msvs_lat_debug(unsigned long long * out16)
-{
-    return guarded([&] {
-        if (!g_lat_dbg)
-        {
-            MSVS_HIP(hipMalloc(&g_lat_dbg, 16 * 8));
-            MSVS_HIP(hipMemset(g_lat_dbg, 0, 16 * 8));
-        }
-        MSVS_HIP(hipDeviceSynchronize());
-        if (out16)
-            MSVS_HIP(hipMemcpy(out16, g_lat_dbg, 16 * 8, hipMemcpyDeviceToHost));
-    });
-}
 
 /// Tests only (not in msvs.h): the candidate keys of this thread's last shadow pass -- (ordered approximate distance << 32 |
 /// stored row position) -- up to cap_out per query, and how many each query has.
