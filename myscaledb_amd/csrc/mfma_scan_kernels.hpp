@@ -957,6 +957,8 @@ struct RerankParams
     unsigned long long * stat_fail; // nullable: process-wide running total
     unsigned long long * stat_skip; // nullable (experiments): [0] += candidates beyond e_k +- eps, [1] += candidates
     int early_exit; // rounds after the first ceil(k / 16) skip candidates whose approximate value is beyond e_k +- eps
+    int band; // probe lists (out_probes) only: candidates that are certainly inside / outside the exact top-k by their approximate
+              // values alone are not evaluated (see ivf_rerank_kernel)
     uint64_t * ek_out; // nullable [nq]: a query WITHOUT a certificate leaves the k-th exact key of the candidates it evaluated here
                        // (KEY_NONE: fewer than k) -- an upper bound of its true k-th distance for the second chance
 };
@@ -987,6 +989,92 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
         keys[c] = KEY_NONE;
     __syncthreads();
     const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
+    // BAND (probe lists): only the SET of the k best rows leaves this kernel, and most of it is decided by the approximate
+    // values alone.  With a_(k), a_(k+1) the k-th and (k+1)-th smallest approximate values of the candidates and
+    // |a - exact| <= eps for every row: a candidate with a + 2 eps < a_(k+1) is beaten by at most the k - 1 other rows of
+    // approximate rank <= k (everything else has exact >= a_(k+1) - eps > a + eps) -- certainly IN; one with a - 2 eps > a_(k)
+    // is beaten by the k rows of approximate rank <= k -- certainly OUT, and so is every row that is not a candidate when
+    // min(last, bound) - 2 eps > a_(k).  The rest, the band around the boundary, is evaluated canonically and fills the
+    // remaining slots in exact order.  On the bench step 3-4 of 64 centroid rows per query instead of 64 (45 -> ~10 us).
+    __shared__ uint8_t s_state[64 * R]; // 0: evaluate, 1: certainly in, 2: certainly out
+    __shared__ uint64_t s_ak, s_ak1;
+    __shared__ uint32_t s_nin;
+    __shared__ int s_band;
+    if (a.band && a.out_probes && kc > a.k && kc <= 16 * G)
+    {
+        if (tid < kc)
+            keys[tid] = a.cand[(size_t)q * kc + tid];
+        if (tid == 0)
+        {
+            s_ak = s_ak1 = KEY_NONE;
+            s_nin = 0;
+            s_band = 0;
+        }
+        __syncthreads();
+        const uint64_t mine = tid < kc ? keys[tid] : KEY_NONE;
+        if (mine != KEY_NONE)
+        {
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < kc; j++)
+                rank += keys[j] < mine || (keys[j] == mine && j < tid) ? 1u : 0u;
+            if (rank == a.k - 1)
+                s_ak = mine;
+            if (rank == a.k)
+                s_ak1 = mine;
+        }
+        __syncthreads();
+        const float qn = a.qnorm[q];
+        const bool usable = s_ak != KEY_NONE && s_ak1 != KEY_NONE && qn < 1e30f && a.xmax < 1e30f;
+        double eps2 = 0.0, ak = 0.0, ak1 = 0.0;
+        bool band_ok = usable;
+        if (usable)
+        {
+            eps2 = 2.0 * rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn * 1.001));
+            ak = (double)key_value<METRIC>(s_ak);
+            ak1 = (double)key_value<METRIC>(s_ak1);
+            uint64_t last = keys[kc - 1]; // the candidates' largest approximate value comes last; KEY_NONE: every row is a candidate
+            if (a.bound && a.bound[q] < last)
+                last = a.bound[q];
+            if (last != KEY_NONE)
+            {
+                const double al = (double)key_value<METRIC>(last);
+                band_ok = METRIC == M_L2 ? (al - eps2 > ak) : (al + eps2 < ak);
+            }
+        }
+        if (band_ok && tid < kc)
+        {
+            uint8_t st = 2;
+            if (mine != KEY_NONE)
+            {
+                const double aj = (double)key_value<METRIC>(mine);
+                const bool in = METRIC == M_L2 ? (aj + eps2 < ak1) : (aj - eps2 > ak1);
+                const bool out = METRIC == M_L2 ? (aj - eps2 > ak) : (aj + eps2 < ak);
+                st = in ? 1 : (out ? 2 : 0);
+                if (in)
+                {
+                    const uint32_t pos = (uint32_t)mine;
+                    a.out_probes[(size_t)q * a.k + atomicAdd(&s_nin, 1u)] = (int32_t)(a.ids ? a.ids[pos] : pos);
+                }
+            }
+            s_state[tid] = st;
+        }
+        if (tid == 0)
+            s_band = band_ok ? 1 : 0;
+        __syncthreads();
+        if (tid < kc)
+            keys[tid] = KEY_NONE;
+        __syncthreads();
+    }
+    else
+    {
+        if (tid == 0)
+        {
+            s_band = 0;
+            s_nin = 0;
+        }
+        __syncthreads();
+    }
+    const bool band = s_band != 0;
     // Early exit: the candidates arrive in ascending approximate order, G per round.  Once the first ceil(k / G) rounds
     // have given an exact k-th distance e, a later candidate with approximate value a beyond e by more than the error
     // bound (a - eps > e: its exact distance is > e >= the final k-th) cannot enter the result: its row is not read
@@ -1029,7 +1117,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
             __syncthreads();
         }
         const uint64_t ck = a.cand[(size_t)q * kc + c]; // uniform over the 16 lanes that own candidate c
-        if (ck == KEY_NONE)
+        if (ck == KEY_NONE || (band && s_state[c] != 0))
             continue;
         if (c - grp >= first && s_skip)
         {
@@ -1071,7 +1159,13 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
         uint32_t rank = 0;
         for (uint32_t j = 0; j < 64 * R; j++)
             rank += keys[j] < mine || (keys[j] == mine && j < i) ? 1u : 0u;
-        if (rank < a.k)
+        if (band)
+        {
+            // the band's rows fill the slots the certainly-in rows left, in exact order
+            if (mine != KEY_NONE && s_nin + rank < a.k)
+                a.out_probes[(size_t)q * a.k + s_nin + rank] = (int32_t)(uint32_t)mine;
+        }
+        else if (rank < a.k)
         {
             const size_t o = (size_t)q * a.k + rank;
             if (a.out_probes)
@@ -1087,7 +1181,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
         }
     }
     __syncthreads();
-    if (wave != 0)
+    if (wave != 0 || band) // (a band that could be formed IS the certificate)
         return;
     // certificate (see the header comment): `last` = the smallest approximate key a non-candidate row can have; a
     // candidate list that is not full (and no truncated slice) holds every probed row

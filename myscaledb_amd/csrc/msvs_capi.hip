@@ -542,6 +542,7 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
     rp.failq = failq;
     rp.nfail = nfail;
     rp.early_exit = options().rerank_early != 0 && !t.out_probes ? 1 : 0; // result passes only: the centroid table gains nothing
+    rp.band = t.out_probes && h16 && options().coarse_band != 0 ? 1 : 0;
     rp.stat_fail = prefilter_fail_counter() + (t.out_probes ? 1 : 0); // msvs_prefilter_stats / msvs_coarse_stats
     rp.stat_skip = options().rerank_stats != 0 ? prefilter_fail_counter() + (t.out_probes ? 4 : 2) : nullptr;
     if (t.out_probes)

@@ -535,6 +535,44 @@ def test_shadow_pass_serves_k_up_to_128_with_256_candidates(metric, opt):
     assert capi.prefilter_stats()[0] == q2
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("data", ["blobs", "iid", "tied_centroids"])
+def test_coarse_band_decides_most_probes_without_reading_the_centroids(metric, data, opt):
+    """The coarse quantiser of a batch (centroid shadow -> 64 candidates -> exact top-nprobe): candidates whose approximate
+    value puts them certainly inside / outside the top-nprobe are not evaluated canonically (coarse_band, default), only the
+    band around the boundary is.  The probe SET must be the oracle's whatever the data does to the band: well separated
+    centroids (band of a few rows), iid centroids (band = most candidates), groups of IDENTICAL centroids (the boundary falls
+    inside a tie: decided by id).  Results == the oracle's with the band on and off."""
+    rng = np.random.default_rng({"blobs": 5, "iid": 6, "tied_centroids": 7}[data] + metric)
+    n, d, nlist, nq, nprobe, k = 40000, 96, 256, 512, 20, 10
+    if data == "blobs":
+        centres = 3.0 * rng.standard_normal((nlist, d), dtype=np.float32)
+        x = (centres[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+        q = (centres[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+        ix = build_ivf(x, metric, nlist)
+    else:
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        q = rng.standard_normal((nq, d), dtype=np.float32)
+        if data == "iid":
+            ix = build_ivf(x, metric, nlist)
+        else:
+            base = rng.standard_normal((16, d), dtype=np.float32)  # 16 distinct centroids, each 16 times
+            cent = np.repeat(base, nlist // 16, axis=0)[rng.permutation(nlist)]
+            ix = capi.Index(capi.INDEX_IVFFLAT, metric, d, "ncentroids=%d" % nlist)
+            ix.set_centroids(cent if metric != capi.METRIC_COSINE else o.normalize_rows(cent))
+            ix.add(x)
+            ix.build()
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+    for band in ("1", "0"):
+        opt("coarse_band", band)
+        c0 = capi.coarse_stats()
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+        c1 = capi.coarse_stats()
+        assert c1[0] - c0[0] == nq, "the batch did not go through the centroid-shadow pass"
+    opt("coarse_band", None)
+
+
 def test_second_chance_rerank_of_the_whole_candidate_buffer(opt):
     """Distances that concentrate (gaussian blobs of sigma 0.3 in a few hundred dimensions: the 10th and the 32nd neighbour of a
     query are a couple of error bounds apart) fail the first certificate -- k-th exact distance against the kc-th approximate
