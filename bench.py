@@ -364,6 +364,15 @@ def main():
     pf1 = capi.prefilter_stats()
     cand_pass = pf1[0] > pf0[0]
     scan_ms = fam["ivf_scan"] + fam["ivf_sample_scan"]
+    # share of the step's (query, list) pairs the probe pruning proved useless and kept out of the main launch (two counted steps)
+    capi.set_option("rerank_stats", "1")
+    ps0 = capi.debug_prune_stats()
+    for i in range(2):
+        step(i)
+    torch.cuda.synchronize()
+    ps1 = capi.debug_prune_stats()
+    capi.set_option("rerank_stats", None)
+    pruned_frac = (ps1[0] - ps0[0]) / float(ps1[1] - ps0[1]) if ps1[1] > ps0[1] else 0.0
     sr = [ix.scanned_rows(q_all[(i % n_pool) * B:(i % n_pool + 1) * B].cpu().numpy(), nprobe) for i in range(n_prof)]
     rows_model = sum(r[0] for r in sr) / n_prof   # sum over (query, probed list) of list length (SURVEY 8d per-query model)
     rows_unique = sum(r[2] for r in sr) / n_prof  # rows probed by >= 1 query of the batch: must leave HBM once
@@ -404,8 +413,9 @@ def main():
         "mfma_tflops": round(mfma_tf, 1), "mfma_frac_of_2500": round(mfma_tf / 2500.0, 4),
         "per_query_model_gbs": round(rows_model * (4 * d + 4) / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else None,
         "prefilter": [pf1[0] - pf0[0], pf1[1] - pf0[1]],
+        "pruned_pair_fraction": round(pruned_frac, 4),
         "step_kernels_ms": {f: round(v, 4) for f, v in fam.items() if v},
-        "note": "achieved / frac = the bytes the two launches have to read -- union of the step's probed rows x (2d + 8) B: the fp16 "
+        "note": "achieved / frac = the bytes the two launches have to read -- union of the step's probed rows (the rows the reference's scan visits: every probed list, whatever the probe pruning keeps out of the main launch) x (2d + 8) B: the fp16 "
                 "shadow row, its f32 norm and its id -- / (sample + main launch time, HIP events on the launch stream); "
                 "whole_step_* = the same bytes over the whole step; f32_equiv_* = the same rows x (4d + 4) B (SURVEY 8d's "
                 "per-row figure: credits bytes that never move, can exceed 1); traffic = FETCH_SIZE (x2, gfx950) + WRITE_SIZE of both "

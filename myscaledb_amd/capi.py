@@ -668,6 +668,13 @@ def hybrid_fuse_device(fusion, d_vec_dis, d_vec_ids, kv, d_txt_scores, d_txt_ids
                                          C.c_void_p(stream)))
 
 
+def debug_prune_stats():
+    """(pairs the probe pruning of the shadow list scan dropped, pairs it looked at) -- counted only under rerank_stats = 1."""
+    out = (C.c_uint64 * 2)()
+    _check(lib().msvs_debug_prune_stats(out))
+    return int(out[0]), int(out[1])
+
+
 def bm25_stats():
     """(queries through the sample / emit path, of which fallbacks)."""
     q, f = C.c_uint64(0), C.c_uint64(0)

@@ -725,10 +725,34 @@ __device__ inline uint32_t h16_cut_floor(const uint32_t (&word)[NW], uint32_t cu
     return floor_word > cut ? floor_word : cut;
 }
 
+/// PROBE PRUNING (L2; round 3).  The oracle scans all nprobe lists of a query; most of them cannot hold one of its k nearest rows,
+/// and that can be PROVED before the main launch: the k-th smallest approximate distance among the query's sample rows (real,
+/// probed, unfiltered rows) plus eps is an upper bound U of its k-th best canonical distance; a row x of list l has
+/// ||q - x|| >= ||q - c_l|| - r_l (triangle inequality, r_l = the list's radius: ivf_build_kernels.hpp), ||q - c_l||^2 is known
+/// from the coarse pass to within eps_c.  A pair (q, l) with (sqrt(a_c - 2 eps_c) - r_l)^2 > U + 2 eps_x holds only rows whose
+/// canonical distance is strictly beyond the k-th best: dropping it from the plan of the main launch cannot change the result
+/// (the sample rows it contributed stay candidates: they are real rows of probed lists).  On data with cluster structure most
+/// pairs go -- a list is then probed by a third of the queries, ONE tile instead of two, and the launch reads every list once:
+/// 548 -> ~300 us per 4096-query step on the bench index; on iid data nothing is dropped and the second plan costs ~20 us.
+struct H16Prune
+{
+    const uint32_t * coarse_words; // [nq][npad]: the coarse pass's approximate distance word of every centroid; nullptr: no pruning
+    uint32_t npad;
+    const float * radius; // [nlist]
+    const float * cnorm;  // [nlist] |c_l|^2 (cosine form only)
+    int ip;               // 0: L2 index; 1: cosine index (unit rows and queries, the scan ranks by inner product)
+    const float * qnorm;  // |q|^2 (+inf: unusable)
+    float xmax, cmax;     // max |x|^2 over the rows / the centroids
+    double c_dot, c_norm, c_canon; // the shadow passes' error model
+    uint32_t k;
+    int32_t * out_probes;      // [nq][nprobe]: the probes that survive (-1: dropped or absent)
+    unsigned long long * stat; // nullable: [0] += pairs dropped, [1] += pairs
+};
+
 template <int NW>
 __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t * qprobes, const int64_t * list_off, uint32_t nprobe,
                                            uint32_t target, uint32_t * qthr, uint32_t * qcnt, uint64_t * dst, uint32_t cap,
-                                           uint32_t lane, uint32_t * hist, const H16CutFloor & fl, uint32_t q)
+                                           uint32_t lane, uint32_t * hist, const H16CutFloor & fl, uint32_t q, const H16Prune & pr)
 {
     const uint32_t n = nprobe * H_ROWS;
     uint32_t word[NW];
@@ -762,7 +786,64 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
     }
     uint32_t m = rows ? (uint32_t)(((uint64_t)target * have + rows - 1) / rows) : 4u;
     m = m < 4 ? 4 : (m > 64 ? 64 : m);
+    if (pr.coarse_words && m < pr.k)
+        m = pr.k; // the cut doubles as the pruning's upper bound: at least k sample rows must lie at or below it (one selection, not two)
     uint32_t cut = target == 0 ? 0xFFFFFFFFu : wave_kth_word<NW>(word, m, hist, lane);
+    if (pr.coarse_words)
+    {
+        // the m-th smallest sample word, m >= k (0xFFFFFFFF: fewer than m sample rows -- no bound, nothing is dropped)
+        const uint32_t uw = target != 0 ? cut : wave_kth_word<NW>(word, pr.k, hist, lane);
+        const int32_t l = lane < nprobe ? qprobes[lane] : -1;
+        bool keep = true;
+        const float qn = pr.qnorm[q];
+        if (uw != 0xFFFFFFFFu && l >= 0 && qn < 1e30f && pr.xmax < 1e30f && pr.cmax < 1e30f)
+        {
+            const double sq = sqrt((double)qn * 1.001), sx = sqrt((double)pr.xmax * 1.001), sc = sqrt((double)pr.cmax * 1.001);
+            if (!pr.ip)
+            {
+                const double eps_x = 2.0 * pr.c_dot * sx * sq + pr.c_norm * (sx * sx + sq * sq) + (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30;
+                const double eps_c = 2.0 * pr.c_dot * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
+                const double ak = (double)ord2f(uw), ac = (double)ord2f(pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l]);
+                const double inner = ac - 2.0 * eps_c;
+                if (inner > 0.0)
+                {
+                    const double dc = sqrt(inner) * (1.0 - 1e-7), r = (double)pr.radius[l];
+                    if (dc > r)
+                        keep = !((dc - r) * (dc - r) * (1.0 - 1e-7) > ak + 2.0 * eps_x);
+                }
+            }
+            else
+            {
+                // cosine index: the words order inner products (larger is better).  ||q - c||^2 = |q|^2 + |c|^2 - 2 <q, c> from the
+                // coarse pass's <q, c> and the (f32, fma-accumulated: relative error c_norm) norms; a row x of the list has
+                // ||q - x|| >= ||q - c|| - r_l, i.e. <q, x> <= (|q|^2 + |x|^2 - (||q - c|| - r_l)^2) / 2
+                const double eps_x = (pr.c_dot + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.c_dot + pr.c_canon) * sc * sq + 1e-30;
+                const double ipk = (double)ord2f(~uw), ipc = (double)ord2f(~pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l]);
+                const double cn = (double)pr.cnorm[l];
+                const double d2 = (double)qn * (1.0 - pr.c_norm) + cn * (1.0 - pr.c_norm) - 2.0 * (ipc + eps_c);
+                if (d2 > 0.0)
+                {
+                    const double dc = sqrt(d2) * (1.0 - 1e-7), r = (double)pr.radius[l];
+                    if (dc > r)
+                    {
+                        const double ub = 0.5 * (((double)qn + (double)pr.xmax) * (1.0 + pr.c_norm) - (dc - r) * (dc - r) * (1.0 - 1e-7));
+                        keep = !(ub < ipk - 2.0 * eps_x);
+                    }
+                }
+            }
+        }
+        if (lane < nprobe)
+            pr.out_probes[(size_t)q * nprobe + lane] = keep ? l : -1;
+        if (pr.stat)
+        {
+            const uint64_t dropped = __ballot(l >= 0 && !keep), all = __ballot(l >= 0);
+            if (lane == 0)
+            {
+                atomicAdd(pr.stat, (unsigned long long)__popcll(dropped));
+                atomicAdd(pr.stat + 1, (unsigned long long)__popcll(all));
+            }
+        }
+    }
     if (fl.qnorm && cut != 0xFFFFFFFFu)
         cut = h16_cut_floor<NW>(word, cut, fl, q);
     uint32_t count = 0;
@@ -789,7 +870,8 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
 static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_wave_kernel(const uint32_t * sample, const int32_t * probes,
                                                                             const int64_t * list_off, uint32_t nq, uint32_t nprobe,
                                                                             uint32_t target, uint32_t * qthr, uint32_t * qcnt,
-                                                                            uint64_t * partial, uint32_t cap, int radix, const H16CutFloor fl)
+                                                                            uint64_t * partial, uint32_t cap, int radix, const H16CutFloor fl,
+                                                                            const H16Prune pr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -800,13 +882,13 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_wave_kernel(const
     const int32_t * qp = probes + (size_t)q * nprobe;
     uint64_t * dst = partial + (size_t)q * cap;
     if (nprobe <= 8)
-        h16_sample_thr_wave<4>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q);
+        h16_sample_thr_wave<4>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q, pr);
     else if (nprobe <= 16)
-        h16_sample_thr_wave<8>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q);
+        h16_sample_thr_wave<8>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q, pr);
     else if (nprobe <= 32)
-        h16_sample_thr_wave<16>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q);
+        h16_sample_thr_wave<16>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q, pr);
     else
-        h16_sample_thr_wave<32>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q);
+        h16_sample_thr_wave<32>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q, pr);
 }
 
 static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint32_t * sample, const int32_t * probes,

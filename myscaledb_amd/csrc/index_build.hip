@@ -154,6 +154,15 @@ void index_finalize_norms(msvs_index & ix, hipStream_t stream)
     MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
     MSVS_HIP(hipStreamSynchronize(stream));
     memcpy(&ix.xnorm_max, &bits, 4); // NaN / inf / huge values switch the candidate pass off (see plan_ivf)
+    if (ix.type == MSVS_INDEX_IVFFLAT && ix.nlist && ix.metric != MSVS_METRIC_IP)
+    {
+        // how far a list's rows lie from its centroid at most: lets a batched search drop (query, list) pairs that provably
+        // cannot hold one of the query's k nearest rows (triangle inequality; h16_list_scan)
+        ix.list_radius.alloc(ix.nlist);
+        hipLaunchKernelGGL(list_radius_kernel, dim3((unsigned)ix.nlist), dim3(256), 0, stream, ix.vecs.p, ix.centroids.p, ix.list_off.p,
+                           (uint32_t)ix.dim, ix.ld, ix.list_radius.p);
+        MSVS_HIP(hipGetLastError());
+    }
     index_build_shadow(ix, stream);
 }
 }

@@ -52,6 +52,7 @@ struct msvs_index
     DevBuf<float> xnorm;
     float xnorm_max = 0.f;
     DevBuf<float> cnorm; // same for the centroids (the coarse quantiser goes through the same pass)
+    DevBuf<float> list_radius; // nlist: an upper bound of max ||x - c_l|| over the rows of list l (probe pruning, L2 / cosine)
     float cnorm_max = 0.f;
     DevBuf<int64_t> list_mid; // nlist: end of the SAMPLE slice of list l = min(list_off[l] + 128, list_off[l+1])
     // fp16 shadow of the lists (h16_scan_kernels.hpp): the list scan of batched searches reads this instead of vecs

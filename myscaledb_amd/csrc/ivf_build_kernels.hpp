@@ -209,4 +209,46 @@ static __global__ void gather_rows_kernel(const float4 * __restrict__ src, float
     dst[i] = src[(size_t)idx[r] * ld4 + c];
 }
 
+
+/// radius[l] = an upper bound of max over the rows x of list l of ||x - c_l|| (Euclidean), one block per list: differences and sums
+/// in double (the inputs are exact f32: the error is ~1e-13 relative), the square root rounded up and widened by 1e-6.  What the
+/// probe pruning of the shadow list scan subtracts from a query's distance to the centroid (h16_scan_kernels.hpp).
+static __global__ __launch_bounds__(256) void list_radius_kernel(const float * vecs, const float * centroids, const int64_t * list_off,
+                                                                  uint32_t d, uint32_t ld, float * radius)
+{
+    __shared__ double s_max[4];
+    const uint32_t l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lbeg = list_off[l], lend = list_off[l + 1];
+    const float * c = centroids + (size_t)l * ld;
+    double mx = 0.0;
+    for (int64_t r = lbeg + wave; r < lend; r += 4) // a wavefront per row
+    {
+        const float * x = vecs + (size_t)r * ld;
+        double s = 0.0;
+        for (uint32_t e = lane; e < d; e += 64)
+        {
+            const double df = (double)x[e] - (double)c[e];
+            s += df * df;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            s += __shfl_xor(s, o);
+        mx = s > mx || !(s == s) ? s : mx; // NaN sticks: the list is then never pruned
+    }
+    if (lane == 0)
+        s_max[wave] = mx;
+    __syncthreads();
+    if (tid == 0)
+    {
+        double m = s_max[0];
+        for (int w = 1; w < 4; w++)
+            m = s_max[w] > m || !(s_max[w] == s_max[w]) ? s_max[w] : m;
+        const double r = sqrt(m) * (1.0 + 1e-6) + 1e-30;
+        float rf = (float)r;
+        if ((double)rf < r)
+            rf = nextafterf(rf, INFINITY);
+        radius[l] = r == r ? rf : INFINITY;
+    }
+}
+
 }

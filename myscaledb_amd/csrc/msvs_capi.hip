@@ -221,8 +221,8 @@ static unsigned long long * prefilter_fail_counter()
     if (it != per_device.end())
         return it->second;
     unsigned long long * p = nullptr;
-    MSVS_HIP(hipMalloc(&p, 64));
-    MSVS_HIP(hipMemset(p, 0, 64));
+    MSVS_HIP(hipMalloc(&p, 128));
+    MSVS_HIP(hipMemset(p, 0, 128));
     per_device[dev] = p;
     return p;
 }
@@ -405,7 +405,8 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
         + nq * nprobe * 4
         + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768
-        + (2 * ix.nlist + 18) * 4 + HR_CPP * 128 + 1024 // the list scan's counters taken up front, the padded query images
+        + (4 * ix.nlist + 18) * 4 + HR_CPP * 128 + 1024 // the list scan's counters taken up front, the padded query images
+        + 2 * nq * nprobe * 4 + 2 * (ix.nlist + 1) * 4 + 1024 // probe pruning: surviving probes, the second plan
         + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 8192 : 0);
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
@@ -439,6 +440,8 @@ struct H16Queries
     float * qnorm = nullptr;
     uint32_t * counters = nullptr; // in: the list scan's counters, to be zeroed along the way (cleared flag: qh != nullptr)
     uint32_t n_counters = 0;
+    const uint32_t * coarse_words = nullptr; // out: the coarse pass's approximate distance word of every (query, centroid) ...
+    uint32_t coarse_npad = 0;                // ... [nq][coarse_npad]: what the probe pruning of the list scan reads
 };
 
 struct TablePass
@@ -696,6 +699,11 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
             t.h16_out->qh = qh;
             t.h16_out->qinfo = qinfo;
             t.h16_out->qnorm = qn16;
+            if (options().coarse_h16 != 2) // (the dedicated kernel writes every word)
+            {
+                t.h16_out->coarse_words = sample;
+                t.h16_out->coarse_npad = n_pad;
+            }
         }
         if (options().coarse_h16 != 2)
         {
@@ -872,8 +880,9 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.rows_per_block = 0x7fffffffu; // one segment per non-empty row range
     const bool reg_tile = pl.h_ks != 0 && !d_alive; // filtered searches keep the LDS-resident tile (the register kernel has no bit test)
     pp.T = reg_tile ? 32 * (8 / pl.h_ks) : 32 * pl.h_ncb;
-    const bool zeroed = prepared.qh && prepared.counters && prepared.n_counters >= 2 * ix.nlist + 2 + 16;
-    uint32_t * counters = zeroed ? prepared.counters : scr.take<uint32_t>(2 * ix.nlist + 2 + 16);
+    const size_t n_counters = 4 * ix.nlist + 2 + 16; // two plans (cnt, fill each), nfail, 16 queue cursors, nfail2
+    const bool zeroed = prepared.qh && prepared.counters && prepared.n_counters >= n_counters;
+    uint32_t * counters = zeroed ? prepared.counters : scr.take<uint32_t>(n_counters);
     pp.cnt = counters;
     pp.fill = counters + ix.nlist;
     uint32_t * nfail = counters + 2 * ix.nlist;
@@ -883,7 +892,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.work_off = scr.take<uint32_t>(ix.nlist + 1);
     pp.pairs = scr.take<uint32_t>(nq * nprobe);
     if (!zeroed)
-        MSVS_HIP(hipMemsetAsync(counters, 0, (2 * ix.nlist + 2 + 16) * sizeof(uint32_t), stream));
+        MSVS_HIP(hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), stream));
     // ... and the sample launch's partition of the same pairs: block 0 of every probed list, tiles of 32 queries (small
     // workgroups) -- one scan launch computes both
     const uint32_t sample_nqb = options().h16_sample_nqb == 2 ? 2u : 1u; // column blocks of 32 queries per sample item
@@ -939,6 +948,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     const uint32_t per_cu = (uint32_t)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
     const uint32_t grid = options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count() * per_cu;
     const bool nt = options().h16_nt != 0;
+    H16Prune pr{};
     {
         ProfileScope prof("ivf_sample_scan", stream);
         a.work_off = pa.work_off;
@@ -968,14 +978,54 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
                 fl.c_canon = em.c_canon;
                 fl.ip = scan_metric(m) == M_IP ? 1 : 0;
             }
+            // probe pruning (h16_scan_kernels.hpp: H16Prune): L2 indexes whose coarse pass left every centroid's approximate
+            // distance behind; the surviving probes get their own plan for the main launch
+            if (options().h16_prune != 0 && ix.metric != MSVS_METRIC_IP && prepared.coarse_words && ix.list_radius.p && !reg_tile
+                && k <= 64)
+            {
+                RerankParams em{};
+                set_error_model_h16(em, ix.dim);
+                pr.coarse_words = prepared.coarse_words;
+                pr.npad = prepared.coarse_npad;
+                pr.radius = ix.list_radius.p;
+                pr.cnorm = ix.cnorm.p;
+                pr.ip = ix.metric == MSVS_METRIC_COSINE ? 1 : 0;
+                pr.qnorm = qnorm;
+                pr.xmax = ix.xnorm_max;
+                pr.cmax = ix.cnorm_max;
+                pr.c_dot = em.c_dot;
+                pr.c_norm = em.c_norm;
+                pr.c_canon = em.c_canon;
+                pr.k = k;
+                pr.out_probes = scr.take<int32_t>(nq * nprobe);
+                pr.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
+            }
             hipLaunchKernelGGL(h16_sample_thr_wave_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
                                sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
-                               qstate + nq, partial, pl.h_cap, options().wave_select == 3 ? 0 : 1, fl);
+                               qstate + nq, partial, pl.h_cap, options().wave_select == 3 ? 0 : 1, fl, pr);
         }
         else
             hipLaunchKernelGGL(h16_sample_thr_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
                                sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
                                qstate + nq, partial, pl.h_cap);
+    }
+    if (pr.coarse_words)
+    {
+        // the main launch's plan over the surviving pairs
+        IvfPlanParams p2 = pp;
+        p2.probes = pr.out_probes;
+        p2.cnt = counters + 2 * ix.nlist + 18;
+        p2.fill = p2.cnt + ix.nlist;
+        p2.pair_off = scr.take<uint32_t>(ix.nlist + 1);
+        p2.work_off = scr.take<uint32_t>(ix.nlist + 1);
+        p2.pairs = scr.take<uint32_t>(nq * nprobe);
+        p2.work_off2 = nullptr;
+        launch_ivf_plan(p2, stream);
+        pp.pairs = p2.pairs;
+        pp.pair_off = p2.pair_off;
+        pp.work_off = p2.work_off;
+        a.pairs = pp.pairs;
+        a.pair_off = pp.pair_off;
     }
     {
         ProfileScope prof("ivf_scan", stream);
@@ -1163,7 +1213,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     }
     // 1. coarse quantiser: exact top-nprobe of the centroids (canonical arithmetic, so probes match the oracle)
     H16Queries prepared{};
-    prepared.n_counters = (uint32_t)(2 * ix.nlist + 2 + 16); // the shadow list scan's counters (h16_list_scan)
+    prepared.n_counters = (uint32_t)(4 * ix.nlist + 2 + 16); // the shadow list scan's counters (h16_list_scan)
     prepared.counters = scr.take<uint32_t>(prepared.n_counters);
     int32_t * d_probes = probes_only ? probes_only : scr.take<int32_t>(nq * nprobe);
     if (given_probes)
@@ -1548,6 +1598,18 @@ extern "C" __attribute__((visibility("default"))) int msvs_debug_rerank_stats(ui
         MSVS_HIP(hipMemcpy(v, prefilter_fail_counter() + 2, 48, hipMemcpyDeviceToHost));
         for (int i = 0; i < 6; i++)
             out[i] = v[i];
+    });
+}
+
+/// Experiments / tests (not in msvs.h; needs rerank_stats = 1): (query, list) pairs the probe pruning dropped, pairs it looked at.
+extern "C" __attribute__((visibility("default"))) int msvs_debug_prune_stats(uint64_t * out2)
+{
+    return guarded([&] {
+        unsigned long long v[2];
+        MSVS_HIP(hipDeviceSynchronize());
+        MSVS_HIP(hipMemcpy(v, prefilter_fail_counter() + 8, 16, hipMemcpyDeviceToHost));
+        out2[0] = v[0];
+        out2[1] = v[1];
     });
 }
 

@@ -573,6 +573,53 @@ def test_coarse_band_decides_most_probes_without_reading_the_centroids(metric, d
     opt("coarse_band", None)
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_COSINE])
+@pytest.mark.parametrize("data", ["blobs", "iid", "outlier_rows"])
+def test_probe_pruning_drops_pairs_and_keeps_the_oracle_result(data, metric, opt):
+    """The shadow list scan of an L2 batch drops (query, list) pairs that provably cannot hold one of the query's k nearest rows
+    (triangle inequality with the list radius against the k-th best sample row: H16Prune; L2 and cosine indexes).  Whatever it drops, the result is the
+    oracle's, which scans every probed list: well separated blobs (most pairs go), iid rows (nothing can be proved: nothing goes),
+    lists with a far outlier row each (huge radii: nothing goes, and the outliers are still found by the queries placed on
+    them); with and without a filter; == the same search with the pruning off."""
+    rng = np.random.default_rng({"blobs": 11, "iid": 12, "outlier_rows": 13}[data])
+    n, d, nlist, nq, nprobe, k = 60000, 64, 256, 600, 16, 10
+    if data == "iid":
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        q = rng.standard_normal((nq, d), dtype=np.float32)
+    else:
+        centres = 4.0 * rng.standard_normal((nlist, d), dtype=np.float32)
+        z = rng.integers(0, nlist, n)
+        x = (centres[z] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+        q = (centres[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+        if data == "outlier_rows":
+            far = rng.choice(n, 300, replace=False)
+            x[far] += 40.0 * rng.standard_normal((300, d), dtype=np.float32)  # rows far from every centroid
+            q[:100] = x[far[:100]] + 0.01 * rng.standard_normal((100, d), dtype=np.float32)  # ... and queries sitting on them
+    ix = build_ivf(x, metric, nlist)
+    alive = rng.random(n) < 0.5
+    opt("rerank_stats", "1")
+    for al in (None, alive):
+        oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric, alive=al)
+        opt("h16_prune", "1")
+        s0 = capi.debug_prune_stats()
+        p0 = capi.prefilter_stats()
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=al)
+        same(ids, dis, oi, od)
+        s1 = capi.debug_prune_stats()
+        assert capi.prefilter_stats()[0] - p0[0] == nq, "the batch did not go through the shadow pass"
+        assert s1[1] - s0[1] == nq * nprobe, "the pruning did not look at the batch"
+        dropped = (s1[0] - s0[0]) / float(nq * nprobe)
+        if data == "blobs":
+            assert dropped > (0.5 if metric == capi.METRIC_L2 else 0.02), dropped  # (5 k-means iterations leave merged blobs: wide lists)
+        if data == "iid":
+            assert dropped < 0.05, dropped
+        opt("h16_prune", "0")
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=al)
+        same(ids, dis, oi, od)
+    opt("h16_prune", None)
+    opt("rerank_stats", None)
+
+
 def test_second_chance_rerank_of_the_whole_candidate_buffer(opt):
     """Distances that concentrate (gaussian blobs of sigma 0.3 in a few hundred dimensions: the 10th and the 32nd neighbour of a
     query are a couple of error bounds apart) fail the first certificate -- k-th exact distance against the kc-th approximate
