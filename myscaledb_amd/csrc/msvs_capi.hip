@@ -980,7 +980,10 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             }
             // probe pruning (h16_scan_kernels.hpp: H16Prune): L2 indexes whose coarse pass left every centroid's approximate
             // distance behind; the surviving probes get their own plan for the main launch
-            if (options().h16_prune != 0 && ix.metric != MSVS_METRIC_IP && prepared.coarse_words && ix.list_radius.p && !reg_tile
+            // ... when the lists are probed by more queries than one tile holds (then fewer pairs mean fewer passes over a list;
+            // below that the second plan and the looser cut cost more than the dropped pairs save: sigma-0.3 blobs at nprobe 2)
+            const bool prune_pays = options().h16_prune == 2 || (double)nq * (double)nprobe > (double)ix.nlist * (double)pp.T;
+            if (options().h16_prune != 0 && prune_pays && ix.metric != MSVS_METRIC_IP && prepared.coarse_words && ix.list_radius.p && !reg_tile
                 && k <= 64)
             {
                 RerankParams em{};

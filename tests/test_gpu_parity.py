@@ -600,7 +600,7 @@ def test_probe_pruning_drops_pairs_and_keeps_the_oracle_result(data, metric, opt
     opt("rerank_stats", "1")
     for al in (None, alive):
         oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric, alive=al)
-        opt("h16_prune", "1")
+        opt("h16_prune", "2")  # always (the default only prunes when a list is probed by more queries than one tile holds)
         s0 = capi.debug_prune_stats()
         p0 = capi.prefilter_stats()
         ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=al)
