@@ -173,10 +173,7 @@ struct Options
     double h16_nocut = 0;     // shadow pass: no sample cut, every probed row becomes a candidate (tests)
     double h16_ncb = 0;       // shadow pass: column blocks (32 queries each) per tile, 0 = planned
     double rerank_second = 1; // queries whose first certificate fails get their whole candidate buffer re-ranked before the canonical scan
-    double h16_dbg = 0;       // experiments: ablation bits of h16r_scan_kernel (wrong results)
-    double h16_reg = 0;       // shadow pass with the queries in registers and the rows through LDS (h16r_scan_kernels.hpp): 0 never
-                              // (measured: at par or slower than the LDS-tile kernel, profiles/r03_h16r_notes.txt), 1 when the average
-                              // list is probed by more queries than an LDS-resident tile holds, 2 whenever the shape is eligible
+    double h16_stamps = 0;    // experiments: the main launch records per-item wall-clock stamps (msvs_debug_h16_stamps)
     double lat_path = 1;      // few-query IVFFLAT searches in two self-merging launches (latency_kernels.hpp): 0 off,
                               // 1 for 1-2 queries per call, 2 up to 4
     double filter_compact_below = -1;  // filtered searches run over a compacted view when less than this fraction of the

@@ -72,7 +72,10 @@ struct H16Params
     uint32_t * sample_out;    // [nq * nprobe][32] ordered distance word of row r of block 0 (0xFFFFFFFF = no row)
     uint32_t * sched;         // [8] work-queue cursors of this launch (zeroed by the caller)
     uint32_t dbg;             // experiments (option h16_dbg; results are WRONG with any bit set): 1 no MFMA work, 2 no epilogue, 4 no norms
+    uint64_t * stamps;        // nullable (option h16_stamps): [grid][H_STAMP_ITEMS][4] {item popped, tile resident, rows done, l << 32 | nvalid << 8}
+                              // in wall_clock64 ticks (100 MHz), [grid][0][0] = items of the workgroup
 };
+constexpr uint32_t H_STAMP_ITEMS = 64;
 
 /// Largest |element| of a table as float bits (NaN compares largest); max_bits zeroed by the caller.
 static __global__ void absmax_kernel(const float4 * x, size_t n4, uint32_t * max_bits)
@@ -267,7 +270,7 @@ constexpr uint32_t H_NONE = 0xFFFFFFFFu;
 inline size_t h16_lds_bytes(uint32_t ncb, uint32_t nch)
 {
     const size_t tq = 32 * (size_t)ncb;
-    return tq * nch * 128 + 5 * tq * 4 + (size_t)H_NW * H_STAGE * 12 + 16;
+    return tq * nch * 128 + 4 * tq * 4 + (size_t)H_NW * H_STAGE * 12 + 16;
 }
 
 /// A wavefront's share of a work item: shadow blocks blk0, blk0 + stride, ... < nblk of the list (32 rows each) against
@@ -275,17 +278,19 @@ inline size_t h16_lds_bytes(uint32_t ncb, uint32_t nch)
 /// multiple of H_RING (the chunks requested past the end of a block are the first chunks of the wavefront's next
 /// block), so in steady state every request is a useful one; otherwise, and after the last block, the requests past
 /// the end re-load the last chunk (harmless, L2 hits).
-template <int METRIC, int NCBI, bool SAMPLE, bool NT>
-__device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned char * qt /* tile + column-block offset */,
+/// (Round 4 measured a dynamic hand-out of the blocks -- one counter per item, idle workgroups joining items in progress -- against
+/// this static striding: 3 % slower without joiners, no faster with them; profiles/r04_scan_notes.txt.)
+template <int METRIC, int NCBI, int RING = H_RING>
+__device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned char * qt /* tile */,
                                            const uint32_t chunk_stride, const float * m2_s, const float * qn_s,
-                                           const uint32_t * thr_s, const uint32_t * qrow_s, const uint32_t * qpair_s,
-                                           uint32_t * stage, const uint32_t cb0, const uint32_t lane, const uint32_t nch,
-                                           const uint32_t hb_list /* first shadow block of the list */,
+                                           const uint32_t * thr_s, const uint32_t * qrow_s, uint32_t * stage, const uint32_t lane,
+                                           const uint32_t nch, const uint32_t hb_list /* first shadow block of the list */,
                                            const uint32_t blk0, const uint32_t stride, const uint32_t nblk,
-                                           const int64_t lbeg, const int64_t lend, const uint32_t nvalid)
+                                           const int64_t lbeg, const int64_t lend)
 {
     if (blk0 >= nblk)
         return;
+    uint32_t blk = blk0;
     const uint32_t r32 = lane & 31, h = lane >> 5;
     // operand read offsets of this lane inside a 128-byte query row: piece (2 j + h) ^ swizzle
     const uint32_t sw = (r32 >> 1) & 7;
@@ -296,24 +301,26 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
     const u32x4 * const hbase = reinterpret_cast<const u32x4 *>(a.H) + lane;
     const size_t blk_pieces = (size_t)nch * 256; // 4 steps x 64 lanes per chunk
     const uint32_t last = nch - 1;
-    const bool chain = nch % H_RING == 0;
+    const bool chain = nch % RING == 0;
 
-    u32x4 ring[H_RING][4];
+    u32x4 ring[RING][4];
     auto load_chunk = [&](u32x4 (&b)[4], const u32x4 * p) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            b[j] = NT ? __builtin_nontemporal_load(p + j * 64) : p[j * 64];
+            b[j] = p[j * 64];
     };
-    const u32x4 * hp = hbase + (size_t)(hb_list + blk0) * blk_pieces;
+    const u32x4 * hp = hbase + (size_t)(hb_list + blk) * blk_pieces;
 #pragma unroll
-    for (int u = 0; u < H_RING - 1; u++)
+    for (int u = 0; u < RING - 1; u++)
         load_chunk(ring[u], hp + (size_t)((uint32_t)u < last ? (uint32_t)u : last) * 256);
     __builtin_amdgcn_sched_barrier(0);
 
-    for (uint32_t blk = blk0; blk < nblk; blk += stride)
+    for (; blk < nblk; blk += stride)
     {
-        const bool has_next = chain && blk + stride < nblk;
-        const u32x4 * const hp_next = has_next ? hbase + (size_t)(hb_list + blk + stride) * blk_pieces : hp;
+        const uint32_t nxt = blk + stride;
+        const bool more = nxt < nblk;
+        const bool has_next = chain && more;
+        const u32x4 * const hp_next = has_next ? hbase + (size_t)(hb_list + nxt) * blk_pieces : hp;
         const int64_t row = lbeg + (int64_t)blk * H_ROWS + r32;
         bool ok = row < lend;
         float xn = 0.f;
@@ -348,32 +355,32 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf, acc[cb], 0, 0, 0);
             }
         };
-        for (uint32_t c0 = 0; c0 < nch; c0 += H_RING)
+        for (uint32_t c0 = 0; c0 < nch; c0 += RING)
         {
 #pragma unroll
-            for (int u = 0; u < H_RING; u++)
+            for (int u = 0; u < RING; u++)
             {
                 const uint32_t c = c0 + u;
                 if (c >= nch)
                     break;
-                // the chunk H_RING - 1 ahead: of this block, of the wavefront's next block, or a re-load of the last one.
+                // the chunk RING - 1 ahead: of this block, of the wavefront's next block, or a re-load of the last one.
                 // sched_barrier: without a fence hipcc sinks the prefetch loads down to their first use (register
                 // pressure heuristic) and the ring degenerates into load -> vmcnt(0) -> use
-                const uint32_t pc = c + H_RING - 1;
+                const uint32_t pc = c + RING - 1;
                 const u32x4 * src = pc < nch ? hp + (size_t)pc * 256
                                              : (has_next ? hp_next + (size_t)(pc - nch) * 256 : hp + (size_t)last * 256);
-                load_chunk(ring[(u + H_RING - 1) % H_RING], src);
+                load_chunk(ring[(u + RING - 1) % RING], src);
                 __builtin_amdgcn_sched_barrier(0);
                 step(ring[u], c);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (!chain && blk + stride < nblk)
+        if (!chain && more)
         {
             // no chaining: restart the ring on the next block
-            const u32x4 * const nx = hbase + (size_t)(hb_list + blk + stride) * blk_pieces;
+            const u32x4 * const nx = hbase + (size_t)(hb_list + nxt) * blk_pieces;
 #pragma unroll
-            for (int u = 0; u < H_RING - 1; u++)
+            for (int u = 0; u < RING - 1; u++)
                 load_chunk(ring[u], nx + (size_t)((uint32_t)u < last ? (uint32_t)u : last) * 256);
             hp = nx;
         }
@@ -396,58 +403,46 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
             cnt = 0;
         };
 #pragma unroll
-        for (int cbi = 0; cbi < NCBI; cbi++)
+        for (int cb = 0; cb < NCBI; cb++)
         {
-            const uint32_t cb = cb0 + (uint32_t)cbi;
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++)
             {
                 const uint32_t q0 = 32 * cb + 8 * g4 + 4 * h;
                 const float4 m2 = *reinterpret_cast<const float4 *>(&m2_s[q0]);
                 const float4 qn = *reinterpret_cast<const float4 *>(&qn_s[q0]);
-                uint4 cut = make_uint4(0u, 0u, 0u, 0u);
-                if (!SAMPLE)
-                    cut = *reinterpret_cast<const uint4 *>(&thr_s[q0]);
+                const uint4 cut = *reinterpret_cast<const uint4 *>(&thr_s[q0]);
                 const float m2v[4] = {m2.x, m2.y, m2.z, m2.w}, qnv[4] = {qn.x, qn.y, qn.z, qn.w};
                 const uint32_t cutv[4] = {cut.x, cut.y, cut.z, cut.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                 {
-                    const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2v[e], acc[cbi][4 * g4 + e], xn), qnv[e])
-                                                   : __fmul_rn(m2v[e], acc[cbi][4 * g4 + e]);
+                    const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2v[e], acc[cb][4 * g4 + e], xn), qnv[e])
+                                                   : __fmul_rn(m2v[e], acc[cb][4 * g4 + e]);
                     const uint64_t key = ok ? make_key<METRIC>(v, (uint32_t)row) : KEY_NONE;
                     const uint32_t word = (uint32_t)(key >> 32);
-                    if (SAMPLE)
+                    const bool pass = word < cutv[e]; // KEY_NONE has word 0xFFFFFFFF: never below a cut
+                    const uint64_t mask = __ballot(pass);
+                    if (mask)
                     {
-                        if (q0 + e < nvalid)
-                            a.sample_out[(size_t)qpair_s[q0 + e] * H_ROWS + r32] = word;
-                    }
-                    else
-                    {
-                        const bool pass = word < cutv[e]; // KEY_NONE has word 0xFFFFFFFF: never below a cut
-                        const uint64_t mask = __ballot(pass);
-                        if (mask)
+                        const uint32_t np = __popcll(mask);
+                        if (cnt + np > (uint32_t)H_STAGE)
+                            flush();
+                        if (pass)
                         {
-                            const uint32_t np = __popcll(mask);
-                            if (cnt + np > (uint32_t)H_STAGE)
-                                flush();
-                            if (pass)
-                            {
-                                const uint32_t at = cnt
-                                    + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                                stage[at] = (uint32_t)key;
-                                stage[H_STAGE + at] = word;
-                                stage[2 * H_STAGE + at] = qrow_s[q0 + e];
-                            }
-                            cnt += np;
+                            const uint32_t at = cnt
+                                + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            stage[at] = (uint32_t)key;
+                            stage[H_STAGE + at] = word;
+                            stage[2 * H_STAGE + at] = qrow_s[q0 + e];
                         }
+                        cnt += np;
                     }
                 }
             }
         }
-        if (!SAMPLE)
-            flush();
+        flush();
     }
 }
 
@@ -468,33 +463,44 @@ __device__ __forceinline__ uint32_t h16_next_item(uint32_t * sched, const uint32
     return H_NONE;
 }
 
-template <int METRIC, int NCB, bool NT>
+/// Persistent workgroups pulling work items (list, tile) from the per-XCD queues.  An item that holds fewer probing queries than
+/// the tile can (the last tile of a list; most tiles once the probe pruning has thinned the pairs) loads and multiplies only the
+/// column blocks it has queries for (round 4: the per-item stamps of option h16_stamps showed 61 % of the bench step's items
+/// holding <= 32 queries; 0.505 -> 0.475 ms).
+template <int METRIC, int NCB>
 __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
 {
     constexpr uint32_t TQ = 32 * NCB;
     constexpr uint32_t NW = H_NW;
-    constexpr bool SAMPLE = false;
     const uint32_t nch = a.nch;
     unsigned char * const tile = msvs_smem; // [chunk][query][8 x 16 B]
     float * const m2_s = reinterpret_cast<float *>(tile + (size_t)TQ * nch * 128);
     float * const qn_s = m2_s + TQ;
     uint32_t * const thr_s = reinterpret_cast<uint32_t *>(qn_s + TQ);
     uint32_t * const qrow_s = thr_s + TQ;
-    uint32_t * const qpair_s = qrow_s + TQ;
-    uint32_t * const stage_s = qpair_s + TQ; // [NW][3][H_STAGE]
+    uint32_t * const stage_s = qrow_s + TQ; // [NW][3][H_STAGE]
     uint32_t * const item_s = stage_s + NW * 3 * H_STAGE;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t total = a.work_off[a.nlist];
+    uint64_t * const stamp = a.stamps ? a.stamps + (size_t)blockIdx.x * H_STAMP_ITEMS * 4 : nullptr;
+    uint32_t n_items = 0;
     for (;;)
     {
         __syncthreads(); // the previous work item is done with the tile, the tables and item_s
         if (tid == 0)
+        {
+            if (stamp && n_items >= 1 && n_items < H_STAMP_ITEMS)
+                stamp[n_items * 4 + 2] = wall_clock64();
             *item_s = h16_next_item(a.sched, total, blockIdx.x & 7);
+        }
         __syncthreads();
         const uint32_t w = *item_s;
         if (w == H_NONE)
             break;
+        n_items++;
+        if (stamp && tid == 0 && n_items < H_STAMP_ITEMS)
+            stamp[n_items * 4 + 0] = wall_clock64();
         uint32_t lo = 0, hi = a.nlist;
         while (hi - lo > 1)
         {
@@ -511,6 +517,9 @@ __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
         const uint32_t pb = a.pair_off[l] + tidx * TQ;
         const uint32_t nvalid = pe - pb < TQ ? pe - pb : TQ;
         const uint32_t nblk = a.hoff[l + 1] - a.hoff[l];
+        // column blocks this item needs, and the rows of its tile in LDS
+        const uint32_t ncb_e = (nvalid + 31) >> 5;
+        const uint32_t tq_e = 32 * ncb_e;
 
         if (tid < TQ)
         {
@@ -518,42 +527,63 @@ __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
             const uint32_t qp = a.pairs[v ? pb + tid : pe - 1];
             const uint32_t q = qp / a.nprobe;
             qrow_s[tid] = q;
-            qpair_s[tid] = qp;
             const float2 qi = a.qinfo[q];
             m2_s[tid] = qi.x;
             qn_s[tid] = qi.y;
-            thr_s[tid] = (!SAMPLE && v) ? a.qthr[q] : 0u; // padding queries of a short tile never pass
+            thr_s[tid] = v ? a.qthr[q] : 0u; // padding queries of a short tile never pass
         }
         __syncthreads();
-        // the tile: piece p = (chunk, query, slot) in LDS order holds piece slot ^ swizzle(query) of the query's chunk
+        // the tile: piece p = (chunk, query < tq_e, slot) holds piece slot ^ swizzle(query) of the query's chunk; LDS keeps the
+        // full tile's strides (compile-time operand offsets in the stream), an item with fewer column blocks leaves rows unwritten
         {
-            const uint32_t npieces = TQ * nch * 8; // a multiple of 256
+            const uint32_t npieces = tq_e * nch * 8;
             for (uint32_t p0 = tid; p0 < npieces; p0 += 4 * 64 * NW)
             {
-                uint4 v0, v1, v2, v3; // 4 loads in flight per thread; pieces past the end re-load the last one
-                auto fetch = [&](const uint32_t pp) {
+                uint4 v[4]; // 4 loads in flight per thread; pieces past the end re-load the last one
+                uint32_t at[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const uint32_t pp = p0 + u * 64 * NW;
                     const uint32_t p = pp < npieces ? pp : npieces - 1;
-                    const uint32_t slot = p & 7, qi = (p >> 3) % TQ, c = (p >> 3) / TQ;
-                    return a.Qh[((size_t)qrow_s[qi] * nch + c) * 8 + (slot ^ ((qi >> 1) & 7))];
-                };
-                v0 = fetch(p0);
-                v1 = fetch(p0 + 64 * NW);
-                v2 = fetch(p0 + 2 * 64 * NW);
-                v3 = fetch(p0 + 3 * 64 * NW);
-                *reinterpret_cast<uint4 *>(tile + (size_t)p0 * 16) = v0;
-                if (p0 + 64 * NW < npieces)
-                    *reinterpret_cast<uint4 *>(tile + (size_t)(p0 + 64 * NW) * 16) = v1;
-                if (p0 + 2 * 64 * NW < npieces)
-                    *reinterpret_cast<uint4 *>(tile + (size_t)(p0 + 2 * 64 * NW) * 16) = v2;
-                if (p0 + 3 * 64 * NW < npieces)
-                    *reinterpret_cast<uint4 *>(tile + (size_t)(p0 + 3 * 64 * NW) * 16) = v3;
+                    const uint32_t slot = p & 7, qi = (p >> 3) % tq_e, c = (p >> 3) / tq_e;
+                    v[u] = a.Qh[((size_t)qrow_s[qi] * nch + c) * 8 + (slot ^ ((qi >> 1) & 7))];
+                    at[u] = ((c * TQ + qi) * 8 + slot) * 16;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (p0 + u * 64 * NW < npieces)
+                        *reinterpret_cast<uint4 *>(tile + at[u]) = v[u];
             }
         }
         __syncthreads();
+        if (stamp && tid == 0 && n_items < H_STAMP_ITEMS)
+        {
+            stamp[n_items * 4 + 1] = wall_clock64();
+            stamp[n_items * 4 + 3] = (uint64_t)l << 32 | nvalid << 8;
+        }
         uint32_t * const stage = stage_s + wave * 3 * H_STAGE;
-        h16_stream<METRIC, NCB, false, NT>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, qpair_s, stage, 0, lane, nch,
-                                               a.hoff[l], 1 + wave, NW, nblk, lbeg, lend, nvalid);
+        // block 0 is the sample launch's
+#define MSVS_H16_STREAM(N)                                                                                                         \
+    h16_stream<METRIC, N>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, a.hoff[l], 1 + wave, NW, nblk, lbeg, lend)
+        if constexpr (NCB == 1)
+            MSVS_H16_STREAM(1);
+        else if (ncb_e == 1)
+            MSVS_H16_STREAM(1);
+        else if constexpr (NCB == 2)
+            MSVS_H16_STREAM(2);
+        else if (ncb_e == 2)
+            MSVS_H16_STREAM(2);
+        else if constexpr (NCB == 3)
+            MSVS_H16_STREAM(3);
+        else if (ncb_e == 3)
+            MSVS_H16_STREAM(3);
+        else
+            MSVS_H16_STREAM(4);
+#undef MSVS_H16_STREAM
     }
+    if (stamp && tid == 0)
+        stamp[0] = n_items;
 }
 
 /// The sample launch: block 0 (<= 32 rows) of every probed list against the queries probing it, one wavefront per

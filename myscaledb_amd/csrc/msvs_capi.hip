@@ -19,7 +19,6 @@
 #include "index_internal.hpp"
 #include "ivf_build_kernels.hpp"
 #include "h16_scan_kernels.hpp"
-#include "h16r_scan_kernels.hpp"
 #include "io_stream.hpp"
 #include "latency_kernels.hpp"
 #include "filter_kernels.hpp"
@@ -249,7 +248,6 @@ struct IvfSearchPlan
     uint32_t h_mth;    // ... the number of rows per query its cut aims to leave below it (h16_sample_thr_kernel)
     uint32_t h_cap;    // ... and its candidate-buffer capacity per query
     uint32_t h_ncb;    // ... and its query tile: 32 * h_ncb queries resident in LDS
-    uint32_t h_ks;     // ... or, != 0: the tile lives in REGISTERS (h16r_scan_kernels.hpp), the reduction dimension in h_ks parts
     bool mfma() const { return nqg != 0; }
 };
 
@@ -284,13 +282,6 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 while (ncb > 1 && h16_lds_bytes(ncb, ix.h_nch) > 160 * 1024)
                     ncb--;
                 p.h_ncb = ncb;
-                // queries in registers, rows through LDS: 256 / 128 queries per pass over a list (d <= 768 / 1536) where LDS holds
-                // 32 * ncb -- taken when the lists are probed by more queries than that (twice the average, as above)
-                const uint32_t ks = ix.h_nch <= HR_CPP ? 1u : 2u;
-                const int reg = (int)options().h16_reg;
-                if (reg != 0 && ix.h_nch % ks == 0 && h16r_cpp_supported(ix.h_nch / ks) && h16r_lds_bytes(ks, ix.h_nch / ks) <= 160 * 1024
-                    && (reg >= 2 || 2 * ceil_div(pairs, nlist) > 32 * (size_t)ncb))
-                    p.h_ks = ks;
             }
             {
                 // sample = block 0 (<= 32 rows) of every probed list; the cut of a query = its m-th best sample row with
@@ -405,14 +396,14 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
         + nq * nprobe * 4
         + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768
-        + (4 * ix.nlist + 18) * 4 + HR_CPP * 128 + 1024 // the list scan's counters taken up front, the padded query images
+        + (4 * ix.nlist + 18) * 4 + 1024 + 1024 // the list scan's counters taken up front, the padded query images
         + 2 * nq * nprobe * 4 + 2 * (ix.nlist + 1) * 4 + 1024 // probe pruning: surviving probes, the second plan
         + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 8192 : 0);
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
             + nq * (size_t)p.kc * 8 + nq * 32 + 8192
             + fallback_cap(nq, nprobe, p.seg_max1, k) * nprobe * (size_t)p.seg_max1 * k * 8
-            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8 + 4) + HR_CPP * 128 + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
+            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8 + 4) + 1024 + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
     return need;
@@ -668,7 +659,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     {
         // every approximate distance of the batch through the centroid shadow, then the kc best per query
         const uint32_t G = (uint32_t)ceil_div(t.n, (size_t)H_ROWS), n_pad = G * H_ROWS;
-        uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + HR_CPP * 8); // + what the register-tile list scan may read past the end
+        uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + 64); // + what the register-tile list scan may read past the end
         float2 * qinfo = scr.take<float2>(nq);
         float * qn16 = qnorm; // computed by the preparation kernel itself
         uint32_t * sample = scr.take<uint32_t>(nq * (size_t)n_pad);
@@ -798,41 +789,32 @@ static void set_error_model_h16(RerankParams & rp, size_t dim)
 }
 
 template <int METRIC, int NCB>
-static void h16_launch(bool nt, uint32_t grid, size_t lds, const H16Params & a, hipStream_t stream)
+static void h16_launch(uint32_t grid, size_t lds, const H16Params & a, hipStream_t stream)
 {
     // more than 64 KiB of dynamic LDS needs the attribute raised once per kernel
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&h16_scan_kernel<METRIC, NCB, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&h16_scan_kernel<METRIC, NCB, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&h16_scan_kernel<METRIC, NCB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    if (nt)
-        hipLaunchKernelGGL((h16_scan_kernel<METRIC, NCB, true>), dim3(grid), dim3(64 * H_NW), lds, stream, a);
-    else
-        hipLaunchKernelGGL((h16_scan_kernel<METRIC, NCB, false>), dim3(grid), dim3(64 * H_NW), lds, stream, a);
+    hipLaunchKernelGGL((h16_scan_kernel<METRIC, NCB>), dim3(grid), dim3(64 * H_NW), lds, stream, a);
 }
 
 template <int METRIC>
-static void h16_dispatch(uint32_t ncb, bool nt, uint32_t grid, size_t lds, const H16Params & a, hipStream_t stream)
+static void h16_dispatch(uint32_t ncb, uint32_t grid, size_t lds, const H16Params & a, hipStream_t stream)
 {
     switch (ncb)
     {
-        case 1:
-            h16_launch<METRIC, 1>(nt, grid, lds, a, stream);
-            break;
-        case 2:
-            h16_launch<METRIC, 2>(nt, grid, lds, a, stream);
-            break;
-        case 3:
-            h16_launch<METRIC, 3>(nt, grid, lds, a, stream);
-            break;
-        default:
-            h16_launch<METRIC, 4>(nt, grid, lds, a, stream);
-            break;
+        case 1: h16_launch<METRIC, 1>(grid, lds, a, stream); break;
+        case 2: h16_launch<METRIC, 2>(grid, lds, a, stream); break;
+        case 3: h16_launch<METRIC, 3>(grid, lds, a, stream); break;
+        default: h16_launch<METRIC, 4>(grid, lds, a, stream); break;
     }
 }
+
+/// Experiments (option h16_stamps): the per-item wall-clock stamps of the last main launch (H16Params::stamps).
+static DevBuf<uint64_t> & g_h16_stamps = *new DevBuf<uint64_t>(); // leaked on purpose: no hipFree after the runtime is gone
+static uint32_t g_h16_stamp_grid = 0;
 
 uint32_t device_cu_count()
 {
@@ -878,8 +860,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.n_pairs = (uint32_t)(nq * nprobe);
     pp.nlist = (uint32_t)ix.nlist;
     pp.rows_per_block = 0x7fffffffu; // one segment per non-empty row range
-    const bool reg_tile = pl.h_ks != 0 && !d_alive; // filtered searches keep the LDS-resident tile (the register kernel has no bit test)
-    pp.T = reg_tile ? 32 * (8 / pl.h_ks) : 32 * pl.h_ncb;
+    pp.T = 32 * pl.h_ncb;
     const size_t n_counters = 4 * ix.nlist + 2 + 16; // two plans (cnt, fill each), nfail, 16 queue cursors, nfail2
     const bool zeroed = prepared.qh && prepared.counters && prepared.n_counters >= n_counters;
     uint32_t * counters = zeroed ? prepared.counters : scr.take<uint32_t>(n_counters);
@@ -905,7 +886,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pa.work_off = pp.work_off2;
     // the queries' fp16 images: the coarse pass over the centroid shadow left them behind, or they are made here
     float * qnorm = prepared.qh ? prepared.qnorm : scr.take<float>(nq);
-    uint4 * qh = prepared.qh ? prepared.qh : scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + HR_CPP * 8); // + what the register kernel may read past the last image
+    uint4 * qh = prepared.qh ? prepared.qh : scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + 64); // + what the register kernel may read past the last image
     float2 * qinfo = prepared.qh ? prepared.qinfo : scr.take<float2>(nq);
     uint32_t * sample = scr.take<uint32_t>(nq * nprobe * H_ROWS);
     uint32_t * qstate = scr.take<uint32_t>(2 * nq);
@@ -942,12 +923,10 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     a.partial = partial;
     a.cand_cap = pl.h_cap;
     a.sample_out = sample;
-    a.dbg = (uint32_t)options().h16_dbg;
     // persistent workgroups pulling work items from per-XCD queues: one per CU (the tile takes most of the LDS)
     const size_t lds = h16_lds_bytes(pl.h_ncb, ix.h_nch);
     const uint32_t per_cu = (uint32_t)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
     const uint32_t grid = options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count() * per_cu;
-    const bool nt = options().h16_nt != 0;
     H16Prune pr{};
     {
         ProfileScope prof("ivf_sample_scan", stream);
@@ -983,7 +962,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             // ... when the lists are probed by more queries than one tile holds (then fewer pairs mean fewer passes over a list;
             // below that the second plan and the looser cut cost more than the dropped pairs save: sigma-0.3 blobs at nprobe 2)
             const bool prune_pays = options().h16_prune == 2 || (double)nq * (double)nprobe > (double)ix.nlist * (double)pp.T;
-            if (options().h16_prune != 0 && prune_pays && ix.metric != MSVS_METRIC_IP && prepared.coarse_words && ix.list_radius.p && !reg_tile
+            if (options().h16_prune != 0 && prune_pays && ix.metric != MSVS_METRIC_IP && prepared.coarse_words && ix.list_radius.p
                 && k <= 64)
             {
                 RerankParams em{};
@@ -1034,12 +1013,21 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         ProfileScope prof("ivf_scan", stream);
         a.work_off = pp.work_off;
         a.sched = sched + 8;
-        if (reg_tile)
-            h16r_dispatch(scan_metric(m), pl.h_ks, a, options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count(), stream);
-        else if (scan_metric(m) == M_IP)
-            h16_dispatch<M_IP>(pl.h_ncb, nt, grid, lds, a, stream);
-        else
-            h16_dispatch<M_L2>(pl.h_ncb, nt, grid, lds, a, stream);
+        {
+            if (options().h16_stamps != 0)
+            {
+                const size_t words = (size_t)grid * H_STAMP_ITEMS * 4;
+                if (g_h16_stamps.n < words)
+                    g_h16_stamps.alloc(words);
+                MSVS_HIP(hipMemsetAsync(g_h16_stamps.p, 0, words * 8, stream));
+                a.stamps = g_h16_stamps.p;
+                g_h16_stamp_grid = grid;
+            }
+            if (scan_metric(m) == M_IP)
+                h16_dispatch<M_IP>(pl.h_ncb, grid, lds, a, stream);
+            else
+                h16_dispatch<M_L2>(pl.h_ncb, grid, lds, a, stream);
+        }
     }
     MSVS_HIP(hipGetLastError());
     g_h16_last = H16Last{partial, qstate + nq, pl.h_cap, nq, stream};
@@ -1671,6 +1659,18 @@ extern "C" __attribute__((visibility("default"))) int msvs_debug_h16_keys(uint64
         const size_t take = std::min<size_t>(cap_out, h.cap);
         MSVS_HIP(hipMemcpy2D(keys_out, cap_out * 8, h.partial, (size_t)h.cap * 8, take * 8, nq, hipMemcpyDeviceToHost));
         g_h16_last = H16Last{}; // one fetch per pass: a later search that takes another path must not be mistaken for it
+    });
+}
+
+/// Experiments only (not in msvs.h; option h16_stamps): out[grid][64][4] of the last shadow main launch, *grid its workgroups.
+extern "C" __attribute__((visibility("default"))) int msvs_debug_h16_stamps(uint64_t * out, size_t cap_words, uint32_t * grid)
+{
+    return guarded([&] {
+        MSVS_HIP(hipDeviceSynchronize());
+        const size_t words = (size_t)g_h16_stamp_grid * H_STAMP_ITEMS * 4;
+        *grid = g_h16_stamp_grid;
+        if (words && cap_words >= words)
+            MSVS_HIP(hipMemcpy(out, g_h16_stamps.p, words * 8, hipMemcpyDeviceToHost));
     });
 }
 

@@ -582,6 +582,8 @@ struct IvfPlanParams
     const int64_t * list_end2 = nullptr;
     uint32_t T2 = 0;
     uint32_t * work_off2 = nullptr; // [nlist+1]
+    uint32_t * zero = nullptr;      // a region of 32-bit words the scan launch clears on the way (the consumer's counters), ...
+    uint32_t nzero = 0;             // ... and its length
 };
 
 static __global__ void ivf_hist_kernel(const IvfPlanParams p)
@@ -605,6 +607,8 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
     const uint32_t tid = threadIdx.x;
     if (tid < 3)
         carry[tid] = 0;
+    for (uint32_t i = tid; i < p.nzero; i += 1024)
+        p.zero[i] = 0;
     __syncthreads();
     for (uint32_t base = 0; base < p.nlist; base += 1024)
     {

@@ -256,13 +256,6 @@ def test_c4_one_gpu_share_12m5_rows_1536_ip_against_the_oracle():
     same(ids[:64], dis[:64], ei, ed)
     i1, d1 = ix.search(q[70:71], k, "nprobe=%d" % nprobe)
     same(i1, d1, ids[70:71], dis[70:71])
-    capi.set_option("h16_reg", "2")
-    try:
-        ix.search_device(q_dev.data_ptr(), B, k, nprobe, oi.data_ptr(), od.data_ptr(), stream)
-        torch.cuda.synchronize()
-    finally:
-        capi.set_option("h16_reg", None)
-    same(oi.cpu().numpy(), od.cpu().numpy(), ids, dis)
     ix.close()
 
 

@@ -362,21 +362,20 @@ def h16_keys(nq, cap=4096):
 
 
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
-@pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(40000, 768, 16, 900, 4, 10),    # 12 chunks: 9 in registers + 3 LDS-resident
+@pytest.mark.parametrize("n,d,nlist,nq,nprobe,k", [(40000, 768, 16, 900, 4, 10),    # 12 chunks: the ring chains through the blocks
                                                    (30000, 500, 8, 300, 8, 10),     # 8 chunks
-                                                   (30000, 384, 8, 2100, 8, 40),    # 6 chunks; > 256 queries per list: several tiles
-                                                   (20000, 20, 8, 129, 3, 1),       # not a shape the register kernel has: the LDS-tile kernel
-                                                   (3000, 330, 4, 100, 4, 12),      # 6 chunks, lists of ~750 rows, few queries
-                                                   (12000, 1536, 4, 300, 2, 10),    # 24 chunks: two parts of 12
-                                                   (12000, 1000, 6, 200, 3, 10),    # 16 chunks: two parts of 8
-                                                   (9000, 1400, 3, 150, 3, 5),      # 22 chunks: no such shape
+                                                   (30000, 384, 8, 2100, 8, 40),    # > 96 queries per list: several tiles, short last ones
+                                                   (20000, 20, 8, 129, 3, 1),       # one chunk
+                                                   (3000, 330, 4, 100, 4, 12),      # 6 chunks: no chaining, lists of ~750 rows
+                                                   (12000, 1536, 4, 300, 2, 10),    # 24 chunks: one column block fits
+                                                   (9000, 1400, 3, 150, 3, 5),      # 22 chunks
                                                    (2000, 512, 40, 700, 5, 10)])    # lists of ~50 rows: one or two blocks beyond the sample
-def test_register_tile_list_scan_matches_oracle(metric, n, d, nlist, nq, nprobe, k, opt):
-    """h16r_scan_kernel: the query tile in registers (256 / 128 queries per pass over a list), the rows through an LDS ring
-    filled by LDS-DMA, survivors staged in LDS.  Forced (h16_reg = 2) on shapes covering one and two parts of the reduction
-    dimension, the LDS-resident 12th chunk, short lists, several tiles per list, no cut at all (every probed row is appended: the
-    stage flushes all the time), tiny candidate buffers (overflow -> fallback) and failing certificates.  Always the canonical
-    answer, bit for bit; and the candidate SETS equal those of the LDS-tile kernel when there is one part (same MFMA chain)."""
+def test_shadow_scan_items_of_every_size_match_oracle(metric, n, d, nlist, nq, nprobe, k, opt):
+    """h16_scan_kernel's work items hold 1 .. 32 NCB probing queries and load / multiply only the column blocks they have queries
+    for; whatever the tile the planner or the knob picks (ncb 1 .. 4: the same lists cut into more or fewer items) and whatever
+    the grid (2 workgroups walk every item in turn; 1024: more workgroups than items), with no cut at all (every probed row
+    is appended), tiny candidate buffers (overflow -> fallback): the canonical answer bit for bit, and the SAME candidate sets
+    (every block of every list scanned exactly once per probing query)."""
     rng = np.random.default_rng(n + d + nlist + 11)
     centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
     x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
@@ -384,23 +383,22 @@ def test_register_tile_list_scan_matches_oracle(metric, n, d, nlist, nq, nprobe,
     ix = build_ivf(x, metric, nlist)
     oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
     opt("ivf_pass", "2")
-    opt("h16_reg", "2")
-    q0, f0 = capi.prefilter_stats()
-    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
-    same(ids, dis, oi, od)
-    q1, f1 = capi.prefilter_stats()
-    assert q1 - q0 == nq and f1 - f0 <= nq // 4  # the candidate pass ran and certified (almost) everybody
-    keys_r, cnt_r = h16_keys(nq)
-    opt("h16_reg", "0")
-    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
-    same(ids, dis, oi, od)
-    keys_l, cnt_l = h16_keys(nq)
-    if d <= 768:  # one part: the very same approximate values, hence the same survivors (appended in another order)
-        assert (cnt_r == cnt_l).all()
-        for i in range(0, nq, max(1, nq // 16)):
-            if cnt_r[i] <= keys_r.shape[1]:
-                assert sorted(keys_r[i][: cnt_r[i]].tolist()) == sorted(keys_l[i][: cnt_l[i]].tolist())
-    opt("h16_reg", "2")
+    ref_keys = None
+    for grid, ncb in ((0, 0), (0, 1), (2, 2), (1024, 3), (37, 4)):
+        opt("h16_grid", str(grid))
+        opt("h16_ncb", str(ncb))
+        q0, f0 = capi.prefilter_stats()
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+        q1, f1 = capi.prefilter_stats()
+        assert q1 - q0 == nq and f1 - f0 <= nq // 4  # the candidate pass ran and certified (almost) everybody
+        keys, cnt = h16_keys(nq)
+        sets = [sorted(keys[i][: cnt[i]].tolist()) if cnt[i] <= keys.shape[1] else None for i in range(0, nq, max(1, nq // 16))]
+        if ref_keys is None:
+            ref_keys, ref_cnt = sets, cnt
+        else:
+            assert (cnt == ref_cnt).all() and sets == ref_keys
+    opt("h16_grid", "1024")
     opt("h16_nocut", "1")  # every probed row a candidate
     ids, dis = ix.search(q[:64], k, "nprobe=%d" % nprobe)
     same(ids, dis, oi[:64], od[:64])
