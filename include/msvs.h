@@ -44,7 +44,9 @@ typedef enum msvs_status {
     MSVS_ERR_NOT_READY = 5, /* index->ready() == false, VIWithDataPart.cpp:876-879 */
     MSVS_ERR_UNSUPPORTED_K = 6,
     MSVS_ERR_ID_RANGE = 7,
-    MSVS_ERR_IO = 8
+    MSVS_ERR_IO = 8,
+    MSVS_ERR_ABORTED = 236 /* = DB::ErrorCodes::ABORTED (src/Common/ErrorCodes.cpp: M(236, ABORTED)): the build was cancelled
+                              through msvs_index_set_cancel -- what the host itself throws at VIPartReader.h:175-176 */
 } msvs_status;
 
 enum msvs_metric { MSVS_METRIC_L2 = 0, MSVS_METRIC_IP = 1, MSVS_METRIC_COSINE = 2, MSVS_METRIC_HAMMING = 3, MSVS_METRIC_JACCARD = 4 };
@@ -163,6 +165,10 @@ MSVS_API int msvs_index_set_centroids(msvs_index_t * index, const float * centro
 /* One chunk of the build feed: n rows (n*dim f32) + their ids (nullable => consecutive from the current count).
  * Mirrors Search::DataChunk{data, n, dim} + setDataID(ids) (VIPartReader.h:296-303). */
 MSVS_API int msvs_index_add(msvs_index_t * index, const float * x, const int64_t * ids, size_t n, int mem);
+/* The factory's check_cancelled callback (VIWithDataPart.cpp:425-430: BaseDaemon::isCancelled): polled between k-means
+ * iterations of train, at every add and between the phases of build; nonzero -> the call returns MSVS_ERR_ABORTED
+ * ("Cancelled building vector index") and the index stays unbuilt.  NULL clears it. */
+MSVS_API int msvs_index_set_cancel(msvs_index_t * index, int (*is_cancelled)(void * ctx), void * ctx);
 /* Finalise: assign rows to lists, lay lists out contiguously (ascending id inside a list), drop staging. */
 MSVS_API int msvs_index_build(msvs_index_t * index);
 MSVS_API int msvs_index_ready(const msvs_index_t * index);

@@ -22,7 +22,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_NOT_IMPLEMENTED, ERR_DEVICE, ERR_OOM, ERR_NOT_READ
 SYMBOLS = [
     "msvs_last_error", "msvs_version", "msvs_device_count", "msvs_set_device", "msvs_device_synchronize",
     "msvs_knn_f32", "msvs_normalize_f32", "msvs_index_create", "msvs_index_free", "msvs_index_train",
-    "msvs_index_set_centroids", "msvs_index_add", "msvs_index_build", "msvs_index_ready", "msvs_index_num_data",
+    "msvs_index_set_centroids", "msvs_index_set_cancel", "msvs_index_add", "msvs_index_build", "msvs_index_ready", "msvs_index_num_data",
     "msvs_index_num_lists", "msvs_index_memory_usage", "msvs_index_search", "msvs_index_search_device",
     "msvs_index_export", "msvs_index_export_list", "msvs_index_list_stats", "msvs_index_serialize", "msvs_index_load", "msvs_merge_topk", "msvs_merge_topk_device",
     "msvs_postings_create", "msvs_postings_create_fields", "msvs_postings_set_alive", "msvs_postings_free",

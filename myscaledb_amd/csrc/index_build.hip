@@ -312,6 +312,13 @@ extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, in
         std::vector<uint32_t> members(ns);
         for (int it = 0; it < ix->kmeans_iters; it++)
         {
+            if (ix->is_cancelled && ix->is_cancelled(ix->cancel_ctx))
+            {
+                MSVS_HIP(hipStreamSynchronize(stream));
+                ix->centroids.release(); // an index whose training was cut short is untrained again
+                ix->nlist = 0;
+                fail(MSVS_ERR_ABORTED, "Cancelled building vector index");
+            }
             // Lloyd step: L2 assignment (IP/cosine indexes train on L2 too, like Faiss' default clustering)
             msvs_index tmp_view;
             (void)tmp_view;
@@ -428,6 +435,23 @@ extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, in
     });
 }
 
+/// The host's check_cancelled callback (VIWithDataPart.cpp:425-430), polled where a build can still stop cleanly.
+static void poll_cancel(const msvs_index_t * ix)
+{
+    if (ix->is_cancelled && ix->is_cancelled(ix->cancel_ctx))
+        fail(MSVS_ERR_ABORTED, "Cancelled building vector index");
+}
+
+extern "C" int msvs_index_set_cancel(msvs_index_t * ix, int (*is_cancelled)(void *), void * ctx)
+{
+    return guarded([&] {
+        if (!ix)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
+        ix->is_cancelled = is_cancelled;
+        ix->cancel_ctx = ctx;
+    });
+}
+
 extern "C" int msvs_index_add(msvs_index_t * ix, const float * x, const int64_t * ids, size_t n, int mem)
 {
     return guarded([&] {
@@ -435,6 +459,7 @@ extern "C" int msvs_index_add(msvs_index_t * ix, const float * x, const int64_t 
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index/data");
         if (ix->ready)
             fail(MSVS_ERR_INVALID_ARGUMENT, "index already built");
+        poll_cancel(ix);
         if (n == 0)
             return;
         if (ix->type == MSVS_INDEX_IVFFLAT && ix->nlist == 0)
@@ -529,6 +554,7 @@ extern "C" int msvs_index_build(msvs_index_t * ix)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
         if (ix->ready)
             return;
+        poll_cancel(ix);
         hipStream_t stream = nullptr;
         const uint32_t ld = ix->ld;
         const size_t nlist = ix->type == MSVS_INDEX_IVFFLAT ? ix->nlist : 1;

@@ -24,6 +24,8 @@ struct msvs_index
     size_t train_sample = 0;
     uint64_t seed = 1234;
     int shard_rank = 0, shard_world = 1;
+    int (*is_cancelled)(void *) = nullptr; // msvs_index_set_cancel: the host's check_cancelled callback, polled by train / add / build
+    void * cancel_ctx = nullptr;
     // coarse quantiser (IVFFLAT)
     size_t nlist = 0;
     DevBuf<float> centroids; // nlist x ld

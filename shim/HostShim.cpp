@@ -9,6 +9,19 @@
 //            Search::VectorIndex<IS, OS, Bitmap, BinaryVector>  -> MsvsBinaryIndex            (BinaryFLAT, BinaryMSTG*)
 //   seam A2  faiss::knn_L2sqr / knn_inner_product / hammings_knn_mc / jaccard_knn -> msvs_knn_f32 / msvs_knn_bin
 //   (* MSTG is proprietary and absent: its partition scan is served by IVFFLAT with the same metric)
+//
+// FORWARDING (-DMSVS_SEARCH_FORWARD_SUFFIX=<suffix>): a build that keeps contrib/search-index for the index types libmsvs does
+// not serve -- HNSWFLAT / HNSWSQ / HNSWPQ, IVFPQ, IVFSQ, SCANN: the types the open-source README recommends and the functional
+// tests name ~90 times -- compiles that library with its four entry points renamed by the preprocessor
+//     -DcreateVectorIndex=createVectorIndex<suffix> -DgetDefaultIndexType=getDefaultIndexType<suffix>
+//     -DMYSCALE_VALID_INDEX_PARAMETER=MYSCALE_VALID_INDEX_PARAMETER<suffix>
+//     -Dknn_L2sqr=knn_L2sqr<suffix> -Dknn_inner_product=knn_inner_product<suffix> -Dhammings_knn_mc=... -Djaccard_knn=...
+// (a macro renames definition AND internal callers, so the library stays self-consistent; its CLASSES keep their names and are the
+// very types of the stub headers, which is why the rename is by symbol and not by namespace) and links both.  This file then
+// forwards createVectorIndex for every type it does not serve to createVectorIndex<suffix>, takes getDefaultIndexType and the
+// parameter table from the original, and keeps serving FLAT / IVFFLAT / MSTG / Binary* itself.  Same device as TextShim.cpp's
+// MSVS_TANTIVY_FORWARD_NS tee.  Without the macro this library stands alone: unserved types throw NOT_IMPLEMENTED, which the
+// host turns into its CPU brute-force fallback (VIWithDataPart.cpp:948-956).
 #include <SearchIndex/VectorIndex.h>
 #include <faiss/utils/distances.h>
 
@@ -17,8 +30,39 @@
 
 #include "../include/msvs.h"
 
+#ifdef MSVS_SEARCH_FORWARD_SUFFIX
+#define MSVS_CAT2(a, b) a##b
+#define MSVS_CAT(a, b) MSVS_CAT2(a, b)
+#define MSVS_FWD(name) MSVS_CAT(name, MSVS_SEARCH_FORWARD_SUFFIX)
+namespace Search
+{
+// the original library's entry points under their build-time names (see the header of this file)
+template <typename IS, typename OS, typename Bitmap, DataType T>
+std::shared_ptr<VectorIndex<IS, OS, Bitmap, T>> MSVS_FWD(createVectorIndex)(const std::string & name, IndexType type, Metric metric,
+                                                                            size_t dimension, size_t total_vec, const Parameters & params,
+                                                                            size_t max_threads, const std::string & cache_prefix,
+                                                                            std::function<bool()> check_cancelled);
+std::string MSVS_FWD(getDefaultIndexType)(const DataType & search_type);
+extern const std::string MSVS_FWD(MYSCALE_VALID_INDEX_PARAMETER);
+}
+#endif
+
 namespace
 {
+
+/// The index types libmsvs serves itself (everything else: forwarded, or NOT_IMPLEMENTED).
+[[maybe_unused]] bool served_by_msvs(Search::IndexType t)
+{
+    return t == Search::IndexType::FLAT || t == Search::IndexType::IVFFLAT || t == Search::IndexType::MSTG
+        || t == Search::IndexType::BinaryFLAT || t == Search::IndexType::BinaryMSTG;
+}
+
+/// msvs_index_set_cancel's C callback over the factory's std::function (VIWithDataPart.cpp:425-430).
+int cancel_trampoline(void * ctx)
+{
+    auto * f = static_cast<std::function<bool()> *>(ctx);
+    return (*f && (*f)()) ? 1 : 0;
+}
 
 [[noreturn]] void raise(int code)
 {
@@ -108,8 +152,8 @@ public:
     using Reader = Search::IndexSourceDataReader<float>;
 
     MsvsVectorIndex(Search::IndexType type_, Search::Metric metric_, size_t dim_, size_t total_vec_,
-                    const Search::Parameters & params_)
-        : type(type_), metric(metric_), dim(dim_), total_vec(total_vec_), params(params_)
+                    const Search::Parameters & params_, std::function<bool()> factory_cancel_ = {})
+        : type(type_), metric(metric_), dim(dim_), total_vec(total_vec_), params(params_), factory_cancel(std::move(factory_cancel_))
     {
         create();
     }
@@ -121,8 +165,20 @@ public:
     /// train on a sample, then add the part chunk by chunk (VIPartReader::readDataImpl feeds dense float[n x dim] +
     /// idx_t[n]; rows of empty arrays arrive as zero vectors with id 0 and are listed in the reader's emptyIds(): the
     /// host excludes them through the filter bitmap, as it does for every index type)
+    /// check_cancelled (and the factory's callback, VIWithDataPart.cpp:425-430) are polled between the chunks here AND inside the
+    /// library between k-means iterations / at every add / in build (msvs_index_set_cancel): a cancelled build leaves with the
+    /// host's own error, code DB::ErrorCodes::ABORTED (236) "Cancelled building vector index" (VIPartReader.h:175-176).
     void build(Reader * reader, int /*num_threads*/, std::function<bool()> check_cancelled) override
     {
+        std::function<bool()> either = [this, check_cancelled] {
+            return (check_cancelled && check_cancelled()) || (factory_cancel && factory_cancel());
+        };
+        struct Uninstall
+        {
+            msvs_index_t * ix;
+            ~Uninstall() { msvs_index_set_cancel(ix, nullptr, nullptr); }
+        } uninstall{ix};
+        check(msvs_index_set_cancel(ix, &cancel_trampoline, &either));
         const size_t row_bytes = dim * sizeof(float);
         if (msvs_kind() == MSVS_INDEX_IVFFLAT)
         {
@@ -133,8 +189,8 @@ public:
         const size_t rows_per = std::max<size_t>(1, (add_chunk ? add_chunk : ((size_t)64 << 20)) / row_bytes);
         while (!reader->eof())
         {
-            if (check_cancelled && check_cancelled())
-                throw Search::SearchIndexException(MSVS_ERR_DEVICE, "Cancelled building vector index");
+            if (either())
+                throw Search::SearchIndexException(MSVS_ERR_ABORTED, "Cancelled building vector index");
             auto chunk = reader->readData(rows_per);
             if (!chunk)
                 break;
@@ -186,15 +242,22 @@ public:
             o->close();
     }
     void saveDataID(Search::IndexDataFileWriter<OS> *) override {} // id_list travels with serialize()
+    /// check_expired (VIWithDataPart.cpp:577-600, :698: the cache entry was dropped while the load was queued) is asked before the
+    /// files are read and again before the loaded index replaces the old one: an expired load leaves the object untouched
     void load(Search::IndexDataFileReader<IS> * reader, std::function<bool()> check_expired) override
     {
         if (check_expired && check_expired())
-            throw Search::SearchIndexException(MSVS_ERR_IO, "index files expired before load");
+            throw Search::SearchIndexException(MSVS_ERR_ABORTED, "vector index expired before load");
         StreamIO<IS, OS> s;
         s.reader = reader;
         const msvs_io_t io = s.io();
         msvs_index_t * loaded = nullptr;
         check(msvs_index_load_io(&io, &loaded));
+        if (check_expired && check_expired())
+        {
+            msvs_index_free(loaded);
+            throw Search::SearchIndexException(MSVS_ERR_ABORTED, "vector index expired during load");
+        }
         msvs_index_free(ix);
         ix = loaded;
     }
@@ -235,6 +298,7 @@ private:
     Search::Metric metric;
     size_t dim, total_vec;
     Search::Parameters params;
+    std::function<bool()> factory_cancel;
     size_t train_chunk = 0, add_chunk = 0;
     msvs_index_t * ix = nullptr;
 };
@@ -249,8 +313,9 @@ class MsvsBinaryIndex final : public Search::VectorIndex<IS, OS, Bitmap, Search:
 public:
     using Reader = Search::IndexSourceDataReader<bool>;
 
-    MsvsBinaryIndex(Search::IndexType type_, Search::Metric metric_, size_t dim_bits, size_t total_vec_)
-        : type(type_), metric(metric_), dim(dim_bits), total_vec(total_vec_)
+    MsvsBinaryIndex(Search::IndexType type_, Search::Metric metric_, size_t dim_bits, size_t total_vec_,
+                    std::function<bool()> factory_cancel_ = {})
+        : type(type_), metric(metric_), dim(dim_bits), total_vec(total_vec_), factory_cancel(std::move(factory_cancel_))
     {
         if (type != Search::IndexType::BinaryFLAT && type != Search::IndexType::BinaryMSTG)
             throw Search::SearchIndexException(MSVS_ERR_NOT_IMPLEMENTED,
@@ -270,8 +335,8 @@ public:
         const size_t rows_per = std::max<size_t>(1, (add_chunk ? add_chunk : ((size_t)64 << 20)) / row_bytes);
         while (!reader->eof())
         {
-            if (check_cancelled && check_cancelled())
-                throw Search::SearchIndexException(MSVS_ERR_DEVICE, "Cancelled building vector index");
+            if ((check_cancelled && check_cancelled()) || (factory_cancel && factory_cancel()))
+                throw Search::SearchIndexException(MSVS_ERR_ABORTED, "Cancelled building vector index");
             auto chunk = reader->readData(rows_per);
             if (!chunk)
                 break;
@@ -345,6 +410,7 @@ private:
     Search::IndexType type;
     Search::Metric metric;
     size_t dim, total_vec;
+    std::function<bool()> factory_cancel;
     size_t add_chunk = 0;
     bool built = false;
     msvs_bin_index_t * ix = nullptr;
@@ -399,16 +465,71 @@ IndexType getVectorIndexType(const std::string & name, DataType)
     throw SearchIndexException(MSVS_ERR_INVALID_ARGUMENT, "unknown vector index type `" + name + "`");
 }
 
-template <typename IS, typename OS, typename Bitmap, DataType T>
-std::shared_ptr<VectorIndex<IS, OS, Bitmap, T>> createVectorIndex(const std::string & /*name*/, IndexType type, Metric metric,
-                                                                  size_t dimension, size_t total_vec, const Parameters & params,
-                                                                  size_t /*max_threads*/, const std::string & /*cache_prefix*/,
-                                                                  std::function<bool()> /*check_cancelled*/)
+/// `TYPE DEFAULT` (VIDescriptions.cpp:133-137): the library's pick per data type.  The cloud build's default is MSTG /
+/// BinaryMSTG (tests/queries/2_vector_search: `TYPE default('metric_type=IP')`, `default('metric_type=Jaccard')` on binary
+/// columns); both are served here (MSTG's partition scan by IVFFLAT).  Forwarding builds ask the original.
+std::string getDefaultIndexType(const DataType & search_type)
 {
+#ifdef MSVS_SEARCH_FORWARD_SUFFIX
+    return MSVS_FWD(getDefaultIndexType)(search_type);
+#else
+    return search_type == DataType::FloatVector ? "MSTG" : "BinaryMSTG";
+#endif
+}
+
+/// The parameter table (parseVSParameters.cpp:78-222, VIDescriptions.cpp:172-330) of the types libmsvs serves: what
+/// msvs_index_create parses (ncentroids, kmeans_iters, train_sample, seed) and what msvs_index_search takes (nprobe; MSTG's
+/// `alpha`, seen in the functional tests as distance('alpha=4') / 'alpha=3.7', is accepted and ignored: the stand-in scans
+/// nprobe partitions), plus the `metric_type` every type carries (`metric`: the spelling of 00005's IVFFLAT DDL) and MSTG's
+/// `disk_mode` (00028: accepted, no effect -- the index lives in HBM).
+static const char * const msvs_parameter_table = R"JSON({
+"FLAT": {"metric_type": {"type": "string", "case_sensitive": false, "range": [], "candidates": ["L2", "Cosine", "IP"]}},
+"IVFFLAT": {"metric_type": {"type": "string", "case_sensitive": false, "range": [], "candidates": ["L2", "Cosine", "IP"]},
+            "metric": {"type": "string", "case_sensitive": false, "range": [], "candidates": ["L2", "Cosine", "IP"]},
+            "ncentroids": {"type": "int", "case_sensitive": false, "range": [1, 1048576], "candidates": []},
+            "kmeans_iters": {"type": "int", "case_sensitive": false, "range": [1, 1000], "candidates": []},
+            "train_sample": {"type": "int", "case_sensitive": false, "range": [1, 2147483647], "candidates": []},
+            "seed": {"type": "int", "case_sensitive": false, "range": [0, 2147483647], "candidates": []},
+            "nprobe": {"type": "int", "case_sensitive": false, "range": [1, 1048576], "candidates": []}},
+"MSTG": {"metric_type": {"type": "string", "case_sensitive": false, "range": [], "candidates": ["L2", "Cosine", "IP"]},
+         "disk_mode": {"type": "int", "case_sensitive": false, "range": [0, 2], "candidates": []},
+         "ncentroids": {"type": "int", "case_sensitive": false, "range": [1, 1048576], "candidates": []},
+         "nprobe": {"type": "int", "case_sensitive": false, "range": [1, 1048576], "candidates": []},
+         "alpha": {"type": "float", "case_sensitive": false, "range": [1, 4], "candidates": []}},
+"BINARYFLAT": {"metric_type": {"type": "string", "case_sensitive": false, "range": [], "candidates": ["Hamming", "Jaccard"]}},
+"BINARYMSTG": {"metric_type": {"type": "string", "case_sensitive": false, "range": [], "candidates": ["Hamming", "Jaccard"]},
+               "disk_mode": {"type": "int", "case_sensitive": false, "range": [0, 2], "candidates": []},
+               "alpha": {"type": "float", "case_sensitive": false, "range": [1, 4], "candidates": []}}
+})JSON";
+
+#ifdef MSVS_SEARCH_FORWARD_SUFFIX
+/// forwarding build: the original library's table is the reference's truth for every type, including the ones served here
+/// (initialised from the original's object: link the original as a shared library this one depends on, so that its
+/// initialisers have run -- or make the original's table a constant-initialised string)
+const std::string MYSCALE_VALID_INDEX_PARAMETER = MSVS_FWD(MYSCALE_VALID_INDEX_PARAMETER);
+#else
+const std::string MYSCALE_VALID_INDEX_PARAMETER = msvs_parameter_table;
+#endif
+
+template <typename IS, typename OS, typename Bitmap, DataType T>
+std::shared_ptr<VectorIndex<IS, OS, Bitmap, T>> createVectorIndex(const std::string & name, IndexType type, Metric metric,
+                                                                  size_t dimension, size_t total_vec, const Parameters & params,
+                                                                  size_t max_threads, const std::string & cache_prefix,
+                                                                  std::function<bool()> check_cancelled)
+{
+#ifdef MSVS_SEARCH_FORWARD_SUFFIX
+    if (!served_by_msvs(type)) // HNSW*, IVFPQ, IVFSQ, SCANN: the original library's object behind the same interface
+        return MSVS_FWD(createVectorIndex)<IS, OS, Bitmap, T>(name, type, metric, dimension, total_vec, params, max_threads,
+                                                              cache_prefix, std::move(check_cancelled));
+#else
+    (void)name;
+    (void)max_threads;
+    (void)cache_prefix;
+#endif
     if constexpr (T == DataType::FloatVector)
-        return std::make_shared<MsvsVectorIndex<IS, OS, Bitmap>>(type, metric, dimension, total_vec, params);
+        return std::make_shared<MsvsVectorIndex<IS, OS, Bitmap>>(type, metric, dimension, total_vec, params, std::move(check_cancelled));
     else
-        return std::make_shared<MsvsBinaryIndex<IS, OS, Bitmap>>(type, metric, dimension, total_vec);
+        return std::make_shared<MsvsBinaryIndex<IS, OS, Bitmap>>(type, metric, dimension, total_vec, std::move(check_cancelled));
 }
 
 // the instantiation the host uses (VICommon.h:142-143)

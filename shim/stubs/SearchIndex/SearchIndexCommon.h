@@ -54,6 +54,12 @@ std::string enumToString(Metric m);
 /// case-insensitive (helpers/00000_prepare_index_cosine.sh:6 writes "cosine")
 Metric getMetricType(const std::string & name, DataType type);
 IndexType getVectorIndexType(const std::string & name, DataType type);
+/// VIDescriptions.cpp:41,133 (`TYPE DEFAULT`), declared there with exactly this signature
+std::string getDefaultIndexType(const DataType & search_type);
+/// parseVSParameters.cpp:78, VIDescriptions.cpp:172: a JSON object  INDEX TYPE (upper case) -> parameter name ->
+/// {"type": "int" | "float" | "string", "case_sensitive": bool, "range": [lo, hi] | [], "candidates": [...]}  driving the DDL
+/// check of `TYPE X('k=v', ...)` (VIDescriptions.cpp:248-330) and the check of search arguments (parseVSParameters.cpp:76-222)
+extern const std::string MYSCALE_VALID_INDEX_PARAMETER;
 
 /// string -> string map (VICommon.h:127,186-212; MergeTreeVSManager.cpp:361-366; VIWithDataPart.cpp:645,910-911)
 class Parameters : public std::map<std::string, std::string>

@@ -220,6 +220,63 @@ int main(int argc, char ** argv)
         dump(dir + "/out_ids_f.bin", r2->getResultIndices(), nq * k);
         dump(dir + "/out_dis_f.bin", r2->getResultDistances(), nq * k);
 
+        // ---- cancellation (VIWithDataPart.cpp:425-430: the factory's callback; VIPartReader.h:175-176: the host's own error):
+        // (a) the callback turns true after two add chunks, (b) it turns true in the middle of the k-means iterations (polled
+        // inside the library) -- both builds must leave with code DB::ErrorCodes::ABORTED = 236 and an unbuilt index
+        for (int scenario = 0; scenario < 2; scenario++)
+        {
+            int calls = 0;
+            // scenario 0: build()'s chunk loop polls once per chunk (+ the library once per add): true from the 5th call on;
+            // scenario 1: the FACTORY callback, true from its 3rd call on -- for IVFFLAT that is inside msvs_index_train
+            const int limit = scenario == 0 ? 5 : 3;
+            std::function<bool()> counting = [&calls, limit]() { return ++calls >= limit; };
+            std::function<bool()> never = []() { return false; };
+            auto doomed = Search::createVectorIndex<IS, OS, Bitmap, Search::DataType::FloatVector>(
+                "v3", type, metric, d, n, des, 8, "cache/", scenario == 1 ? counting : never);
+            doomed->setAddDataChunkSize((size_t)64 << 10); // many small chunks
+            PartReader part2(x, n, d);
+            int code = 0;
+            std::string what;
+            try
+            {
+                doomed->build(&part2, 4, scenario == 0 ? counting : never);
+            }
+            catch (const SearchIndexException & e)
+            {
+                code = e.getCode();
+                what = e.what();
+            }
+            if (code != 236 || what.find("Cancelled building vector index") == std::string::npos || doomed->ready())
+                throw std::runtime_error("cancelled build (scenario " + std::to_string(scenario) + "): code " + std::to_string(code) + " `" + what + "`");
+            std::cout << "cancel_scenario_" << scenario << " code " << code << " after " << calls << " polls\n";
+        }
+        // an expired load (VIWithDataPart.cpp:698: check_index_expired) leaves the object as it was
+        {
+            auto fresh = Search::createVectorIndex<IS, OS, Bitmap, Search::DataType::FloatVector>("v1", type, metric, d, n, load_params, 8,
+                                                                                                   "cache/", cancel);
+            auto fr = Search::IndexDataFileReader<IS>(
+                "part/v1-", [&](const std::string & name, std::ios::openmode) { return std::make_shared<MemReader>(name); });
+            bool expired = false;
+            try
+            {
+                fresh->load(&fr, []() { return true; });
+            }
+            catch (const SearchIndexException & e)
+            {
+                expired = e.getCode() == 236;
+            }
+            if (!expired || fresh->ready())
+                throw std::runtime_error("expired load did not abort");
+        }
+        // the parameter table and the default type the DDL / search-argument checks read (parseVSParameters.cpp:78, VIDescriptions.cpp:133,172)
+        {
+            std::ofstream t(dir + "/param_table.json");
+            t << Search::MYSCALE_VALID_INDEX_PARAMETER;
+            std::ofstream dflt(dir + "/default_types.txt");
+            dflt << Search::getDefaultIndexType(Search::DataType::FloatVector) << " "
+                 << Search::getDefaultIndexType(Search::DataType::BinaryVector) << "\n";
+        }
+
         // an index type libmsvs does not serve must surface as SearchIndexException (-> VIException in the host)
         bool threw = false;
         try

@@ -19,11 +19,44 @@ def test_shim_is_built_against_the_stub_headers():
     out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", os.path.join(ROOT, "shim", "_build", "libmsvs_shim.so")],
                                   text=True)
     for sym in ("faiss::knn_L2sqr", "faiss::knn_inner_product", "faiss::hammings_knn_mc", "jaccard_knn",
-                "Search::createVectorIndex", "Search::getMetricType"):
+                "Search::createVectorIndex", "Search::getMetricType",
+                # what the DDL and the search-argument checks link against (parseVSParameters.cpp:78, VIDescriptions.cpp:41,133,172)
+                "Search::MYSCALE_VALID_INDEX_PARAMETER", "Search::getDefaultIndexType"):
         assert sym in out, sym
     # both instantiations the host links against (VICommon.h:142-143): FloatVector = (Search::DataType)0, BinaryVector = 1
     made = [ln for ln in out.split("\n") if "Search::createVectorIndex<" in ln]
     assert any("(Search::DataType)0" in ln for ln in made) and any("(Search::DataType)1" in ln for ln in made), made
+
+
+def test_forwarding_build_compiles():
+    """-DMSVS_SEARCH_FORWARD_SUFFIX: every index type libmsvs does not serve (HNSW*, IVFPQ, IVFSQ, SCANN) goes to the original
+    library's factory under its build-time name, the parameter table and the default type come from the original (header of
+    shim/HostShim.cpp) -- same device as TextShim.cpp's forwarding namespace."""
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Istubs",
+                           "-DMSVS_SEARCH_FORWARD_SUFFIX=Original", "HostShim.cpp"], cwd=os.path.join(ROOT, "shim"))
+    pre = subprocess.check_output(["g++", "-std=c++17", "-E", "-P", "-Istubs", "-DMSVS_SEARCH_FORWARD_SUFFIX=Original", "HostShim.cpp"],
+                                  cwd=os.path.join(ROOT, "shim"), text=True)
+    assert "createVectorIndexOriginal<IS, OS, Bitmap, T>(name, type" in pre and "getDefaultIndexTypeOriginal(search_type)" in pre
+    assert "MYSCALE_VALID_INDEX_PARAMETER = MYSCALE_VALID_INDEX_PARAMETEROriginal" in pre
+
+
+def test_parameter_table_is_the_json_the_host_parses():
+    """Search::MYSCALE_VALID_INDEX_PARAMETER as VIDescriptions.cpp:172-330 / parseVSParameters.cpp:78-222 read it: index type (upper
+    case) -> parameter -> {type, case_sensitive, range, candidates}; it names what msvs_index_create / msvs_index_search parse and
+    the arguments the reference's functional tests pass to the served types."""
+    import json
+    import re
+    src = open(os.path.join(ROOT, "shim", "HostShim.cpp")).read()
+    table = json.loads(re.search(r'R"JSON\((.*?)\)JSON"', src, re.S).group(1))
+    assert set(table) == {"FLAT", "IVFFLAT", "MSTG", "BINARYFLAT", "BINARYMSTG"}
+    for typ, params in table.items():
+        assert typ == typ.upper() and "metric_type" in params
+        for name, spec in params.items():
+            assert set(spec) == {"type", "case_sensitive", "range", "candidates"} and spec["type"] in ("int", "float", "string"), (typ, name)
+            assert len(spec["range"]) in (0, 2) and isinstance(spec["candidates"], list)
+    assert {"ncentroids", "nprobe", "metric"} <= set(table["IVFFLAT"])  # 00005: TYPE IVFFLAT('metric=IP', 'ncentroids=5000'), distance('nprobe = 8')
+    assert {"alpha", "disk_mode"} <= set(table["MSTG"])  # 00028: TYPE mstg('metric_type=Cosine', 'disk_mode=1'), distance('alpha=4.2')
+    assert set(table["BINARYFLAT"]["metric_type"]["candidates"]) == {"Hamming", "Jaccard"}
 
 
 @pytest.mark.gpu
@@ -46,6 +79,11 @@ def test_shim_end_to_end_matches_oracle(metric, typ):
         r = subprocess.run([EXE, td], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
         rd = lambda name, dt: np.fromfile(os.path.join(td, name + ".bin"), dt)
+        # both cancellation scenarios left with the host's ABORTED code; the table is JSON; TYPE DEFAULT resolves to served types
+        assert "cancel_scenario_0 code 236" in r.stdout and "cancel_scenario_1 code 236" in r.stdout, r.stdout
+        import json
+        assert "IVFFLAT" in json.load(open(os.path.join(td, "param_table.json")))
+        assert open(os.path.join(td, "default_types.txt")).read().split() == ["MSTG", "BinaryMSTG"]
         files = open(os.path.join(td, "files.txt")).read().split("\n")
         assert files[0].startswith("part/v1-data_bin.vidx3 ") and files[1].startswith("part/v1-id_list.vidx3 ")
         assert files[2].startswith("version msvs-")
