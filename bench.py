@@ -433,7 +433,8 @@ def main():
     def step(i):
         q = q_all[(i % n_pool) * B:(i % n_pool + 1) * B]
         if world > 1:
-            ix.shard_search_device(comm, q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
+            # two batches in flight: batch i's top-k exchange + merge under batch i + 1's scan; fence() drains (device sync)
+            ix.shard_search_device_async(comm, q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
         else:
             ix.search_device(q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
 
@@ -1177,7 +1178,8 @@ def main():
             "config": {"workload": "IVFFLAT nlist=%d, %dx%d f32, L2, nprobe=%d, top-%d, batch %d queries/step "
                                    "(BASELINE.json configs[1])" % (nlist, n, d, nprobe, k, B),
                        "rows": n, "dim": d, "nlist": nlist, "nprobe": nprobe, "k": k, "batch": B,
-                       "parallelism": ("lists %% %d, coarse quantiser by query, probe + packed top-k all-gathers; transport: %s"
+                       "parallelism": ("lists %% %d, coarse quantiser by query, probe (+ coarse distance word) and packed top-k all-gathers, "
+                                       "two batches in flight (msvs_shard_search_device_async); transport: %s"
                                        % (world, comm_kind)) if world > 1 else "single GPU",
                        "data_model": data_desc},
             "recall_at_10": None if recall is None else round(recall, 4),

@@ -312,6 +312,18 @@ MSVS_API int msvs_comm_size(const msvs_comm_t * comm);
 MSVS_API int msvs_shard_search_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries,
                                       size_t nq, int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits,
                                       int64_t * d_ids, float * d_dis, void * hip_stream);
+/* The same search with TWO BATCHES IN FLIGHT: the call returns once batch i is enqueued; `hip_stream` orders its INPUTS only,
+ * its results are complete when *done_event -- a hipEvent_t owned by the communicator, valid until the second-next async call on
+ * it -- has fired: hipStreamWaitEvent on whatever stream reads d_ids / d_dis, or msvs_shard_search_drain.  The coarse pass and
+ * the list scan run on the communicator's compute stream, both all-gathers and the merge on its exchange stream, so the packed
+ * top-k exchange + merge of batch i (latency-bound: tens of microseconds over xGMI) hide under the list scan of batch i + 1 --
+ * the per-part searches of MergeTreeBaseSearchManager.cpp:207-299 overlapping with the merge of the previous query.  d_queries,
+ * d_ids, d_dis of a batch must stay untouched until its event; every rank issues the same sequence of calls. */
+MSVS_API int msvs_shard_search_device_async(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries,
+                                            size_t nq, int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits,
+                                            int64_t * d_ids, float * d_dis, void * hip_stream, void ** done_event);
+/* `hip_stream` waits for every batch still in flight on the communicator. */
+MSVS_API int msvs_shard_search_drain(const msvs_comm_t * comm, void * hip_stream);
 
 /* Multi-part / multi-GPU merge of partial top-k lists with the canonical total order -- the
  * device-side analogue of MergeTreeBaseSearchManager::getTotalTopSearchResultImpl

@@ -36,7 +36,7 @@ SYMBOLS = [
     "msvs_bin_index_add", "msvs_bin_index_num_data", "msvs_bin_index_search", "msvs_bin_index_serialize_io", "msvs_bin_index_load_io",
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
     "msvs_index_set_merged_maps", "msvs_comm_unique_id", "msvs_comm_init", "msvs_comm_init_custom",
-    "msvs_comm_free", "msvs_comm_all_reduce_u64", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device",
+    "msvs_comm_free", "msvs_comm_all_reduce_u64", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device", "msvs_shard_search_device_async", "msvs_shard_search_drain",
     "msvs_hybrid_fuse_device",
 ]
 
@@ -329,6 +329,10 @@ class Comm:
         self._h = h
         self.nranks, self.rank = nranks, rank
 
+    def drain(self, stream=0):
+        """msvs_shard_search_drain: `stream` waits for every batch of msvs_shard_search_device_async still in flight."""
+        _check(lib().msvs_shard_search_drain(self._h, C.c_void_p(int(stream)) if stream else None))
+
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.msvs_comm_free.argtypes = [C.c_void_p]
@@ -513,6 +517,15 @@ class Index:
                                               int(nprobe), C.c_void_p(int(d_alive)) if d_alive else None,
                                               C.c_size_t(nbits), C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
                                               C.c_void_p(int(stream)) if stream else None))
+
+    def shard_search_device_async(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0):
+        """msvs_shard_search_device_async: two batches in flight; returns the batch's done event (a hipEvent_t address)."""
+        ev = C.c_void_p()
+        _check(lib().msvs_shard_search_device_async(self._h, comm._h, C.c_void_p(int(d_queries)), C.c_size_t(nq), int(k),
+                                                    int(nprobe), C.c_void_p(int(d_alive)) if d_alive else None,
+                                                    C.c_size_t(nbits), C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
+                                                    C.c_void_p(int(stream)) if stream else None, C.byref(ev)))
+        return ev.value
 
     def scanned_rows(self, queries, nprobe):
         q = _f32(queries).reshape(-1, self.dim)

@@ -755,7 +755,18 @@ __device__ inline uint32_t h16_cut_floor(const uint32_t (&word)[NW], uint32_t cu
     return floor_word > cut ? floor_word : cut;
 }
 
-/// PROBE PRUNING (L2; round 3).  The oracle scans all nprobe lists of a query; most of them cannot hold one of its k nearest rows,
+/// Probe words of a sharded search: words[q][p] = the coarse pass's approximate distance word of probe p's centroid (0xFFFFFFFF: none).
+static __global__ void gather_probe_words_kernel(const int32_t * probes, const uint32_t * coarse_words, uint32_t npad, uint32_t nprobe,
+                                                 size_t n_pairs, uint32_t * words)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs)
+        return;
+    const int32_t l = probes[i];
+    words[i] = l >= 0 ? coarse_words[(i / nprobe) * npad + (uint32_t)l] : 0xFFFFFFFFu;
+}
+
+/// PROBE PRUNING (L2 and cosine: round 3; inner product, probes computed on another rank, k > 64: round 4).  The oracle scans all nprobe lists of a query; most of them cannot hold one of its k nearest rows,
 /// and that can be PROVED before the main launch: the k-th smallest approximate distance among the query's sample rows (real,
 /// probed, unfiltered rows) plus eps is an upper bound U of its k-th best canonical distance; a row x of list l has
 /// ||q - x|| >= ||q - c_l|| - r_l (triangle inequality, r_l = the list's radius: ivf_build_kernels.hpp), ||q - c_l||^2 is known
@@ -766,11 +777,15 @@ __device__ inline uint32_t h16_cut_floor(const uint32_t (&word)[NW], uint32_t cu
 /// 548 -> ~300 us per 4096-query step on the bench index; on iid data nothing is dropped and the second plan costs ~20 us.
 struct H16Prune
 {
-    const uint32_t * coarse_words; // [nq][npad]: the coarse pass's approximate distance word of every centroid; nullptr: no pruning
+    const uint32_t * coarse_words; // [nq][npad]: the coarse pass's approximate distance word of every centroid; nullptr: ...
     uint32_t npad;
+    const uint32_t * probe_words;  // ... or [nq][nprobe]: the same words gathered per probe (a sharded search: the coarse pass of a
+                                   // query ran on another rank and its words came with the probe lists); both nullptr: no pruning
     const float * radius; // [nlist]
     const float * cnorm;  // [nlist] |c_l|^2 (cosine form only)
-    int ip;               // 0: L2 index; 1: cosine index (unit rows and queries, the scan ranks by inner product)
+    int ip;               // 0: L2 index; 1: cosine index (unit rows and queries, the scan ranks by inner product); 2: inner-product
+                          // index: <q, x> = <q, c> + <q, x - c> <= <q, c> + |q| r_l (Cauchy-Schwarz)
+    __host__ __device__ bool on() const { return coarse_words || probe_words; }
     const float * qnorm;  // |q|^2 (+inf: unusable)
     float xmax, cmax;     // max |x|^2 over the rows / the centroids
     double c_dot, c_norm, c_canon; // the shadow passes' error model
@@ -816,24 +831,32 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
     }
     uint32_t m = rows ? (uint32_t)(((uint64_t)target * have + rows - 1) / rows) : 4u;
     m = m < 4 ? 4 : (m > 64 ? 64 : m);
-    if (pr.coarse_words && m < pr.k)
-        m = pr.k; // the cut doubles as the pruning's upper bound: at least k sample rows must lie at or below it (one selection, not two)
+    // the cut doubles as the pruning's upper bound when it can: at least k sample rows must lie at or below it (one selection, not
+    // two).  Not when the query has fewer than k live sample rows (a selective filter: the cut would be "none", every probed row a
+    // candidate) and not beyond k = 64 (a hybrid search's top-100: the cut would triple the candidates) -- the bound then takes a
+    // selection of its own.
+    if (pr.on() && m < pr.k && have >= pr.k && pr.k <= 64)
+        m = pr.k;
     uint32_t cut = target == 0 ? 0xFFFFFFFFu : wave_kth_word<NW>(word, m, hist, lane);
-    if (pr.coarse_words)
+    if (pr.on())
     {
-        // the m-th smallest sample word, m >= k (0xFFFFFFFF: fewer than m sample rows -- no bound, nothing is dropped)
-        const uint32_t uw = target != 0 ? cut : wave_kth_word<NW>(word, pr.k, hist, lane);
+        // the k-th smallest sample word or a larger one (0xFFFFFFFF: fewer than k sample rows -- no bound, nothing is dropped)
+        const uint32_t uw = target != 0 && m >= pr.k ? cut : wave_kth_word<NW>(word, pr.k, hist, lane);
         const int32_t l = lane < nprobe ? qprobes[lane] : -1;
+        const uint32_t cw = l >= 0 ? (pr.probe_words ? pr.probe_words[(size_t)q * nprobe + lane] : pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l])
+                                   : 0xFFFFFFFFu;
         bool keep = true;
         const float qn = pr.qnorm[q];
         if (uw != 0xFFFFFFFFu && l >= 0 && qn < 1e30f && pr.xmax < 1e30f && pr.cmax < 1e30f)
         {
             const double sq = sqrt((double)qn * 1.001), sx = sqrt((double)pr.xmax * 1.001), sc = sqrt((double)pr.cmax * 1.001);
-            if (!pr.ip)
+            if (cw == 0xFFFFFFFFu)
+                ; // no coarse value for this probe: kept
+            else if (pr.ip == 0)
             {
                 const double eps_x = 2.0 * pr.c_dot * sx * sq + pr.c_norm * (sx * sx + sq * sq) + (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30;
                 const double eps_c = 2.0 * pr.c_dot * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
-                const double ak = (double)ord2f(uw), ac = (double)ord2f(pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l]);
+                const double ak = (double)ord2f(uw), ac = (double)ord2f(cw);
                 const double inner = ac - 2.0 * eps_c;
                 if (inner > 0.0)
                 {
@@ -842,13 +865,24 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
                         keep = !((dc - r) * (dc - r) * (1.0 - 1e-7) > ak + 2.0 * eps_x);
                 }
             }
+            else if (pr.ip == 2)
+            {
+                // inner-product index: the words order inner products (larger is better).  >= k sample rows have an approximate
+                // value >= ipk, hence a canonical one >= ipk - eps_x: the k-th best canonical value of the query is at least that.
+                // A row x of list l has <q, x> = <q, c> + <q, x - c> <= <q, c> + |q| r_l, the coarse pass knows <q, c> to within
+                // eps_c (twice: approximate -> canonical -> real), a canonical value exceeds the real one by <= c_canon |x||q| <= eps_x
+                const double eps_x = (pr.c_dot + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.c_dot + pr.c_canon) * sc * sq + 1e-30;
+                const double ipk = (double)ord2f(~uw), ipc = (double)ord2f(~cw);
+                const double ub = ipc + 2.0 * eps_c + sq * (double)pr.radius[l] * (1.0 + 1e-6);
+                keep = !(ub < ipk - 2.0 * eps_x);
+            }
             else
             {
                 // cosine index: the words order inner products (larger is better).  ||q - c||^2 = |q|^2 + |c|^2 - 2 <q, c> from the
                 // coarse pass's <q, c> and the (f32, fma-accumulated: relative error c_norm) norms; a row x of the list has
                 // ||q - x|| >= ||q - c|| - r_l, i.e. <q, x> <= (|q|^2 + |x|^2 - (||q - c|| - r_l)^2) / 2
                 const double eps_x = (pr.c_dot + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.c_dot + pr.c_canon) * sc * sq + 1e-30;
-                const double ipk = (double)ord2f(~uw), ipc = (double)ord2f(~pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l]);
+                const double ipk = (double)ord2f(~uw), ipc = (double)ord2f(~cw);
                 const double cn = (double)pr.cnorm[l];
                 const double d2 = (double)qn * (1.0 - pr.c_norm) + cn * (1.0 - pr.c_norm) - 2.0 * (ipc + eps_c);
                 if (d2 > 0.0)

@@ -154,7 +154,7 @@ void index_finalize_norms(msvs_index & ix, hipStream_t stream)
     MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
     MSVS_HIP(hipStreamSynchronize(stream));
     memcpy(&ix.xnorm_max, &bits, 4); // NaN / inf / huge values switch the candidate pass off (see plan_ivf)
-    if (ix.type == MSVS_INDEX_IVFFLAT && ix.nlist && ix.metric != MSVS_METRIC_IP)
+    if (ix.type == MSVS_INDEX_IVFFLAT && ix.nlist)
     {
         // how far a list's rows lie from its centroid at most: lets a batched search drop (query, list) pairs that provably
         // cannot hold one of the query's k nearest rows (triangle inequality; h16_list_scan)

@@ -54,7 +54,7 @@ struct msvs_index
     DevBuf<float> xnorm;
     float xnorm_max = 0.f;
     DevBuf<float> cnorm; // same for the centroids (the coarse quantiser goes through the same pass)
-    DevBuf<float> list_radius; // nlist: an upper bound of max ||x - c_l|| over the rows of list l (probe pruning, L2 / cosine)
+    DevBuf<float> list_radius; // nlist: an upper bound of max ||x - c_l|| over the rows of list l (probe pruning)
     float cnorm_max = 0.f;
     DevBuf<int64_t> list_mid; // nlist: end of the SAMPLE slice of list l = min(list_off[l] + 128, list_off[l+1])
     // fp16 shadow of the lists (h16_scan_kernels.hpp): the list scan of batched searches reads this instead of vecs
@@ -133,9 +133,17 @@ void combiner_forget(const msvs_index * ix);
 /// The search proper: all pointers on the device, everything enqueued on `stream` (msvs_capi.hip).  given_probes (nullable):
 /// [nq][nprobe] list ids computed elsewhere (another rank's share of the coarse quantiser): step 1 is skipped.  probes_only
 /// (nullable): run ONLY step 1 and leave the probe lists there.
+/// ProbeWords: the probe lists of a sharded search travel with the coarse pass's distance word of every probe (the probe pruning of the list
+/// scan needs it and the rank that scans did not run the coarse pass of that query): [nq][nprobe] each, nullable.
+struct ProbeWords
+{
+    const uint32_t * given = nullptr; // with given_probes
+    uint32_t * out = nullptr;         // with probes_only (0xFFFFFFFF where the coarse pass left no word)
+};
 void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq, uint32_t k, size_t nprobe,
                          const uint64_t * d_alive, size_t nbits, int64_t * d_ids, float * d_dis, hipStream_t stream,
-                         const int32_t * given_probes = nullptr, int32_t * probes_only = nullptr, const SearchView * view = nullptr);
+                         const int32_t * given_probes = nullptr, int32_t * probes_only = nullptr, const SearchView * view = nullptr,
+                         ProbeWords words = ProbeWords{});
 /// The filter a search really runs with: (per-search filter, converted to label space for a decoupled part) AND the resident
 /// delete bitmap.  Returns the device pointer (nullptr = no filter) and its valid bits; scratch from aux_for(stream).
 const uint64_t * effective_filter(const msvs_index & ix, const msvs_index::Meta * meta, const uint64_t * d_alive, size_t nbits,

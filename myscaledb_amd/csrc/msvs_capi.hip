@@ -386,12 +386,15 @@ static size_t big_cand_cap(size_t nprobe, size_t slices_max)
     return std::min<size_t>(nprobe * slices_max * BG_SLICE_K, limit);
 }
 
-static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k, size_t nprobe)
+/// allow_pass: false for a search over a compacted view (it runs the canonical plan, whose partial lists can be LARGER than the
+/// candidate pass's buffers: an inner-product index with one giant list has many segments per probe -- round 4's sparse-filter
+/// case overflowed an arena reserved for the candidate-pass plan)
+static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k, size_t nprobe, bool allow_pass = true)
 {
     size_t b = nq * (size_t)ix.ld * 4 + 2 * (nq * (size_t)(ix.ld + 32) * 4 + 4096) + 4096; // queries (+ split copies)
     if (ix.type == MSVS_INDEX_FLAT)
         return b + flat_scratch_bytes(ix.n, nq, k, ix.ld) + table_pass_scratch(ix.n, nq, std::min<uint32_t>(k, 40));
-    IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k);
+    IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k, allow_pass);
     size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe, ix.ld)
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
         + nq * nprobe * 4
@@ -433,6 +436,7 @@ struct H16Queries
     uint32_t n_counters = 0;
     const uint32_t * coarse_words = nullptr; // out: the coarse pass's approximate distance word of every (query, centroid) ...
     uint32_t coarse_npad = 0;                // ... [nq][coarse_npad]: what the probe pruning of the list scan reads
+    const uint32_t * probe_words = nullptr;  // or, a sharded search: the words of the given probes, [nq][nprobe] (ProbeWords::given)
 };
 
 struct TablePass
@@ -962,16 +966,16 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             // ... when the lists are probed by more queries than one tile holds (then fewer pairs mean fewer passes over a list;
             // below that the second plan and the looser cut cost more than the dropped pairs save: sigma-0.3 blobs at nprobe 2)
             const bool prune_pays = options().h16_prune == 2 || (double)nq * (double)nprobe > (double)ix.nlist * (double)pp.T;
-            if (options().h16_prune != 0 && prune_pays && ix.metric != MSVS_METRIC_IP && prepared.coarse_words && ix.list_radius.p
-                && k <= 64)
+            if (options().h16_prune != 0 && prune_pays && (prepared.coarse_words || prepared.probe_words) && ix.list_radius.p && k <= 128)
             {
                 RerankParams em{};
                 set_error_model_h16(em, ix.dim);
                 pr.coarse_words = prepared.coarse_words;
                 pr.npad = prepared.coarse_npad;
+                pr.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
                 pr.radius = ix.list_radius.p;
                 pr.cnorm = ix.cnorm.p;
-                pr.ip = ix.metric == MSVS_METRIC_COSINE ? 1 : 0;
+                pr.ip = ix.metric == MSVS_METRIC_COSINE ? 1 : ix.metric == MSVS_METRIC_IP ? 2 : 0;
                 pr.qnorm = qnorm;
                 pr.xmax = ix.xnorm_max;
                 pr.cmax = ix.cnorm_max;
@@ -991,7 +995,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
                                sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
                                qstate + nq, partial, pl.h_cap);
     }
-    if (pr.coarse_words)
+    if (pr.on())
     {
         // the main launch's plan over the surviving pairs
         IvfPlanParams p2 = pp;
@@ -1119,33 +1123,34 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
 static void index_search_device_one(const msvs_index & ix, const float * d_queries, size_t nq, uint32_t k, size_t nprobe,
                                     const uint64_t * d_alive, size_t nbits, int64_t * d_ids, float * d_dis,
                                     hipStream_t stream, const int32_t * given_probes = nullptr,
-                                    int32_t * probes_only = nullptr, const SearchView * view = nullptr);
+                                    int32_t * probes_only = nullptr, const SearchView * view = nullptr, ProbeWords words = ProbeWords{});
 
 /// The search proper: all pointers on the device, everything enqueued on `stream`.  Very large batches are cut into
 /// sub-batches of at most 2^21 (query, probe) pairs, stream-ordered one after the other: every scratch buffer of a search
 /// is proportional to the pairs of ONE sub-batch, so the per-(thread, stream) arena stays bounded (~0.5 GB) whatever nq.
 void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq, uint32_t k, size_t nprobe,
                          const uint64_t * d_alive, size_t nbits, int64_t * d_ids, float * d_dis, hipStream_t stream,
-                         const int32_t * given_probes, int32_t * probes_only, const SearchView * view)
+                         const int32_t * given_probes, int32_t * probes_only, const SearchView * view, ProbeWords words)
 {
     const size_t np_eff = ix.type == MSVS_INDEX_IVFFLAT ? std::max<size_t>(1, std::min(nprobe, std::max<size_t>(ix.nlist, 1))) : 1;
     const size_t sub = std::max<size_t>(256, ((size_t)1 << 21) / np_eff);
     if (nq <= sub)
         return index_search_device_one(ix, d_queries, nq, k, nprobe, d_alive, nbits, d_ids, d_dis, stream, given_probes,
-                                       probes_only, view);
+                                       probes_only, view, words);
     for (size_t q0 = 0; q0 < nq; q0 += sub)
     {
         const size_t m = std::min(sub, nq - q0);
         index_search_device_one(ix, d_queries + q0 * ix.dim, m, k, nprobe, d_alive, nbits, d_ids ? d_ids + q0 * k : nullptr,
                                 d_dis ? d_dis + q0 * k : nullptr, stream, given_probes ? given_probes + q0 * np_eff : nullptr,
-                                probes_only ? probes_only + q0 * np_eff : nullptr, view);
+                                probes_only ? probes_only + q0 * np_eff : nullptr, view,
+                                ProbeWords{words.given ? words.given + q0 * np_eff : nullptr, words.out ? words.out + q0 * np_eff : nullptr});
     }
 }
 
 static void index_search_device_one(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq,
                                     uint32_t k, size_t nprobe, const uint64_t * d_alive, size_t nbits, int64_t * d_ids,
                                     float * d_dis, hipStream_t stream, const int32_t * given_probes, int32_t * probes_only,
-                                    const SearchView * view)
+                                    const SearchView * view, ProbeWords words)
 {
     if (!ix.ready)
         fail(MSVS_ERR_NOT_READY, "index is not ready");
@@ -1161,7 +1166,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     }
     const uint32_t d = (uint32_t)ix.dim, ld = ix.ld;
     Scratch & scr = scratch_for(stream);
-    scr.reserve(index_search_scratch(ix, nq, k, nprobe), stream);
+    scr.reserve(index_search_scratch(ix, nq, k, nprobe, view == nullptr), stream);
     // queries: pad and/or normalise into scratch when needed
     const float * dq = d_queries;
     if (ld != d || ix.metric == MSVS_METRIC_COSINE)
@@ -1234,7 +1239,20 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
                            stream);
     }
     if (probes_only)
+    {
+        if (words.out)
+        {
+            // the words of the probes, for the rank that scans (ProbeWords); without a shadow coarse pass there are none
+            if (prepared.coarse_words)
+                hipLaunchKernelGGL(gather_probe_words_kernel, dim3((unsigned)ceil_div(nq * nprobe, (size_t)256)), dim3(256), 0, stream,
+                                   probes_only, prepared.coarse_words, prepared.coarse_npad, (uint32_t)nprobe, nq * nprobe, words.out);
+            else
+                MSVS_HIP(hipMemsetAsync(words.out, 0xFF, nq * nprobe * 4, stream));
+        }
         return;
+    }
+    if (given_probes)
+        prepared.probe_words = words.given;
     // 2. scan the probed lists
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");

@@ -255,64 +255,179 @@ extern "C" int msvs_comm_all_reduce_u64(const msvs_comm_t * comm, uint64_t * val
 extern "C" int msvs_comm_rank(const msvs_comm_t * c) { return c ? c->rank : -1; }
 extern "C" int msvs_comm_size(const msvs_comm_t * c) { return c ? c->nranks : 0; }
 
+/// The pipelined form's state, owned by the communicator: a compute stream, an exchange stream, and per parity of the call
+/// count the events that order the stages and the arena that holds the exchange buffers.
+struct ShardPipe
+{
+    hipStream_t compute = nullptr, xchg = nullptr;
+    hipEvent_t in_ev[2] = {nullptr, nullptr}, ab_ev[2] = {nullptr, nullptr}, x1_ev[2] = {nullptr, nullptr}, b_ev[2] = {nullptr, nullptr},
+               done_ev[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    uint64_t calls = 0;
+    std::mutex mu;
+};
+
+static ShardPipe & pipe_of(const msvs_comm_t * comm)
+{
+    static std::mutex mu;
+    static std::map<const msvs_comm_t *, std::unique_ptr<ShardPipe>> pipes; // (never torn down: a handful per process)
+    std::lock_guard<std::mutex> lk(mu);
+    auto & p = pipes[comm];
+    if (!p)
+    {
+        p.reset(new ShardPipe);
+        MSVS_HIP(hipStreamCreateWithFlags(&p->compute, hipStreamNonBlocking));
+        MSVS_HIP(hipStreamCreateWithFlags(&p->xchg, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++)
+            for (hipEvent_t * e : {&p->in_ev[i], &p->ab_ev[i], &p->x1_ev[i], &p->b_ev[i], &p->done_ev[i]})
+                MSVS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    return *p;
+}
+
+/// cs: the stream of the coarse pass, the list scan and the small copies; xs: the stream of the two all-gathers and the merge
+/// (== cs for the one-stream form); ev_a / ev_x1 / ev_b order the stages across the two when they differ; sh: where the exchange
+/// buffers live (one arena per call in flight).
+static void shard_search_stages(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq, int k, int nprobe,
+                                const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids, float * d_dis, hipStream_t cs,
+                                hipStream_t xs, hipEvent_t ev_a, hipEvent_t ev_x1, hipEvent_t ev_b, Scratch & sh)
+{
+    auto hand_over = [&](hipStream_t from, hipStream_t to, hipEvent_t ev) {
+        if (from == to)
+            return;
+        MSVS_HIP(hipEventRecord(ev, from));
+        MSVS_HIP(hipStreamWaitEvent(to, ev, 0));
+    };
+    const auto meta = ix->get_meta();
+    size_t eff_bits = nbits;
+    const uint64_t * eff = effective_filter(*ix, meta.get(), d_alive_bits, nbits, &eff_bits, cs);
+    const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank;
+    const size_t part = round_up(nq * (size_t)k * 12, 16); // one rank's {ids | dis}
+    const bool ivf = ix->type == MSVS_INDEX_IVFFLAT;
+    const size_t np = ivf ? std::min<size_t>(std::max(nprobe, 1), ix->nlist) : 0;
+    const size_t chunk = ceil_div(nq, W);
+    sh.reserve(W * part + 4 * W * chunk * np * 4 + 8192, cs);
+    unsigned char * packed = sh.take<unsigned char>(W * part);
+    int64_t * my_ids = reinterpret_cast<int64_t *>(packed + r * part);
+    float * my_dis = reinterpret_cast<float *>(packed + r * part + nq * (size_t)k * 8);
+    if (ivf)
+    {
+        // one record per rank: its chunk's probe lists [chunk][np] followed by the coarse pass's distance word of every probe
+        // [chunk][np] -- the probe pruning of the list scan runs on every rank, for every query, although the rank ran the
+        // coarse pass of a W-th of them only (nq np 4 B more in the same all-gather)
+        const size_t rec = 2 * chunk * np; // 32-bit words per rank
+        int32_t * exch = sh.take<int32_t>(W * rec);
+        int32_t * mine = exch + r * rec;
+        uint32_t * mine_words = reinterpret_cast<uint32_t *>(mine + chunk * np);
+        const size_t q0 = std::min(nq, r * chunk), m = std::min(chunk, nq - q0);
+        MSVS_HIP(hipMemsetAsync(mine, 0xFF, rec * 4, cs)); // queries past nq: no probes, no words
+        if (m)
+            index_search_device(*ix, d_queries + q0 * ix->dim, m, 1, np, nullptr, 0, nullptr, nullptr, cs, nullptr, mine, nullptr,
+                                ProbeWords{nullptr, mine_words});
+        hand_over(cs, xs, ev_a);
+        {
+            ProfileScope prof("shard_exchange", xs);
+            comm->all_gather(reinterpret_cast<unsigned char *>(exch), rec * 4, xs);
+        }
+        hand_over(xs, cs, ev_x1);
+        // [rank][probes | words] -> probes [nq][np], words [nq][np]
+        int32_t * probes = sh.take<int32_t>(W * chunk * np);
+        uint32_t * pwords = sh.take<uint32_t>(W * chunk * np);
+        MSVS_HIP(hipMemcpy2DAsync(probes, chunk * np * 4, exch, rec * 4, chunk * np * 4, W, hipMemcpyDeviceToDevice, cs));
+        MSVS_HIP(hipMemcpy2DAsync(pwords, chunk * np * 4, exch + chunk * np, rec * 4, chunk * np * 4, W, hipMemcpyDeviceToDevice, cs));
+        index_search_device(*ix, d_queries, nq, (uint32_t)k, np, eff, eff_bits, my_ids, my_dis, cs, probes, nullptr, nullptr,
+                            ProbeWords{pwords, nullptr});
+    }
+    else
+        index_search_device(*ix, d_queries, nq, (uint32_t)k, 0, eff, eff_bits, my_ids, my_dis, cs);
+    hand_over(cs, xs, ev_b);
+    {
+        ProfileScope prof("shard_exchange", xs);
+        comm->all_gather(packed, part, xs);
+    }
+    // cosine distances leave the search as 1 - ip: ascending like L2
+    const int order = ix->metric == MSVS_METRIC_IP ? MSVS_METRIC_IP : MSVS_METRIC_L2;
+    merge_topk_device(reinterpret_cast<const int64_t *>(packed), part / 8, reinterpret_cast<const float *>(packed + nq * (size_t)k * 8),
+                      part / 4, W, nq, (size_t)k, order, d_ids, d_dis, xs);
+    apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, xs);
+}
+
+static void shard_check(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq, int k, const int64_t * d_ids,
+                        const float * d_dis)
+{
+    if (!ix || !comm || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "null index / communicator / buffer or negative k");
+    if (comm->nranks != ix->shard_world || comm->rank != ix->shard_rank)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "the index is shard %d of %d but the communicator is rank %d of %d", ix->shard_rank,
+             ix->shard_world, comm->rank, comm->nranks);
+}
+
 extern "C" int msvs_shard_search_device(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq,
                                         int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
                                         float * d_dis, void * hip_stream)
 {
     return guarded([&] {
-        if (!ix || !comm || (nq && (!d_queries || !d_ids || !d_dis)) || k < 0)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null index / communicator / buffer or negative k");
-        if (comm->nranks != ix->shard_world || comm->rank != ix->shard_rank)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "the index is shard %d of %d but the communicator is rank %d of %d", ix->shard_rank,
-                 ix->shard_world, comm->rank, comm->nranks);
+        shard_check(ix, comm, d_queries, nq, k, d_ids, d_dis);
         hipStream_t stream = as_stream(hip_stream);
         if (nq == 0 || k == 0)
             return;
-        const auto meta = ix->get_meta();
-        size_t eff_bits = nbits;
-        const uint64_t * eff = effective_filter(*ix, meta.get(), d_alive_bits, nbits, &eff_bits, stream);
-        const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank;
-        if (W == 1 && !comm->nccl)
+        if (comm->nranks == 1 && !comm->nccl)
         {
+            const auto meta = ix->get_meta();
+            size_t eff_bits = nbits;
+            const uint64_t * eff = effective_filter(*ix, meta.get(), d_alive_bits, nbits, &eff_bits, stream);
             index_search_device(*ix, d_queries, nq, (uint32_t)k, (size_t)std::max(nprobe, 0), eff, eff_bits, d_ids, d_dis, stream);
             apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
             return;
         }
-        const size_t part = round_up(nq * (size_t)k * 12, 16); // one rank's {ids | dis}
-        const bool ivf = ix->type == MSVS_INDEX_IVFFLAT;
-        const size_t np = ivf ? std::min<size_t>(std::max(nprobe, 1), ix->nlist) : 0;
-        const size_t chunk = ceil_div(nq, W);
-        Scratch & sh = shard_for(stream);
-        sh.reserve(W * part + W * chunk * np * 4 + 4096, stream);
-        unsigned char * packed = sh.take<unsigned char>(W * part);
-        int64_t * my_ids = reinterpret_cast<int64_t *>(packed + r * part);
-        float * my_dis = reinterpret_cast<float *>(packed + r * part + nq * (size_t)k * 8);
-        if (ivf)
-        {
-            int32_t * probes = sh.take<int32_t>(W * chunk * np);
-            int32_t * mine = probes + r * chunk * np;
-            const size_t q0 = std::min(nq, r * chunk), m = std::min(chunk, nq - q0);
-            MSVS_HIP(hipMemsetAsync(mine, 0xFF, chunk * np * 4, stream)); // queries past nq: no probes
-            if (m)
-                index_search_device(*ix, d_queries + q0 * ix->dim, m, 1, np, nullptr, 0, nullptr, nullptr, stream, nullptr, mine);
-            {
-                ProfileScope prof("shard_exchange", stream);
-                comm->all_gather(reinterpret_cast<unsigned char *>(probes), chunk * np * 4, stream);
-            }
-            index_search_device(*ix, d_queries, nq, (uint32_t)k, np, eff, eff_bits, my_ids, my_dis, stream, probes, nullptr);
-        }
-        else
-            index_search_device(*ix, d_queries, nq, (uint32_t)k, 0, eff, eff_bits, my_ids, my_dis, stream);
-        {
-            ProfileScope prof("shard_exchange", stream);
-            comm->all_gather(packed, part, stream);
-        }
-        // cosine distances leave the search as 1 - ip: ascending like L2
-        const int order = ix->metric == MSVS_METRIC_IP ? MSVS_METRIC_IP : MSVS_METRIC_L2;
-        merge_topk_device(reinterpret_cast<const int64_t *>(packed), part / 8,
-                          reinterpret_cast<const float *>(packed + nq * (size_t)k * 8), part / 4, W, nq, (size_t)k, order, d_ids,
-                          d_dis, stream);
-        apply_row_ids_map(meta.get(), d_ids, nq * (size_t)k, stream);
+        shard_search_stages(ix, comm, d_queries, nq, k, nprobe, d_alive_bits, nbits, d_ids, d_dis, stream, stream, nullptr, nullptr, nullptr,
+                            shard_for(stream));
     });
 }
 
+/// Two batches in flight (msvs.h): batch i's top-k all-gather and merge run on the communicator's exchange stream while the
+/// coarse pass and the list scan of batch i + 1 run on its compute stream.  Every collective of the communicator is issued on
+/// the ONE exchange stream, in call order: the order RCCL needs is the program order of the calls, the same on every rank.
+extern "C" int msvs_shard_search_device_async(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq,
+                                              int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
+                                              float * d_dis, void * hip_stream, void ** done_event)
+{
+    return guarded([&] {
+        shard_check(ix, comm, d_queries, nq, k, d_ids, d_dis);
+        if (!done_event)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null done_event");
+        ShardPipe & pp = pipe_of(comm);
+        std::lock_guard<std::mutex> lk(pp.mu);
+        const int p = (int)(pp.calls++ & 1);
+        // inputs: whatever the caller's stream has enqueued so far
+        MSVS_HIP(hipEventRecord(pp.in_ev[p], as_stream(hip_stream)));
+        MSVS_HIP(hipStreamWaitEvent(pp.compute, pp.in_ev[p], 0));
+        // this parity's exchange buffers were last read by the merge of the call before the previous one
+        if (pp.used[p])
+            MSVS_HIP(hipStreamWaitEvent(pp.compute, pp.done_ev[p], 0));
+        pp.used[p] = true;
+        if (nq && k)
+            shard_search_stages(ix, comm, d_queries, nq, k, nprobe, d_alive_bits, nbits, d_ids, d_dis, pp.compute, pp.xchg, pp.ab_ev[p],
+                                pp.x1_ev[p], pp.b_ev[p], shard_for(p ? pp.xchg : pp.compute));
+        else
+        {
+            MSVS_HIP(hipEventRecord(pp.b_ev[p], pp.compute));
+            MSVS_HIP(hipStreamWaitEvent(pp.xchg, pp.b_ev[p], 0));
+        }
+        MSVS_HIP(hipEventRecord(pp.done_ev[p], pp.xchg));
+        *done_event = pp.done_ev[p];
+    });
+}
+
+extern "C" int msvs_shard_search_drain(const msvs_comm_t * comm, void * hip_stream)
+{
+    return guarded([&] {
+        if (!comm)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null communicator");
+        ShardPipe & pp = pipe_of(comm);
+        std::lock_guard<std::mutex> lk(pp.mu);
+        for (int p = 0; p < 2; p++)
+            if (pp.used[p])
+                MSVS_HIP(hipStreamWaitEvent(as_stream(hip_stream), pp.done_ev[p], 0));
+    });
+}

@@ -571,11 +571,12 @@ def test_coarse_band_decides_most_probes_without_reading_the_centroids(metric, d
     opt("coarse_band", None)
 
 
-@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_COSINE])
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_COSINE, capi.METRIC_IP])
 @pytest.mark.parametrize("data", ["blobs", "iid", "outlier_rows"])
 def test_probe_pruning_drops_pairs_and_keeps_the_oracle_result(data, metric, opt):
-    """The shadow list scan of an L2 batch drops (query, list) pairs that provably cannot hold one of the query's k nearest rows
-    (triangle inequality with the list radius against the k-th best sample row: H16Prune; L2 and cosine indexes).  Whatever it drops, the result is the
+    """The shadow list scan of a batch drops (query, list) pairs that provably cannot hold one of the query's k nearest rows
+    (triangle inequality with the list radius against the k-th best sample row: H16Prune; L2 and cosine indexes; inner-product
+    indexes through <q, x> <= <q, c> + |q| r).  Whatever it drops, the result is the
     oracle's, which scans every probed list: well separated blobs (most pairs go), iid rows (nothing can be proved: nothing goes),
     lists with a far outlier row each (huge radii: nothing goes, and the outliers are still found by the queries placed on
     them); with and without a filter; == the same search with the pruning off."""
@@ -608,12 +609,23 @@ def test_probe_pruning_drops_pairs_and_keeps_the_oracle_result(data, metric, opt
         assert s1[1] - s0[1] == nq * nprobe, "the pruning did not look at the batch"
         dropped = (s1[0] - s0[0]) / float(nq * nprobe)
         if data == "blobs":
-            assert dropped > (0.5 if metric == capi.METRIC_L2 else 0.02), dropped  # (5 k-means iterations leave merged blobs: wide lists)
+            # (5 k-means iterations leave merged blobs: wide lists; inner product: |q| r is a loose bound next to <q, c>)
+            assert dropped > {capi.METRIC_L2: 0.5, capi.METRIC_COSINE: 0.02, capi.METRIC_IP: 0.0}[metric], dropped
         if data == "iid":
             assert dropped < 0.05, dropped
         opt("h16_prune", "0")
         ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=al)
         same(ids, dis, oi, od)
+    # a hybrid search's top-100 (k > 64: the bound takes a selection of its own) and a filter that leaves most queries fewer than
+    # k live sample rows (no bound for those: nothing dropped, no cut "none" either)
+    opt("h16_prune", "2")
+    oi, od, _ = oracle_on_exported(ix, q[:200], nprobe, 100, metric)
+    ids, dis = ix.search(q[:200], 100, "nprobe=%d" % nprobe)
+    same(ids, dis, oi, od)
+    sparse = rng.random(n) < 0.02
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric, alive=sparse)
+    ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=sparse)
+    same(ids, dis, oi, od)
     opt("h16_prune", None)
     opt("rerank_stats", None)
 

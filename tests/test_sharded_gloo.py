@@ -264,6 +264,95 @@ def test_product_sharded_search_two_processes_equals_unsharded(metric_name, typ)
     assert res[0][1]["stats"] == res[1][1]["stats"] == (2001, 60007, [11, 0, 2 ** 41 + 1])
 
 
+def _pruned_case():
+    rng = np.random.default_rng(77)
+    n, d, nlist, nq = 60000, 64, 256, 800  # (the centroid-shadow coarse pass -- the source of the probe words -- serves nlist >= 256)
+    centres = 4.0 * rng.standard_normal((nlist, d), dtype=np.float32)
+    x = (centres[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centres[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    return x, q, centres, nlist, 10, 8
+
+
+def _pruned_worker(rank, world, port, metric_name, out):
+    """The sharded search with the probe pruning ON on every rank: the coarse pass of a query runs on ONE rank, its distance word
+    per probe travels with the probe lists (ProbeWords), and every rank prunes the pairs of its own lists."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import myscaledb_amd.capi as capi
+        from myscaledb_amd import sharded
+        capi.set_device(0)
+        metric = {"L2": capi.METRIC_L2, "IP": capi.METRIC_IP, "cosine": capi.METRIC_COSINE}[metric_name]
+        x, q, centres, nlist, k, nprobe = _pruned_case()
+        ix = capi.Index(capi.INDEX_IVFFLAT, metric, x.shape[1], "ncentroids=%d,shard_rank=%d,shard_world=%d" % (nlist, rank, world))
+        ix.set_centroids(centres)
+        ix.add(x)
+        ix.build()
+        comm = sharded.gloo_comm()
+        capi.set_option("h16_prune", "2")
+        capi.set_option("rerank_stats", "1")
+        capi.set_option("ivf_pass", "2")
+        nq = q.shape[0]
+        dq = torch.from_numpy(q).cuda()
+        oi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        od = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        s0 = capi.debug_prune_stats()
+        ix.shard_search_device(comm, dq.data_ptr(), nq, k, nprobe, oi.data_ptr(), od.data_ptr())
+        torch.cuda.synchronize()
+        s1 = capi.debug_prune_stats()
+        # two batches in flight (msvs_shard_search_device_async): four batches of different sizes back to back, each with its own
+        # result buffers, one drain at the end -- the exchange + merge of batch i run beside the scan of batch i + 1
+        cuts = [(0, 300), (300, 301), (301, 800), (0, 800)]
+        outs = [(torch.empty((hi - lo, k), dtype=torch.int64, device="cuda"), torch.empty((hi - lo, k), dtype=torch.float32, device="cuda"))
+                for lo, hi in cuts]
+        for (lo, hi), (bi, bd) in zip(cuts, outs):
+            ix.shard_search_device_async(comm, dq[lo:hi].data_ptr(), hi - lo, k, nprobe, bi.data_ptr(), bd.data_ptr())
+        comm.drain()
+        torch.cuda.synchronize()
+        piped = [(bi.cpu().numpy(), bd.cpu().numpy()) for bi, bd in outs]
+        out.put((rank, oi.cpu().numpy(), od.cpu().numpy(), (s1[0] - s0[0], s1[1] - s0[1]), piped))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric_name", ["L2", "cosine", "IP"])
+def test_product_sharded_search_prunes_on_every_rank_and_equals_unsharded(metric_name):
+    import myscaledb_amd.capi as capi
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pruned_worker, args=(r, world, port, metric_name, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    metric = {"L2": capi.METRIC_L2, "IP": capi.METRIC_IP, "cosine": capi.METRIC_COSINE}[metric_name]
+    x, q, centres, nlist, k, nprobe = _pruned_case()
+    ix = capi.Index(capi.INDEX_IVFFLAT, metric, x.shape[1], "ncentroids=%d" % nlist)
+    ix.set_centroids(centres)
+    ix.add(x)
+    ix.build()
+    capi.set_option("h16_prune", "0")
+    try:
+        fi, fd = ix.search(q, k, "nprobe=%d" % nprobe)
+    finally:
+        capi.set_option("h16_prune", None)
+    for r in range(world):
+        assert (res[r][1] == fi).all() and (res[r][2].view(np.uint32) == fd.view(np.uint32)).all()
+        dropped, looked = res[r][3]
+        assert looked == q.shape[0] * nprobe, "rank %d: the pruning did not look at the batch" % r
+        if metric_name == "L2":
+            assert dropped > 0.1 * looked, (r, dropped, looked)  # well separated blobs (the bound comes from the rank's OWN sample rows: looser than unsharded)
+        for (lo, hi), (bi, bd) in zip([(0, 300), (300, 301), (301, 800), (0, 800)], res[r][4]):
+            assert (bi == fi[lo:hi]).all() and (bd.view(np.uint32) == fd[lo:hi].view(np.uint32)).all(), (r, lo, hi)
+
+
 @pytest.mark.gpu
 def test_rccl_transport_single_rank_roundtrip():
     """The RCCL code path itself (dlopen'd librccl: ncclGetUniqueId, ncclCommInitRank, in-place ncclAllGather on the
