@@ -280,7 +280,10 @@ inline size_t h16_lds_bytes(uint32_t ncb, uint32_t nch)
 /// the end re-load the last chunk (harmless, L2 hits).
 /// (Round 4 measured a dynamic hand-out of the blocks -- one counter per item, idle workgroups joining items in progress -- against
 /// this static striding: 3 % slower without joiners, no faster with them; profiles/r04_scan_notes.txt.)
-template <int METRIC, int NCBI, int RING = H_RING>
+/// NRB = 2 (exhaustive batches: h16_flat_kernel): a wavefront walks TWO consecutive blocks at a time, so every A fragment read
+/// from LDS feeds two MFMAs -- with hundreds of queries per row the pass is bound by the LDS reads of the A operands (1 KiB per
+/// MFMA against 128 B/clk per CU: exactly the matrix pipe's rate), not by the row stream, which then comes out of L2.
+template <int METRIC, int NCBI, int RING = H_RING, int NRB = 1>
 __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned char * qt /* tile */,
                                            const uint32_t chunk_stride, const float * m2_s, const float * qn_s,
                                            const uint32_t * thr_s, const uint32_t * qrow_s, uint32_t * stage, const uint32_t lane,
@@ -303,56 +306,90 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
     const uint32_t last = nch - 1;
     const bool chain = nch % RING == 0;
 
-    u32x4 ring[RING][4];
+    u32x4 ring[NRB][RING][4];
     auto load_chunk = [&](u32x4 (&b)[4], const u32x4 * p) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
             b[j] = p[j * 64];
     };
-    const u32x4 * hp = hbase + (size_t)(hb_list + blk) * blk_pieces;
+    // row block rb of the group that starts at block g: g + rb, or (past the end of the list) g again -- loaded, never offered
+    auto blk_ptr = [&](const uint32_t g, const int rb) {
+        return hbase + (size_t)(hb_list + (g + rb < nblk ? g + rb : g)) * blk_pieces;
+    };
+    const u32x4 * hp[NRB];
 #pragma unroll
-    for (int u = 0; u < RING - 1; u++)
-        load_chunk(ring[u], hp + (size_t)((uint32_t)u < last ? (uint32_t)u : last) * 256);
+    for (int rb = 0; rb < NRB; rb++)
+    {
+        hp[rb] = blk_ptr(blk, rb);
+#pragma unroll
+        for (int u = 0; u < RING - 1; u++)
+            load_chunk(ring[rb][u], hp[rb] + (size_t)((uint32_t)u < last ? (uint32_t)u : last) * 256);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
+    uint32_t cnt = 0; // records staged, wave-uniform (0 again after every block)
+    auto flush = [&]() {
+        if (lane < cnt)
+        {
+            const uint32_t q = stage[2 * H_STAGE + lane];
+            const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
+            if (pos < a.cand_cap)
+                a.partial[(size_t)q * a.cand_cap + pos] = (uint64_t)stage[H_STAGE + lane] << 32 | stage[lane];
+        }
+        cnt = 0;
+    };
     for (; blk < nblk; blk += stride)
     {
         const uint32_t nxt = blk + stride;
         const bool more = nxt < nblk;
         const bool has_next = chain && more;
-        const u32x4 * const hp_next = has_next ? hbase + (size_t)(hb_list + nxt) * blk_pieces : hp;
-        const int64_t row = lbeg + (int64_t)blk * H_ROWS + r32;
-        bool ok = row < lend;
-        float xn = 0.f;
-        if (ok)
+        const u32x4 * hp_next[NRB];
+        int64_t row[NRB];
+        bool ok[NRB];
+        float xn[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; rb++)
         {
-            if (METRIC == M_L2)
-                xn = a.xnorm[row];
-            if (a.alive)
+            hp_next[rb] = has_next ? blk_ptr(nxt, rb) : hp[rb];
+            row[rb] = lbeg + (int64_t)(blk + rb) * H_ROWS + r32;
+            ok[rb] = blk + rb < nblk && row[rb] < lend;
+            xn[rb] = 0.f;
+            if (ok[rb])
             {
-                const uint32_t id = a.ids[row];
-                ok = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
+                if (METRIC == M_L2)
+                    xn[rb] = a.xnorm[row[rb]];
+                if (a.alive)
+                {
+                    const uint32_t id = a.ids[row[rb]];
+                    ok[rb] = id < a.nbits && ((a.alive[id >> 6] >> (id & 63)) & 1);
+                }
             }
         }
-        f32x16 acc[NCBI];
+        f32x16 acc[NRB][NCBI];
 #pragma unroll
-        for (int cb = 0; cb < NCBI; cb++)
+        for (int rb = 0; rb < NRB; rb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                acc[cb][r] = 0.f;
-        auto step = [&](const u32x4 (&b)[4], const uint32_t c) {
+            for (int cb = 0; cb < NCBI; cb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc[rb][cb][r] = 0.f;
+        auto step = [&](const int u, const uint32_t c) {
             const unsigned char * qb = qt + (size_t)c * chunk_stride;
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
-                const half8 bf = __builtin_bit_cast(half8, b[j]);
                 half8 af[NCBI];
 #pragma unroll
                 for (int cb = 0; cb < NCBI; cb++)
                     af[cb] = *reinterpret_cast<const half8 *>(qb + cb * 4096 + aoff[j]);
 #pragma unroll
-                for (int cb = 0; cb < NCBI; cb++)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf, acc[cb], 0, 0, 0);
+                for (int rb = 0; rb < NRB; rb++)
+                {
+                    const half8 bf = __builtin_bit_cast(half8, ring[rb][u][j]);
+#pragma unroll
+                    for (int cb = 0; cb < NCBI; cb++)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb], bf, acc[rb][cb], 0, 0, 0);
+                }
             }
         };
         for (uint32_t c0 = 0; c0 < nch; c0 += RING)
@@ -367,41 +404,45 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
                 // sched_barrier: without a fence hipcc sinks the prefetch loads down to their first use (register
                 // pressure heuristic) and the ring degenerates into load -> vmcnt(0) -> use
                 const uint32_t pc = c + RING - 1;
-                const u32x4 * src = pc < nch ? hp + (size_t)pc * 256
-                                             : (has_next ? hp_next + (size_t)(pc - nch) * 256 : hp + (size_t)last * 256);
-                load_chunk(ring[(u + RING - 1) % RING], src);
+#pragma unroll
+                for (int rb = 0; rb < NRB; rb++)
+                {
+                    const u32x4 * src = pc < nch ? hp[rb] + (size_t)pc * 256
+                                                 : (has_next ? hp_next[rb] + (size_t)(pc - nch) * 256 : hp[rb] + (size_t)last * 256);
+                    load_chunk(ring[rb][(u + RING - 1) % RING], src);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                step(ring[u], c);
+                step(u, c);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (!chain && more)
         {
             // no chaining: restart the ring on the next block
-            const u32x4 * const nx = hbase + (size_t)(hb_list + nxt) * blk_pieces;
 #pragma unroll
-            for (int u = 0; u < RING - 1; u++)
-                load_chunk(ring[u], nx + (size_t)((uint32_t)u < last ? (uint32_t)u : last) * 256);
-            hp = nx;
+            for (int rb = 0; rb < NRB; rb++)
+            {
+                const u32x4 * const nx = blk_ptr(nxt, rb);
+#pragma unroll
+                for (int u = 0; u < RING - 1; u++)
+                    load_chunk(ring[rb][u], nx + (size_t)((uint32_t)u < last ? (uint32_t)u : last) * 256);
+                hp[rb] = nx;
+            }
         }
         else
-            hp = hp_next;
+        {
+#pragma unroll
+            for (int rb = 0; rb < NRB; rb++)
+                hp[rb] = hp_next[rb];
+        }
 
         // ---- epilogue: accumulator register i of column block cb = query 32 cb + (i & 3) + 8 (i >> 2) + 4 h, row r32.
-        // Survivors are compacted per wavefront into an LDS stage (ballot + mbcnt) and appended to the queries'
-        // candidate buffers in ONE parallel round of global atomics per <= 64 records (a returning atomic per passing
-        // register serialises one L2 round trip each).
-        uint32_t cnt = 0; // records staged, wave-uniform
-        auto flush = [&]() {
-            if (lane < cnt)
-            {
-                const uint32_t q = stage[2 * H_STAGE + lane];
-                const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
-                if (pos < a.cand_cap)
-                    a.partial[(size_t)q * a.cand_cap + pos] = (uint64_t)stage[H_STAGE + lane] << 32 | stage[lane];
-            }
-            cnt = 0;
-        };
+        // Survivors are compacted per wavefront into an LDS stage (ballot + mbcnt) and appended to the queries' candidate
+        // buffers in ONE parallel round of global atomics per <= 64 records, at the end of every block (a returning atomic
+        // per passing register serialises one L2 round trip each; carrying the stage from block to block and flushing only
+        // when it is full -- fewer, fuller rounds -- measured SLOWER: 0.545 against 0.476 ms on the bench step, round 4).
+#pragma unroll
+        for (int rb = 0; rb < NRB; rb++)
 #pragma unroll
         for (int cb = 0; cb < NCBI; cb++)
         {
@@ -417,9 +458,9 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                 {
-                    const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2v[e], acc[cb][4 * g4 + e], xn), qnv[e])
-                                                   : __fmul_rn(m2v[e], acc[cb][4 * g4 + e]);
-                    const uint64_t key = ok ? make_key<METRIC>(v, (uint32_t)row) : KEY_NONE;
+                    const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2v[e], acc[rb][cb][4 * g4 + e], xn[rb]), qnv[e])
+                                                   : __fmul_rn(m2v[e], acc[rb][cb][4 * g4 + e]);
+                    const uint64_t key = ok[rb] ? make_key<METRIC>(v, (uint32_t)row[rb]) : KEY_NONE;
                     const uint32_t word = (uint32_t)(key >> 32);
                     const bool pass = word < cutv[e]; // KEY_NONE has word 0xFFFFFFFF: never below a cut
                     const uint64_t mask = __ballot(pass);
@@ -1030,6 +1071,142 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint
     }
 }
 
+// ------------------------------------------------------------------------------------------ FLAT tables: exhaustive batches
+//
+// A FLAT index (BASELINE configs[0]; the operating point of data without cluster structure; tryBruteForceSearch's resident
+// form) is one list of n rows.  A batch scans its fp16 shadow with the list scan's machinery -- resident query tile, register
+// ring, cut + append epilogue -- over work items (segment of H_FLAT_SEGB blocks, tile of 32 NCB queries), the tiles of a segment
+// consecutive so that they meet in one XCD's L2: the table leaves HBM once per step however many tiles there are.  No plan,
+// no pair lists: item -> (segment, tile) is a division.  The cut comes from a SAMPLE of <= 64 blocks spread evenly over the table
+// (coarse_h16_kernel with a block stride: every approximate distance of the batch to the sample rows) -- the m-th smallest
+// sample word of a query, m chosen so that ~`target` rows of the whole table lie below it (flat_cut_kernel); the sample rows are
+// scanned again by the main launch like all the others.  Candidates -> cand_select -> canonical re-rank -> certificate ->
+// canonical fallback as everywhere (table_candidate_pass).
+//
+// With hundreds of queries per row the pass is bound by the matrix pipe / the LDS reads that feed it, not by HBM: NRB = 2 row
+// blocks per wavefront halve the LDS traffic per MFMA (h16_stream).  A single tile (<= 96 queries) streams the table once:
+// HBM-bound, NRB = 1 with the deep ring.
+
+constexpr uint32_t H_FLAT_SEGB = 64;      // blocks per segment: 2048 rows (3 MB of shadow at d = 768)
+constexpr uint32_t H_FLAT_SAMPLE_BLK = 64; // sample blocks: 2048 rows, one register-resident selection per query
+
+struct H16FlatParams
+{
+    uint32_t nq, nblk, n_rows; // queries of the batch; blocks and rows of the table
+    uint32_t nseg, ntiles, segb; // segments of segb blocks each; tiles
+};
+
+/// One wavefront per query: the m-th smallest of its n_pad <= 2048 sample words becomes the cut; no candidate is appended here
+/// (the main launch scans the sample rows again).  Fewer than m sample rows (a very selective filter): no cut.
+static __global__ __launch_bounds__(BLOCK) void flat_cut_kernel(const uint32_t * sample, uint32_t nq, uint32_t n_pad, uint32_t m,
+                                                                 uint32_t * qthr, uint32_t * qcnt)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq)
+        return;
+    uint32_t word[32];
+#pragma unroll
+    for (int u = 0; u < 32; u++)
+    {
+        const uint32_t i = u * WAVE + lane;
+        word[u] = i < n_pad ? sample[(size_t)q * n_pad + i] : 0xFFFFFFFFu;
+    }
+    const uint32_t cut = wave_kth_word<32>(word, m, s_hist[threadIdx.x >> 6], lane);
+    if (lane == 0)
+    {
+        qthr[q] = cut;
+        qcnt[q] = 0;
+    }
+}
+
+template <int METRIC, int NCB, int NRB, int RING>
+__global__ __launch_bounds__(64 * H_NW) void h16_flat_kernel(const H16Params a, const H16FlatParams f)
+{
+    constexpr uint32_t TQ = 32 * NCB;
+    constexpr uint32_t NW = H_NW;
+    const uint32_t nch = a.nch;
+    unsigned char * const tile = msvs_smem; // [chunk][query][8 x 16 B]
+    float * const m2_s = reinterpret_cast<float *>(tile + (size_t)TQ * nch * 128);
+    float * const qn_s = m2_s + TQ;
+    uint32_t * const thr_s = reinterpret_cast<uint32_t *>(qn_s + TQ);
+    uint32_t * const qrow_s = thr_s + TQ;
+    uint32_t * const stage_s = qrow_s + TQ; // [NW][3][H_STAGE]
+    uint32_t * const item_s = stage_s + NW * 3 * H_STAGE;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t total = f.nseg * f.ntiles;
+    uint32_t resident = H_NONE; // the tile in LDS (a batch of one tile loads it once per workgroup, whatever the number of segments)
+    for (;;)
+    {
+        __syncthreads(); // the previous work item is done with the tile, the tables and item_s
+        if (tid == 0)
+            *item_s = h16_next_item(a.sched, total, blockIdx.x & 7);
+        __syncthreads();
+        const uint32_t w = *item_s;
+        if (w == H_NONE)
+            break;
+        const uint32_t seg = w / f.ntiles, tidx = w - seg * f.ntiles; // the tiles of a segment are consecutive items
+        const uint32_t q0 = tidx * TQ;
+        const uint32_t nvalid = f.nq - q0 < TQ ? f.nq - q0 : TQ;
+        const uint32_t ncb_e = (nvalid + 31) >> 5;
+        const uint32_t tq_e = 32 * ncb_e;
+        if (tidx != resident)
+        {
+        resident = tidx;
+        if (tid < TQ)
+        {
+            const bool v = tid < nvalid;
+            const uint32_t q = v ? q0 + tid : f.nq - 1;
+            qrow_s[tid] = q;
+            const float2 qi = a.qinfo[q];
+            m2_s[tid] = qi.x;
+            qn_s[tid] = qi.y;
+            thr_s[tid] = v ? a.qthr[q] : 0u; // padding queries of a short tile never pass
+        }
+        __syncthreads();
+        {
+            const uint32_t npieces = tq_e * nch * 8;
+            for (uint32_t p0 = tid; p0 < npieces; p0 += 4 * 64 * NW)
+            {
+                uint4 v[4];
+                uint32_t at[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const uint32_t pp = p0 + u * 64 * NW;
+                    const uint32_t p = pp < npieces ? pp : npieces - 1;
+                    const uint32_t slot = p & 7, qi = (p >> 3) % tq_e, c = (p >> 3) / tq_e;
+                    v[u] = a.Qh[((size_t)qrow_s[qi] * nch + c) * 8 + (slot ^ ((qi >> 1) & 7))];
+                    at[u] = ((c * TQ + qi) * 8 + slot) * 16;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (p0 + u * 64 * NW < npieces)
+                        *reinterpret_cast<uint4 *>(tile + at[u]) = v[u];
+            }
+        }
+        __syncthreads();
+        }
+        uint32_t * const stage = stage_s + wave * 3 * H_STAGE;
+        const uint32_t b0 = seg * f.segb, b1 = b0 + f.segb < f.nblk ? b0 + f.segb : f.nblk;
+#define MSVS_H16_FLAT_STREAM(N)                                                                                                    \
+    h16_stream<METRIC, N, RING, NRB>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, 0, b0 + wave * NRB, NW * NRB, \
+                                     b1, 0, (int64_t)f.n_rows)
+        if constexpr (NCB == 1)
+            MSVS_H16_FLAT_STREAM(1);
+        else if (ncb_e == 1)
+            MSVS_H16_FLAT_STREAM(1);
+        else if constexpr (NCB == 2)
+            MSVS_H16_FLAT_STREAM(2);
+        else if (ncb_e == 2)
+            MSVS_H16_FLAT_STREAM(2);
+        else
+            MSVS_H16_FLAT_STREAM(3);
+#undef MSVS_H16_FLAT_STREAM
+    }
+}
+
 // ------------------------------------------------------------------------------------------ coarse quantiser of a batch
 //
 // The centroid table through the same shadow: its ceil(nlist / 32) blocks are presented to h16_sample_kernel as G "lists"
@@ -1042,10 +1219,14 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint
 /// plan took 44 us for 4096 x 1024 x 768, its operands being 96 KB per 32 x 32 tile).  No plan, no LDS: block g of the
 /// shadow = centroids [32 g, 32 g + 32), query block b = queries [32 b, 32 b + 32).  Writes EVERY word of
 /// sample_out[q][n_pad = 32 G] (0xFFFFFFFF for the padding rows of the last block): no memset.
+/// blk_stride > 1 (the sample of a FLAT table: h16_flat_kernel's cut): block g of this launch is block g * blk_stride of the shadow,
+/// its rows g * blk_stride * 32 .. of n_total; ids / alive (nullable): rows the filter drops get the word 0xFFFFFFFF.
 template <int METRIC>
 __global__ __launch_bounds__(BLOCK, 1) void coarse_h16_kernel(const uint4 * H, uint32_t nch, const uint4 * Qh, const float2 * qinfo,
                                                                const float * xnorm, uint32_t n_rows, uint32_t nq,
-                                                               uint32_t * sample_out)
+                                                               uint32_t * sample_out, uint32_t blk_stride = 1, uint32_t n_total = 0xFFFFFFFFu,
+                                                               const uint32_t * ids = nullptr, const uint64_t * alive = nullptr,
+                                                               uint32_t nbits = 0)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
     const uint32_t G = (n_rows + H_ROWS - 1) / H_ROWS, n_pad = G * H_ROWS, QB = (nq + 31) / 32;
@@ -1065,7 +1246,7 @@ __global__ __launch_bounds__(BLOCK, 1) void coarse_h16_kernel(const uint4 * H, u
             const uint32_t q = qb[t] * 32 + r32 < nq ? qb[t] * 32 + r32 : nq - 1;
             qi[t] = qinfo[q];
             ap[t] = reinterpret_cast<const u32x4 *>(Qh) + (size_t)q * nch * 8 + h;
-            bp[t] = reinterpret_cast<const u32x4 *>(H) + (size_t)gb[t] * nch * 256 + lane;
+            bp[t] = reinterpret_cast<const u32x4 *>(H) + (size_t)gb[t] * blk_stride * nch * 256 + lane;
         }
         f32x16 acc[2][2];
 #pragma unroll
@@ -1116,9 +1297,15 @@ __global__ __launch_bounds__(BLOCK, 1) void coarse_h16_kernel(const uint4 * H, u
         {
             if (s == 1 && gb[1] == gb[0])
                 break;
-            const uint32_t row = gb[s] * H_ROWS + r32;
-            const bool ok = row < n_rows;
-            const float xn = ok && METRIC == M_L2 ? xnorm[row] : 0.f;
+            const uint32_t row = gb[s] * H_ROWS + r32;                    // in this launch's numbering (the output slot)
+            const uint32_t srow = gb[s] * blk_stride * H_ROWS + r32;      // in the table
+            bool ok = row < n_rows && srow < n_total;
+            const float xn = ok && METRIC == M_L2 ? xnorm[srow] : 0.f;
+            if (ok && alive)
+            {
+                const uint32_t id = ids ? ids[srow] : srow;
+                ok = id < nbits && ((alive[id >> 6] >> (id & 63)) & 1);
+            }
 #pragma unroll
             for (int t = 0; t < 2; t++)
             {
@@ -1131,7 +1318,7 @@ __global__ __launch_bounds__(BLOCK, 1) void coarse_h16_kernel(const uint4 * H, u
                     const int qidx = (i & 3) + 8 * (i >> 2) + 4 * (int)h;
                     const float m2 = __shfl(qi[t].x, qidx), qn = __shfl(qi[t].y, qidx);
                     const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2, acc[t][s][i], xn), qn) : __fmul_rn(m2, acc[t][s][i]);
-                    const uint64_t key = ok ? make_key<METRIC>(v, row) : KEY_NONE;
+                    const uint64_t key = ok ? make_key<METRIC>(v, srow) : KEY_NONE;
                     const uint32_t q = qb[t] * 32 + (uint32_t)qidx;
                     if (q < nq)
                         sample_out[(size_t)q * n_pad + row] = (uint32_t)(key >> 32);

@@ -21,6 +21,56 @@ using namespace msvs;
 static void index_build_shadow(msvs_index & ix, hipStream_t stream)
 {
     ix.shadow_ready = false;
+    if (ix.type == MSVS_INDEX_FLAT)
+    {
+        // a FLAT index is ONE list of n rows in id order: ceil(n / 32) blocks in the same operand layout (round 4): batches scan
+        // it through h16_flat_kernel instead of converting the f32 rows to split bf16 on the fly
+        if (!ix.want_shadow || ix.n == 0 || !(ix.xnorm_max < 1e30f) || ix.n > 0xfffffff0ull)
+            return;
+        DevBuf<uint32_t> mx(1);
+        MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
+        const size_t n4 = ix.n * (size_t)(ix.ld / 4);
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>(ceil_div(n4, (size_t)256), 4096)), dim3(256), 0, stream,
+                           reinterpret_cast<const float4 *>(ix.vecs.p), n4, mx.p);
+        uint32_t bits = 0;
+        MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+        float maxabs;
+        memcpy(&maxabs, &bits, 4);
+        if (!(maxabs < 3.0e38f))
+            return;
+        int ex = 0;
+        if (maxabs > 0.f)
+            (void)frexpf(maxabs, &ex);
+        const int sh = 14 - ex;
+        if (sh > 100 || sh < -100)
+            return;
+        ix.h_scale = ldexpf(1.f, sh);
+        ix.h_inv_scale = ldexpf(1.f, -sh);
+        ix.h_nch = (uint32_t)ceil_div(ix.dim, (size_t)H_CHUNK);
+        ix.h_nks = 4 * ix.h_nch;
+        const size_t G = ceil_div(ix.n, (size_t)H_ROWS);
+        const std::vector<uint32_t> one_hoff = {0u, (uint32_t)G};
+        const std::vector<int64_t> one_off = {0, (int64_t)ix.n};
+        DevBuf<uint32_t> d_one_hoff(2), d_blk(G);
+        DevBuf<int64_t> d_one_off(2);
+        MSVS_HIP(hipMemsetAsync(d_blk.p, 0, G * 4, stream)); // every block belongs to list 0
+        MSVS_HIP(hipMemcpyAsync(d_one_hoff.p, one_hoff.data(), 8, hipMemcpyHostToDevice, stream));
+        MSVS_HIP(hipMemcpyAsync(d_one_off.p, one_off.data(), 16, hipMemcpyHostToDevice, stream));
+        const size_t npieces = G * (size_t)ix.h_nks * 64;
+        ix.shadow.alloc(npieces);
+        const size_t per_launch = (size_t)1 << 30;
+        for (size_t p0 = 0; p0 < npieces; p0 += per_launch)
+        {
+            const size_t m = std::min(per_launch, npieces - p0);
+            hipLaunchKernelGGL(h16_build_kernel, dim3((unsigned)ceil_div(m, (size_t)256)), dim3(256), 0, stream, ix.vecs.p, ix.ld,
+                               d_one_off.p, d_blk.p, d_one_hoff.p, ix.h_nks, ix.h_scale, ix.shadow.p, p0, m);
+        }
+        MSVS_HIP(hipGetLastError());
+        MSVS_HIP(hipStreamSynchronize(stream));
+        ix.shadow_ready = true;
+        return;
+    }
     if (ix.type != MSVS_INDEX_IVFFLAT || !ix.want_shadow || ix.n == 0 || ix.nlist == 0 || !(ix.xnorm_max < 1e30f)
         || ix.n > 0xfffffff0ull)
         return;
@@ -66,7 +116,7 @@ static void index_build_shadow(msvs_index & ix, hipStream_t stream)
     ix.hoff.alloc(ix.nlist + 1);
     ix.list_mid32.alloc(ix.nlist);
     const size_t npieces = nblocks * (size_t)ix.h_nks * 64;
-    ix.shadow.alloc(npieces + 32768); // + 512 KiB: h16r_scan_kernel's load ring runs a few stages past the end of a list
+    ix.shadow.alloc(npieces + 32768); // (+ 512 KiB of zeros past the last list)
     MSVS_HIP(hipMemsetAsync(ix.shadow.p + npieces, 0, 32768 * sizeof(uint4), stream));
     MSVS_HIP(hipMemcpyAsync(d_blk.p, blk_list.data(), nblocks * 4, hipMemcpyHostToDevice, stream));
     MSVS_HIP(hipMemcpyAsync(ix.hoff.p, hoff.data(), (ix.nlist + 1) * 4, hipMemcpyHostToDevice, stream));

@@ -375,6 +375,8 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
     return p;
 }
 
+static void h16_flat_dispatch(int metric, uint32_t ncb, int shape, uint32_t grid, size_t lds, const H16Params & a,
+                              const H16FlatParams & f, hipStream_t stream);
 static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k);
 static size_t fallback_cap(size_t nq, size_t nprobe, size_t seg_max, uint32_t k);
 
@@ -393,7 +395,8 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
 {
     size_t b = nq * (size_t)ix.ld * 4 + 2 * (nq * (size_t)(ix.ld + 32) * 4 + 4096) + 4096; // queries (+ split copies)
     if (ix.type == MSVS_INDEX_FLAT)
-        return b + flat_scratch_bytes(ix.n, nq, k, ix.ld) + table_pass_scratch(ix.n, nq, std::min<uint32_t>(k, 40));
+        return b + flat_scratch_bytes(ix.n, nq, k, ix.ld) + table_pass_scratch(ix.n, nq, std::min<uint32_t>(k, 40))
+            + (ix.shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + (size_t)H_FLAT_SAMPLE_BLK * H_ROWS * 4) + 8192 : 0); // shadow pass: query images, sample words
     IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k, allow_pass);
     size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe, ix.ld)
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
@@ -454,6 +457,7 @@ struct TablePass
     float * out_dis;
     int cosine;
     const char * prof_name;
+    bool flat_h16 = false; // the table is a FLAT index with an fp16 shadow: candidates through h16_flat_kernel
     bool h16 = false; // the table is the centroid table and its fp16 shadow is usable: scan through h16_sample_kernel
     H16Queries * h16_out = nullptr; // h16: where the pass leaves the queries' fp16 images for the list scan that follows
 };
@@ -602,7 +606,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     uint64_t * partial1 = scr.take<uint64_t>(fb_cap * (size_t)seg_max1 * t.k);
     uint32_t * nfail = small + 2;
     const uint32_t rpb = BG_ROWS; // work item = 1 slice (see plan_ivf)
-    if (!t.h16) // (the centroid-shadow pass keeps no per-query cut / count, and its query preparation kernel does the rest)
+    if (!t.h16 && !t.flat_h16) // (the shadow passes' query preparation kernel does the rest)
     {
         MSVS_HIP(hipMemsetAsync(small, 0, 9 * sizeof(uint32_t), stream));
         MSVS_HIP(hipMemsetAsync(qstate, 0xFF, nq * sizeof(uint32_t), stream));
@@ -611,7 +615,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         launch_single_list_plan((uint32_t)nq, 0, nrows, rpb, tq, pairs, probes0, list_off, small, small + 3, stream);
     }
     float4 * qsplit = nullptr;
-    if (!t.h16)
+    if (!t.h16 && !t.flat_h16)
     {
         launch_row_sqnorm(dq, qnorm, nq, ld / 4, nullptr, stream);
         qsplit = scr.take<float4>(nq * (size_t)ceil_div((size_t)ld / 4, (size_t)8) * 8);
@@ -746,6 +750,88 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
                         stream);
         return;
     }
+    if (t.flat_h16)
+    {
+        // the FLAT table's fp16 shadow (h16_scan_kernels.hpp, "FLAT tables"): sample -> cut -> exhaustive shadow scan
+        const uint32_t nblk = (uint32_t)ceil_div(t.n, (size_t)H_ROWS);
+        const uint32_t gs = std::min<uint32_t>(nblk, H_FLAT_SAMPLE_BLK), blk_stride = std::max<uint32_t>(1, nblk / gs);
+        const uint32_t n_pad = gs * H_ROWS;
+        uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + 64);
+        float2 * qinfo = scr.take<float2>(nq);
+        uint32_t * sample = scr.take<uint32_t>(nq * (size_t)n_pad);
+        uint32_t * sched = scr.take<uint32_t>(8);
+        H16PrepAux aux{};
+        aux.pairs = pairs;
+        aux.probes0 = probes0;
+        aux.list_off = list_off;
+        aux.pair_off = small;
+        aux.work_off = small + 3;
+        aux.nfail = nfail;
+        aux.row_end = nrows;
+        aux.rows_per_block = rpb;
+        aux.tq = tq;
+        aux.zero[0] = sched;
+        aux.nzero[0] = 8;
+        hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq, (uint32_t)nq, ld,
+                           ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, aux);
+        {
+            const uint32_t items = (uint32_t)(ceil_div((size_t)gs, (size_t)2) * ceil_div(ceil_div(nq, (size_t)32), (size_t)2));
+            const uint32_t cgrid = (uint32_t)std::min<size_t>(ceil_div((size_t)items, (size_t)4), (size_t)device_cu_count() * 2);
+            if (scan_metric(m) == M_IP)
+                hipLaunchKernelGGL((coarse_h16_kernel<M_IP>), dim3(cgrid), dim3(BLOCK), 0, stream, ix.shadow.p, ix.h_nch, qh, qinfo, t.norms,
+                                   n_pad, (uint32_t)nq, sample, blk_stride, nrows, t.ids, t.alive, a.nbits);
+            else
+                hipLaunchKernelGGL((coarse_h16_kernel<M_L2>), dim3(cgrid), dim3(BLOCK), 0, stream, ix.shadow.p, ix.h_nch, qh, qinfo, t.norms,
+                                   n_pad, (uint32_t)nq, sample, blk_stride, nrows, t.ids, t.alive, a.nbits);
+        }
+        // ~target rows of the whole table below the cut: the m-th smallest of the S sample rows, m = target S / n (the sample is a
+        // 1 / blk_stride share of the table), at least 4 (the certificate fails when fewer than k rows lie below the cut)
+        const size_t target = std::max<size_t>(64, 25 * (size_t)t.k);
+        const uint32_t mth = (uint32_t)std::min<size_t>(64, std::max<size_t>(4, ceil_div(target * n_pad, std::max<size_t>(t.n, 1))));
+        hipLaunchKernelGGL(flat_cut_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, mth,
+                           qstate, qstate + nq);
+        H16Params h{};
+        h.H = ix.shadow.p;
+        h.nks = ix.h_nks;
+        h.nch = ix.h_nch;
+        h.Qh = qh;
+        h.qinfo = qinfo;
+        h.xnorm = t.norms;
+        h.ids = t.ids;
+        h.alive = t.alive;
+        h.nbits = a.nbits;
+        h.qthr = qstate;
+        h.qcnt = qstate + nq;
+        h.partial = candbuf;
+        h.cand_cap = cap;
+        h.sched = sched;
+        uint32_t ncb = (uint32_t)std::min<size_t>(3, ceil_div(nq, (size_t)32));
+        if (options().flat_ncb >= 1)
+            ncb = (uint32_t)std::min(3.0, options().flat_ncb);
+        while (ncb > 1 && h16_lds_bytes(ncb, ix.h_nch) > 160 * 1024)
+            ncb--;
+        H16FlatParams f{};
+        f.nq = (uint32_t)nq;
+        f.nblk = nblk;
+        f.n_rows = nrows;
+        f.ntiles = (uint32_t)ceil_div(nq, (size_t)32 * ncb);
+        // segments of 64 blocks (3 MB of shadow at d = 768) for a single tile (it stays in LDS from item to item: 489 items for 256
+        // CUs at 1M rows), 128 / 256 blocks with several / many tiles: the tiles of a segment are consecutive items, the CUs of an
+        // XCD walk it together and share it through their L2 whatever its size, and the tile load (147 KB per item) weighs less
+        // (measured at 4096 queries: 64 / 128 / 256 / 512 / 1024 blocks -> 573 / 587 / 602 / 580 / 552 k QPS)
+        f.segb = options().flat_segb >= 1 ? (uint32_t)options().flat_segb : (f.ntiles >= 8 ? 4 * H_FLAT_SEGB : f.ntiles >= 2 ? 2 * H_FLAT_SEGB : H_FLAT_SEGB);
+        f.nseg = (uint32_t)ceil_div((size_t)nblk, (size_t)f.segb);
+        const size_t lds = h16_lds_bytes(ncb, ix.h_nch);
+        const uint32_t per_cu = (uint32_t)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
+        const uint32_t fgrid = options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count() * per_cu;
+        const int shape = options().flat_h16 == 3 ? 1 : options().flat_h16 == 6 ? 6 : (f.ntiles >= 2 ? 2 : 1); // (3 / 6: experiments)
+        h16_flat_dispatch(scan_metric(m), ncb, shape, fgrid, lds, h, f, stream);
+        MSVS_HIP(hipGetLastError());
+        launch_cand_select(candbuf, h.qcnt, h.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
+        table_pass_tail(ix, m, t, a, nq, qnorm, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true,
+                        stream);
+        return;
+    }
     if (two_phase)
     {
         ScanParams sa = a;
@@ -814,6 +900,51 @@ static void h16_dispatch(uint32_t ncb, uint32_t grid, size_t lds, const H16Param
         case 3: h16_launch<METRIC, 3>(grid, lds, a, stream); break;
         default: h16_launch<METRIC, 4>(grid, lds, a, stream); break;
     }
+}
+
+template <int METRIC, int NCB, int NRB, int RING>
+static void h16_flat_launch(uint32_t grid, size_t lds, const H16Params & a, const H16FlatParams & f, hipStream_t stream)
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&h16_flat_kernel<METRIC, NCB, NRB, RING>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL((h16_flat_kernel<METRIC, NCB, NRB, RING>), dim3(grid), dim3(64 * H_NW), lds, stream, a, f);
+}
+
+/// shape: 2 = two row blocks per wavefront, 3-slot ring (batches of several tiles); 1 = one row block, the list scan's 4-slot ring
+/// (a single tile: the table streams out of HBM once); 6 = one row block, 6-slot ring (experiment)
+template <int METRIC>
+static void h16_flat_dispatch_m(uint32_t ncb, int shape, uint32_t grid, size_t lds, const H16Params & a, const H16FlatParams & f,
+                                hipStream_t stream)
+{
+    if (shape == 2 && ncb >= 3)
+        h16_flat_launch<METRIC, 3, 2, 3>(grid, lds, a, f, stream);
+    else if (shape == 2 && ncb == 2)
+        h16_flat_launch<METRIC, 2, 2, 3>(grid, lds, a, f, stream);
+    else if (shape == 6 && ncb >= 3)
+        h16_flat_launch<METRIC, 3, 1, 6>(grid, lds, a, f, stream);
+    else if (shape == 6 && ncb == 2)
+        h16_flat_launch<METRIC, 2, 1, 6>(grid, lds, a, f, stream);
+    else if (shape == 6)
+        h16_flat_launch<METRIC, 1, 1, 6>(grid, lds, a, f, stream);
+    else if (ncb >= 3)
+        h16_flat_launch<METRIC, 3, 1, H_RING>(grid, lds, a, f, stream);
+    else if (ncb == 2)
+        h16_flat_launch<METRIC, 2, 1, H_RING>(grid, lds, a, f, stream);
+    else
+        h16_flat_launch<METRIC, 1, 1, H_RING>(grid, lds, a, f, stream);
+}
+
+static void h16_flat_dispatch(int metric, uint32_t ncb, int shape, uint32_t grid, size_t lds, const H16Params & a,
+                              const H16FlatParams & f, hipStream_t stream)
+{
+    ProfileScope prof("flat_shadow_scan", stream);
+    if (metric == M_IP)
+        h16_flat_dispatch_m<M_IP>(ncb, shape, grid, lds, a, f, stream);
+    else
+        h16_flat_dispatch_m<M_L2>(ncb, shape, grid, lds, a, f, stream);
 }
 
 /// Experiments (option h16_stamps): the per-item wall-clock stamps of the last main launch (H16Params::stamps).
@@ -1199,6 +1330,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
             t.out_ids = d_ids;
             t.out_dis = d_dis;
             t.cosine = ix.metric == MSVS_METRIC_COSINE;
+            t.flat_h16 = ix.shadow_ready && options().flat_h16 != 0 && h16_lds_bytes(1, ix.h_nch) <= 160 * 1024;
             t.prof_name = "flat_pass";
             table_candidate_pass(ix, scr, m, dq, nq, t, stream);
             g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
