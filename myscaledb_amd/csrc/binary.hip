@@ -2,6 +2,7 @@
 #include <algorithm>
 
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -161,10 +162,16 @@ struct msvs_bin_index
     std::vector<uint8_t> rows;   // host copy: n x nbytes (the serialised form)
     std::vector<int64_t> labels; // n
     mutable std::mutex mu;
-    mutable DevBuf<unsigned char> d_rows; // n x round_up(nbytes, 16), uploaded at the first search after an add
-    mutable DevBuf<uint32_t> d_labels;
-    mutable bool dirty = true;
-    mutable int device = 0;
+    /// The rows as a search reads them, on ONE device: n x round_up(nbytes, 16) + labels, uploaded at the first search (on that
+    /// device) after an add.  Searches hold the image through a shared_ptr while they scan: an add that comes in meanwhile
+    /// replaces the map entry, the buffers go when the last scan that uses them is done.
+    struct Image
+    {
+        DevBuf<unsigned char> rows;
+        DevBuf<uint32_t> labels;
+        size_t n = 0;
+    };
+    mutable std::map<int, std::shared_ptr<Image>> images; // by device; cleared by add
 };
 
 extern "C" int msvs_bin_index_create(size_t nbytes, int metric, msvs_bin_index_t ** out)
@@ -199,7 +206,7 @@ extern "C" int msvs_bin_index_add(msvs_bin_index_t * ix, const uint8_t * rows, c
             ix->labels.push_back(id);
         }
         ix->rows.insert(ix->rows.end(), rows, rows + n * ix->nbytes);
-        ix->dirty = true;
+        ix->images.clear(); // (scans in flight keep theirs alive)
     });
 }
 
@@ -217,28 +224,38 @@ extern "C" int msvs_bin_index_search(const msvs_bin_index_t * ix, const uint8_t 
         if (!x || !ids || !dis)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
         hipStream_t stream = thread_stream();
-        const size_t n = ix->labels.size(), ldb = round_up(ix->nbytes, (size_t)16);
+        const size_t ldb = round_up(ix->nbytes, (size_t)16);
+        int dev = 0;
+        MSVS_HIP(hipGetDevice(&dev));
+        std::shared_ptr<msvs_bin_index::Image> img;
         {
+            // the row count is read and the upload made under ONE lock: an add between the two would otherwise leave rows that
+            // are never searched; the image is per device (a search thread bound to another GPU gets its own copy)
             std::lock_guard<std::mutex> lk(ix->mu);
-            if (ix->dirty)
+            auto & slot = ix->images[dev];
+            if (!slot)
             {
-                ix->d_rows.alloc(std::max<size_t>(n, 1) * ldb);
-                ix->d_labels.alloc(std::max<size_t>(n, 1));
-                MSVS_HIP(hipMemsetAsync(ix->d_rows.p, 0, std::max<size_t>(n, 1) * ldb, stream));
+                const size_t n = ix->labels.size();
+                auto fresh = std::make_shared<msvs_bin_index::Image>();
+                fresh->n = n;
+                fresh->rows.alloc(std::max<size_t>(n, 1) * ldb);
+                fresh->labels.alloc(std::max<size_t>(n, 1));
+                MSVS_HIP(hipMemsetAsync(fresh->rows.p, 0, std::max<size_t>(n, 1) * ldb, stream));
                 if (n)
                 {
-                    MSVS_HIP(hipMemcpy2DAsync(ix->d_rows.p, ldb, ix->rows.data(), ix->nbytes, ix->nbytes, n, hipMemcpyHostToDevice, stream));
+                    MSVS_HIP(hipMemcpy2DAsync(fresh->rows.p, ldb, ix->rows.data(), ix->nbytes, ix->nbytes, n, hipMemcpyHostToDevice, stream));
                     std::vector<uint32_t> l32(n);
                     for (size_t i = 0; i < n; i++)
                         l32[i] = (uint32_t)ix->labels[i];
-                    MSVS_HIP(hipMemcpyAsync(ix->d_labels.p, l32.data(), n * 4, hipMemcpyHostToDevice, stream));
+                    MSVS_HIP(hipMemcpyAsync(fresh->labels.p, l32.data(), n * 4, hipMemcpyHostToDevice, stream));
                     MSVS_HIP(hipStreamSynchronize(stream)); // l32 is about to go
                 }
                 MSVS_HIP(hipStreamSynchronize(stream));
-                ix->dirty = false;
+                slot = fresh;
             }
+            img = slot;
         }
-        bin_search_rows(ix->d_rows.p, ix->d_labels.p, n, ix->nbytes, x, nx, k, ix->metric, alive_bits, nbits, ids, dis, stream);
+        bin_search_rows(img->rows.p, img->labels.p, img->n, ix->nbytes, x, nx, k, ix->metric, alive_bits, nbits, ids, dis, stream);
     });
 }
 
@@ -299,9 +316,16 @@ extern "C" int msvs_bin_index_load_io(const msvs_io_t * io, msvs_bin_index_t ** 
                 fail(MSVS_ERR_IO, "corrupt msvs binary index header");
             ix->nbytes = h.nbytes;
             ix->metric = h.metric;
-            ix->rows.resize(h.n * h.nbytes);
-            if (h.n)
-                f.read(ix->rows.data(), ix->rows.size());
+            // the header is untrusted: the rows arrive in pieces and the buffer grows with what has really been read, so a corrupt
+            // or truncated file ends in MSVS_ERR_IO (a short read) instead of a 2.8e14-byte allocation
+            const size_t total = (size_t)h.n * (size_t)h.nbytes, piece = (size_t)64 << 20;
+            for (size_t got = 0; got < total;)
+            {
+                const size_t m = std::min(piece, total - got);
+                ix->rows.resize(got + m);
+                f.read(ix->rows.data() + got, m);
+                got += m;
+            }
             ix->labels.resize(h.n);
         }
         {

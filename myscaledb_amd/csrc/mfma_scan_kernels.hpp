@@ -1012,9 +1012,9 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
         }
         __syncthreads();
         const uint64_t mine = tid < kc ? keys[tid] : KEY_NONE;
+        uint32_t rank = 0; // of this candidate among all of them by approximate key
         if (mine != KEY_NONE)
         {
-            uint32_t rank = 0;
             for (uint32_t j = 0; j < kc; j++)
                 rank += keys[j] < mine || (keys[j] == mine && j < tid) ? 1u : 0u;
             if (rank == a.k - 1)
@@ -1052,8 +1052,12 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
                 st = in ? 1 : (out ? 2 : 0);
                 if (in)
                 {
+                    // "in" is monotone in the approximate value: the certainly-in rows are the ranks 0 .. n_in - 1, and each
+                    // takes the slot of its rank -- the probe list's head is in approximate order, the same from run to run
+                    // (slots taken with an atomic counter made the order a race: ADVICE round 3)
                     const uint32_t pos = (uint32_t)mine;
-                    a.out_probes[(size_t)q * a.k + atomicAdd(&s_nin, 1u)] = (int32_t)(a.ids ? a.ids[pos] : pos);
+                    a.out_probes[(size_t)q * a.k + rank] = (int32_t)(a.ids ? a.ids[pos] : pos);
+                    atomicAdd(&s_nin, 1u);
                 }
             }
             s_state[tid] = st;

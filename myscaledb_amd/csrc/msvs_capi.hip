@@ -819,7 +819,13 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         // CUs at 1M rows), 128 / 256 blocks with several / many tiles: the tiles of a segment are consecutive items, the CUs of an
         // XCD walk it together and share it through their L2 whatever its size, and the tile load (147 KB per item) weighs less
         // (measured at 4096 queries: 64 / 128 / 256 / 512 / 1024 blocks -> 573 / 587 / 602 / 580 / 552 k QPS)
-        f.segb = options().flat_segb >= 1 ? (uint32_t)options().flat_segb : (f.ntiles >= 8 ? 4 * H_FLAT_SEGB : f.ntiles >= 2 ? 2 * H_FLAT_SEGB : H_FLAT_SEGB);
+        f.segb = f.ntiles >= 8 ? 4 * H_FLAT_SEGB : f.ntiles >= 2 ? 2 * H_FLAT_SEGB : H_FLAT_SEGB;
+        // ... but a short table is cut finer: at least ~4 items per CU, down to one block (pair) per wavefront
+        const uint32_t want_items = 4 * device_cu_count();
+        if ((size_t)ceil_div((size_t)nblk, (size_t)f.segb) * f.ntiles < want_items)
+            f.segb = (uint32_t)std::max<size_t>((size_t)H_NW * (f.ntiles >= 2 ? 2 : 1), (size_t)nblk * f.ntiles / want_items);
+        if (options().flat_segb >= 1)
+            f.segb = (uint32_t)options().flat_segb;
         f.nseg = (uint32_t)ceil_div((size_t)nblk, (size_t)f.segb);
         const size_t lds = h16_lds_bytes(ncb, ix.h_nch);
         const uint32_t per_cu = (uint32_t)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));

@@ -123,10 +123,13 @@ static void put_utf8(std::string & s, uint32_t cp)
 void tokenize(const char * text, std::vector<std::string> & out)
 {
     std::string cur;
+    size_t raw = 0; // bytes of the token as SimpleTokenizer cut it: RemoveLongFilter(40) sits BEFORE LowerCaser in tantivy's default
+                    // chain, and lower-casing changes byte lengths (U+212A KELVIN SIGN, 3 bytes -> 'k'; U+0130 -> "i" + U+0307)
     auto flush = [&] {
-        if (!cur.empty() && cur.size() < 40)
+        if (!cur.empty() && raw < 40)
             out.push_back(cur);
         cur.clear();
+        raw = 0;
     };
     const unsigned char * p = reinterpret_cast<const unsigned char *>(text);
     while (*p)
@@ -136,9 +139,9 @@ void tokenize(const char * text, std::vector<std::string> & out)
         {
             p++;
             if ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z'))
-                cur.push_back((char)c);
+                cur.push_back((char)c), raw++;
             else if (c >= 'A' && c <= 'Z')
-                cur.push_back((char)(c - 'A' + 'a'));
+                cur.push_back((char)(c - 'A' + 'a')), raw++;
             else
                 flush();
             continue;
@@ -170,7 +173,16 @@ void tokenize(const char * text, std::vector<std::string> & out)
         }
         p += len;
         if (uni_alnum(cp))
-            put_utf8(cur, uni_lower(cp));
+        {
+            raw += (size_t)len;
+            if (cp == 0x130) // LATIN CAPITAL LETTER I WITH DOT ABOVE: char::to_lowercase gives TWO code points, "i" + U+0307
+            {
+                cur.push_back('i');
+                put_utf8(cur, 0x307);
+            }
+            else
+                put_utf8(cur, uni_lower(cp));
+        }
         else
             flush();
     }

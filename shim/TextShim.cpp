@@ -13,6 +13,7 @@
 // tantivy's own files for the boolean FTS functions); without it this library stands alone.
 #include <tantivy_search/tantivy_search.h>
 
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -109,6 +110,44 @@ FFIBoolResult ffi_create_index_with_parameter(const std::string & index_path, co
         const size_t q1 = q0 == std::string::npos ? q0 : index_json_parameter.find('"', q0 + 1);
         if (q1 == std::string::npos || index_json_parameter.substr(q0 + 1, q1 - q0 - 1) != "default")
             return failed<FFIBoolResult>("msvs text export: only tantivy's default tokenizer chain is implemented, got " + index_json_parameter);
+    }
+    // ... and the default chain WITH options (tantivy_search documents case_sensitive, stop_word_filters, stem_languages,
+    // length_limit for it) is another chain: anything but their defaults fails here too
+    {
+        const std::string & j = index_json_parameter;
+        auto value_after = [&](const char * key, size_t from) -> std::string {
+            const size_t at = j.find(key, from);
+            if (at == std::string::npos)
+                return "";
+            size_t b = j.find(':', at);
+            if (b == std::string::npos)
+                return "";
+            b++;
+            while (b < j.size() && (j[b] == ' ' || j[b] == '\t' || j[b] == '\n'))
+                b++;
+            size_t e = b;
+            if (e < j.size() && j[e] == '[')
+                e = j.find(']', e) == std::string::npos ? j.size() : j.find(']', e) + 1;
+            else
+                while (e < j.size() && j[e] != ',' && j[e] != '}')
+                    e++;
+            std::string v = j.substr(b, e - b);
+            v.erase(std::remove_if(v.begin(), v.end(), [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '"'; }), v.end());
+            return v;
+        };
+        for (size_t from = 0; j.find("\"case_sensitive\"", from) != std::string::npos; from = j.find("\"case_sensitive\"", from) + 1)
+            if (value_after("\"case_sensitive\"", from) == "true")
+                return failed<FFIBoolResult>("msvs text export: tokenizer option case_sensitive = true is not implemented (" + j + ")");
+        for (const char * key : {"\"stop_word_filters\"", "\"stem_languages\""})
+            for (size_t from = 0; j.find(key, from) != std::string::npos; from = j.find(key, from) + 1)
+            {
+                const std::string v = value_after(key, from);
+                if (!v.empty() && v != "[]")
+                    return failed<FFIBoolResult>(std::string("msvs text export: tokenizer option ") + key + " is not implemented (" + j + ")");
+            }
+        for (size_t from = 0; j.find("\"length_limit\"", from) != std::string::npos; from = j.find("\"length_limit\"", from) + 1)
+            if (value_after("\"length_limit\"", from) != "40")
+                return failed<FFIBoolResult>("msvs text export: tokenizer option length_limit other than 40 is not implemented (" + j + ")");
     }
     std::vector<const char *> cols;
     for (const auto & c : column_names)

@@ -66,6 +66,16 @@ int main(int argc, char ** argv)
     std::printf("default_tokenizer_is_fine %d\n",
                 TANTIVY::ffi_create_index_with_parameter(dir + "/nope", {col}, "{\"doc\": {\"tokenizer\": {\"type\": \"default\"}}}").result ? 1 : 0);
     TANTIVY::ffi_free_index_writer(dir + "/nope");
+    // the default chain WITH non-default options is another chain: rejected; spelled-out defaults are fine
+    std::printf("tokenizer_options_are_errors %d\n",
+                (TANTIVY::ffi_create_index_with_parameter(dir + "/nope", {col}, "{\"doc\": {\"tokenizer\": {\"type\": \"default\", \"case_sensitive\": true}}}").error.is_error
+                 && TANTIVY::ffi_create_index_with_parameter(dir + "/nope", {col}, "{\"doc\": {\"tokenizer\": {\"type\": \"default\", \"stop_word_filters\": [\"english\"]}}}").error.is_error
+                 && TANTIVY::ffi_create_index_with_parameter(dir + "/nope", {col}, "{\"doc\": {\"tokenizer\": {\"type\": \"default\", \"stem_languages\": [\"english\"]}}}").error.is_error
+                 && TANTIVY::ffi_create_index_with_parameter(dir + "/nope", {col}, "{\"doc\": {\"tokenizer\": {\"type\": \"default\", \"length_limit\": 60}}}").error.is_error)
+                    ? 1 : 0);
+    std::printf("default_options_spelled_out_are_fine %d\n",
+                TANTIVY::ffi_create_index_with_parameter(dir + "/nope", {col}, "{\"doc\": {\"tokenizer\": {\"type\": \"default\", \"case_sensitive\": false, \"stop_word_filters\": [], \"stem_languages\": [ ], \"length_limit\": 40}}}").result ? 1 : 0);
+    TANTIVY::ffi_free_index_writer(dir + "/nope");
     // the host side: statistics over the parts, then one search per part
     TANTIVY::Statistics stats;
     std::map<std::pair<uint32_t, std::string>, uint64_t> df;

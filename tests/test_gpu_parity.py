@@ -190,6 +190,80 @@ def test_flat_index_filter_and_labels(metric, n, d, nq, k):
 
 
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("n,d,nq,k,order", [(70000, 96, 300, 10, "random"),    # several tiles: two row blocks per wavefront
+                                           (20000, 768, 48, 10, "random"),    # one tile: the table streams once
+                                           (33001, 100, 130, 40, "random"),   # rows not a multiple of 32, 64 candidates re-ranked
+                                           (1500, 20, 17, 1, "random"),       # a table smaller than the sample
+                                           (60000, 64, 100, 10, "clustered")])  # rows SORTED by cluster: a strided sample still sees them all
+def test_flat_shadow_pass_matches_oracle(metric, n, d, nq, k, order, opt):
+    """A batch against a FLAT index goes through the index's fp16 shadow (h16_flat_kernel: sample of 64 blocks spread over the
+    table -> cut -> exhaustive scan of (segment, tile) items -> candidates -> canonical re-rank + certificate): the canonical
+    exhaustive answer bit for bit, with labels, filters (dense and nearly empty), tables sorted by cluster, every segment size
+    and tile shape, overflowing candidate buffers and failing certificates (canonical fallback); == the split-bf16 pass it replaces."""
+    rng = np.random.default_rng(n + d + nq + 3)
+    if order == "clustered":
+        centres = 4.0 * rng.standard_normal((40, d), dtype=np.float32)
+        z = np.sort(rng.integers(0, 40, n))
+        x = (centres[z] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+        q = (centres[rng.integers(0, 40, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    else:
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        q = (x[rng.integers(0, n, nq)] + 0.3 * rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    x[100:105] = x[7]  # ties
+    labels = rng.permutation(n * 2)[:n].astype(np.int64)
+    ix = capi.Index(capi.INDEX_FLAT, metric, d)
+    ix.add(x, labels)
+    ix.build()
+    opt("flat_mfma", "2")  # also for the shapes below the automatic threshold
+    xs, qs, om = (o.normalize_rows(x), o.normalize_rows(q), o.METRIC_IP) if metric == capi.METRIC_COSINE else (x, q, OM[metric])
+
+    def expect(alive=None):
+        oi, od = o.knn(qs, xs, k, om, labels=labels, alive=None if alive is None else alive[labels])
+        return oi, ((np.float32(1) - od).astype(np.float32) if metric == capi.METRIC_COSINE else od)
+
+    capi.profile_reset()
+    capi.profile_enable(True)
+    q0, f0 = capi.prefilter_stats()
+    ids, dis = ix.search(q, k)
+    capi.profile_enable(False)
+    same(ids, dis, *expect())
+    q1, f1 = capi.prefilter_stats()
+    assert q1 - q0 == nq and capi.profile_get("flat_shadow_scan")[0] >= 1, "the shadow pass is the one that ran"
+    capi.profile_reset()
+    if order == "random":
+        assert f1 - f0 <= nq // 10
+    dense, sparse = rng.random(n * 2) < 0.4, rng.random(n * 2) < 0.003
+    for alive in (dense, sparse):
+        ids, dis = ix.search(q, k, alive=alive)
+        same(ids, dis, *expect(alive))
+    for segb, ncb, shape in ((8, 1, 1), (17, 2, 3), (256, 3, 6), (1, 0, 1)):
+        opt("flat_segb", str(segb))
+        opt("flat_ncb", str(ncb))
+        opt("flat_h16", str(shape))
+        ids, dis = ix.search(q, k)
+        same(ids, dis, *expect())
+    opt("flat_segb", None)
+    opt("flat_ncb", None)
+    opt("flat_h16", None)
+    opt("h16_grid", "3")  # three workgroups walk every item
+    ids, dis = ix.search(q, k, alive=dense)
+    same(ids, dis, *expect(dense))
+    opt("h16_grid", None)
+    opt("cand_cap", "64")  # overflowing candidate buffers: no certificate, canonical fallback
+    ids, dis = ix.search(q, k)
+    same(ids, dis, *expect())
+    opt("cand_cap", None)
+    opt("ivf_eps_scale", "1e12")  # no certificates at all
+    ids, dis = ix.search(q[:40], k)
+    ei, ed = expect()
+    same(ids, dis, ei[:40], ed[:40])
+    opt("ivf_eps_scale", None)
+    opt("flat_h16", "0")  # the split-bf16 pass over the f32 rows
+    ids, dis = ix.search(q, k)
+    same(ids, dis, *expect())
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
 @pytest.mark.parametrize("n,d,nq,k", [(40000, 96, 200, 10), (20000, 768, 48, 10), (33000, 100, 130, 40), (5000, 20, 17, 1)])
 def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, opt):
     """A batch against the whole table: matrix-core candidate pass + canonical re-rank, exact and certified; the

@@ -295,24 +295,29 @@ def test_default_tokenizer_on_non_ascii_text_matches_a_python_restatement():
     import unicodedata
 
     def py_tokens(text):
-        out, cur = [], ""
+        # RemoveLongFilter(40) sees the token as SimpleTokenizer cut it (its raw UTF-8 length), LowerCaser runs after it
+        out, cur, raw = [], "", 0
         for ch in text:
             c = unicodedata.category(ch)
             if c[0] == "L" or c in ("Nd", "Nl", "No"):
                 lo = ch.lower()
-                cur += lo[0] if lo != ch else ch
+                cur += lo if ch == "\u0130" else (lo[0] if lo != ch else ch)  # U+0130 lower-cases to TWO code points (i + U+0307)
+                raw += len(ch.encode("utf-8"))
             else:
-                if cur and len(cur.encode("utf-8")) < 40:
+                if cur and raw < 40:
                     out.append(cur)
-                cur = ""
-        if cur and len(cur.encode("utf-8")) < 40:
+                cur, raw = "", 0
+        if cur and raw < 40:
             out.append(cur)
         return out
 
     texts = ["History's LESSONS \u2014 r\u00e9sum\u00e9\u00a0na\u00efve caf\u00c9, \u00dcBER-stra\u00dfe",
              "\u5317\u4eac\uff0c\u4e0a\u6d77\u3002\u6771\u4eac\u30bf\u30ef\u30fc 2024\u5e74", "\u041c\u043e\u0441\u043a\u0432\u0410 \u2013 \u0391\u0398\u0397\u039d\u0391 \u03c3\u03c4\u03b7\u03bd",
              "\uff11\uff12\uff13 abc\u00b2 x\u2082 \u2167 \u00bd", "a" * 39 + " " + "b" * 40 + " \u00e9" * 3 + " " + "\u00e9" * 20,
-             "", "   \u3000\u2003 ", "\U0001d400\U0001d401 emoji \U0001f600 done"]
+             "", "   \u3000\u2003 ", "\U0001d400\U0001d401 emoji \U0001f600 done",
+             # lower-casing that changes the byte length: KELVIN SIGN (3 bytes -> k) in a token of exactly 40 raw bytes (dropped: the
+             # filter runs first) and of 39 (kept); I WITH DOT ABOVE -> "i" + combining dot (2 -> 3 bytes) in a 39-byte token (kept)
+             "x" * 37 + "\u212a yes", "x" * 36 + "\u212a yes", "\u0130stanbul " + "y" * 37 + "\u0130"]
     for t in texts:
         assert host.tokenize(t) == py_tokens(t), t
     # malformed sequences are separators: a lone continuation byte, a truncated 3-byte sequence, an overlong encoding

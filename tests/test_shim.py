@@ -157,3 +157,4 @@ def test_text_shim_replays_the_two_part_bm25_golden():
     assert ["missing_index_is_error", "1"] in lines
     assert ["freed_writer_is_error", "1"] in lines and ["other_tokenizer_is_error", "1"] in lines
     assert ["default_tokenizer_is_fine", "1"] in lines
+    assert ["tokenizer_options_are_errors", "1"] in lines and ["default_options_spelled_out_are_fine", "1"] in lines

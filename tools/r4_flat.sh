@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r4
-timeout 900 python tools/flat_sweep.py B=64 B=64,h16_flush_each=1 B=64 B=16 B=16,h16_flush_each=1 B=128 B=128,h16_flush_each=1 B=256 B=256,h16_flush_each=1 B=256 B=4096 B=4096,h16_flush_each=1 > gpurun_out/r4/flat_sweep6.txt 2>&1
-cat gpurun_out/r4/flat_sweep6.txt | cut -c1-300
-timeout 600 python tools/ivf_sweep.py B=4096 B=4096,h16_flush_each=1 B=4096 B=4096,h16_flush_each=1 B=1024 B=1024,h16_flush_each=1 B=256 B=256,h16_flush_each=1 B=64 B=64,h16_flush_each=1 > gpurun_out/r4/scan4_latent.txt 2>&1
-cat gpurun_out/r4/scan4_latent.txt | cut -c1-400
+SWEEP_ROWS=10000 SWEEP_DIM=128 timeout 600 python tools/flat_sweep.py B=1000,flat_h16=0 B=1000 B=1000,flat_segb=8 B=1000,flat_segb=16 B=1000,flat_segb=32 B=1000,flat_segb=64 B=1000,flat_h16=3 B=100,flat_h16=0 B=100 B=4096,flat_h16=0 B=4096 > gpurun_out/r4/flat_c1.txt 2>&1
+cat gpurun_out/r4/flat_c1.txt | cut -c1-330
+SWEEP_ROWS=100000 SWEEP_DIM=128 timeout 600 python tools/flat_sweep.py B=1000,flat_h16=0 B=1000 B=100,flat_h16=0 B=100 > gpurun_out/r4/flat_c1b.txt 2>&1
+cat gpurun_out/r4/flat_c1b.txt | cut -c1-330
