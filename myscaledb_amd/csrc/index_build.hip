@@ -256,6 +256,10 @@ extern "C" int msvs_index_create(int index_type, int metric, size_t dim, const c
         MSVS_HIP(hipGetDevice(&ix->device));
         ix->ncentroids = (size_t)param_int(p, "ncentroids", 1024);
         ix->kmeans_iters = (int)param_int(p, "kmeans_iters", 10);
+        if (p.count("kmeans_split_big"))
+            ix->split_big = std::max(1.1, atof(p.at("kmeans_split_big").c_str()));
+        if (p.count("kmeans_split_small"))
+            ix->split_small = std::min(1.0, std::max(0.0, atof(p.at("kmeans_split_small").c_str())));
         ix->train_sample = (size_t)param_int(p, "train_sample", 0);
         ix->seed = (uint64_t)param_int(p, "seed", 1234);
         ix->shard_rank = (int)param_int(p, "shard_rank", 0);
@@ -407,10 +411,15 @@ extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, in
                 nempty += (size_t)(off[j + 1] - off[j]) <= tiny;
             // ... and the oversized: Lloyd's iteration cannot undo a seeding that put two centroids into one well-separated blob
             // and none into another (the orphan blobs merge into a neighbour's list: 12 blobs in one list on SURVEY 8d's
-            // sigma-0.3 model).  While a cluster holds more than 2.5 x the average, the smallest cluster below 0.75 x the average
-            // gives its centroid up to split it; its members fall to their next centroid (the twin inside the same blob).
+            // sigma-0.3 model).  While a cluster holds more than `split_big` x the average, the smallest cluster below
+            // `split_small` x the average gives its centroid up to split it; its members fall to their next centroid (the twin
+            // inside the same blob).  split_big = 1.7 (round 3: 2.5): a list that holds TWO blobs is 2 x the average, and round 4's
+            // probe of the pruning (tools/prune_probe.py) found 141 such lists of 1024 on the sigma-0.3 model holding 93 % of the
+            // (query, list) pairs the pruning could not drop -- their radius is half the distance between two blobs, and their
+            // centroid, the mean of two, is closer to every query than a blob centre is.
             std::vector<std::pair<size_t, size_t>> forced; // (small cluster, the giant it splits)
-            if (!last_it && ns > 4 * nlist)
+            // (not in the last two iterations: a pair of twins needs a Lloyd step or two to part and settle)
+            if (it + 2 < ix->kmeans_iters && ns > 4 * nlist)
             {
                 const double avg = (double)ns / (double)nlist;
                 std::vector<size_t> order(nlist);
@@ -424,7 +433,7 @@ extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, in
                 {
                     const size_t small = order[lo], big = order[hi - 1];
                     const double ssz = (double)(off[small + 1] - off[small]), bsz = (double)(off[big + 1] - off[big]);
-                    if (!(bsz > 2.5 * avg && ssz < 0.75 * avg))
+                    if (!(bsz > ix->split_big * avg && ssz < ix->split_small * avg))
                         break;
                     if (ssz > (double)tiny) // the tiny ones are re-seeded by the draw below anyway
                     {

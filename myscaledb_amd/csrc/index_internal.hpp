@@ -20,6 +20,7 @@ struct msvs_index
     // build parameters
     size_t ncentroids = 1024;
     int kmeans_iters = 10;
+    double split_big = 1.7, split_small = 0.75; // trainer: clusters above / below these multiples of the average size trade a centroid
     size_t train_empty_last = 0; // empty clusters the last k-means iteration re-seeded (diagnostics)
     size_t train_sample = 0;
     uint64_t seed = 1234;
