@@ -831,9 +831,90 @@ struct H16Prune
     float xmax, cmax;     // max |x|^2 over the rows / the centroids
     double c_dot, c_norm, c_canon; // the shadow passes' error model
     uint32_t k;
+    float * upre;              // nullable [nq]: h16_preprune_kernel leaves its upper bound of the query's k-th best (real) distance,
+                               // slack included, rounded up (+inf: none); the second stage takes the smaller of its own bound and this
     int32_t * out_probes;      // [nq][nprobe]: the probes that survive (-1: dropped or absent)
     unsigned long long * stat; // nullable: [0] += pairs dropped, [1] += pairs
 };
+
+/// PRE-PRUNING (round 4; L2 indexes, no filter): before a single sample row is scored, the list radius alone rules most pairs
+/// out on data with cluster structure.  Every row of probed list p lies within ||q - c_p|| + r_p of the query, so a list with at
+/// least k rows puts an upper bound U_p = (||q - c_p|| + r_p)^2 on the query's k-th best distance; U = min over such probes.  A pair
+/// whose nearest possible row is beyond it -- (||q - c_l|| - r_l)^2 > U -- cannot hold one of the k nearest rows: it is dropped from
+/// the plan of the SAMPLE launch already (and with it from the cut, the second pruning and the main launch; the canonical fallback
+/// still walks every probed list).  ||q - c||^2 comes from the coarse pass's approximate word, widened by its error bound both ways;
+/// the slack on the right covers the canonical arithmetic of the rows' distances.  One wavefront per query, lane = probe.
+/// On SURVEY 8d's sigma-0.3 blobs 97 % of the pairs go before the sample launch (0.080 -> ~0.01 ms).
+static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_t * probes, const H16Prune pr, const int64_t * list_off,
+                                                                     uint32_t nq, uint32_t nprobe, int32_t * out_probes)
+{
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq)
+        return;
+    const int32_t l = lane < nprobe ? probes[(size_t)q * nprobe + lane] : -1;
+    const uint32_t cw = l >= 0 ? (pr.probe_words ? pr.probe_words[(size_t)q * nprobe + lane] : pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l])
+                               : 0xFFFFFFFFu;
+    const float qn = pr.qnorm[q];
+    const bool usable = qn < 1e30f && pr.xmax < 1e30f && pr.cmax < 1e30f;
+    double ub = 1e300, lb = 0.0; // this probe's upper bound of the k-th distance; lower bound of its rows' distances
+    if (usable && l >= 0 && cw != 0xFFFFFFFFu)
+    {
+        const double sq = sqrt((double)qn * 1.001), sc = sqrt((double)pr.cmax * 1.001);
+        const double eps_c = 2.0 * pr.c_dot * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
+        const double ac = (double)ord2f(cw), r = (double)pr.radius[l];
+        const double hi2 = ac + 2.0 * eps_c, lo2 = ac - 2.0 * eps_c;
+        if ((uint64_t)(list_off[l + 1] - list_off[l]) >= pr.k && r == r && hi2 == hi2)
+        {
+            const double hi = sqrt(hi2 > 0.0 ? hi2 : 0.0) * (1.0 + 1e-7) + r;
+            ub = hi * hi * (1.0 + 1e-7);
+        }
+        if (lo2 > 0.0)
+        {
+            const double lo = sqrt(lo2) * (1.0 - 1e-7);
+            if (lo > r)
+                lb = (lo - r) * (lo - r) * (1.0 - 1e-7);
+        }
+    }
+    double U = ub;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        const double other = __shfl_xor(U, o);
+        U = other < U ? other : U;
+    }
+    bool keep = true;
+    if (usable && l >= 0 && U < 1e299)
+    {
+        const double sq = sqrt((double)qn * 1.001), sx = sqrt((double)pr.xmax * 1.001);
+        const double slack = 2.0 * (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30; // canonical vs real distance, both sides
+        keep = !(lb > U + slack);
+    }
+    if (lane < nprobe)
+        out_probes[(size_t)q * nprobe + lane] = keep ? l : -1;
+    if (pr.upre && lane == 0)
+    {
+        float u = __uint_as_float(0x7f800000u);
+        if (usable && U < 1e299)
+        {
+            const double sq = sqrt((double)qn * 1.001), sx = sqrt((double)pr.xmax * 1.001);
+            const double v = U + 2.0 * (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30;
+            u = v < 3.0e38 ? (float)v : u;
+            if ((double)u < v)
+                u = nextafterf(u, __uint_as_float(0x7f800000u));
+        }
+        pr.upre[q] = u;
+    }
+    if (pr.stat)
+    {
+        // [0] pairs dropped, [1] pairs looked at: the second stage counts the pairs it still sees, this one the pairs it takes away
+        const uint64_t dropped = __ballot(l >= 0 && !keep);
+        if (lane == 0 && dropped)
+        {
+            atomicAdd(pr.stat, (unsigned long long)__popcll(dropped));
+            atomicAdd(pr.stat + 1, (unsigned long long)__popcll(dropped));
+        }
+    }
+}
 
 template <int NW>
 __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t * qprobes, const int64_t * list_off, uint32_t nprobe,
@@ -902,8 +983,12 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
                 if (inner > 0.0)
                 {
                     const double dc = sqrt(inner) * (1.0 - 1e-7), r = (double)pr.radius[l];
+                    // the k-th best canonical distance is at most ak + 2 eps_x (k sample rows) and at most the pre-pruning's bound
+                    double kth = ak + 2.0 * eps_x;
+                    if (pr.upre && (double)pr.upre[q] < kth)
+                        kth = (double)pr.upre[q];
                     if (dc > r)
-                        keep = !((dc - r) * (dc - r) * (1.0 - 1e-7) > ak + 2.0 * eps_x);
+                        keep = !((dc - r) * (dc - r) * (1.0 - 1e-7) > kth);
                 }
             }
             else if (pr.ip == 2)

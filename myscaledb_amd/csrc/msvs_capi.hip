@@ -403,7 +403,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + nq * nprobe * 4
         + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768
         + (4 * ix.nlist + 18) * 4 + 1024 + 1024 // the list scan's counters taken up front, the padded query images
-        + 2 * nq * nprobe * 4 + 2 * (ix.nlist + 1) * 4 + 1024 // probe pruning: surviving probes, the second plan
+        + 3 * nq * nprobe * 4 + nq * 4 + 2 * (ix.nlist + 1) * 4 + 4096 // probe pruning: surviving probes (two stages), the second plan
         + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 8192 : 0);
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
@@ -993,8 +993,36 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
 {
     const uint32_t ld = ix.ld;
     // work item = (list, tile of 32 * h_ncb probing queries); main launch: rows [list_off + 32, end), sample launch: block 0
+    // pre-pruning by the list radius alone (h16_preprune_kernel): L2 indexes whose coarse pass left its distance words behind, no
+    // filter (a list must be known to hold k rows the query may take)
+    const int32_t * plan_probes = d_probes; // the probes the shadow pass works on; the canonical fallback keeps d_probes
+    H16Prune pr0{};
+    if (options().h16_prune != 0 && options().h16_preprune != 0 && ix.metric == MSVS_METRIC_L2 && !d_alive && ix.list_radius.p
+        && (prepared.coarse_words || prepared.probe_words) && prepared.qnorm && nprobe <= 64 && k <= 128)
+    {
+        RerankParams em{};
+        set_error_model_h16(em, ix.dim);
+        pr0.coarse_words = prepared.coarse_words;
+        pr0.npad = prepared.coarse_npad;
+        pr0.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
+        pr0.radius = ix.list_radius.p;
+        pr0.qnorm = prepared.qnorm;
+        pr0.xmax = ix.xnorm_max;
+        pr0.cmax = ix.cnorm_max;
+        pr0.c_dot = em.c_dot;
+        pr0.c_norm = em.c_norm;
+        pr0.c_canon = em.c_canon;
+        pr0.k = k;
+        pr0.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
+        int32_t * probes1 = scr.take<int32_t>(nq * nprobe);
+        pr0.upre = scr.take<float>(nq);
+        ProfileScope prof("ivf_plan", stream);
+        hipLaunchKernelGGL(h16_preprune_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, d_probes, pr0, ix.list_off.p,
+                           (uint32_t)nq, (uint32_t)nprobe, probes1);
+        plan_probes = probes1;
+    }
     IvfPlanParams pp{};
-    pp.probes = d_probes;
+    pp.probes = plan_probes;
     pp.list_off = ix.list_mid32.p;
     pp.list_end = ix.list_off.p + 1;
     pp.whole_off = ix.list_off.p;
@@ -1121,15 +1149,16 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
                 pr.c_canon = em.c_canon;
                 pr.k = k;
                 pr.out_probes = scr.take<int32_t>(nq * nprobe);
+                pr.upre = pr0.upre; // (null without the pre-pruning)
                 pr.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
             }
             hipLaunchKernelGGL(h16_sample_thr_wave_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
-                               sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
+                               sample, plan_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
                                qstate + nq, partial, pl.h_cap, options().wave_select == 3 ? 0 : 1, fl, pr);
         }
         else
             hipLaunchKernelGGL(h16_sample_thr_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
-                               sample, d_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
+                               sample, plan_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
                                qstate + nq, partial, pl.h_cap);
     }
     if (pr.on())
@@ -1229,7 +1258,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     c.Q = rp.Q;
     c.ld4 = ld / 4;
     c.nq = (uint32_t)nq;
-    c.probes = d_probes;
+    c.probes = plan_probes; // (the lists the pre-pruning dropped provably hold none of the k nearest rows: not for the fallback either)
     c.list_off = ix.list_off.p;
     c.nprobe = (uint32_t)nprobe;
     c.nlist = (uint32_t)ix.nlist;
@@ -1241,7 +1270,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     c.qcount = nfail_final;
     IvfMergeParams fm{};
     fm.partial = partial1;
-    fm.probes = d_probes;
+    fm.probes = plan_probes;
     fm.list_off = ix.list_off.p;
     fm.nprobe = (uint32_t)nprobe;
     fm.seg_max = pl.seg_max1;
