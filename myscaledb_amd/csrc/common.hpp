@@ -182,6 +182,7 @@ struct Options
     double filter_compact_below = -1;  // filtered searches run over a compacted view when less than this fraction of the
                                        // rows passes the filter (1: always, 0: never, < 0: by batch size,
                                        // profiles/r02_filter.txt)
+    double lat_prune = 1;     // few-query path (L2, no filter): probed lists the list radius rules out get no work items (0: off)
     double h16_preprune = 1;  // shadow list scan (L2, no filter): pairs the list radius alone rules out leave before the sample launch (0: off)
     double h16_prune = 1;     // shadow list scan (L2): drop (query, list) pairs that provably cannot hold one of the query's k nearest rows when the lists are probed by more than a tile of queries (0: off, 2: always)
     double coarse_band = 1;   // coarse quantiser of batches: only the candidates near the top-nprobe boundary are evaluated canonically (0: all 64)

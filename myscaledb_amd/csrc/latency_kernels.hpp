@@ -43,6 +43,15 @@ struct LatParams
     uint32_t c_blocks;    // ceil(nlist / c_rows)
     uint64_t * c_partial; // [nq][c_blocks][nprobe]
     int32_t * probes;     // [nq][nprobe]
+    uint32_t * cut;       // [nq][nprobe + 3]: stage 1's last block leaves stage 2's work partition here (lat_cut: items before list p,
+                          // then their total, then the rows per item) -- every stage-2 block read it off the probe list itself before,
+                          // a serial loop of nprobe dependent loads per block (2.9 us of a 35 us search)
+    float * probe_dis;    // [nq][nprobe] canonical distance of the query to the probe's centroid (what the radius pruning reads)
+    // radius pruning of stage 2 (round 4; L2, no filter; nullptr: off): lat_cut gives no work to a probed list that provably holds
+    // none of the k nearest rows -- (||q - c_l|| - r_l)^2 beyond the smallest (||q - c_p|| + r_p)^2 over probed lists of >= k rows
+    const float * radius; // [nlist]
+    float cmax, xmax;     // max |c|^2, max |x|^2
+    double c_canon;       // relative rounding of a canonical distance
     // stage 2
     const float4 * Y;
     const uint32_t * ids;
@@ -213,7 +222,8 @@ __device__ __forceinline__ uint64_t * lat_merge_lists(const uint64_t * src, uint
 /// oracle's: smallest (distance, id) first) -- 11.3 -> ~4 us for 1024 keys against popping 32 heads off 32 sorted
 /// lists.  The probes leave in arbitrary order (the list scan's result does not depend on it).
 template <int NW>
-__device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, uint32_t np, int32_t * probes, uint32_t lane, uint32_t * hist)
+__device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, uint32_t np, int32_t * probes, float * dis, uint32_t lane,
+                                         uint32_t * hist)
 {
     uint32_t hi[NW], lo[NW];
 #pragma unroll
@@ -249,9 +259,66 @@ __device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, u
         const uint64_t mask = __ballot(take);
         const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (take && pos < np)
+        {
             probes[pos] = hi[u] == 0xFFFFFFFFu && lo[u] == 0xFFFFFFFFu ? -1 : (int32_t)lo[u];
+            dis[pos] = ord2f(hi[u]); // (an L2 key's high word; read by the radius pruning of L2 searches only)
+        }
         run += (uint32_t)__popcll(mask);
     }
+}
+
+/// The rows of a query's probed lists are cut into work items of equal size WHATEVER the list lengths are (a grid shaped
+/// by the longest list leaves half its blocks without rows): rows per item = the probed rows / `items`, rounded up to the
+/// 16 rows a block scans per step; list p gets ceil(len_p / rpb) items, at most items + nprobe in total.  Computed ONCE, by one
+/// wavefront of stage 1's last block (lat_make_cut: lane = probe, wave-wide sums), read back by every block of stage 2.
+struct LatCut
+{
+    uint32_t rpb, total;
+};
+__device__ __forceinline__ void lat_make_cut(const LatParams & p, uint32_t q, uint32_t lane)
+{
+    const int32_t l = lane < p.nprobe ? p.probes[(size_t)q * p.nprobe + lane] : -1;
+    const uint32_t len = l >= 0 ? (uint32_t)(p.list_off[l + 1] - p.list_off[l]) : 0u;
+    uint64_t rows = len;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        rows += (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)rows, o) | ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(rows >> 32), o) << 32);
+    uint32_t rpb = (uint32_t)((rows + p.items - 1) / p.items);
+    rpb = rpb < 16 ? 16 : (rpb + 15) / 16 * 16;
+    const uint32_t mine = (len + rpb - 1) / rpb;
+    uint32_t incl = mine; // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o)
+            incl += up;
+    }
+    uint32_t * dst = p.cut + (size_t)q * (p.nprobe + 3);
+    if (lane < p.nprobe)
+        dst[lane] = incl - mine;
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (lane == 0)
+    {
+        dst[p.nprobe] = total;
+        dst[p.nprobe + 1] = rpb;
+    }
+}
+__device__ __forceinline__ LatCut lat_cut(const LatParams & p, uint32_t q, int32_t * s_probe /* [nprobe] */,
+                                          uint32_t * s_first /* [nprobe + 1] */)
+{
+    __shared__ uint32_t s_rpb;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t * src = p.cut + (size_t)q * (p.nprobe + 3);
+    __syncthreads();
+    if (tid < p.nprobe)
+        s_probe[tid] = p.probes[(size_t)q * p.nprobe + tid];
+    if (tid <= p.nprobe)
+        s_first[tid] = src[tid];
+    if (tid == 0)
+        s_rpb = src[p.nprobe + 1];
+    __syncthreads();
+    return LatCut{s_rpb, s_first[p.nprobe]};
 }
 
 /// dynamic LDS: ld4 * 16 + max(5 * nprobe * 8, lat_merge_lds(c_blocks, nprobe)) bytes
@@ -292,14 +359,15 @@ __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
         {
             const uint64_t * src = p.c_partial + (size_t)qq * total;
             int32_t * dst = p.probes + (size_t)qq * np;
+            float * dd = p.probe_dis + (size_t)qq * np;
             if (total <= 4 * WAVE)
-                lat_select_probes<4>(src, total, np, dst, tid & 63, hist);
+                lat_select_probes<4>(src, total, np, dst, dd, tid & 63, hist);
             else if (total <= 8 * WAVE)
-                lat_select_probes<8>(src, total, np, dst, tid & 63, hist);
+                lat_select_probes<8>(src, total, np, dst, dd, tid & 63, hist);
             else if (total <= 16 * WAVE)
-                lat_select_probes<16>(src, total, np, dst, tid & 63, hist);
+                lat_select_probes<16>(src, total, np, dst, dd, tid & 63, hist);
             else
-                lat_select_probes<32>(src, total, np, dst, tid & 63, hist);
+                lat_select_probes<32>(src, total, np, dst, dd, tid & 63, hist);
         }
         __syncthreads();
     }
@@ -308,8 +376,58 @@ __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
         {
             const uint64_t * merged = lat_merge_lists<true>(p.c_partial + (size_t)qq * p.c_blocks * np, p.c_blocks, p.c_blocks, np, lds_merge);
             if (tid < np)
+            {
                 p.probes[(size_t)qq * np + tid] = merged[tid] == KEY_NONE ? -1 : (int32_t)(uint32_t)merged[tid];
+                p.probe_dis[(size_t)qq * np + tid] = key_value<METRIC>(merged[tid]);
+            }
         }
+    // radius pruning (LatParams::radius), once per search: lane i of wavefront qq weighs probe i of query qq; the probes it rules
+    // out become -1 and get no work items in stage 2
+    if (METRIC == M_L2 && p.radius && !p.alive)
+    {
+        __syncthreads(); // (the probes and their distances were written by this block: visible after the barrier)
+        for (uint32_t qq = tid >> 6; qq < p.nq; qq += BLOCK / WAVE)
+        {
+            const uint32_t lane = tid & 63;
+            const int32_t l = lane < np ? p.probes[(size_t)qq * np + lane] : -1;
+            double ub = 1e300, lb = 0.0;
+            if (l >= 0)
+            {
+                const double dc2 = (double)p.probe_dis[(size_t)qq * np + lane], r = (double)p.radius[l];
+                if (dc2 == dc2 && dc2 >= 0.0 && dc2 < 1e30 && r == r && r < 1e18)
+                {
+                    // the centroid distance is canonical f32: widened by its rounding; |q| <= ||q - c|| + |c|
+                    const double sc = sqrt((double)p.cmax * 1.001), sq = sqrt(dc2) + sc, sx = sqrt((double)p.xmax * 1.001);
+                    const double eps_c = (p.c_canon + 4e-7) * (sq + sc) * (sq + sc) + 1e-30;
+                    const double slack = 2.0 * (p.c_canon + 4e-7) * (sq + sx) * (sq + sx) + 1e-30;
+                    if ((uint64_t)(p.list_off[l + 1] - p.list_off[l]) >= p.k)
+                    {
+                        const double hi = sqrt(dc2 + eps_c) * (1.0 + 1e-7) + r;
+                        ub = hi * hi * (1.0 + 1e-7) + slack; // every row of the list is within this: k of them bound the k-th best
+                    }
+                    if (dc2 - eps_c > 0.0)
+                    {
+                        const double lo = sqrt(dc2 - eps_c) * (1.0 - 1e-7);
+                        if (lo > r)
+                            lb = (lo - r) * (lo - r) * (1.0 - 1e-7);
+                    }
+                }
+            }
+            double U = ub;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+            {
+                const double other = __shfl_xor(U, o);
+                U = other < U ? other : U;
+            }
+            if (l >= 0 && lb > U) // strictly beyond the k-th best: no row of this list is a result (ties included)
+                p.probes[(size_t)qq * np + lane] = -1;
+        }
+    }
+    // stage 2's work partition, from the final probe lists (wavefront qq: query qq)
+    __syncthreads();
+    for (uint32_t qq = tid >> 6; qq < p.nq; qq += BLOCK / WAVE)
+        lat_make_cut(p, qq, tid & 63);
     if (tid == 0)
         p.done[0] = 0;
     if (p.dbg && tid == 0)
@@ -319,49 +437,6 @@ __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
         p.dbg[2] = t2;
         p.dbg[3] = wall_clock64();
     }
-}
-
-/// The rows of a query's probed lists are cut into work items of equal size WHATEVER the list lengths are (a grid shaped
-/// by the longest list leaves half its blocks without rows): rows per item = the probed rows / `items`, rounded up to the
-/// 16 rows a block scans per step; list p gets ceil(len_p / rpb) items, at most items + nprobe in total.  Every block
-/// derives the same cut from the probe list: s_first[p] = items before list p.
-struct LatCut
-{
-    uint32_t rpb, total;
-};
-__device__ __forceinline__ LatCut lat_cut(const LatParams & p, uint32_t q, int32_t * s_probe /* [nprobe] */,
-                                          uint32_t * s_first /* [nprobe + 1] */)
-{
-    __shared__ uint32_t s_len[LAT_MAX_K];
-    __shared__ uint32_t s_rpb, s_total;
-    const uint32_t tid = threadIdx.x;
-    __syncthreads();
-    if (tid < p.nprobe)
-    {
-        const int32_t l = p.probes[(size_t)q * p.nprobe + tid];
-        s_probe[tid] = l;
-        s_len[tid] = l >= 0 ? (uint32_t)(p.list_off[l + 1] - p.list_off[l]) : 0u;
-    }
-    __syncthreads();
-    if (tid == 0)
-    {
-        uint64_t rows = 0;
-        for (uint32_t i = 0; i < p.nprobe; i++)
-            rows += s_len[i];
-        uint32_t rpb = (uint32_t)((rows + p.items - 1) / p.items);
-        rpb = rpb < 16 ? 16 : (rpb + 15) / 16 * 16;
-        uint32_t acc = 0;
-        for (uint32_t i = 0; i < p.nprobe; i++)
-        {
-            s_first[i] = acc;
-            acc += (s_len[i] + rpb - 1) / rpb;
-        }
-        s_first[p.nprobe] = acc;
-        s_rpb = rpb;
-        s_total = acc;
-    }
-    __syncthreads();
-    return LatCut{s_rpb, s_total};
 }
 
 /// grid (items + nprobe, nq); dynamic LDS: ld4 * 16 + max(5 * k * 8, lat_merge_lds(items + nprobe, k)) bytes

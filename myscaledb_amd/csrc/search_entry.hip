@@ -27,6 +27,8 @@ struct LatCtx
 {
     DevBuf<float> dq;
     DevBuf<int32_t> probes;
+    DevBuf<float> probe_dis;
+    DevBuf<uint32_t> cut;
     DevBuf<uint64_t> c_partial, partial;
     DevBuf<uint32_t> done;
     // host side (pinned, device-visible): queries in, results + completion word out
@@ -121,6 +123,10 @@ void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, u
             c.dq.alloc(n_dq);
         if (!c.probes.p)
             c.probes.alloc(LAT_MAX_Q * LAT_MAX_K);
+        if (!c.probe_dis.p)
+            c.probe_dis.alloc(LAT_MAX_Q * LAT_MAX_K);
+        if (!c.cut.p)
+            c.cut.alloc(LAT_MAX_Q * (LAT_MAX_K + 3));
         if (c.c_partial.n < n_cp)
             c.c_partial.alloc(n_cp + n_cp / 2);
         if (c.partial.n < n_part)
@@ -135,6 +141,16 @@ void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, u
     p.dq = reinterpret_cast<float4 *>(c.dq.p);
     p.c_partial = c.c_partial.p;
     p.probes = c.probes.p;
+    p.probe_dis = c.probe_dis.p;
+    p.cut = c.cut.p;
+    // radius pruning of the list scan (latency_kernels.hpp: lat_cut): L2 indexes, unfiltered searches
+    p.radius = options().h16_prune != 0 && options().lat_prune != 0 && ix.metric == MSVS_METRIC_L2 && !d_alive && ix.list_radius.p
+            && ix.cnorm_max < 1e30f && ix.xnorm_max < 1e30f
+        ? ix.list_radius.p
+        : nullptr;
+    p.cmax = ix.cnorm_max;
+    p.xmax = ix.xnorm_max;
+    p.c_canon = 1.05 * 32.0 * ldexp(1.0, -24);
     p.Y = reinterpret_cast<const float4 *>(ix.vecs.p);
     p.ids = ix.row_ids.p;
     p.list_off = ix.list_off.p;

@@ -970,6 +970,38 @@ def test_few_query_path_equals_general_path_and_oracle(metric, d, opt):
             same(oi_t[:nq].cpu().numpy(), od_t[:nq].cpu().numpy(), hi, hd)
 
 
+def test_few_query_path_radius_pruning_keeps_the_oracle_result(opt):
+    """One or two queries per call on an L2 index: stage 1's last block drops the probed lists that the list radius rules out
+    ((||q - c_l|| - r_l)^2 beyond the smallest (||q - c_p|| + r_p)^2 over probed lists of >= k rows) and cuts stage 2's work from
+    the survivors.  Well separated blobs (almost every probe goes), lists shorter than k (they give no bound), k larger than any
+    list, a query in the middle of nowhere, duplicates of a row across lists: == the unpruned path == the oracle, bit for bit."""
+    rng = np.random.default_rng(4242)
+    d, nlist = 96, 64
+    centres = 6.0 * rng.standard_normal((nlist, d), dtype=np.float32)
+    sizes = rng.integers(200, 900, nlist)
+    sizes[5], sizes[9] = 3, 0  # a list shorter than k, an empty one
+    x = np.concatenate([centres[i] + rng.standard_normal((int(sizes[i]), d), dtype=np.float32) for i in range(nlist)]).astype(np.float32)
+    x[10:14] = x[len(x) - 1]  # the same row in several lists
+    q = (centres[rng.integers(0, nlist, 6)] + rng.standard_normal((6, d), dtype=np.float32)).astype(np.float32)
+    q[4] = centres[5] + 0.1 * rng.standard_normal(d).astype(np.float32)  # sits on the 3-row list
+    q[5] = 40.0 * rng.standard_normal(d).astype(np.float32)  # far from everything
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=%d" % nlist)
+    ix.set_centroids(centres)
+    ix.add(x)
+    ix.build()
+    opt("lat_path", "2")
+    for k, nprobe in ((10, 16), (1, 64), (64, 8), (10, 1)):
+        oi, od, _ = oracle_on_exported(ix, q, nprobe, k, capi.METRIC_L2)
+        for nq0 in range(0, 6, 2):
+            for nqc in (1, 2):
+                for lp in ("1", "0"):
+                    opt("lat_prune", lp)
+                    ids, dis = ix.search(q[nq0:nq0 + nqc], k, "nprobe=%d" % nprobe)
+                    same(ids, dis, oi[nq0:nq0 + nqc], od[nq0:nq0 + nqc])
+    opt("lat_prune", None)
+    opt("lat_path", None)
+
+
 @pytest.mark.parametrize("lat_select", ["1", "0"])
 def test_few_query_path_probe_ties_are_broken_by_centroid_id(lat_select, opt):
     """A zero query under inner product is equally far from every centroid: the probe list is the nprobe smallest centroid

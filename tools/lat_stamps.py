@@ -1,13 +1,13 @@
 import os, sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import myscaledb_amd.capi as capi
-from bench import make_data, make_queries
+from bench import data_model, ivf_params
 dev = torch.device("cuda", 0)
 n, d, nlist, nprobe, k = 1_000_000, 768, 1024, 32, 10
-model, x = make_data(n, d, 1234, dev)
-ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, "ncentroids=1024,kmeans_iters=10,train_sample=65536")
+x, qd, _ = data_model(os.environ.get("LAT_DATA", "blobs03"), n, 256, d, dev)
+ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, ivf_params(nlist, n))
 ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE); ix.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE); ix.build()
-qh = make_queries(model, 256, 777, dev).cpu().numpy()
+qh = qd.cpu().numpy()
 out = (C.c_ulonglong * 16)()
 capi.lib().msvs_lat_debug(out)
 acc = np.zeros(9)
