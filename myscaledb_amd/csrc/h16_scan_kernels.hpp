@@ -820,13 +820,15 @@ struct H16Prune
 {
     const uint32_t * coarse_words; // [nq][npad]: the coarse pass's approximate distance word of every centroid; nullptr: ...
     uint32_t npad;
+    const float * probe_dis;       // pre-pruning only: [nq][nprobe] CANONICAL distances of the probes' centroids (the canonical coarse scan of
+                                   // a small batch: merge_kernel) instead of approximate words -- no query norms needed
     const uint32_t * probe_words;  // ... or [nq][nprobe]: the same words gathered per probe (a sharded search: the coarse pass of a
                                    // query ran on another rank and its words came with the probe lists); both nullptr: no pruning
     const float * radius; // [nlist]
     const float * cnorm;  // [nlist] |c_l|^2 (cosine form only)
     int ip;               // 0: L2 index; 1: cosine index (unit rows and queries, the scan ranks by inner product); 2: inner-product
                           // index: <q, x> = <q, c> + <q, x - c> <= <q, c> + |q| r_l (Cauchy-Schwarz)
-    __host__ __device__ bool on() const { return coarse_words || probe_words; }
+    __host__ __device__ bool on() const { return coarse_words || probe_words; } // (the second stage: it needs the words)
     const float * qnorm;  // |q|^2 (+inf: unusable)
     float xmax, cmax;     // max |x|^2 over the rows / the centroids
     double c_dot, c_norm, c_canon; // the shadow passes' error model
@@ -852,27 +854,62 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
     if (q >= nq)
         return;
     const int32_t l = lane < nprobe ? probes[(size_t)q * nprobe + lane] : -1;
-    const uint32_t cw = l >= 0 ? (pr.probe_words ? pr.probe_words[(size_t)q * nprobe + lane] : pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l])
-                               : 0xFFFFFFFFu;
-    const float qn = pr.qnorm[q];
-    const bool usable = qn < 1e30f && pr.xmax < 1e30f && pr.cmax < 1e30f;
     double ub = 1e300, lb = 0.0; // this probe's upper bound of the k-th distance; lower bound of its rows' distances
-    if (usable && l >= 0 && cw != 0xFFFFFFFFu)
+    double sq = 0.0;             // an upper bound of |q|
+    bool usable = pr.xmax < 1e30f && pr.cmax < 1e30f;
+    const double sc = sqrt((double)pr.cmax * 1.001);
+    if (pr.probe_dis)
     {
-        const double sq = sqrt((double)qn * 1.001), sc = sqrt((double)pr.cmax * 1.001);
-        const double eps_c = 2.0 * pr.c_dot * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
-        const double ac = (double)ord2f(cw), r = (double)pr.radius[l];
-        const double hi2 = ac + 2.0 * eps_c, lo2 = ac - 2.0 * eps_c;
-        if ((uint64_t)(list_off[l + 1] - list_off[l]) >= pr.k && r == r && hi2 == hi2)
+        // canonical centroid distances: their rounding is all there is to widen; |q| <= ||q - c|| + |c| (the nearest probe's)
+        const double dc2 = l >= 0 ? (double)pr.probe_dis[(size_t)q * nprobe + lane] : 1e300;
+        double mn = dc2 == dc2 ? dc2 : 1e300;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
         {
-            const double hi = sqrt(hi2 > 0.0 ? hi2 : 0.0) * (1.0 + 1e-7) + r;
-            ub = hi * hi * (1.0 + 1e-7);
+            const double other = __shfl_xor(mn, o);
+            mn = other < mn ? other : mn;
         }
-        if (lo2 > 0.0)
+        usable = usable && mn < 1e30 && mn >= 0.0;
+        sq = usable ? sqrt(mn) + sc : 0.0;
+        if (usable && l >= 0 && dc2 == dc2 && dc2 >= 0.0 && dc2 < 1e30)
         {
-            const double lo = sqrt(lo2) * (1.0 - 1e-7);
-            if (lo > r)
-                lb = (lo - r) * (lo - r) * (1.0 - 1e-7);
+            const double eps_c = (pr.c_canon + 4e-7) * (sqrt(dc2) + 2.0 * sc) * (sqrt(dc2) + 2.0 * sc) + 1e-30, r = (double)pr.radius[l];
+            if ((uint64_t)(list_off[l + 1] - list_off[l]) >= pr.k && r == r)
+            {
+                const double hi = sqrt(dc2 + eps_c) * (1.0 + 1e-7) + r;
+                ub = hi * hi * (1.0 + 1e-7);
+            }
+            if (dc2 - eps_c > 0.0)
+            {
+                const double lo = sqrt(dc2 - eps_c) * (1.0 - 1e-7);
+                if (lo > r)
+                    lb = (lo - r) * (lo - r) * (1.0 - 1e-7);
+            }
+        }
+    }
+    else
+    {
+        const uint32_t cw = l >= 0 ? (pr.probe_words ? pr.probe_words[(size_t)q * nprobe + lane] : pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l])
+                                   : 0xFFFFFFFFu;
+        const float qn = pr.qnorm[q];
+        usable = usable && qn < 1e30f;
+        sq = sqrt((double)qn * 1.001);
+        if (usable && l >= 0 && cw != 0xFFFFFFFFu)
+        {
+            const double eps_c = 2.0 * pr.c_dot * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
+            const double ac = (double)ord2f(cw), r = (double)pr.radius[l];
+            const double hi2 = ac + 2.0 * eps_c, lo2 = ac - 2.0 * eps_c;
+            if ((uint64_t)(list_off[l + 1] - list_off[l]) >= pr.k && r == r && hi2 == hi2)
+            {
+                const double hi = sqrt(hi2 > 0.0 ? hi2 : 0.0) * (1.0 + 1e-7) + r;
+                ub = hi * hi * (1.0 + 1e-7);
+            }
+            if (lo2 > 0.0)
+            {
+                const double lo = sqrt(lo2) * (1.0 - 1e-7);
+                if (lo > r)
+                    lb = (lo - r) * (lo - r) * (1.0 - 1e-7);
+            }
         }
     }
     double U = ub;
@@ -883,12 +920,10 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
         U = other < U ? other : U;
     }
     bool keep = true;
+    const double sx = sqrt((double)pr.xmax * 1.001);
+    const double slack = 2.0 * (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30; // canonical vs real distance, both sides
     if (usable && l >= 0 && U < 1e299)
-    {
-        const double sq = sqrt((double)qn * 1.001), sx = sqrt((double)pr.xmax * 1.001);
-        const double slack = 2.0 * (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30; // canonical vs real distance, both sides
         keep = !(lb > U + slack);
-    }
     if (lane < nprobe)
         out_probes[(size_t)q * nprobe + lane] = keep ? l : -1;
     if (pr.upre && lane == 0)
@@ -896,8 +931,7 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
         float u = __uint_as_float(0x7f800000u);
         if (usable && U < 1e299)
         {
-            const double sq = sqrt((double)qn * 1.001), sx = sqrt((double)pr.xmax * 1.001);
-            const double v = U + 2.0 * (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30;
+            const double v = U + slack;
             u = v < 3.0e38 ? (float)v : u;
             if ((double)u < v)
                 u = nextafterf(u, __uint_as_float(0x7f800000u));

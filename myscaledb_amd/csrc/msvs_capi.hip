@@ -403,7 +403,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + nq * nprobe * 4
         + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768
         + (4 * ix.nlist + 18) * 4 + 1024 + 1024 // the list scan's counters taken up front, the padded query images
-        + 3 * nq * nprobe * 4 + nq * 4 + 2 * (ix.nlist + 1) * 4 + 4096 // probe pruning: surviving probes (two stages), the second plan
+        + 4 * nq * nprobe * 4 + nq * 4 + 2 * (ix.nlist + 1) * 4 + 8192 // probe pruning: surviving probes (two stages), the second plan
         + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 8192 : 0);
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
@@ -440,6 +440,8 @@ struct H16Queries
     const uint32_t * coarse_words = nullptr; // out: the coarse pass's approximate distance word of every (query, centroid) ...
     uint32_t coarse_npad = 0;                // ... [nq][coarse_npad]: what the probe pruning of the list scan reads
     const uint32_t * probe_words = nullptr;  // or, a sharded search: the words of the given probes, [nq][nprobe] (ProbeWords::given)
+    const float * probe_dis = nullptr;       // or, a small batch: canonical distances of the probes from the canonical coarse scan
+    float * upre = nullptr;                  // the pre-pruning's bound per query (h16_preprune_kernel), for the list scan's second stage
 };
 
 struct TablePass
@@ -993,34 +995,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
 {
     const uint32_t ld = ix.ld;
     // work item = (list, tile of 32 * h_ncb probing queries); main launch: rows [list_off + 32, end), sample launch: block 0
-    // pre-pruning by the list radius alone (h16_preprune_kernel): L2 indexes whose coarse pass left its distance words behind, no
-    // filter (a list must be known to hold k rows the query may take)
-    const int32_t * plan_probes = d_probes; // the probes the shadow pass works on; the canonical fallback keeps d_probes
-    H16Prune pr0{};
-    if (options().h16_prune != 0 && options().h16_preprune != 0 && ix.metric == MSVS_METRIC_L2 && !d_alive && ix.list_radius.p
-        && (prepared.coarse_words || prepared.probe_words) && prepared.qnorm && nprobe <= 64 && k <= 128)
-    {
-        RerankParams em{};
-        set_error_model_h16(em, ix.dim);
-        pr0.coarse_words = prepared.coarse_words;
-        pr0.npad = prepared.coarse_npad;
-        pr0.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
-        pr0.radius = ix.list_radius.p;
-        pr0.qnorm = prepared.qnorm;
-        pr0.xmax = ix.xnorm_max;
-        pr0.cmax = ix.cnorm_max;
-        pr0.c_dot = em.c_dot;
-        pr0.c_norm = em.c_norm;
-        pr0.c_canon = em.c_canon;
-        pr0.k = k;
-        pr0.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
-        int32_t * probes1 = scr.take<int32_t>(nq * nprobe);
-        pr0.upre = scr.take<float>(nq);
-        ProfileScope prof("ivf_plan", stream);
-        hipLaunchKernelGGL(h16_preprune_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, d_probes, pr0, ix.list_off.p,
-                           (uint32_t)nq, (uint32_t)nprobe, probes1);
-        plan_probes = probes1;
-    }
+    const int32_t * plan_probes = d_probes; // (pre-pruned by the caller where that applies: index_search_device_one)
     IvfPlanParams pp{};
     pp.probes = plan_probes;
     pp.list_off = ix.list_mid32.p;
@@ -1149,7 +1124,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
                 pr.c_canon = em.c_canon;
                 pr.k = k;
                 pr.out_probes = scr.take<int32_t>(nq * nprobe);
-                pr.upre = pr0.upre; // (null without the pre-pruning)
+                pr.upre = prepared.upre; // (null without the pre-pruning)
                 pr.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
             }
             hipLaunchKernelGGL(h16_sample_thr_wave_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
@@ -1402,6 +1377,12 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         MergeParams co{};
         co.mode = 1;
         co.out_probes = d_probes;
+        if (!probes_only && ix.metric == MSVS_METRIC_L2 && options().h16_preprune != 0)
+        {
+            float * pd = scr.take<float>(nq * nprobe);
+            co.out_probe_dis = pd;
+            prepared.probe_dis = pd;
+        }
         flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co,
                            stream);
     }
@@ -1420,6 +1401,43 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     }
     if (given_probes)
         prepared.probe_words = words.given;
+    // 1b. pre-pruning by the list radius alone (h16_preprune_kernel): L2 indexes, unfiltered searches over the stored lists, whenever
+    // the coarse stage left distances behind -- approximate words (centroid shadow; a sharded search's probe words) or the canonical
+    // values of a small batch.  What it drops is gone for every path below, the canonical ones and the fallbacks included.
+    const int32_t * all_probes = d_probes;
+    (void)all_probes;
+    if (options().h16_prune != 0 && options().h16_preprune != 0 && ix.metric == MSVS_METRIC_L2 && !d_alive && !view && ix.list_radius.p
+        && nprobe <= 64 && nprobe >= 2 && ix.cnorm_max < 1e30f && ix.xnorm_max < 1e30f
+        && (prepared.probe_dis || ((prepared.coarse_words || prepared.probe_words) && prepared.qnorm)))
+    {
+        RerankParams em{};
+        set_error_model_h16(em, ix.dim);
+        H16Prune pr0{};
+        if (prepared.coarse_words || prepared.probe_words)
+        {
+            pr0.coarse_words = prepared.coarse_words;
+            pr0.npad = prepared.coarse_npad;
+            pr0.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
+            pr0.qnorm = prepared.qnorm;
+        }
+        else
+            pr0.probe_dis = prepared.probe_dis;
+        pr0.radius = ix.list_radius.p;
+        pr0.xmax = ix.xnorm_max;
+        pr0.cmax = ix.cnorm_max;
+        pr0.c_dot = em.c_dot;
+        pr0.c_norm = em.c_norm;
+        pr0.c_canon = em.c_canon;
+        pr0.k = k;
+        pr0.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
+        pr0.upre = scr.take<float>(nq);
+        int32_t * probes1 = scr.take<int32_t>(nq * nprobe);
+        ProfileScope prof("ivf_plan", stream);
+        hipLaunchKernelGGL(h16_preprune_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, d_probes, pr0, ix.list_off.p,
+                           (uint32_t)nq, (uint32_t)nprobe, probes1);
+        prepared.upre = pr0.upre;
+        d_probes = probes1;
+    }
     // 2. scan the probed lists
     if (nq * nprobe > 0x7fffffffull)
         fail(MSVS_ERR_INVALID_ARGUMENT, "nq * nprobe too large for one call");

@@ -1068,6 +1068,7 @@ struct MergeParams
     int64_t * out_ids;    // [nq][k] (mode 0)
     float * out_dis;      // [nq][k] (mode 0)
     int32_t * out_probes; // [nq][k] (mode 1)
+    float * out_probe_dis = nullptr; // nullable [nq][k] (mode 1): the keys' values -- the canonical distance of the query to every probe
     uint64_t * out_keys;  // [nq][k] (mode 2: keep keys, for multi-level merges)
     int mode;
     int cosine; // mode 0: report 1 - ip
@@ -1099,7 +1100,11 @@ __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams a)
             uint64_t key = outk[i];
             size_t o = (size_t)q * k + i;
             if (a.mode == 1)
+            {
                 a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
+                if (a.out_probe_dis)
+                    a.out_probe_dis[o] = key_value<METRIC>(key);
+            }
             else if (a.mode == 2)
                 a.out_keys[o] = key;
             else
@@ -1136,7 +1141,11 @@ __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams a)
         uint64_t key = merged[i];
         size_t o = (size_t)q * k + i;
         if (a.mode == 1)
+        {
             a.out_probes[o] = key == KEY_NONE ? -1 : (int32_t)(uint32_t)key;
+            if (a.out_probe_dis)
+                a.out_probe_dis[o] = key_value<METRIC>(key);
+        }
         else if (a.mode == 2)
             a.out_keys[o] = key;
         else
