@@ -180,7 +180,8 @@ def ivf_params(nlist, n_train, extra=""):
 def oracle_on_index_lists(ix, q, nprobe, k, metric, threads=8):
     """The parity oracle on what the queries touch, for an index too large to export whole: probes from the oracle's exact scan
     of the exported centroids, then the oracle's exact scan of the rows of the probed lists, exported list by list from the
-    index's own storage (msvs_index_export_list).  Test infrastructure: only the check legs of this script and tests/ call it."""
+    index's own storage (msvs_index_export_list); bulk: rows_by_id is called ONCE with every id (a source that is regenerated
+    rather than resident).  Test infrastructure: only the check legs of this script and tests/ call it."""
     from oracle import oracle as o
     om = {capi.METRIC_L2: o.METRIC_L2, capi.METRIC_IP: o.METRIC_IP, capi.METRIC_COSINE: o.METRIC_IP}[metric]
     cent, off, _, _ = ix.export(with_vecs=False)
@@ -206,7 +207,7 @@ def oracle_on_index_lists(ix, q, nprobe, k, metric, threads=8):
     return np.stack(out_i), np.stack(out_d)
 
 
-def probed_sub_index(ix, q, nprobe, metric, rows_by_id=None):
+def probed_sub_index(ix, q, nprobe, metric, rows_by_id=None, bulk=False):
     """What a query sample touches of an index too large to export whole, as the arrays the parity oracle and the SIMD baseline
     take: the centroid table complete, the probed lists' rows, every other list empty -- so a search of the sub-index with
     the same nprobe IS the search of the whole index for these queries.  The probes come from the oracle's exact scan of the
@@ -230,9 +231,12 @@ def probed_sub_index(ix, q, nprobe, metric, rows_by_id=None):
         ids[lo:hi] = lids[off[l]:off[l + 1]]
         if rows_by_id is None:
             vecs[lo:hi] = ix.export_list(l, hi - lo)[0]
-        else:
+        elif not bulk:
             r = rows_by_id(ids[lo:hi])
             vecs[lo:hi] = o.normalize_rows(r) if metric == capi.METRIC_COSINE else r
+    if rows_by_id is not None and bulk:
+        r = rows_by_id(ids)  # one call: a source that is regenerated rather than resident
+        vecs[:] = o.normalize_rows(r) if metric == capi.METRIC_COSINE else r
     return cent, sub_off, vecs, ids, qn, om
 
 
@@ -298,6 +302,23 @@ def profiled(fn, steps, families):
         out[f] = ms / steps if c else 0.0
     capi.profile_reset()
     return out
+
+
+def rows_read_per_step(fn, steps):
+    """Rows the shadow list scan's two launches READ per step (main launch: the lists with surviving pairs beyond block 0; sample
+    launch: block 0 of the lists probed after the pre-pruning), counted on the device by the plan kernels (msvs_debug_scan_rows
+    under rerank_stats): with the probe pruning the launches read less than the union of the probed lists, and the roofline
+    prices what moves."""
+    capi.set_option("rerank_stats", "1")
+    try:
+        r0 = capi.debug_scan_rows()
+        for i in range(steps):
+            fn(i)
+        torch.cuda.synchronize()
+        r1 = capi.debug_scan_rows()
+    finally:
+        capi.set_option("rerank_stats", None)
+    return ((r1[0] - r0[0]) + (r1[1] - r0[1])) / float(steps)
 
 
 SCAN_FAMILIES = ("ivf_scan", "ivf_sample_scan")
@@ -482,8 +503,9 @@ def main():
     # f32 row + its id, whatever the kernel actually reads.  This round's kernel reads an fp16 shadow of the rows
     # (2d B + 4 B norm) and re-ranks a few dozen f32 rows per query, so it moves about HALF the algorithmic bytes:
     # `achieved` can exceed what HBM delivered; moved_gbs / moved_frac price the bytes the launch really has to move.
+    rows_read = rows_read_per_step(step, n_prof) if cand_pass and world == 1 else rows_unique  # (N > 1: every rank reads its own share)
     bytes_alg = rows_unique * (4 * d + 4)
-    bytes_moved = rows_unique * (2 * d + 8) if cand_pass else bytes_alg
+    bytes_moved = rows_read * (2 * d + 8) if cand_pass else bytes_alg
     achieved = bytes_alg / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     moved_gbs = bytes_moved / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
@@ -506,7 +528,7 @@ def main():
         "kernel": "h16_scan_kernel + h16_sample_kernel (fp16-shadow MFMA candidate pass of the list scan; exact f32 re-rank + "
                   "certificate follow)" if cand_pass else "ivf_batched_scan_kernel / ivf_scan_kernel (canonical f32 scan)",
         "launch_ms": round(scan_ms, 4), "launches_per_step": 2 if fam["ivf_sample_scan"] else 1,
-        "bytes_per_launch": int(bytes_moved),
+        "bytes_per_launch": int(bytes_moved), "rows_read_per_step": int(rows_read), "rows_probed_union_per_step": int(rows_unique),
         "whole_step_gbs": round(bytes_moved / (step_ms * 1e-3) / 1e9, 1),
         "whole_step_frac": round(bytes_moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "non_scan_ms_per_step": round(step_ms - scan_ms, 4),
@@ -517,7 +539,7 @@ def main():
         "prefilter": [pf1[0] - pf0[0], pf1[1] - pf0[1]],
         "pruned_pair_fraction": round(pruned_frac, 4),
         "step_kernels_ms": {f: round(v, 4) for f, v in fam.items() if v},
-        "note": "achieved / frac = the bytes the two launches have to read -- union of the step's probed rows (the rows the reference's scan visits: every probed list, whatever the probe pruning keeps out of the main launch) x (2d + 8) B: the fp16 "
+        "note": "achieved / frac = the bytes the two launches READ -- the rows of the lists their plans hold (counted on the device: the probe pruning keeps lists out of them; rows_probed_union_per_step is what the reference's scan would visit) x (2d + 8) B: the fp16 "
                 "shadow row, its f32 norm and its id -- / (sample + main launch time, HIP events on the launch stream); "
                 "whole_step_* = the same bytes over the whole step; f32_equiv_* = the same rows x (4d + 4) B (SURVEY 8d's "
                 "per-row figure: credits bytes that never move, can exceed 1); traffic = FETCH_SIZE (x2, gfx950) + WRITE_SIZE of both "
@@ -605,11 +627,13 @@ def main():
             # bytes the path MOVES: the two-launch path reads f32 (3 MB of centroids + the probed rows + their ids), the canonical
             # batched scan f32 rows, the shadow pass fp16 rows + norms + ids
             shadow = bool(f2["ivf_sample_scan"])
-            by = u2 * (2 * d + 8) if shadow else u2 * (4 * d + 4) + (nlist * d * 4 if f2["lat_search"] else 0)
+            # the shadow pass: rows its launches read (pruning counted); the canonical paths read f32 rows of the lists they keep --
+            # not counted on the device, so no fraction is quoted for them once pruning may have thinned the probes
+            by = rows_read_per_step(step2, 8) * (2 * d + 8) if shadow else None
             res[str(b2)] = {"qps": round(b2 / dt2, 1), "ms_per_step": round(dt2 * 1e3, 4), "list_scan_ms": round(sc, 4),
-                            "hbm_frac": round(by / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
-                            "whole_step_hbm_frac": round(by / dt2 / 1e9 / HBM_PEAK_GBS, 4),
-                            "bytes_moved_per_step": int(by),
+                            "hbm_frac": round(by / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc and by else None,
+                            "whole_step_hbm_frac": round(by / dt2 / 1e9 / HBM_PEAK_GBS, 4) if by else None,
+                            "bytes_moved_per_step": int(by) if by else None, "rows_probed_union_per_step": int(u2),
                             "path": "two-launch (f32 rows)" if f2["lat_search"] else ("fp16-shadow pass" if shadow else "canonical (f32 rows)")}
         return res
 
@@ -731,9 +755,10 @@ def main():
             fo = profiled(istep, 4, STEP_FAMILIES)
             uni = sum(iix.scanned_rows(qi[j * B:(j + 1) * B].cpu().numpy(), npb)[2] for j in range(2)) / 2
             sc = fo["ivf_scan"] + fo["ivf_sample_scan"]
-            mv = uni * (2 * d + 8)
+            mv = rows_read_per_step(istep, 2) * (2 * d + 8)
             return {"nprobe": npb, "qps": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "list_scan_ms": round(sc, 4),
-                    "union_rows_per_step": int(uni), "roofline_frac": round(mv / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
+                    "union_rows_per_step": int(uni), "rows_read_per_step": int(mv / (2 * d + 8)),
+                    "roofline_frac": round(mv / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
                     "whole_step_frac": round(mv / dt / 1e9 / HBM_PEAK_GBS, 4),
                     "candidate_pass_queries": p1[0] - p0[0], "fallback_queries": p1[1] - p0[1],
                     "step_kernels_ms": {f: round(v, 4) for f, v in fo.items() if v}}
@@ -881,13 +906,14 @@ def main():
         f3 = profiled(cstep, 8, STEP_FAMILIES)
         uni = sum(cix.scanned_rows(qs[i * bq:(i + 1) * bq].cpu().numpy(), npb)[2] for i in range(8)) / 8
         sc = f3["ivf_scan"] + f3["ivf_sample_scan"]
+        rr = rows_read_per_step(cstep, 8)
         big["index"], big["model"], big["nprobe"] = cix, mdl, npb
         res = {"workload": "IVFFLAT (MSTG stand-in) %d x %d cosine, nlist=%d, nprobe=%d, batch %d, top-%d" % (nb, d, nl, npb, bq, k),
                "qps": round(bq / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "build_s": round(build_s, 1),
-               "union_rows_per_batch": int(uni), "list_scan_ms": round(sc, 4),
-               "roofline_frac": round(uni * (2 * d + 8) / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
-               "whole_step_frac": round(uni * (2 * d + 8) / dt / 1e9 / HBM_PEAK_GBS, 4),
-               "bytes_moved_per_batch": int(uni * (2 * d + 8)),
+               "union_rows_per_batch": int(uni), "rows_read_per_batch": int(rr), "list_scan_ms": round(sc, 4),
+               "roofline_frac": round(rr * (2 * d + 8) / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
+               "whole_step_frac": round(rr * (2 * d + 8) / dt / 1e9 / HBM_PEAK_GBS, 4),
+               "bytes_moved_per_batch": int(rr * (2 * d + 8)),
                "step_kernels_ms": {f: round(v, 4) for f, v in f3.items() if v}}
         if not args.no_cpu_baseline and "cpu" not in skip:
             # the SIMD CPU restatement on the lists a 16-query sample of one batch probes (exported from the index), repeated
@@ -944,10 +970,11 @@ def main():
             f4 = profiled(cstep, 4, STEP_FAMILIES)
             uni = sum(cix.scanned_rows(qs[j * bq:(j + 1) * bq].cpu().numpy(), npb)[2] for j in range(4)) / 4
             sc = f4["ivf_scan"] + f4["ivf_sample_scan"]
-            mv = uni * (2 * d4 + 8)
+            mv = rows_read_per_step(cstep, 4) * (2 * d4 + 8)
             res["batches"][str(bq)] = {
                 "qps": round(bq / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "list_scan_ms": round(sc, 4),
-                "union_rows_per_batch": int(uni), "roofline_frac": round(mv / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
+                "union_rows_per_batch": int(uni), "rows_read_per_batch": int(mv / (2 * d4 + 8)),
+                "roofline_frac": round(mv / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
                 "roofline_gbs": round(mv / (sc * 1e-3) / 1e9, 1) if sc else None,
                 "whole_step_frac": round(mv / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "candidate_pass_queries": p1[0] - p0[0], "fallback_queries": p1[1] - p0[1],
@@ -1010,10 +1037,10 @@ def main():
             ft = profiled(tstep, 4, STEP_FAMILIES)
             uni = sum(tix.scanned_rows(qs[j * bq:(j + 1) * bq].cpu().numpy(), npb)[2] for j in range(4)) / 4
             sc = ft["ivf_scan"] + ft["ivf_sample_scan"]
-            mv = uni * (2 * d1 + 8)
+            mv = rows_read_per_step(tstep, 4) * (2 * d1 + 8)
             res["batches"][str(bq)] = {
                 "qps": round(bq / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "list_scan_ms": round(sc, 4),
-                "union_rows_per_batch": int(uni), "bytes_moved_per_batch": int(mv),
+                "union_rows_per_batch": int(uni), "rows_read_per_batch": int(mv / (2 * d1 + 8)), "bytes_moved_per_batch": int(mv),
                 "roofline_frac": round(mv / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
                 "roofline_gbs": round(mv / (sc * 1e-3) / 1e9, 1) if sc else None,
                 "whole_step_frac": round(mv / dt / 1e9 / HBM_PEAK_GBS, 4),

@@ -688,6 +688,13 @@ def debug_prune_stats():
     return int(out[0]), int(out[1])
 
 
+def debug_scan_rows():
+    """(rows the shadow main launches read, rows their sample launches read), cumulative -- counted only under rerank_stats = 1."""
+    out = (C.c_uint64 * 2)()
+    _check(lib().msvs_debug_scan_rows(out))
+    return int(out[0]), int(out[1])
+
+
 def bm25_stats():
     """(queries through the sample / emit path, of which fallbacks)."""
     q, f = C.c_uint64(0), C.c_uint64(0)

@@ -578,6 +578,16 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
     run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, slots, stream);
 }
 
+/// Tests (msvs_debug_coarse_words): where this host thread's last centroid-shadow pass left its words (valid until the thread's
+/// next search on that stream).
+struct CoarseLast
+{
+    const uint32_t * words = nullptr;
+    uint32_t nq = 0, npad = 0;
+    hipStream_t stream = nullptr;
+};
+static thread_local CoarseLast g_coarse_last;
+
 static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, const float * dq, size_t nq,
                                  const TablePass & t, hipStream_t stream)
 {
@@ -704,6 +714,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
             {
                 t.h16_out->coarse_words = sample;
                 t.h16_out->coarse_npad = n_pad;
+                g_coarse_last = CoarseLast{sample, (uint32_t)nq, n_pad, stream};
             }
         }
         if (options().coarse_h16 != 2)
@@ -1025,7 +1036,17 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.list_end2 = ix.list_mid32.p;
     pp.T2 = 32 * sample_nqb;
     pp.work_off2 = scr.take<uint32_t>(ix.nlist + 1);
+    // (measurement: rows the two launches read -- the second pruning's plan, when there is one, is the main launch's)
+    const bool prune_pays = options().h16_prune == 2 || (double)nq * (double)nprobe > (double)ix.nlist * (double)pp.T;
+    const bool prune2 = options().h16_prune != 0 && prune_pays && (prepared.coarse_words || prepared.probe_words) && ix.list_radius.p && k <= 128
+        && nprobe <= 64 && options().wave_select != 0;
+    if (options().rerank_stats != 0)
+    {
+        pp.stat_rows = prefilter_fail_counter() + 10;
+        pp.stat_first = prune2 ? 0 : 1;
+    }
     launch_ivf_plan(pp, stream);
+    pp.stat_rows = nullptr;
     IvfPlanParams pa = pp;
     pa.work_off = pp.work_off2;
     // the queries' fp16 images: the coarse pass over the centroid shadow left them behind, or they are made here
@@ -1105,8 +1126,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             // distance behind; the surviving probes get their own plan for the main launch
             // ... when the lists are probed by more queries than one tile holds (then fewer pairs mean fewer passes over a list;
             // below that the second plan and the looser cut cost more than the dropped pairs save: sigma-0.3 blobs at nprobe 2)
-            const bool prune_pays = options().h16_prune == 2 || (double)nq * (double)nprobe > (double)ix.nlist * (double)pp.T;
-            if (options().h16_prune != 0 && prune_pays && (prepared.coarse_words || prepared.probe_words) && ix.list_radius.p && k <= 128)
+            if (prune2)
             {
                 RerankParams em{};
                 set_error_model_h16(em, ix.dim);
@@ -1147,6 +1167,11 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         p2.work_off = scr.take<uint32_t>(ix.nlist + 1);
         p2.pairs = scr.take<uint32_t>(nq * nprobe);
         p2.work_off2 = nullptr;
+        if (options().rerank_stats != 0)
+        {
+            p2.stat_rows = prefilter_fail_counter() + 10;
+            p2.stat_first = 1;
+        }
         launch_ivf_plan(p2, stream);
         pp.pairs = p2.pairs;
         pp.pair_off = p2.pair_off;
@@ -1795,6 +1820,20 @@ extern "C" __attribute__((visibility("default"))) int msvs_debug_rerank_stats(ui
     });
 }
 
+/// Measurement (not in msvs.h; needs rerank_stats = 1): rows of the lists the shadow list scan's launches read, cumulative --
+/// out2[0] = main launch (rows beyond block 0 of the lists with surviving pairs), out2[1] = sample launch (block 0 of the lists
+/// probed after the pre-pruning).  bench.py prices these: what the launches move, not what the reference's scan would visit.
+extern "C" __attribute__((visibility("default"))) int msvs_debug_scan_rows(uint64_t * out2)
+{
+    return guarded([&] {
+        unsigned long long v[2];
+        MSVS_HIP(hipDeviceSynchronize());
+        MSVS_HIP(hipMemcpy(v, prefilter_fail_counter() + 10, 16, hipMemcpyDeviceToHost));
+        out2[0] = v[0];
+        out2[1] = v[1];
+    });
+}
+
 /// Experiments / tests (not in msvs.h; needs rerank_stats = 1): (query, list) pairs the probe pruning dropped, pairs it looked at.
 extern "C" __attribute__((visibility("default"))) int msvs_debug_prune_stats(uint64_t * out2)
 {
@@ -1874,6 +1913,20 @@ extern "C" __attribute__((visibility("default"))) int msvs_debug_h16_stamps(uint
         *grid = g_h16_stamp_grid;
         if (words && cap_words >= words)
             MSVS_HIP(hipMemcpy(out, g_h16_stamps.p, words * 8, hipMemcpyDeviceToHost));
+    });
+}
+
+/// Tests only (not in msvs.h): the approximate distance words of this thread's last centroid-shadow coarse pass, [nq][npad]
+/// (ordered words: f2ord(distance) for L2, ~f2ord(inner product) otherwise; 0xFFFFFFFF past the last centroid).
+extern "C" __attribute__((visibility("default"))) int msvs_debug_coarse_words(uint32_t * out, size_t nq, size_t npad)
+{
+    return guarded([&] {
+        const CoarseLast & c = g_coarse_last;
+        if (!c.words || c.nq != nq || c.npad != npad)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "no coarse pass of %zu queries x %zu words on record (last: %u x %u)", nq, npad, c.nq, c.npad);
+        MSVS_HIP(hipStreamSynchronize(c.stream));
+        MSVS_HIP(hipMemcpy(out, c.words, nq * npad * 4, hipMemcpyDeviceToHost));
+        g_coarse_last = CoarseLast{};
     });
 }
 

@@ -584,6 +584,10 @@ struct IvfPlanParams
     uint32_t * work_off2 = nullptr; // [nlist+1]
     uint32_t * zero = nullptr;      // a region of 32-bit words the scan launch clears on the way (the consumer's counters), ...
     uint32_t nzero = 0;             // ... and its length
+    // measurement (option rerank_stats; nullable): += the rows of the lists that have pairs -- [0] in the first partition's row range
+    // (when stat_first), [1] in the second's: what the launches over this plan read
+    unsigned long long * stat_rows = nullptr;
+    int stat_first = 1;
 };
 
 static __global__ void ivf_hist_kernel(const IvfPlanParams p)
@@ -604,9 +608,12 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
     __shared__ uint32_t sw[2][1024];
     __shared__ uint32_t sv[2][1024];
     __shared__ uint32_t carry[3];
+    __shared__ unsigned long long s_rows[2];
     const uint32_t tid = threadIdx.x;
     if (tid < 3)
         carry[tid] = 0;
+    if (tid < 2)
+        s_rows[tid] = 0;
     for (uint32_t i = tid; i < p.nzero; i += 1024)
         p.zero[i] = 0;
     __syncthreads();
@@ -619,10 +626,14 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
             c = p.cnt[l];
             uint32_t len = (uint32_t)((p.list_end ? p.list_end[l] : p.list_off[l + 1]) - p.list_off[l]);
             w = ((c + p.T - 1) / p.T) * ((len + p.rows_per_block - 1) / p.rows_per_block);
+            if (p.stat_rows && c && p.stat_first)
+                atomicAdd(&s_rows[0], (unsigned long long)len);
             if (p.work_off2)
             {
                 const uint32_t len2 = (uint32_t)((p.list_end2 ? p.list_end2[l] : p.list_off2[l + 1]) - p.list_off2[l]);
                 v = ((c + p.T2 - 1) / p.T2) * ((len2 + p.rows_per_block - 1) / p.rows_per_block);
+                if (p.stat_rows && c)
+                    atomicAdd(&s_rows[1], (unsigned long long)len2);
             }
         }
         int cur = 0;
@@ -668,6 +679,11 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
         p.work_off[p.nlist] = carry[1];
         if (p.work_off2)
             p.work_off2[p.nlist] = carry[2];
+        if (p.stat_rows)
+        {
+            atomicAdd(p.stat_rows, s_rows[0]);
+            atomicAdd(p.stat_rows + 1, s_rows[1]);
+        }
     }
 }
 

@@ -14,7 +14,8 @@ import torch
 
 import myscaledb_amd.capi as capi
 import myscaledb_amd.host as mhost
-from bench import _latent_model, _sample, build_postings, ivf_params, make_data, make_queries, oracle_on_index_lists
+from bench import (_latent_model, _sample, build_postings, ivf_params, make_data, make_queries, oracle_on_index_lists,
+                   oracle_on_sub_index, probed_sub_index)
 from oracle import oracle as o
 
 pytestmark = pytest.mark.gpu
@@ -218,8 +219,8 @@ def test_c4_shape_ivfflat_ip_1536_eight_shards():
 def test_c4_one_gpu_share_12m5_rows_1536_ip_against_the_oracle():
     """One GPU's share of BASELINE config 4 at FULL size: 12.5M rows x 1536, inner product, 2048 lists (16384 / 8), 8 probes per
     query (64 / 8) -- bench.py's C4 leg.  A 1024-query batch through the candidate pass; 64 of its queries against the parity
-    oracle on the lists they probe (exported from the index's own 77 GB of rows list by list); whole-batch properties; a query
-    alone == inside the batch; and the register-tile kernel (two parts of the reduction dimension) returns the same bits."""
+    oracle on the lists they probe (exported from the index's own 77 GB of rows list by list) and 8 more on rows re-gathered from
+    the SOURCE generator by id; whole-batch properties; a query alone == inside the batch."""
     n, d, nlist, nprobe, k = 12_500_000, 1536, 2048, 8, 10
     dev = torch.device("cuda", 0)
     model = _latent_model(d, 99, dev, nlist)
@@ -256,6 +257,29 @@ def test_c4_one_gpu_share_12m5_rows_1536_ip_against_the_oracle():
     same(ids[:64], dis[:64], ei, ed)
     i1, d1 = ix.search(q[70:71], k, "nprobe=%d" % nprobe)
     same(i1, d1, ids[70:71], dis[70:71])
+
+    # ... and 8 queries against rows RE-GATHERED FROM THE SOURCE: the generator is run again, chunk by chunk with the seed the index
+    # was fed from, and the rows of the probed lists are picked out by their ids -- a row damaged on its way into the index's
+    # storage (add, assignment, list layout) would show up here, where the exported-list check above compares storage with itself
+    def regenerate(want):
+        order = np.argsort(want, kind="stable")
+        sw = want[order]
+        out = np.empty((len(want), d), np.float32)
+        gg = torch.Generator(device=dev).manual_seed(1234)
+        chunk = torch.empty((500_000, d), device=dev, dtype=torch.float32)
+        at = 0
+        for lo in range(0, n, 500_000):
+            _sample(model, 500_000, gg, dev, out=chunk)
+            hi = int(np.searchsorted(sw, lo + 500_000))
+            if hi > at:
+                out[order[at:hi]] = chunk[torch.from_numpy(sw[at:hi] - lo).to(dev)].cpu().numpy()
+                at = hi
+        assert at == len(want)
+        return out
+
+    sub = probed_sub_index(ix, q[100:108], nprobe, capi.METRIC_IP, rows_by_id=regenerate, bulk=True)
+    si, sd = oracle_on_sub_index(sub, nprobe, k, capi.METRIC_IP, threads=16)
+    same(ids[100:108], dis[100:108], si, sd)
     ix.close()
 
 

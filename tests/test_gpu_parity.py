@@ -1197,6 +1197,54 @@ def test_mfma_accumulation_error_bound_on_hardware(name, metric, d, opt):
     same(ids, dis, oi, od)
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP])
+@pytest.mark.parametrize("name", sorted(ADVERSARIAL))
+def test_centroid_shadow_error_bound_on_hardware(name, metric, opt):
+    """The probe pruning and the coarse band rest on the COARSE pass's words -- coarse_h16_kernel over the centroid table's fp16
+    shadow -- being within eps_c of the real centroid distances: |approximate - true| <= 2 c_dot |c||q| + c_norm (|c|^2 + |q|^2)
+    (L2), c_dot |c||q| (inner product), the constants of set_error_model_h16.  Reads the kernel's OWN words back
+    (msvs_debug_coarse_words) for adversarial centroids and queries and measures the ratio, like the row shadow's test above."""
+    import ctypes as C
+
+    d, nlist, nq, n = 200, 256, 256, 8192
+    rng = np.random.default_rng(sorted(ADVERSARIAL).index(name) * 31 + metric)
+    cent = ADVERSARIAL[name](rng, nlist, d).astype(np.float32)
+    q = ADVERSARIAL[name](rng, nq, d).astype(np.float32)
+    if name == "near_duplicates_of_the_queries":
+        q = (cent[:nq] + rng.standard_normal((nq, d)).astype(np.float32) * 1e-3).astype(np.float32)
+    # rows: the centroids' own magnitudes (the shadows share ONE scale taken from the rows: a centroid above it has no shadow)
+    x = (cent[rng.integers(0, nlist, n)] * np.float32(1.001)).astype(np.float32)
+    ix = capi.Index(capi.INDEX_IVFFLAT, metric, d, "ncentroids=%d" % nlist)
+    ix.set_centroids(cent)
+    ix.add(x)
+    ix.build()
+    c0 = capi.coarse_stats()
+    ids, dis = ix.search(q, 5, "nprobe=8")
+    assert capi.coarse_stats()[0] - c0[0] == nq, "the centroid-shadow pass did not run"
+    npad = (nlist + 31) // 32 * 32
+    words = np.zeros((nq, npad), np.uint32)
+    fn = capi.lib().msvs_debug_coarse_words
+    fn.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t]
+    assert fn(words.ctypes.data_as(C.POINTER(C.c_uint32)), nq, npad) == 0, capi.lib().msvs_last_error()
+    cd, cn, cc = C.c_double(), C.c_double(), C.c_double()
+    capi.lib().msvs_debug_error_model_h16.restype = None
+    capi.lib().msvs_debug_error_model_h16(C.c_size_t(d), C.byref(cd), C.byref(cn), C.byref(cc))
+    ip = metric != capi.METRIC_L2
+    c64, q64 = cent.astype(np.float64), q.astype(np.float64)
+    cnorm, qnorm = np.sqrt((c64 * c64).sum(1)), np.sqrt((q64 * q64).sum(1))
+    approx = _key_values(words[:, :nlist].reshape(-1), ip).astype(np.float64).reshape(nq, nlist)
+    if ip:
+        true = q64 @ c64.T
+        eps = cd.value * np.outer(qnorm, cnorm)
+    else:
+        true = (q64 * q64).sum(1)[:, None] + (c64 * c64).sum(1)[None, :] - 2.0 * (q64 @ c64.T)
+        eps = 2 * cd.value * np.outer(qnorm, cnorm) + cn.value * (qnorm[:, None] ** 2 + cnorm[None, :] ** 2)
+    worst = float((np.abs(approx - true) / (eps + 1e-300)).max())
+    assert worst < 1.0, "coarse words leave the certified band: max |approx - true| / eps_c = %.3f" % worst
+    oi, od, _ = oracle_on_exported(ix, q, 8, 5, metric)
+    same(ids, dis, oi, od)
+
+
 # ---------------------------------------------------------------------------------------- filters (PREWHERE -> bitmap, strategy)
 
 def test_filter_producers_match_numpy():
