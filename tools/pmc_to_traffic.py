@@ -4,7 +4,7 @@ which bench.py reports as roofline.traffic.  FETCH_SIZE is in KiB and, on gfx950
 wide coalesced streams: doubled (MI355X_MICROARCH.md, section HBM; calibrated in the same pass on gather_rows_kernel,
 which reads exactly rows x dim x 4 B).  WRITE_SIZE (KiB) is taken as is.  The list scan of a step is two launches
 (h16_sample_kernel, h16_scan_kernel): the per-step value is the sum of their per-launch means.
-Usage: tools/pmc_to_traffic.py <fetch.db> <write.db> <batch> <rows> <dim> <round tag>"""
+Usage: tools/pmc_to_traffic.py <fetch.db> <write.db> <batch> <rows> <dim> <round tag> [data model]"""
 import json
 import os
 import sqlite3
@@ -22,6 +22,7 @@ def mean(db, counter, kern):
 
 def main():
     fdb, wdb, batch, rows, dim, tag = sys.argv[1:7]
+    data = sys.argv[7] if len(sys.argv) > 7 else "blobs03"
     per = {}
     f_total = w_total = 0.0
     for kname in KERNELS:
@@ -33,7 +34,7 @@ def main():
     c = sqlite3.connect(fdb)  # the largest gather_rows_kernel call is the 1M-row list layout pass
     cal = list(c.execute("select max(value) from counters_collection where counter_name = 'FETCH_SIZE' and "
                          "kernel_name like '%gather_rows_kernel%'"))[0][0] or 0.0
-    out = {"round": tag, "kernels": per, "batch": int(batch), "rows": int(rows), "dim": int(dim),
+    out = {"round": tag, "data": data, "kernels": per, "batch": int(batch), "rows": int(rows), "dim": int(dim),
            "fetch_bytes_per_step": int(f_total * 2 * 1024), "write_bytes_per_step": int(w_total * 1024),
            "hbm_bytes_per_step": int(f_total * 2 * 1024 + w_total * 1024),
            "calibration": {"kernel": "gather_rows_kernel", "expected_bytes": int(rows) * int(dim) * 4,

@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import myscaledb_amd.capi as capi  # noqa: E402
-from bench import ivf_params, make_data, make_queries  # noqa: E402
+from bench import data_model, ivf_params  # noqa: E402
 
 
 def main():
@@ -21,12 +21,11 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     dev = torch.device("cuda", 0)
     n, d, nlist, nprobe, k = 1_000_000, 768, 1024, 32, 10
-    model, x = make_data(n, d, 1234, dev)
+    x, q, _ = data_model(os.environ.get("PMC_DATA", "blobs03"), n, 16 * B, d, dev)  # the headline's data model
     ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, d, ivf_params(nlist, n))
     ix.train(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
     ix.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
     ix.build()
-    q = make_queries(model, 16 * B, 4321, dev)
     oi = torch.empty((B, k), device=dev, dtype=torch.int64)
     od = torch.empty((B, k), device=dev, dtype=torch.float32)
     stream = torch.cuda.current_stream().cuda_stream
