@@ -104,6 +104,47 @@ __device__ __forceinline__ uint32_t pack_h2(const float a, const float b)
     return __builtin_bit_cast(uint32_t, t);
 }
 
+/// What the rounding really did to a table (round 4): rho = max over rows of |x' - x| / |x|, x' = fp16(x scale) / scale, as float
+/// bits (atomicMax; zeroed by the caller).  The dot product of two rounded vectors is off by <dx, q> + <x, dq> + <dx, dq>, at most
+/// (rho_x + rho_q + rho_x rho_q) |x||q| by Cauchy-Schwarz -- with the MEASURED rho of the stored rows and of the query image
+/// instead of the worst case 2^-11 per element each (a rounding error is uniform in its interval and relative to the element's
+/// binade: ~0.43 x 2^-11 in the root mean square over a row), the certificate's eps is less than half, still a proof
+/// (set_error_model_h16).  One wavefront per row; differences and sums in double.
+static __global__ __launch_bounds__(256) void h16_rho_kernel(const float * rows, size_t n, uint32_t ld, float scale, float inv_scale,
+                                                             uint32_t * rho_bits)
+{
+    const size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (r >= n)
+        return;
+    const float * src = rows + r * ld;
+    double num = 0.0, den = 0.0;
+    for (uint32_t e = lane * 4; e < ld; e += 256)
+    {
+        const float4 v = *reinterpret_cast<const float4 *>(src + e);
+        const float c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const float back = (float)(_Float16)(c[i] * scale) * inv_scale; // (powers of two: the products are exact)
+            const double dlt = (double)c[i] - (double)back;
+            num += dlt * dlt;
+            den += (double)c[i] * (double)c[i];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        num += __shfl_xor(num, o);
+        den += __shfl_xor(den, o);
+    }
+    if (lane == 0 && den > 0.0)
+    {
+        const float rho = (float)(sqrt(num / den) * 1.000001) ; // (double arithmetic + one rounding to float: far inside the margin)
+        atomicMax(rho_bits, __float_as_uint(rho > 0.f ? rho : 0.f));
+    }
+}
+
 /// f32 list-major rows -> shadow blocks; one thread per 16-byte piece.
 static __global__ void h16_build_kernel(const float * vecs, uint32_t ld, const int64_t * list_off,
                                         const uint32_t * blk_list, const uint32_t * hoff, uint32_t nks, float scale,
@@ -154,7 +195,7 @@ struct H16PrepAux
 
 static __global__ void h16_prep_queries_kernel(const float * Q, uint32_t nq, uint32_t ld, uint32_t nch,
                                                float inv_sx, int ip, uint4 * Qh, float2 * qinfo, float * qnorm, int compute_norm,
-                                               const H16PrepAux aux)
+                                               const H16PrepAux aux, float * qrho)
 {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     {
@@ -203,6 +244,7 @@ static __global__ void h16_prep_queries_kernel(const float * Q, uint32_t nq, uin
         sh = sh > 0 ? 100 : -100;
     }
     const float sq = ldexpf(1.f, sh), inv_sq = ldexpf(1.f, -sh);
+    double rnum = 0.0, rden = 0.0; // |q' - q|^2, |q|^2 of this lane's elements: the image's measured rounding error (h16_rho_kernel)
     for (uint32_t p = lane; p < nch * 8; p += 64)
     {
         const uint32_t k0 = p * 8;
@@ -211,8 +253,34 @@ static __global__ void h16_prep_queries_kernel(const float * Q, uint32_t nq, uin
             v0 = *reinterpret_cast<const float4 *>(src + k0);
         if (k0 + 4 < ld)
             v1 = *reinterpret_cast<const float4 *>(src + k0 + 4);
-        Qh[(size_t)q * nch * 8 + p] = make_uint4(pack_h2(v0.x * sq, v0.y * sq), pack_h2(v0.z * sq, v0.w * sq),
-                                                 pack_h2(v1.x * sq, v1.y * sq), pack_h2(v1.z * sq, v1.w * sq));
+        const uint4 img = make_uint4(pack_h2(v0.x * sq, v0.y * sq), pack_h2(v0.z * sq, v0.w * sq),
+                                     pack_h2(v1.x * sq, v1.y * sq), pack_h2(v1.z * sq, v1.w * sq));
+        Qh[(size_t)q * nch * 8 + p] = img;
+        if (qrho)
+        {
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            const float c[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const uint32_t w[4] = {img.x, img.y, img.z, img.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                const half2v h = __builtin_bit_cast(half2v, w[i >> 1]);
+                const double dlt = (double)c[i] - (double)((float)h[i & 1] * inv_sq);
+                rnum += dlt * dlt;
+                rden += (double)c[i] * (double)c[i];
+            }
+        }
+    }
+    if (qrho)
+    {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+        {
+            rnum += __shfl_xor(rnum, o);
+            rden += __shfl_xor(rden, o);
+        }
+        if (lane == 0) // (a query with non-finite or out-of-range elements is marked `bad` below and never certified)
+            qrho[q] = rden > 0.0 && !bad ? (float)(sqrt(rnum / rden) * 1.000001) : 0.f;
     }
     float qn = 0.f;
     if (compute_norm)
@@ -831,7 +899,12 @@ struct H16Prune
     __host__ __device__ bool on() const { return coarse_words || probe_words; } // (the second stage: it needs the words)
     const float * qnorm;  // |q|^2 (+inf: unusable)
     float xmax, cmax;     // max |x|^2 over the rows / the centroids
-    double c_dot, c_norm, c_canon; // the shadow passes' error model
+    double c_dot, c_norm, c_canon; // the shadow passes' error model: rows ...
+    double c_dot_c;                // ... and centroids (their table has its own measured rounding error: set_error_model_h16)
+    const float * qrho;            // nullable [nq]: the query image's measured rounding error, added as qrho_scale{,_c} * qrho[q]
+    double qrho_scale, qrho_scale_c;
+    __device__ double cd_x(uint32_t q) const { return qrho ? c_dot + qrho_scale * (double)qrho[q] : c_dot; }
+    __device__ double cd_c(uint32_t q) const { return qrho ? c_dot_c + qrho_scale_c * (double)qrho[q] : c_dot_c; }
     uint32_t k;
     float * upre;              // nullable [nq]: h16_preprune_kernel leaves its upper bound of the query's k-th best (real) distance,
                                // slack included, rounded up (+inf: none); the second stage takes the smaller of its own bound and this
@@ -896,7 +969,7 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
         sq = sqrt((double)qn * 1.001);
         if (usable && l >= 0 && cw != 0xFFFFFFFFu)
         {
-            const double eps_c = 2.0 * pr.c_dot * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
+            const double eps_c = 2.0 * pr.cd_c(q) * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
             const double ac = (double)ord2f(cw), r = (double)pr.radius[l];
             const double hi2 = ac + 2.0 * eps_c, lo2 = ac - 2.0 * eps_c;
             if ((uint64_t)(list_off[l + 1] - list_off[l]) >= pr.k && r == r && hi2 == hi2)
@@ -1010,8 +1083,8 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
                 ; // no coarse value for this probe: kept
             else if (pr.ip == 0)
             {
-                const double eps_x = 2.0 * pr.c_dot * sx * sq + pr.c_norm * (sx * sx + sq * sq) + (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30;
-                const double eps_c = 2.0 * pr.c_dot * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
+                const double eps_x = 2.0 * pr.cd_x(q) * sx * sq + pr.c_norm * (sx * sx + sq * sq) + (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30;
+                const double eps_c = 2.0 * pr.cd_c(q) * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
                 const double ak = (double)ord2f(uw), ac = (double)ord2f(cw);
                 const double inner = ac - 2.0 * eps_c;
                 if (inner > 0.0)
@@ -1031,7 +1104,7 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
                 // value >= ipk, hence a canonical one >= ipk - eps_x: the k-th best canonical value of the query is at least that.
                 // A row x of list l has <q, x> = <q, c> + <q, x - c> <= <q, c> + |q| r_l, the coarse pass knows <q, c> to within
                 // eps_c (twice: approximate -> canonical -> real), a canonical value exceeds the real one by <= c_canon |x||q| <= eps_x
-                const double eps_x = (pr.c_dot + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.c_dot + pr.c_canon) * sc * sq + 1e-30;
+                const double eps_x = (pr.cd_x(q) + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.cd_c(q) + pr.c_canon) * sc * sq + 1e-30;
                 const double ipk = (double)ord2f(~uw), ipc = (double)ord2f(~cw);
                 const double ub = ipc + 2.0 * eps_c + sq * (double)pr.radius[l] * (1.0 + 1e-6);
                 keep = !(ub < ipk - 2.0 * eps_x);
@@ -1041,7 +1114,7 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
                 // cosine index: the words order inner products (larger is better).  ||q - c||^2 = |q|^2 + |c|^2 - 2 <q, c> from the
                 // coarse pass's <q, c> and the (f32, fma-accumulated: relative error c_norm) norms; a row x of the list has
                 // ||q - x|| >= ||q - c|| - r_l, i.e. <q, x> <= (|q|^2 + |x|^2 - (||q - c|| - r_l)^2) / 2
-                const double eps_x = (pr.c_dot + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.c_dot + pr.c_canon) * sc * sq + 1e-30;
+                const double eps_x = (pr.cd_x(q) + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.cd_c(q) + pr.c_canon) * sc * sq + 1e-30;
                 const double ipk = (double)ord2f(~uw), ipc = (double)ord2f(~cw);
                 const double cn = (double)pr.cnorm[l];
                 const double d2 = (double)qn * (1.0 - pr.c_norm) + cn * (1.0 - pr.c_norm) - 2.0 * (ipc + eps_c);

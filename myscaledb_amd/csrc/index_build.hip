@@ -18,9 +18,27 @@
 using namespace msvs;
 
 /// The fp16 shadow of an IVF index (see h16_scan_kernels.hpp); called once the final storage and the norms are in place.
+/// max |x' - x| / |x| over the rows of a table as the shadow stores them (h16_rho_kernel); < 0 when it cannot be measured.
+static float measure_shadow_rho(const float * rows, size_t n, uint32_t ld, float scale, float inv_scale, hipStream_t stream)
+{
+    if (n == 0)
+        return 0.f;
+    DevBuf<uint32_t> rb(1);
+    MSVS_HIP(hipMemsetAsync(rb.p, 0, 4, stream));
+    hipLaunchKernelGGL(h16_rho_kernel, dim3((unsigned)ceil_div(n, (size_t)4)), dim3(256), 0, stream, rows, n, ld, scale, inv_scale, rb.p);
+    MSVS_HIP(hipGetLastError());
+    uint32_t bits = 0;
+    MSVS_HIP(hipMemcpyAsync(&bits, rb.p, 4, hipMemcpyDeviceToHost, stream));
+    MSVS_HIP(hipStreamSynchronize(stream));
+    float rho;
+    memcpy(&rho, &bits, 4);
+    return rho >= 0.f && rho < 1.f ? rho : -1.f;
+}
+
 static void index_build_shadow(msvs_index & ix, hipStream_t stream)
 {
     ix.shadow_ready = false;
+    ix.h_rho = ix.c_rho = -1.f;
     if (ix.type == MSVS_INDEX_FLAT)
     {
         // a FLAT index is ONE list of n rows in id order: ceil(n / 32) blocks in the same operand layout (round 4): batches scan
@@ -68,6 +86,7 @@ static void index_build_shadow(msvs_index & ix, hipStream_t stream)
         }
         MSVS_HIP(hipGetLastError());
         MSVS_HIP(hipStreamSynchronize(stream));
+        ix.h_rho = measure_shadow_rho(ix.vecs.p, ix.n, ix.ld, ix.h_scale, ix.h_inv_scale, stream);
         ix.shadow_ready = true;
         return;
     }
@@ -131,6 +150,7 @@ static void index_build_shadow(msvs_index & ix, hipStream_t stream)
     }
     MSVS_HIP(hipGetLastError());
     MSVS_HIP(hipStreamSynchronize(stream));
+    ix.h_rho = measure_shadow_rho(ix.vecs.p, ix.n, ix.ld, ix.h_scale, ix.h_inv_scale, stream);
     ix.shadow_ready = true;
     // the centroid table in the same form (one list of nlist rows = G blocks), if it fits the rows' scale
     ix.c_shadow_ready = false;
@@ -168,6 +188,7 @@ static void index_build_shadow(msvs_index & ix, hipStream_t stream)
                            d_one_off.p, d_cblk.p, d_one_hoff.p, ix.h_nks, ix.h_scale, ix.c_shadow.p, (size_t)0, cpieces);
         MSVS_HIP(hipGetLastError());
         MSVS_HIP(hipStreamSynchronize(stream));
+        ix.c_rho = measure_shadow_rho(ix.centroids.p, ix.nlist, ix.ld, ix.h_scale, ix.h_inv_scale, stream);
         ix.c_shadow_ready = true;
     }
 }

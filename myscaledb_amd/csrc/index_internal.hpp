@@ -65,6 +65,7 @@ struct msvs_index
     DevBuf<int64_t> list_mid32; // nlist: end of block 0 of list l = min(list_off[l] + 32, list_off[l+1])
     uint32_t h_nks = 0, h_nch = 0;
     float h_scale = 0.f, h_inv_scale = 0.f; // stored value = fp16(x * h_scale)
+    float h_rho = -1.f, c_rho = -1.f; // measured max |x' - x| / |x| over the stored rows / the centroid shadow (h16_rho_kernel; < 0: unknown)
     bool shadow_ready = false;
     // fp16 shadow of the CENTROID table (same scale, same block layout: ceil(nlist / 32) blocks) for the coarse quantiser of
     // batches, and the G-lists-of-one-block view the sample kernel walks it through

@@ -949,6 +949,8 @@ struct RerankParams
     int cosine;
     // error model of the approximate pass (each times the experiment knob MSVS_IVF_EPS_SCALE):
     double c_dot;   // |approximate <x,q> - true| <= c_dot * |x||q|
+    const float * qrho; // nullable [nq] (fp16 shadow passes): ... <= (c_dot + qrho_scale * qrho[q]) * |x||q| -- the measured rounding
+    double qrho_scale;  //   error of the query's own image (set_error_model_h16)
     double c_norm;  // |approximate |v|^2 - true| <= c_norm * |v|^2
     double c_canon; // |canonical result - true| <= c_canon * (|x|+|q|)^2 (L2), * |x||q| (IP)
     float xmax;     // max |x|^2 over the index rows
@@ -966,10 +968,11 @@ struct RerankParams
 /// |approximate value - canonical value| <= eps for every row of the table and this query (sx, sq: upper bounds of |x|, |q|).
 /// L2: a = |x|^2 + |q|^2 - 2<x,q> with approximate norms and product; IP: a = <x,q>.
 template <int METRIC>
-__device__ __forceinline__ double rerank_eps(const RerankParams & a, double sx, double sq)
+__device__ __forceinline__ double rerank_eps(const RerankParams & a, double sx, double sq, uint32_t q)
 {
-    return (METRIC == M_L2 ? 2.0 * a.c_dot * sx * sq + a.c_norm * (sx * sx + sq * sq) + (a.c_canon + 4e-7) * (sx + sq) * (sx + sq)
-                           : (a.c_dot + a.c_canon) * sx * sq)
+    const double c_dot = a.qrho ? a.c_dot + a.qrho_scale * (double)a.qrho[q] : a.c_dot;
+    return (METRIC == M_L2 ? 2.0 * c_dot * sx * sq + a.c_norm * (sx * sx + sq * sq) + (a.c_canon + 4e-7) * (sx + sq) * (sx + sq)
+                           : (c_dot + a.c_canon) * sx * sq)
         + 1e-30;
 }
 
@@ -1029,7 +1032,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
         bool band_ok = usable;
         if (usable)
         {
-            eps2 = 2.0 * rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn * 1.001));
+            eps2 = 2.0 * rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn * 1.001), q);
             ak = (double)key_value<METRIC>(s_ak);
             ak1 = (double)key_value<METRIC>(s_ak1);
             uint64_t last = keys[kc - 1]; // the candidates' largest approximate value comes last; KEY_NONE: every row is a candidate
@@ -1115,7 +1118,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
                 {
                     const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
                     s_e = (double)key_value<METRIC>(s_ek);
-                    s_eps = rerank_eps<METRIC>(a, sx, sq);
+                    s_eps = rerank_eps<METRIC>(a, sx, sq, q);
                 }
             }
             __syncthreads();
@@ -1203,7 +1206,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
         {
             const double al = (double)key_value<METRIC>(last), e = (double)key_value<METRIC>(ek);
             const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
-            const double eps = rerank_eps<METRIC>(a, sx, sq);
+            const double eps = rerank_eps<METRIC>(a, sx, sq, q);
             ok = METRIC == M_L2 ? (al - eps > e) : (al + eps < e);
             if (a.stat_skip) // experiment: how many candidates an early exit could have skipped (approximate value beyond e_k +- eps)
             {
@@ -1283,7 +1286,7 @@ __global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams 
             if (have_hint)
             {
                 e0 = (double)key_value<METRIC>(hint);
-                eps0 = rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn0 * 1.001));
+                eps0 = rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn0 * 1.001), q);
             }
             for (uint32_t c = tid; c < ld4; c += 256)
                 qs[c] = a.Q[(size_t)q * ld4 + c];
@@ -1368,7 +1371,7 @@ __global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams 
                     {
                         const double al = (double)key_value<METRIC>((uint64_t)cutw << 32), e = (double)key_value<METRIC>(ek);
                         const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
-                        const double eps = rerank_eps<METRIC>(a, sx, sq);
+                        const double eps = rerank_eps<METRIC>(a, sx, sq, q);
                         good = METRIC == M_L2 ? (al - eps > e) : (al + eps < e);
                     }
                 }

@@ -396,7 +396,7 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
     size_t b = nq * (size_t)ix.ld * 4 + 2 * (nq * (size_t)(ix.ld + 32) * 4 + 4096) + 4096; // queries (+ split copies)
     if (ix.type == MSVS_INDEX_FLAT)
         return b + flat_scratch_bytes(ix.n, nq, k, ix.ld) + table_pass_scratch(ix.n, nq, std::min<uint32_t>(k, 40))
-            + (ix.shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + (size_t)H_FLAT_SAMPLE_BLK * H_ROWS * 4) + 8192 : 0); // shadow pass: query images, sample words
+            + (ix.shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 24 + (size_t)H_FLAT_SAMPLE_BLK * H_ROWS * 4) + 9216 : 0); // shadow pass: query images, sample words
     IvfSearchPlan p = plan_ivf(ix, nq, nprobe, k, allow_pass);
     size_t need = b + flat_scratch_bytes(ix.nlist, nq, (uint32_t)nprobe, ix.ld)
         + table_pass_scratch(ix.nlist, nq, (uint32_t)std::min<size_t>(nprobe, 40))
@@ -404,12 +404,12 @@ static size_t index_search_scratch(const msvs_index & ix, size_t nq, uint32_t k,
         + (5 * ix.nlist + 16 + nq * nprobe) * 4 + 32768
         + (4 * ix.nlist + 18) * 4 + 1024 + 1024 // the list scan's counters taken up front, the padded query images
         + 4 * nq * nprobe * 4 + nq * 4 + 2 * (ix.nlist + 1) * 4 + 8192 // probe pruning: surviving probes (two stages), the second plan
-        + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 16 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 8192 : 0);
+        + (ix.c_shadow_ready ? nq * ((size_t)ix.h_nch * 128 + 24 + round_up(ix.nlist, (size_t)H_ROWS) * 4 + ceil_div(ix.nlist, (size_t)H_ROWS) * 4) + 9216 : 0);
     if (p.mfma())
         need += nq * (p.h16 ? (size_t)p.h_cap : big_cand_cap(nprobe, p.seg_max)) * 8
             + nq * (size_t)p.kc * 8 + nq * 32 + 8192
             + fallback_cap(nq, nprobe, p.seg_max1, k) * nprobe * (size_t)p.seg_max1 * k * 8
-            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8 + 4) + 1024 + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
+            + (p.h16 ? nq * ((size_t)ix.h_nch * 128 + 8 + 4 + 4) + 2048 + nq * nprobe * H_ROWS * 4 + 4 * ix.nlist + 4096 : 0);
     else
         need += nq * nprobe * (size_t)p.seg_max * k * 8;
     return need;
@@ -435,6 +435,7 @@ struct H16Queries
     uint4 * qh = nullptr;
     float2 * qinfo = nullptr;
     float * qnorm = nullptr;
+    float * qrho = nullptr; // measured rounding error of every query's image (set_error_model_h16)
     uint32_t * counters = nullptr; // in: the list scan's counters, to be zeroed along the way (cleared flag: qh != nullptr)
     uint32_t n_counters = 0;
     const uint32_t * coarse_words = nullptr; // out: the coarse pass's approximate distance word of every (query, centroid) ...
@@ -460,6 +461,7 @@ struct TablePass
     int cosine;
     const char * prof_name;
     bool flat_h16 = false; // the table is a FLAT index with an fp16 shadow: candidates through h16_flat_kernel
+    float h16_rho = -1.f;  // measured rounding error of the table's shadow (set_error_model_h16; < 0: worst case)
     bool h16 = false; // the table is the centroid table and its fp16 shadow is usable: scan through h16_sample_kernel
     H16Queries * h16_out = nullptr; // h16: where the pass leaves the queries' fp16 images for the list scan that follows
 };
@@ -515,14 +517,14 @@ static void run_fallback_rounds(int metric, ScanParams c, IvfMergeParams fm, siz
     }
 }
 
-static void set_error_model_h16(RerankParams & rp, size_t dim);
+static void set_error_model_h16(RerankParams & rp, size_t dim, float rho_table = -1.f, const float * qrho = nullptr);
 
 /// Second half of a table pass, whatever produced the candidates: canonical re-rank + certificate, then the canonical scan
 /// of the table for the queries on the fail list.
 static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, const ScanParams & a, size_t nq, const float * qnorm,
                             const uint64_t * cand, const uint64_t * bound, uint32_t kc, uint32_t * failq, uint32_t * nfail,
                             uint64_t * partial1, size_t fb_cap, uint32_t rpb1, uint32_t seg_max1, const int32_t * probes0,
-                            const int64_t * list_off, bool h16, hipStream_t stream)
+                            const int64_t * list_off, bool h16, const float * qrho, hipStream_t stream)
 {
     RerankParams rp{};
     rp.Y = a.Y;
@@ -539,7 +541,7 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
     rp.out_dis = t.out_dis;
     rp.cosine = t.cosine;
     if (h16)
-        set_error_model_h16(rp, ix.dim);
+        set_error_model_h16(rp, ix.dim, t.h16_rho, qrho);
     else
         set_error_model(rp, ix.dim);
     rp.xmax = t.norm_max;
@@ -681,6 +683,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         const uint32_t G = (uint32_t)ceil_div(t.n, (size_t)H_ROWS), n_pad = G * H_ROWS;
         uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + 64); // + what the register-tile list scan may read past the end
         float2 * qinfo = scr.take<float2>(nq);
+        float * qrho = scr.take<float>(nq); // measured rounding error of every image (set_error_model_h16)
         float * qn16 = qnorm; // computed by the preparation kernel itself
         uint32_t * sample = scr.take<uint32_t>(nq * (size_t)n_pad);
         uint32_t * cpairs = scr.take<uint32_t>(nq * (size_t)G);
@@ -704,9 +707,10 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
             aux.nzero[0] = t.h16_out->n_counters;
         }
         hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq, (uint32_t)nq, ld,
-                           ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qn16, 1, aux);
+                           ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qn16, 1, aux, qrho);
         if (t.h16_out)
         {
+            t.h16_out->qrho = qrho;
             t.h16_out->qh = qh;
             t.h16_out->qinfo = qinfo;
             t.h16_out->qnorm = qn16;
@@ -759,7 +763,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
                            n_pad, kc, cand, bound, (int)options().wave_select);
         MSVS_HIP(hipGetLastError());
-        table_pass_tail(ix, m, t, a, nq, qn16, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true,
+        table_pass_tail(ix, m, t, a, nq, qn16, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true, qrho,
                         stream);
         return;
     }
@@ -771,6 +775,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         const uint32_t n_pad = gs * H_ROWS;
         uint4 * qh = scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + 64);
         float2 * qinfo = scr.take<float2>(nq);
+        float * qrho = scr.take<float>(nq);
         uint32_t * sample = scr.take<uint32_t>(nq * (size_t)n_pad);
         uint32_t * sched = scr.take<uint32_t>(8);
         H16PrepAux aux{};
@@ -786,7 +791,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         aux.zero[0] = sched;
         aux.nzero[0] = 8;
         hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq, (uint32_t)nq, ld,
-                           ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, aux);
+                           ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, aux, qrho);
         {
             const uint32_t items = (uint32_t)(ceil_div((size_t)gs, (size_t)2) * ceil_div(ceil_div(nq, (size_t)32), (size_t)2));
             const uint32_t cgrid = (uint32_t)std::min<size_t>(ceil_div((size_t)items, (size_t)4), (size_t)device_cu_count() * 2);
@@ -847,7 +852,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         h16_flat_dispatch(scan_metric(m), ncb, shape, fgrid, lds, h, f, stream);
         MSVS_HIP(hipGetLastError());
         launch_cand_select(candbuf, h.qcnt, h.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
-        table_pass_tail(ix, m, t, a, nq, qnorm, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true,
+        table_pass_tail(ix, m, t, a, nq, qnorm, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true, qrho,
                         stream);
         return;
     }
@@ -876,7 +881,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
                              (uint32_t)std::min<size_t>(tiles * ceil_div(t.n, (size_t)rpb), 4096 / nqg), a, stream,
                              "table_scan", false);
     launch_cand_select(candbuf, a.qcnt, a.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
-    table_pass_tail(ix, m, t, a, nq, qnorm, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, false,
+    table_pass_tail(ix, m, t, a, nq, qnorm, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, false, nullptr,
                     stream);
 }
 
@@ -888,13 +893,39 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
 ///   per-addition rounding we do not rely on: <= n 2^-23 sum|x'_i q'_i| <= 1.01 n 2^-23 |x||q|
 ///   (tests/test_gpu_parity.py::test_mfma_accumulation_error_bound_on_hardware measures it);
 /// c_norm / c_canon as in set_error_model (the norms and the canonical distance do not change).
-static void set_error_model_h16(RerankParams & rp, size_t dim)
+/// Round 4: the rounding term is MEASURED where it can be.  With dx = x' - x, dq = q' - q:
+///   |<x', q'> - <x, q>| = |<dx, q> + <x, dq> + <dx, dq>| <= (rho_x + rho_q + rho_x rho_q) |x||q|,  rho_x = max over the table's rows
+///   of |dx| / |x| (h16_rho_kernel at build: `rho_table`), rho_q = |dq| / |q| of the query's image (h16_prep_queries_kernel: `qrho`,
+///   added per query by rerank_eps / the cut kernels).  Rounding errors are uniform in their interval and relative to the element's
+///   binade, so rho ~ 0.43 u over a row of hundreds of elements where the worst case is u (+ the subnormal terms, which the
+///   measurement contains): eps drops to ~0.45 of the worst case and stays a proof.  rho_table < 0 or no qrho: the worst case.
+static void set_error_model_h16(RerankParams & rp, size_t dim, float rho_table, const float * qrho)
 {
     const double scale = 1.05 * options().ivf_eps_scale, dd = (double)round_up(dim, H_CHUNK);
-    rp.c_dot = scale * (ldexp(1.0, -10) + ldexp(1.0, -22) + 2.01 * sqrt(dd) * ldexp(1.0, -38) + dd * ldexp(1.0, -76)
-                        + 1.01 * dd * ldexp(1.0, -23));
+    const double rho_worst = ldexp(1.0, -11) + 2.01 * sqrt(dd) * ldexp(1.0, -38); // u |v| + the fp16 subnormal quantum per element
+    const bool measured = options().h16_rho != 0;
+    const double rho_x = measured && rho_table >= 0.f ? (double)rho_table : rho_worst;
+    rp.qrho = measured ? qrho : nullptr;
+    rp.qrho_scale = scale * (1.0 + rho_x);
+    rp.c_dot = scale * (rho_x + (rp.qrho ? 0.0 : rho_worst * (1.0 + rho_x)) + 1.01 * dd * ldexp(1.0, -23));
     rp.c_norm = scale * ((double)dim + 8.0) * ldexp(1.0, -24);
     rp.c_canon = scale * 32.0 * ldexp(1.0, -24);
+}
+
+/// The same model for the kernels that bound sample / centroid words (H16Prune): the rows' table and the centroid table each
+/// with its own measured rounding error.
+static void set_prune_error_model(H16Prune & pr, const msvs_index & ix, const float * qrho)
+{
+    RerankParams ex{}, ec{};
+    set_error_model_h16(ex, ix.dim, ix.h_rho, qrho);
+    set_error_model_h16(ec, ix.dim, ix.c_rho, qrho);
+    pr.c_dot = ex.c_dot;
+    pr.c_dot_c = ec.c_dot;
+    pr.c_norm = ex.c_norm;
+    pr.c_canon = ex.c_canon;
+    pr.qrho = ex.qrho;
+    pr.qrho_scale = ex.qrho_scale;
+    pr.qrho_scale_c = ec.qrho_scale;
 }
 
 template <int METRIC, int NCB>
@@ -1053,6 +1084,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     float * qnorm = prepared.qh ? prepared.qnorm : scr.take<float>(nq);
     uint4 * qh = prepared.qh ? prepared.qh : scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + 64); // + what the register kernel may read past the last image
     float2 * qinfo = prepared.qh ? prepared.qinfo : scr.take<float2>(nq);
+    float * qrho = prepared.qh ? prepared.qrho : scr.take<float>(nq);
     uint32_t * sample = scr.take<uint32_t>(nq * nprobe * H_ROWS);
     uint32_t * qstate = scr.take<uint32_t>(2 * nq);
     uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
@@ -1062,7 +1094,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     {
         ProfileScope prof("ivf_prep", stream);
         hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq,
-                           (uint32_t)nq, ld, ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, H16PrepAux{});
+                           (uint32_t)nq, ld, ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, H16PrepAux{}, qrho);
     }
     // (no fill of `sample`: the sample launch writes all 32 words of every pair whose list has rows, and the cut kernels
     // take a pair whose list is empty as 32 missing rows)
@@ -1114,7 +1146,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             if (options().h16_cut_floor != 0)
             {
                 RerankParams em{};
-                set_error_model_h16(em, ix.dim);
+                set_error_model_h16(em, ix.dim, ix.h_rho, nullptr);
                 fl.qnorm = qnorm;
                 fl.xmax = ix.xnorm_max;
                 fl.c_dot = em.c_dot;
@@ -1128,8 +1160,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             // below that the second plan and the looser cut cost more than the dropped pairs save: sigma-0.3 blobs at nprobe 2)
             if (prune2)
             {
-                RerankParams em{};
-                set_error_model_h16(em, ix.dim);
+                set_prune_error_model(pr, ix, qrho);
                 pr.coarse_words = prepared.coarse_words;
                 pr.npad = prepared.coarse_npad;
                 pr.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
@@ -1139,9 +1170,6 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
                 pr.qnorm = qnorm;
                 pr.xmax = ix.xnorm_max;
                 pr.cmax = ix.cnorm_max;
-                pr.c_dot = em.c_dot;
-                pr.c_norm = em.c_norm;
-                pr.c_canon = em.c_canon;
                 pr.k = k;
                 pr.out_probes = scr.take<int32_t>(nq * nprobe);
                 pr.upre = prepared.upre; // (null without the pre-pruning)
@@ -1215,7 +1243,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     rp.out_ids = d_ids;
     rp.out_dis = d_dis;
     rp.cosine = ix.metric == MSVS_METRIC_COSINE;
-    set_error_model_h16(rp, ix.dim);
+    set_error_model_h16(rp, ix.dim, ix.h_rho, qrho);
     rp.xmax = ix.xnorm_max;
     rp.failq = failq;
     rp.nfail = nfail;
@@ -1366,6 +1394,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
             t.out_dis = d_dis;
             t.cosine = ix.metric == MSVS_METRIC_COSINE;
             t.flat_h16 = ix.shadow_ready && options().flat_h16 != 0 && h16_lds_bytes(1, ix.h_nch) <= 160 * 1024;
+            t.h16_rho = ix.h_rho;
             t.prof_name = "flat_pass";
             table_candidate_pass(ix, scr, m, dq, nq, t, stream);
             g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
@@ -1387,6 +1416,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         TablePass t{};
         // the centroid shadow: every approximate distance of the batch in one LDS-free MFMA launch (h16_scan_kernels.hpp)
         t.h16 = ix.c_shadow_ready && options().coarse_h16 != 0 && nq * round_up(ix.nlist, (size_t)H_ROWS) * 4 <= ((size_t)128 << 20);
+        t.h16_rho = ix.c_rho;
         t.rows = ix.centroids.p;
         t.norms = ix.cnorm.p;
         t.norm_max = ix.cnorm_max;
@@ -1435,9 +1465,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         && nprobe <= 64 && nprobe >= 2 && ix.cnorm_max < 1e30f && ix.xnorm_max < 1e30f
         && (prepared.probe_dis || ((prepared.coarse_words || prepared.probe_words) && prepared.qnorm)))
     {
-        RerankParams em{};
-        set_error_model_h16(em, ix.dim);
         H16Prune pr0{};
+        set_prune_error_model(pr0, ix, prepared.qh ? prepared.qrho : nullptr);
         if (prepared.coarse_words || prepared.probe_words)
         {
             pr0.coarse_words = prepared.coarse_words;
@@ -1450,9 +1479,6 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         pr0.radius = ix.list_radius.p;
         pr0.xmax = ix.xnorm_max;
         pr0.cmax = ix.cnorm_max;
-        pr0.c_dot = em.c_dot;
-        pr0.c_norm = em.c_norm;
-        pr0.c_canon = em.c_canon;
         pr0.k = k;
         pr0.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
         pr0.upre = scr.take<float>(nq);
@@ -1939,4 +1965,19 @@ extern "C" __attribute__((visibility("default"))) void msvs_debug_error_model_h1
     *c_dot = rp.c_dot;
     *c_norm = rp.c_norm;
     *c_canon = rp.c_canon;
+}
+
+/// Tests only: the measured form of the same model for an index's rows (centroids = 0) or its centroid shadow (1): the table's rho,
+/// the coefficient of |x||q| without the query's share, and the factor of the query image's own rho (set_error_model_h16).
+extern "C" __attribute__((visibility("default"))) void msvs_debug_error_model_h16_measured(const msvs_index_t * ix, int centroids,
+                                                                                          double * rho_table, double * c_dot_table,
+                                                                                          double * qrho_scale)
+{
+    static const float one_query_rho = 0.f; // (any non-null pointer selects the per-query form)
+    RerankParams rp{};
+    const float rho = centroids ? ix->c_rho : ix->h_rho;
+    set_error_model_h16(rp, ix->dim, rho, &one_query_rho);
+    *rho_table = (double)rho;
+    *c_dot_table = rp.c_dot;
+    *qrho_scale = rp.qrho ? rp.qrho_scale : 0.0;
 }

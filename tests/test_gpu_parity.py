@@ -1192,6 +1192,42 @@ def test_mfma_accumulation_error_bound_on_hardware(name, metric, d, opt):
         ratio = np.abs(approx - true) / (eps + 1e-300)
         worst = max(worst, float(ratio.max()))
     assert worst < 1.0, "approximate keys leave the certified band: max |approx - true| / eps = %.3f" % worst
+    # round 4: the bound the certificate really uses -- the MEASURED rounding error of the stored rows (h16_rho_kernel, at build) and
+    # of each query image (h16_prep_queries_kernel) instead of 2^-11 per element: rho_x + rho_q + rho_x rho_q in place of 2^-10
+    rho_t, cdt, qsc = C.c_double(), C.c_double(), C.c_double()
+    capi.lib().msvs_debug_error_model_h16_measured.restype = None
+    capi.lib().msvs_debug_error_model_h16_measured(ix._h, C.c_int(0), C.byref(rho_t), C.byref(cdt), C.byref(qsc))
+    assert 0.0 <= rho_t.value < 2.0 ** -10 and qsc.value > 1.0
+
+    def image_rho(v32):  # max over rows of |fp16(v s) / s - v| / |v|, one power-of-two scale for the whole array (numpy rounds like the device)
+        mx = float(np.abs(v32).max())
+        if mx == 0.0:
+            return np.zeros(len(v32))
+        s_ = np.float32(2.0 ** (14 - np.frexp(np.float32(mx))[1]))
+        back = (v32 * s_).astype(np.float16).astype(np.float64) / float(s_)
+        v64 = v32.astype(np.float64)
+        den = np.sqrt((v64 * v64).sum(1))
+        return np.where(den > 0, np.sqrt(((v64 - back) ** 2).sum(1)) / np.maximum(den, 1e-300), 0.0)
+
+    rho_rows = image_rho(vecs)
+    assert rho_rows.max() <= rho_t.value * (1 + 1e-9) and rho_rows.max() >= rho_t.value * (1 - 1e-5), (rho_rows.max(), rho_t.value)
+    worst_m = 0.0
+    for qi in range(nq):
+        kk = keys[qi, :n]
+        pos = (kk & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        approx = _key_values((kk >> np.uint64(32)).astype(np.uint32), ip).astype(np.float64)
+        qn = np.sqrt((q64[qi] * q64[qi]).sum())
+        cdq = cdt.value + qsc.value * float(image_rho(q[qi:qi + 1])[0]) * 1.000001
+        if ip:
+            true = x64[pos] @ q64[qi]
+            eps = cdq * xn[pos] * qn
+        else:
+            diff = x64[pos] - q64[qi]
+            true = (diff * diff).sum(1)
+            eps = 2 * cdq * xn[pos] * qn + cn.value * (xn[pos] ** 2 + qn ** 2)
+        worst_m = max(worst_m, float((np.abs(approx - true) / (eps + 1e-300)).max()))
+    assert worst_m < 1.0, "approximate keys leave the MEASURED band: max |approx - true| / eps = %.3f" % worst_m
+    print("h16 error: %.3f of the worst-case bound, %.3f of the measured one (rho_x = %.3f u)" % (worst, worst_m, rho_t.value * 2048))
     # and the results are exact all the same
     oi, od, _ = oracle_on_exported(ix, q, nlist, 10, metric)
     same(ids, dis, oi, od)
