@@ -354,6 +354,8 @@ def main():
     ap.add_argument("--nlist", type=int, default=1024)
     ap.add_argument("--nprobe", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent batches in flight on one GPU: step i runs on HIP stream i %% streams (N = 1 only)")
     ap.add_argument("--data", default="blobs03", choices=("blobs03", "iid", "latent32"),
                     help="data model of the headline: SURVEY 8d's clustered variant (default), its iid one, or the 32-d latent mixture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -450,12 +452,21 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     out_ids = torch.empty((B, k), device=dev, dtype=torch.int64)
     out_dis = torch.empty((B, k), device=dev, dtype=torch.float32)
+    # --streams S: S independent batches in flight, each search on its own stream with its own result buffers (a server with S
+    # worker streams): the small launches around one batch's list scan run beside the other batch's scan
+    n_streams = max(1, args.streams) if world == 1 else 1
+    xs = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else []
+    xs_out = [(torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B, k), device=dev, dtype=torch.float32)) for _ in xs]
+    multi = {"on": False}
 
     def step(i):
         q = q_all[(i % n_pool) * B:(i % n_pool + 1) * B]
         if world > 1:
             # two batches in flight: batch i's top-k exchange + merge under batch i + 1's scan; fence() drains (device sync)
             ix.shard_search_device_async(comm, q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
+        elif multi["on"]:
+            s_ = i % n_streams
+            ix.search_device(q.data_ptr(), B, k, nprobe, xs_out[s_][0].data_ptr(), xs_out[s_][1].data_ptr(), xs[s_].cuda_stream)
         else:
             ix.search_device(q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
 
@@ -465,6 +476,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    multi["on"] = n_streams > 1
     for i in range(args.warmup):
         step(i)
     fence()
@@ -473,6 +485,7 @@ def main():
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    multi["on"] = False  # (the profiled passes below run one batch at a time on the current stream)
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1207,8 +1220,9 @@ def main():
                        "rows": n, "dim": d, "nlist": nlist, "nprobe": nprobe, "k": k, "batch": B,
                        "parallelism": ("lists %% %d, coarse quantiser by query, probe (+ coarse distance word) and packed top-k all-gathers, "
                                        "two batches in flight (msvs_shard_search_device_async); transport: %s"
-                                       % (world, comm_kind)) if world > 1 else "single GPU",
-                       "data_model": data_desc},
+                                       % (world, comm_kind)) if world > 1 else
+                                      ("single GPU" if n_streams == 1 else "single GPU, %d independent batches in flight on %d HIP streams" % (n_streams, n_streams)),
+                       "streams": n_streams, "data_model": data_desc},
             "recall_at_10": None if recall is None else round(recall, 4),
             "p50_ms_batch1": extra.get("latency", {}).get("p50_us", 0) / 1e3 if "latency" in extra and "p50_us" in extra["latency"] else None,
             "roofline": roof,

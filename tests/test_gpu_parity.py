@@ -732,6 +732,7 @@ def test_second_chance_rerank_of_the_whole_candidate_buffer(opt):
     ix = build_ivf(x, capi.METRIC_L2, blobs)
     oi, od, _ = oracle_on_exported(ix, q, nprobe, k, capi.METRIC_L2)
     opt("ivf_pass", "2")
+    opt("h16_rho", "0")  # the worst-case error model: with the measured one (round 4) most of these queries pass the first stage
     opt("rerank_second", "0")
     q0, f0 = capi.prefilter_stats()
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
