@@ -475,9 +475,30 @@ class Index:
     def memory_usage(self):
         return lib().msvs_index_memory_usage(self._h)
 
+    _search_fn = None  # msvs_index_search with integer-address argtypes (the unfiltered fast path below)
+
     def search(self, queries, k, params="", alive=None):
         q = _f32(queries).reshape(-1, self.dim)
         nq = q.shape[0]
+        if alive is None:
+            # host-pointer call without the per-argument ctypes pointer objects (1.8 us each: a third of the wrapper's overhead on a
+            # 40 us single-query call): one result block, raw addresses
+            fn = Index._search_fn
+            if fn is None:
+                fn = lib()["msvs_index_search"]
+                fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+                fn.restype = C.c_int
+                Index._search_fn = fn
+            out = np.empty(nq * k * 12, np.uint8)
+            base = C.addressof(C.c_char.from_buffer(out))
+            try:
+                qaddr = C.addressof(C.c_char.from_buffer(q))  # (0.3 us; .ctypes.data builds an interface object: 0.9 us)
+            except (TypeError, ValueError):  # read-only or empty array
+                qaddr = q.ctypes.data
+            rc = fn(self._h, qaddr, nq, k, params.encode(), None, 0, base, base + nq * k * 8)
+            if rc:
+                _check(rc)
+            return np.ndarray((nq, k), np.int64, out, 0), np.ndarray((nq, k), np.float32, out, nq * k * 8)
         ids = np.empty((nq, k), np.int64)
         dis = np.empty((nq, k), np.float32)
         bits, nbits = None, 0

@@ -173,6 +173,7 @@ struct Options
     double h16_nocut = 0;     // shadow pass: no sample cut, every probed row becomes a candidate (tests)
     double h16_ncb = 0;       // shadow pass: column blocks (32 queries each) per tile, 0 = planned
     double rerank_second = 1; // queries whose first certificate fails get their whole candidate buffer re-ranked before the canonical scan
+    double h16_segs = 1;      // shadow list scan: lists cut into row segments on the device so that a launch has ~4 items per workgroup; 0: one item per (list, tile)
     double h16_rho = 1;       // fp16 shadow passes: error bound from the MEASURED rounding error of the stored rows and of each query image; 0: the worst case per element
     double flat_h16 = 1;      // FLAT batches through the index's fp16 shadow (h16_flat_kernel); 0: the split-bf16 pass over the f32 rows; 3: one row block per wavefront
     double flat_ncb = 0;      // FLAT shadow pass: column blocks per tile (0: by batch size)

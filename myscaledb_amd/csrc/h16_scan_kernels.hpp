@@ -62,6 +62,7 @@ struct H16Params
     const uint32_t * pairs;   // (query, probe) pairs grouped by list (IvfPlanParams)
     const uint32_t * pair_off;
     const uint32_t * work_off;
+    const uint32_t * seg_blocks; // nullable (main launch): [0] = blocks per row segment chosen by the plan kernel (IvfPlanParams::seg_out)
     uint32_t nlist, nprobe, xcd_order;
     // main launch
     const uint32_t * qthr;    // [nq] cut (ordered distance word; 0xFFFFFFFF = none)
@@ -621,11 +622,21 @@ __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
         }
         const uint32_t l = lo;
         const int64_t lbeg = a.list_off[l], lend = a.list_off[l + 1];
-        const uint32_t tidx = w - a.work_off[l];
-        const uint32_t pe = a.pair_off[l + 1];
-        const uint32_t pb = a.pair_off[l] + tidx * TQ;
-        const uint32_t nvalid = pe - pb < TQ ? pe - pb : TQ;
         const uint32_t nblk = a.hoff[l + 1] - a.hoff[l];
+        const uint32_t pe = a.pair_off[l + 1], p0 = a.pair_off[l];
+        // item t of the list = (row segment, tile): the tiles of a segment are consecutive items (they meet in one XCD's L2)
+        const uint32_t t_in = w - a.work_off[l], ntiles = (pe - p0 + TQ - 1) / TQ;
+        const uint32_t seg = t_in / ntiles, tidx = t_in - seg * ntiles;
+        uint32_t b_first = 1, b_end = nblk; // (block 0 is the sample launch's)
+        if (a.seg_blocks)
+        {
+            const uint32_t nseg = plan_nseg(nblk - 1, a.seg_blocks[0]);
+            const uint32_t per = (nblk - 1 + nseg - 1) / nseg;
+            b_first = 1 + seg * per;
+            b_end = b_first + per < nblk ? b_first + per : nblk;
+        }
+        const uint32_t pb = p0 + tidx * TQ;
+        const uint32_t nvalid = pe - pb < TQ ? pe - pb : TQ;
         // column blocks this item needs, and the rows of its tile in LDS
         const uint32_t ncb_e = (nvalid + 31) >> 5;
         const uint32_t tq_e = 32 * ncb_e;
@@ -672,9 +683,8 @@ __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
             stamp[n_items * 4 + 3] = (uint64_t)l << 32 | nvalid << 8;
         }
         uint32_t * const stage = stage_s + wave * 3 * H_STAGE;
-        // block 0 is the sample launch's
 #define MSVS_H16_STREAM(N)                                                                                                         \
-    h16_stream<METRIC, N>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, a.hoff[l], 1 + wave, NW, nblk, lbeg, lend)
+    h16_stream<METRIC, N>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, a.hoff[l], b_first + wave, NW, b_end, lbeg, lend)
         if constexpr (NCB == 1)
             MSVS_H16_STREAM(1);
         else if (ncb_e == 1)

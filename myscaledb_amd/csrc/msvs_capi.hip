@@ -1058,6 +1058,10 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.pair_off = scr.take<uint32_t>(ix.nlist + 1);
     pp.work_off = scr.take<uint32_t>(ix.nlist + 1);
     pp.pairs = scr.take<uint32_t>(nq * nprobe);
+    // row segments of the main launch, sized on the device for ~4 items per workgroup of its grid (option h16_segs = 0: one item per (list, tile))
+    uint32_t * seg_words = options().h16_segs != 0 ? scr.take<uint32_t>(2) : nullptr;
+    pp.seg_out = seg_words;
+    pp.seg_target_items = 4 * device_cu_count();
     if (!zeroed)
         MSVS_HIP(hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), stream));
     // ... and the sample launch's partition of the same pairs: block 0 of every probed list, tiles of 32 queries (small
@@ -1194,6 +1198,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         p2.pair_off = scr.take<uint32_t>(ix.nlist + 1);
         p2.work_off = scr.take<uint32_t>(ix.nlist + 1);
         p2.pairs = scr.take<uint32_t>(nq * nprobe);
+        p2.seg_out = seg_words ? seg_words + 1 : nullptr;
         p2.work_off2 = nullptr;
         if (options().rerank_stats != 0)
         {
@@ -1204,12 +1209,14 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         pp.pairs = p2.pairs;
         pp.pair_off = p2.pair_off;
         pp.work_off = p2.work_off;
+        pp.seg_out = p2.seg_out;
         a.pairs = pp.pairs;
         a.pair_off = pp.pair_off;
     }
     {
         ProfileScope prof("ivf_scan", stream);
         a.work_off = pp.work_off;
+        a.seg_blocks = pp.seg_out;
         a.sched = sched + 8;
         {
             if (options().h16_stamps != 0)

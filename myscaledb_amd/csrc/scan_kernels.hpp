@@ -588,7 +588,22 @@ struct IvfPlanParams
     // (when stat_first), [1] in the second's: what the launches over this plan read
     unsigned long long * stat_rows = nullptr;
     int stat_first = 1;
+    // Row segments chosen ON THE DEVICE (the shadow list scan's main launch; nullable): the first partition's lists are cut into
+    // segments of ~seg_out[0] 32-row blocks so that the launch has about seg_target_items work items whatever survived the probe
+    // pruning -- a batch of 64 queries keeps ~64 lists, one item per list would leave three quarters of the CUs idle (plan_nseg)
+    uint32_t * seg_out = nullptr;
+    uint32_t seg_target_items = 0;
 };
+
+/// Segments of a list of `blocks` 32-row blocks at a segment size of sb blocks (rounded to the nearest count, at least one;
+/// an empty range has none), and the blocks per segment that go with it: shared by the plan kernel and the scan kernel.
+__host__ __device__ inline uint32_t plan_nseg(uint32_t blocks, uint32_t sb)
+{
+    if (blocks == 0)
+        return 0;
+    const uint32_t n = (blocks + sb / 2) / sb;
+    return n ? n : 1;
+}
 
 static __global__ void ivf_hist_kernel(const IvfPlanParams p)
 {
@@ -617,6 +632,31 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
     for (uint32_t i = tid; i < p.nzero; i += 1024)
         p.zero[i] = 0;
     __syncthreads();
+    uint32_t seg_blocks = 0; // (0: segments of rows_per_block rows as given)
+    if (p.seg_out)
+    {
+        // block-tiles of the whole launch -> blocks per segment for ~seg_target_items items, a multiple of 8 (one per wavefront)
+        __shared__ unsigned long long s_units;
+        if (tid == 0)
+            s_units = 0;
+        __syncthreads();
+        unsigned long long mine = 0;
+        for (uint32_t l = tid; l < p.nlist; l += 1024)
+        {
+            const uint32_t c = p.cnt[l];
+            const uint32_t len = (uint32_t)((p.list_end ? p.list_end[l] : p.list_off[l + 1]) - p.list_off[l]);
+            mine += (unsigned long long)((c + p.T - 1) / p.T) * ((len + 31) >> 5);
+        }
+        if (mine)
+            atomicAdd(&s_units, mine);
+        __syncthreads();
+        const unsigned long long per = (s_units + p.seg_target_items - 1) / (p.seg_target_items ? p.seg_target_items : 1);
+        seg_blocks = per >= 0x40000000ull ? 0x40000000u : (uint32_t)((per + 7) / 8 * 8);
+        if (seg_blocks < 8)
+            seg_blocks = 8;
+        if (tid == 0)
+            p.seg_out[0] = seg_blocks;
+    }
     for (uint32_t base = 0; base < p.nlist; base += 1024)
     {
         const uint32_t l = base + tid;
@@ -625,7 +665,7 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
         {
             c = p.cnt[l];
             uint32_t len = (uint32_t)((p.list_end ? p.list_end[l] : p.list_off[l + 1]) - p.list_off[l]);
-            w = ((c + p.T - 1) / p.T) * ((len + p.rows_per_block - 1) / p.rows_per_block);
+            w = ((c + p.T - 1) / p.T) * (seg_blocks ? plan_nseg((len + 31) >> 5, seg_blocks) : (len + p.rows_per_block - 1) / p.rows_per_block);
             if (p.stat_rows && c && p.stat_first)
                 atomicAdd(&s_rows[0], (unsigned long long)len);
             if (p.work_off2)
