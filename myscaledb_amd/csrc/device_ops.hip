@@ -523,7 +523,7 @@ void launch_ivf_rerank_all(int metric, const RerankParams & a, const RerankAllPa
         return;
     if (a.k > RA_KMAX)
         fail(MSVS_ERR_INVALID_ARGUMENT, "second-chance re-rank for k = %u", a.k);
-    const size_t lds = (size_t)a.ld4 * 16 + (2 * RA_KMAX + RA_CHUNK) * 8;
+    const size_t lds = (size_t)a.ld4 * 16 + (2 * RA_KMAX + RA_CHUNK) * 8 + RA_CHUNK * 4 + 16;
     ProfileScope prof("rerank", stream);
     const uint32_t grid = std::min<uint32_t>(nq, 2048); // usually nobody is on the list: every block exits at once
     if (metric == M_IP)

@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
 /// true k-th from above, and a row whose approximate value lies beyond E0 by more than eps has an exact distance > E0 -- it
 /// cannot enter the result and its 3 KB are not read (on the sigma-0.3 blobs at nprobe 2 most of the ~250 rows of a buffer).
 /// One block of 256 threads per failed query (grid-stride over *nfail_in), 16 lanes per candidate row as in ivf_rerank_kernel.
-/// dynamic LDS: ld4 * 16 + (2 * RA_KMAX + RA_CHUNK) * 8 bytes.
+/// dynamic LDS: ld4 * 16 + (2 * RA_KMAX + RA_CHUNK) * 8 + RA_CHUNK * 4 + 16 bytes.
 constexpr uint32_t RA_KMAX = 128, RA_CHUNK = 256;
 struct RerankAllParams
 {
@@ -1266,6 +1266,8 @@ __global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams 
     uint64_t * best = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16); // [RA_KMAX] running exact top-k, ascending
     uint64_t * chunk = best + RA_KMAX;                                              // [RA_CHUNK] this round's exact keys
     uint64_t * tmp = chunk + RA_CHUNK;                                              // [RA_KMAX]
+    uint32_t * sel = reinterpret_cast<uint32_t *>(tmp + RA_KMAX);                   // [RA_CHUNK] row positions to evaluate this round
+    uint32_t * wcnt = sel + RA_CHUNK;                                               // [4] of them per wavefront
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, g = tid & 15;
     const uint32_t ld4 = a.ld4, k = a.k;
     const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
@@ -1295,45 +1297,67 @@ __global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams 
             __syncthreads();
             for (uint32_t base = 0; base < cnt; base += RA_CHUNK)
             {
-                for (uint32_t c = grp; c < RA_CHUNK; c += 16)
+                // which of this chunk's candidates have to be evaluated: compacted, so that the 16 row groups share them evenly
+                // (most are skipped by the hint; a group per candidate slot left most groups idle round after round, and one
+                // failing query of a small batch costs the whole step its ~16 rounds)
                 {
-                    uint64_t key = KEY_NONE;
-                    bool take = base + c < cnt; // uniform over the 16 lanes of the group
+                    bool take = base + tid < cnt;
                     uint64_t pk = 0;
                     if (take)
                     {
-                        pk = b.partial[(size_t)q * b.cap + base + c];
+                        pk = b.partial[(size_t)q * b.cap + base + tid];
                         if (have_hint)
                         {
                             const double aj = (double)key_value<METRIC>(pk & 0xFFFFFFFF00000000ull);
                             take = METRIC == M_L2 ? !(aj - eps0 > e0) : !(aj + eps0 < e0);
                         }
                     }
+                    const uint64_t m = __ballot(take);
+                    if (lane == 0)
+                        wcnt[wave] = (uint32_t)__popcll(m);
+                    chunk[tid] = KEY_NONE;
+                    __syncthreads();
+                    uint32_t off = 0;
+                    for (uint32_t w2 = 0; w2 < wave; w2++)
+                        off += wcnt[w2];
                     if (take)
+                        sel[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)pk;
+                    __syncthreads();
+                }
+                const uint32_t ntake = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+                for (uint32_t c = grp; c < ntake; c += 16)
+                {
+                    const uint32_t pos = sel[c];
+                    const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
+                    const float4 * qrow = qs + g;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    uint32_t j = 0;
+                    for (; j + 8 <= jfull; j += 8) // 8 row pieces in flight per lane (the arithmetic stays in column order)
                     {
-                        const uint32_t pos = (uint32_t)pk;
-                        const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
-                        const float4 * qrow = qs + g;
-                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                        uint32_t j = 0;
-                        for (; j + 4 <= jfull; j += 4)
-                        {
-                            const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16], y3 = yrow[(j + 3) * 16];
-                            canonical_update<METRIC>(acc, qrow[j * 16], y0);
-                            canonical_update<METRIC>(acc, qrow[(j + 1) * 16], y1);
-                            canonical_update<METRIC>(acc, qrow[(j + 2) * 16], y2);
-                            canonical_update<METRIC>(acc, qrow[(j + 3) * 16], y3);
-                        }
-                        for (; j < jfull; j++)
-                            canonical_update<METRIC>(acc, qrow[j * 16], yrow[j * 16]);
-                        if (g < jtail)
-                            canonical_update<METRIC>(acc, qrow[jfull * 16], yrow[jfull * 16]);
-                        float s = __fadd_rn(__fadd_rn(acc.x, acc.y), __fadd_rn(acc.z, acc.w));
-                        s = row16_tree_sum(s);
-                        key = make_key<METRIC>(s, a.ids ? a.ids[pos] : pos);
+                        float4 y[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            y[u] = yrow[(j + u) * 16];
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            canonical_update<METRIC>(acc, qrow[(j + u) * 16], y[u]);
                     }
+                    for (; j + 4 <= jfull; j += 4)
+                    {
+                        const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16], y3 = yrow[(j + 3) * 16];
+                        canonical_update<METRIC>(acc, qrow[j * 16], y0);
+                        canonical_update<METRIC>(acc, qrow[(j + 1) * 16], y1);
+                        canonical_update<METRIC>(acc, qrow[(j + 2) * 16], y2);
+                        canonical_update<METRIC>(acc, qrow[(j + 3) * 16], y3);
+                    }
+                    for (; j < jfull; j++)
+                        canonical_update<METRIC>(acc, qrow[j * 16], yrow[j * 16]);
+                    if (g < jtail)
+                        canonical_update<METRIC>(acc, qrow[jfull * 16], yrow[jfull * 16]);
+                    float s = __fadd_rn(__fadd_rn(acc.x, acc.y), __fadd_rn(acc.z, acc.w));
+                    s = row16_tree_sum(s);
                     if (g == 0)
-                        chunk[c] = key;
+                        chunk[c] = make_key<METRIC>(s, a.ids ? a.ids[pos] : pos);
                 }
                 __syncthreads();
                 // the k best of (running k, this chunk): every key ranks itself among the RA_KMAX + RA_CHUNK slots
@@ -1395,8 +1419,6 @@ __global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams 
             if (b.stat_fail)
                 atomicAdd(b.stat_fail, 1ull);
         }
-        (void)lane;
-        (void)wave;
     }
 }
 
