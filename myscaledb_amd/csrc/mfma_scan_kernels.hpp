@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
         const float4 * qrow = qs + g;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         uint32_t j = 0;
-        for (; j + 4 <= jfull; j += 4)
+        for (; j + 4 <= jfull; j += 4) // (8 pieces in flight measured slower here: 4096 blocks, the occupancy is the parallelism)
         {
             const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16], y3 = yrow[(j + 3) * 16];
             canonical_update<METRIC>(acc, qrow[j * 16], y0);

@@ -633,6 +633,13 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
         p.zero[i] = 0;
     __syncthreads();
     uint32_t seg_blocks = 0; // (0: segments of rows_per_block rows as given)
+    // the first 1024 lists' counts and lengths stay in registers for the scan below
+    uint32_t c_first = 0, len_first = 0;
+    if (tid < p.nlist)
+    {
+        c_first = p.cnt[tid];
+        len_first = (uint32_t)((p.list_end ? p.list_end[tid] : p.list_off[tid + 1]) - p.list_off[tid]);
+    }
     if (p.seg_out)
     {
         // block-tiles of the whole launch -> blocks per segment for ~seg_target_items items, a multiple of 8 (one per wavefront)
@@ -640,14 +647,17 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
         if (tid == 0)
             s_units = 0;
         __syncthreads();
-        unsigned long long mine = 0;
-        for (uint32_t l = tid; l < p.nlist; l += 1024)
+        unsigned long long mine = (unsigned long long)((c_first + p.T - 1) / p.T) * ((len_first + 31) >> 5);
+        for (uint32_t l = tid + 1024; l < p.nlist; l += 1024)
         {
             const uint32_t c = p.cnt[l];
             const uint32_t len = (uint32_t)((p.list_end ? p.list_end[l] : p.list_off[l + 1]) - p.list_off[l]);
             mine += (unsigned long long)((c + p.T - 1) / p.T) * ((len + 31) >> 5);
         }
-        if (mine)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            mine += __shfl_xor(mine, o);
+        if ((tid & 63) == 0 && mine)
             atomicAdd(&s_units, mine);
         __syncthreads();
         const unsigned long long per = (s_units + p.seg_target_items - 1) / (p.seg_target_items ? p.seg_target_items : 1);
@@ -663,8 +673,8 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
         uint32_t c = 0, w = 0, v = 0;
         if (l < p.nlist)
         {
-            c = p.cnt[l];
-            uint32_t len = (uint32_t)((p.list_end ? p.list_end[l] : p.list_off[l + 1]) - p.list_off[l]);
+            c = base ? p.cnt[l] : c_first;
+            uint32_t len = base ? (uint32_t)((p.list_end ? p.list_end[l] : p.list_off[l + 1]) - p.list_off[l]) : len_first;
             w = ((c + p.T - 1) / p.T) * (seg_blocks ? plan_nseg((len + 31) >> 5, seg_blocks) : (len + p.rows_per_block - 1) / p.rows_per_block);
             if (p.stat_rows && c && p.stat_first)
                 atomicAdd(&s_rows[0], (unsigned long long)len);
