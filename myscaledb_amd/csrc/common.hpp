@@ -146,7 +146,7 @@ struct Options
     double rerank_groups = 16; // candidate rows in flight per re-rank block (32: 512-thread blocks, measured slower: 70 vs 47 us)
     double rerank_stats = 0;  // experiments: count the candidates an early exit of the re-rank could skip (msvs_debug_rerank_stats)
     double combine = 8;       // msvs_index_search: single-query callers beyond this many in flight are batched by the next finisher (0: off)
-    double combine_batches = 1; // ... and at most this many combined batches in flight
+    double combine_batches = 1; // ... and at most this many combined batches in flight (2: measured slower -- a batch of any size up to 64 costs the device the same ~0.2 ms and two of them do not overlap: the larger the batches the better)
     double h16_k128 = 1;      // shadow pass for 40 < k <= 128 with 256 candidates (0: the canonical scan as before)
     double h16_cut_floor = 0; // experiment: the sample cut kept >= 2.2 eps beyond the third best sample row (measured: 10 -> 4
                               // fallbacks per 94 208 queries on the mixture, but 2 -> 8 and +3 % step time on iid gaussians: off)

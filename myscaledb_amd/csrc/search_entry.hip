@@ -463,6 +463,25 @@ void combine_run(const msvs_index * ix, CombineReq & lead)
     g_comb_batched.fetch_add(total, std::memory_order_relaxed);
 }
 
+/// `lead` takes every compatible waiter's queries with it (same k, same parameter string; waiters with another k / parameter
+/// string follow in a later batch).  Called with the combiner's mutex held.
+void combine_collect(Combiner & c, CombineReq * lead)
+{
+    lead->batch.assign(1, lead);
+    size_t total = lead->nq;
+    for (auto it = c.queue.begin(); it != c.queue.end() && total < COMBINE_MAX_QUERIES;)
+        if ((*it)->k == lead->k && (*it)->params == lead->params && total + (*it)->nq <= COMBINE_MAX_QUERIES)
+        {
+            total += (*it)->nq;
+            lead->batch.push_back(*it);
+            it = c.queue.erase(it);
+        }
+        else
+            ++it;
+    if (lead->batch.size() > 1)
+        c.batches++;
+}
+
 int combined_search(const msvs_index * ix, const float * queries, size_t nq, int k, const char * params, int64_t * ids, float * dis)
 {
     const int max_direct = (int)options().combine;
@@ -484,6 +503,13 @@ int combined_search(const msvs_index * ix, const float * queries, size_t nq, int
     {
         c.active++;
         me.batch.assign(1, &me);
+    }
+    else if (c.batches >= 1 && c.batches < max_batches && !c.queue.empty())
+    {
+        // a batch is running and callers are waiting already: this one leads them NOW (a second batch in flight keeps the device
+        // busy through the first one's completion, hand-over and wake-ups; whoever arrives meanwhile waits for the next finisher)
+        c.active++;
+        combine_collect(c, &me);
     }
     else
     {
@@ -511,38 +537,26 @@ int combined_search(const msvs_index * ix, const float * queries, size_t nq, int
         }
     }
     lk.lock();
+    c.active--;
+    if (me.batch.size() > 1)
+        c.batches--;
+    // the hand-over comes FIRST (the device idles until the next leader runs; this batch's callers only have to be told)
+    if (!c.queue.empty() && c.batches < max_batches)
+    {
+        // the first waiter leads next, with every compatible waiter's queries
+        c.active++;
+        CombineReq * next = c.queue.front();
+        c.queue.pop_front();
+        combine_collect(c, next);
+        next->state = 1;
+        next->cv.notify_one();
+    }
     for (auto * r : me.batch)
         if (r != &me)
         {
             r->state = 2;
             r->cv.notify_one();
         }
-    c.active--;
-    if (me.batch.size() > 1)
-        c.batches--;
-    if (!c.queue.empty() && c.batches < max_batches)
-    {
-        // the first waiter leads next, with every compatible waiter's queries (waiters with another k / parameter string
-        // follow when this batch is done)
-        c.active++;
-        CombineReq * next = c.queue.front();
-        c.queue.pop_front();
-        next->batch.assign(1, next);
-        size_t total = next->nq;
-        for (auto it = c.queue.begin(); it != c.queue.end() && total < COMBINE_MAX_QUERIES;)
-            if ((*it)->k == next->k && (*it)->params == next->params && total + (*it)->nq <= COMBINE_MAX_QUERIES)
-            {
-                total += (*it)->nq;
-                next->batch.push_back(*it);
-                it = c.queue.erase(it);
-            }
-            else
-                ++it;
-        if (next->batch.size() > 1)
-            c.batches++;
-        next->state = 1;
-        next->cv.notify_one();
-    }
     lk.unlock();
     if (me.status)
         set_last_error(me.err);

@@ -449,7 +449,7 @@ def test_shadow_scan_items_of_every_size_match_oracle(metric, n, d, nlist, nq, n
     for; whatever the tile the planner or the knob picks (ncb 1 .. 4: the same lists cut into more or fewer items) and whatever
     the grid (2 workgroups walk every item in turn; 1024: more workgroups than items), with no cut at all (every probed row
     is appended), tiny candidate buffers (overflow -> fallback): the canonical answer bit for bit, and the SAME candidate sets
-    (every block of every list scanned exactly once per probing query)."""
+    (every block of every list scanned exactly once per probing query, with and without row segments)."""
     rng = np.random.default_rng(n + d + nlist + 11)
     centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
     x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
@@ -458,9 +458,11 @@ def test_shadow_scan_items_of_every_size_match_oracle(metric, n, d, nlist, nq, n
     oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
     opt("ivf_pass", "2")
     ref_keys = None
-    for grid, ncb in ((0, 0), (0, 1), (2, 2), (1024, 3), (37, 4)):
+    # (h16_segs: lists cut into row segments sized on the device -- 0 never, 1 when the launch could run short of items, 2 always)
+    for grid, ncb, segs in ((0, 0, 1), (0, 1, 2), (2, 2, 0), (1024, 3, 2), (37, 4, 2)):
         opt("h16_grid", str(grid))
         opt("h16_ncb", str(ncb))
+        opt("h16_segs", str(segs))
         q0, f0 = capi.prefilter_stats()
         ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
         same(ids, dis, oi, od)
