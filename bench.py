@@ -455,9 +455,10 @@ def main():
     # --streams S: S independent batches in flight, each search on its own stream with its own result buffers (a server with S
     # worker streams): the small launches around one batch's list scan run beside the other batch's scan
     n_streams = max(1, args.streams) if world == 1 else 1
-    xs = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else []
+    side_streams = 3 if world == 1 and n_streams == 1 else 0  # reported beside the headline (`concurrent_batches`), never as `value`
+    xs = [torch.cuda.Stream() for _ in range(max(n_streams, side_streams))] if max(n_streams, side_streams) > 1 else []
     xs_out = [(torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B, k), device=dev, dtype=torch.float32)) for _ in xs]
-    multi = {"on": False}
+    multi = {"on": False, "n": n_streams}
 
     def step(i):
         q = q_all[(i % n_pool) * B:(i % n_pool + 1) * B]
@@ -465,7 +466,7 @@ def main():
             # two batches in flight: batch i's top-k exchange + merge under batch i + 1's scan; fence() drains (device sync)
             ix.shard_search_device_async(comm, q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
         elif multi["on"]:
-            s_ = i % n_streams
+            s_ = i % multi["n"]
             ix.search_device(q.data_ptr(), B, k, nprobe, xs_out[s_][0].data_ptr(), xs_out[s_][1].data_ptr(), xs[s_].cuda_stream)
         else:
             ix.search_device(q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
@@ -486,6 +487,22 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     multi["on"] = False  # (the profiled passes below run one batch at a time on the current stream)
+    concurrent = None
+    if side_streams:
+        # the same steps with 3 independent batches in flight (a server with 3 worker streams): the small launches around one
+        # batch's list scan run beside another batch's scan
+        multi.update(on=True, n=side_streams)
+        for i in range(2 * side_streams):
+            step(i)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        fence()
+        e1 = time.perf_counter() - t1
+        multi.update(on=False, n=n_streams)
+        concurrent = {"streams": side_streams, "qps": round(args.steps * B / e1, 1), "ms_per_step": round(e1 / args.steps * 1e3, 4),
+                      "note": "%d independent batches in flight on %d HIP streams, same steps; `value` is the single-stream rate" % (side_streams, side_streams)}
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1226,6 +1243,7 @@ def main():
             "recall_at_10": None if recall is None else round(recall, 4),
             "p50_ms_batch1": extra.get("latency", {}).get("p50_us", 0) / 1e3 if "latency" in extra and "p50_us" in extra["latency"] else None,
             "roofline": roof,
+            "concurrent_batches": concurrent,
             "cpu_baseline": cpu,
             "other_batches": extra.get("other_batches"),
             "latency": extra.get("latency"),

@@ -96,6 +96,19 @@ static __global__ void absmax_kernel(const float4 * x, size_t n4, uint32_t * max
         atomicMax(max_bits, m);
 }
 
+/// Smallest value of an array of non-negative floats as float bits (min_bits = 0x7f800000 from the caller).
+static __global__ void min_f32_kernel(const float * v, size_t n, uint32_t * min_bits)
+{
+    uint32_t m = 0x7f800000u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = min(m, __float_as_uint(v[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        m = min(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0)
+        atomicMin(min_bits, m);
+}
+
 __device__ __forceinline__ uint32_t pack_h2(const float a, const float b)
 {
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -906,9 +919,12 @@ struct H16Prune
     const float * cnorm;  // [nlist] |c_l|^2 (cosine form only)
     int ip;               // 0: L2 index; 1: cosine index (unit rows and queries, the scan ranks by inner product); 2: inner-product
                           // index: <q, x> = <q, c> + <q, x - c> <= <q, c> + |q| r_l (Cauchy-Schwarz)
-    __host__ __device__ bool on() const { return coarse_words || probe_words; } // (the second stage: it needs the words)
+    __host__ __device__ bool on() const { return coarse_words || probe_words || probe_dis; } // (the second stage: it needs the centroid distances)
     const float * qnorm;  // |q|^2 (+inf: unusable)
     float xmax, cmax;     // max |x|^2 over the rows / the centroids
+    float xmin;           // min |x|^2 over the rows (cosine pre-pruning)
+    const float * Q;      // the (normalised) queries, row stride ldq floats (cosine pre-pruning: |q|^2 is taken from them)
+    uint32_t ldq;
     double c_dot, c_norm, c_canon; // the shadow passes' error model: rows ...
     double c_dot_c;                // ... and centroids (their table has its own measured rounding error: set_error_model_h16)
     const float * qrho;            // nullable [nq]: the query image's measured rounding error, added as qrho_scale{,_c} * qrho[q]
@@ -941,7 +957,61 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
     double sq = 0.0;             // an upper bound of |q|
     bool usable = pr.xmax < 1e30f && pr.cmax < 1e30f;
     const double sc = sqrt((double)pr.cmax * 1.001);
-    if (pr.probe_dis)
+    double spread = 0.0; // cosine: how far the row norms are from each other
+    if (pr.ip == 1)
+    {
+        // COSINE index: rows and queries are normalised (to within rounding; a zero vector stays zero), the coarse stage ranks the
+        // centroids by <q, c>.  ||q - c||^2 = |q|^2 + |c|^2 - 2 <q, c> puts the list's rows between (||q - c|| - r)^2 and
+        // (||q - c|| + r)^2 away from the query as for L2; the scan ranks by <q, x> = (|q|^2 + |x|^2 - ||q - x||^2) / 2, so a row that
+        // is farther than another by more than the spread of the row norms (+ the arithmetic's slack) has the smaller product.
+        double qn = 0.0;
+        for (uint32_t e = lane; e < pr.ldq; e += 64)
+        {
+            const double v = (double)pr.Q[(size_t)q * pr.ldq + e];
+            qn += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            qn += __shfl_xor(qn, o);
+        usable = usable && qn < 1e30 && qn == qn;
+        sq = usable ? sqrt(qn) * (1.0 + 1e-12) : 0.0;
+        spread = (double)pr.xmax * (1.0 + pr.c_norm) - (double)pr.xmin * (1.0 - pr.c_norm);
+        if (!(spread >= 0.0))
+            usable = false;
+        double ipc = 0.0, e_ip = 0.0;
+        bool have = false;
+        if (pr.probe_dis)
+        {
+            ipc = l >= 0 ? (double)pr.probe_dis[(size_t)q * nprobe + lane] : 0.0;
+            e_ip = (pr.c_canon + 4e-7) * sc * sq + 1e-30;
+            have = l >= 0 && ipc == ipc && fabs(ipc) < 1e30;
+        }
+        else
+        {
+            const uint32_t cw = l >= 0 ? (pr.probe_words ? pr.probe_words[(size_t)q * nprobe + lane] : pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l])
+                                       : 0xFFFFFFFFu;
+            ipc = (double)ord2f(~cw);
+            e_ip = 2.0 * ((pr.cd_c(q) + pr.c_canon) * sc * sq + 1e-30);
+            have = l >= 0 && cw != 0xFFFFFFFFu && ipc == ipc && fabs(ipc) < 1e30;
+        }
+        if (usable && have)
+        {
+            const double cn = (double)pr.cnorm[l], r = (double)pr.radius[l];
+            const double hi2 = qn + cn * (1.0 + pr.c_norm) - 2.0 * (ipc - e_ip), lo2 = qn + cn * (1.0 - pr.c_norm) - 2.0 * (ipc + e_ip);
+            if ((uint64_t)(list_off[l + 1] - list_off[l]) >= pr.k && r == r && hi2 == hi2)
+            {
+                const double hi = sqrt(hi2 > 0.0 ? hi2 : 0.0) * (1.0 + 1e-7) + r;
+                ub = hi * hi * (1.0 + 1e-7);
+            }
+            if (lo2 > 0.0)
+            {
+                const double lo = sqrt(lo2) * (1.0 - 1e-7);
+                if (lo > r)
+                    lb = (lo - r) * (lo - r) * (1.0 - 1e-7);
+            }
+        }
+    }
+    else if (pr.probe_dis)
     {
         // canonical centroid distances: their rounding is all there is to widen; |q| <= ||q - c|| + |c| (the nearest probe's)
         const double dc2 = l >= 0 ? (double)pr.probe_dis[(size_t)q * nprobe + lane] : 1e300;
@@ -1004,7 +1074,7 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
     }
     bool keep = true;
     const double sx = sqrt((double)pr.xmax * 1.001);
-    const double slack = 2.0 * (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30; // canonical vs real distance, both sides
+    const double slack = 2.0 * (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + spread * (1.0 + 1e-6) + 1e-30; // canonical vs real distance, both sides
     if (usable && l >= 0 && U < 1e299)
         keep = !(lb > U + slack);
     if (lane < nprobe)
@@ -1074,7 +1144,10 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
     // two).  Not when the query has fewer than k live sample rows (a selective filter: the cut would be "none", every probed row a
     // candidate) and not beyond k = 64 (a hybrid search's top-100: the cut would triple the candidates) -- the bound then takes a
     // selection of its own.
-    if (pr.on() && m < pr.k && have >= pr.k && pr.k <= 64)
+    // Nor when the sample is a small share of the probed rows (long lists): the k-th of S sample rows leaves k R / S rows below
+    // the cut, and beyond twice the target the appends cost the main launch more than the second selection (12.5M x 768, 8 probes
+    // of ~6000 rows: 1900 candidates per query instead of 760 -- the scan of a 64-query batch took twice as long).
+    if (pr.on() && m < pr.k && have >= pr.k && pr.k <= 64 && (uint64_t)pr.k * rows <= 2ull * target * have)
         m = pr.k;
     uint32_t cut = target == 0 ? 0xFFFFFFFFu : wave_kth_word<NW>(word, m, hist, lane);
     if (pr.on())
@@ -1082,20 +1155,35 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
         // the k-th smallest sample word or a larger one (0xFFFFFFFF: fewer than k sample rows -- no bound, nothing is dropped)
         const uint32_t uw = target != 0 && m >= pr.k ? cut : wave_kth_word<NW>(word, pr.k, hist, lane);
         const int32_t l = lane < nprobe ? qprobes[lane] : -1;
-        const uint32_t cw = l >= 0 ? (pr.probe_words ? pr.probe_words[(size_t)q * nprobe + lane] : pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l])
-                                   : 0xFFFFFFFFu;
+        // the probe's centroid distance (L2) / product (cosine, inner product): the coarse pass's approximate word, or -- a small
+        // batch -- the canonical value of the canonical coarse scan (cd_c = 0 then: only the canonical rounding is left)
+        double cval = 0.0;
+        bool cok = false;
+        if (pr.probe_dis)
+        {
+            cval = l >= 0 ? (double)pr.probe_dis[(size_t)q * nprobe + lane] : 0.0;
+            cok = l >= 0 && cval == cval && fabs(cval) < 1e30;
+        }
+        else
+        {
+            const uint32_t cw = l >= 0 ? (pr.probe_words ? pr.probe_words[(size_t)q * nprobe + lane] : pr.coarse_words[(size_t)q * pr.npad + (uint32_t)l])
+                                       : 0xFFFFFFFFu;
+            cok = cw != 0xFFFFFFFFu;
+            cval = (double)ord2f(pr.ip ? ~cw : cw);
+        }
+        const double cdc = pr.probe_dis ? 0.0 : pr.cd_c(q);
         bool keep = true;
         const float qn = pr.qnorm[q];
         if (uw != 0xFFFFFFFFu && l >= 0 && qn < 1e30f && pr.xmax < 1e30f && pr.cmax < 1e30f)
         {
             const double sq = sqrt((double)qn * 1.001), sx = sqrt((double)pr.xmax * 1.001), sc = sqrt((double)pr.cmax * 1.001);
-            if (cw == 0xFFFFFFFFu)
+            if (!cok)
                 ; // no coarse value for this probe: kept
             else if (pr.ip == 0)
             {
                 const double eps_x = 2.0 * pr.cd_x(q) * sx * sq + pr.c_norm * (sx * sx + sq * sq) + (pr.c_canon + 4e-7) * (sx + sq) * (sx + sq) + 1e-30;
-                const double eps_c = 2.0 * pr.cd_c(q) * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
-                const double ak = (double)ord2f(uw), ac = (double)ord2f(cw);
+                const double eps_c = 2.0 * cdc * sc * sq + pr.c_norm * (sc * sc + sq * sq) + (pr.c_canon + 4e-7) * (sc + sq) * (sc + sq) + 1e-30;
+                const double ak = (double)ord2f(uw), ac = cval;
                 const double inner = ac - 2.0 * eps_c;
                 if (inner > 0.0)
                 {
@@ -1114,8 +1202,8 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
                 // value >= ipk, hence a canonical one >= ipk - eps_x: the k-th best canonical value of the query is at least that.
                 // A row x of list l has <q, x> = <q, c> + <q, x - c> <= <q, c> + |q| r_l, the coarse pass knows <q, c> to within
                 // eps_c (twice: approximate -> canonical -> real), a canonical value exceeds the real one by <= c_canon |x||q| <= eps_x
-                const double eps_x = (pr.cd_x(q) + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.cd_c(q) + pr.c_canon) * sc * sq + 1e-30;
-                const double ipk = (double)ord2f(~uw), ipc = (double)ord2f(~cw);
+                const double eps_x = (pr.cd_x(q) + pr.c_canon) * sx * sq + 1e-30, eps_c = (cdc + pr.c_canon + 4e-7) * sc * sq + 1e-30;
+                const double ipk = (double)ord2f(~uw), ipc = cval;
                 const double ub = ipc + 2.0 * eps_c + sq * (double)pr.radius[l] * (1.0 + 1e-6);
                 keep = !(ub < ipk - 2.0 * eps_x);
             }
@@ -1124,8 +1212,8 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
                 // cosine index: the words order inner products (larger is better).  ||q - c||^2 = |q|^2 + |c|^2 - 2 <q, c> from the
                 // coarse pass's <q, c> and the (f32, fma-accumulated: relative error c_norm) norms; a row x of the list has
                 // ||q - x|| >= ||q - c|| - r_l, i.e. <q, x> <= (|q|^2 + |x|^2 - (||q - c|| - r_l)^2) / 2
-                const double eps_x = (pr.cd_x(q) + pr.c_canon) * sx * sq + 1e-30, eps_c = (pr.cd_c(q) + pr.c_canon) * sc * sq + 1e-30;
-                const double ipk = (double)ord2f(~uw), ipc = (double)ord2f(~cw);
+                const double eps_x = (pr.cd_x(q) + pr.c_canon) * sx * sq + 1e-30, eps_c = (cdc + pr.c_canon + 4e-7) * sc * sq + 1e-30;
+                const double ipk = (double)ord2f(~uw), ipc = cval;
                 const double cn = (double)pr.cnorm[l];
                 const double d2 = (double)qn * (1.0 - pr.c_norm) + cn * (1.0 - pr.c_norm) - 2.0 * (ipc + eps_c);
                 if (d2 > 0.0)

@@ -225,6 +225,16 @@ void index_finalize_norms(msvs_index & ix, hipStream_t stream)
     MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
     MSVS_HIP(hipStreamSynchronize(stream));
     memcpy(&ix.xnorm_max, &bits, 4); // NaN / inf / huge values switch the candidate pass off (see plan_ivf)
+    {
+        const uint32_t inf_bits = 0x7f800000u;
+        MSVS_HIP(hipMemcpyAsync(mx.p, &inf_bits, 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(min_f32_kernel, dim3((unsigned)std::min<size_t>(ceil_div(ix.n, (size_t)256), 1024)), dim3(256), 0, stream, ix.xnorm.p,
+                           ix.n, mx.p);
+        MSVS_HIP(hipGetLastError());
+        MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+        memcpy(&ix.xnorm_min, &bits, 4);
+    }
     if (ix.type == MSVS_INDEX_IVFFLAT && ix.nlist)
     {
         // how far a list's rows lie from its centroid at most: lets a batched search drop (query, list) pairs that provably

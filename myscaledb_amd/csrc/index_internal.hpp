@@ -54,6 +54,7 @@ struct msvs_index
     // matrix-core candidate pass (mfma_scan_kernels.hpp): |x|^2 of every stored row and their maximum
     DevBuf<float> xnorm;
     float xnorm_max = 0.f;
+    float xnorm_min = 0.f; // smallest |x|^2 over the rows (IVFFLAT: the cosine form of the pre-pruning needs the spread of the row norms)
     DevBuf<float> cnorm; // same for the centroids (the coarse quantiser goes through the same pass)
     DevBuf<float> list_radius; // nlist: an upper bound of max ||x - c_l|| over the rows of list l (probe pruning)
     float cnorm_max = 0.f;

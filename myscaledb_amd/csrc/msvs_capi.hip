@@ -1075,9 +1075,13 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.T2 = 32 * sample_nqb;
     pp.work_off2 = scr.take<uint32_t>(ix.nlist + 1);
     // (measurement: rows the two launches read -- the second pruning's plan, when there is one, is the main launch's)
-    const bool prune_pays = options().h16_prune == 2 || (double)nq * (double)nprobe > (double)ix.nlist * (double)pp.T;
-    const bool prune2 = options().h16_prune != 0 && prune_pays && (prepared.coarse_words || prepared.probe_words) && ix.list_radius.p && k <= 128
-        && nprobe <= 64 && options().wave_select != 0;
+    // ... or when the lists are LONG (a pair of >= 2.5 MB: a second plan's 18 us are a fraction of one list's scan -- batches of 64
+    // over 10M+ rows; on the 1.5 MB lists of the 1M-row config the pre-pruning has done what can be done by then)
+    const double pair_bytes = (double)ix.n / (double)std::max<size_t>(ix.nlist, 1) * (2.0 * (double)ix.dim + 8.0);
+    const bool prune_pays = options().h16_prune == 2 || (double)nq * (double)nprobe > (double)ix.nlist * (double)pp.T || pair_bytes >= 2.5e6;
+    const bool prune2 = options().h16_prune != 0 && prune_pays && (prepared.coarse_words || prepared.probe_words || prepared.probe_dis)
+        && ix.list_radius.p && k <= 128 && nprobe <= 64 && options().wave_select != 0
+        && (!prepared.probe_dis || ((ix.metric == MSVS_METRIC_L2 || ix.metric == MSVS_METRIC_COSINE) && !d_alive));
     if (options().rerank_stats != 0)
     {
         pp.stat_rows = prefilter_fail_counter() + 10;
@@ -1171,6 +1175,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
                 pr.coarse_words = prepared.coarse_words;
                 pr.npad = prepared.coarse_npad;
                 pr.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
+                pr.probe_dis = prepared.coarse_words || prepared.probe_words ? nullptr : prepared.probe_dis;
                 pr.radius = ix.list_radius.p;
                 pr.cnorm = ix.cnorm.p;
                 pr.ip = ix.metric == MSVS_METRIC_COSINE ? 1 : ix.metric == MSVS_METRIC_IP ? 2 : 0;
@@ -1442,7 +1447,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         MergeParams co{};
         co.mode = 1;
         co.out_probes = d_probes;
-        if (!probes_only && ix.metric == MSVS_METRIC_L2 && options().h16_preprune != 0)
+        if (!probes_only && (ix.metric == MSVS_METRIC_L2 || ix.metric == MSVS_METRIC_COSINE) && options().h16_preprune != 0)
         {
             float * pd = scr.take<float>(nq * nprobe);
             co.out_probe_dis = pd;
@@ -1471,7 +1476,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     // values of a small batch.  What it drops is gone for every path below, the canonical ones and the fallbacks included.
     const int32_t * all_probes = d_probes;
     (void)all_probes;
-    if (options().h16_prune != 0 && options().h16_preprune != 0 && ix.metric == MSVS_METRIC_L2 && !d_alive && !view && ix.list_radius.p
+    if (options().h16_prune != 0 && options().h16_preprune != 0 && (ix.metric == MSVS_METRIC_L2 || ix.metric == MSVS_METRIC_COSINE) && !d_alive && !view
+        && ix.list_radius.p
         && nprobe <= 64 && nprobe >= 2 && ix.cnorm_max < 1e30f && ix.xnorm_max < 1e30f
         && (prepared.probe_dis || ((prepared.coarse_words || prepared.probe_words) && prepared.qnorm)))
     {
@@ -1489,9 +1495,18 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         pr0.radius = ix.list_radius.p;
         pr0.xmax = ix.xnorm_max;
         pr0.cmax = ix.cnorm_max;
+        const bool cosine_form = ix.metric == MSVS_METRIC_COSINE;
+        if (cosine_form)
+        {
+            pr0.ip = 1;
+            pr0.cnorm = ix.cnorm.p;
+            pr0.xmin = ix.xnorm_min;
+            pr0.Q = dq; // (normalised above)
+            pr0.ldq = ld;
+        }
         pr0.k = k;
         pr0.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
-        pr0.upre = scr.take<float>(nq);
+        pr0.upre = cosine_form ? nullptr : scr.take<float>(nq); // (an L2 bound: the cosine scan's second stage compares inner products)
         int32_t * probes1 = scr.take<int32_t>(nq * nprobe);
         ProfileScope prof("ivf_plan", stream);
         hipLaunchKernelGGL(h16_preprune_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, d_probes, pr0, ix.list_off.p,

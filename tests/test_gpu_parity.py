@@ -702,8 +702,9 @@ def test_probe_pruning_drops_pairs_and_keeps_the_oracle_result(data, metric, opt
     oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric, alive=sparse)
     ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=sparse)
     same(ids, dis, oi, od)
-    # the pre-pruning (list radius alone, before the sample launch; L2, unfiltered) on and off: the same answer
-    if metric == capi.METRIC_L2:
+    # the pre-pruning (list radius alone, before the sample launch; L2 and -- through ||q - c||^2 = |q|^2 + |c|^2 - 2 <q, c> -- cosine,
+    # unfiltered) on and off: the same answer; a small batch takes its centroid distances from the canonical coarse scan
+    if metric in (capi.METRIC_L2, capi.METRIC_COSINE):
         oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
         for pre in ("0", "1"):
             opt("h16_preprune", pre)
@@ -712,6 +713,11 @@ def test_probe_pruning_drops_pairs_and_keeps_the_oracle_result(data, metric, opt
             same(ids, dis, oi, od)
             s1 = capi.debug_prune_stats()
             assert s1[1] - s0[1] == nq * nprobe
+            ids, dis = ix.search(q[:40], k, "nprobe=%d" % nprobe)
+            same(ids, dis, oi[:40], od[:40])
+            s2 = capi.debug_prune_stats()
+            if data == "blobs" and pre == "1":
+                assert s2[0] - s1[0] > 40 * nprobe // 4, "the small batch's pre-pruning dropped nothing: %d of %d" % (s2[0] - s1[0], 40 * nprobe)
         opt("ivf_eps_scale", "1e12")  # every query takes the canonical fallback -- over the pre-pruned probe lists
         ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
         same(ids, dis, oi, od)
