@@ -994,6 +994,7 @@ def main():
 
             def cstep(i):
                 cix.search_device(qs[(i % 4) * bq:(i % 4 + 1) * bq].data_ptr(), bq, k, npb, o_i.data_ptr(), o_d.data_ptr(), stream)
+            capi.release_scratch()  # (the arena of the previous batch size would be given back somewhere inside the timed steps: a 30 ms free + malloc)
             p0 = capi.prefilter_stats()
             dt = timed(cstep, 12)
             p1 = capi.prefilter_stats()
@@ -1061,6 +1062,7 @@ def main():
 
             def tstep(i):
                 tix.search_device(qs[(i % 4) * bq:(i % 4 + 1) * bq].data_ptr(), bq, k, npb, o_i.data_ptr(), o_d.data_ptr(), stream)
+            capi.release_scratch()
             p0 = capi.prefilter_stats()
             dt = timed(tstep, 12)
             p1 = capi.prefilter_stats()

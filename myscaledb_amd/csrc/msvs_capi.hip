@@ -848,7 +848,9 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         const size_t lds = h16_lds_bytes(ncb, ix.h_nch);
         const uint32_t per_cu = (uint32_t)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
         const uint32_t fgrid = options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count() * per_cu;
-        const int shape = options().flat_h16 == 3 ? 1 : options().flat_h16 == 6 ? 6 : (f.ntiles >= 2 ? 2 : 1); // (3 / 6: experiments)
+        // two row blocks per wavefront whenever a tile has two column blocks or more (every query fragment read from LDS feeds two MFMAs:
+        // a single 64-query tile 0.488 -> 0.437 ms per step over 1M x 768; a 32-query tile gains nothing)
+        const int shape = options().flat_h16 == 3 ? 1 : options().flat_h16 == 6 ? 6 : (f.ntiles >= 2 || ncb >= 2 ? 2 : 1); // (3 / 6: experiments)
         h16_flat_dispatch(scan_metric(m), ncb, shape, fgrid, lds, h, f, stream);
         MSVS_HIP(hipGetLastError());
         launch_cand_select(candbuf, h.qcnt, h.qthr, cap, (uint32_t)nq, kc, cand, bound, stream);
