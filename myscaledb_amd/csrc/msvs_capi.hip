@@ -290,8 +290,13 @@ static IvfSearchPlan plan_ivf(const msvs_index & ix, size_t nq, size_t nprobe, u
                 // fewer than k rows do (>= m of the k + m best rows fell into the sample: ~1e-6 there, and the floor m = 4
                 // is only reached when the sample is a small fraction of the probed rows)
                 // ... k > 40 (256 candidates re-ranked): 10 k, at least what k = 40 gets -- the sample's rank noise is relative
+                // Round 4: 15 k where the wavefront cut kernel runs (nprobe <= 64).  Every appended row costs the main launch (a staged
+                // record + its share of an atomic: 250 -> 150 rows per query took 27 us off the 0.34 ms launch of the bench step),
+                // and a failed certificate has become cheap there -- the second chance, then a canonical scan of the few lists the
+                // pruning left (4 of 32 768 queries on sigma-0.3 blobs).  Every list probed by every query (nprobe 256) keeps
+                // 25 k: 66 instead of 11 fallbacks over 256 lists each cost 40 % of the step.
                 p.h_mth = options().h16_nocut != 0 ? 0u
-                                                    : (uint32_t)(k <= 40 ? std::max<size_t>(64, 25 * (size_t)k)
+                                                    : (uint32_t)(k <= 40 ? std::max<size_t>(64, (nprobe <= 64 ? 15 : 25) * (size_t)k)
                                                                          : std::max<size_t>(1000, 10 * (size_t)k)); // the target
                 if (options().h16_target >= 1 && options().h16_nocut == 0) // experiment knob
                     p.h_mth = (uint32_t)options().h16_target;

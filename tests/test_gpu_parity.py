@@ -457,6 +457,8 @@ def test_shadow_scan_items_of_every_size_match_oracle(metric, n, d, nlist, nq, n
     ix = build_ivf(x, metric, nlist)
     oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
     opt("ivf_pass", "2")
+    opt("h16_prune", "2")  # (whether the pruning runs depends on the tile size, and with it the rank of the cut: pinned, so that the
+    #                         candidate SETS can be compared across the configurations below)
     ref_keys = None
     # (h16_segs: lists cut into row segments sized on the device -- 0 never, 1 when the launch could run short of items, 2 always)
     for grid, ncb, segs in ((0, 0, 1), (0, 1, 2), (2, 2, 0), (1024, 3, 2), (37, 4, 2)):
