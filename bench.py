@@ -359,6 +359,7 @@ def main():
     ap.add_argument("--data", default="blobs03", choices=("blobs03", "iid", "latent32"),
                     help="data model of the headline: SURVEY 8d's clustered variant (default), its iid one, or the 32-d latent mixture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the 3-stream side measurement (kernel traces of the single-stream steps)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps + the roofline pass (profiler runs)")
     ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,blobs03,latent32,target,c1,c3,c4,c5,cpu")
@@ -455,7 +456,7 @@ def main():
     # --streams S: S independent batches in flight, each search on its own stream with its own result buffers (a server with S
     # worker streams): the small launches around one batch's list scan run beside the other batch's scan
     n_streams = max(1, args.streams) if world == 1 else 1
-    side_streams = 3 if world == 1 and n_streams == 1 else 0  # reported beside the headline (`concurrent_batches`), never as `value`
+    side_streams = 3 if world == 1 and n_streams == 1 and not args.no_concurrent else 0  # reported beside the headline (`concurrent_batches`), never as `value`
     xs = [torch.cuda.Stream() for _ in range(max(n_streams, side_streams))] if max(n_streams, side_streams) > 1 else []
     xs_out = [(torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B, k), device=dev, dtype=torch.float32)) for _ in xs]
     multi = {"on": False, "n": n_streams}

@@ -22,7 +22,7 @@ pmc() { # name, counters, filter, command...
   rm -rf /tmp/r04p_$name
 }
 if [ "$WHAT" = headline ] || [ "$WHAT" = all ]; then
-  trace headline --headline-only --steps 20 --warmup 5
+  trace headline --headline-only --no-concurrent --steps 20 --warmup 5
   pmc fetch "FETCH_SIZE" h16_ python $REPO/tools/pmc_workload.py 4 4096
   pmc write "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" h16_ python $REPO/tools/pmc_workload.py 4 4096
   pmc sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" h16_ python $REPO/tools/pmc_workload.py 4 4096
