@@ -148,12 +148,9 @@ struct Options
     double combine = 8;       // msvs_index_search: single-query callers beyond this many in flight are batched by the next finisher (0: off)
     double combine_batches = 1; // ... and at most this many combined batches in flight (2: measured slower -- a batch of any size up to 64 costs the device the same ~0.2 ms and two of them do not overlap: the larger the batches the better)
     double h16_k128 = 1;      // shadow pass for 40 < k <= 128 with 256 candidates (0: the canonical scan as before)
-    double h16_cut_floor = 0; // experiment: the sample cut kept >= 2.2 eps beyond the third best sample row (measured: 10 -> 4
-                              // fallbacks per 94 208 queries on the mixture, but 2 -> 8 and +3 % step time on iid gaussians: off)
     double coarse_h16_min_q = 192; // coarse quantiser through the centroid shadow from this many queries on (0: only with 128-query
                                    // tiles, ~1000 queries); measured on nlist 1024: 512 queries -6 %, 256 -2.6 %, 64 +10 % (ten launches)
-    double h16_sample_nqb = 1; // column blocks (32 queries) per item of the sample launch (2: measured slower, 80 vs 73 us: 240 VGPRs)
-    double h16_target = 0;    // rows of a query's probed lists the sample cut aims to keep (0: 25 k, 10 k beyond k = 40)
+    double h16_target = 0;    // rows of a query's probed lists the sample cut aims to keep (0: 15 k up to nprobe 64, 25 k beyond; 10 k beyond k = 40)
     double h16_kc = 0;        // candidates re-ranked per query after the fp16-shadow list scan (0: 32 for k <= 12, else 64)
     double coarse_kc = 0;     // ... after the centroid-shadow pass
     double fb_segs = 0;       // segments per list of the canonical fallback scan (0: automatic 4 / 16)
@@ -166,7 +163,6 @@ struct Options
     double ivf_xcd = 1;       // XCD-contiguous work ranges
     double cand_cap = 0;      // candidate-buffer capacity per query (0 = planned; small values force overflow)
     double ivf_eps_scale = 1; // multiplies the certificate's error bound (1e12: every query takes the fallback)
-    double h16_nt = 0;        // shadow pass: non-temporal row loads
     double h16_grid = 0;      // shadow pass: grid size (0 = planned)
     double h16_min_pairs = 0.25; // shadow pass from this many (query, list) pairs per list on
     double fb_cap = 0;        // queries per round of the canonical fallback (0 = by memory; small values: many rounds)

@@ -612,14 +612,14 @@ const OptionField g_option_fields[] = {
     {"bm25_fine_sample", &Options::bm25_fine_sample}, {"lat_select", &Options::lat_select},
     {"rerank_stats", &Options::rerank_stats},   {"rerank_early", &Options::rerank_early},
     {"rerank_groups", &Options::rerank_groups}, {"combine", &Options::combine},           {"h16_k128", &Options::h16_k128},
-    {"h16_target", &Options::h16_target},       {"h16_cut_floor", &Options::h16_cut_floor},
-    {"coarse_h16_min_q", &Options::coarse_h16_min_q}, {"h16_sample_nqb", &Options::h16_sample_nqb},
+    {"h16_target", &Options::h16_target},       
+    {"coarse_h16_min_q", &Options::coarse_h16_min_q}, 
     {"combine_batches", &Options::combine_batches},
     {"flat_mfma", &Options::flat_mfma},     {"ivf_nqg", &Options::ivf_nqg},
     {"ivf_rpb", &Options::ivf_rpb},         {"ivf_grid", &Options::ivf_grid},
     {"ivf_t", &Options::ivf_t},             {"ivf_xcd", &Options::ivf_xcd},
     {"cand_cap", &Options::cand_cap},       {"ivf_eps_scale", &Options::ivf_eps_scale},
-    {"h16_nt", &Options::h16_nt},           {"h16_grid", &Options::h16_grid},
+               {"h16_grid", &Options::h16_grid},
     {"h16_min_pairs", &Options::h16_min_pairs}, {"h16_ncb", &Options::h16_ncb},
     {"h16_nocut", &Options::h16_nocut},     {"fb_cap", &Options::fb_cap},           {"rerank_second", &Options::rerank_second},
     {"lat_path", &Options::lat_path},         {"filter_compact_below", &Options::filter_compact_below},

@@ -72,7 +72,6 @@ struct H16Params
     // sample launch
     uint32_t * sample_out;    // [nq * nprobe][32] ordered distance word of row r of block 0 (0xFFFFFFFF = no row)
     uint32_t * sched;         // [8] work-queue cursors of this launch (zeroed by the caller)
-    uint32_t dbg;             // experiments (option h16_dbg; results are WRONG with any bit set): 1 no MFMA work, 2 no epilogue, 4 no norms
     uint64_t * stamps;        // nullable (option h16_stamps): [grid][H_STAMP_ITEMS][4] {item popped, tile resident, rows done, l << 32 | nvalid << 8}
                               // in wall_clock64 ticks (100 MHz), [grid][0][0] = items of the workgroup
 };
@@ -724,7 +723,7 @@ __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
 /// query q's image; the four steps of a chunk use up the 128-byte line).  The plan behind pair_off / work_off is built
 /// with T = 32 over the row range [list_off, list_off + 32).  Writes the 32 x 32 ordered distance words of the item
 /// to a.sample_out[pair][row].
-/// NQB = 2 (knob h16_sample_nqb, off): an item is TWO column blocks (64 probing queries; the plan is built with T = 64), every
+/// NQB = 2 (not instantiated any more): an item is TWO column blocks (64 probing queries; the plan is built with T = 64), every
 /// row fragment feeds two MFMAs, a quarter less operand traffic -- measured SLOWER (80 against 73 us per 4096-query step: 240
 /// VGPRs, and half of the second blocks are empty).  A short second block repeats the item's last pair and stores nothing.
 template <int METRIC, int NQB>
@@ -831,60 +830,6 @@ __global__ __launch_bounds__(BLOCK) void h16_sample_kernel(const H16Params a)
                     a.sample_out[(size_t)pair * H_ROWS + r32] = (uint32_t)(key >> 32);
             }
     }
-}
-
-/// One wavefront per query: the m-th smallest of its nprobe x 32 sample words becomes the cut qthr[q], and the sample
-/// rows below the cut open the candidate buffer (qcnt[q] = their number).  m is chosen per query so that about
-/// `target` rows of everything the query probes lie below the cut: m = target * S / R with S = sample rows that exist
-/// (and pass the filter) and R = rows of the probed lists, clamped to [4, 64] -- lists of very different lengths
-/// (a sample block is 32 rows of ANY list) would otherwise let a query that probes the long lists overflow its buffer.
-/// Fewer than m sample rows: no cut (0xFFFFFFFF), everything is appended.
-/// The same for nprobe <= 64 (NW = nprobe / 2 words per lane): the sample words are read ONCE into registers, the cut is
-/// wave_kth_word of them, the rows below it are appended from the registers (27 -> ~8 us on the bench step).
-/// A floor under the cut: the certificate needs (value at the cut) - eps > e_k, and e_k is, short of a 1 % chance, at most
-/// the exact value of the THIRD best sample row (a 1/30 sample: its third best row has an overall rank around 90), i.e.
-/// <= v3 + eps.  A cut closer than 2.2 eps to v3 -- a query whose best rows sit closer together than the fp16 pass can
-/// tell apart -- is raised to v3 + 2.2 eps: that query keeps more candidates instead of taking the canonical fallback.
-/// EXPERIMENT (option h16_cut_floor, off): on the bench mixture 10 -> 4 fallbacks per 94 208 queries, but on iid gaussian
-/// data (all distances within a few eps of each other) the floor lifts most cuts: buffers overflow, 2 -> 8 fallbacks, +3 %.
-struct H16CutFloor
-{
-    const float * qnorm; // nullptr: no floor
-    float xmax;
-    double c_dot, c_norm, c_canon; // the re-rank's error model
-    int ip;
-};
-
-template <int NW>
-__device__ inline uint32_t h16_cut_floor(const uint32_t (&word)[NW], uint32_t cut, const H16CutFloor & fl, uint32_t q)
-{
-    // third smallest distinct sample word (all below the cut: m >= 4)
-    uint32_t v = 0;
-#pragma unroll 1
-    for (int r = 0; r < 3; r++)
-    {
-        uint32_t mn = 0xFFFFFFFFu;
-#pragma unroll
-        for (int u = 0; u < NW; u++)
-            mn = min(mn, r == 0 || word[u] > v ? word[u] : 0xFFFFFFFFu);
-        v = wave_min_u32(mn);
-        if (v == 0xFFFFFFFFu)
-            return cut;
-    }
-    const float qn = fl.qnorm[q];
-    if (!(qn < 1e30f) || !(fl.xmax < 1e30f))
-        return cut;
-    const double sx = sqrt((double)fl.xmax * 1.001), sq = sqrt((double)qn * 1.001);
-    const double eps = fl.ip ? (fl.c_dot + fl.c_canon) * sx * sq
-                             : 2.0 * fl.c_dot * sx * sq + fl.c_norm * (sx * sx + sq * sq) + (fl.c_canon + 4e-7) * (sx + sq) * (sx + sq);
-    // sample words are the high words of make_key: f2ord(distance) (L2), ~f2ord(inner product) (IP: larger is better)
-    const float v3 = ord2f(fl.ip ? ~v : v);
-    const float want = fl.ip ? (float)((double)v3 - 2.2 * eps) : (float)((double)v3 + 2.2 * eps);
-    if (!(want == want) || fabsf(want) > 3.0e38f)
-        return cut;
-    const uint32_t w = (fl.ip ? ~f2ord(want) : f2ord(want));
-    const uint32_t floor_word = w < 0xFFFFFFFEu ? w + 1 : w; // one ulp looser: the float conversion may have rounded towards v3
-    return floor_word > cut ? floor_word : cut;
 }
 
 /// Probe words of a sharded search: words[q][p] = the coarse pass's approximate distance word of probe p's centroid (0xFFFFFFFF: none).
@@ -1106,7 +1051,7 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
 template <int NW>
 __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t * qprobes, const int64_t * list_off, uint32_t nprobe,
                                            uint32_t target, uint32_t * qthr, uint32_t * qcnt, uint64_t * dst, uint32_t cap,
-                                           uint32_t lane, uint32_t * hist, const H16CutFloor & fl, uint32_t q, const H16Prune & pr)
+                                           uint32_t lane, uint32_t * hist, uint32_t q, const H16Prune & pr)
 {
     const uint32_t n = nprobe * H_ROWS;
     uint32_t word[NW];
@@ -1239,8 +1184,6 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
             }
         }
     }
-    if (fl.qnorm && cut != 0xFFFFFFFFu)
-        cut = h16_cut_floor<NW>(word, cut, fl, q);
     uint32_t count = 0;
 #pragma unroll
     for (int u = 0; u < NW; u++)
@@ -1265,7 +1208,7 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
 static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_wave_kernel(const uint32_t * sample, const int32_t * probes,
                                                                             const int64_t * list_off, uint32_t nq, uint32_t nprobe,
                                                                             uint32_t target, uint32_t * qthr, uint32_t * qcnt,
-                                                                            uint64_t * partial, uint32_t cap, int radix, const H16CutFloor fl,
+                                                                            uint64_t * partial, uint32_t cap, int radix,
                                                                             const H16Prune pr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
@@ -1277,13 +1220,13 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_wave_kernel(const
     const int32_t * qp = probes + (size_t)q * nprobe;
     uint64_t * dst = partial + (size_t)q * cap;
     if (nprobe <= 8)
-        h16_sample_thr_wave<4>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q, pr);
+        h16_sample_thr_wave<4>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, q, pr);
     else if (nprobe <= 16)
-        h16_sample_thr_wave<8>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q, pr);
+        h16_sample_thr_wave<8>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, q, pr);
     else if (nprobe <= 32)
-        h16_sample_thr_wave<16>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q, pr);
+        h16_sample_thr_wave<16>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, q, pr);
     else
-        h16_sample_thr_wave<32>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, fl, q, pr);
+        h16_sample_thr_wave<32>(src, qp, list_off, nprobe, target, qthr + q, qcnt + q, dst, cap, lane, hist, q, pr);
 }
 
 static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint32_t * sample, const int32_t * probes,

@@ -1076,10 +1076,9 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         MSVS_HIP(hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), stream));
     // ... and the sample launch's partition of the same pairs: block 0 of every probed list, tiles of 32 queries (small
     // workgroups) -- one scan launch computes both
-    const uint32_t sample_nqb = options().h16_sample_nqb == 2 ? 2u : 1u; // column blocks of 32 queries per sample item
     pp.list_off2 = ix.list_off.p;
     pp.list_end2 = ix.list_mid32.p;
-    pp.T2 = 32 * sample_nqb;
+    pp.T2 = 32; // one column block of 32 queries per sample item
     pp.work_off2 = scr.take<uint32_t>(ix.nlist + 1);
     // (measurement: rows the two launches read -- the second pruning's plan, when there is one, is the main launch's)
     // ... or when the lists are LONG (a pair of >= 2.5 MB: a second plan's 18 us are a fraction of one list's scan -- batches of 64
@@ -1147,31 +1146,12 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         ProfileScope prof("ivf_sample_scan", stream);
         a.work_off = pa.work_off;
         const uint32_t sgrid = device_cu_count() * 8; // one wavefront per (list, 32-query column block), grid-stride
-        if (sample_nqb == 2)
-        {
-            if (scan_metric(m) == M_IP)
-                hipLaunchKernelGGL((h16_sample_kernel<M_IP, 2>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
-            else
-                hipLaunchKernelGGL((h16_sample_kernel<M_L2, 2>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
-        }
-        else if (scan_metric(m) == M_IP)
+        if (scan_metric(m) == M_IP)
             hipLaunchKernelGGL((h16_sample_kernel<M_IP, 1>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
         else
             hipLaunchKernelGGL((h16_sample_kernel<M_L2, 1>), dim3(sgrid), dim3(BLOCK), 0, stream, a);
         if (nprobe <= 64 && options().wave_select != 0)
         {
-            H16CutFloor fl{};
-            if (options().h16_cut_floor != 0)
-            {
-                RerankParams em{};
-                set_error_model_h16(em, ix.dim, ix.h_rho, nullptr);
-                fl.qnorm = qnorm;
-                fl.xmax = ix.xnorm_max;
-                fl.c_dot = em.c_dot;
-                fl.c_norm = em.c_norm;
-                fl.c_canon = em.c_canon;
-                fl.ip = scan_metric(m) == M_IP ? 1 : 0;
-            }
             // probe pruning (h16_scan_kernels.hpp: H16Prune): L2 indexes whose coarse pass left every centroid's approximate
             // distance behind; the surviving probes get their own plan for the main launch
             // ... when the lists are probed by more queries than one tile holds (then fewer pairs mean fewer passes over a list;
@@ -1196,7 +1176,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             }
             hipLaunchKernelGGL(h16_sample_thr_wave_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
                                sample, plan_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
-                               qstate + nq, partial, pl.h_cap, options().wave_select == 3 ? 0 : 1, fl, pr);
+                               qstate + nq, partial, pl.h_cap, options().wave_select == 3 ? 0 : 1, pr);
         }
         else
             hipLaunchKernelGGL(h16_sample_thr_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,

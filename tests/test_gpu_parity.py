@@ -400,11 +400,7 @@ def test_ivfflat_matrix_core_candidate_pass_matches_oracle(metric, n, d, nlist, 
         same(ids, dis, oa, oda)
         opt("ivf_nqg", None)
     else:
-        # non-temporal row loads, every tile size that fits LDS: same answer
-        opt("h16_nt", "1")
-        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe, alive=alive)
-        same(ids, dis, oa, oda)
-        opt("h16_nt", None)
+        # every tile size that fits LDS: same answer
         for ncb in (1, 2, 3, 4):
             opt("h16_ncb", str(ncb))
             ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)

@@ -1,6 +1,6 @@
 """Tuning sweep of the IVF search on the bench workload (1M x 768, nlist 1024, nprobe 32) through msvs_set_option knobs:
 
-    python tools/ivf_sweep.py B=4096 B=4096,ivf_h16=0 B=256,h16_nt=1 B=1024,h16_grid=2048
+    python tools/ivf_sweep.py B=4096 B=4096,ivf_h16=0 B=256,h16_ncb=2 B=1024,h16_grid=2048
 
 Every argument is one configuration: B = queries per step, the other key=value pairs are option names.
 Prints ms/step, QPS, whether the ids equal the first configuration's at that B, fallbacks and kernel-family times.
