@@ -262,7 +262,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     // posting scorer, EMIT pass: items of about equal postings (a uniform spread of a term over the documents assumed), twice
     // as many as resident wavefronts -- the launch walks them with a static stride
     const uint32_t cus = bm25_cu_count();
-    const double per_item = std::max(800.0, (double)all_postings / (2.0 * cus * 16));
+    const double per_item = std::max(800.0, (double)all_postings / (2.0 * cus * (BP_BLOCKS_PER_CU * BP_WAVES)));
     auto spi_of = [&](size_t q) -> uint32_t {
         if (q_postings[q] == 0)
             return n_blocks;
@@ -278,14 +278,14 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     // items on 4096 wavefront slots were two rounds of them)
     const uint32_t spi_s = wave && options().bm25_fine_sample != 0
         ? std::max<uint32_t>(std::max<uint32_t>(1, spi / 8),
-                             posting ? (uint32_t)ceil_div((size_t)n_blocks * nq, (size_t)BM25_SAMPLE_STEP * cus * 16) : 1u)
+                             posting ? (uint32_t)ceil_div((size_t)n_blocks * nq, (size_t)BM25_SAMPLE_STEP * cus * (BP_BLOCKS_PER_CU * BP_WAVES)) : 1u)
         : spi;
     const uint32_t n_chunks_s = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi_s) : n_blocks;
     uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks_s, (size_t)BM25_SAMPLE_STEP);
     // posting scorer: the sample's items hold equal postings too (every 16th chunk of a PER-QUERY chunking: one window each,
     // one item per resident wavefront at most) -- with the same chunks for every query the launch lasted as long as the densest
     // query's items, 50 us
-    const double per_item_s = std::max(384.0, (double)all_postings / BM25_SAMPLE_STEP / (cus * 16.0));
+    const double per_item_s = std::max(384.0, (double)all_postings / BM25_SAMPLE_STEP / (cus * (double)(BP_BLOCKS_PER_CU * BP_WAVES)));
     // ... at least 64 chunks per query whatever its terms: the sample must stay 1 / 16 of the documents (a rare term whose one
     // chunk is the whole corpus would make the cut the m-th best of ALL documents: m < k pass, the query takes the fallback)
     const uint32_t spi_s_cap = std::max<uint32_t>(1, n_blocks / 64);
@@ -435,7 +435,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
                 w.items = items;
                 w.n_items_tab = (uint32_t)n_items_tab;
                 const size_t n_it = items ? n_items_tab : (size_t)lists * slots_bound;
-                const unsigned pgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div(n_it, (size_t)BP_WAVES), (size_t)cus * 4));
+                const unsigned pgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div(n_it, (size_t)BP_WAVES), (size_t)cus * BP_BLOCKS_PER_CU));
                 if (r == 1)
                     hipLaunchKernelGGL((bm25p_kernel<BM25_TOPK, 1>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, w);
                 else if (r == 2)
@@ -548,7 +548,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         const bool nf1k = ps.num_fields == 1;
         const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)n_chunks * nq, (size_t)BW_WAVES), (size_t)cus * bw_blocks_per_cu(nf1k)));
         if (posting)
-            hipLaunchKernelGGL((bm25p_kernel<BM25_EMIT, 1>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)n_chunks * nq, (size_t)BP_WAVES), (size_t)cus * 4))),
+            hipLaunchKernelGGL((bm25p_kernel<BM25_EMIT, 1>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)n_chunks * nq, (size_t)BP_WAVES), (size_t)cus * BP_BLOCKS_PER_CU))),
                                dim3(64 * BP_WAVES), 0, stream, w);
         else if (nf1k)
             hipLaunchKernelGGL((bm25w_kernel<BM25_EMIT, 1, 1>), dim3(grid), dim3(64 * BW_WAVES), 0, stream, w);

@@ -32,6 +32,12 @@ namespace msvs
 {
 
 constexpr uint32_t BP_WAVES = 4;             // wavefronts per workgroup
+#ifndef MSVS_BP_BLOCKS_PER_CU
+#define MSVS_BP_BLOCKS_PER_CU 4
+#endif
+constexpr uint32_t BP_BLOCKS_PER_CU = MSVS_BP_BLOCKS_PER_CU; // resident workgroups per CU the item tables are sized for (= waves per SIMD)
+// (3: 135-140 VGPRs, no spills, scratch 0 -- measured round 4: 0.287 vs 0.283 ms per 64-query batch, 0.698 vs 0.628 at 256, 0.189 vs 0.199
+//  at 16: the fourth wavefront per SIMD is worth more than the 2-8 spilled VGPRs cost)
 constexpr uint32_t BP_RMAX = 8;              // records per lane and window
 constexpr uint32_t BP_CAP = 64 * BP_RMAX;    // postings per window
 constexpr uint32_t BP_SLOTS = 4096;          // hash slots of the shared-document filter (a power of two)
@@ -56,7 +62,7 @@ __device__ __forceinline__ uint64_t bp_wave_sum(uint64_t v)
 }
 
 template <int MODE, int R>
-__global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25p_kernel(const Bm25WParams a)
+__global__ __launch_bounds__(64 * BP_WAVES, BP_BLOCKS_PER_CU) void bm25p_kernel(const Bm25WParams a)
 {
     __shared__ uint32_t rdoc_s[BP_WAVES][BP_CAP];
     __shared__ float rsc_s[BP_WAVES][BP_CAP];
