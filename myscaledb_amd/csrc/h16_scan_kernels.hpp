@@ -1317,8 +1317,8 @@ static __global__ __launch_bounds__(BLOCK) void h16_sample_thr_kernel(const uint
 // canonical fallback as everywhere (table_candidate_pass).
 //
 // With hundreds of queries per row the pass is bound by the matrix pipe / the LDS reads that feed it, not by HBM: NRB = 2 row
-// blocks per wavefront halve the LDS traffic per MFMA (h16_stream).  A single tile (<= 96 queries) streams the table once:
-// HBM-bound, NRB = 1 with the deep ring.
+// blocks per wavefront halve the LDS traffic per MFMA (h16_stream) -- for every tile of two column blocks or more.  A single
+// 32-query tile streams the table once: HBM-bound, NRB = 1 with the deep ring.
 
 constexpr uint32_t H_FLAT_SEGB = 64;      // blocks per segment: 2048 rows (3 MB of shadow at d = 768)
 constexpr uint32_t H_FLAT_SAMPLE_BLK = 64; // sample blocks: 2048 rows, one register-resident selection per query
