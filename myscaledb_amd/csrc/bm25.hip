@@ -7,6 +7,7 @@
 
 #include "bm25_kernels.hpp"
 #include "bm25p_kernels.hpp"
+#include "bm25r_kernels.hpp"
 #include "device_ops.hpp"
 
 using namespace msvs;
@@ -24,6 +25,15 @@ struct msvs_postings
     mutable std::mutex mu;
     std::shared_ptr<DevBuf<uint64_t>> alive;
     size_t alive_nbits = 0;
+    // score-ready records (bm25r_kernels.hpp): derived from the postings and ONE fieldnorm cache (= the corpus statistics of the
+    // searches that use it); rebuilt when a search arrives with other statistics, published under `mu`, a search keeps its own
+    // reference (a replaced set is released by hipFree, which waits for the device)
+    struct RecSet
+    {
+        DevBuf<uint2> rec;
+        std::vector<float> key; // the cache it was built for, [num_fields][256]
+    };
+    mutable std::shared_ptr<RecSet> recs;
 };
 
 namespace
@@ -203,13 +213,44 @@ extern "C" int msvs_postings_set_alive(msvs_postings_t * ps, const uint64_t * al
 
 namespace
 {
+/// The posting set's score-ready records for this fieldnorm cache (built on `stream` when the cached set is for other
+/// statistics; the build is synchronised before it is published: other host threads may pick it up at once).
+std::shared_ptr<msvs_postings::RecSet> records_for(const msvs_postings & ps, const std::vector<float> & cache, hipStream_t stream)
+{
+    {
+        std::lock_guard<std::mutex> lk(ps.mu);
+        if (ps.recs && ps.recs->key == cache)
+            return ps.recs;
+    }
+    auto set = std::make_shared<msvs_postings::RecSet>();
+    set->key = cache;
+    set->rec.alloc(std::max<size_t>(ps.num_postings, 1));
+    if (ps.num_postings)
+    {
+        DevBuf<float> d_cache(cache.size());
+        MSVS_HIP(hipMemcpyAsync(d_cache.p, cache.data(), cache.size() * 4, hipMemcpyHostToDevice, stream));
+        const unsigned grid = (unsigned)std::min<size_t>(ceil_div(ps.num_postings, (size_t)256), (size_t)bm25_cu_count() * 32);
+        hipLaunchKernelGGL(bm25_rec_build_kernel, dim3(grid), dim3(256), 0, stream, ps.doc_ids.p, ps.tfs.p, ps.fieldnorm_ids.p,
+                           ps.post_off.p, ps.h_term_field.empty() ? (const uint8_t *)nullptr : ps.term_field.p, (uint32_t)ps.num_terms,
+                           (uint32_t)ps.num_docs, d_cache.p, set->rec.p, (uint64_t)ps.num_postings);
+        MSVS_HIP(hipGetLastError());
+        MSVS_HIP(hipStreamSynchronize(stream)); // (d_cache is freed at scope exit; the set is complete when published)
+    }
+    std::lock_guard<std::mutex> lk(ps.mu);
+    ps.recs = set;
+    return set;
+}
+
+/// Resident workgroups of bm25r_kernel per CU by its LDS (8192 hash slots: 38 KB per workgroup; 16384: 46 KB).
+uint32_t br_blocks_per_cu(bool big_slots) { return big_slots ? 3u : 4u; }
+
 /// One pass over a chunk of the batch.  Host inputs (term ids, df, statistics: a few numbers per query -- the weights
 /// need libm's logf to match tantivy), device work on `stream`, results left in d_ids / d_scores ([nq][k], id -1 = no
 /// hit).  d_alive: the effective filter, already on the device.
 void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qoff, const uint32_t * qterms,
                        const uint32_t * qgroups, const uint64_t * df, uint64_t total_docs, const float * cache,
                        int operator_or, const uint64_t * d_alive, size_t nbits, size_t k, int64_t * d_ids, float * d_scores,
-                       hipStream_t stream)
+                       const uint2 * d_rec, hipStream_t stream)
 {
     const size_t f0 = qoff[0], n_flat = qoff[nq] - f0, nf1 = std::max<size_t>(n_flat, 1), nc = ps.num_fields * 256;
     const float K1 = 1.2f;
@@ -262,7 +303,11 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     // posting scorer, EMIT pass: items of about equal postings (a uniform spread of a term over the documents assumed), twice
     // as many as resident wavefronts -- the launch walks them with a static stride
     const uint32_t cus = bm25_cu_count();
-    const double per_item = std::max(800.0, (double)all_postings / (2.0 * cus * (BP_BLOCKS_PER_CU * BP_WAVES)));
+    // the record scorer (bm25r_kernel) when the posting set has its score-ready records for this call's statistics
+    const bool recs = posting && d_rec != nullptr;
+    const bool big_slots = options().bm25_slots >= 16384;
+    const uint32_t bpc = recs ? br_blocks_per_cu(big_slots) : BP_BLOCKS_PER_CU; // resident workgroups per CU of the posting scorer
+    const double per_item = std::max(800.0, (double)all_postings / (2.0 * cus * (bpc * BP_WAVES)));
     auto spi_of = [&](size_t q) -> uint32_t {
         if (q_postings[q] == 0)
             return n_blocks;
@@ -278,14 +323,14 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     // items on 4096 wavefront slots were two rounds of them)
     const uint32_t spi_s = wave && options().bm25_fine_sample != 0
         ? std::max<uint32_t>(std::max<uint32_t>(1, spi / 8),
-                             posting ? (uint32_t)ceil_div((size_t)n_blocks * nq, (size_t)BM25_SAMPLE_STEP * cus * (BP_BLOCKS_PER_CU * BP_WAVES)) : 1u)
+                             posting ? (uint32_t)ceil_div((size_t)n_blocks * nq, (size_t)BM25_SAMPLE_STEP * cus * (bpc * BP_WAVES)) : 1u)
         : spi;
     const uint32_t n_chunks_s = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi_s) : n_blocks;
     uint32_t n_sb = (uint32_t)ceil_div((size_t)n_chunks_s, (size_t)BM25_SAMPLE_STEP);
     // posting scorer: the sample's items hold equal postings too (every 16th chunk of a PER-QUERY chunking: one window each,
     // one item per resident wavefront at most) -- with the same chunks for every query the launch lasted as long as the densest
     // query's items, 50 us
-    const double per_item_s = std::max(384.0, (double)all_postings / BM25_SAMPLE_STEP / (cus * (double)(BP_BLOCKS_PER_CU * BP_WAVES)));
+    const double per_item_s = std::max(384.0, (double)all_postings / BM25_SAMPLE_STEP / (cus * (double)(bpc * BP_WAVES)));
     // ... at least 64 chunks per query whatever its terms: the sample must stay 1 / 16 of the documents (a rare term whose one
     // chunk is the whole corpus would make the cut the m-th best of ALL documents: m < k pass, the query takes the fallback)
     const uint32_t spi_s_cap = std::max<uint32_t>(1, n_blocks / 64);
@@ -435,7 +480,23 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
                 w.items = items;
                 w.n_items_tab = (uint32_t)n_items_tab;
                 const size_t n_it = items ? n_items_tab : (size_t)lists * slots_bound;
-                const unsigned pgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div(n_it, (size_t)BP_WAVES), (size_t)cus * BP_BLOCKS_PER_CU));
+                const unsigned pgrid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div(n_it, (size_t)BP_WAVES), (size_t)cus * bpc));
+                if (recs)
+                {
+                    Bm25RParams rp{w, d_rec};
+#define MSVS_BM25R(RR) \
+    do \
+    { \
+        if (big_slots) \
+            hipLaunchKernelGGL((bm25r_kernel<BM25_TOPK, RR, 16384>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, rp); \
+        else \
+            hipLaunchKernelGGL((bm25r_kernel<BM25_TOPK, RR, 8192>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, rp); \
+    } while (0)
+                    if (r == 1) MSVS_BM25R(1); else if (r == 2) MSVS_BM25R(2); else MSVS_BM25R(4);
+#undef MSVS_BM25R
+                    MSVS_HIP(hipGetLastError());
+                    return;
+                }
                 if (r == 1)
                     hipLaunchKernelGGL((bm25p_kernel<BM25_TOPK, 1>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, w);
                 else if (r == 2)
@@ -486,9 +547,15 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     uint32_t * counters = emit ? scr.take<uint32_t>(2 * nq + 4) : nullptr; // ccnt[nq] | nfail | failq[nq]
     const bool fills_ride = emit && n_flat != 0;
     if (n_flat)
-        hipLaunchKernelGGL(bm25_bounds_kernel, dim3((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256)), dim3(256), 0,
-                           stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block, counters, fills_ride ? nq + 1 : (size_t)0,
-                           sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0);
+    {
+        const dim3 bgrid((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256));
+        if (options().bm25_bounds8 != 0)
+            hipLaunchKernelGGL(bm25_bounds8_kernel, bgrid, dim3(256), 0, stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block,
+                               counters, fills_ride ? nq + 1 : (size_t)0, sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0);
+        else
+            hipLaunchKernelGGL(bm25_bounds_kernel, bgrid, dim3(256), 0, stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block,
+                               counters, fills_ride ? nq + 1 : (size_t)0, sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0);
+    }
     if (!emit)
     {
         a.partial = partial;
@@ -518,13 +585,28 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     }
     else
         launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq, spi_s, n_chunks_s);
-    MergeParams m{};
-    m.partial = sample;
-    m.n_lists = n_sb;
-    m.k = cut_m;
-    m.mode = 2;
-    m.out_keys = cut_keys;
-    launch_merge(M_IP, m, (uint32_t)nq, stream);
+    const size_t n_sample_keys = (size_t)n_sb * cut_m;
+    if (options().bm25_cutk != 0 && n_sample_keys <= 4096)
+    {
+        // only the score of the m-th best sample key is ever read (entry cut_m - 1): one wavefront per query selects it
+        const dim3 cgrid((unsigned)ceil_div(nq, (size_t)(BLOCK / 64)));
+        if (n_sample_keys <= 1024)
+            hipLaunchKernelGGL((bm25_cut_kernel<16>), cgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);
+        else if (n_sample_keys <= 2048)
+            hipLaunchKernelGGL((bm25_cut_kernel<32>), cgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);
+        else
+            hipLaunchKernelGGL((bm25_cut_kernel<64>), cgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);
+    }
+    else
+    {
+        MergeParams m{};
+        m.partial = sample;
+        m.n_lists = n_sb;
+        m.k = cut_m;
+        m.mode = 2;
+        m.out_keys = cut_keys;
+        launch_merge(M_IP, m, (uint32_t)nq, stream);
+    }
     // 2. every chunk: emit what passes the cut
     Bm25Params ep = a;
     ep.cut_keys = cut_keys;
@@ -547,7 +629,16 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         w.n_items_tab = (uint32_t)n_items_e;
         const bool nf1k = ps.num_fields == 1;
         const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)n_chunks * nq, (size_t)BW_WAVES), (size_t)cus * bw_blocks_per_cu(nf1k)));
-        if (posting)
+        if (recs)
+        {
+            const dim3 egrid((unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div(std::max<size_t>(n_items_e, 1), (size_t)BP_WAVES), (size_t)cus * bpc)));
+            Bm25RParams rp{w, d_rec};
+            if (big_slots)
+                hipLaunchKernelGGL((bm25r_kernel<BM25_EMIT, 1, 16384>), egrid, dim3(64 * BP_WAVES), 0, stream, rp);
+            else
+                hipLaunchKernelGGL((bm25r_kernel<BM25_EMIT, 1, 8192>), egrid, dim3(64 * BP_WAVES), 0, stream, rp);
+        }
+        else if (posting)
             hipLaunchKernelGGL((bm25p_kernel<BM25_EMIT, 1>), dim3((unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div((size_t)n_chunks * nq, (size_t)BP_WAVES), (size_t)cus * BP_BLOCKS_PER_CU))),
                                dim3(64 * BP_WAVES), 0, stream, w);
         else if (nf1k)
@@ -644,19 +735,44 @@ void bm25_batch_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
             eff_bits = res_bits;
         }
     }
-    const size_t n_blocks = std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)(options().bm25_posting != 0 ? BP_MIN_DOCS : BW_DOCS))); // an upper bound of the lists per query
-    // per query: candidate slots + ~4 terms of sub-range bounds (the per-chunk lists are ~8192 x k keys for the whole batch)
+    // score-ready records of the posting scorer (bm25r_kernels.hpp): derived per fieldnorm cache, built on first use
+    std::shared_ptr<msvs_postings::RecSet> recset;
+    if (options().bm25_wave != 0 && options().bm25_posting != 0 && options().bm25_rec != 0)
+        recset = records_for(ps, cache, stream);
+    // an upper bound of the sub-ranges per query term: the posting scorer's sub-range size follows the densest query (a chunk's
+    // densest query is no denser than the batch's, so its sub-ranges are no shorter than this one)
+    size_t sub_ub = BW_DOCS;
+    if (options().bm25_wave != 0 && options().bm25_posting != 0)
+    {
+        double rho = 0;
+        for (size_t q = 0; q < nq; q++)
+        {
+            uint64_t sum = 0;
+            for (size_t j = qoff[q]; j < qoff[q + 1] && qoff[q + 1] >= qoff[q]; j++)
+                if (qterms[j] < ps.num_terms)
+                    sum += (uint64_t)(ps.h_post_off[qterms[j] + 1] - ps.h_post_off[qterms[j]]);
+            rho = std::max(rho, (double)sum / (double)std::max<size_t>(ps.num_docs, 1));
+        }
+        const size_t formula = (size_t)std::min<double>(BP_MAX_DOCS, std::max<double>(BP_MIN_DOCS, std::floor(0.75 * BP_CAP / std::max(rho, 1e-9))));
+        const size_t sub_p = options().bm25_sub_docs >= 16 ? (size_t)options().bm25_sub_docs : formula;
+        // no chunk can be denser than the batch: all of them take the posting scorer, or some may keep the dense accumulator
+        sub_ub = rho <= 0.125 || options().bm25_posting == 2 ? sub_p : std::min<size_t>(BW_DOCS, sub_p);
+    }
+    const size_t n_blocks = std::max<size_t>(1, ceil_div(ps.num_docs, sub_ub));
+    // per query: candidate slots + ~4 terms of sub-range bounds (the per-chunk lists are ~8192 x k keys for the whole batch); chunks
+    // of queries sized so that this stays under 1 GB (round 5: 256 MB cut a 1024-query batch over 10M documents into 6 chunks of
+    // seven launches each)
     const size_t per_q = (size_t)BM25_CAND_CAP * 8 + 4 * 16 * (n_blocks + 1) + 64 * k * 8 + 64
         + (options().bm25_wave != 0 ? 0 : ceil_div(ps.num_docs, (size_t)BM25_DOCS) * k * 8); // the block scorer: a list per block
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)256 << 20) / per_q));
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)1024 << 20) / per_q));
     for (size_t q0 = 0; q0 < nq; q0 += chunk)
     {
         const size_t nqc = std::min(chunk, nq - q0);
         bm25_chunk_device(ps, nqc, qoff + q0, qterms, qgroups, df, total_docs, cache.data(), operator_or, eff, eff_bits, k,
-                          d_ids + q0 * k, d_scores + q0 * k, stream);
+                          d_ids + q0 * k, d_scores + q0 * k, recset ? recset->rec.p : nullptr, stream);
     }
-    // `resident` is held until every kernel reading it is enqueued; a swapped-out bitmap is released by hipFree, which
-    // waits for the device
+    // `resident` / `recset` are held until every kernel reading them is enqueued; a swapped-out buffer is released by hipFree,
+    // which waits for the device
 }
 }
 

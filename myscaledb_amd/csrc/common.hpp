@@ -191,6 +191,11 @@ struct Options
     double bm25_sub_docs = 0; // BM25 posting scorer: documents per sub-range (0: from the batch's posting density)
     double bm25_emit = 1;     // BM25 over long corpora: sample / cut / emit (1) or per-block top-k lists only (0)
     double bm25_cand_cap = 0; // BM25 candidate slots per query (0 = 2048; small values force the fallback)
+    double flat_few = 1;      // FLAT index, fewer than 16 queries over a large table: through the fp16 shadow pass (0: the canonical f32 scan; 2: whatever the table size)
+    double bm25_rec = 1;      // BM25 posting scorer over score-ready records (bm25r_kernel; 0: bm25p_kernel over doc ids / tfs / gathered fieldnorms)
+    double bm25_slots = 0;    // bm25r_kernel: hash slots of the shared-document filter (0 = 8192, 4 workgroups per CU; 16384: 3 per CU, fewer false alarms)
+    double bm25_cutk = 1;     // BM25 cut by a register radix select per query (0: the list merge kernel)
+    double bm25_bounds8 = 1;  // BM25 sub-range bounds by an 8-ary search (0: binary)
 };
 const Options & options();
 /// name without the MSVS_ prefix, any case; value nullptr / "" restores the default.  false = unknown name.

@@ -626,6 +626,9 @@ const OptionField g_option_fields[] = {
     {"bm25_wave", &Options::bm25_wave},     {"rerank_hint", &Options::rerank_hint}, {"coarse_band", &Options::coarse_band}, {"h16_prune", &Options::h16_prune}, {"h16_preprune", &Options::h16_preprune}, {"lat_prune", &Options::lat_prune},     {"bm25_posting", &Options::bm25_posting}, {"bm25_sub_docs", &Options::bm25_sub_docs}, {"bm25_dbg", &Options::bm25_dbg},
     {"h16_rho", &Options::h16_rho}, {"h16_segs", &Options::h16_segs}, {"h16_stamps", &Options::h16_stamps},   {"flat_h16", &Options::flat_h16},     {"flat_segb", &Options::flat_segb},   {"flat_ncb", &Options::flat_ncb},
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},
+    {"flat_few", &Options::flat_few},
+    {"bm25_rec", &Options::bm25_rec},       {"bm25_slots", &Options::bm25_slots},
+    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8},
 };
 Options g_options;
 std::once_flag g_options_once;

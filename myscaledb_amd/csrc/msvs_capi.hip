@@ -1380,7 +1380,14 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     const int m = ix.metric == MSVS_METRIC_L2 ? MSVS_METRIC_L2 : MSVS_METRIC_IP;
     if (ix.type == MSVS_INDEX_FLAT)
     {
-        if (!view && table_pass_eligible(ix.n, ix.xnorm.p, ix.xnorm_max, nq, k, options().flat_mfma))
+        // round 5: a FEW queries over a large table take the fp16 shadow too -- the canonical scan moves 4 B per element, the shadow
+        // pass 2 B plus its ~8 small launches (~80 us): it pays from ~128 M elements on for 1-4 queries, earlier when the canonical
+        // scan needs several query tiles (VIWithDataPart.cpp:922-926 with IndexType::FLAT: one query per call)
+        const bool shadow_few = !view && nq < 16 && options().flat_few != 0 && options().flat_mfma != 0 && options().flat_h16 != 0
+            && ix.shadow_ready && ix.xnorm.p && ix.xnorm_max < 1e30f && k <= 40 && ix.n >= 256 && ix.n <= 0xfffffff0ull
+            && (double)ix.n * (double)ix.dim >= (options().flat_few >= 2 ? 0.0 : nq <= 4 ? 128e6 : 32e6)
+            && h16_lds_bytes(1, ix.h_nch) <= 160 * 1024;
+        if (!view && (table_pass_eligible(ix.n, ix.xnorm.p, ix.xnorm_max, nq, k, options().flat_mfma) || shadow_few))
         {
             // a batch against the whole table: matrix-core candidate pass + canonical re-rank (exact, certified)
             TablePass t{};

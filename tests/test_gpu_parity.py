@@ -264,6 +264,56 @@ def test_flat_shadow_pass_matches_oracle(metric, n, d, nq, k, order, opt):
 
 
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+@pytest.mark.parametrize("n,d,k", [(50000, 768, 10), (33001, 100, 40), (200_000, 64, 10)])
+def test_flat_shadow_few_queries_match_oracle(metric, n, d, k, opt):
+    """Round 5: ONE query per call (and 2 .. 15) over a FLAT index takes the fp16 shadow pass too (`flat_few`; by default from
+    ~128 M elements on, here forced): the canonical exhaustive answer bit for bit -- through the host-pointer entry the host calls
+    (one query per VectorIndex::search, VIWithDataPart.cpp:922-926), with labels, filters, failing certificates, and equal to
+    what the same query returns inside a batch and from the canonical f32 scan."""
+    rng = np.random.default_rng(n + d + k)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = (x[rng.integers(0, n, 15)] + 0.3 * rng.standard_normal((15, d), dtype=np.float32)).astype(np.float32)
+    x[100:105] = x[7]  # ties
+    q[3] = x[7]
+    labels = rng.permutation(n * 2)[:n].astype(np.int64)
+    ix = capi.Index(capi.INDEX_FLAT, metric, d)
+    ix.add(x, labels)
+    ix.build()
+    opt("flat_few", "2")
+    xs, qs, om = (o.normalize_rows(x), o.normalize_rows(q), o.METRIC_IP) if metric == capi.METRIC_COSINE else (x, q, OM[metric])
+
+    def expect(alive=None):
+        oi, od = o.knn(qs, xs, k, om, labels=labels, alive=None if alive is None else alive[labels])
+        return oi, ((np.float32(1) - od).astype(np.float32) if metric == capi.METRIC_COSINE else od)
+
+    ei, ed = expect()
+    capi.profile_reset()
+    capi.profile_enable(True)
+    for nq in (1, 2, 5, 15):
+        ids, dis = ix.search(q[:nq], k)
+        same(ids, dis, ei[:nq], ed[:nq])
+    for j in (3, 14):  # alone == inside the batch
+        ids, dis = ix.search(q[j:j + 1], k)
+        same(ids, dis, ei[j:j + 1], ed[j:j + 1])
+    capi.profile_enable(False)
+    assert capi.profile_get("flat_shadow_scan")[0] >= 6, "the shadow pass is the one that ran"
+    capi.profile_reset()
+    dense, sparse = rng.random(n * 2) < 0.4, rng.random(n * 2) < 0.003
+    for alive in (dense, sparse):
+        fi, fd = expect(alive)
+        for nq in (1, 7):
+            ids, dis = ix.search(q[:nq], k, alive=alive)
+            same(ids, dis, fi[:nq], fd[:nq])
+    opt("ivf_eps_scale", "1e12")  # no certificates at all: the canonical fallback answers
+    ids, dis = ix.search(q[:2], k)
+    same(ids, dis, ei[:2], ed[:2])
+    opt("ivf_eps_scale", None)
+    opt("flat_few", "0")  # the canonical f32 scan
+    ids, dis = ix.search(q[:1], k)
+    same(ids, dis, ei[:1], ed[:1])
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
 @pytest.mark.parametrize("n,d,nq,k", [(40000, 96, 200, 10), (20000, 768, 48, 10), (33000, 100, 130, 40), (5000, 20, 17, 1)])
 def test_flat_index_batches_through_the_candidate_pass(metric, n, d, nq, k, opt):
     """A batch against the whole table: matrix-core candidate pass + canonical re-rank, exact and certified; the
@@ -1446,13 +1496,15 @@ def test_bm25_synthetic_corpus_matches_oracle():
 
 
 def bm25_scorer(opt, which):
-    """"p": the posting-as-unit scorer forced (frequent terms take its split path), "w": the wave-private dense accumulator,
-    "0": the block scorer it replaced.  (The default routes a batch to "p" or "w" by its posting density.)"""
+    """"r": the posting scorer over score-ready records forced (bm25r_kernel; frequent terms take its split path), "p": the
+    same over doc ids / tfs / gathered fieldnorms (bm25p_kernel, round 3), "w": the wave-private dense accumulator, "0": the
+    block scorer it replaced.  (The default routes a batch to "r" or "w" by its posting density.)"""
     opt("bm25_wave", "0" if which == "0" else "1")
-    opt("bm25_posting", "2" if which == "p" else "0")
+    opt("bm25_posting", "2" if which in ("p", "r") else "0")
+    opt("bm25_rec", "1" if which == "r" else "0")
 
 
-@pytest.mark.parametrize("wave", ["p", "w", "0"])
+@pytest.mark.parametrize("wave", ["r", "p", "w", "0"])
 @pytest.mark.parametrize("mode", ["emit", "lists", "forced_fallback"])
 def test_bm25_many_doc_blocks(mode, wave, opt):
     """>= 64 document blocks (here 700k documents = 86 blocks): sample -> cut -> emit -> select; the same with the
@@ -1519,7 +1571,7 @@ def synthetic_postings(rng, n_docs, vocab, mean_len, num_fields=1):
     return post_off, np.concatenate(docs), np.concatenate(tfs), np.stack(fns), term_field, np.asarray(tokens, np.uint64)
 
 
-@pytest.mark.parametrize("wave", ["p", "w", "0"])
+@pytest.mark.parametrize("wave", ["r", "p", "w", "0"])
 def test_bm25_batch_equals_single_queries_and_oracle(wave, opt):
     """msvs_bm25_search_batch: every query of a batch == the one-query entry point == the oracle, bit for bit; the
     resident alive bitmap (msvs_postings_set_alive) ANDs with the per-call one."""
@@ -1570,7 +1622,7 @@ def test_bm25_batch_equals_single_queries_and_oracle(wave, opt):
         assert (od[qi].cpu().numpy()[:len(gr)].view(np.uint32) == gs.view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("wave", ["p", "w", "0"])
+@pytest.mark.parametrize("wave", ["r", "p", "w", "0"])
 @pytest.mark.parametrize("num_fields", [1, 3])
 def test_bm25_and_operator_and_text_columns(num_fields, wave, opt):
     """operator_or = false (every token must match, in any column) and an index over several text columns: one term
@@ -1601,12 +1653,16 @@ def test_bm25_and_operator_and_text_columns(num_fields, wave, opt):
             assert n_hits > 0
 
 
+@pytest.mark.parametrize("rec", ["1", "0", "16384"])
 @pytest.mark.parametrize("sub_docs", ["0", "8192", "512"])
-def test_bm25_posting_scorer_windows_duplicates_and_density_routing(sub_docs, opt):
+def test_bm25_posting_scorer_windows_duplicates_and_density_routing(sub_docs, rec, opt):
     """The default routing: a batch of sparse terms goes to the posting-as-unit scorer (bm25p_kernel), whatever sub-range
     size it cuts its windows from; terms repeated inside a query, terms sharing most of their documents, 40-term queries
     and empty posting lists -- every hit and score bit == the oracle's dense term-order accumulation."""
     opt("bm25_sub_docs", sub_docs)
+    opt("bm25_rec", "0" if rec == "0" else "1")  # 0: bm25p_kernel; else bm25r_kernel with 8192 / 16384 hash slots
+    if rec == "16384":
+        opt("bm25_slots", rec)
     rng = np.random.default_rng(123)
     n_docs, vocab = 600_000, 4000
     # terms 0..39: ~0.25 % of the documents each (the 40-term query stays under 1/8 posting per document), term 1 = half of
@@ -1645,6 +1701,36 @@ def test_bm25_posting_scorer_windows_duplicates_and_density_routing(sub_docs, op
                 assert (gs.view(np.uint32) == es.view(np.uint32)).all(), q
     q1, f1 = capi.bm25_stats()
     assert q1 - q0 == 4 * len(queries) and f1 - f0 <= 8  # the sample/emit path, a rare exact fallback
+
+
+def test_bm25_records_follow_the_statistics_of_the_call(opt):
+    """bm25r_kernel reads (doc, tf / (tf + cache[fieldnorm])) records derived for ONE fieldnorm cache, i.e. one average field
+    length: searches that alternate between two corpus statistics (a part alone / the sum over parts, BM25InfoInDataParts.cpp)
+    must each see records for their own -- against the oracle, bit for bit -- and a w = 0 term (df == N on a large corpus:
+    ln(1 + 0.5 / (N + 0.5)) rounds to 0 in f32) scores 0 without breaking ownership of shared documents."""
+    opt("bm25_posting", "2")
+    rng = np.random.default_rng(321)
+    n_docs, vocab = 400_000, 800
+    post_off, doc, tf, fn, _, tokens = synthetic_postings(rng, n_docs, vocab, 10)
+    ps = capi.Postings(post_off, doc, tf, fn[0])
+    df_all = np.diff(post_off)
+    queries = [list(rng.choice(vocab, 3, replace=False)) for _ in range(24)] + [[0, 1], [2, 2], [700]]
+    dfs = [[int(df_all[t]) for t in q] for q in queries]
+    stats = [(n_docs, int(tokens[0])), (3 * n_docs, 5 * int(tokens[0])), (n_docs, int(tokens[0]))]
+    for total_docs, total_tokens in stats:
+        got = ps.bm25_search_batch(queries, dfs, total_docs, total_tokens, 20)
+        for q, dfq, (gr, gs) in zip(queries, dfs, got):
+            er, es = o.bm25_search(post_off, doc, tf, fn[0], q, dfq, total_docs, total_tokens, 20)
+            assert gr.tolist() == er.tolist(), q
+            assert (gs.view(np.uint32) == es.view(np.uint32)).all(), q
+    # a term present in EVERY document of a 9M-document corpus statistics: idf = ln(1 + 0.5 / (N + 0.5)) = 0 in f32
+    big = 9_000_000
+    q = [[5, 9], [9, 5, 11]]
+    dfq = [[big, int(df_all[9])], [int(df_all[9]), big, int(df_all[11])]]
+    got = ps.bm25_search_batch(q, dfq, big, 10 * big, 15)
+    for qq, dd, (gr, gs) in zip(q, dfq, got):
+        er, es = o.bm25_search(post_off, doc, tf, fn[0], qq, dd, big, 10 * big, 15)
+        assert gr.tolist() == er.tolist() and (gs.view(np.uint32) == es.view(np.uint32)).all()
 
 
 @pytest.mark.parametrize("fusion", ["rrf", "rsf"])
