@@ -8,6 +8,7 @@
 #include "bm25_kernels.hpp"
 #include "bm25p_kernels.hpp"
 #include "bm25r_kernels.hpp"
+#include "bm25l_kernels.hpp"
 #include "device_ops.hpp"
 
 using namespace msvs;
@@ -34,6 +35,11 @@ struct msvs_postings
         std::vector<float> key; // the cache it was built for, [num_fields][256]
     };
     mutable std::shared_ptr<RecSet> recs;
+    // skip table of the frequent terms (bm25_skip_build_kernel): first posting at or past every 8192nd document, relative to the
+    // term's first -- the sub-range bounds of a batch start their search inside one such stretch instead of the whole list
+    DevBuf<int32_t> skip_row;  // [num_terms]: row of the term, -1 = none
+    DevBuf<uint32_t> skip_tab; // [rows][skip_n + 1]
+    uint32_t skip_n = 0;       // stretches per term (0: no table)
 };
 
 namespace
@@ -178,6 +184,36 @@ extern "C" int msvs_postings_create_fields(const int64_t * post_off, size_t num_
             p->term_field.alloc(num_terms);
             MSVS_HIP(hipMemcpy(p->term_field.p, term_field, num_terms, hipMemcpyHostToDevice));
         }
+        // the skip table: terms with at least 4 postings per stretch, the most frequent first, at most 1/8 of the postings' bytes
+        if (np && num_docs > BM25_SKIP_DOCS && options().bm25_skip != 0)
+        {
+            const uint32_t n_c = (uint32_t)ceil_div(num_docs, (size_t)BM25_SKIP_DOCS);
+            std::vector<uint32_t> sel;
+            for (size_t t = 0; t < num_terms; t++)
+                if ((uint64_t)(post_off[t + 1] - post_off[t]) >= 4ull * n_c)
+                    sel.push_back((uint32_t)t);
+            std::sort(sel.begin(), sel.end(), [&](uint32_t x, uint32_t y) { return post_off[x + 1] - post_off[x] > post_off[y + 1] - post_off[y]; });
+            const size_t max_rows = std::max<size_t>(1, np * 8 / 8 / ((size_t)(n_c + 1) * 4));
+            if (sel.size() > max_rows)
+                sel.resize(max_rows);
+            if (!sel.empty())
+            {
+                std::vector<int32_t> row(num_terms, -1);
+                for (size_t i = 0; i < sel.size(); i++)
+                    row[sel[i]] = (int32_t)i;
+                p->skip_row.alloc(num_terms);
+                p->skip_tab.alloc(sel.size() * (size_t)(n_c + 1));
+                DevBuf<uint32_t> d_sel(sel.size());
+                MSVS_HIP(hipMemcpy(p->skip_row.p, row.data(), num_terms * 4, hipMemcpyHostToDevice));
+                MSVS_HIP(hipMemcpy(d_sel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice));
+                const size_t n_e = sel.size() * (size_t)(n_c + 1);
+                hipLaunchKernelGGL(bm25_skip_build_kernel, dim3((unsigned)ceil_div(n_e, (size_t)256)), dim3(256), 0, nullptr, p->post_off.p,
+                                   p->doc_ids.p, d_sel.p, (uint32_t)sel.size(), n_c, p->skip_tab.p);
+                MSVS_HIP(hipGetLastError());
+                MSVS_HIP(hipDeviceSynchronize());
+                p->skip_n = n_c;
+            }
+        }
         *out = p.release();
     });
 }
@@ -224,7 +260,9 @@ std::shared_ptr<msvs_postings::RecSet> records_for(const msvs_postings & ps, con
     }
     auto set = std::make_shared<msvs_postings::RecSet>();
     set->key = cache;
-    set->rec.alloc(std::max<size_t>(ps.num_postings, 1));
+    // (one record of padding at either end: bm25l_kernel's dead lanes may read the neighbour of a slice, never use it)
+    set->rec.alloc(ps.num_postings + 2);
+    MSVS_HIP(hipMemsetAsync(set->rec.p, 0, (ps.num_postings + 2) * sizeof(uint2), stream));
     if (ps.num_postings)
     {
         DevBuf<float> d_cache(cache.size());
@@ -232,7 +270,7 @@ std::shared_ptr<msvs_postings::RecSet> records_for(const msvs_postings & ps, con
         const unsigned grid = (unsigned)std::min<size_t>(ceil_div(ps.num_postings, (size_t)256), (size_t)bm25_cu_count() * 32);
         hipLaunchKernelGGL(bm25_rec_build_kernel, dim3(grid), dim3(256), 0, stream, ps.doc_ids.p, ps.tfs.p, ps.fieldnorm_ids.p,
                            ps.post_off.p, ps.h_term_field.empty() ? (const uint8_t *)nullptr : ps.term_field.p, (uint32_t)ps.num_terms,
-                           (uint32_t)ps.num_docs, d_cache.p, set->rec.p, (uint64_t)ps.num_postings);
+                           (uint32_t)ps.num_docs, d_cache.p, set->rec.p + 1, (uint64_t)ps.num_postings);
         MSVS_HIP(hipGetLastError());
         MSVS_HIP(hipStreamSynchronize(stream)); // (d_cache is freed at scope exit; the set is complete when published)
     }
@@ -294,7 +332,11 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     const uint32_t docs_per_block = posting ? sub_docs : (wave ? BW_DOCS : BM25_DOCS);
     const uint32_t n_blocks = (uint32_t)std::max<size_t>(1, ceil_div(ps.num_docs, (size_t)docs_per_block));
     // wave scorer: an item = spi consecutive sub-ranges of one query; enough items for ~4 per resident wavefront
-    const uint32_t spi = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, (size_t)n_blocks * nq / 8192));
+    // (posting scorer: at least 32 chunks whenever there are 32 sub-ranges -- the sample / cut / emit flow below needs them, and a batch
+    // whose densest query is sparse (8192-document sub-ranges, 1221 of them over 10M documents) must not fall off it: measured 2.2 ms
+    // of per-chunk lists for a 1024-query batch against 0.95 ms)
+    const uint32_t spi = (uint32_t)std::min<size_t>(std::min<size_t>(64, posting ? std::max<size_t>(1, n_blocks / 32) : 64),
+                                                    std::max<size_t>(1, (size_t)n_blocks * nq / 8192));
     const uint32_t n_chunks = wave ? (uint32_t)ceil_div((size_t)n_blocks, (size_t)spi) : n_blocks;
     // long corpora: sample -> cut -> emit -> select (+ exact fallback); short ones: per-chunk top-k lists, one merge
     const bool emit = n_chunks >= (wave ? 32u : 64u) && ps.num_docs >= 500000 && options().bm25_emit != 0;
@@ -306,6 +348,10 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     // the record scorer (bm25r_kernel) when the posting set has its score-ready records for this call's statistics
     const bool recs = posting && d_rec != nullptr;
     const bool big_slots = options().bm25_slots >= 16384;
+    // ... and its lean form (bm25l_kernels.hpp) when no query of the chunk has more than four terms
+    bool lean = recs && options().bm25_lean != 0;
+    for (size_t q = 0; q < nq && lean; q++)
+        lean = qoff[q + 1] < qoff[q] || qoff[q + 1] - qoff[q] <= BL_NT;
     const uint32_t bpc = recs ? br_blocks_per_cu(big_slots) : BP_BLOCKS_PER_CU; // resident workgroups per CU of the posting scorer
     const double per_item = std::max(800.0, (double)all_postings / (2.0 * cus * (bpc * BP_WAVES)));
     auto spi_of = [&](size_t q) -> uint32_t {
@@ -487,7 +533,9 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
 #define MSVS_BM25R(RR) \
     do \
     { \
-        if (big_slots) \
+        if (lean) \
+            hipLaunchKernelGGL((bm25l_kernel<BM25_TOPK, RR, 8192>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, rp); \
+        else if (big_slots) \
             hipLaunchKernelGGL((bm25r_kernel<BM25_TOPK, RR, 16384>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, rp); \
         else \
             hipLaunchKernelGGL((bm25r_kernel<BM25_TOPK, RR, 8192>), dim3(pgrid), dim3(64 * BP_WAVES), 0, stream, rp); \
@@ -550,8 +598,10 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     {
         const dim3 bgrid((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256));
         if (options().bm25_bounds8 != 0)
-            hipLaunchKernelGGL(bm25_bounds8_kernel, bgrid, dim3(256), 0, stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block,
-                               counters, fills_ride ? nq + 1 : (size_t)0, sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0);
+            hipLaunchKernelGGL(bm25_bounds8_kernel, dim3((unsigned)ceil_div((size_t)n_blocks + 1, (size_t)256), (unsigned)std::min<size_t>(n_flat, 65535)), dim3(256), 0, stream, a, d_bounds,
+                               recs ? (int64_t *)nullptr : d_bounds_hi /* only bm25p_kernel reads the shifted copy */, (uint32_t)n_flat, docs_per_block,
+                               counters, fills_ride ? nq + 1 : (size_t)0, sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0,
+                               ps.skip_n ? ps.skip_row.p : (const int32_t *)nullptr, ps.skip_tab.p, ps.skip_n);
         else
             hipLaunchKernelGGL(bm25_bounds_kernel, bgrid, dim3(256), 0, stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block,
                                counters, fills_ride ? nq + 1 : (size_t)0, sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0);
@@ -633,7 +683,9 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         {
             const dim3 egrid((unsigned)std::max<size_t>(1, std::min<size_t>(ceil_div(std::max<size_t>(n_items_e, 1), (size_t)BP_WAVES), (size_t)cus * bpc)));
             Bm25RParams rp{w, d_rec};
-            if (big_slots)
+            if (lean)
+                hipLaunchKernelGGL((bm25l_kernel<BM25_EMIT, 1, 8192>), egrid, dim3(64 * BP_WAVES), 0, stream, rp);
+            else if (big_slots)
                 hipLaunchKernelGGL((bm25r_kernel<BM25_EMIT, 1, 16384>), egrid, dim3(64 * BP_WAVES), 0, stream, rp);
             else
                 hipLaunchKernelGGL((bm25r_kernel<BM25_EMIT, 1, 8192>), egrid, dim3(64 * BP_WAVES), 0, stream, rp);
@@ -769,7 +821,7 @@ void bm25_batch_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     {
         const size_t nqc = std::min(chunk, nq - q0);
         bm25_chunk_device(ps, nqc, qoff + q0, qterms, qgroups, df, total_docs, cache.data(), operator_or, eff, eff_bits, k,
-                          d_ids + q0 * k, d_scores + q0 * k, recset ? recset->rec.p : nullptr, stream);
+                          d_ids + q0 * k, d_scores + q0 * k, recset ? recset->rec.p + 1 : nullptr, stream);
     }
     // `resident` / `recset` are held until every kernel reading them is enqueued; a swapped-out buffer is released by hipFree,
     // which waits for the device

@@ -82,6 +82,8 @@ __device__ __forceinline__ uint32_t br_wave_sum_sat(int64_t len)
     return wave_sum_u32(len > (int64_t)(1 << 20) ? (1u << 20) : (uint32_t)len);
 }
 
+#define BR_LOG2(x) (31 - __builtin_clz((unsigned)(x)))
+
 template <int MODE, int R, int SLOTS>
 __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25r_kernel(const Bm25RParams ar)
 {
@@ -463,6 +465,42 @@ __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25r_kernel(const Bm25RPara
                 }
                 bp_wave_lds_fence();
             }
+            // ---- second look at the flagged few, one per lane: a DIFFERENT hash (of the whole document id) through the same bitmap
+            // pair (cleared above).  Two records of one document meet again whatever the hash; the first filter's false alarms --
+            // records whose documents only share their low bits: ~6 % of a window that spans 4 x SLOTS documents -- do not, and
+            // leave with their own partial like the unshared ones.  What is flagged twice (true shares; a false alarm per ~30
+            // windows) is resolved pairwise below.
+            uint32_t f2 = 0; // bit c: record c * 64 + lane of the flagged list is flagged again
+            const bool second = nfl != 0 && nfl <= 4 * 64 && !(a.dbg & 2);
+            if (second)
+            {
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++)
+                    if (c * 64 < nfl && c * 64 + lane < nfl)
+                    {
+                        const uint32_t hs = (fdoc[c * 64 + lane] * 0x9E3779B1u) >> (32 - BR_LOG2(SLOTS)), bit = 1u << (hs & 31);
+                        const uint32_t old = atomicOr(&bm[2 * (hs >> 5)], bit);
+                        if (old & bit)
+                            atomicOr(&bm[2 * (hs >> 5) + 1], bit);
+                    }
+                bp_wave_lds_fence();
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++)
+                    if (c * 64 < nfl && c * 64 + lane < nfl)
+                    {
+                        const uint32_t hs = (fdoc[c * 64 + lane] * 0x9E3779B1u) >> (32 - BR_LOG2(SLOTS));
+                        f2 |= ((bm[2 * (hs >> 5) + 1] >> (hs & 31)) & 1u) << c;
+                    }
+                bp_wave_lds_fence();
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++)
+                    if (c * 64 < nfl && c * 64 + lane < nfl)
+                    {
+                        const uint32_t hs = (fdoc[c * 64 + lane] * 0x9E3779B1u) >> (32 - BR_LOG2(SLOTS));
+                        *reinterpret_cast<uint2 *>(&bm[2 * (hs >> 5)]) = make_uint2(0u, 0u);
+                    }
+            }
+            const bool any2 = !second || __ballot(f2 != 0) != 0; // uniform
             for (uint32_t i0 = 0; i0 < nfl; i0 += 64)
             {
                 const uint32_t me = i0 + lane;
@@ -472,25 +510,34 @@ __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25r_kernel(const Bm25RPara
                 float acc = fsc[mi];
                 uint32_t mask = tfb[ft[mi]] >> 8;
                 bool dead = !have;
-                for (uint32_t j = 0; j < nfl; j++)
-                {
-                    const uint32_t dj = fdoc[j]; // the same address in every lane: a broadcast read
-                    const bool match = have && dj == docid && j != me;
-                    if (!__ballot(match))
-                        continue;
-                    const float sj = fsc[j];
-                    const uint32_t bj = tfb[ft[j]] >> 8;
-                    if (match)
+                // the records flagged twice (all of them without the second look): their partners are flagged twice as well
+                const bool mine2 = have && (!second || ((f2 >> (i0 >> 6)) & 1u));
+                if (any2 && __ballot(mine2))
+                    for (uint32_t j0 = 0; j0 < nfl; j0 += 64)
                     {
-                        if (j < me)
-                            dead = true; // an earlier term has the document: not the owner
-                        else
+                        uint64_t cand_j = second ? __ballot((f2 >> (j0 >> 6)) & 1u) : __ballot(j0 + lane < nfl);
+                        while (cand_j)
                         {
-                            acc = __fadd_rn(acc, sj); // later terms in term order, onto the owner's own partial
-                            mask |= bj;
+                            const uint32_t j = j0 + (uint32_t)__builtin_ctzll(cand_j);
+                            cand_j &= cand_j - 1;
+                            const uint32_t dj = fdoc[j]; // the same address in every lane: a broadcast read
+                            const bool match = mine2 && dj == docid && j != me;
+                            if (!__ballot(match))
+                                continue;
+                            const float sj = fsc[j];
+                            const uint32_t bj = tfb[ft[j]] >> 8;
+                            if (match)
+                            {
+                                if (j < me)
+                                    dead = true; // an earlier term has the document: not the owner
+                                else
+                                {
+                                    acc = __fadd_rn(acc, sj); // later terms in term order, onto the owner's own partial
+                                    mask |= bj;
+                                }
+                            }
                         }
                     }
-                }
                 bool ok = !(a.dbg & 4) && !dead && (p.operator_or || mask == full) && (MODE != BM25_EMIT || acc >= cut);
                 if (ok && p.alive)
                     ok = docid < p.nbits && ((p.alive[docid >> 6] >> (docid & 63)) & 1);
@@ -547,26 +594,72 @@ __global__ __launch_bounds__(BLOCK) void bm25_cut_kernel(const uint64_t * sample
         cut_keys[(size_t)q * m + m - 1] = H == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)H << 32;
 }
 
+constexpr uint32_t BM25_SKIP_DOCS = 8192; // documents per stretch of the skip table
+
+/// Skip table of a posting set: tab[row][c] = postings of term sel[row] with a document id below c * BM25_SKIP_DOCS (c = 0 .. n_c).
+static __global__ void bm25_skip_build_kernel(const int64_t * post_off, const uint32_t * doc_ids, const uint32_t * sel, uint32_t n_rows,
+                                              uint32_t n_c, uint32_t * tab)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_rows * (n_c + 1))
+        return;
+    const uint32_t row = (uint32_t)(i / (n_c + 1)), c = (uint32_t)(i - (size_t)row * (n_c + 1));
+    const uint32_t term = sel[row];
+    const uint64_t target = (uint64_t)c * BM25_SKIP_DOCS;
+    const int64_t base = post_off[term];
+    int64_t lo = base, hi = post_off[term + 1];
+    while (lo < hi)
+    {
+        const int64_t mid = (lo + hi) >> 1;
+        if (doc_ids[mid] < target)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    tab[i] = (uint32_t)(lo - base);
+}
+
 /// bm25_bounds_kernel with an 8-ary search: the chain of dependent loads is what the launch costs (21 steps for a list of 2M
 /// postings); seven independent probes per step cut it to 7.
 static __global__ void bm25_bounds8_kernel(const Bm25Params a, int64_t * bounds, int64_t * bounds_hi, uint32_t n_flat,
-                                           uint32_t docs_per_block, uint32_t * zero, size_t n_zero, uint64_t * ones, size_t n_ones)
+                                           uint32_t docs_per_block, uint32_t * zero, size_t n_zero, uint64_t * ones, size_t n_ones,
+                                           const int32_t * skip_row, const uint32_t * skip_tab, uint32_t skip_n)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid: x over the boundaries of a term, y over the flat terms (the term and its list ends are uniform: scalar loads, and no
+    // 64-bit division per thread -- the flat index form spent more on `i / nb1` than on its search)
     {
-        const size_t gsz = (size_t)gridDim.x * blockDim.x;
+        const size_t gsz = (size_t)gridDim.x * gridDim.y * blockDim.x;
+        const size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         for (size_t j = i; j < n_zero; j += gsz)
             zero[j] = 0;
         for (size_t j = i; j < n_ones; j += gsz)
             ones[j] = KEY_NONE;
     }
     const uint32_t nb1 = a.n_blocks + 1;
-    if (i >= (size_t)n_flat * nb1)
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb1)
         return;
-    const uint32_t j = (uint32_t)(i / nb1), b = (uint32_t)(i - (size_t)j * nb1);
+    for (uint32_t j = blockIdx.y; j < n_flat; j += gridDim.y)
+    {
+    const size_t i = (size_t)j * nb1 + b;
     const uint32_t term = a.qterms[j];
     const uint64_t target = (uint64_t)b * docs_per_block;
     int64_t lo = a.post_off[term], hi = a.post_off[term + 1]; // the answer lies in [lo, hi]
+    if (skip_row)
+    {
+        // a frequent term: the stretch of 8192 documents that holds the target (the posting set's skip table) -- two 8-ary steps
+        // through a few cache lines instead of six through the whole list
+        const int32_t row = skip_row[term];
+        if (row >= 0)
+        {
+            const uint32_t * const tab = skip_tab + (size_t)row * (skip_n + 1);
+            const uint64_t c = target / BM25_SKIP_DOCS;
+            const uint32_t c0 = c < skip_n ? (uint32_t)c : skip_n, c1 = c0 < skip_n ? c0 + 1 : skip_n;
+            const int64_t base = lo;
+            lo = base + tab[c0];
+            hi = base + tab[c1];
+        }
+    }
     while (hi - lo > 7)
     {
         const int64_t step = (hi - lo) >> 3; // >= 1; probes lo + step .. lo + 7 step, all < hi
@@ -584,17 +677,22 @@ static __global__ void bm25_bounds8_kernel(const Bm25Params a, int64_t * bounds,
         lo = nlo;
         hi = nhi;
     }
-    while (lo < hi)
     {
-        const int64_t mid = (lo + hi) >> 1;
-        if (a.doc_ids[mid] < target)
-            lo = mid + 1;
-        else
-            hi = mid;
+        // at most 7 postings left: all of them side by side, the ones below the target are a prefix
+        const int64_t n = hi - lo;
+        int below = 0;
+#pragma unroll
+        for (int u = 0; u < 7; u++)
+        {
+            const uint32_t d = a.doc_ids[u < n ? lo + u : (lo > 0 ? lo - 1 : 0)]; // (a readable posting; its value is not used)
+            below += u < n && d < target ? 1 : 0;
+        }
+        lo += below;
     }
     bounds[i] = lo;
-    if (b > 0)
+    if (b > 0 && bounds_hi)
         bounds_hi[i - 1] = lo;
+    }
 }
 
 }

@@ -20,6 +20,14 @@ VARIANTS = [
     ("records, list-merge cut", {"bm25_cutk": "0"}),
     ("records, binary bounds", {"bm25_bounds8": "0"}),
     ("bm25p + radix cut + 8-ary bounds (bm25_rec=0)", {"bm25_rec": "0"}),
+    # ablations of the record scorer (results are WRONG by construction: timing only)
+    ("ablation: windows generated, nothing loaded or scored (dbg=8)", {"bm25_dbg": "8"}),
+    ("ablation: no shared-document filter (dbg=1)", {"bm25_dbg": "1"}),
+    ("ablation: nothing leaves a window (dbg=4)", {"bm25_dbg": "4"}),
+    ("ablation: no filter, no output (dbg=5)", {"bm25_dbg": "5"}),
+    ("no second look at the flagged records (dbg=2; exact)", {"bm25_dbg": "2"}),
+    ("general record scorer (bm25_lean=0)", {"bm25_lean": "0"}),
+    ("ablation: filter runs, its flags are ignored (dbg=16)", {"bm25_dbg": "16"}),
 ]
 
 
@@ -48,6 +56,9 @@ def main():
             sets.append((qs, dfs_, ps.prepare_batch(qs, dfs_, total)))
         byts = np.mean([sum(int(d.sum()) * 8 + min(int(d.sum()), a.docs) for d in dfs) for _, dfs, _ in sets])
         ref = None
+        for qs, dfs, prep in sets:  # scratch arenas grow to this batch size before any variant is timed
+            ps.bm25_search_batch_device(qs, dfs, a.docs, total, a.k, oi.data_ptr(), od.data_ptr(), stream, prepared=prep)
+        torch.cuda.synchronize()
         for vi in sel:
             name, opts = VARIANTS[vi]
             for k_, v_ in opts.items():
@@ -68,19 +79,20 @@ def main():
                         "DIFFERS from default in %d of %d rows" % (int((got[0] != ref[0]).any(axis=1).sum()), B)
                 capi.profile_reset()
                 capi.profile_enable(True)
-                steps = 12 if B <= 256 else 6
+                steps = int(os.environ.get("STEPS", "0")) or (40 if B <= 256 else 24)
                 t = time.perf_counter()
                 for i in range(steps):
                     qs, dfs, prep = sets[i % len(sets)]
                     ps.bm25_search_batch_device(qs, dfs, a.docs, total, a.k, oi.data_ptr(), od.data_ptr(), stream, prepared=prep)
+                host = (time.perf_counter() - t) / steps  # what the calls themselves took (the device runs behind)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t) / steps
                 capi.profile_enable(False)
                 cnt, ms = capi.profile_get("bm25_score")
                 capi.profile_reset()
                 q_, f_ = capi.bm25_stats()
-                print("batch %5d  %-62s %.3f ms/batch  %.2f us/query  kernels %.3f ms  %.0f GB/s = %.4f of HBM  [%s; fallbacks so far %d]"
-                      % (B, name, dt * 1e3, dt / B * 1e6, ms / steps, byts / dt / 1e9, byts / dt / 8e12, eq, f_), flush=True)
+                print("batch %5d  %-62s %.3f ms/batch  %.2f us/query  kernels %.3f ms  host %.3f ms  %.0f GB/s = %.4f of HBM  [%s; fallbacks so far %d]"
+                      % (B, name, dt * 1e3, dt / B * 1e6, ms / steps, host * 1e3, byts / dt / 1e9, byts / dt / 8e12, eq, f_), flush=True)
             except Exception as e:
                 print("batch %5d  %-62s FAILED: %r" % (B, name, e), flush=True)
             for k_ in opts:
