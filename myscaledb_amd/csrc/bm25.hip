@@ -636,11 +636,22 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     else
         launch_topk(sp, n_sb, BM25_SAMPLE_STEP, nq, spi_s, n_chunks_s);
     const size_t n_sample_keys = (size_t)n_sb * cut_m;
-    if (options().bm25_cutk != 0 && n_sample_keys <= 4096)
+    if (options().bm25_cutk != 0 && (n_sample_keys <= 4096 || (nq <= 512 && n_sample_keys <= 8192 && cut_m <= 64)))
     {
         // only the score of the m-th best sample key is ever read (entry cut_m - 1): one wavefront per query selects it
         const dim3 cgrid((unsigned)ceil_div(nq, (size_t)(BLOCK / 64)));
-        if (n_sample_keys <= 1024)
+        if (nq <= 512 && n_sample_keys > 256 && cut_m <= 64) // few queries: a workgroup each
+        {
+            if (n_sample_keys <= 1024)
+                hipLaunchKernelGGL((bm25_cut_block_kernel<4>), dim3((unsigned)nq), dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);
+            else if (n_sample_keys <= 2048)
+                hipLaunchKernelGGL((bm25_cut_block_kernel<8>), dim3((unsigned)nq), dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);
+            else if (n_sample_keys <= 4096)
+                hipLaunchKernelGGL((bm25_cut_block_kernel<16>), dim3((unsigned)nq), dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);
+            else
+                hipLaunchKernelGGL((bm25_cut_block_kernel<32>), dim3((unsigned)nq), dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);
+        }
+        else if (n_sample_keys <= 1024)
             hipLaunchKernelGGL((bm25_cut_kernel<16>), cgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);
         else if (n_sample_keys <= 2048)
             hipLaunchKernelGGL((bm25_cut_kernel<32>), cgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)n_sample_keys, (uint32_t)nq, cut_m, cut_keys);

@@ -594,6 +594,48 @@ __global__ __launch_bounds__(BLOCK) void bm25_cut_kernel(const uint64_t * sample
         cut_keys[(size_t)q * m + m - 1] = H == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)H << 32;
 }
 
+/// bm25_cut_kernel for small batches: a WORKGROUP per query (one wavefront per query leaves a 64-query batch on 16 workgroups,
+/// 64 words per lane: 12.7 us).  Each of the four wavefronts selects the m best of its quarter (their m-th best word H: the words
+/// below it, then copies of H up to m), the first one selects the m-th best of the 4 m.
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void bm25_cut_block_kernel(const uint64_t * sample, uint32_t n, uint32_t nq, uint32_t m, uint64_t * cut_keys)
+{
+    __shared__ uint32_t hist_s[BLOCK / 64][256];
+    __shared__ uint32_t best_s[BLOCK / 64][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = blockIdx.x;
+    const uint64_t * src = sample + (size_t)q * n;
+    uint32_t word[NW];
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const uint32_t i = (uint32_t)u * BLOCK + threadIdx.x;
+        word[u] = i < n ? (uint32_t)(src[i] >> 32) : 0xFFFFFFFFu;
+    }
+    const uint32_t H = wave_kth_word_radix<NW>(word, m, hist_s[wave], lane); // 0xFFFFFFFF: fewer than m real keys in this quarter
+    best_s[wave][lane] = H; // (m <= 64: lanes past m are not read)
+    __builtin_amdgcn_wave_barrier();
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++)
+    {
+        const bool take = word[u] < H;
+        const uint64_t mask = __ballot(take);
+        if (take)
+            best_s[wave][run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = word[u];
+        run += (uint32_t)__popcll(mask); // < m in total: H is the m-th smallest
+    }
+    __syncthreads();
+    if (wave != 0)
+        return;
+    uint32_t w4[BLOCK / 64];
+#pragma unroll
+    for (uint32_t v = 0; v < BLOCK / 64; v++)
+        w4[v] = lane < m ? best_s[v][lane] : 0xFFFFFFFFu;
+    const uint32_t G = wave_kth_word_radix<BLOCK / 64>(w4, m, hist_s[0], lane);
+    if (lane == 0)
+        cut_keys[(size_t)q * m + m - 1] = G == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)G << 32;
+}
+
 constexpr uint32_t BM25_SKIP_DOCS = 8192; // documents per stretch of the skip table
 
 /// Skip table of a posting set: tab[row][c] = postings of term sel[row] with a document id below c * BM25_SKIP_DOCS (c = 0 .. n_c).

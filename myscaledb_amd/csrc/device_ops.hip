@@ -476,7 +476,7 @@ void launch_cand_select(const uint64_t * buf, const uint32_t * qcnt, const uint3
     if (cap <= CAND_SELECT_WAVE_CAP && kc <= 64 && options().wave_select != 0)
         hipLaunchKernelGGL(cand_select_wave_kernel, dim3((nq + 3) / 4), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out,
                            bound, options().wave_select == 3 ? 0 : 1, options().rerank_early != 0 ? 1 : 0);
-    else if (kc <= 64)
+    else if (kc <= 64 && !(nq <= 16 && options().wave_select != 0)) // (a few queries with ~2000 candidates each: the block-wide radix select, 19 -> ~6 us)
         hipLaunchKernelGGL(cand_select_kernel<1>, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
     else if (options().wave_select != 0)
         hipLaunchKernelGGL(cand_select_block_kernel, dim3(nq), dim3(BLOCK), 0, stream, buf, qcnt, qthr, cap, nq, kc, out, bound);
@@ -628,7 +628,7 @@ const OptionField g_option_fields[] = {
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},
     {"flat_few", &Options::flat_few},
     {"bm25_rec", &Options::bm25_rec},       {"bm25_slots", &Options::bm25_slots},
-    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8}, {"bm25_lean", &Options::bm25_lean}, {"bm25_skip", &Options::bm25_skip},
+    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8}, {"bm25_lean", &Options::bm25_lean}, {"bm25_skip", &Options::bm25_skip}, {"flat_host_signal", &Options::flat_host_signal}, {"flat_sample_few", &Options::flat_sample_few},
 };
 Options g_options;
 std::once_flag g_options_once;

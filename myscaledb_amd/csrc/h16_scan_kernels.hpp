@@ -1561,6 +1561,122 @@ __global__ __launch_bounds__(BLOCK, 1) void coarse_h16_kernel(const uint4 * H, u
     }
 }
 
+/// The sample of a FLAT table for ONE query tile (<= 32 queries: the few-query path), with the cut: a workgroup per sample block,
+/// its four wavefronts take every fourth 64-element chunk of the reduction (coarse_h16_kernel walks all of them in one wavefront: 12
+/// dependent steps, 15 us for a launch of 32 wavefronts), the partial tiles meet in LDS; the last workgroup to finish selects every
+/// query's cut (flat_cut_kernel's selection: one launch and its gap less).  The words differ from the scan's in the last bits (another
+/// summation order): the cut is a threshold, whatever it is the scan reports it as the bound of what it dropped.
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) void flat_sample_few_kernel(const uint4 * H, uint32_t nch, const uint4 * Qh, const float2 * qinfo,
+                                                                 const float * xnorm, uint32_t gs, uint32_t nq, uint32_t * sample_out,
+                                                                 uint32_t blk_stride, uint32_t n_total, const uint32_t * ids,
+                                                                 const uint64_t * alive, uint32_t nbits, uint32_t mth, uint32_t * qthr,
+                                                                 uint32_t * qcnt, uint32_t * ticket)
+{
+    __shared__ float part_s[BLOCK / WAVE][16][WAVE];
+    __shared__ __attribute__((aligned(16))) uint32_t hist_s[BLOCK / WAVE][256];
+    __shared__ uint32_t last_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const uint32_t g = blockIdx.x, n_pad = gs * H_ROWS;
+    const uint32_t ql = r32 < nq ? r32 : nq - 1;
+    const float2 qi = qinfo[ql];
+    const u32x4 * const ap = reinterpret_cast<const u32x4 *>(Qh) + (size_t)ql * nch * 8 + h;
+    const u32x4 * const bp = reinterpret_cast<const u32x4 *>(H) + (size_t)g * blk_stride * nch * 256 + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        acc[r] = 0.f;
+    u32x4 ar[2][4], br[2][4];
+    auto load = [&](const int b, const uint32_t c) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            ar[b][j] = ap[(size_t)c * 8 + 2 * j];
+            br[b][j] = bp[(size_t)c * 256 + j * 64];
+        }
+    };
+    auto mul = [&](const int b) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ar[b][j]), __builtin_bit_cast(half8, br[b][j]), acc, 0, 0, 0);
+    };
+    if (wave < nch)
+    {
+        load(0, wave);
+        for (uint32_t c = wave; c < nch; c += 2 * (BLOCK / WAVE))
+        {
+            const uint32_t c1 = c + BLOCK / WAVE, c2 = c + 2 * (BLOCK / WAVE);
+            if (c1 < nch)
+                load(1, c1);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c1 >= nch)
+                break;
+            if (c2 < nch)
+                load(0, c2);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        part_s[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave == 0)
+    {
+        const uint32_t row = g * H_ROWS + r32;               // the output slot
+        const uint32_t srow = g * blk_stride * H_ROWS + r32; // in the table
+        bool ok = srow < n_total;
+        const float xn = ok && METRIC == M_L2 ? xnorm[srow] : 0.f;
+        if (ok && alive)
+        {
+            const uint32_t id = ids ? ids[srow] : srow;
+            ok = id < nbits && ((alive[id >> 6] >> (id & 63)) & 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            // accumulator register i = query (i & 3) + 8 (i >> 2) + 4 h of the tile, row r32 (as in coarse_h16_kernel)
+            const int qidx = (i & 3) + 8 * (i >> 2) + 4 * (int)h;
+            const float a4 = __fadd_rn(__fadd_rn(part_s[0][i][lane], part_s[1][i][lane]), __fadd_rn(part_s[2][i][lane], part_s[3][i][lane]));
+            const float m2 = __shfl(qi.x, qidx), qn = __shfl(qi.y, qidx);
+            const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2, a4, xn), qn) : __fmul_rn(m2, a4);
+            const uint64_t key = ok ? make_key<METRIC>(v, srow) : KEY_NONE;
+            if ((uint32_t)qidx < nq)
+                sample_out[(size_t)qidx * n_pad + row] = (uint32_t)(key >> 32);
+        }
+    }
+    // the last workgroup selects the cuts
+    __threadfence();
+    __syncthreads();
+    if (tid == 0)
+        last_s = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_s)
+        return;
+    __threadfence();
+    for (uint32_t q = wave; q < nq; q += BLOCK / WAVE)
+    {
+        uint32_t word[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++)
+        {
+            const uint32_t i = u * WAVE + lane;
+            word[u] = i < n_pad ? __builtin_nontemporal_load(&sample_out[(size_t)q * n_pad + i]) : 0xFFFFFFFFu;
+        }
+        const uint32_t cut = wave_kth_word<32>(word, mth, hist_s[wave], lane);
+        if (lane == 0)
+        {
+            qthr[q] = cut;
+            qcnt[q] = 0;
+        }
+    }
+    if (tid == 0)
+        *ticket = 0;
+}
+
 /// The trivial plan: pairs of list g = (query i, g) for every i; pair index = i * G + g.
 static __global__ void coarse_plan_kernel(uint32_t nq, uint32_t G, uint32_t * pairs, uint32_t * pair_off, uint32_t * work_off)
 {

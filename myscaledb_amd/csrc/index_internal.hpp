@@ -143,6 +143,19 @@ struct ProbeWords
     const uint32_t * given = nullptr; // with given_probes
     uint32_t * out = nullptr;         // with probes_only (0xFFFFFFFF where the coarse pass left no word)
 };
+/// A host-pointer search of a few queries over a FLAT shadow (search_entry.hip: flat_few_search_host) arms this before it calls
+/// index_search_device: the table pass then ends with a one-thread launch that copies the certificate-failure count to `nfail` and
+/// sets `flag` to `seq` (both in pinned memory), waits for the word itself, and runs the canonical fallback only when somebody
+/// failed -- the two (normally empty) fallback launches, both result copies and the stream synchronisation leave the call.
+struct HostSignal
+{
+    uint32_t * flag = nullptr;
+    uint32_t * nfail = nullptr;
+    uint32_t seq = 0;
+    bool armed = false, used = false;
+};
+HostSignal & host_signal();
+
 void index_search_device(const msvs_index & ix, const float * d_queries /* nq x dim, dense */, size_t nq, uint32_t k, size_t nprobe,
                          const uint64_t * d_alive, size_t nbits, int64_t * d_ids, float * d_dis, hipStream_t stream,
                          const int32_t * given_probes = nullptr, int32_t * probes_only = nullptr, const SearchView * view = nullptr,

@@ -524,6 +524,19 @@ static void run_fallback_rounds(int metric, ScanParams c, IvfMergeParams fm, siz
 
 static void set_error_model_h16(RerankParams & rp, size_t dim, float rho_table = -1.f, const float * qrho = nullptr);
 
+HostSignal & host_signal()
+{
+    static thread_local HostSignal s;
+    return s;
+}
+
+static __global__ void host_signal_kernel(const uint32_t * nfail, uint32_t * h_nfail, uint32_t * h_flag, uint32_t seq)
+{
+    *h_nfail = *nfail;
+    __builtin_amdgcn_s_waitcnt(0);
+    __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // the re-rank's result stores ended with its launch
+}
+
 /// Second half of a table pass, whatever produced the candidates: canonical re-rank + certificate, then the canonical scan
 /// of the table for the queries on the fail list.
 static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, const ScanParams & a, size_t nq, const float * qnorm,
@@ -582,6 +595,34 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
     fm.cosine = t.cosine;
     fm.qmap = failq;
     fm.qcount = nfail;
+    HostSignal & hs = host_signal();
+    if (hs.armed && t.flat_h16 && !t.out_probes)
+    {
+        // host-pointer call of a few queries: tell the host, let it decide about the fallback
+        hs.armed = false;
+        hs.used = true;
+        hipLaunchKernelGGL(host_signal_kernel, dim3(1), dim3(1), 0, stream, nfail, hs.nfail, hs.flag, hs.seq);
+        MSVS_HIP(hipGetLastError());
+        for (uint64_t spins = 1; __atomic_load_n(hs.flag, __ATOMIC_ACQUIRE) != hs.seq; spins++)
+        {
+            __builtin_ia32_pause();
+            if ((spins & 0xfff) == 0) // a failed launch never sets the word: look at the stream now and then
+            {
+                const hipError_t e = hipStreamQuery(stream);
+                if (e == hipSuccess)
+                    break;
+                if (e != hipErrorNotReady)
+                    fail(MSVS_ERR_DEVICE, "few-query search: %s", hipGetErrorString(e));
+            }
+        }
+        if (__atomic_load_n(hs.flag, __ATOMIC_ACQUIRE) != hs.seq)
+            MSVS_HIP(hipStreamSynchronize(stream));
+        if (*hs.nfail == 0)
+            return;
+        run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, slots, stream);
+        MSVS_HIP(hipStreamSynchronize(stream));
+        return;
+    }
     run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, slots, stream);
 }
 
@@ -646,7 +687,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
     const uint32_t sample = two_phase
         ? (uint32_t)std::min<size_t>(t.n / 2, round_up(std::max<size_t>(32768, t.n / 32), (size_t)rpb))
         : 0;
-    if (two_phase)
+    if (two_phase && !t.h16 && !t.flat_h16) // (the shadow passes sample their own way)
     {
         launch_single_list_plan((uint32_t)nq, 0, sample, rpb, tq, pairs, probes0, list_off + 2, small, small + 5,
                                 stream);
@@ -782,7 +823,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         float2 * qinfo = scr.take<float2>(nq);
         float * qrho = scr.take<float>(nq);
         uint32_t * sample = scr.take<uint32_t>(nq * (size_t)n_pad);
-        uint32_t * sched = scr.take<uint32_t>(8);
+        uint32_t * sched = scr.take<uint32_t>(9); // 8 item cursors of the scan + the sample's ticket
         H16PrepAux aux{};
         aux.pairs = pairs;
         aux.probes0 = probes0;
@@ -794,9 +835,24 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         aux.rows_per_block = rpb;
         aux.tq = tq;
         aux.zero[0] = sched;
-        aux.nzero[0] = 8;
+        aux.nzero[0] = 9;
         hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq, (uint32_t)nq, ld,
                            ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, aux, qrho);
+        // ~target rows of the whole table below the cut: the m-th smallest of the S sample rows, m = target S / n (the sample is a
+        // 1 / blk_stride share of the table), at least 4 (the certificate fails when fewer than k rows lie below the cut)
+        const size_t target = std::max<size_t>(64, 25 * (size_t)t.k);
+        const uint32_t mth = (uint32_t)std::min<size_t>(64, std::max<size_t>(4, ceil_div(target * n_pad, std::max<size_t>(t.n, 1))));
+        const bool few = nq <= 32 && options().flat_sample_few != 0; // one query tile: sample and cut in one launch
+        if (few)
+        {
+            if (scan_metric(m) == M_IP)
+                hipLaunchKernelGGL((flat_sample_few_kernel<M_IP>), dim3(gs), dim3(BLOCK), 0, stream, ix.shadow.p, ix.h_nch, qh, qinfo, t.norms, gs,
+                                   (uint32_t)nq, sample, blk_stride, nrows, t.ids, t.alive, a.nbits, mth, qstate, qstate + nq, sched + 8);
+            else
+                hipLaunchKernelGGL((flat_sample_few_kernel<M_L2>), dim3(gs), dim3(BLOCK), 0, stream, ix.shadow.p, ix.h_nch, qh, qinfo, t.norms, gs,
+                                   (uint32_t)nq, sample, blk_stride, nrows, t.ids, t.alive, a.nbits, mth, qstate, qstate + nq, sched + 8);
+        }
+        else
         {
             const uint32_t items = (uint32_t)(ceil_div((size_t)gs, (size_t)2) * ceil_div(ceil_div(nq, (size_t)32), (size_t)2));
             const uint32_t cgrid = (uint32_t)std::min<size_t>(ceil_div((size_t)items, (size_t)4), (size_t)device_cu_count() * 2);
@@ -807,12 +863,9 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
                 hipLaunchKernelGGL((coarse_h16_kernel<M_L2>), dim3(cgrid), dim3(BLOCK), 0, stream, ix.shadow.p, ix.h_nch, qh, qinfo, t.norms,
                                    n_pad, (uint32_t)nq, sample, blk_stride, nrows, t.ids, t.alive, a.nbits);
         }
-        // ~target rows of the whole table below the cut: the m-th smallest of the S sample rows, m = target S / n (the sample is a
-        // 1 / blk_stride share of the table), at least 4 (the certificate fails when fewer than k rows lie below the cut)
-        const size_t target = std::max<size_t>(64, 25 * (size_t)t.k);
-        const uint32_t mth = (uint32_t)std::min<size_t>(64, std::max<size_t>(4, ceil_div(target * n_pad, std::max<size_t>(t.n, 1))));
-        hipLaunchKernelGGL(flat_cut_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, mth,
-                           qstate, qstate + nq);
+        if (!few)
+            hipLaunchKernelGGL(flat_cut_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, mth,
+                               qstate, qstate + nq);
         H16Params h{};
         h.H = ix.shadow.p;
         h.nks = ix.h_nks;

@@ -242,6 +242,43 @@ void lat_search_host(const msvs_index & ix, const float * queries, size_t nq, ui
 }
 }
 
+namespace
+{
+/// See index_search_host_call.  The device-level search reads the queries from pinned memory (dense, ix.dim floats per row) and
+/// writes ids / distances to pinned memory; when the table pass used the signal the results are complete at its return.
+void flat_few_search_host(const msvs_index & ix, const float * queries, size_t nq, uint32_t k, int64_t * ids, float * dis, hipStream_t stream)
+{
+    LatCtx & c = lat_ctx(stream);
+    const size_t o_ids = round_up(16 * ix.dim * 4, (size_t)256), o_dis = o_ids + 16 * 40 * 8, o_flag = o_dis + 16 * 40 * 4;
+    c.need_pinned(std::max<size_t>(o_flag + 256, c.pinned_bytes));
+    float * hq = reinterpret_cast<float *>(c.pinned);
+    memcpy(hq, queries, nq * ix.dim * 4);
+    int64_t * h_ids = reinterpret_cast<int64_t *>(c.pinned + o_ids);
+    float * h_dis = reinterpret_cast<float *>(c.pinned + o_dis);
+    uint32_t * flag = reinterpret_cast<uint32_t *>(c.pinned + o_flag);
+    HostSignal & hs = host_signal();
+    hs.flag = flag;
+    hs.nfail = flag + 16;
+    hs.seq = ++c.seq ? c.seq : ++c.seq; // never 0: the word starts at 0
+    hs.armed = true;
+    hs.used = false;
+    try
+    {
+        index_search_device(ix, hq, nq, k, 1, nullptr, 0, h_ids, h_dis, stream);
+    }
+    catch (...)
+    {
+        hs.armed = false;
+        throw;
+    }
+    hs.armed = false;
+    if (!hs.used) // another path served the call (a small table, an option): its results are in flight
+        MSVS_HIP(hipStreamSynchronize(stream));
+    memcpy(ids, h_ids, nq * k * 8);
+    memcpy(dis, h_dis, nq * k * 4);
+}
+}
+
 extern "C" int msvs_index_search_device(const msvs_index_t * ix, const float * d_queries, size_t nq, int k, int nprobe,
                                         const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids, float * d_dis,
                                         void * hip_stream)
@@ -311,6 +348,15 @@ int index_search_host_call(const msvs_index_t * ix, const float * queries, size_
         {
             // a few queries: two launches, queries and results through pinned memory (no copies, no stream sync)
             lat_search_host(*ix, queries, nq, (uint32_t)k, (size_t)nprobe, eff, eff_bits, ids, dis, stream);
+            return;
+        }
+        if (ix->type == MSVS_INDEX_FLAT && !eff_filtered && nq < 16 && (size_t)k <= 40 && ix->shadow_ready && options().flat_few != 0
+            && options().flat_host_signal != 0 && !(meta && meta->row_ids_n))
+        {
+            // a few queries over a FLAT index (VIWithDataPart.cpp:922-926 with IndexType::FLAT: one query per call): queries in and
+            // results out through pinned memory, a completion word instead of copies + synchronisation, the canonical fallback
+            // launched only when a certificate failed (HostSignal, index_internal.hpp)
+            flat_few_search_host(*ix, queries, nq, (uint32_t)k, ids, dis, stream);
             return;
         }
         MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
