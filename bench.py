@@ -62,6 +62,7 @@ MFMA_F16_PEAK_TF = 2500.0  # dense fp16 matrix peak (MI355X_MICROARCH.md; the 5 
 
 LATENT_DIM = 32
 N_BLOBS = 1024
+MID_BLOBS = 64  # the `mid` model: fewer blobs than lists
 
 
 def _latent_model(d, seed, device, blobs=N_BLOBS):
@@ -144,6 +145,12 @@ def data_model(kind, n, nq, d, device):
         return (_sample(model, n, g, device), _sample(model, nq, gq, device).contiguous(),
                 "1024-blob gaussian mixture in a 32-d latent space embedded in R^%d + 0.05 noise, seeds 99 / 1234 / 4321 (the model "
                 "rounds 1-3 quoted; not one of SURVEY 8d's)" % d)
+    if kind == "mid":
+        model = _latent_model(d, 99, device, blobs=MID_BLOBS)
+        return (_sample(model, n, g, device), _sample(model, nq, gq, device).contiguous(),
+                "%d-blob gaussian mixture in a 32-d latent space (centres 3 N(0,I), unit spread) embedded in R^%d + 0.05 noise, seeds 99 / 1234 / "
+                "4321: 16 lists per blob -- a query's neighbours lie in several lists of its blob (recall@10 0.29 / 0.69 / 0.90 / 0.999 at nprobe "
+                "1 / 4 / 8 / 16), the other blobs' lists can be pruned: the regime between SURVEY 8d's two models" % (MID_BLOBS, d))
     raise SystemExit("unknown data model %r" % kind)
 
 
@@ -356,13 +363,13 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--streams", type=int, default=1,
                     help="independent batches in flight on one GPU: step i runs on HIP stream i %% streams (N = 1 only)")
-    ap.add_argument("--data", default="blobs03", choices=("blobs03", "iid", "latent32"),
+    ap.add_argument("--data", default="blobs03", choices=("blobs03", "iid", "latent32", "mid"),
                     help="data model of the headline: SURVEY 8d's clustered variant (default), its iid one, or the 32-d latent mixture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the 3-stream side measurement (kernel traces of the single-stream steps)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps + the roofline pass (profiler runs)")
-    ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,blobs03,latent32,target,c1,c3,c4,c5,cpu")
+    ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,blobs03,latent32,mid,target,c1,c3,c4,c5,cpu")
     ap.add_argument("--only", default="", help="comma list of legs to run (the others are skipped; the headline always runs)")
     ap.add_argument("--c4-rows", type=int, default=12_500_000, help="rows per GPU of the C4 leg (100M / 8)")
     ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the C3 / C5 legs")
@@ -372,7 +379,7 @@ def main():
                          "code path of this script on a one-GPU box (not a measurement)")
     args = ap.parse_args()
     skip = set(x for x in args.skip.split(",") if x)
-    ALL_LEGS = ("other_batches", "latency", "iid", "blobs03", "latent32", "target", "c1", "c3", "c4", "c5", "cpu")
+    ALL_LEGS = ("other_batches", "latency", "iid", "blobs03", "latent32", "mid", "target", "c1", "c3", "c4", "c5", "cpu")
     if args.only:
         skip |= set(ALL_LEGS) - set(x for x in args.only.split(",") if x)
 
@@ -539,13 +546,9 @@ def main():
     bytes_moved = rows_read * (2 * d + 8) if cand_pass else bytes_alg
     achieved = bytes_alg / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     moved_gbs = bytes_moved / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # (HBM traffic from the PMC counters is NOT measured inside this run: the FETCH_SIZE / WRITE_SIZE passes of the same step are
+    # kept under profiles/ -- traffic.json, rNN_pmc_*.txt -- and the line says null rather than quoting another run's number)
     traffic = None
-    tp = os.path.join(ROOT, "profiles", "traffic.json")
-    if world == 1 and os.path.exists(tp):
-        with open(tp) as f:
-            tj = json.load(f)
-        if tj.get("batch") == B and tj.get("rows") == n and tj.get("dim") == d and tj.get("data", "latent32") == args.data:
-            traffic = tj.get("hbm_bytes_per_step")
     # matrix-core work of the same launches: fp16 MFMA, 2 flop per (query, probed row, element padded to 64)
     mfma_tf = rows_model * 2 * ((d + 63) // 64 * 64) / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 and cand_pass else 0.0
     if world > 1:
@@ -563,8 +566,6 @@ def main():
         "whole_step_gbs": round(bytes_moved / (step_ms * 1e-3) / 1e9, 1),
         "whole_step_frac": round(bytes_moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "non_scan_ms_per_step": round(step_ms - scan_ms, 4),
-        "f32_equiv_bytes_per_launch": int(bytes_alg), "f32_equiv_gbs": round(achieved, 1),
-        "f32_equiv_frac": round(achieved / HBM_PEAK_GBS, 4),
         "mfma_tflops": round(mfma_tf, 1), "mfma_frac_of_2500": round(mfma_tf / 2500.0, 4),
         "per_query_model_gbs": round(rows_model * (4 * d + 4) / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else None,
         "prefilter": [pf1[0] - pf0[0], pf1[1] - pf0[1]],
@@ -572,9 +573,8 @@ def main():
         "step_kernels_ms": {f: round(v, 4) for f, v in fam.items() if v},
         "note": "achieved / frac = the bytes the two launches READ -- the rows of the lists their plans hold (counted on the device: the probe pruning keeps lists out of them; rows_probed_union_per_step is what the reference's scan would visit) x (2d + 8) B: the fp16 "
                 "shadow row, its f32 norm and its id -- / (sample + main launch time, HIP events on the launch stream); "
-                "whole_step_* = the same bytes over the whole step; f32_equiv_* = the same rows x (4d + 4) B (SURVEY 8d's "
-                "per-row figure: credits bytes that never move, can exceed 1); traffic = FETCH_SIZE (x2, gfx950) + WRITE_SIZE of both "
-                "launches from rocprofv3 --pmc (profiles/); prefilter = (queries through the candidate pass, queries that needed "
+                "whole_step_* = the same bytes over the whole step; traffic: null here -- the FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of "
+                "this step live in profiles/ (traffic.json: 1.045 x the rows read); prefilter = (queries through the candidate pass, queries that needed "
                 "the canonical fallback) during the profiled steps; per_query_model_gbs exceeds HBM speed because one pass over "
                 "a list serves every query of the step that probes it",
     }
@@ -787,7 +787,15 @@ def main():
             uni = sum(iix.scanned_rows(qi[j * B:(j + 1) * B].cpu().numpy(), npb)[2] for j in range(2)) / 2
             sc = fo["ivf_scan"] + fo["ivf_sample_scan"]
             mv = rows_read_per_step(istep, 2) * (2 * d + 8)
+            capi.set_option("rerank_stats", "1")
+            ps0 = capi.debug_prune_stats()
+            for i in range(2):
+                istep(i)
+            torch.cuda.synchronize()
+            ps1 = capi.debug_prune_stats()
+            capi.set_option("rerank_stats", None)
             return {"nprobe": npb, "qps": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "list_scan_ms": round(sc, 4),
+                    "pruned_pair_fraction": round((ps1[0] - ps0[0]) / float(2 * B * npb), 4),  # (query, list) pairs dropped / pairs probed, two steps
                     "union_rows_per_step": int(uni), "rows_read_per_step": int(mv / (2 * d + 8)),
                     "roofline_frac": round(mv / (sc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sc else None,
                     "whole_step_frac": round(mv / dt / 1e9 / HBM_PEAK_GBS, 4),
@@ -796,6 +804,32 @@ def main():
         if op is not None:
             del xi
             res["at_recall_0.95"] = run_at(op)
+            if kind == "mid":
+                # the metric's other half at this operating point: one query per msvs_index_search call (host pointers), and the CPU
+                # port on the exported index structure beside it (bounded sample)
+                for i in range(30):
+                    iix.search(qh[i:i + 1], k, "nprobe=%d" % op)
+                lat1 = np.empty(1500)
+                for i in range(1500):
+                    t2 = time.perf_counter()
+                    iix.search(qh[i % 1000:i % 1000 + 1], k, "nprobe=%d" % op)
+                    lat1[i] = time.perf_counter() - t2
+                res["at_recall_0.95"]["single_query_p50_us"] = round(float(np.percentile(lat1, 50)) * 1e6, 1)
+                res["at_recall_0.95"]["single_query_p99_us"] = round(float(np.percentile(lat1, 99)) * 1e6, 1)
+                if not args.no_cpu_baseline and "cpu" not in skip:
+                    from oracle import oracle as o
+                    cent, off, vecs, lids = iix.export()
+                    cores = cpu_cores()
+                    o.simd_ivf_search(cent, off, vecs, lids, qh[:cores], op, k, o.METRIC_L2, cores)
+                    nqs = min(1000, 16 * cores)
+                    t2 = time.perf_counter()
+                    si, _ = o.simd_ivf_search(cent, off, vecs, lids, qh[:nqs], op, k, o.METRIC_L2, cores)
+                    cs = time.perf_counter() - t2
+                    oi_, od_, _ = o.ivf_search(cent, off, vecs, lids, qh[:64], op, k, o.METRIC_L2, threads=cores)
+                    gi_, gd_ = iix.search(qh[:64], k, "nprobe=%d" % op)
+                    res["at_recall_0.95"]["cpu_port"] = {"qps": round(nqs / cs, 1), "cores": cores, "queries": nqs, "kind": "port",
+                                                         "oracle_check_64_queries_bit_identical": bool((oi_ == gi_).all() and (od_.view(np.uint32) == gd_.view(np.uint32)).all())}
+                    del cent, off, vecs, lids
         else:
             # ... or, twice as fast, through the list scan's fp16 shadow: an IVFFLAT index of 256 lists with ALL of them probed
             # is an exhaustive scan too (every row is in some list; results exact as always), and its candidate pass reads
@@ -878,7 +912,7 @@ def main():
         iix.close()
         return res
 
-    for kind in ("blobs03", "iid", "latent32"):
+    for kind in ("blobs03", "iid", "latent32", "mid"):
         if solo and kind not in skip:
             leg(kind, lambda kind=kind: operating_point(kind), extra)
 
@@ -1233,7 +1267,8 @@ def main():
             def st(i):
                 terms, dfs, prep = ss[i % 3]
                 ps.bm25_search_batch_device(terms, dfs, nb, total, 100, o_i.data_ptr(), o_d.data_ptr(), stream, prepared=prep)
-            st(0)
+            for i_ in range(3):  # every query set once: the scratch arenas grow to the batch size before the clock runs
+                st(i_)
             torch.cuda.synchronize()
             d_ = timed(st, steps)
             by = np.mean([sum(int(x_.sum()) * 8 + min(int(x_.sum()), nb) for x_ in dfs) for _, dfs, _ in ss])
@@ -1241,7 +1276,7 @@ def main():
                     "algorithmic_mb_per_batch": round(by / 1e6, 1), "gbs": round(by / d_ / 1e9, 1),
                     "hbm_frac": round(by / d_ / 1e9 / HBM_PEAK_GBS, 4)}
         bm_more = {}
-        for B_, st_ in ((256, 8), (1024, 6), (4096, 3)):
+        for B_, st_ in ((256, 24), (1024, 18), (4096, 9)):
             try:
                 bm_more["bm25_batch%d" % B_] = bm25_leg(B_, st_)
             except Exception as e:  # (a leg must not cost the line)
@@ -1292,6 +1327,16 @@ def main():
                    "first_nprobe_with_recall_0.95": a95.get("nprobe", a95.get("chosen")), "qps_there": a95.get("qps"),
                    "ms_per_step_there": a95.get("ms_per_step"),
                    "value_is": "the rate at the configuration's nprobe = %d (recall %s)" % (nprobe, None if recall is None else round(recall, 4))}
+        mid_op = None
+        mm = extra.get("mid")
+        if isinstance(mm, dict) and "at_recall_0.95" in mm:
+            a95, a32 = mm["at_recall_0.95"], mm.get("at_config_nprobe") or mm["at_recall_0.95"]
+            mid_op = {"model": "mid", "data": mm.get("data"), "recall_by_nprobe": mm.get("recall_at_%d" % k),
+                      "first_nprobe_with_recall_0.95": a95.get("nprobe"),
+                      "there": {f: a95.get(f) for f in ("nprobe", "qps", "ms_per_step", "roofline_frac", "whole_step_frac", "pruned_pair_fraction",
+                                                        "rows_read_per_step", "union_rows_per_step", "single_query_p50_us", "single_query_p99_us", "cpu_port")},
+                      "at_nprobe_32": {f: a32.get(f) for f in ("nprobe", "qps", "ms_per_step", "roofline_frac", "whole_step_frac", "pruned_pair_fraction",
+                                                               "rows_read_per_step", "union_rows_per_step")}}
         out = {
             "metric": "QPS at recall@10>=0.95, 1Mx768-d L2 top-10 (IVFFLAT nlist=1024 nprobe=%d)" % nprobe,
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1312,10 +1357,11 @@ def main():
             "cpu_baseline": cpu,
             "other_batches": extra.get("other_batches"),
             "latency": extra.get("latency"),
-            "operating_points": ops,
+            "operating_points": dict(ops or {}, mid=mid_op) if (ops or mid_op) else None,
             "iid": extra.get("iid"),
             "blobs03": extra.get("blobs03"),
             "latent32": extra.get("latent32"),
+            "mid": extra.get("mid"),
             "target_100m": extra.get("target_100m"),
             "c4_sharded": extra.get("c4_sharded"),
             "other_configs": other_cfg or None,

@@ -308,6 +308,12 @@ def test_flat_shadow_few_queries_match_oracle(metric, n, d, k, opt):
     ids, dis = ix.search(q[:2], k)
     same(ids, dis, ei[:2], ed[:2])
     opt("ivf_eps_scale", None)
+    for knob in ("flat_host_signal", "flat_sample_few"):  # copies + stream synchronisation / the two-launch sample + cut
+        opt(knob, "0")
+        for nq in (1, 6):
+            ids, dis = ix.search(q[:nq], k)
+            same(ids, dis, ei[:nq], ed[:nq])
+        opt(knob, None)
     opt("flat_few", "0")  # the canonical f32 scan
     ids, dis = ix.search(q[:1], k)
     same(ids, dis, ei[:1], ed[:1])
