@@ -1033,6 +1033,105 @@ def test_few_query_path_equals_general_path_and_oracle(metric, d, opt):
             same(oi_t[:nq].cpu().numpy(), od_t[:nq].cpu().numpy(), hi, hd)
 
 
+GEOMETRIES = ["outlier_neighbour", "ties_across_the_cut", "k_equals_list_length", "short_lists_only", "zero_norm_rows",
+              "query_is_a_centroid"]
+
+
+def _adversarial_lists(geometry, rng, d=64, nlist=64):
+    """(centroids, rows, queries, k, nprobe) of a hand-made IVF structure (msvs_index_set_centroids: rows go to their nearest
+    centroid) that aims at one assumption of the radius bounds each."""
+    centres = (6.0 * rng.standard_normal((nlist, d))).astype(np.float32)
+    sizes = rng.integers(150, 500, nlist)
+    k, nprobe = 10, 16
+    if geometry == "k_equals_list_length":
+        sizes[::4] = k      # lists of exactly k rows: the smallest list that may give a bound
+        sizes[1::8] = 3     # shorter than k: no bound from them
+        sizes[2] = 0
+    if geometry == "short_lists_only":
+        sizes[:] = rng.integers(4, 31, nlist)  # every list shorter than one shadow block, k larger than every list
+        k = 40
+    x = np.concatenate([centres[i] + rng.standard_normal((int(sizes[i]), d)).astype(np.float32) for i in range(nlist) if sizes[i]]).astype(np.float32)
+    q = (centres[rng.integers(0, nlist, 320)] + rng.standard_normal((320, d))).astype(np.float32)
+    if geometry == "outlier_neighbour":
+        # one far row per list sets the list's radius -- and is the nearest row of a query sitting next to it
+        u = rng.standard_normal((nlist, d)).astype(np.float32)
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        far = (centres + 25.0 * u).astype(np.float32)
+        x = np.concatenate([x, far]).astype(np.float32)
+        q[:nlist] = far + 0.05 * rng.standard_normal((nlist, d)).astype(np.float32)
+        q[nlist:2 * nlist] = (centres + 12.0 * u).astype(np.float32)  # half way out: the outlier is among the k nearest of few of them
+    if geometry == "ties_across_the_cut":
+        # for the first queries: 6 copies of the row that would be their 8th neighbour (ranks 8 .. 13 tie across k = 10), and a row
+        # repeated in the rows of several lists
+        for j in range(40):
+            dist = np.linalg.norm(x - q[j], axis=1)
+            r8 = int(np.argsort(dist)[7])
+            x = np.concatenate([x, np.repeat(x[r8:r8 + 1], 5, axis=0)]).astype(np.float32)
+        x[10:14] = x[len(x) - 1]
+    if geometry == "zero_norm_rows":
+        x[rng.choice(len(x), 200, replace=False)] = 0.0  # a cosine index keeps them unnormalised: |x| = 0
+        q[5] = 0.0
+    if geometry == "query_is_a_centroid":
+        q[:nlist] = centres
+        q[nlist:nlist + 8] = x[:8]  # ... and queries equal to stored rows
+    return centres, x, q, k, nprobe
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_COSINE, capi.METRIC_IP])
+@pytest.mark.parametrize("geometry", GEOMETRIES)
+def test_radius_bounds_on_adversarial_geometry(geometry, metric, opt):
+    """The pruning proofs (h16_scan_kernels.hpp: pre-pruning by the list radius, the sample-based second stage; latency_kernels.hpp:
+    lat_cut) are only as good as their premises: a list whose radius is one far outlier that IS the query's neighbour, ties across
+    the k-th rank, lists of exactly k rows / shorter than k / shorter than a shadow block, k larger than every probed list, zero
+    rows in a cosine index, queries equal to centroids or stored rows.  A wrong drop is silent -- so: ids and distance bits of the
+    pruned batch search, of the unpruned one and of the few-query path == the oracle's scan of every probed list, and the counters
+    show that the pruning did look at the batch (and, where the geometry allows a proof, that it dropped pairs)."""
+    rng = np.random.default_rng(7 + GEOMETRIES.index(geometry))
+    centres, x, q, k, nprobe = _adversarial_lists(geometry, rng)
+    d, nlist = x.shape[1], centres.shape[0]
+    ix = capi.Index(capi.INDEX_IVFFLAT, metric, d, "ncentroids=%d" % nlist)
+    ix.set_centroids(centres)
+    ix.add(x)
+    ix.build()
+    oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+    opt("rerank_stats", "1")
+    dropped = {}
+    for prune, pre in (("2", "1"), ("2", "0"), ("0", "0")):
+        opt("h16_prune", prune)
+        opt("h16_preprune", pre)
+        s0 = capi.debug_prune_stats()
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+        s1 = capi.debug_prune_stats()
+        dropped[(prune, pre)] = (s1[0] - s0[0], s1[1] - s0[1])
+        for nqs in (40, 7):  # a small batch (canonical coarse scan feeds the pre-pruning), a handful
+            ids, dis = ix.search(q[:nqs], k, "nprobe=%d" % nprobe)
+            same(ids, dis, oi[:nqs], od[:nqs])
+    # (lists shorter than k give no bound and the shadow pass may not be chosen at all; inner-product indexes of this size keep the
+    # canonical scan: results only)
+    if geometry != "short_lists_only" and metric != capi.METRIC_IP:
+        assert dropped[("2", "1")][1] >= q.shape[0] * nprobe, "the pruning did not look at the batch: %r" % (dropped,)
+        if metric == capi.METRIC_L2:
+            assert dropped[("2", "1")][0] > 0, "well separated lists and nothing dropped: %r" % (dropped,)
+    assert dropped[("0", "0")][0] == 0
+    opt("ivf_eps_scale", "1e12")  # no certificate: the canonical fallback over the pre-pruned probe lists
+    opt("h16_prune", "2")
+    opt("h16_preprune", "1")
+    ids, dis = ix.search(q[:64], k, "nprobe=%d" % nprobe)
+    same(ids, dis, oi[:64], od[:64])
+    opt("ivf_eps_scale", None)
+    # one and two queries per call: the latency path with its radius cut (L2), and without
+    opt("lat_path", "2")
+    for lp in ("1", "0"):
+        opt("lat_prune", lp)
+        for j0 in (0, 2, 64, 65, 130):
+            for nqc in (1, 2):
+                ids, dis = ix.search(q[j0:j0 + nqc], k, "nprobe=%d" % nprobe)
+                same(ids, dis, oi[j0:j0 + nqc], od[j0:j0 + nqc])
+    for name in ("lat_prune", "lat_path", "h16_prune", "h16_preprune", "rerank_stats"):
+        opt(name, None)
+
+
 def test_few_query_path_radius_pruning_keeps_the_oracle_result(opt):
     """One or two queries per call on an L2 index: stage 1's last block drops the probed lists that the list radius rules out
     ((||q - c_l|| - r_l)^2 beyond the smallest (||q - c_p|| + r_p)^2 over probed lists of >= k rows) and cuts stage 2's work from
