@@ -264,16 +264,26 @@ def test_product_sharded_search_two_processes_equals_unsharded(metric_name, typ)
     assert res[0][1]["stats"] == res[1][1]["stats"] == (2001, 60007, [11, 0, 2 ** 41 + 1])
 
 
-def _pruned_case():
+def _pruned_case(geometry="blobs"):
     rng = np.random.default_rng(77)
     n, d, nlist, nq = 60000, 64, 256, 800  # (the centroid-shadow coarse pass -- the source of the probe words -- serves nlist >= 256)
     centres = 4.0 * rng.standard_normal((nlist, d), dtype=np.float32)
     x = (centres[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
     q = (centres[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    if geometry == "outlier_neighbour":
+        # adversarial for the radius bounds: one far row per list sets its radius and IS the nearest row of a query next to it; ties
+        # across the k-th rank; lists of exactly k rows do not exist here, zero rows do (cosine keeps them unnormalised)
+        u = rng.standard_normal((nlist, d)).astype(np.float32)
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        far = (centres + 18.0 * u).astype(np.float32)
+        x = np.concatenate([x, far, np.repeat(x[7:8], 6, axis=0), np.zeros((5, d), np.float32)]).astype(np.float32)
+        q[:nlist] = far + 0.05 * rng.standard_normal((nlist, d)).astype(np.float32)
+        q[nlist] = x[7]
+        q[nlist + 1:nlist + 9] = centres[:8]
     return x, q, centres, nlist, 10, 8
 
 
-def _pruned_worker(rank, world, port, metric_name, out):
+def _pruned_worker(rank, world, port, metric_name, out, geometry="blobs"):
     """The sharded search with the probe pruning ON on every rank: the coarse pass of a query runs on ONE rank, its distance word
     per probe travels with the probe lists (ProbeWords), and every rank prunes the pairs of its own lists."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -284,7 +294,7 @@ def _pruned_worker(rank, world, port, metric_name, out):
         from myscaledb_amd import sharded
         capi.set_device(0)
         metric = {"L2": capi.METRIC_L2, "IP": capi.METRIC_IP, "cosine": capi.METRIC_COSINE}[metric_name]
-        x, q, centres, nlist, k, nprobe = _pruned_case()
+        x, q, centres, nlist, k, nprobe = _pruned_case(geometry)
         ix = capi.Index(capi.INDEX_IVFFLAT, metric, x.shape[1], "ncentroids=%d,shard_rank=%d,shard_world=%d" % (nlist, rank, world))
         ix.set_centroids(centres)
         ix.add(x)
@@ -318,14 +328,15 @@ def _pruned_worker(rank, world, port, metric_name, out):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("metric_name", ["L2", "cosine", "IP"])
-def test_product_sharded_search_prunes_on_every_rank_and_equals_unsharded(metric_name):
+@pytest.mark.parametrize("metric_name,geometry", [("L2", "blobs"), ("cosine", "blobs"), ("IP", "blobs"),
+                                                  ("L2", "outlier_neighbour"), ("cosine", "outlier_neighbour")])
+def test_product_sharded_search_prunes_on_every_rank_and_equals_unsharded(metric_name, geometry):
     import myscaledb_amd.capi as capi
     world = 2
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pruned_worker, args=(r, world, port, metric_name, out)) for r in range(world)]
+    procs = [ctx.Process(target=_pruned_worker, args=(r, world, port, metric_name, out, geometry)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
@@ -333,7 +344,7 @@ def test_product_sharded_search_prunes_on_every_rank_and_equals_unsharded(metric
         p.join(60)
         assert p.exitcode == 0
     metric = {"L2": capi.METRIC_L2, "IP": capi.METRIC_IP, "cosine": capi.METRIC_COSINE}[metric_name]
-    x, q, centres, nlist, k, nprobe = _pruned_case()
+    x, q, centres, nlist, k, nprobe = _pruned_case(geometry)
     ix = capi.Index(capi.INDEX_IVFFLAT, metric, x.shape[1], "ncentroids=%d" % nlist)
     ix.set_centroids(centres)
     ix.add(x)
