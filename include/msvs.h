@@ -312,6 +312,17 @@ MSVS_API int msvs_comm_size(const msvs_comm_t * comm);
 MSVS_API int msvs_shard_search_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries,
                                       size_t nq, int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits,
                                       int64_t * d_ids, float * d_dis, void * hip_stream);
+/* The ROUTED form (round 5): every rank brings its OWN batch (nq may differ per rank, 0 included) and gets the results of its own
+ * queries -- the queries that arrived at this server, StorageDistributed.cpp:1213-1255 -- instead of every rank working through the
+ * same batch.  A query's coarse quantiser and the pre-pruning by the list radius (over the lists of the whole index) run on its home
+ * rank; the query then visits only the ranks that own lists it still needs (ncclSend / ncclRecv of the exact sizes, grouped), each of
+ * which returns the exact top-k over its lists; the home rank merges (MergeTreeBaseSearchManager.cpp:207-299).  ids and distances
+ * == the unsharded index's, bit for bit.  IVFFLAT shards, unfiltered, <= 32 ranks; COLLECTIVE: every rank of the communicator calls
+ * it for every step (the one host synchronisation of the step reads the rank x rank count matrix).  routed_pairs (nullable): the
+ * (query, rank) pairs this rank served -- its share of the step's list-scan work.  A caller-supplied transport (msvs_comm_init_custom)
+ * emulates the point-to-point exchange with its all-gather (tests). */
+MSVS_API int msvs_shard_search_routed_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries, size_t nq,
+                                             int k, int nprobe, int64_t * d_ids, float * d_dis, void * hip_stream, uint64_t * routed_pairs);
 /* The same search with TWO BATCHES IN FLIGHT: the call returns once batch i is enqueued; `hip_stream` orders its INPUTS only,
  * its results are complete when *done_event -- a hipEvent_t owned by the communicator, valid until the second-next async call on
  * it -- has fired: hipStreamWaitEvent on whatever stream reads d_ids / d_dis, or msvs_shard_search_drain.  The coarse pass and

@@ -36,7 +36,7 @@ SYMBOLS = [
     "msvs_bin_index_add", "msvs_bin_index_num_data", "msvs_bin_index_search", "msvs_bin_index_serialize_io", "msvs_bin_index_load_io",
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
     "msvs_index_set_merged_maps", "msvs_comm_unique_id", "msvs_comm_init", "msvs_comm_init_custom",
-    "msvs_comm_free", "msvs_comm_all_reduce_u64", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device", "msvs_shard_search_device_async", "msvs_shard_search_drain",
+    "msvs_comm_free", "msvs_comm_all_reduce_u64", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device", "msvs_shard_search_device_async", "msvs_shard_search_drain", "msvs_shard_search_routed_device",
     "msvs_hybrid_fuse_device",
 ]
 
@@ -538,6 +538,16 @@ class Index:
                                               int(nprobe), C.c_void_p(int(d_alive)) if d_alive else None,
                                               C.c_size_t(nbits), C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
                                               C.c_void_p(int(stream)) if stream else None))
+
+    def shard_search_routed_device(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0):
+        """msvs_shard_search_routed_device: this rank's OWN nq queries (0 allowed), routed to the ranks that own lists they still need
+        after the pre-pruning; collective.  Returns the (query, rank) pairs this rank served."""
+        served = C.c_uint64(0)
+        _check(lib().msvs_shard_search_routed_device(self._h, comm._h, C.c_void_p(int(d_queries)) if d_queries else None, C.c_size_t(nq), int(k),
+                                                     int(nprobe), C.c_void_p(int(d_ids)) if d_ids else None,
+                                                     C.c_void_p(int(d_dis)) if d_dis else None,
+                                                     C.c_void_p(int(stream)) if stream else None, C.byref(served)))
+        return served.value
 
     def shard_search_device_async(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0):
         """msvs_shard_search_device_async: two batches in flight; returns the batch's done event (a hipEvent_t address)."""

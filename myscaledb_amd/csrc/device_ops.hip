@@ -56,7 +56,7 @@ namespace
 /// Every arena of the calling host thread, keyed by (device, stream).
 struct ThreadArenas
 {
-    std::map<std::pair<int, hipStream_t>, Scratch> scratch, staging, aux, shard, view;
+    std::map<std::pair<int, hipStream_t>, Scratch> scratch, staging, aux, shard, view, route;
 };
 thread_local ThreadArenas t_arenas;
 
@@ -73,12 +73,13 @@ Scratch & aux_for(hipStream_t stream) { return arena_in(t_arenas.aux, stream); }
 Scratch & shard_for(hipStream_t stream) { return arena_in(t_arenas.shard, stream); }
 Scratch & staging_for(hipStream_t stream) { return arena_in(t_arenas.staging, stream); }
 Scratch & view_for(hipStream_t stream) { return arena_in(t_arenas.view, stream); }
+Scratch & route_for(hipStream_t stream) { return arena_in(t_arenas.route, stream); }
 
 size_t release_thread_arenas()
 {
     size_t freed = 0;
     (void)hipDeviceSynchronize(); // nothing enqueued may still use them
-    for (auto * m : {&t_arenas.scratch, &t_arenas.staging, &t_arenas.aux, &t_arenas.shard, &t_arenas.view})
+    for (auto * m : {&t_arenas.scratch, &t_arenas.staging, &t_arenas.aux, &t_arenas.shard, &t_arenas.view, &t_arenas.route})
     {
         for (auto & kv : *m)
             freed += kv.second.buf.n;

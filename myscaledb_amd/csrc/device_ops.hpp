@@ -44,6 +44,7 @@ Scratch & staging_for(hipStream_t stream);
 Scratch & aux_for(hipStream_t stream);
 /// ... and one for the exchange buffers of a sharded search (probe lists, packed partial top-k of every rank).
 Scratch & shard_for(hipStream_t stream);
+Scratch & route_for(hipStream_t stream); // the routed sharded search's exchange buffers (shard.hip)
 /// ... and one for the compacted view of a filtered search and small per-filter counters.
 Scratch & view_for(hipStream_t stream);
 /// Free every arena of the calling host thread (after a device synchronisation); returns the bytes released.

@@ -88,6 +88,15 @@ struct msvs_index
         size_t inv_n = 0;
         uint32_t own_id = 0;
     };
+    // the routed sharded search (shard.hip): radius and length of every list of the WHOLE index (all ranks' shards) and the
+    // extremes of the row norms, gathered at the first routed search on a communicator
+    struct Global
+    {
+        DevBuf<float> radius;      // [nlist]
+        DevBuf<int64_t> list_off;  // [nlist + 1] prefix of the global list lengths
+        float xmax = 0.f, xmin = 0.f;
+    };
+    mutable std::shared_ptr<Global> global;
     mutable std::mutex meta_mu;
     std::shared_ptr<Meta> meta;
     std::shared_ptr<Meta> get_meta() const
@@ -142,6 +151,13 @@ struct ProbeWords
 {
     const uint32_t * given = nullptr; // with given_probes
     uint32_t * out = nullptr;         // with probes_only (0xFFFFFFFF where the coarse pass left no word)
+    // with probes_only, the routed sharded search (shard.hip): the pre-pruning by the list radius over the lists of the WHOLE index
+    // (radius and list lengths of every rank's lists, gathered once) -- pruned_out [nq][nprobe] gets the probes that survive (-1:
+    // dropped), all of them when the pre-pruning cannot run for this index / batch
+    const float * g_radius = nullptr;
+    const int64_t * g_list_off = nullptr;
+    float g_xmax = 0.f, g_xmin = 0.f; // max / min |x|^2 over the rows of every rank (the bounds' error terms)
+    int32_t * pruned_out = nullptr;
 };
 /// A host-pointer search of a few queries over a FLAT shadow (search_entry.hip: flat_few_search_host) arms this before it calls
 /// index_search_device: the table pass then ends with a one-thread launch that copies the certificate-failure count to `nfail` and

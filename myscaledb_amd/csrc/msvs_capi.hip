@@ -974,11 +974,14 @@ static void set_error_model_h16(RerankParams & rp, size_t dim, float rho_table, 
 
 /// The same model for the kernels that bound sample / centroid words (H16Prune): the rows' table and the centroid table each
 /// with its own measured rounding error.
-static void set_prune_error_model(H16Prune & pr, const msvs_index & ix, const float * qrho)
+/// remote_words: the coarse words were computed by ANOTHER rank's centroid shadow and query images (ProbeWords::given): its measured
+/// rounding errors are not known here -- the worst-case model covers them.  foreign_rows: the bound speaks about rows of other ranks
+/// (the routed search's pre-pruning over the whole index): the worst-case row error instead of this shard's measured one.
+static void set_prune_error_model(H16Prune & pr, const msvs_index & ix, const float * qrho, bool remote_words = false, bool foreign_rows = false)
 {
     RerankParams ex{}, ec{};
-    set_error_model_h16(ex, ix.dim, ix.h_rho, qrho);
-    set_error_model_h16(ec, ix.dim, ix.c_rho, qrho);
+    set_error_model_h16(ex, ix.dim, foreign_rows ? -1.f : ix.h_rho, qrho); // (the query images of the row scan are this rank's own)
+    set_error_model_h16(ec, ix.dim, remote_words ? -1.f : ix.c_rho, remote_words ? nullptr : qrho);
     pr.c_dot = ex.c_dot;
     pr.c_dot_c = ec.c_dot;
     pr.c_norm = ex.c_norm;
@@ -1211,7 +1214,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             // below that the second plan and the looser cut cost more than the dropped pairs save: sigma-0.3 blobs at nprobe 2)
             if (prune2)
             {
-                set_prune_error_model(pr, ix, qrho);
+                set_prune_error_model(pr, ix, qrho, !prepared.coarse_words && prepared.probe_words != nullptr);
                 pr.coarse_words = prepared.coarse_words;
                 pr.npad = prepared.coarse_npad;
                 pr.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
@@ -1503,6 +1506,51 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co,
                            stream);
     }
+    // 1b. pre-pruning by the list radius alone (h16_preprune_kernel): L2 and cosine indexes, unfiltered searches over the stored lists,
+    // whenever the coarse stage left distances behind -- approximate words (centroid shadow; a sharded search's probe words) or the
+    // canonical values of a small batch.  What it drops is gone for every path below, the canonical ones and the fallbacks included.
+    // radius / list_off: the index's own lists, or (the routed sharded search) those of the whole index.
+    auto preprune = [&](const int32_t * in_probes, const float * radius, const int64_t * list_off, int32_t * out_probes, bool keep_upre, float xmax,
+                        float xmin) -> bool {
+        if (!(options().h16_prune != 0 && options().h16_preprune != 0 && (ix.metric == MSVS_METRIC_L2 || ix.metric == MSVS_METRIC_COSINE) && !d_alive
+              && !view && radius && nprobe <= 64 && nprobe >= 2 && ix.cnorm_max < 1e30f && xmax < 1e30f
+              && (prepared.probe_dis || ((prepared.coarse_words || prepared.probe_words) && prepared.qnorm))))
+            return false;
+        H16Prune pr0{};
+        set_prune_error_model(pr0, ix, prepared.qh ? prepared.qrho : nullptr, !prepared.coarse_words && prepared.probe_words != nullptr,
+                              radius != ix.list_radius.p);
+        if (prepared.coarse_words || prepared.probe_words)
+        {
+            pr0.coarse_words = prepared.coarse_words;
+            pr0.npad = prepared.coarse_npad;
+            pr0.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
+            pr0.qnorm = prepared.qnorm;
+        }
+        else
+            pr0.probe_dis = prepared.probe_dis;
+        pr0.radius = radius;
+        pr0.xmax = xmax;
+        pr0.cmax = ix.cnorm_max;
+        const bool cosine_form = ix.metric == MSVS_METRIC_COSINE;
+        if (cosine_form)
+        {
+            pr0.ip = 1;
+            pr0.cnorm = ix.cnorm.p;
+            pr0.xmin = xmin;
+            pr0.Q = dq; // (normalised above)
+            pr0.ldq = ld;
+        }
+        pr0.k = k;
+        pr0.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
+        pr0.upre = cosine_form || !keep_upre ? nullptr : scr.take<float>(nq); // (an L2 bound: the cosine scan's second stage compares inner products)
+        ProfileScope prof("ivf_plan", stream);
+        hipLaunchKernelGGL(h16_preprune_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, in_probes, pr0, list_off,
+                           (uint32_t)nq, (uint32_t)nprobe, out_probes);
+        MSVS_HIP(hipGetLastError());
+        if (keep_upre)
+            prepared.upre = pr0.upre;
+        return true;
+    };
     if (probes_only)
     {
         if (words.out)
@@ -1514,52 +1562,23 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
             else
                 MSVS_HIP(hipMemsetAsync(words.out, 0xFF, nq * nprobe * 4, stream));
         }
+        if (words.pruned_out) // the routed sharded search: which probes (of ANY rank's lists) are worth a visit
+        {
+            // (xnorm_max / xnorm_min of a shard are those of its own rows: the routed entry refuses indexes whose bounds were not made
+            // global -- see shard.hip)
+            if (!(words.g_radius && words.g_list_off && preprune(probes_only, words.g_radius, words.g_list_off, words.pruned_out, false, words.g_xmax, words.g_xmin)))
+                MSVS_HIP(hipMemcpyAsync(words.pruned_out, probes_only, nq * nprobe * 4, hipMemcpyDeviceToDevice, stream));
+        }
         return;
     }
     if (given_probes)
         prepared.probe_words = words.given;
-    // 1b. pre-pruning by the list radius alone (h16_preprune_kernel): L2 indexes, unfiltered searches over the stored lists, whenever
-    // the coarse stage left distances behind -- approximate words (centroid shadow; a sharded search's probe words) or the canonical
-    // values of a small batch.  What it drops is gone for every path below, the canonical ones and the fallbacks included.
     const int32_t * all_probes = d_probes;
     (void)all_probes;
-    if (options().h16_prune != 0 && options().h16_preprune != 0 && (ix.metric == MSVS_METRIC_L2 || ix.metric == MSVS_METRIC_COSINE) && !d_alive && !view
-        && ix.list_radius.p
-        && nprobe <= 64 && nprobe >= 2 && ix.cnorm_max < 1e30f && ix.xnorm_max < 1e30f
-        && (prepared.probe_dis || ((prepared.coarse_words || prepared.probe_words) && prepared.qnorm)))
     {
-        H16Prune pr0{};
-        set_prune_error_model(pr0, ix, prepared.qh ? prepared.qrho : nullptr);
-        if (prepared.coarse_words || prepared.probe_words)
-        {
-            pr0.coarse_words = prepared.coarse_words;
-            pr0.npad = prepared.coarse_npad;
-            pr0.probe_words = prepared.coarse_words ? nullptr : prepared.probe_words;
-            pr0.qnorm = prepared.qnorm;
-        }
-        else
-            pr0.probe_dis = prepared.probe_dis;
-        pr0.radius = ix.list_radius.p;
-        pr0.xmax = ix.xnorm_max;
-        pr0.cmax = ix.cnorm_max;
-        const bool cosine_form = ix.metric == MSVS_METRIC_COSINE;
-        if (cosine_form)
-        {
-            pr0.ip = 1;
-            pr0.cnorm = ix.cnorm.p;
-            pr0.xmin = ix.xnorm_min;
-            pr0.Q = dq; // (normalised above)
-            pr0.ldq = ld;
-        }
-        pr0.k = k;
-        pr0.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
-        pr0.upre = cosine_form ? nullptr : scr.take<float>(nq); // (an L2 bound: the cosine scan's second stage compares inner products)
         int32_t * probes1 = scr.take<int32_t>(nq * nprobe);
-        ProfileScope prof("ivf_plan", stream);
-        hipLaunchKernelGGL(h16_preprune_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, d_probes, pr0, ix.list_off.p,
-                           (uint32_t)nq, (uint32_t)nprobe, probes1);
-        prepared.upre = pr0.upre;
-        d_probes = probes1;
+        if (preprune(d_probes, ix.list_radius.p, ix.list_off.p, probes1, true, ix.xnorm_max, ix.xnorm_min))
+            d_probes = probes1;
     }
     // 2. scan the probed lists
     if (nq * nprobe > 0x7fffffffull)

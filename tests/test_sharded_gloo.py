@@ -364,6 +364,83 @@ def test_product_sharded_search_prunes_on_every_rank_and_equals_unsharded(metric
             assert (bi == fi[lo:hi]).all() and (bd.view(np.uint32) == fd[lo:hi].view(np.uint32)).all(), (r, lo, hi)
 
 
+def _routed_worker(rank, world, port, metric_name, geometry, out):
+    """The routed sharded search: every rank brings its OWN queries (different counts, one rank with an odd count, an empty batch),
+    gets its own results back, and reports how many (query, rank) pairs it served."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import myscaledb_amd.capi as capi
+        from myscaledb_amd import sharded
+        capi.set_device(0)
+        metric = {"L2": capi.METRIC_L2, "IP": capi.METRIC_IP, "cosine": capi.METRIC_COSINE}[metric_name]
+        x, q, centres, nlist, k, nprobe = _pruned_case(geometry)
+        ix = capi.Index(capi.INDEX_IVFFLAT, metric, x.shape[1], "ncentroids=%d,shard_rank=%d,shard_world=%d" % (nlist, rank, world))
+        ix.set_centroids(centres)
+        ix.add(x)
+        ix.build()
+        comm = sharded.gloo_comm()
+        capi.set_option("h16_prune", "2")
+        capi.set_option("ivf_pass", "2")
+        res = []
+        # (step, this rank's slice of q): rank 0 takes the even queries, rank 1 the odd ones; then unequal shares; then one rank idle
+        for lo, hi, mine in ((0, 800, lambda i: i % world == rank), (0, 301, lambda i: (i < 77) == (rank == 0)), (300, 340, lambda i: rank == 1)):
+            sel = np.array([i for i in range(lo, hi) if mine(i)], np.int64)
+            nq = len(sel)
+            dq = torch.from_numpy(q[sel]).cuda() if nq else None
+            oi = torch.empty((max(nq, 1), k), dtype=torch.int64, device="cuda")
+            od = torch.empty((max(nq, 1), k), dtype=torch.float32, device="cuda")
+            served = ix.shard_search_routed_device(comm, dq.data_ptr() if nq else 0, nq, k, nprobe, oi.data_ptr(), od.data_ptr())
+            torch.cuda.synchronize()
+            res.append((sel, oi.cpu().numpy()[:nq], od.cpu().numpy()[:nq], served))
+        out.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric_name,geometry", [("L2", "blobs"), ("cosine", "blobs"), ("IP", "blobs"), ("L2", "outlier_neighbour")])
+def test_routed_sharded_search_two_processes_equals_unsharded(metric_name, geometry):
+    """msvs_shard_search_routed_device over two processes (gloo transport: the point-to-point exchange emulated by its all-gather):
+    every rank's own queries come back with the unsharded index's ids and distance bits; with the pre-pruning at work (L2, cosine: well
+    separated blobs) a query visits fewer than all ranks; the inner-product index routes every query everywhere and is still right."""
+    import myscaledb_amd.capi as capi
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_routed_worker, args=(r, world, port, metric_name, geometry, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    metric = {"L2": capi.METRIC_L2, "IP": capi.METRIC_IP, "cosine": capi.METRIC_COSINE}[metric_name]
+    x, q, centres, nlist, k, nprobe = _pruned_case(geometry)
+    ix = capi.Index(capi.INDEX_IVFFLAT, metric, x.shape[1], "ncentroids=%d" % nlist)
+    ix.set_centroids(centres)
+    ix.add(x)
+    ix.build()
+    capi.set_option("h16_prune", "0")
+    try:
+        fi, fd = ix.search(q, k, "nprobe=%d" % nprobe)
+    finally:
+        capi.set_option("h16_prune", None)
+    for step in range(3):
+        total_queries = sum(len(res[r][1][step][0]) for r in range(world))
+        served = sum(res[r][1][step][3] for r in range(world))
+        for r in range(world):
+            sel, gi, gd, _ = res[r][1][step]
+            assert (gi == fi[sel]).all(), (r, step, np.argwhere(gi != fi[sel])[:4])
+            assert (gd.view(np.uint32) == fd[sel].view(np.uint32)).all(), (r, step)
+        assert total_queries <= served <= world * total_queries, (step, served, total_queries)
+        if metric_name == "L2" and geometry == "blobs" and step == 0:
+            assert served < 1.7 * total_queries, "well separated blobs: most queries need one rank (%d pairs for %d queries)" % (served, total_queries)
+
+
 @pytest.mark.gpu
 def test_rccl_transport_single_rank_roundtrip():
     """The RCCL code path itself (dlopen'd librccl: ncclGetUniqueId, ncclCommInitRank, in-place ncclAllGather on the
