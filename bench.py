@@ -370,6 +370,9 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps + the roofline pass (profiler runs)")
     ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,blobs03,latent32,mid,target,c1,c3,c4,c5,cpu")
+    ap.add_argument("--shard-mode", default="routed", choices=("routed", "replicated"),
+                    help="N > 1: every rank brings its own batch and queries are routed to the ranks that own their lists (default), or "
+                         "every rank works through the same batch (msvs_shard_search_device_async)")
     ap.add_argument("--only", default="", help="comma list of legs to run (the others are skipped; the headline always runs)")
     ap.add_argument("--c4-rows", type=int, default=12_500_000, help="rows per GPU of the C4 leg (100M / 8)")
     ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the C3 / C5 legs")
@@ -468,7 +471,17 @@ def main():
     xs_out = [(torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B, k), device=dev, dtype=torch.float32)) for _ in xs]
     multi = {"on": False, "n": n_streams}
 
+    routed = world > 1 and args.shard_mode == "routed"
+    routed_served = []
+
     def step(i):
+        if routed:
+            # every rank brings its OWN batch (the queries that arrived at its server); a query visits the ranks that own lists it still
+            # needs after the pre-pruning at its home rank (msvs_shard_search_routed_device)
+            j = (i * world + rank) % n_pool
+            routed_served.append(ix.shard_search_routed_device(comm, q_all[j * B:(j + 1) * B].data_ptr(), B, k, nprobe, out_ids.data_ptr(),
+                                                               out_dis.data_ptr(), stream))
+            return
         q = q_all[(i % n_pool) * B:(i % n_pool + 1) * B]
         if world > 1:
             # two batches in flight: batch i's top-k exchange + merge under batch i + 1's scan; fence() drains (device sync)
@@ -515,7 +528,41 @@ def main():
         t = torch.tensor([elapsed], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    qps = args.steps * B / elapsed
+    qps = args.steps * B * (world if routed else 1) / elapsed
+    multi_gpu = None
+    if world > 1:
+        # both forms side by side: the routed one (own batch per rank) and the replicated one (every rank works through the same batch)
+        served = torch.tensor([float(np.mean(routed_served[-args.steps:])) if routed_served else 0.0], dtype=torch.float64)
+        allv = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        if args.test_single_device:
+            dist.all_gather(allv, served)
+        else:
+            sv = served.to(dev)
+            av = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(av, sv)
+            allv = [a.cpu() for a in av]
+        fam_r = None
+        if routed:
+            fam_r = profiled(step, min(args.steps, 4), ("shard_exchange", "coarse_pass", "ivf_plan", "ivf_scan", "ivf_sample_scan", "rerank", "merge"))
+        routed_now = routed
+        routed = False
+        for i in range(2):
+            step(i)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        fence()
+        e2 = time.perf_counter() - t1
+        routed = routed_now
+        t = torch.tensor([e2], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        multi_gpu = {"mode": args.shard_mode,
+                     "routed": {"queries_per_step_per_rank": B, "routed_pairs_per_step_by_rank": [round(float(a.item()), 1) for a in allv],
+                                "qps": round(qps, 1) if routed_now else None, "stage_ms_rank0": fam_r,
+                                "note": "routed_pairs = (query, rank) pairs a rank served: its share of the list-scan work; W x batch when nothing can be pruned"},
+                     "replicated": {"qps": round(args.steps * B / float(t.item()), 1), "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4),
+                                    "note": "msvs_shard_search_device_async: every rank works through the SAME batch (strong scaling of one batch's latency)"}}
 
     # ---- roofline of the dominant kernel: the list scan = h16_sample_kernel + h16_scan_kernel (HIP events on the launch
     # stream, separate pass over the same steps)
@@ -1341,19 +1388,23 @@ def main():
             "metric": "QPS at recall@10>=0.95, 1Mx768-d L2 top-10 (IVFFLAT nlist=1024 nprobe=%d)" % nprobe,
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if routed else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "IVFFLAT nlist=%d, %dx%d f32, L2, nprobe=%d, top-%d, batch %d queries/step "
                                    "(BASELINE.json configs[1])" % (nlist, n, d, nprobe, k, B),
                        "rows": n, "dim": d, "nlist": nlist, "nprobe": nprobe, "k": k, "batch": B,
-                       "parallelism": ("lists %% %d, coarse quantiser by query, probe (+ coarse distance word) and packed top-k all-gathers, "
-                                       "two batches in flight (msvs_shard_search_device_async); transport: %s"
-                                       % (world, comm_kind)) if world > 1 else
+                       "parallelism": (("lists %% %d, ROUTED: a batch of %d queries per rank and step, coarse quantiser + pre-pruning at the home rank, "
+                                        "point-to-point exchange of the surviving (query, rank) pairs, local search, results back, merge at home "
+                                        "(msvs_shard_search_routed_device); transport: %s" % (world, B, comm_kind)) if routed else
+                                       ("lists %% %d, coarse quantiser by query, probe (+ coarse distance word) and packed top-k all-gathers, "
+                                        "two batches in flight (msvs_shard_search_device_async); transport: %s"
+                                        % (world, comm_kind))) if world > 1 else
                                       ("single GPU" if n_streams == 1 else "single GPU, %d independent batches in flight on %d HIP streams" % (n_streams, n_streams)),
                        "streams": n_streams, "data_model": data_desc},
             "recall_at_10": None if recall is None else round(recall, 4),
             "p50_ms_batch1": extra.get("latency", {}).get("p50_us", 0) / 1e3 if "latency" in extra and "p50_us" in extra["latency"] else None,
             "roofline": roof,
             "concurrent_batches": concurrent,
+            "multi_gpu": multi_gpu,
             "cpu_baseline": cpu,
             "other_batches": extra.get("other_batches"),
             "latency": extra.get("latency"),

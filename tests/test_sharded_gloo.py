@@ -530,5 +530,9 @@ def test_bench_n_gt_1_code_path_runs_on_one_gpu():
     line = [ln for ln in r.stdout.split("\n") if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"].startswith("lists % 2")
+    mg = out["multi_gpu"]  # the routed form is the headline of N > 1 (its own batch per rank), the replicated one timed beside it
+    assert mg["mode"] == "routed" and out["scaling"] == "weak" and len(mg["routed"]["routed_pairs_per_step_by_rank"]) == 2
+    assert all(512 <= p_ <= 2 * 512 for p_ in mg["routed"]["routed_pairs_per_step_by_rank"]), mg
+    assert mg["replicated"]["qps"] > 0 and mg["routed"]["stage_ms_rank0"]["shard_exchange"] > 0
     c4 = out["c4_sharded"]
     assert "error" not in c4 and c4["batches"]["4096"]["qps"] > 0 and 0 < c4["rows_on_rank0"] < 120000, c4
