@@ -742,6 +742,36 @@ def main():
                                      "p99_us": round(float(np.percentile(al, 99)), 1),
                                      "combined_batches": int(b1[1] - b0[1]), "queries_in_batches": int(b1[2] - b0[2]),
                                      "driver": "native threads (msvs_host_concurrent_search)"}
+        # the seam's real call form for a batch (VIWithDataPart.cpp:900-926: a host DataSet<float> in, host result buffers out):
+        # H2D of 4096 x 768 x 4 B = 12.6 MB, the search, D2H of the results -- one thread; then two host threads (each on its own
+        # stream: one's copies beside the other's search -- the double-buffered form a serving loop would run)
+        import threading
+        for i in range(3):
+            ix.search(qh, k, sp)
+        t1 = time.perf_counter()
+        for i in range(20):
+            ix.search(qh, k, sp)
+        hp = (time.perf_counter() - t1) / 20
+        res["host_pointer_batch4096"] = {"qps": round(4096 / hp, 1), "ms": round(hp * 1e3, 4),
+                                         "api": "msvs_index_search, 4096 queries in HOST memory per call (pageable: numpy), results to host"}
+
+        def worker(reps):
+            for _ in range(reps):
+                ix.search(qh, k, sp)
+        th = [threading.Thread(target=worker, args=(3,)) for _ in range(2)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        th = [threading.Thread(target=worker, args=(20,)) for _ in range(2)]
+        t1 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        hp2 = (time.perf_counter() - t1) / 40
+        res["host_pointer_batch4096_two_threads"] = {"qps": round(4096 / hp2, 1), "ms_per_batch": round(hp2 * 1e3, 4),
+                                                     "note": "two host threads, each msvs_index_search of 4096 host queries on its own stream (ctypes releases the GIL)"}
         return res
 
     # ---- recall@10 against the exact scan of the same rows
