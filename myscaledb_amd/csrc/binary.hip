@@ -318,6 +318,8 @@ extern "C" int msvs_bin_index_load_io(const msvs_io_t * io, msvs_bin_index_t ** 
             ix->metric = h.metric;
             // the header is untrusted: the rows arrive in pieces and the buffer grows with what has really been read, so a corrupt
             // or truncated file ends in MSVS_ERR_IO (a short read) instead of a 2.8e14-byte allocation
+            if (h.nbytes != 0 && h.n > SIZE_MAX / h.nbytes) // (n <= 0xfffffff0 and nbytes <= 65536 above: cannot wrap in 64 bits -- kept explicit)
+                fail(MSVS_ERR_IO, "corrupt msvs binary index header");
             const size_t total = (size_t)h.n * (size_t)h.nbytes, piece = (size_t)64 << 20;
             for (size_t got = 0; got < total;)
             {
@@ -326,16 +328,22 @@ extern "C" int msvs_bin_index_load_io(const msvs_io_t * io, msvs_bin_index_t ** 
                 f.read(ix->rows.data() + got, m);
                 got += m;
             }
-            ix->labels.resize(h.n);
+            // (the labels are sized by the id list's own count below, piece by piece like the rows -- not by the header)
         }
         {
             IoStream f(io, "id_list", 0);
             uint64_t n = 0;
             f.read(&n, 8);
-            if (n != ix->labels.size())
-                fail(MSVS_ERR_IO, "corrupt msvs binary index: %llu ids for %zu rows", (unsigned long long)n, ix->labels.size());
-            if (n)
-                f.read(ix->labels.data(), n * 8);
+            const size_t rows_read = ix->nbytes ? ix->rows.size() / ix->nbytes : 0;
+            if (n != rows_read)
+                fail(MSVS_ERR_IO, "corrupt msvs binary index: %llu ids for %zu rows", (unsigned long long)n, rows_read);
+            for (size_t got = 0; got < n;) // in pieces, like the rows: the buffer grows with what has really been read
+            {
+                const size_t m = std::min<size_t>((size_t)8 << 20, n - got);
+                ix->labels.resize(got + m);
+                f.read(ix->labels.data() + got, m * 8);
+                got += m;
+            }
             for (int64_t id : ix->labels)
                 if (id < 0 || id > 0xfffffff0ll)
                     fail(MSVS_ERR_IO, "corrupt msvs binary index: row id %lld outside the u32 row-offset range", (long long)id);

@@ -972,7 +972,7 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
             mn = other < mn ? other : mn;
         }
         usable = usable && mn < 1e30 && mn >= 0.0;
-        sq = usable ? sqrt(mn) + sc : 0.0;
+        sq = usable ? sqrt(mn * (1.0 + 4.0 * (pr.c_canon + 4e-7))) * (1.0 + 1e-6) + sc : 0.0; // (mn is a canonical f32 value: widened by its own error before the root)
         if (usable && l >= 0 && dc2 == dc2 && dc2 >= 0.0 && dc2 < 1e30)
         {
             const double eps_c = (pr.c_canon + 4e-7) * (sqrt(dc2) + 2.0 * sc) * (sqrt(dc2) + 2.0 * sc) + 1e-30, r = (double)pr.radius[l];

@@ -397,7 +397,8 @@ __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
                 if (dc2 == dc2 && dc2 >= 0.0 && dc2 < 1e30 && r == r && r < 1e18)
                 {
                     // the centroid distance is canonical f32: widened by its rounding; |q| <= ||q - c|| + |c|
-                    const double sc = sqrt((double)p.cmax * 1.001), sq = sqrt(dc2) + sc, sx = sqrt((double)p.xmax * 1.001);
+                    const double sc = sqrt((double)p.cmax * 1.001), sq = sqrt(dc2 * (1.0 + 4.0 * (p.c_canon + 4e-7))) * (1.0 + 1e-6) + sc,
+                                 sx = sqrt((double)p.xmax * 1.001); // (dc2 is a canonical f32 value: widened by its own error before the root)
                     const double eps_c = (p.c_canon + 4e-7) * (sq + sc) * (sq + sc) + 1e-30;
                     const double slack = 2.0 * (p.c_canon + 4e-7) * (sq + sx) * (sq + sx) + 1e-30;
                     if ((uint64_t)(p.list_off[l + 1] - p.list_off[l]) >= p.k)

@@ -1274,7 +1274,15 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
             {
                 const size_t words = (size_t)grid * H_STAMP_ITEMS * 4;
                 if (g_h16_stamps.n < words)
-                    g_h16_stamps.alloc(words);
+                {
+                    // (experiment knob h16_stamps: one process-wide buffer -- another stream's scan may still write stamps into the old
+                    // one: the device is drained before it is replaced; the knob is not meant for concurrent searches)
+                    static std::mutex stamps_mu;
+                    std::lock_guard<std::mutex> lk(stamps_mu);
+                    MSVS_HIP(hipDeviceSynchronize());
+                    if (g_h16_stamps.n < words)
+                        g_h16_stamps.alloc(words);
+                }
                 MSVS_HIP(hipMemsetAsync(g_h16_stamps.p, 0, words * 8, stream));
                 a.stamps = g_h16_stamps.p;
                 g_h16_stamp_grid = grid;

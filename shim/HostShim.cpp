@@ -506,7 +506,15 @@ static const char * const msvs_parameter_table = R"JSON({
 /// forwarding build: the original library's table is the reference's truth for every type, including the ones served here
 /// (initialised from the original's object: link the original as a shared library this one depends on, so that its
 /// initialisers have run -- or make the original's table a constant-initialised string)
-const std::string MYSCALE_VALID_INDEX_PARAMETER = MSVS_FWD(MYSCALE_VALID_INDEX_PARAMETER);
+/// (cross-translation-unit dynamic initialisation: safe only when the original is a separately loaded shared library whose
+/// initialisers have run -- an empty copy, the statically linked case, falls back to this library's own table instead of handing the
+/// host's DDL check an empty JSON document)
+static std::string forwarded_parameter_table()
+{
+    const std::string & theirs = MSVS_FWD(MYSCALE_VALID_INDEX_PARAMETER);
+    return theirs.empty() ? std::string(msvs_parameter_table) : theirs;
+}
+const std::string MYSCALE_VALID_INDEX_PARAMETER = forwarded_parameter_table();
 #else
 const std::string MYSCALE_VALID_INDEX_PARAMETER = msvs_parameter_table;
 #endif

@@ -37,7 +37,9 @@ def test_forwarding_build_compiles():
     pre = subprocess.check_output(["g++", "-std=c++17", "-E", "-P", "-Istubs", "-DMSVS_SEARCH_FORWARD_SUFFIX=Original", "HostShim.cpp"],
                                   cwd=os.path.join(ROOT, "shim"), text=True)
     assert "createVectorIndexOriginal<IS, OS, Bitmap, T>(name, type" in pre and "getDefaultIndexTypeOriginal(search_type)" in pre
-    assert "MYSCALE_VALID_INDEX_PARAMETER = MYSCALE_VALID_INDEX_PARAMETEROriginal" in pre
+    # (the table is taken from the original's object through a function that falls back to this library's own when the original's
+    # initialiser has not run yet: static linking)
+    assert "theirs = MYSCALE_VALID_INDEX_PARAMETEROriginal" in pre and "MYSCALE_VALID_INDEX_PARAMETER = forwarded_parameter_table()" in pre
 
 
 def test_parameter_table_is_the_json_the_host_parses():
