@@ -184,13 +184,13 @@ extern "C" int msvs_postings_create_fields(const int64_t * post_off, size_t num_
             p->term_field.alloc(num_terms);
             MSVS_HIP(hipMemcpy(p->term_field.p, term_field, num_terms, hipMemcpyHostToDevice));
         }
-        // the skip table: terms with at least 4 postings per stretch, the most frequent first, at most 1/8 of the postings' bytes
+        // the skip table: terms with at least a posting per stretch, the most frequent first, at most 1/8 of the postings' bytes
         if (np && num_docs > BM25_SKIP_DOCS && options().bm25_skip != 0)
         {
             const uint32_t n_c = (uint32_t)ceil_div(num_docs, (size_t)BM25_SKIP_DOCS);
             std::vector<uint32_t> sel;
             for (size_t t = 0; t < num_terms; t++)
-                if ((uint64_t)(post_off[t + 1] - post_off[t]) >= 4ull * n_c)
+                if ((uint64_t)(post_off[t + 1] - post_off[t]) >= (uint64_t)n_c) // (a posting per stretch on average; the byte cap below decides the rest)
                     sel.push_back((uint32_t)t);
             std::sort(sel.begin(), sel.end(), [&](uint32_t x, uint32_t y) { return post_off[x + 1] - post_off[x] > post_off[y + 1] - post_off[y]; });
             const size_t max_rows = std::max<size_t>(1, np * 8 / 8 / ((size_t)(n_c + 1) * 4));
@@ -279,6 +279,19 @@ std::shared_ptr<msvs_postings::RecSet> records_for(const msvs_postings & ps, con
     return set;
 }
 
+static __global__ void bm25_nop_kernel() {}
+
+/// Documents per sub-range for a batch whose densest query has `rho` postings per document: that query's windows are single
+/// sub-ranges ~3/4 full.  From 2048 on a multiple of the skip table's stretch (BM25_SKIP_DOCS): the bounds of the frequent terms are
+/// then table entries (bm25_bounds8_kernel reads no posting for them).
+static uint32_t bm25_sub_docs_for(double rho)
+{
+    uint32_t s = (uint32_t)std::min<double>(BP_MAX_DOCS, std::max<double>(BP_MIN_DOCS, std::floor(0.75 * BP_CAP / std::max(rho, 1e-9))));
+    if (s >= BM25_SKIP_DOCS)
+        s = s / BM25_SKIP_DOCS * BM25_SKIP_DOCS;
+    return s;
+}
+
 /// Resident workgroups of bm25r_kernel per CU by its LDS (8192 hash slots: 38 KB per workgroup; 16384: 46 KB).
 uint32_t br_blocks_per_cu(bool big_slots) { return big_slots ? 3u : 4u; }
 
@@ -324,7 +337,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         else
         {
             // the densest query's windows are single sub-ranges filled to ~3/4 of the cap; sparser queries take several
-            sub_docs = (uint32_t)std::min<double>(BP_MAX_DOCS, std::max<double>(BP_MIN_DOCS, std::floor(0.75 * BP_CAP / std::max(rho, 1e-9))));
+            sub_docs = bm25_sub_docs_for(rho);
             if (options().bm25_sub_docs >= 16)
                 sub_docs = (uint32_t)options().bm25_sub_docs;
         }
@@ -596,9 +609,12 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     const bool fills_ride = emit && n_flat != 0;
     if (n_flat)
     {
+        if ((uint32_t)options().bm25_dbg & 32u) // experiment: does the first launch of a batch wait for the blob copy?
+            hipLaunchKernelGGL(bm25_nop_kernel, dim3(1), dim3(64), 0, stream);
         const dim3 bgrid((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256));
         if (options().bm25_bounds8 != 0)
-            hipLaunchKernelGGL(bm25_bounds8_kernel, dim3((unsigned)ceil_div((size_t)n_blocks + 1, (size_t)256), (unsigned)std::min<size_t>(n_flat, 65535)), dim3(256), 0, stream, a, d_bounds,
+            hipLaunchKernelGGL(bm25_bounds8_kernel,
+                               dim3((unsigned)ceil_div((size_t)n_blocks + 1, (size_t)256), (unsigned)std::min<size_t>(n_flat, 65535)), dim3(256), 0, stream, a, d_bounds,
                                recs ? (int64_t *)nullptr : d_bounds_hi /* only bm25p_kernel reads the shifted copy */, (uint32_t)n_flat, docs_per_block,
                                counters, fills_ride ? nq + 1 : (size_t)0, sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0,
                                ps.skip_n ? ps.skip_row.p : (const int32_t *)nullptr, ps.skip_tab.p, ps.skip_n);
@@ -816,7 +832,7 @@ void bm25_batch_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
                     sum += (uint64_t)(ps.h_post_off[qterms[j] + 1] - ps.h_post_off[qterms[j]]);
             rho = std::max(rho, (double)sum / (double)std::max<size_t>(ps.num_docs, 1));
         }
-        const size_t formula = (size_t)std::min<double>(BP_MAX_DOCS, std::max<double>(BP_MIN_DOCS, std::floor(0.75 * BP_CAP / std::max(rho, 1e-9))));
+        const size_t formula = bm25_sub_docs_for(rho);
         const size_t sub_p = options().bm25_sub_docs >= 16 ? (size_t)options().bm25_sub_docs : formula;
         // no chunk can be denser than the batch: all of them take the posting scorer, or some may keep the dense accumulator
         sub_ub = rho <= 0.125 || options().bm25_posting == 2 ? sub_p : std::min<size_t>(BW_DOCS, sub_p);

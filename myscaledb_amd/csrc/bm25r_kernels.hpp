@@ -636,7 +636,8 @@ __global__ __launch_bounds__(BLOCK) void bm25_cut_block_kernel(const uint64_t * 
         cut_keys[(size_t)q * m + m - 1] = G == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)G << 32;
 }
 
-constexpr uint32_t BM25_SKIP_DOCS = 8192; // documents per stretch of the skip table
+constexpr uint32_t BM25_SKIP_DOCS = 2048; // documents per stretch of the skip table (the sub-range sizes 2048 / 4096 / 8192 are multiples: their
+                                          // bounds are table entries, no posting is read)
 
 /// Skip table of a posting set: tab[row][c] = postings of term sel[row] with a document id below c * BM25_SKIP_DOCS (c = 0 .. n_c).
 static __global__ void bm25_skip_build_kernel(const int64_t * post_off, const uint32_t * doc_ids, const uint32_t * sel, uint32_t n_rows,
@@ -678,10 +679,41 @@ static __global__ void bm25_bounds8_kernel(const Bm25Params a, int64_t * bounds,
             ones[j] = KEY_NONE;
     }
     const uint32_t nb1 = a.n_blocks + 1;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb1)
-        return;
     for (uint32_t j = blockIdx.y; j < n_flat; j += gridDim.y)
+    {
+    if (skip_row && docs_per_block % BM25_SKIP_DOCS == 0)
+    {
+        // a frequent term whose boundaries are stretch boundaries: the table holds the answers.  The launch is a chain of dependent
+        // loads per thread (term -> list ends / table row -> entry) at 8 wavefronts per SIMD: four entries per thread, their loads side
+        // by side, quarter the chains
+        const uint32_t term = a.qterms[j];
+        const int32_t row = skip_row[term];
+        if (row >= 0)
+        {
+            const uint32_t * const tab = skip_tab + (size_t)row * (skip_n + 1);
+            const int64_t base = a.post_off[term];
+            const uint32_t mul = docs_per_block / BM25_SKIP_DOCS;
+            const uint32_t b0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+            {
+                const uint64_t c = (uint64_t)(b0 + u) * mul;
+                v[u] = b0 + u < nb1 ? tab[c < skip_n ? (uint32_t)c : skip_n] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (b0 + u < nb1)
+                {
+                    const size_t i = (size_t)j * nb1 + b0 + u;
+                    bounds[i] = base + v[u];
+                    if (b0 + u > 0 && bounds_hi)
+                        bounds_hi[i - 1] = base + v[u];
+                }
+            continue;
+        }
+    }
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb1; b += gridDim.x * blockDim.x)
     {
     const size_t i = (size_t)j * nb1 + b;
     const uint32_t term = a.qterms[j];
@@ -695,6 +727,17 @@ static __global__ void bm25_bounds8_kernel(const Bm25Params a, int64_t * bounds,
         if (row >= 0)
         {
             const uint32_t * const tab = skip_tab + (size_t)row * (skip_n + 1);
+            if (docs_per_block % BM25_SKIP_DOCS == 0)
+            {
+                // the boundary IS a stretch boundary: the table holds the answer (the doc ids of the list are not touched -- with
+                // ~2.5 postings per sub-range the searches of a batch read every cache line of its terms' doc ids: 600 MB at 1024 queries)
+                const uint64_t c = target / BM25_SKIP_DOCS;
+                const int64_t v = lo + tab[c < skip_n ? (uint32_t)c : skip_n];
+                bounds[i] = v;
+                if (b > 0 && bounds_hi)
+                    bounds_hi[i - 1] = v;
+                continue;
+            }
             const uint64_t c = target / BM25_SKIP_DOCS;
             const uint32_t c0 = c < skip_n ? (uint32_t)c : skip_n, c1 = c0 < skip_n ? c0 + 1 : skip_n;
             const int64_t base = lo;
@@ -734,6 +777,7 @@ static __global__ void bm25_bounds8_kernel(const Bm25Params a, int64_t * bounds,
     bounds[i] = lo;
     if (b > 0 && bounds_hi)
         bounds_hi[i - 1] = lo;
+    }
     }
 }
 

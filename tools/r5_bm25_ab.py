@@ -28,6 +28,7 @@ VARIANTS = [
     ("no second look at the flagged records (dbg=2; exact)", {"bm25_dbg": "2"}),
     ("general record scorer (bm25_lean=0)", {"bm25_lean": "0"}),
     ("ablation: filter runs, its flags are ignored (dbg=16)", {"bm25_dbg": "16"}),
+    ("experiment: an empty launch in front of the bounds launch (dbg=32; exact)", {"bm25_dbg": "32"}),
 ]
 
 
