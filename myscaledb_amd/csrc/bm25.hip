@@ -366,7 +366,13 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     for (size_t q = 0; q < nq && lean; q++)
         lean = qoff[q + 1] < qoff[q] || qoff[q + 1] - qoff[q] <= BL_NT;
     const uint32_t bpc = recs ? br_blocks_per_cu(big_slots) : BP_BLOCKS_PER_CU; // resident workgroups per CU of the posting scorer
-    const double per_item = std::max(800.0, (double)all_postings / (2.0 * cus * (bpc * BP_WAVES)));
+    // items per resident wavefront of the EMIT pass: an item costs ~7 us of dependent loads before its first window, a wavefront with
+    // one long item cannot even out the others' tails -- measured: 1 item at 64 queries (0.163 -> 0.146 ms), 2 at 256, 4 at 1024
+    // (0.749 -> 0.698 ms): ~4600 postings per item, between 1 and 4 items
+    const double ipw = options().bm25_items_per_wave > 0
+        ? options().bm25_items_per_wave
+        : std::min(4.0, std::max(1.0, (double)all_postings / (4600.0 * cus * (bpc * BP_WAVES))));
+    const double per_item = std::max(800.0, (double)all_postings / (ipw * cus * (bpc * BP_WAVES)));
     auto spi_of = [&](size_t q) -> uint32_t {
         if (q_postings[q] == 0)
             return n_blocks;
@@ -420,7 +426,12 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
                  blob_bytes = round_up(o_items_s + n_items_s * 16, (size_t)16);
     PinnedRing & ring = pinned_ring(stream);
     int slot = 0;
-    unsigned char * blob = static_cast<unsigned char *>(ring.take(blob_bytes, slot));
+    // (the blob is put together in ordinary memory and copied into the pinned slot in one go: stores into the pinned mapping cost
+    // ~50 ns each -- 4.3 ms of host time per 4096-query batch went into writing 16 k items word by word)
+    static thread_local std::vector<unsigned char> blob_heap;
+    blob_heap.resize(blob_bytes);
+    unsigned char * const blob = blob_heap.data();
+    unsigned char * const blob_pinned = static_cast<unsigned char *>(ring.take(blob_bytes, slot));
     uint32_t * h_qoff = reinterpret_cast<uint32_t *>(blob + o_qoff);
     uint32_t * h_terms = reinterpret_cast<uint32_t *>(blob + o_terms);
     float * weight = reinterpret_cast<float *>(blob + o_w);
@@ -493,7 +504,8 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     int64_t * d_bounds = scr.take<int64_t>(nf1 * (n_blocks + 1));
     int64_t * d_bounds_hi = scr.take<int64_t>(nf1 * (n_blocks + 1));
     uint64_t * partial = scr.take<uint64_t>(nq * (size_t)n_chunks * k);
-    MSVS_HIP(hipMemcpyAsync(d_blob, blob, blob_bytes, hipMemcpyHostToDevice, stream));
+    memcpy(blob_pinned, blob, blob_bytes);
+    MSVS_HIP(hipMemcpyAsync(d_blob, blob_pinned, blob_bytes, hipMemcpyHostToDevice, stream));
     MSVS_HIP(hipEventRecord(ring.ev[slot], stream)); // the slot is free again once the copy has run
     a.post_off = ps.post_off.p;
     a.doc_ids = ps.doc_ids.p;

@@ -198,6 +198,7 @@ struct Options
     double bm25_lean = 1;     // BM25 record scorer: the four-term form (bm25l_kernel) when every query of the chunk has <= 4 terms (0: bm25r_kernel)
     double flat_sample_few = 1;  // FLAT shadow pass, <= 32 queries: sample + cut in one launch (flat_sample_few_kernel; 0: coarse_h16_kernel + flat_cut_kernel)
     double flat_host_signal = 1; // FLAT, a few queries, host pointers: pinned in / out + a completion word (0: copies + stream synchronisation)
+    double bm25_items_per_wave = 0; // BM25 emit pass: equal-postings items per resident wavefront (0 = 2)
     double bm25_skip = 1;     // BM25 posting sets carry a skip table of their frequent terms (read at msvs_postings_create)
     double bm25_bounds8 = 1;  // BM25 sub-range bounds by an 8-ary search (0: binary)
 };
