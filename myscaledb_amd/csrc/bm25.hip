@@ -745,8 +745,12 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     }
     // 3. select, or queue for the fallback
     const size_t lds_k = (size_t)5 * k * 8;
-    hipLaunchKernelGGL(bm25_select_kernel, dim3((unsigned)nq), dim3(BM25_SELECT_THREADS), 0, stream, cand, ccnt, cand_cap, cut_keys, cut_m,
-                       (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
+    if (options().bm25_select2 != 0 && k <= 256)
+        hipLaunchKernelGGL(bm25_select2_kernel, dim3((unsigned)nq), dim3(BLOCK), 0, stream, cand, ccnt, cand_cap, cut_keys, cut_m, (uint32_t)k, d_ids,
+                           d_scores, failq, nfail, stat_fail);
+    else
+        hipLaunchKernelGGL(bm25_select_kernel, dim3((unsigned)nq), dim3(BM25_SELECT_THREADS), 0, stream, cand, ccnt, cand_cap, cut_keys, cut_m,
+                           (uint32_t)k, d_ids, d_scores, failq, nfail, stat_fail);
     // 4. the exact fallback over the queue (empty launches when nobody queued)
     Bm25Params fp = a;
     fp.partial = partial;

@@ -636,6 +636,141 @@ __global__ __launch_bounds__(BLOCK) void bm25_cut_block_kernel(const uint64_t * 
         cut_keys[(size_t)q * m + m - 1] = G == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)G << 32;
 }
 
+/// bm25_select_kernel by SELECTION instead of ranking every candidate against every other (~500 candidates per query: 14 us per launch,
+/// as long as the sample pass of a 64-query batch): the four wavefronts of a workgroup each select the k smallest score words of a
+/// quarter of the keys (register radix select), the first one the k-th smallest of those 4 k -- the k-th smallest word G of all; the keys
+/// with a word <= G (k of them plus the ties of the last score) are ranked among themselves.  More than 1024 such keys (a score
+/// shared by a thousand documents at the cut): the full ranking.  Same outputs, same failure rule.
+static __global__ __launch_bounds__(BLOCK) void bm25_select2_kernel(const uint64_t * cand, const uint32_t * ccnt, uint32_t cand_cap,
+                                                                     const uint64_t * cut_keys, uint32_t cut_m, uint32_t k, int64_t * out_ids,
+                                                                     float * out_scores, uint32_t * failq, uint32_t * nfail,
+                                                                     unsigned long long * stat_fail)
+{
+    constexpr uint32_t NW = BM25_CAND_CAP / BLOCK; // 8 keys per thread
+    __shared__ __attribute__((aligned(16))) uint64_t keys[BM25_CAND_CAP + 2];
+    __shared__ uint64_t sel[1024 + 2];
+    __shared__ uint32_t hist_s[BLOCK / 64][256];
+    __shared__ uint32_t best_s[BLOCK / 64][256];
+    __shared__ uint32_t s_cnt, s_G;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    const uint32_t cnt = ccnt[q];
+    const bool real_cut = cut_keys[(size_t)q * cut_m + cut_m - 1] != KEY_NONE;
+    if (cnt > cand_cap || (real_cut && cnt < k))
+    {
+        if (tid == 0)
+        {
+            failq[atomicAdd(nfail, 1u)] = q;
+            atomicAdd(stat_fail, 1ull);
+        }
+        return;
+    }
+    const uint64_t * src = cand + (size_t)q * BM25_CAND_CAP;
+    uint64_t mine[NW];
+    uint32_t word[NW];
+#pragma unroll
+    for (uint32_t u = 0; u < NW; u++)
+    {
+        const uint32_t i = (u * (BLOCK / 64) + wave) * 64 + lane; // wavefront w holds every fourth run of 64 keys
+        mine[u] = i < cnt ? src[i] : KEY_NONE;
+        word[u] = (uint32_t)(mine[u] >> 32);
+    }
+    for (uint32_t i = cnt + tid; i < k; i += BLOCK) // fewer candidates than k: the tail is "no hit"
+    {
+        out_ids[(size_t)q * k + i] = -1;
+        out_scores[(size_t)q * k + i] = key_value<M_IP>(KEY_NONE);
+    }
+    if (tid == 0)
+        s_cnt = 0;
+    uint32_t G = 0xFFFFFFFFu;
+    if (cnt > k)
+    {
+        const uint32_t H = wave_kth_word_radix<(int)NW>(word, k, hist_s[wave], lane); // 0xFFFFFFFF: fewer than k real keys in this quarter
+        for (uint32_t i = lane; i < k; i += 64)
+            best_s[wave][i] = H;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t run = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < NW; u++)
+        {
+            const bool take = word[u] < H;
+            const uint64_t mask = __ballot(take);
+            if (take)
+                best_s[wave][run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = word[u];
+            run += (uint32_t)__popcll(mask); // < k in total: H is the k-th smallest
+        }
+        __syncthreads();
+        if (wave == 0)
+        {
+            uint32_t w4[16]; // 4 k <= 1024 words
+#pragma unroll
+            for (uint32_t v = 0; v < 16; v++)
+            {
+                const uint32_t i = v * 64 + lane, w = i / k, j = i - w * k; // (k >= 1)
+                w4[v] = i < 4 * k ? best_s[w][j] : 0xFFFFFFFFu;
+            }
+            const uint32_t g = wave_kth_word_radix<16>(w4, k, hist_s[0], lane);
+            if (lane == 0)
+                s_G = g;
+        }
+        __syncthreads();
+        G = s_G;
+    }
+    else
+        __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < NW; u++)
+        if (mine[u] != KEY_NONE && word[u] <= G)
+        {
+            const uint32_t at = atomicAdd(&s_cnt, 1u);
+            if (at < 1024)
+                sel[at] = mine[u];
+        }
+    __syncthreads();
+    const uint32_t s = s_cnt;
+    if (s <= 1024)
+    {
+        if (tid == 0)
+            sel[s] = sel[s + 1] = KEY_NONE; // pad: the count loop reads pairs
+        __syncthreads();
+        for (uint32_t i = tid; i < s; i += BLOCK)
+        {
+            const uint64_t me = sel[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < s; j += 2)
+                rank += (sel[j] < me ? 1u : 0u) + (sel[j + 1] < me ? 1u : 0u);
+            if (rank < k)
+            {
+                out_ids[(size_t)q * k + rank] = (int64_t)(uint32_t)me;
+                out_scores[(size_t)q * k + rank] = key_value<M_IP>(me);
+            }
+        }
+        return;
+    }
+    // a thousand ties at the cut: rank everything
+#pragma unroll
+    for (uint32_t u = 0; u < NW; u++)
+    {
+        const uint32_t i = (u * (BLOCK / 64) + wave) * 64 + lane;
+        if (i < cnt + 2)
+            keys[i] = mine[u];
+    }
+    if (tid < 2)
+        keys[cnt + tid] = KEY_NONE;
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt; i += BLOCK)
+    {
+        const uint64_t me = keys[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < cnt; j += 2)
+            rank += (keys[j] < me ? 1u : 0u) + (keys[j + 1] < me ? 1u : 0u);
+        if (rank < k)
+        {
+            out_ids[(size_t)q * k + rank] = (int64_t)(uint32_t)me;
+            out_scores[(size_t)q * k + rank] = key_value<M_IP>(me);
+        }
+    }
+}
+
 constexpr uint32_t BM25_SKIP_DOCS = 2048; // documents per stretch of the skip table (the sub-range sizes 2048 / 4096 / 8192 are multiples: their
                                           // bounds are table entries, no posting is read)
 

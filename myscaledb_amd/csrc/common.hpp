@@ -199,6 +199,7 @@ struct Options
     double flat_sample_few = 1;  // FLAT shadow pass, <= 32 queries: sample + cut in one launch (flat_sample_few_kernel; 0: coarse_h16_kernel + flat_cut_kernel)
     double flat_host_signal = 1; // FLAT, a few queries, host pointers: pinned in / out + a completion word (0: copies + stream synchronisation)
     double bm25_items_per_wave = 0; // BM25 emit pass: equal-postings items per resident wavefront (0 = 2)
+    double bm25_select2 = 1;  // BM25 top-k of the candidates by selection (bm25_select2_kernel; 0: rank every candidate against every other)
     double bm25_skip = 1;     // BM25 posting sets carry a skip table of their frequent terms (read at msvs_postings_create)
     double bm25_bounds8 = 1;  // BM25 sub-range bounds by an 8-ary search (0: binary)
 };

@@ -29,7 +29,7 @@ VARIANTS = [
     ("general record scorer (bm25_lean=0)", {"bm25_lean": "0"}),
     ("ablation: filter runs, its flags are ignored (dbg=16)", {"bm25_dbg": "16"}),
     ("experiment: an empty launch in front of the bounds launch (dbg=32; exact)", {"bm25_dbg": "32"}),
-    ("one emit item per resident wavefront", {"bm25_items_per_wave": "1"}),
+    ("ranking select kernel (bm25_select2=0)", {"bm25_select2": "0"}),
     ("1.5 emit items per resident wavefront", {"bm25_items_per_wave": "1.5"}),
     ("four emit items per resident wavefront", {"bm25_items_per_wave": "4"}),
 ]
