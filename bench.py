@@ -499,6 +499,21 @@ def main():
             torch.cuda.synchronize()
 
     multi["on"] = n_streams > 1
+    if routed:
+        # the routed entry has only ever run on a 1-GPU box (two ranks sharing it): if its first step fails on any rank, every rank
+        # falls back to the replicated form instead of losing the N > 1 line
+        ok_r = 1
+        try:
+            step(0)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("rank %d: routed search failed (%r): replicated form\n" % (rank, e))
+            ok_r = 0
+        t_ok = torch.tensor([ok_r], device="cpu" if args.test_single_device else dev)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 0:
+            routed = False
+            routed_served.clear()
     for i in range(args.warmup):
         step(i)
     fence()
@@ -557,7 +572,7 @@ def main():
         routed = routed_now
         t = torch.tensor([e2], device="cpu" if args.test_single_device else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        multi_gpu = {"mode": args.shard_mode,
+        multi_gpu = {"mode": "routed" if routed_now else "replicated",
                      "routed": {"queries_per_step_per_rank": B, "routed_pairs_per_step_by_rank": [round(float(a.item()), 1) for a in allv],
                                 "qps": round(qps, 1) if routed_now else None, "stage_ms_rank0": fam_r,
                                 "note": "routed_pairs = (query, rank) pairs a rank served: its share of the list-scan work; W x batch when nothing can be pruned"},
