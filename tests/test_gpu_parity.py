@@ -1808,6 +1808,65 @@ def test_bm25_posting_scorer_windows_duplicates_and_density_routing(sub_docs, re
     assert q1 - q0 == 4 * len(queries) and f1 - f0 <= 8  # the sample/emit path, a rare exact fallback
 
 
+@pytest.mark.parametrize("sub_docs", ["0", "512", "8192"])
+@pytest.mark.parametrize("operator_or", [True, False])
+def test_bm25_four_term_scorer_paths(sub_docs, operator_or, opt):
+    """bm25l_kernel (every query of the batch has <= 4 terms): the look-ahead with a stride (sparse queries beside a dense one),
+    the fall-back to single sub-ranges inside a burst, the split of a sub-range by document id (a burst of consecutive documents,
+    frequent terms under bm25_posting = 2), terms repeated inside a query (every record shares its document: the flagged path with
+    hundreds of records), terms sharing half their documents, an empty posting list, one-term queries, filters, AND -- every hit and
+    score bit == the oracle's dense term-order accumulation; and == the general record scorer (bm25_lean = 0)."""
+    opt("bm25_sub_docs", sub_docs)
+    opt("bm25_posting", "2")  # the posting scorer whatever the density: dense sub-ranges are split
+    rng = np.random.default_rng(321)
+    n_docs, vocab = 600_000, 3000  # (>= 500 000 documents: the sample / cut / emit flow)
+    lists = []
+    base = np.sort(rng.choice(n_docs, 2500, replace=False)).astype(np.uint32)
+    lists.append(base)                                                                                    # 0
+    lists.append(np.unique(np.concatenate([base[::2], rng.choice(n_docs, 900, replace=False).astype(np.uint32)])))  # 1: shares half of 0
+    burst = np.arange(123_000, 127_000, dtype=np.uint32)  # 4000 consecutive documents
+    lists.append(np.unique(np.concatenate([burst, rng.choice(n_docs, 1500, replace=False).astype(np.uint32)])))     # 2: sparse + a burst
+    lists.append(np.unique(np.concatenate([burst[::3], rng.choice(n_docs, 800, replace=False).astype(np.uint32)]))) # 3: a third of the burst
+    lists.append(np.sort(rng.choice(n_docs, 180_000, replace=False)).astype(np.uint32))                   # 4: 30 % of the documents
+    lists.append(np.sort(rng.choice(n_docs, 90_000, replace=False)).astype(np.uint32))                    # 5: 15 %
+    for t in range(6, vocab - 1):
+        lists.append(np.sort(rng.choice(n_docs, int(rng.integers(1, 600)), replace=False)).astype(np.uint32))
+    lists.append(np.zeros(0, np.uint32))                                                                  # vocab - 1: empty
+    post_off = np.zeros(vocab + 1, np.int64)
+    np.cumsum([len(x) for x in lists], out=post_off[1:])
+    doc = np.concatenate(lists)
+    tf = rng.integers(1, 6, len(doc)).astype(np.uint32)
+    lens = np.maximum(1, rng.poisson(20, n_docs))
+    fn = np.array([o.fieldnorm_id(int(n)) for n in range(int(lens.max()) + 1)], np.uint8)[lens]
+    total_tokens = int(lens.sum())
+    ps = capi.Postings(post_off, doc, tf, fn)
+    df_all = np.diff(post_off)
+    queries = [[0, 1], [1, 0, 1], [7, 7, 7, 7], [2, 3], [3, 2, 900, 17], [4, 5], [5, 4, 2, 0], [4], [vocab - 1, 7], [vocab - 1], [2],
+               [2000, 2001, 2002, 2003], [4, 4]]
+    queries += [list(rng.choice(vocab - 1, rng.integers(1, 5), replace=False)) for _ in range(51)]
+    assert max(len(q) for q in queries) <= 4
+    dfs = [[int(df_all[t]) for t in q] for q in queries]
+    alive = rng.random(n_docs) < 0.5
+    for k, emit in ((10, "1"), (100, "1"), (10, "0")):  # (emit 0: per-chunk top-k lists -- the scorer's other output mode)
+        opt("bm25_emit", emit)
+        for al in (None, alive):
+            ref = None
+            for lean in ("1", "0"):
+                opt("bm25_lean", lean)
+                got = ps.bm25_search_batch(queries, dfs, n_docs, total_tokens, k, alive=al, operator_or=operator_or)
+                if ref is None:
+                    ref = got
+                    for q, dfq, (gr, gs) in zip(queries, dfs, got):
+                        er, es = o.bm25_search_ex(post_off, doc, tf, fn, q, dfq, n_docs, total_tokens, k, alive=al, operator_or=operator_or)
+                        assert gr.tolist() == er.tolist(), q
+                        assert (gs.view(np.uint32) == es.view(np.uint32)).all(), q
+                else:
+                    for (gr, gs), (rr, rs) in zip(got, ref):
+                        assert gr.tolist() == rr.tolist() and (gs.view(np.uint32) == rs.view(np.uint32)).all()
+    opt("bm25_lean", None)
+    opt("bm25_emit", None)
+
+
 def test_bm25_records_follow_the_statistics_of_the_call(opt):
     """bm25r_kernel reads (doc, tf / (tf + cache[fieldnorm])) records derived for ONE fieldnorm cache, i.e. one average field
     length: searches that alternate between two corpus statistics (a part alone / the sum over parts, BM25InfoInDataParts.cpp)
