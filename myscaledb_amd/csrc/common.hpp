@@ -196,6 +196,9 @@ struct Options
     double bm25_slots = 0;    // bm25r_kernel: hash slots of the shared-document filter (0 = 8192, 4 workgroups per CU; 16384: 3 per CU, fewer false alarms)
     double bm25_cutk = 1;     // BM25 cut by a register radix select per query (0: the list merge kernel)
     double bm25_lean = 1;     // BM25 record scorer: the four-term form (bm25l_kernel) when every query of the chunk has <= 4 terms (0: bm25r_kernel)
+    double coarse_few = 128;     // the canonical coarse quantiser of a batch of at most this many queries in one self-merging launch (0: scan + merge launches)
+    double host_pinned = 256;    // msvs_index_search over an IVFFLAT index, unfiltered batches of at most this many queries: queries and results through pinned memory (0: staged copies)
+    double plan_fused = 1;       // grouping the (query, list) pairs of a small batch (<= 8192 pairs) in one launch (0: memset + three launches)
     double flat_sample_few = 1;  // FLAT shadow pass, <= 32 queries: sample + cut in one launch (flat_sample_few_kernel; 0: coarse_h16_kernel + flat_cut_kernel)
     double flat_host_signal = 1; // FLAT, a few queries, host pointers: pinned in / out + a completion word (0: copies + stream synchronisation)
     double bm25_items_per_wave = 0; // BM25 emit pass: equal-postings items per resident wavefront (0 = 2)

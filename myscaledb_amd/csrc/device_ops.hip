@@ -290,23 +290,30 @@ void launch_ivf_scan(int metric, ScanParams a, hipStream_t stream)
     MSVS_HIP(hipGetLastError());
 }
 
+bool ivf_plan_fused(const IvfPlanParams & p)
+{
+    return p.n_pairs <= PLAN_FUSED_PAIRS && p.nlist <= PLAN_LDS_LISTS && options().plan_lds != 0 && options().plan_fused != 0;
+}
+
 void launch_ivf_plan(const IvfPlanParams & p, hipStream_t stream)
 {
     if (p.n_pairs == 0)
         return;
     ProfileScope prof("ivf_plan", stream);
-    if (p.nlist <= PLAN_LDS_LISTS && options().plan_lds != 0)
+    if (ivf_plan_fused(p))
+        hipLaunchKernelGGL(ivf_plan_scan_kernel<true>, dim3(1), dim3(1024), 0, stream, p);
+    else if (p.nlist <= PLAN_LDS_LISTS && options().plan_lds != 0)
     {
         unsigned g = (unsigned)ceil_div(p.n_pairs, PLAN_CHUNK);
         hipLaunchKernelGGL(ivf_hist_lds_kernel, dim3(g), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(ivf_plan_scan_kernel<false>, dim3(1), dim3(1024), 0, stream, p);
         hipLaunchKernelGGL(ivf_scatter_lds_kernel, dim3(g), dim3(256), 0, stream, p);
     }
     else
     {
         unsigned g = (unsigned)ceil_div(p.n_pairs, 256);
         hipLaunchKernelGGL(ivf_hist_kernel, dim3(g), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(ivf_plan_scan_kernel<false>, dim3(1), dim3(1024), 0, stream, p);
         hipLaunchKernelGGL(ivf_scatter_kernel, dim3(g), dim3(256), 0, stream, p);
     }
     MSVS_HIP(hipGetLastError());
@@ -316,7 +323,7 @@ void launch_ivf_plan_rescan(const IvfPlanParams & p, hipStream_t stream)
 {
     if (p.n_pairs == 0)
         return;
-    hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(ivf_plan_scan_kernel<false>, dim3(1), dim3(1024), 0, stream, p);
     MSVS_HIP(hipGetLastError());
 }
 
@@ -629,7 +636,7 @@ const OptionField g_option_fields[] = {
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},
     {"flat_few", &Options::flat_few},
     {"bm25_rec", &Options::bm25_rec},       {"bm25_slots", &Options::bm25_slots},
-    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8}, {"bm25_lean", &Options::bm25_lean}, {"bm25_skip", &Options::bm25_skip}, {"bm25_select2", &Options::bm25_select2}, {"bm25_items_per_wave", &Options::bm25_items_per_wave}, {"flat_host_signal", &Options::flat_host_signal}, {"flat_sample_few", &Options::flat_sample_few},
+    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8}, {"bm25_lean", &Options::bm25_lean}, {"bm25_skip", &Options::bm25_skip}, {"bm25_select2", &Options::bm25_select2}, {"bm25_items_per_wave", &Options::bm25_items_per_wave}, {"flat_host_signal", &Options::flat_host_signal}, {"flat_sample_few", &Options::flat_sample_few}, {"plan_fused", &Options::plan_fused}, {"host_pinned", &Options::host_pinned}, {"coarse_few", &Options::coarse_few},
 };
 Options g_options;
 std::once_flag g_options_once;

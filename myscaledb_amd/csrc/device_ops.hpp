@@ -87,6 +87,8 @@ void launch_ivf_scan(int metric, ScanParams a, hipStream_t stream);
 
 /// Group the (query, probed list) pairs by list: histogram, scans, scatter (p.cnt / p.fill must be zeroed).
 void launch_ivf_plan(const IvfPlanParams & p, hipStream_t stream);
+/// ... in ONE launch (small batches: nothing to zero beforehand, p.zero cleared on the way)?
+bool ivf_plan_fused(const IvfPlanParams & p);
 /// Only the two exclusive scans again (pair_off, work_off) for another row range / work-item size of the same pairs.
 void launch_ivf_plan_rescan(const IvfPlanParams & p, hipStream_t stream);
 

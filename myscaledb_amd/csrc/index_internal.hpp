@@ -159,6 +159,10 @@ struct ProbeWords
     float g_xmax = 0.f, g_xmin = 0.f; // max / min |x|^2 over the rows of every rank (the bounds' error terms)
     int32_t * pruned_out = nullptr;
 };
+/// search_entry.hip: the canonical coarse quantiser of a small batch in one launch (-> false: not for this shape).
+bool coarse_few_launch(const msvs_index & ix, const float * dq, size_t nq, size_t nprobe, int32_t * d_probes, float * d_probe_dis,
+                       hipStream_t stream);
+
 /// A host-pointer search of a few queries over a FLAT shadow (search_entry.hip: flat_few_search_host) arms this before it calls
 /// index_search_device: the table pass then ends with a one-thread launch that copies the certificate-failure count to `nfail` and
 /// sets `flag` to `seq` (both in pinned memory), waits for the word itself, and runs the canonical fallback only when somebody

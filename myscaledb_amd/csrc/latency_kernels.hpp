@@ -1,4 +1,5 @@
-// latency_kernels.hpp -- the few-query (nq <= 4) IVFFLAT search in TWO launches.
+// latency_kernels.hpp -- the few-query (nq <= 4) IVFFLAT search in TWO launches (and, at the end, the one-launch coarse quantiser of
+// small batches built from the same pieces: coarse_few_kernel).
 //
 // A single query of BASELINE config 2 moves ~99 MB (3 MB of centroids + 32 lists): 20 us of HBM time.  The general path
 // spends four launches on it (centroid scan, merge, list scan, merge); the two one-block merge kernels alone are 40 of
@@ -31,6 +32,8 @@ namespace msvs
 
 constexpr uint32_t LAT_MAX_Q = 4;  // queries per call on this path
 constexpr uint32_t LAT_MAX_K = 64; // k and nprobe (one register of a wavefront top-k)
+constexpr uint32_t LAT_COARSE_MAX_Q = 128; // coarse_few_kernel: queries per call
+constexpr int LAT_COARSE_T = 4;            // ... and per block (one wavefront each in the selection)
 
 struct LatParams
 {
@@ -65,6 +68,7 @@ struct LatParams
     int cosine;
     int reg_select;  // stage 1: probe list by the register selection (lat_select_probes) instead of the list merge
     uint32_t * done; // [2] arrival counters of the two stages; zero between calls
+    uint32_t * done_q; // coarse_few_kernel: [ceil(nq / T)] arrival counters of the query groups; zero between calls
     uint32_t * flag; // nullable: host-visible completion word, set to `seq` after the results are written
     uint32_t seq;
     unsigned long long * dbg; // nullable: [16] wall-clock stamps (100 MHz) of the two last blocks (experiments)
@@ -517,6 +521,74 @@ __global__ __launch_bounds__(BLOCK) void lat_scan_kernel(const LatParams p)
                       // visible to the host thread that acquires the word
             __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+/// The canonical coarse quantiser of a SMALL batch in one launch (search_entry.hip: coarse_few_launch; step 1 of the general search for
+/// up to LAT_COARSE_MAX_Q queries): grid (c_blocks, ceil(nq / T)).  Block (b, g) scans c_rows centroids for the T queries of group g
+/// (scan_rows: the canonical arithmetic, one pass over the rows for the T of them -- one query per block re-reads the 3 MB table per
+/// query: 36 us of L2 -> CU streaming at 64 queries), publishes their T lists and arrives at the GROUP's counter; the last block of a
+/// group selects its queries' probes, one wavefront per query (lat_select_probes: exact top-nprobe in the oracle's order of keys; the
+/// probes leave in arbitrary order).  The batched kernels spend a scan and a merge launch on this: 22 + 14 us at 32 queries.
+/// dynamic LDS: T * ld4 * 16 + T * 5 * nprobe * 8 bytes; c_blocks * nprobe <= 32 * WAVE.
+template <int METRIC, int T>
+__global__ __launch_bounds__(BLOCK) void coarse_few_kernel(const LatParams p)
+{
+    static_assert(T <= BLOCK / WAVE, "one wavefront per query in the selection");
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)T * p.ld4 * 16);
+    const uint32_t tid = threadIdx.x, g = blockIdx.y, b = blockIdx.x, np = p.nprobe, q0 = g * T;
+    ScanParams a{};
+    a.Y = p.C;
+    a.Q = p.Q;
+    a.ld4 = p.ld4;
+    a.k = np;
+    a.nq = p.nq;
+    __shared__ uint64_t s_list[T][LAT_MAX_K];
+    __shared__ uint32_t s_last;
+    uint32_t qidx[T];
+    uint64_t * out[T];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+    {
+        qidx[t] = q0 + t < p.nq ? q0 + t : p.nq - 1;
+        out[t] = s_list[t];
+    }
+    stage_queries<T>(a, qidx, qs);
+    const uint32_t rb = b * p.c_rows, re = rb + p.c_rows < p.nlist ? rb + p.c_rows : p.nlist;
+    scan_rows<METRIC, T, 1>(a, rb, re, qs, lds_merge, out);
+    __syncthreads();
+    // the T lists go out with agent-scope stores that are waited for before the arrival (lat_publish_and_arrive)
+#pragma unroll
+    for (int t = 0; t < T; t++)
+        if (q0 + t < p.nq && tid < np)
+            __hip_atomic_store(p.c_partial + ((size_t)(q0 + t) * p.c_blocks + b) * np + tid, s_list[t][tid], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0)
+        s_last = atomicAdd(p.done_q + g, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last)
+        return;
+    const uint32_t total = p.c_blocks * np, w = tid >> 6, q = q0 + w;
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
+    uint32_t * hist = p.reg_select == 3 ? nullptr : s_hist[w];
+    if (w < (uint32_t)T && q < p.nq)
+    {
+        const uint64_t * src = p.c_partial + (size_t)q * total;
+        int32_t * dst = p.probes + (size_t)q * np;
+        float * dd = p.probe_dis + (size_t)q * np;
+        if (total <= 4 * WAVE)
+            lat_select_probes<4>(src, total, np, dst, dd, tid & 63, hist);
+        else if (total <= 8 * WAVE)
+            lat_select_probes<8>(src, total, np, dst, dd, tid & 63, hist);
+        else if (total <= 16 * WAVE)
+            lat_select_probes<16>(src, total, np, dst, dd, tid & 63, hist);
+        else
+            lat_select_probes<32>(src, total, np, dst, dd, tid & 63, hist);
+    }
+    if (tid == 0)
+        p.done_q[g] = 0;
 }
 
 }

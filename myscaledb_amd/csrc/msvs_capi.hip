@@ -1129,7 +1129,15 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.seg_out = seg_words;
     pp.seg_target_items = 4 * device_cu_count();
     if (!zeroed)
-        MSVS_HIP(hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), stream));
+    {
+        if (ivf_plan_fused(pp)) // (a small batch: the one-launch plan needs no zeroed counts and clears nfail / the cursors / nfail2 itself)
+        {
+            pp.zero = nfail;
+            pp.nzero = 18;
+        }
+        else
+            MSVS_HIP(hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), stream));
+    }
     // ... and the sample launch's partition of the same pairs: block 0 of every probed list, tiles of 32 queries (small
     // workgroups) -- one scan launch computes both
     pp.list_off2 = ix.list_off.p;
@@ -1243,6 +1251,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     {
         // the main launch's plan over the surviving pairs
         IvfPlanParams p2 = pp;
+        p2.zero = nullptr;
+        p2.nzero = 0;
         p2.probes = pr.out_probes;
         p2.cnt = counters + 2 * ix.nlist + 18;
         p2.fill = p2.cnt + ix.nlist;
@@ -1511,8 +1521,10 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
             co.out_probe_dis = pd;
             prepared.probe_dis = pd;
         }
-        flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co,
-                           stream);
+        // a small batch: one self-merging launch (search_entry.hip: coarse_few_launch); a sharded search's probe lists keep the
+        // sorted form the scan + merge launches leave
+        if (probes_only || !coarse_few_launch(ix, dq, nq, nprobe, d_probes, co.out_probe_dis, stream))
+            flat_search_device(scr, m, ix.centroids.p, nullptr, ix.nlist, ld, dq, nq, (uint32_t)nprobe, nullptr, 0, co, stream);
     }
     // 1b. pre-pruning by the list radius alone (h16_preprune_kernel): L2 and cosine indexes, unfiltered searches over the stored lists,
     // whenever the coarse stage left distances behind -- approximate words (centroid shadow; a sharded search's probe words) or the

@@ -31,22 +31,31 @@ struct LatCtx
     DevBuf<uint32_t> cut;
     DevBuf<uint64_t> c_partial, partial;
     DevBuf<uint32_t> done;
+    // stage 1 as the coarse quantiser of a small batch (coarse_few_launch): its own lists and per-query arrival counters
+    DevBuf<uint64_t> cf_partial;
+    DevBuf<uint32_t> cf_done;
+    DevBuf<float> cf_dis;
     // host side (pinned, device-visible): queries in, results + completion word out
     unsigned char * pinned = nullptr;
     size_t pinned_bytes = 0;
     uint32_t seq = 0;
-    void need_pinned(size_t bytes)
+    // ... and of a small batch (index_search_host_call): its own block -- the few-query paths keep a completion word in theirs
+    unsigned char * batch_pinned = nullptr;
+    size_t batch_pinned_bytes = 0;
+    static void grow(unsigned char *& p, size_t & have, size_t bytes)
     {
-        if (bytes <= pinned_bytes)
+        if (bytes <= have)
             return;
-        if (pinned)
-            MSVS_HIP(hipHostFree(pinned));
-        pinned = nullptr;
-        pinned_bytes = 0;
-        MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), bytes, hipHostMallocCoherent)); // fine-grained whatever HIP_HOST_COHERENT says
-        pinned_bytes = bytes;
-        memset(pinned, 0, bytes);
+        if (p)
+            MSVS_HIP(hipHostFree(p));
+        p = nullptr;
+        have = 0;
+        MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), bytes, hipHostMallocCoherent)); // fine-grained whatever HIP_HOST_COHERENT says
+        have = bytes;
+        memset(p, 0, bytes);
     }
+    void need_pinned(size_t bytes) { grow(pinned, pinned_bytes, bytes); }
+    void need_batch_pinned(size_t bytes) { grow(batch_pinned, batch_pinned_bytes, bytes + bytes / 2); }
 };
 
 LatCtx & lat_ctx(hipStream_t stream)
@@ -180,6 +189,80 @@ void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, u
     MSVS_HIP(hipGetLastError());
 }
 
+}
+
+/// Step 1 of the general IVFFLAT search for a SMALL batch (msvs_capi.hip: index_search_device_one): the canonical top-nprobe of the
+/// centroids in ONE launch -- coarse_few_kernel: grid (c_blocks, groups of 4 queries), the last block of a group selects
+/// its queries' probes -- where the batched kernels take a scan and a merge launch (22 + 14 us for 32 queries over 1024 centroids; this: one
+/// launch of ~10 us).  Same canonical arithmetic and total order (the probes are the oracle's; they leave in arbitrary order, which
+/// no consumer of the general path depends on).  dq: nq scan-ready rows.  probe_dis: nullable.  -> false: not for this shape.
+bool msvs::coarse_few_launch(const msvs_index & ix, const float * dq, size_t nq, size_t nprobe, int32_t * d_probes, float * d_probe_dis,
+                             hipStream_t stream)
+{
+    if (options().coarse_few == 0 || nq < 1 || nq > std::min<size_t>(LAT_COARSE_MAX_Q, (size_t)options().coarse_few) || nprobe < 1
+        || nprobe > LAT_MAX_K || nprobe > ix.nlist || options().lat_select == 0)
+        return false;
+    // centroids per block: 32, more when a query's lists would not fit the selection's registers or the launch would be far beyond
+    // two blocks per CU
+    // queries per block: one while the table's re-reads are cheap (<= 16 queries: 41.7 against 49.7 us per 4-query search, 129
+    // against 134 at 16), LAT_COARSE_T beyond (137.8 against 144.5 us at 32, 164 against 186 at 64)
+    const int T = nq <= 16 ? 1 : LAT_COARSE_T;
+    const size_t groups = ceil_div(nq, (size_t)T);
+    size_t c_rows = 32 * ceil_div(ix.nlist * nprobe, (size_t)32 * 32 * WAVE);
+    while (c_rows < 256 && ceil_div(ix.nlist, c_rows) * groups > (size_t)4 * device_cu_count())
+        c_rows *= 2;
+    const size_t c_blocks = ceil_div(ix.nlist, c_rows);
+    const size_t lds = (size_t)T * ix.ld * 4 + (size_t)T * 5 * nprobe * 8;
+    if (lds > SCAN_LDS_BUDGET || c_blocks * nprobe > 32 * WAVE)
+        return false;
+    LatCtx & c = lat_ctx(stream);
+    const size_t n_cp = nq * c_blocks * nprobe;
+    if (c.cf_partial.n < n_cp || !c.cf_done.p)
+    {
+        MSVS_HIP(hipStreamSynchronize(stream)); // an earlier call on this stream may still use the old buffers
+        if (c.cf_partial.n < n_cp)
+            c.cf_partial.alloc(LAT_COARSE_MAX_Q * (size_t)32 * WAVE);
+        if (!c.cf_done.p)
+        {
+            c.cf_done.alloc(LAT_COARSE_MAX_Q);
+            c.cf_dis.alloc(LAT_COARSE_MAX_Q * LAT_MAX_K);
+            MSVS_HIP(hipMemset(c.cf_done.p, 0, LAT_COARSE_MAX_Q * 4));
+            MSVS_HIP(hipDeviceSynchronize());
+        }
+    }
+    LatParams p{};
+    p.Q = reinterpret_cast<const float4 *>(dq);
+    p.nq = (uint32_t)nq;
+    p.ld4 = ix.ld / 4;
+    p.nprobe = (uint32_t)nprobe;
+    p.nlist = (uint32_t)ix.nlist;
+    p.C = reinterpret_cast<const float4 *>(ix.centroids.p);
+    p.c_rows = (uint32_t)c_rows;
+    p.c_blocks = (uint32_t)c_blocks;
+    p.reg_select = (int)options().lat_select;
+    p.c_partial = c.cf_partial.p;
+    p.probes = d_probes;
+    p.probe_dis = d_probe_dis ? d_probe_dis : c.cf_dis.p;
+    p.done_q = c.cf_done.p;
+    const dim3 g1(p.c_blocks, (unsigned)groups);
+    ProfileScope prof("coarse_few", stream);
+    if (ix.metric == MSVS_METRIC_L2)
+    {
+        if (T == 1)
+            hipLaunchKernelGGL((coarse_few_kernel<M_L2, 1>), g1, dim3(BLOCK), lds, stream, p);
+        else
+            hipLaunchKernelGGL((coarse_few_kernel<M_L2, LAT_COARSE_T>), g1, dim3(BLOCK), lds, stream, p);
+    }
+    else if (T == 1)
+        hipLaunchKernelGGL((coarse_few_kernel<M_IP, 1>), g1, dim3(BLOCK), lds, stream, p);
+    else
+        hipLaunchKernelGGL((coarse_few_kernel<M_IP, LAT_COARSE_T>), g1, dim3(BLOCK), lds, stream, p);
+    MSVS_HIP(hipGetLastError());
+    return true;
+}
+
+namespace
+{
 /// VectorDataset::normalize() of one row on the host: the arithmetic of normalize_rows_kernel (strictly sequential f32
 /// sum of squares, IEEE sqrt and divide), so a query prepared here equals one prepared on the device bit for bit.
 void normalize_row_host(float * p, uint32_t d)
@@ -357,6 +440,26 @@ int index_search_host_call(const msvs_index_t * ix, const float * queries, size_
             // results out through pinned memory, a completion word instead of copies + synchronisation, the canonical fallback
             // launched only when a certificate failed (HostSignal, index_internal.hpp)
             flat_few_search_host(*ix, queries, nq, (uint32_t)k, ids, dis, stream);
+            return;
+        }
+        if (ix->type == MSVS_INDEX_IVFFLAT && !filtered && !eff_filtered && (size_t)k <= MSVS_MAX_K && nq <= (size_t)options().host_pinned
+            && !(meta && meta->row_ids_n))
+        {
+            // a small batch (a combined batch of concurrent single-query callers; a few rows of a batch_distance call): the queries
+            // go up from pinned memory and the result kernels write ids / distances straight into pinned memory -- the copy from
+            // pageable memory and the two copies back cost ~35 of the call's ~185 us at 32 queries
+            LatCtx & c = lat_ctx(stream);
+            const size_t o_ids = round_up(nq * ix->dim * 4, (size_t)256), o_dis = o_ids + round_up(nq * (size_t)k * 8, (size_t)256);
+            if (o_dis + nq * (size_t)k * 4 > c.batch_pinned_bytes)
+                c.need_batch_pinned(o_dis + nq * (size_t)k * 4);
+            memcpy(c.batch_pinned, queries, nq * ix->dim * 4);
+            int64_t * h_ids = reinterpret_cast<int64_t *>(c.batch_pinned + o_ids);
+            float * h_dis = reinterpret_cast<float *>(c.batch_pinned + o_dis);
+            MSVS_HIP(hipMemcpyAsync(dq.p, c.batch_pinned, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
+            index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, nullptr, 0, h_ids, h_dis, stream);
+            MSVS_HIP(hipStreamSynchronize(stream));
+            memcpy(ids, h_ids, nq * (size_t)k * 8);
+            memcpy(dis, h_dis, nq * (size_t)k * 4);
             return;
         }
         MSVS_HIP(hipMemcpyAsync(dq.p, queries, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));

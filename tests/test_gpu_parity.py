@@ -621,6 +621,34 @@ def test_selection_plan_and_fallback_variants_agree_with_the_oracle(knobs, opt):
         same(ids, dis, oi, od)
 
 
+@pytest.mark.parametrize("knobs", [{}, {"coarse_few": "0"}, {"plan_fused": "0"}, {"host_pinned": "0"}, {"lat_select": "3"},
+                                   {"coarse_few": "0", "plan_fused": "0", "host_pinned": "0"}])
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+def test_small_batches_one_launch_coarse_and_plan_match_oracle(metric, knobs, opt):
+    """Batches of 3 .. 130 queries through msvs_index_search (the combined batches of concurrent single-query callers): the
+    one-launch coarse quantiser (coarse_few_kernel, one and four queries per block), the one-launch pair grouping (the fused plan
+    kernel: up to 8192 pairs, beyond it the three-launch form) and the pinned query / result block, each against its multi-launch /
+    staged form: the oracle's ids and distances whichever runs.  Duplicate centroid distances (two copies of every row) put ties
+    into the probe selection; 1100 lists exercise the second round of the plan's scan (> 1024 lists) and more than 16 lists per
+    query group of the coarse selection."""
+    for name, v in knobs.items():
+        opt(name, v)
+    opt("lat_path", "0")  # (the batches of 1 - 2 queries below go through the general path too)
+    rng = np.random.default_rng(4711)
+    for n, d, nlist, nprobe, k in ((60000, 96, 300, 16, 10), (40000, 768, 64, 32, 10), (70000, 40, 1100, 64, 40), (5000, 20, 8, 8, 1)):
+        centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
+        x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+        x[n // 2:] = x[: n - n // 2]
+        ix = build_ivf(x, metric, nlist)
+        for nq in (1, 3, 4, 5, 16, 17, 33, 64, 130, 300):
+            q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+            oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+            for _ in range(2):  # (the second call reuses the arenas and the arrival counters of the first)
+                ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+                same(ids, dis, oi, od)
+        ix.close()
+
+
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_COSINE])
 def test_shadow_pass_serves_k_up_to_128_with_256_candidates(metric, opt):
     """40 < k <= 128 (a hybrid search takes the vector top-100): the fp16-shadow pass with 256 candidates per query, the
