@@ -146,6 +146,8 @@ struct Options
     double rerank_groups = 16; // candidate rows in flight per re-rank block (32: 512-thread blocks, measured slower: 70 vs 47 us)
     double rerank_stats = 0;  // experiments: count the candidates an early exit of the re-rank could skip (msvs_debug_rerank_stats)
     double combine = 8;       // msvs_index_search: single-query callers beyond this many in flight are batched by the next finisher (0: off)
+    double combine_spin = 0;  // the worker thread that runs the combined batches polls this many microseconds for the next one before it sleeps
+                              // (under load it collects the next batch itself; polling measured no gain: 166 k QPS either way at 64 callers)
     double combine_batches = 1; // ... and at most this many combined batches in flight (2: measured slower -- a batch of any size up to 64 costs the device the same ~0.2 ms and two of them do not overlap: the larger the batches the better)
     double h16_k128 = 1;      // shadow pass for 40 < k <= 128 with 256 candidates (0: the canonical scan as before)
     double coarse_h16_min_q = 192; // coarse quantiser through the centroid shadow from this many queries on (0: only with 128-query

@@ -4,6 +4,7 @@
 // concurrent single-query callers into batches.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -11,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "index_internal.hpp"
@@ -512,14 +514,18 @@ int index_search_host_call(const msvs_index_t * ix, const float * queries, size_
 // ------------------------------------------------------------------------------------------ combining concurrent callers
 //
 // The reference's host calls VectorIndex::search from up to ScanThreadLimiter-many threads, one query each
-// (MergeTreeVSManager.cpp:973).  One query is a whole-GPU job of ~55 us here, so beyond a handful of concurrent callers the
+// (MergeTreeVSManager.cpp:973).  One query is a whole-GPU job of ~45 us here, so beyond a handful of concurrent callers the
 // calls only queue behind each other on the device (64 threads: 26 k QPS), while ONE batched search of 64 queries takes
-// 0.37 ms (170 k QPS).  So: up to `combine` (8) single calls run directly, each on its thread's stream, exactly as
-// before, as long as nobody waits; callers beyond that wait in a queue, and the next call to finish while no batch is in
-// flight hands the lead to the first waiter together with EVERY compatible waiter's query (same k, same parameter string,
-// no filter) -- that thread runs them as one batch and distributes the rows; while a batch runs, new callers queue up for
-// the next one.  No timer, no extra latency for a lone caller; results are the same bits either way (every path is
-// exact).  msvs_combine_stats counts the batches.
+// 0.2 ms.  So: up to `combine` (8) single calls run directly, each on its thread's stream, as long as nobody waits; callers
+// beyond that wait in a queue, and the next search to finish while no batch is in flight collects EVERY compatible waiter's
+// query (same k, same parameter string, no filter) into one batch for the index's WORKER thread, which runs it, wakes its
+// callers and collects the next batch itself while callers keep arriving.  No timer, no extra latency for a lone caller;
+// results are the same bits either way (every path is exact).  msvs_combine_stats counts the batches.
+// Round 5 (tools/r5_threads.py; 64 callers, batches of ~32): the batches ran on the first waiter's thread before -- every
+// batch on another thread with its own stream, scratch arenas and pinned block (cold, or not allocated yet), behind a
+// finisher that woke 31 callers under the lock the new leader needed: 307 us per batch cycle around a 174 us search,
+// 104 k QPS.  One warm worker thread + per-request wake-ups spread over four of the callers: 188 us per cycle, 166 k QPS
+// (128 callers: 134 k -> 269 k).
 namespace
 {
 struct CombineReq
@@ -532,20 +538,75 @@ struct CombineReq
     float * dis;
     int status = 0;
     std::string err;
-    int state = 0; // 0 waiting, 1 leader of `batch`, 2 served
     std::vector<CombineReq *> batch;
+    unsigned long long t_handed = 0; // (experiments) when a finisher made this request the next leader
+    // 0 waiting, 2 served.  Every request waits on its OWN mutex / condition variable (the combiner's mutex guards the queue only):
+    // whoever wakes the callers of a batch holds no lock anybody else needs (with one mutex for everything the next batch sat behind
+    // 31 wake-ups: ~130 us of a ~300 us cycle at 64 callers).
+    std::atomic<int> state{0};
+    std::vector<CombineReq *> to_wake; // a served request may be handed more of its batch to wake (the worker wakes a few heads only)
+    std::mutex m;
     std::condition_variable cv;
+    void wake(int s)
+    {
+        std::lock_guard<std::mutex> l(m); // (the waiter passes this mutex before it returns: `this` outlives the call)
+        state.store(s, std::memory_order_release);
+        cv.notify_one();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return state.load(std::memory_order_acquire) != 0; });
+        return state.load(std::memory_order_acquire);
+    }
 };
 struct Combiner
 {
     std::mutex mu;
     std::deque<CombineReq *> queue;
-    int active = 0;  // leaders running (single calls and batches)
+    int active = 0;  // searches running (single calls and batches)
     int batches = 0; // ... of which batches of several callers
+    // The batches run on ONE worker thread per index: one stream, one set of scratch arenas and pinned blocks, all of them warm.
+    // (Round 4 made the first waiter the leader of the next batch: with 64 callers every batch ran on another thread, each with
+    // its own stream, arenas and pinned block to allocate and fault in -- 40 to 170 us per batch beside the search itself.)
+    const msvs_index * ix = nullptr;
+    std::thread worker;
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::deque<CombineReq *> handed; // collected batches (their first requests) the worker runs next (guarded by wmu)
+    std::atomic<int> n_handed{0};
+    std::atomic<bool> stop{false};
+    CombineReq * take() // wmu held
+    {
+        if (handed.empty())
+            return nullptr;
+        CombineReq * r = handed.front();
+        handed.pop_front();
+        n_handed.fetch_sub(1, std::memory_order_relaxed);
+        return r;
+    }
+    void submit(CombineReq * lead); // a finisher hands the batch over
+    void worker_main();
+    ~Combiner()
+    {
+        if (worker.joinable())
+        {
+            {
+                std::lock_guard<std::mutex> l(wmu);
+                stop.store(true);
+                wcv.notify_one();
+            }
+            worker.join();
+        }
+    }
 };
 std::mutex g_comb_mu;
 std::unordered_map<const msvs_index *, std::shared_ptr<Combiner>> g_comb;
 std::atomic<unsigned long long> g_comb_calls{0}, g_comb_batches{0}, g_comb_batched{0};
+// experiments (msvs_debug_combine_times): ns of batches of several callers -- hand-over (the previous finisher's decision -> this leader
+// running), gather, the search call, distribution
+std::atomic<unsigned long long> g_comb_ns[4];
+inline unsigned long long comb_now() { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 constexpr size_t COMBINE_MAX_QUERIES = 1024;
 
 std::shared_ptr<Combiner> combiner_of(const msvs_index * ix)
@@ -553,7 +614,10 @@ std::shared_ptr<Combiner> combiner_of(const msvs_index * ix)
     std::lock_guard<std::mutex> lk(g_comb_mu);
     auto & c = g_comb[ix];
     if (!c)
+    {
         c = std::make_shared<Combiner>();
+        c->ix = ix;
+    }
     return c;
 }
 }
@@ -583,6 +647,9 @@ void combine_run(const msvs_index * ix, CombineReq & lead)
     for (auto * r : b)
         total += r->nq;
     const size_t d = ix->dim, k = (size_t)lead.k;
+    const unsigned long long t0 = comb_now();
+    if (lead.t_handed)
+        g_comb_ns[0].fetch_add(t0 - lead.t_handed, std::memory_order_relaxed);
     static thread_local std::vector<float> qbuf, dbuf;
     static thread_local std::vector<int64_t> ibuf;
     qbuf.resize(total * d);
@@ -594,7 +661,9 @@ void combine_run(const msvs_index * ix, CombineReq & lead)
         memcpy(qbuf.data() + at * d, r->q, r->nq * d * 4);
         at += r->nq;
     }
+    const unsigned long long t1 = comb_now();
     const int rc = index_search_host_call(ix, qbuf.data(), total, lead.k, lead.params.c_str(), nullptr, 0, ibuf.data(), dbuf.data());
+    const unsigned long long t2 = comb_now();
     const std::string err = rc ? msvs_last_error() : "";
     at = 0;
     for (auto * r : b)
@@ -610,6 +679,9 @@ void combine_run(const msvs_index * ix, CombineReq & lead)
     }
     g_comb_batches.fetch_add(1, std::memory_order_relaxed);
     g_comb_batched.fetch_add(total, std::memory_order_relaxed);
+    g_comb_ns[1].fetch_add(t1 - t0, std::memory_order_relaxed);
+    g_comb_ns[2].fetch_add(t2 - t1, std::memory_order_relaxed);
+    g_comb_ns[3].fetch_add(comb_now() - t2, std::memory_order_relaxed);
 }
 
 /// `lead` takes every compatible waiter's queries with it (same k, same parameter string; waiters with another k / parameter
@@ -629,6 +701,90 @@ void combine_collect(Combiner & c, CombineReq * lead)
             ++it;
     if (lead->batch.size() > 1)
         c.batches++;
+}
+
+void combine_run_guarded(const msvs_index * ix, CombineReq & lead)
+{
+    try
+    {
+        combine_run(ix, lead); // the C entry underneath translates its own exceptions; what is left is the gather's allocation
+    }
+    catch (...)
+    {
+        for (auto * r : lead.batch)
+        {
+            r->status = MSVS_ERR_OUT_OF_MEMORY;
+            r->err = "host allocation failed while combining concurrent searches";
+        }
+    }
+}
+
+/// `done` has run: the books, and the next batch if callers are waiting (-> its first request, collected; else nullptr).
+CombineReq * combine_finish(Combiner & c, const CombineReq & done)
+{
+    const int max_batches = std::max(1, (int)options().combine_batches);
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.active--;
+    if (done.batch.size() > 1)
+        c.batches--;
+    if (c.queue.empty() || c.batches >= max_batches)
+        return nullptr;
+    c.active++;
+    CombineReq * next = c.queue.front();
+    c.queue.pop_front();
+    combine_collect(c, next);
+    next->t_handed = comb_now();
+    return next;
+}
+
+void Combiner::submit(CombineReq * lead)
+{
+    std::lock_guard<std::mutex> l(wmu);
+    if (!worker.joinable())
+        worker = std::thread([this] { worker_main(); });
+    handed.push_back(lead);
+    n_handed.fetch_add(1, std::memory_order_release);
+    wcv.notify_one();
+}
+
+void Combiner::worker_main()
+{
+    (void)hipSetDevice(ix->device);
+    for (;;)
+    {
+        // the next batch: polled for a while after the last one (a futex wake-up is ~50 us of idle device), then slept for
+        CombineReq * lead = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto spin = std::chrono::microseconds((long)options().combine_spin);
+        for (uint32_t i = 1; n_handed.load(std::memory_order_acquire) == 0 && !stop.load(std::memory_order_relaxed); i++)
+        {
+            __builtin_ia32_pause();
+            if ((i & 0xff) == 0 && std::chrono::steady_clock::now() - t0 > spin)
+                break;
+        }
+        {
+            std::unique_lock<std::mutex> l(wmu);
+            wcv.wait(l, [&] { return !handed.empty() || stop.load(); });
+            lead = take();
+            if (!lead)
+                return;
+        }
+        while (lead)
+        {
+            combine_run_guarded(ix, *lead);
+            CombineReq * next = combine_finish(*this, *lead);
+            // the callers of this batch: the worker wakes four of them and each of those its share of the rest -- 32 wake-ups are
+            // ~100 us of system calls the next batch would wait behind.  (A woken request is gone: the list is taken first.)
+            std::vector<CombineReq *> members;
+            members.swap(lead->batch);
+            const size_t heads = std::min<size_t>(4, members.size());
+            for (size_t i = heads; i < members.size(); i++)
+                members[i % heads]->to_wake.push_back(members[i]);
+            for (size_t i = 0; i < heads; i++)
+                members[i]->wake(2);
+            lead = next;
+        }
+    }
 }
 
 int combined_search(const msvs_index * ix, const float * queries, size_t nq, int k, const char * params, int64_t * ids, float * dis)
@@ -663,50 +819,22 @@ int combined_search(const msvs_index * ix, const float * queries, size_t nq, int
     else
     {
         c.queue.push_back(&me);
-        me.cv.wait(lk, [&] { return me.state != 0; });
-        if (me.state == 2)
-        {
-            lk.unlock();
-            if (me.status)
-                set_last_error(me.err);
-            return me.status;
-        }
+        lk.unlock();
+        me.wait(); // (served by the worker's batch)
+        for (auto * r : me.to_wake)
+            r->wake(2);
+        if (me.status)
+            set_last_error(me.err);
+        return me.status;
     }
     lk.unlock();
-    try
-    {
-        combine_run(ix, me); // the C entry underneath translates its own exceptions; what is left is the gather's allocation
-    }
-    catch (...)
-    {
-        for (auto * r : me.batch)
-        {
-            r->status = MSVS_ERR_OUT_OF_MEMORY;
-            r->err = "host allocation failed while combining concurrent searches";
-        }
-    }
-    lk.lock();
-    c.active--;
-    if (me.batch.size() > 1)
-        c.batches--;
-    // the hand-over comes FIRST (the device idles until the next leader runs; this batch's callers only have to be told)
-    if (!c.queue.empty() && c.batches < max_batches)
-    {
-        // the first waiter leads next, with every compatible waiter's queries
-        c.active++;
-        CombineReq * next = c.queue.front();
-        c.queue.pop_front();
-        combine_collect(c, next);
-        next->state = 1;
-        next->cv.notify_one();
-    }
-    for (auto * r : me.batch)
+    combine_run_guarded(ix, me);
+    CombineReq * next = combine_finish(c, me);
+    if (next)
+        c.submit(next);
+    for (auto * r : me.batch) // (a second batch in flight, led by this caller: option combine_batches)
         if (r != &me)
-        {
-            r->state = 2;
-            r->cv.notify_one();
-        }
-    lk.unlock();
+            r->wake(2);
     if (me.status)
         set_last_error(me.err);
     return me.status;
@@ -724,6 +852,13 @@ extern "C" int msvs_index_search(const msvs_index_t * ix, const float * queries,
 }
 
 /// calls that went through the combiner, batches of more than one caller, queries served by such batches
+extern "C" __attribute__((visibility("default"))) int msvs_debug_combine_times(uint64_t * out4)
+{
+    for (int i = 0; i < 4; i++)
+        out4[i] = g_comb_ns[i].load();
+    return 0;
+}
+
 extern "C" int msvs_combine_stats(uint64_t * calls, uint64_t * batches, uint64_t * batched_queries)
 {
     if (calls)

@@ -1305,6 +1305,18 @@ def test_concurrent_single_query_callers_are_combined_into_batches(opt):
     # two- and four-query calls take part too
     i2, d2 = ix.search(q[:4], 10, "nprobe=8")
     same(i2, d2, exp[(10, 8)][0][:4], exp[(10, 8)][1][:4])
+    # the index goes (its worker thread with it); the next one -- possibly at the same address -- starts its own
+    ix.close()
+    for _ in range(2):
+        ix2 = build_ivf(x[:20000], capi.METRIC_L2, 64)
+        opt("combine", "0")
+        e2 = ix2.search(q, 10, "nprobe=8")
+        opt("combine", None)
+        c0 = capi.combine_stats()
+        sec, lat, ci, cd = mhost.concurrent_search(ix2, q, 32, 24, 10, "nprobe=8")
+        same(ci, cd, *e2)
+        assert capi.combine_stats()[1] > c0[1]
+        ix2.close()
 
 
 # ---------------------------------------------------------------------------------------- the certificate's premise, on hardware
