@@ -748,8 +748,10 @@ def main():
         # spend ~30 us per call under the GIL and cannot keep more than a few calls in flight: 26 k QPS whatever the library
         # does).  Callers beyond 8 in flight are served in batches by msvs_index_search's combining front end.
         import myscaledb_amd.host as mhost
-        for c in (1, 8, 64):
+        for c in (1, 8, 64, 128):
             per = 10000 // c if c > 1 else 4000
+            if c > 8:
+                mhost.concurrent_search(ix, qh, c, 20, k, sp)  # (the index's worker thread and its arenas exist)
             b0 = capi.combine_stats()
             sec, al, _, _ = mhost.concurrent_search(ix, qh, c, per, k, sp)
             b1 = capi.combine_stats()
@@ -757,6 +759,17 @@ def main():
                                      "p99_us": round(float(np.percentile(al, 99)), 1),
                                      "combined_batches": int(b1[1] - b0[1]), "queries_in_batches": int(b1[2] - b0[2]),
                                      "driver": "native threads (msvs_host_concurrent_search)"}
+        # small batches through the same entry (what a combined batch of concurrent callers costs; a few rows of a batch_distance call)
+        small = {}
+        for b in (4, 8, 16, 32, 64, 128, 256):
+            for i in range(10):
+                ix.search(qh[i * b:(i + 1) * b], k, sp)
+            t1 = time.perf_counter()
+            for i in range(100):
+                ix.search(qh[(i % 16) * b:(i % 16 + 1) * b], k, sp)
+            dt_ = (time.perf_counter() - t1) / 100
+            small[str(b)] = {"us_per_call": round(dt_ * 1e6, 1), "qps": round(b / dt_, 1)}
+        res["host_pointer_small_batches"] = small
         # the seam's real call form for a batch (VIWithDataPart.cpp:900-926: a host DataSet<float> in, host result buffers out):
         # H2D of 4096 x 768 x 4 B = 12.6 MB, the search, D2H of the results -- one thread; then two host threads (each on its own
         # stream: one's copies beside the other's search -- the double-buffered form a serving loop would run)

@@ -225,7 +225,7 @@ __device__ __forceinline__ uint64_t * lat_merge_lists(const uint64_t * src, uint
 /// no LDS, no barrier), ties at that word broken exactly by a second search over the ids (the probes must be the
 /// oracle's: smallest (distance, id) first) -- 11.3 -> ~4 us for 1024 keys against popping 32 heads off 32 sorted
 /// lists.  The probes leave in arbitrary order (the list scan's result does not depend on it).
-template <int NW>
+template <int NW, int METRIC = -1>
 __device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, uint32_t np, int32_t * probes, float * dis, uint32_t lane,
                                          uint32_t * hist)
 {
@@ -265,7 +265,13 @@ __device__ inline void lat_select_probes(const uint64_t * src, uint32_t total, u
         if (take && pos < np)
         {
             probes[pos] = hi[u] == 0xFFFFFFFFu && lo[u] == 0xFFFFFFFFu ? -1 : (int32_t)lo[u];
-            dis[pos] = ord2f(hi[u]); // (an L2 key's high word; read by the radius pruning of L2 searches only)
+            // (the two-launch search: an L2 key's high word, read by the radius pruning of L2 searches only; METRIC given: the key's
+            // value as the merge launch of the batched coarse quantiser leaves it -- the general path's pre-pruning reads it for
+            // L2 and cosine searches)
+            if constexpr (METRIC < 0)
+                dis[pos] = ord2f(hi[u]);
+            else
+                dis[pos] = key_value<METRIC>((uint64_t)hi[u] << 32 | lo[u]);
         }
         run += (uint32_t)__popcll(mask);
     }
@@ -329,6 +335,7 @@ __device__ __forceinline__ LatCut lat_cut(const LatParams & p, uint32_t q, int32
 template <int METRIC>
 __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
 {
+    constexpr int SELM = -1; // (probe distances as L2 key words: lat_select_probes)
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
     uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)p.ld4 * 16);
     const uint32_t tid = threadIdx.x, q = blockIdx.y, b = blockIdx.x, np = p.nprobe;
@@ -365,13 +372,13 @@ __global__ __launch_bounds__(BLOCK) void lat_coarse_kernel(const LatParams p)
             int32_t * dst = p.probes + (size_t)qq * np;
             float * dd = p.probe_dis + (size_t)qq * np;
             if (total <= 4 * WAVE)
-                lat_select_probes<4>(src, total, np, dst, dd, tid & 63, hist);
+                lat_select_probes<4, SELM>(src, total, np, dst, dd, tid & 63, hist);
             else if (total <= 8 * WAVE)
-                lat_select_probes<8>(src, total, np, dst, dd, tid & 63, hist);
+                lat_select_probes<8, SELM>(src, total, np, dst, dd, tid & 63, hist);
             else if (total <= 16 * WAVE)
-                lat_select_probes<16>(src, total, np, dst, dd, tid & 63, hist);
+                lat_select_probes<16, SELM>(src, total, np, dst, dd, tid & 63, hist);
             else
-                lat_select_probes<32>(src, total, np, dst, dd, tid & 63, hist);
+                lat_select_probes<32, SELM>(src, total, np, dst, dd, tid & 63, hist);
         }
         __syncthreads();
     }
@@ -534,6 +541,7 @@ template <int METRIC, int T>
 __global__ __launch_bounds__(BLOCK) void coarse_few_kernel(const LatParams p)
 {
     static_assert(T <= BLOCK / WAVE, "one wavefront per query in the selection");
+    constexpr int SELM = METRIC; // (probe distances as key values)
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
     uint64_t * lds_merge = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)T * p.ld4 * 16);
     const uint32_t tid = threadIdx.x, g = blockIdx.y, b = blockIdx.x, np = p.nprobe, q0 = g * T;
@@ -579,13 +587,13 @@ __global__ __launch_bounds__(BLOCK) void coarse_few_kernel(const LatParams p)
         int32_t * dst = p.probes + (size_t)q * np;
         float * dd = p.probe_dis + (size_t)q * np;
         if (total <= 4 * WAVE)
-            lat_select_probes<4>(src, total, np, dst, dd, tid & 63, hist);
+            lat_select_probes<4, SELM>(src, total, np, dst, dd, tid & 63, hist);
         else if (total <= 8 * WAVE)
-            lat_select_probes<8>(src, total, np, dst, dd, tid & 63, hist);
+            lat_select_probes<8, SELM>(src, total, np, dst, dd, tid & 63, hist);
         else if (total <= 16 * WAVE)
-            lat_select_probes<16>(src, total, np, dst, dd, tid & 63, hist);
+            lat_select_probes<16, SELM>(src, total, np, dst, dd, tid & 63, hist);
         else
-            lat_select_probes<32>(src, total, np, dst, dd, tid & 63, hist);
+            lat_select_probes<32, SELM>(src, total, np, dst, dd, tid & 63, hist);
     }
     if (tid == 0)
         p.done_q[g] = 0;

@@ -643,9 +643,22 @@ def test_small_batches_one_launch_coarse_and_plan_match_oracle(metric, knobs, op
         for nq in (1, 3, 4, 5, 16, 17, 33, 64, 130, 300):
             q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
             oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+            # the multi-launch / staged forms first: the queries that lose their certificate there ...
+            for name in ("coarse_few", "plan_fused", "host_pinned"):
+                opt(name, "0")
+            f0 = capi.prefilter_stats()[1]
+            ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+            same(ids, dis, oi, od)
+            f_multi = capi.prefilter_stats()[1] - f0
+            for name in ("coarse_few", "plan_fused", "host_pinned"):
+                opt(name, knobs.get(name))
             for _ in range(2):  # (the second call reuses the arenas and the arrival counters of the first)
+                f0 = capi.prefilter_stats()[1]
                 ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
                 same(ids, dis, oi, od)
+                # ... are the ones that lose it here: the same probes, distances to the centroids and bounds reach the list scan (a
+                # wrong probe distance would still end in the right rows -- through the canonical fallback of every query)
+                assert capi.prefilter_stats()[1] - f0 == f_multi
         ix.close()
 
 

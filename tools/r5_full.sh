@@ -20,6 +20,7 @@ print("iid exhaustive_flat", {k: (iid.get("exhaustive_flat") or {}).get(k) for k
 print("iid at_config", {k: (iid.get("at_config_nprobe") or {}).get(k) for k in ("qps", "roofline_frac", "recall")})
 print("mid", json.dumps((d.get("operating_points") or {}).get("mid"))[:900])
 lat = d.get("latency") or {}
-print("latency", {k: lat.get(k) for k in ("p50_us", "p99_us", "host_pointer_batch4096", "host_pointer_batch4096_two_threads")}, (lat.get("threads_64") or {}).get("qps"))
+print("latency", {k: lat.get(k) for k in ("p50_us", "p99_us", "host_pointer_batch4096", "host_pointer_batch4096_two_threads")}, (lat.get("threads_64") or {}).get("qps"), (lat.get("threads_128") or {}).get("qps"))
+print("small batches", lat.get("host_pointer_small_batches"))
 print("setup", d.get("setup_s"), "errors", [k for k, v in d.items() if isinstance(v, dict) and "error" in v])
 PY
