@@ -537,6 +537,31 @@ static __global__ void host_signal_kernel(const uint32_t * nfail, uint32_t * h_n
     __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // the re-rank's result stores ended with its launch
 }
 
+/// The armed signal of a host-pointer call (index_internal.hpp: HostSignal): the certificate-failure count goes to the host behind the
+/// launches enqueued so far, the host waits for the word.  -> true: nobody failed -- the results are complete and in place.
+static bool host_signal_round(HostSignal & hs, const uint32_t * nfail, hipStream_t stream)
+{
+    hs.armed = false;
+    hs.used = true;
+    hipLaunchKernelGGL(host_signal_kernel, dim3(1), dim3(1), 0, stream, nfail, hs.nfail, hs.flag, hs.seq);
+    MSVS_HIP(hipGetLastError());
+    for (uint64_t spins = 1; __atomic_load_n(hs.flag, __ATOMIC_ACQUIRE) != hs.seq; spins++)
+    {
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0) // a failed launch never sets the word: look at the stream now and then
+        {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess)
+                break;
+            if (e != hipErrorNotReady)
+                fail(MSVS_ERR_DEVICE, "host-pointer search: %s", hipGetErrorString(e));
+        }
+    }
+    if (__atomic_load_n(hs.flag, __ATOMIC_ACQUIRE) != hs.seq)
+        MSVS_HIP(hipStreamSynchronize(stream));
+    return *hs.nfail == 0;
+}
+
 /// Second half of a table pass, whatever produced the candidates: canonical re-rank + certificate, then the canonical scan
 /// of the table for the queries on the fail list.
 static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, const ScanParams & a, size_t nq, const float * qnorm,
@@ -599,25 +624,7 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
     if (hs.armed && t.flat_h16 && !t.out_probes)
     {
         // host-pointer call of a few queries: tell the host, let it decide about the fallback
-        hs.armed = false;
-        hs.used = true;
-        hipLaunchKernelGGL(host_signal_kernel, dim3(1), dim3(1), 0, stream, nfail, hs.nfail, hs.flag, hs.seq);
-        MSVS_HIP(hipGetLastError());
-        for (uint64_t spins = 1; __atomic_load_n(hs.flag, __ATOMIC_ACQUIRE) != hs.seq; spins++)
-        {
-            __builtin_ia32_pause();
-            if ((spins & 0xfff) == 0) // a failed launch never sets the word: look at the stream now and then
-            {
-                const hipError_t e = hipStreamQuery(stream);
-                if (e == hipSuccess)
-                    break;
-                if (e != hipErrorNotReady)
-                    fail(MSVS_ERR_DEVICE, "few-query search: %s", hipGetErrorString(e));
-            }
-        }
-        if (__atomic_load_n(hs.flag, __ATOMIC_ACQUIRE) != hs.seq)
-            MSVS_HIP(hipStreamSynchronize(stream));
-        if (*hs.nfail == 0)
+        if (host_signal_round(hs, nfail, stream))
             return;
         run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, slots, stream);
         MSVS_HIP(hipStreamSynchronize(stream));
@@ -1331,6 +1338,13 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     rp.stat_skip = options().rerank_stats != 0 ? prefilter_fail_counter() + 2 : nullptr;
     launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
     g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
+    // a small batch through msvs_index_search (search_entry.hip: the pinned form): the host learns how many queries are without a
+    // certificate and enqueues the second chance and the fallback rounds -- three launches that normally find nothing to do, ~14 of
+    // the batch's ~138 us -- only when somebody is; the results are in pinned memory at its return either way
+    HostSignal & hs = host_signal();
+    const bool signalled = hs.armed;
+    if (signalled && host_signal_round(hs, nfail, stream))
+        return;
     // second chance of the queries without a certificate: every row of their candidate buffers, certified against the cut
     uint32_t * failq2 = failq;
     uint32_t * nfail_final = nfail;
@@ -1386,6 +1400,8 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     fm.qmap = failq2;
     fm.qcount = nfail_final;
     run_fallback_rounds(scan_metric(m), c, fm, nq, fb_cap, pl.fb_slots, stream);
+    if (signalled)
+        MSVS_HIP(hipStreamSynchronize(stream));
 }
 
 /// given_probes (nullable): [nq][nprobe] list ids computed elsewhere (another rank's share of the coarse quantiser):

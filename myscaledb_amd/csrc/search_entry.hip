@@ -452,14 +452,33 @@ int index_search_host_call(const msvs_index_t * ix, const float * queries, size_
             // pageable memory and the two copies back cost ~35 of the call's ~185 us at 32 queries
             LatCtx & c = lat_ctx(stream);
             const size_t o_ids = round_up(nq * ix->dim * 4, (size_t)256), o_dis = o_ids + round_up(nq * (size_t)k * 8, (size_t)256);
-            if (o_dis + nq * (size_t)k * 4 > c.batch_pinned_bytes)
-                c.need_batch_pinned(o_dis + nq * (size_t)k * 4);
+            const size_t o_flag = round_up(o_dis + nq * (size_t)k * 4, (size_t)256);
+            if (o_flag + 256 > c.batch_pinned_bytes)
+                c.need_batch_pinned(o_flag + 256);
             memcpy(c.batch_pinned, queries, nq * ix->dim * 4);
             int64_t * h_ids = reinterpret_cast<int64_t *>(c.batch_pinned + o_ids);
             float * h_dis = reinterpret_cast<float *>(c.batch_pinned + o_dis);
             MSVS_HIP(hipMemcpyAsync(dq.p, c.batch_pinned, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
-            index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, nullptr, 0, h_ids, h_dis, stream);
-            MSVS_HIP(hipStreamSynchronize(stream));
+            // the shadow list scan ends with a completion word instead of its normally-empty fallback launches (HostSignal)
+            HostSignal & hs = host_signal();
+            uint32_t * flag = reinterpret_cast<uint32_t *>(c.batch_pinned + o_flag);
+            hs.flag = flag;
+            hs.nfail = flag + 16;
+            hs.seq = ++c.seq ? c.seq : ++c.seq; // never 0: the word starts at 0
+            hs.armed = options().host_signal_batch != 0 && nq <= 256; // (one pass of the device-level search: index_search_device splits beyond)
+            hs.used = false;
+            try
+            {
+                index_search_device(*ix, dq.p, nq, (uint32_t)k, (size_t)nprobe, nullptr, 0, h_ids, h_dis, stream);
+            }
+            catch (...)
+            {
+                hs.armed = false;
+                throw;
+            }
+            hs.armed = false;
+            if (!hs.used) // (another path than the shadow list scan served the batch: its results are in flight)
+                MSVS_HIP(hipStreamSynchronize(stream));
             memcpy(ids, h_ids, nq * (size_t)k * 8);
             memcpy(dis, h_dis, nq * (size_t)k * 4);
             return;
