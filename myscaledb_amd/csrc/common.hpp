@@ -201,6 +201,7 @@ struct Options
     double coarse_few = 128;     // the canonical coarse quantiser of a batch of at most this many queries in one self-merging launch (0: scan + merge launches)
     double host_pinned = 256;    // msvs_index_search over an IVFFLAT index, unfiltered batches of at most this many queries: queries and results through pinned memory (0: staged copies)
     double host_signal_batch = 1; // ... and their shadow list scan tells the host how many queries lost their certificate instead of launching the (normally empty) second chance and fallback rounds (0: always launched, stream synchronisation)
+    double coarse_dense = 1;     // ... over a table of <= 2048 centroids: every key written, no top-k in the scanning blocks (0: nprobe keys per block)
     double plan_fused = 1;       // grouping the (query, list) pairs of a small batch (<= 8192 pairs) in one launch (0: memset + three launches)
     double flat_sample_few = 1;  // FLAT shadow pass, <= 32 queries: sample + cut in one launch (flat_sample_few_kernel; 0: coarse_h16_kernel + flat_cut_kernel)
     double flat_host_signal = 1; // FLAT, a few queries, host pointers: pinned in / out + a completion word (0: copies + stream synchronisation)

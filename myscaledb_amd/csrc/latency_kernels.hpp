@@ -599,4 +599,102 @@ __global__ __launch_bounds__(BLOCK) void coarse_few_kernel(const LatParams p)
         p.done_q[g] = 0;
 }
 
+/// coarse_few_kernel without the per-block top-k, for tables of at most 32 * WAVE centroids (the selection's registers hold every
+/// key of a query): a block's nprobe-best list is as long as its slice of the table as soon as nprobe >= c_rows (32 of 32 on the bench
+/// index), so the blocks write the canonical key of EVERY (query, centroid) -- 16 lanes per centroid, the arithmetic and order of
+/// scan_rows / the re-rank (canonical_update over the lane's columns in ascending order, the component sums, row16_tree_sum) -- and
+/// the group's last block selects out of the nlist keys.  No top-k registers, no LDS merge: the launch is the row loads and the
+/// selection.  grid (ceil(nlist / c_rows), ceil(nq / T)); c_partial: [nq][nlist]; dynamic LDS: T * ld4 * 16 bytes.
+template <int METRIC, int T>
+__global__ __launch_bounds__(BLOCK) void coarse_dense_kernel(const LatParams p)
+{
+    static_assert(T <= BLOCK / WAVE, "one wavefront per query in the selection");
+    float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
+    const uint32_t tid = threadIdx.x, g = tid & 15, grp = tid >> 4, gq = blockIdx.y, b = blockIdx.x, np = p.nprobe, q0 = gq * T;
+    const uint32_t ld4 = p.ld4, jfull = ld4 >> 4, jtail = ld4 & 15;
+    __shared__ uint32_t s_last;
+#pragma unroll
+    for (int t = 0; t < T; t++)
+    {
+        const float4 * src = p.Q + (size_t)(q0 + t < p.nq ? q0 + t : p.nq - 1) * ld4;
+        for (uint32_t c = tid; c < ld4; c += BLOCK)
+            qs[t * ld4 + c] = src[c];
+    }
+    __syncthreads();
+    const uint32_t rb = b * p.c_rows, re = rb + p.c_rows < p.nlist ? rb + p.c_rows : p.nlist;
+    for (uint32_t base = rb; base < re; base += BLOCK / 16)
+    {
+        const uint32_t r = base + grp;
+        const bool rv = r < re;
+        const float4 * yrow = p.C + (size_t)(rv ? r : re - 1) * ld4 + g;
+        const float4 * qrow = qs + g;
+        float4 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+            acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t j = 0;
+        for (; j + 6 <= jfull; j += 6) // six 16-byte loads in flight per lane, then the queries over them
+        {
+            float4 y[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++)
+                y[u] = yrow[(j + u) * 16];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int u = 0; u < 6; u++)
+                    canonical_update<METRIC>(acc[t], qrow[t * ld4 + (j + u) * 16], y[u]);
+        }
+        for (; j < jfull; j++)
+        {
+            const float4 y1 = yrow[j * 16];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+                canonical_update<METRIC>(acc[t], qrow[t * ld4 + j * 16], y1);
+        }
+        if (g < jtail)
+        {
+            const float4 y1 = yrow[jfull * 16];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+                canonical_update<METRIC>(acc[t], qrow[t * ld4 + jfull * 16], y1);
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++)
+        {
+            float s = __fadd_rn(__fadd_rn(acc[t].x, acc[t].y), __fadd_rn(acc[t].z, acc[t].w));
+            s = row16_tree_sum(s);
+            if (rv && g == 0 && q0 + t < p.nq) // (agent scope: the last block of the group may run on another XCD)
+                __hip_atomic_store(p.c_partial + (size_t)(q0 + t) * p.nlist + r, make_key<METRIC>(s, r), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0)
+        s_last = atomicAdd(p.done_q + gq, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last)
+        return;
+    const uint32_t total = p.nlist, w = tid >> 6, q = q0 + w;
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
+    uint32_t * hist = p.reg_select == 3 ? nullptr : s_hist[w];
+    if (w < (uint32_t)T && q < p.nq)
+    {
+        const uint64_t * src = p.c_partial + (size_t)q * total;
+        int32_t * dst = p.probes + (size_t)q * np;
+        float * dd = p.probe_dis + (size_t)q * np;
+        if (total <= 4 * WAVE)
+            lat_select_probes<4, METRIC>(src, total, np, dst, dd, tid & 63, hist);
+        else if (total <= 8 * WAVE)
+            lat_select_probes<8, METRIC>(src, total, np, dst, dd, tid & 63, hist);
+        else if (total <= 16 * WAVE)
+            lat_select_probes<16, METRIC>(src, total, np, dst, dd, tid & 63, hist);
+        else
+            lat_select_probes<32, METRIC>(src, total, np, dst, dd, tid & 63, hist);
+    }
+    if (tid == 0)
+        p.done_q[gq] = 0;
+}
+
 }

@@ -204,21 +204,24 @@ bool msvs::coarse_few_launch(const msvs_index & ix, const float * dq, size_t nq,
     if (options().coarse_few == 0 || nq < 1 || nq > std::min<size_t>(LAT_COARSE_MAX_Q, (size_t)options().coarse_few) || nprobe < 1
         || nprobe > LAT_MAX_K || nprobe > ix.nlist || options().lat_select == 0)
         return false;
-    // centroids per block: 32, more when a query's lists would not fit the selection's registers or the launch would be far beyond
-    // two blocks per CU
     // queries per block: one while the table's re-reads are cheap (<= 16 queries: 41.7 against 49.7 us per 4-query search, 129
     // against 134 at 16), LAT_COARSE_T beyond (137.8 against 144.5 us at 32, 164 against 186 at 64)
     const int T = nq <= 16 ? 1 : LAT_COARSE_T;
     const size_t groups = ceil_div(nq, (size_t)T);
-    size_t c_rows = 32 * ceil_div(ix.nlist * nprobe, (size_t)32 * 32 * WAVE);
+    // a table of at most 32 * WAVE centroids: every (query, centroid) key goes out, the selection reads them all
+    // (coarse_dense_kernel: no top-k in the scanning blocks); a larger one: nprobe keys per block (coarse_few_kernel)
+    const bool dense = ix.nlist <= 32 * WAVE && options().coarse_dense != 0;
+    // centroids per block: 16 / 32, more when a query's lists would not fit the selection's registers or the launch would be
+    // far beyond four blocks per CU
+    size_t c_rows = dense ? 16 : 32 * ceil_div(ix.nlist * nprobe, (size_t)32 * 32 * WAVE);
     while (c_rows < 256 && ceil_div(ix.nlist, c_rows) * groups > (size_t)4 * device_cu_count())
         c_rows *= 2;
     const size_t c_blocks = ceil_div(ix.nlist, c_rows);
-    const size_t lds = (size_t)T * ix.ld * 4 + (size_t)T * 5 * nprobe * 8;
-    if (lds > SCAN_LDS_BUDGET || c_blocks * nprobe > 32 * WAVE)
+    const size_t lds = (size_t)T * ix.ld * 4 + (dense ? 0 : (size_t)T * 5 * nprobe * 8);
+    if (lds > SCAN_LDS_BUDGET || (!dense && c_blocks * nprobe > 32 * WAVE))
         return false;
     LatCtx & c = lat_ctx(stream);
-    const size_t n_cp = nq * c_blocks * nprobe;
+    const size_t n_cp = dense ? nq * ix.nlist : nq * c_blocks * nprobe;
     if (c.cf_partial.n < n_cp || !c.cf_done.p)
     {
         MSVS_HIP(hipStreamSynchronize(stream)); // an earlier call on this stream may still use the old buffers
@@ -248,7 +251,21 @@ bool msvs::coarse_few_launch(const msvs_index & ix, const float * dq, size_t nq,
     p.done_q = c.cf_done.p;
     const dim3 g1(p.c_blocks, (unsigned)groups);
     ProfileScope prof("coarse_few", stream);
-    if (ix.metric == MSVS_METRIC_L2)
+    if (dense)
+    {
+        if (ix.metric == MSVS_METRIC_L2)
+        {
+            if (T == 1)
+                hipLaunchKernelGGL((coarse_dense_kernel<M_L2, 1>), g1, dim3(BLOCK), lds, stream, p);
+            else
+                hipLaunchKernelGGL((coarse_dense_kernel<M_L2, LAT_COARSE_T>), g1, dim3(BLOCK), lds, stream, p);
+        }
+        else if (T == 1)
+            hipLaunchKernelGGL((coarse_dense_kernel<M_IP, 1>), g1, dim3(BLOCK), lds, stream, p);
+        else
+            hipLaunchKernelGGL((coarse_dense_kernel<M_IP, LAT_COARSE_T>), g1, dim3(BLOCK), lds, stream, p);
+    }
+    else if (ix.metric == MSVS_METRIC_L2)
     {
         if (T == 1)
             hipLaunchKernelGGL((coarse_few_kernel<M_L2, 1>), g1, dim3(BLOCK), lds, stream, p);

@@ -621,12 +621,14 @@ def test_selection_plan_and_fallback_variants_agree_with_the_oracle(knobs, opt):
         same(ids, dis, oi, od)
 
 
-@pytest.mark.parametrize("knobs", [{}, {"coarse_few": "0"}, {"plan_fused": "0"}, {"host_pinned": "0"}, {"lat_select": "3"},
+@pytest.mark.parametrize("knobs", [{}, {"coarse_few": "0"}, {"plan_fused": "0"}, {"host_pinned": "0"}, {"lat_select": "3"}, {"coarse_dense": "0"},
+                                   {"host_signal_batch": "0"},
                                    {"coarse_few": "0", "plan_fused": "0", "host_pinned": "0"}])
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
 def test_small_batches_one_launch_coarse_and_plan_match_oracle(metric, knobs, opt):
     """Batches of 3 .. 130 queries through msvs_index_search (the combined batches of concurrent single-query callers): the
-    one-launch coarse quantiser (coarse_few_kernel, one and four queries per block), the one-launch pair grouping (the fused plan
+    one-launch coarse quantiser (coarse_dense_kernel: every key of a table of <= 2048 centroids; coarse_few_kernel: a top-nprobe
+    list per block -- the 2100-list index and coarse_dense = 0; one and four queries per block), the one-launch pair grouping (the fused plan
     kernel: up to 8192 pairs, beyond it the three-launch form) and the pinned query / result block, each against its multi-launch /
     staged form: the oracle's ids and distances whichever runs.  Duplicate centroid distances (two copies of every row) put ties
     into the probe selection; 1100 lists exercise the second round of the plan's scan (> 1024 lists) and more than 16 lists per
@@ -635,7 +637,7 @@ def test_small_batches_one_launch_coarse_and_plan_match_oracle(metric, knobs, op
         opt(name, v)
     opt("lat_path", "0")  # (the batches of 1 - 2 queries below go through the general path too)
     rng = np.random.default_rng(4711)
-    for n, d, nlist, nprobe, k in ((60000, 96, 300, 16, 10), (40000, 768, 64, 32, 10), (70000, 40, 1100, 64, 40), (5000, 20, 8, 8, 1)):
+    for n, d, nlist, nprobe, k in ((60000, 96, 300, 16, 10), (40000, 768, 64, 32, 10), (70000, 40, 1100, 64, 40), (5000, 20, 8, 8, 1), (60000, 24, 2100, 20, 10)):
         centers = rng.standard_normal((nlist, d), dtype=np.float32) * 2
         x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
         x[n // 2:] = x[: n - n // 2]
