@@ -28,7 +28,8 @@ Prints ONE JSON line on rank 0 (driver contract) with these extra objects:
                    plus a bit-for-bit check of >= 256 bench queries against the parity oracle.
   other_batches -- the same index at 1 / 16 / 64 / 256 / 1024 queries per step.
   latency       -- SURVEY 8d's protocol through the host-pointer C-ABI (query in, ids + distances out): p50 / p99 of
-                   single-query calls, QPS at 1 / 8 / 64 concurrent host threads.
+                   single-query calls, QPS at 1 / 8 / 64 / 128 concurrent host threads (native threads, one query per call: the
+                   reference's calling pattern), small batches of 4 .. 256 host queries per call, the 4096-query host-pointer call.
   iid, blobs03  -- SURVEY 8d's data models at their recall >= 0.95 operating points.
   target_100m   -- one GPU's share of the configuration north_star states its targets on (100M x 768 L2 top-10 over 8 GPUs):
                    12.5M x 768 rows, 2048 local lists, 8 local probes; QPS at 64 / 1024 / 4096 queries per batch, recall@10 against
