@@ -194,10 +194,12 @@ void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, u
 }
 
 /// Step 1 of the general IVFFLAT search for a SMALL batch (msvs_capi.hip: index_search_device_one): the canonical top-nprobe of the
-/// centroids in ONE launch -- coarse_few_kernel: grid (c_blocks, groups of 4 queries), the last block of a group selects
-/// its queries' probes -- where the batched kernels take a scan and a merge launch (22 + 14 us for 32 queries over 1024 centroids; this: one
-/// launch of ~10 us).  Same canonical arithmetic and total order (the probes are the oracle's; they leave in arbitrary order, which
-/// no consumer of the general path depends on).  dq: nq scan-ready rows.  probe_dis: nullable.  -> false: not for this shape.
+/// centroids in ONE launch -- grid (centroid blocks, groups of 1 / 4 queries), the last block of a group (a per-group arrival
+/// counter) selects its queries' probes: coarse_dense_kernel for tables of <= 2048 centroids, coarse_few_kernel beyond -- where the
+/// batched kernels take a scan and a merge launch (22 + 14 us for 32 queries over 1024 centroids; this: one launch of ~20 us, most
+/// of it launch, arrival and the selection).  Same canonical arithmetic and total order (the probes are the oracle's; they leave
+/// in arbitrary order, which no consumer of the general path depends on; a sharded search's probe lists keep the batched form).
+/// dq: nq scan-ready rows.  probe_dis: nullable.  -> false: not for this shape.
 bool msvs::coarse_few_launch(const msvs_index & ix, const float * dq, size_t nq, size_t nprobe, int32_t * d_probes, float * d_probe_dis,
                              hipStream_t stream)
 {
