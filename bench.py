@@ -19,7 +19,9 @@ rows and queries iid N(0,1)^768 (`iid`: no IVF index reaches recall 0.95 on it, 
 the low-intrinsic-dimension mixture the first three rounds quoted (`latent32`: 1024 blobs in a 32-d latent space embedded in
 R^768) are separate legs.  `--data` picks the headline's model.
 
-Prints ONE JSON line on rank 0 (driver contract) with these extra objects:
+Prints ONE JSON line on rank 0 (driver contract): a compact digest (< 6 KB, `compact_line`: the contract's keys, `roofline` and
+`cpu_baseline` without prose, one or two numbers per leg under `legs`).  The FULL object described below goes to bench_detail.json
+(beside bench.py and under gpurun_out/) and to stderr:
   roofline      -- the dominant kernel (the list scan: h16_sample_kernel + h16_scan_kernel, two launches per step).  `frac` prices
                    the bytes the launches HAVE TO READ (the fp16 shadow + norms of the union of the probed rows); the f32-equivalent
                    rate of SURVEY 8d's formula is a side field (it credits bytes that never move); `whole_step_frac` = the same
@@ -1477,11 +1479,145 @@ def main():
             "other_configs": other_cfg or None,
             "setup_s": round(setup_s, 1),
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         comm.close()
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The driver keeps only a few KB of stdout: the ONE JSON line it parses is a compact digest (<= 6 KB) -- the contract's keys, the
+# roofline / cpu_baseline objects without prose, and ONE or two numbers per leg.  The full object (every leg, every note) goes to
+# bench_detail.json beside bench.py (+ gpurun_out/ when present) and to stderr.
+LINE_BUDGET = 6000
+
+
+def _g(o, *path, default=None):
+    for p_ in path:
+        if not isinstance(o, dict) or p_ not in o:
+            return default
+        o = o[p_]
+    return o
+
+
+def _pick(o, *names):
+    return {n_: o[n_] for n_ in names if isinstance(o, dict) and o.get(n_) is not None} or None
+
+
+def compact_line(out):
+    """The driver-facing digest of the full bench object `out` (see main()): numbers only, no prose."""
+    roof = out.get("roofline") or {}
+    cpu = out.get("cpu_baseline") or {}
+    cfg = out.get("config") or {}
+    line = {k_: out.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                       "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg.get("workload"), **{k_: cfg.get(k_) for k_ in ("rows", "dim", "nlist", "nprobe", "k", "batch", "streams")},
+                      "parallelism": (cfg.get("parallelism") or "")[:48], "data_model": (cfg.get("data_model") or "")[:40]}
+    line["recall_at_10"] = out.get("recall_at_10")
+    line["p50_ms_batch1"] = out.get("p50_ms_batch1")
+    line["roofline"] = {k_: roof.get(k_) for k_ in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launches_per_step",
+                                                     "bytes_per_launch", "whole_step_frac", "non_scan_ms_per_step", "pruned_pair_fraction",
+                                                     "launches_all_per_step")}
+    line["roofline"]["kernel"] = (roof.get("kernel") or "").split(" (")[0]
+    line["cpu_baseline"] = {"value": cpu.get("value"), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                            "sample": (cpu.get("sample") or "")[:60],
+                            "oracle_bit_identical": _g(cpu, "oracle_check", "ids_and_distances_bit_identical")}
+    legs = {}
+    ob = out.get("other_batches")
+    if isinstance(ob, dict):
+        legs["other_batches_qps"] = {b_: v_.get("qps") for b_, v_ in ob.items() if isinstance(v_, dict)}
+    cb = out.get("concurrent_batches")
+    if cb:
+        legs["concurrent_batches"] = _pick(cb, "streams", "qps", "ms_per_step")
+    lat = out.get("latency")
+    if isinstance(lat, dict):
+        legs["latency"] = {"p50_us": lat.get("p50_us"), "p99_us": lat.get("p99_us"),
+                           "threads_64_qps": _g(lat, "threads_64", "qps"), "threads_64_p50_us": _g(lat, "threads_64", "p50_us"),
+                           "batch32_us_per_call": _g(lat, "host_pointer_small_batches", "32", "us_per_call"),
+                           "batch4096_host_qps": _g(lat, "host_pointer_batch4096", "qps")}
+    for m_ in ("iid", "blobs03", "latent32", "mid"):
+        v_ = out.get(m_)
+        if not isinstance(v_, dict):
+            continue
+        e_ = {}
+        for pt in ("at_recall_0.95", "at_config_nprobe"):
+            if isinstance(v_.get(pt), dict):
+                e_[pt] = _pick(v_[pt], "nprobe", "chosen", "recall", "qps", "ms_per_step", "roofline_frac", "whole_step_frac", "whole_step_mfma_frac",
+                               "pruned_pair_fraction")
+        if m_ == "iid":
+            e_["exhaustive_flat"] = _pick(v_.get("exhaustive_flat"), "recall", "qps", "ms_per_step", "whole_step_mfma_frac", "kernel_mfma_frac")
+            e_["flat_latency"] = _pick(v_.get("flat_latency"), "p50_us", "p99_us", "recall", "hbm_frac_of_p50")
+            e_.pop("at_recall_0.95", None)  # (== exhaustive_flat)
+        if "error" in v_:
+            e_["error"] = str(v_["error"])[:80]
+        legs[m_] = e_
+    t_ = out.get("target_100m")
+    if isinstance(t_, dict):
+        legs["target_100m"] = {"recall_at_10": t_.get("recall_at_10"),
+                               "batches": {b_: _pick(v_, "qps", "ms_per_batch", "roofline_frac", "whole_step_frac")
+                                           for b_, v_ in (t_.get("batches") or {}).items()},
+                               "oracle_bit_identical": _g(t_, "oracle_check", "ids_and_distances_bit_identical"),
+                               "cpu_baseline": _pick(t_.get("cpu_baseline"), "value", "unit", "cores", "kind"),
+                               "gpu_over_cpu_best": _g(t_, "gpu_over_cpu", "best"), **({"error": str(t_["error"])[:80]} if "error" in t_ else {})}
+    oc = out.get("other_configs") or {}
+    if isinstance(oc.get("C1"), dict):
+        c_ = oc["C1"]
+        legs["C1"] = {"knn_host_call_p50_us": c_.get("knn_host_call_p50_us"), "resident_nq1_us": _g(c_, "resident_nq1", "us_per_call"),
+                      "resident_nq1000_qps": _g(c_, "resident_nq1000", "qps"), "cpu_qps_1core": _g(c_, "cpu_baseline", "value"),
+                      **({"error": str(c_["error"])[:80]} if "error" in c_ else {})}
+    if isinstance(oc.get("C3"), dict):
+        c_ = oc["C3"]
+        legs["C3"] = dict(_pick(c_, "qps", "ms_per_batch", "roofline_frac", "whole_step_frac", "error") or {},
+                          cpu_qps=_g(c_, "cpu_baseline", "value"), cpu_cores=_g(c_, "cpu_baseline", "cores"))
+    if isinstance(oc.get("C4"), dict):
+        c_ = oc["C4"]
+        legs["C4"] = {"batches": {b_: _pick(v_, "qps", "ms_per_batch", "roofline_frac", "whole_step_frac")
+                                  for b_, v_ in (c_.get("batches") or {}).items() if isinstance(v_, dict)},
+                      "oracle_bit_identical": _g(c_, "oracle_check", "ids_and_distances_bit_identical"),
+                      **({"error": str(c_["error"])[:80]} if "error" in c_ else {})}
+    if isinstance(oc.get("C5"), dict):
+        c_ = oc["C5"]
+        legs["C5"] = {"hybrid_qps": c_.get("hybrid_qps"),
+                      **{b_: _pick(c_.get(b_), "ms_per_batch", "us_per_query", "hbm_frac") for b_ in ("bm25_batch64", "bm25_batch1024", "bm25_batch4096")
+                         if isinstance(c_.get(b_), dict)},
+                      **({"error": str(c_["error"])[:80]} if "error" in c_ else {})}
+    mg = out.get("multi_gpu")
+    if isinstance(mg, dict):
+        legs["multi_gpu"] = {"mode": mg.get("mode"),
+                             "routed": _pick(mg.get("routed"), "queries_per_step_per_rank", "routed_pairs_per_step_by_rank", "qps", "stage_ms_rank0"),
+                             "replicated": _pick(mg.get("replicated"), "qps", "ms_per_step")}
+    cs = out.get("c4_sharded")
+    if isinstance(cs, dict):
+        legs["c4_sharded"] = {"rows_on_rank0": cs.get("rows_on_rank0"), "scaling": cs.get("scaling"),
+                              "batches": cs.get("batches"), **({"error": str(cs["error"])[:80]} if "error" in cs else {})}
+    line["legs"] = legs
+    line["setup_s"] = out.get("setup_s")
+    line["detail"] = "bench_detail.json"
+    s_ = json.dumps(line, separators=(",", ":"))
+    # never let a leg cost the line: shed the widest legs until the digest fits
+    while len(s_) > LINE_BUDGET and legs:
+        widest = max(legs, key=lambda k_: len(json.dumps(legs[k_])))
+        legs[widest] = "see bench_detail.json"
+        if all(isinstance(v_, str) for v_ in legs.values()):
+            line["legs"] = legs = {}
+        s_ = json.dumps(line, separators=(",", ":"))
+    return s_
+
+
+def emit(out):
+    """Full object -> bench_detail.json (+ gpurun_out/, stderr); compact digest -> the ONE stdout line."""
+    full = json.dumps(out)
+    for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(full + "\n")
+        except OSError:
+            pass
+    sys.stderr.write("bench detail: " + full + "\n")
+    sys.stderr.flush()
+    print(compact_line(out), flush=True)
 
 
 if __name__ == "__main__":
