@@ -312,17 +312,35 @@ MSVS_API int msvs_comm_size(const msvs_comm_t * comm);
 MSVS_API int msvs_shard_search_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries,
                                       size_t nq, int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits,
                                       int64_t * d_ids, float * d_dis, void * hip_stream);
-/* The ROUTED form (round 5): every rank brings its OWN batch (nq may differ per rank, 0 included) and gets the results of its own
- * queries -- the queries that arrived at this server, StorageDistributed.cpp:1213-1255 -- instead of every rank working through the
- * same batch.  A query's coarse quantiser and the pre-pruning by the list radius (over the lists of the whole index) run on its home
- * rank; the query then visits only the ranks that own lists it still needs (ncclSend / ncclRecv of the exact sizes, grouped), each of
- * which returns the exact top-k over its lists; the home rank merges (MergeTreeBaseSearchManager.cpp:207-299).  ids and distances
- * == the unsharded index's, bit for bit.  IVFFLAT shards, unfiltered, <= 32 ranks; COLLECTIVE: every rank of the communicator calls
- * it for every step (the one host synchronisation of the step reads the rank x rank count matrix).  routed_pairs (nullable): the
- * (query, rank) pairs this rank served -- its share of the step's list-scan work.  A caller-supplied transport (msvs_comm_init_custom)
- * emulates the point-to-point exchange with its all-gather (tests). */
+/* The ROUTED form: every rank brings its OWN batch (nq may differ per rank, 0 included) and gets the results of its own queries -- the
+ * queries that arrived at this server, StorageDistributed.cpp:1213-1255 -- instead of every rank working through the same batch.
+ * FRONT phase: a query's coarse quantiser and the pre-pruning by the list radius (over the lists of the whole index) run on its home
+ * rank; one all-gather of the rank x rank count matrix (+ a header per rank: status, filter / pruning flags, shard instance, k, nprobe)
+ * is read by every host.  BACK phase: the query visits only the ranks that own lists it still needs (ncclSend / ncclRecv of the exact
+ * sizes, grouped), each of which searches it under ITS OWN filter -- d_alive_bits (nullable; 1 = row may be returned, over the row ids
+ * this rank holds, like msvs_index_search_device) AND the shard's resident delete bitmap (VIWithDataPart.cpp:903-908) -- and returns
+ * the exact top-k over its lists; the home rank merges (MergeTreeBaseSearchManager.cpp:207-299) and applies its row-id map.  ids and
+ * distances == the unsharded index's under the union of the filters, bit for bit.  IVFFLAT shards, <= 32 ranks.
+ * COLLECTIVE: every rank of the communicator calls it for every step with the same k and nprobe.  What goes wrong on ONE rank before
+ * the exchange (bad argument, unsupported k, allocation failure, index not ready, mismatching k / nprobe) is published in the matrix:
+ * EVERY rank returns an error for that step and none blocks.  A shard object replaced on one rank (reloaded part) is noticed through
+ * its instance word and the index-wide list statistics are gathered again by every rank in the same step.
+ * routed_pairs (nullable): the (query, rank) pairs this rank served -- its share of the step's list-scan work.  A caller-supplied
+ * transport (msvs_comm_init_custom) emulates the point-to-point exchange with its all-gather (tests). */
 MSVS_API int msvs_shard_search_routed_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries, size_t nq,
                                              int k, int nprobe, int64_t * d_ids, float * d_dis, void * hip_stream, uint64_t * routed_pairs);
+MSVS_API int msvs_shard_search_routed_filtered_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries,
+                                                      size_t nq, int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits,
+                                                      int64_t * d_ids, float * d_dis, void * hip_stream, uint64_t * routed_pairs);
+/* The routed search with TWO STEPS IN FLIGHT: call i enqueues the FRONT phase of its batch (communicator's compute + exchange
+ * streams; `hip_stream` orders the inputs only) and then the BACK phase of batch i - 1, whose count matrix was gathered one call
+ * ago -- the host does not wait for the device while the list scan of step i - 1 and the coarse stage of step i are still to run.
+ * The results (and *routed_pairs) of batch i are complete when the event handed out by call i + 1 in *prev_done_event has fired
+ * (nullptr at the first call), or after msvs_shard_search_drain -- which is COLLECTIVE while a routed step is pending (it runs that
+ * step's back phase).  Buffers of a batch stay untouched until then; every rank issues the same sequence of calls. */
+MSVS_API int msvs_shard_search_routed_device_async(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries, size_t nq,
+                                                   int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
+                                                   float * d_dis, void * hip_stream, uint64_t * routed_pairs, void ** prev_done_event);
 /* The same search with TWO BATCHES IN FLIGHT: the call returns once batch i is enqueued; `hip_stream` orders its INPUTS only,
  * its results are complete when *done_event -- a hipEvent_t owned by the communicator, valid until the second-next async call on
  * it -- has fired: hipStreamWaitEvent on whatever stream reads d_ids / d_dis, or msvs_shard_search_drain.  The coarse pass and

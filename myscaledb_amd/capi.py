@@ -37,6 +37,7 @@ SYMBOLS = [
     "msvs_cache_evict", "msvs_cache_stats", "msvs_knn_resident", "msvs_index_set_delete_bitmap",
     "msvs_index_set_merged_maps", "msvs_comm_unique_id", "msvs_comm_init", "msvs_comm_init_custom",
     "msvs_comm_free", "msvs_comm_all_reduce_u64", "msvs_comm_rank", "msvs_comm_size", "msvs_shard_search_device", "msvs_shard_search_device_async", "msvs_shard_search_drain", "msvs_shard_search_routed_device",
+    "msvs_shard_search_routed_filtered_device", "msvs_shard_search_routed_device_async",
     "msvs_hybrid_fuse_device",
 ]
 
@@ -539,15 +540,31 @@ class Index:
                                               C.c_size_t(nbits), C.c_void_p(int(d_ids)), C.c_void_p(int(d_dis)),
                                               C.c_void_p(int(stream)) if stream else None))
 
-    def shard_search_routed_device(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0):
-        """msvs_shard_search_routed_device: this rank's OWN nq queries (0 allowed), routed to the ranks that own lists they still need
-        after the pre-pruning; collective.  Returns the (query, rank) pairs this rank served."""
+    def shard_search_routed_device(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0):
+        """msvs_shard_search_routed[_filtered]_device: this rank's OWN nq queries (0 allowed), routed to the ranks that own lists they
+        still need after the pre-pruning, searched there under that rank's filter (d_alive: THIS rank's bitmap); collective.  Returns
+        the (query, rank) pairs this rank served."""
         served = C.c_uint64(0)
-        _check(lib().msvs_shard_search_routed_device(self._h, comm._h, C.c_void_p(int(d_queries)) if d_queries else None, C.c_size_t(nq), int(k),
-                                                     int(nprobe), C.c_void_p(int(d_ids)) if d_ids else None,
-                                                     C.c_void_p(int(d_dis)) if d_dis else None,
-                                                     C.c_void_p(int(stream)) if stream else None, C.byref(served)))
+        q = C.c_void_p(int(d_queries)) if d_queries else None
+        oi, od = C.c_void_p(int(d_ids)) if d_ids else None, C.c_void_p(int(d_dis)) if d_dis else None
+        st = C.c_void_p(int(stream)) if stream else None
+        if d_alive:
+            _check(lib().msvs_shard_search_routed_filtered_device(self._h, comm._h, q, C.c_size_t(nq), int(k), int(nprobe), C.c_void_p(int(d_alive)),
+                                                                  C.c_size_t(nbits), oi, od, st, C.byref(served)))
+        else:
+            _check(lib().msvs_shard_search_routed_device(self._h, comm._h, q, C.c_size_t(nq), int(k), int(nprobe), oi, od, st, C.byref(served)))
         return served.value
+
+    def shard_search_routed_device_async(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0, served=None):
+        """msvs_shard_search_routed_device_async: two routed steps in flight.  Returns the done event of the PREVIOUS call's batch (None at
+        the first call); `served` (a ctypes c_uint64 the caller keeps alive) receives this batch's routed pairs when ITS back phase runs."""
+        ev = C.c_void_p()
+        _check(lib().msvs_shard_search_routed_device_async(self._h, comm._h, C.c_void_p(int(d_queries)) if d_queries else None, C.c_size_t(nq), int(k),
+                                                           int(nprobe), C.c_void_p(int(d_alive)) if d_alive else None, C.c_size_t(nbits),
+                                                           C.c_void_p(int(d_ids)) if d_ids else None, C.c_void_p(int(d_dis)) if d_dis else None,
+                                                           C.c_void_p(int(stream)) if stream else None,
+                                                           C.byref(served) if served is not None else None, C.byref(ev)))
+        return ev.value
 
     def shard_search_device_async(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0):
         """msvs_shard_search_device_async: two batches in flight; returns the batch's done event (a hipEvent_t address)."""

@@ -2,6 +2,8 @@
 // the stream-ordered search / filter / merge entry points behind the C-ABI (msvs_capi.hip defines them; shard.hip -- the
 // multi-GPU search and the top-k merge -- calls them).
 #pragma once
+#include <atomic>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -95,8 +97,13 @@ struct msvs_index
         DevBuf<float> radius;      // [nlist]
         DevBuf<int64_t> list_off;  // [nlist + 1] prefix of the global list lengths
         float xmax = 0.f, xmin = 0.f;
+        std::vector<uint64_t> instances; // [W]: the shard objects (msvs_index::instance of every rank) this was gathered from
     };
     mutable std::shared_ptr<Global> global;
+    /// Identity of this object among the shard objects a rank has held (an index is immutable once built; a reloaded shard is a new
+    /// object): the routed search compares it with the instance its Global was gathered from.
+    const uint64_t instance = next_instance();
+    static uint64_t next_instance();
     mutable std::mutex meta_mu;
     std::shared_ptr<Meta> meta;
     std::shared_ptr<Meta> get_meta() const
@@ -105,6 +112,13 @@ struct msvs_index
         return meta;
     }
 };
+
+inline uint64_t msvs_index::next_instance()
+{
+    static std::atomic<uint64_t> counter{0};
+    static const uint64_t salt = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull;
+    return (salt & ~0xFFFFFull) + counter.fetch_add(1) + 1;
+}
 
 namespace msvs
 {

@@ -1426,10 +1426,13 @@ void index_search_device(const msvs_index & ix, const float * d_queries /* nq x 
     for (size_t q0 = 0; q0 < nq; q0 += sub)
     {
         const size_t m = std::min(sub, nq - q0);
+        ProbeWords w = words;  // (the index-wide fields -- g_radius, g_list_off, g_xmax, g_xmin -- stay; the per-pair ones move with q0)
+        w.given = words.given ? words.given + q0 * np_eff : nullptr;
+        w.out = words.out ? words.out + q0 * np_eff : nullptr;
+        w.pruned_out = words.pruned_out ? words.pruned_out + q0 * np_eff : nullptr;
         index_search_device_one(ix, d_queries + q0 * ix.dim, m, k, nprobe, d_alive, nbits, d_ids ? d_ids + q0 * k : nullptr,
                                 d_dis ? d_dis + q0 * k : nullptr, stream, given_probes ? given_probes + q0 * np_eff : nullptr,
-                                probes_only ? probes_only + q0 * np_eff : nullptr, view,
-                                ProbeWords{words.given ? words.given + q0 * np_eff : nullptr, words.out ? words.out + q0 * np_eff : nullptr});
+                                probes_only ? probes_only + q0 * np_eff : nullptr, view, w);
     }
 }
 
@@ -1531,7 +1534,8 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         MergeParams co{};
         co.mode = 1;
         co.out_probes = d_probes;
-        if (!probes_only && (ix.metric == MSVS_METRIC_L2 || ix.metric == MSVS_METRIC_COSINE) && options().h16_preprune != 0)
+        // (a routed sharded search's front phase -- probes_only + pruned_out -- pre-prunes by these distances too)
+        if ((!probes_only || words.pruned_out) && (ix.metric == MSVS_METRIC_L2 || ix.metric == MSVS_METRIC_COSINE) && options().h16_preprune != 0)
         {
             float * pd = scr.take<float>(nq * nprobe);
             co.out_probe_dis = pd;

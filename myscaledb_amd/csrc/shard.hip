@@ -191,9 +191,10 @@ struct msvs_comm
             soff[t + 1] = soff[t] + mat[r * W + t];
             roff[t + 1] = roff[t] + mat[t * W + r];
         }
-        if (mat[r * W + r]) // own piece: a copy
+        const bool self_rccl = nccl && !custom && msvs::options().route_self_rccl != 0; // (tests: the own piece through the group path too)
+        if (mat[r * W + r] && !self_rccl) // own piece: a copy
             MSVS_HIP(hipMemcpyAsync(d_recv + roff[r], d_send + soff[r], mat[r * W + r], hipMemcpyDeviceToDevice, stream));
-        if (W == 1)
+        if (W == 1 && !self_rccl)
             return;
         if (!custom)
         {
@@ -203,7 +204,7 @@ struct msvs_comm
             nccl_check(api.GroupStart(), "ncclGroupStart");
             for (size_t t = 0; t < W; t++)
             {
-                if (t == r)
+                if (t == r && !self_rccl)
                     continue;
                 if (mat[r * W + t])
                     nccl_check(api.Send(d_send + soff[t], mat[r * W + t], ncclInt8, (int)t, nccl, stream), "ncclSend");
@@ -290,10 +291,13 @@ extern "C" int msvs_comm_init_custom(int nranks, int rank, msvs_allgather_fn all
     });
 }
 
+static void forget_pipes(const msvs_comm_t * c);
+
 extern "C" void msvs_comm_free(msvs_comm_t * c)
 {
     if (!c)
         return;
+    forget_pipes(c); // (a later communicator may live at the same address with another size)
     if (c->nccl)
         (void)rccl().CommDestroy(c->nccl);
     delete c;
@@ -342,12 +346,18 @@ struct ShardPipe
     std::mutex mu;
 };
 
-static ShardPipe & pipe_of(const msvs_comm_t * comm)
+static std::mutex g_pipes_mu;
+static std::map<const msvs_comm_t *, std::unique_ptr<ShardPipe>> g_pipes; // (entries dropped by msvs_comm_free)
+
+static ShardPipe * pipe_of(const msvs_comm_t * comm, bool create)
 {
-    static std::mutex mu;
-    static std::map<const msvs_comm_t *, std::unique_ptr<ShardPipe>> pipes; // (never torn down: a handful per process)
-    std::lock_guard<std::mutex> lk(mu);
-    auto & p = pipes[comm];
+    std::lock_guard<std::mutex> lk(g_pipes_mu);
+    if (!create)
+    {
+        auto it = g_pipes.find(comm);
+        return it == g_pipes.end() ? nullptr : it->second.get();
+    }
+    auto & p = g_pipes[comm];
     if (!p)
     {
         p.reset(new ShardPipe);
@@ -357,7 +367,7 @@ static ShardPipe & pipe_of(const msvs_comm_t * comm)
             for (hipEvent_t * e : {&p->in_ev[i], &p->ab_ev[i], &p->x1_ev[i], &p->b_ev[i], &p->done_ev[i]})
                 MSVS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
-    return *p;
+    return p.get();
 }
 
 /// cs: the stream of the coarse pass, the list scan and the small copies; xs: the stream of the two all-gathers and the merge
@@ -471,7 +481,7 @@ extern "C" int msvs_shard_search_device_async(const msvs_index_t * ix, const msv
         shard_check(ix, comm, d_queries, nq, k, d_ids, d_dis);
         if (!done_event)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null done_event");
-        ShardPipe & pp = pipe_of(comm);
+        ShardPipe & pp = *pipe_of(comm, true);
         std::lock_guard<std::mutex> lk(pp.mu);
         const int p = (int)(pp.calls++ & 1);
         // inputs: whatever the caller's stream has enqueued so far
@@ -494,41 +504,63 @@ extern "C" int msvs_shard_search_device_async(const msvs_index_t * ix, const msv
     });
 }
 
-extern "C" int msvs_shard_search_drain(const msvs_comm_t * comm, void * hip_stream)
-{
-    return guarded([&] {
-        if (!comm)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "null communicator");
-        ShardPipe & pp = pipe_of(comm);
-        std::lock_guard<std::mutex> lk(pp.mu);
-        for (int p = 0; p < 2; p++)
-            if (pp.used[p])
-                MSVS_HIP(hipStreamWaitEvent(as_stream(hip_stream), pp.done_ev[p], 0));
-    });
-}
-
-// =========================================================================================== routed search
+// =========================================================================================== routed search (rounds 5-6)
 //
 // msvs_shard_search_device gives every rank the SAME batch: the list scan is sharded, but the per-query stages of the step (cut,
 // selection, re-ranks, plans) run for the whole batch on every rank -- ~0.23 of 0.58 ms on the bench step, Amdahl ~1.8 x at 8
 // ranks.  Here every rank brings its OWN batch (the queries that arrived at its server: StorageDistributed.cpp:1213-1255 sends a
-// query to one replica of every shard) and a query visits only the ranks that own lists it still needs:
-//   1. home rank: coarse quantiser of its own queries, then the pre-pruning by the list radius over the lists of the WHOLE index
-//      (radius / length of every rank's lists and the extremes of the row norms are gathered once per index);
-//   2. one all-gather of the W x W matrix of (source, destination) query counts, read back by the host (the one synchronisation
-//      of the step: the point-to-point sizes must be known on both sides);
-//   3. exchange: {query index, its surviving probes among the destination's lists, their coarse words, the query vector} go to
-//      the ranks that own surviving lists -- ncclSend / ncclRecv of the exact sizes, grouped (xGMI is point to point: a query that
-//      needs one rank travels over one link);
-//   4. every rank searches what arrived (the given-probes form of the search: plan, sample, cut, pruning second stage, scan,
-//      re-rank, certificate -- over its own lists only) and returns exact local top-k lists;
-//   5. exchange back; the home rank merges the <= W lists of each of its queries canonically (getTotalTopSearchResultImpl,
-//      MergeTreeBaseSearchManager.cpp:207-299) -- the result of the unsharded index, bit for bit.
-// Per rank and step: its own nq queries' coarse stage + ~nq (1 + spill) routed queries' list scan, whatever W is.
+// query to one replica of every shard) and a query visits only the ranks that own lists it still needs.  A step has two phases:
+//   FRONT 1. home rank: coarse quantiser of its own queries, then the pre-pruning by the list radius over the lists of the WHOLE
+//            index (radius / length of every rank's lists and the extremes of the row norms: msvs_index::Global, gathered when any
+//            rank asks for it);
+//         2. one all-gather of the W x (W + 6) matrix: (source, destination) query counts + a header per rank -- status of its
+//            front phase, "I have no Global", "I search under a filter / delete bitmap", "I pre-pruned", the instance of its shard
+//            object -- copied to pinned host memory;
+//   BACK  (the host has read the matrix: every rank takes the SAME decision from it -- fail together when any rank failed, gather
+//         the Global again and redo the front phase when a rank asks or a shard object changed, redo it without the pre-pruning
+//         when some rank pre-pruned while another filters: the radius bound counts rows a filter may hide)
+//         3. exchange: {query index, its surviving probes among the destination's lists, their coarse words, the query vector} go
+//            to the ranks that own surviving lists -- ncclSend / ncclRecv of the exact sizes, grouped (xGMI is point to point: a
+//            query that needs one rank travels over one link);
+//         4. every rank searches what arrived over its own lists under ITS filter (per-search bitmap AND resident delete bitmap,
+//            VIWithDataPart.cpp:903-908) and returns exact local top-k lists;
+//         5. exchange back; the home rank merges the <= W lists of each of its queries canonically (getTotalTopSearchResultImpl,
+//            MergeTreeBaseSearchManager.cpp:207-299) and applies its row-id map -- the result of the unsharded index, bit for bit.
+// msvs_shard_search_routed_device runs both phases back to back on the caller's stream (one host synchronisation in between).
+// msvs_shard_search_routed_device_async keeps TWO STEPS IN FLIGHT: call i enqueues FRONT(i), then BACK(i - 1) -- whose matrix was
+// gathered one call ago, so the host does not wait for it while the GPU still has the list scan of step i - 1 and the coarse stage
+// of step i to run.  Every collective of a communicator is issued on its ONE exchange stream in call order, the same on every rank.
 
 namespace
 {
 constexpr uint32_t ROUTE_MAX_RANKS = 32; // destination masks are 32-bit words
+constexpr uint32_t ROUTE_HDR = 8;        // words after a rank's W counts: status | need | filtered | pruned | instance lo | hi | k | nprobe
+enum { RH_STATUS = 0, RH_NEED, RH_FILTERED, RH_PRUNED, RH_INST_LO, RH_INST_HI, RH_K, RH_NP };
+struct RouteHdr
+{
+    uint32_t w[ROUTE_HDR];
+};
+
+/// Per-rank tables a step's kernels need, passed by value (<= 32 ranks: 512 B of kernel arguments, no H2D copies in the step).
+struct RouteTab
+{
+    uint64_t region[ROUTE_MAX_RANKS]; // byte offset of rank t's region in the buffer the kernel walks
+    uint32_t cnt[ROUTE_MAX_RANKS];    // its entries
+    uint32_t first[ROUTE_MAX_RANKS];  // its first entry in the dense (rank-major) arrays
+};
+
+/// The count-matrix row of this rank before the front phase fills it: counts and pack cursors zeroed, the header in place.
+__global__ void route_init_kernel(uint32_t * row, uint32_t W, uint32_t * cursor, const RouteHdr h)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < W)
+    {
+        row[t] = 0;
+        cursor[t] = 0;
+    }
+    if (t < ROUTE_HDR)
+        row[W + t] = h.w[t];
+}
 
 /// mask[q] = ranks that own a surviving probe of query q; cnt[t] += queries that go to rank t.
 __global__ void route_mask_kernel(const int32_t * probes, uint32_t nq, uint32_t np, uint32_t W, uint32_t * mask, uint32_t * cnt)
@@ -557,11 +589,9 @@ struct RoutePack
     const uint32_t * mask;
     uint32_t nq, np, d, W;
     uint32_t * cursor;       // [W] zeroed
-    const uint64_t * region; // [W] byte offset of destination t's region in `send`
-    const uint32_t * cnt;    // [W] entries of the region
     unsigned char * send;
     uint32_t * sent_q;       // [sum cnt]: query of (destination, slot), destinations back to back
-    const uint32_t * sent_off; // [W] first entry of destination t in sent_q
+    RouteTab to;             // region / cnt / first of every destination
 };
 
 /// One wavefront per query: an entry in the region of every destination in its mask.  Region of cnt entries:
@@ -578,8 +608,8 @@ __global__ __launch_bounds__(64) void route_pack_kernel(const RoutePack a)
         if (lane == 0)
             slot = atomicAdd(&a.cursor[t], 1u);
         slot = (uint32_t)__shfl((int)slot, 0);
-        const uint32_t cnt = a.cnt[t];
-        unsigned char * const reg = a.send + a.region[t];
+        const uint32_t cnt = a.to.cnt[t];
+        unsigned char * const reg = a.send + a.to.region[t];
         uint32_t * const qidx = reinterpret_cast<uint32_t *>(reg);
         int32_t * const pr = reinterpret_cast<int32_t *>(reg + (size_t)cnt * 4) + (size_t)slot * a.np;
         uint32_t * const wd = reinterpret_cast<uint32_t *>(reg + (size_t)cnt * 4 * (1 + a.np)) + (size_t)slot * a.np;
@@ -587,7 +617,7 @@ __global__ __launch_bounds__(64) void route_pack_kernel(const RoutePack a)
         if (lane == 0)
         {
             qidx[slot] = q;
-            a.sent_q[a.sent_off[t] + slot] = q;
+            a.sent_q[a.to.first[t] + slot] = q;
         }
         for (uint32_t j = lane; j < a.np; j += 64)
         {
@@ -604,23 +634,28 @@ __global__ __launch_bounds__(64) void route_pack_kernel(const RoutePack a)
 struct RouteUnpack
 {
     const unsigned char * recv;
-    uint64_t region[ROUTE_MAX_RANKS]; // byte offset of source s's region
-    uint32_t cnt[ROUTE_MAX_RANKS], first[ROUTE_MAX_RANKS]; // its entries, its first row in the dense arrays
+    RouteTab from; // region / cnt / first of every source
     uint32_t W, np, d;
     int32_t * probes;  // [n_in][np]
     uint32_t * words;  // [n_in][np]
     float * Q;         // [n_in][d]
 };
 
+__device__ inline uint32_t route_owner(const RouteTab & t, uint32_t W, uint32_t i)
+{
+    uint32_t s = 0;
+    while (s + 1 < W && i >= t.first[s + 1])
+        s++;
+    return s;
+}
+
 /// One wavefront per received entry: the regions of the W sources -> dense arrays in source order.
 __global__ __launch_bounds__(64) void route_unpack_kernel(const RouteUnpack a, uint32_t n_in)
 {
     const uint32_t i = blockIdx.x, lane = threadIdx.x;
-    uint32_t s = 0;
-    while (s + 1 < a.W && i >= a.first[s + 1])
-        s++;
-    const uint32_t slot = i - a.first[s], cnt = a.cnt[s];
-    const unsigned char * const reg = a.recv + a.region[s];
+    const uint32_t s = route_owner(a.from, a.W, i);
+    const uint32_t slot = i - a.from.first[s], cnt = a.from.cnt[s];
+    const unsigned char * const reg = a.recv + a.from.region[s];
     const int32_t * const pr = reinterpret_cast<const int32_t *>(reg + (size_t)cnt * 4) + (size_t)slot * a.np;
     const uint32_t * const wd = reinterpret_cast<const uint32_t *>(reg + (size_t)cnt * 4 * (1 + a.np)) + (size_t)slot * a.np;
     const float * const vec = reinterpret_cast<const float *>(reg + (size_t)cnt * 4 * (1 + 2 * (size_t)a.np)) + (size_t)slot * a.d;
@@ -633,19 +668,35 @@ __global__ __launch_bounds__(64) void route_unpack_kernel(const RouteUnpack a, u
         a.Q[(size_t)i * a.d + c] = vec[c];
 }
 
-/// The results that came back, destination t's block = {ids i64[cnt_t][k] | dis f32[cnt_t][k]} at back[t]: entry (t, slot) belongs
-/// to query sent_q[sent_off[t] + slot] and becomes part t of its merge input (parts the query did not visit stay "no hit").
-__global__ void route_scatter_kernel(const unsigned char * back, const uint64_t * region, const uint32_t * cnt, const uint32_t * sent_q,
-                                     const uint32_t * sent_off, uint32_t W, uint32_t nq, uint32_t k, int64_t * m_ids, float * m_dis)
+/// The way back: the dense results of the entries this rank served -> one block per source, {ids i64[cnt][k] | dis f32[cnt][k]}
+/// at a 16-byte aligned offset (back.region).
+__global__ void route_result_kernel(const int64_t * r_ids, const float * r_dis, uint32_t n_in, uint32_t k, uint32_t W, const RouteTab back,
+                                    unsigned char * res)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_in * k)
+        return;
+    const uint32_t e = (uint32_t)(i / k), j = (uint32_t)(i - (size_t)e * k);
+    const uint32_t s = route_owner(back, W, e);
+    const uint32_t slot = e - back.first[s], cnt = back.cnt[s];
+    unsigned char * const reg = res + back.region[s];
+    reinterpret_cast<int64_t *>(reg)[(size_t)slot * k + j] = r_ids[i];
+    reinterpret_cast<float *>(reg + (size_t)cnt * k * 8)[(size_t)slot * k + j] = r_dis[i];
+}
+
+/// The results that came back, destination t's block at back + home.region[t]: entry (t, slot) belongs to query
+/// sent_q[home.first[t] + slot] and becomes part t of its merge input (parts the query did not visit stay "no hit").
+__global__ void route_scatter_kernel(const unsigned char * back, const RouteTab home, const uint32_t * sent_q, uint32_t nq, uint32_t k,
+                                     int64_t * m_ids, float * m_dis)
 {
     const uint32_t t = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = cnt[t];
+    const uint32_t c = home.cnt[t];
     if (i >= (size_t)c * k)
         return;
     const uint32_t slot = (uint32_t)(i / k), j = (uint32_t)(i - (size_t)slot * k);
-    const uint32_t q = sent_q[sent_off[t] + slot];
-    const unsigned char * const reg = back + region[t];
+    const uint32_t q = sent_q[home.first[t] + slot];
+    const unsigned char * const reg = back + home.region[t];
     m_ids[((size_t)t * nq + q) * k + j] = reinterpret_cast<const int64_t *>(reg)[i];
     m_dis[((size_t)t * nq + q) * k + j] = reinterpret_cast<const float *>(reg + (size_t)c * k * 8)[i];
 }
@@ -674,14 +725,11 @@ __global__ void route_local_lens_kernel(const int64_t * list_off, uint32_t nlist
         lens[l] = (uint32_t)(list_off[l + 1] - list_off[l]);
 }
 
-/// Radius and length of every list of the whole index + the extremes of the row norms: one all-gather at the first routed search.
-std::shared_ptr<msvs_index::Global> route_global(const msvs_index_t * ix, const msvs_comm_t * comm, hipStream_t stream)
+/// Radius and length of every list of the whole index + the extremes of the row norms, and the shard instances they were gathered
+/// from.  COLLECTIVE (one all-gather): the back phase calls it on every rank when the count matrix says so; synchronises `stream`.
+std::shared_ptr<msvs_index::Global> route_global(const msvs_index_t * ix, const msvs_comm_t * comm, const std::vector<uint64_t> & instances,
+                                                 hipStream_t stream)
 {
-    {
-        std::lock_guard<std::mutex> lk(ix->meta_mu);
-        if (ix->global)
-            return ix->global;
-    }
     const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank, nl = ix->nlist;
     const size_t rec = round_up((2 * nl + 2) * 4, (size_t)16); // radius f32[nl] | len u32[nl] | xmax | xmin
     DevBuf<unsigned char> buf(W * rec);
@@ -701,6 +749,7 @@ std::shared_ptr<msvs_index::Global> route_global(const msvs_index_t * ix, const 
     auto g = std::make_shared<msvs_index::Global>();
     g->radius.alloc(nl);
     g->list_off.alloc(nl + 1);
+    g->instances = instances;
     DevBuf<float> radii(W * nl);
     DevBuf<uint32_t> lens(W * nl);
     DevBuf<int64_t> len64(nl);
@@ -725,185 +774,535 @@ std::shared_ptr<msvs_index::Global> route_global(const msvs_index_t * ix, const 
     ix->global = g;
     return g;
 }
+
+/// One routed step between its two phases.
+struct RoutedStep
+{
+    bool pending = false;
+    // the call
+    const msvs_index_t * ix = nullptr;
+    const float * d_queries = nullptr;
+    size_t nq = 0, np = 0, nbits = 0;
+    int k = 0, nprobe = 0;
+    const uint64_t * d_alive = nullptr;
+    int64_t * d_ids = nullptr;
+    float * d_dis = nullptr;
+    uint64_t * routed_pairs = nullptr;
+    // what the front phase left (arena `front`)
+    int32_t * probes = nullptr;
+    uint32_t * words = nullptr;
+    int32_t * alive_probes = nullptr;
+    uint32_t * mask = nullptr;
+    uint32_t * cursor = nullptr;
+    bool pruned = false;
+    int status = MSVS_OK;
+    std::string error;
+    // owned
+    Scratch front;
+    uint32_t * cmat = nullptr; // device [W][W + ROUTE_HDR]
+    uint32_t * h_c = nullptr;  // pinned, the same
+    hipEvent_t in_ev = nullptr, a_ev = nullptr, done_ev = nullptr;
+};
+
+/// The routed search's state on a communicator: the two streams and hand-over events of the pipelined form, two steps' slots
+/// (the stream-at-a-time form uses slot 0 and the caller's stream), the exchange arena, and what the last count matrix said about
+/// filters on the ranks (a hint for the next front phase; the matrix of the step itself decides).
+struct RoutePipe
+{
+    hipStream_t compute = nullptr, xchg = nullptr;
+    hipEvent_t hand[2] = {nullptr, nullptr};
+    RoutedStep step[2];
+    Scratch back;
+    uint64_t calls = 0;
+    bool peers_filtered = false;
+    std::mutex mu;
+};
+
+std::mutex g_route_pipes_mu;
+std::map<const msvs_comm_t *, std::unique_ptr<RoutePipe>> g_route_pipes; // (entries dropped by msvs_comm_free)
+
+RoutePipe * route_pipe_of(const msvs_comm_t * comm, bool create)
+{
+    std::lock_guard<std::mutex> lk(g_route_pipes_mu);
+    if (!create)
+    {
+        auto it = g_route_pipes.find(comm);
+        return it == g_route_pipes.end() ? nullptr : it->second.get();
+    }
+    auto & p = g_route_pipes[comm];
+    if (!p)
+    {
+        p.reset(new RoutePipe);
+        const size_t W = (size_t)comm->nranks, bytes = W * (W + ROUTE_HDR) * 4;
+        MSVS_HIP(hipStreamCreateWithFlags(&p->compute, hipStreamNonBlocking));
+        MSVS_HIP(hipStreamCreateWithFlags(&p->xchg, hipStreamNonBlocking));
+        for (hipEvent_t * e : {&p->hand[0], &p->hand[1]})
+            MSVS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (RoutedStep & st : p->step)
+        {
+            MSVS_HIP(hipMalloc(reinterpret_cast<void **>(&st.cmat), bytes));
+            MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&st.h_c), bytes, hipHostMallocDefault));
+            for (hipEvent_t * e : {&st.in_ev, &st.a_ev, &st.done_ev})
+                MSVS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+    }
+    return p.get();
+}
+
+void hand_over(RoutePipe & pp, int which, hipStream_t from, hipStream_t to)
+{
+    if (from == to)
+        return;
+    MSVS_HIP(hipEventRecord(pp.hand[which], from));
+    MSVS_HIP(hipStreamWaitEvent(to, pp.hand[which], 0));
+}
+
+/// A reservation in an arena that work on BOTH streams may still read.
+void reserve_two(Scratch & sc, size_t bytes, hipStream_t cs, hipStream_t xs)
+{
+    if (xs != cs && (bytes > sc.buf.n || sc.ops >= 63))
+        MSVS_HIP(hipStreamSynchronize(xs));
+    sc.reserve(bytes, cs);
+}
+
+/// FRONT: coarse stage + pre-pruning of the rank's own queries on `cs`, this rank's row of the count matrix, the all-gather and its
+/// copy to pinned memory on `xs`.  A failure of the rank's own part is PUBLISHED in the row instead of thrown: the collective is
+/// issued whatever happened, the back phase fails on every rank together.
+void routed_front(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, bool allow_prune, hipStream_t cs, hipStream_t xs)
+{
+    const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank, RW = W + ROUTE_HDR;
+    uint32_t * const row = st.cmat + r * RW;
+    std::shared_ptr<msvs_index::Global> g;
+    st.status = MSVS_OK;
+    st.error.clear();
+    st.pruned = false;
+    bool filtered = false;
+    uint64_t inst = 0;
+    bool row_ready = false;
+    try
+    {
+        const msvs_index_t * ix = st.ix;
+        shard_check(ix, comm, st.d_queries, st.nq, st.k, st.d_ids, st.d_dis);
+        if (ix->type != MSVS_INDEX_IVFFLAT)
+            fail(MSVS_ERR_NOT_IMPLEMENTED, "the routed search serves IVFFLAT shards (a FLAT index has no lists to route by: msvs_shard_search_device)");
+        if (!ix->ready)
+            fail(MSVS_ERR_NOT_READY, "index is not ready");
+        if (st.k)
+            check_k((size_t)st.k);
+        inst = ix->instance;
+        st.np = std::min<size_t>(std::max(st.nprobe, 1), ix->nlist);
+        const auto meta = ix->get_meta();
+        filtered = st.d_alive != nullptr || (meta && meta->delete_nbits);
+        {
+            std::lock_guard<std::mutex> lk(ix->meta_mu);
+            g = ix->global;
+        }
+        const size_t nq = st.k ? st.nq : 0, np = st.np;
+        reserve_two(st.front, nq * np * 12 + nq * 4 + 4096 + 64 * W, cs, xs);
+        st.probes = st.front.take<int32_t>(std::max<size_t>(nq * np, 1));
+        st.words = st.front.take<uint32_t>(std::max<size_t>(nq * np, 1));
+        st.alive_probes = st.front.take<int32_t>(std::max<size_t>(nq * np, 1));
+        st.mask = st.front.take<uint32_t>(std::max<size_t>(nq, 1));
+        st.cursor = st.front.take<uint32_t>(W);
+        // the pre-pruning bounds the k-th distance by rows it has not seen: every row of a list counts, so nobody may filter
+        const bool prune = allow_prune && g && !filtered && !pp.peers_filtered && nq;
+        hipLaunchKernelGGL(route_init_kernel, dim3(1), dim3(64), 0, cs, row, (uint32_t)W, st.cursor,
+                           RouteHdr{{(uint32_t)MSVS_OK, g ? 0u : 1u, filtered ? 1u : 0u, prune ? 1u : 0u, (uint32_t)inst, (uint32_t)(inst >> 32),
+                                     (uint32_t)st.k, (uint32_t)np}});
+        MSVS_HIP(hipGetLastError());
+        row_ready = true;
+        if (nq)
+        {
+            ProbeWords pw{};
+            pw.out = st.words;
+            if (prune)
+            {
+                pw.g_radius = g->radius.p;
+                pw.g_list_off = g->list_off.p;
+                pw.g_xmax = g->xmax;
+                pw.g_xmin = g->xmin;
+            }
+            pw.pruned_out = st.alive_probes; // (no Global / no pruning: every probe survives)
+            index_search_device(*ix, st.d_queries, nq, (uint32_t)st.k, np, nullptr, 0, nullptr, nullptr, cs, nullptr, st.probes, nullptr, pw);
+            hipLaunchKernelGGL(route_mask_kernel, dim3((unsigned)ceil_div(nq, (size_t)256)), dim3(256), 0, cs, st.alive_probes, (uint32_t)nq,
+                               (uint32_t)np, (uint32_t)W, st.mask, row);
+            MSVS_HIP(hipGetLastError());
+        }
+        st.pruned = prune;
+    }
+    catch (const Error & e)
+    {
+        st.status = e.code ? e.code : MSVS_ERR_DEVICE;
+        st.error = e.msg;
+    }
+    catch (const std::bad_alloc &)
+    {
+        st.status = MSVS_ERR_OUT_OF_MEMORY;
+        st.error = "out of host memory";
+    }
+    if (st.status != MSVS_OK || !row_ready)
+    {
+        // nothing of this rank's queries travels; the others learn why
+        if (!st.cursor)
+            st.cursor = row; // (any W words: the row itself, rewritten below)
+        hipLaunchKernelGGL(route_init_kernel, dim3(1), dim3(64), 0, cs, row, (uint32_t)W, row,
+                           RouteHdr{{(uint32_t)(st.status ? st.status : MSVS_ERR_DEVICE), 0u, 0u, 0u, (uint32_t)inst, (uint32_t)(inst >> 32), 0u, 0u}});
+        MSVS_HIP(hipGetLastError());
+    }
+    hand_over(pp, 0, cs, xs);
+    comm->all_gather(reinterpret_cast<unsigned char *>(st.cmat), RW * 4, xs);
+    MSVS_HIP(hipMemcpyAsync(st.h_c, st.cmat, W * RW * 4, hipMemcpyDeviceToHost, xs));
+    MSVS_HIP(hipEventRecord(st.a_ev, xs));
+}
+
+/// BACK: see the banner.  Returns after everything is enqueued; the results are complete when `cs` has run dry (st.done_ev).
+void routed_back(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, hipStream_t cs, hipStream_t xs)
+{
+    const msvs_index_t * ix = st.ix;
+    const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank, RW = W + ROUTE_HDR;
+    std::vector<uint32_t> h_c(W * W);
+    for (int attempt = 0;; attempt++)
+    {
+        MSVS_HIP(hipEventSynchronize(st.a_ev));
+        // ---- the decision every rank takes alike
+        int peer_status = MSVS_OK;
+        size_t peer = 0;
+        bool need = false, any_filtered = false, any_pruned = false;
+        std::vector<uint64_t> inst(W);
+        for (size_t s = 0; s < W; s++)
+        {
+            const uint32_t * h = st.h_c + s * RW + W;
+            if (h[RH_STATUS] != MSVS_OK && peer_status == MSVS_OK)
+            {
+                peer_status = (int)h[RH_STATUS];
+                peer = s;
+            }
+            need |= h[RH_NEED] != 0;
+            any_filtered |= h[RH_FILTERED] != 0;
+            any_pruned |= h[RH_PRUNED] != 0;
+            inst[s] = (uint64_t)h[RH_INST_LO] | ((uint64_t)h[RH_INST_HI] << 32);
+        }
+        if (st.status != MSVS_OK)
+            throw Error{st.status, st.error};
+        if (peer_status != MSVS_OK)
+            fail(peer_status, "routed search: rank %zu failed in its front phase (status %d); no rank searched", peer, peer_status);
+        for (size_t s = 0; s < W; s++) // the result blocks and the entries are sized by k and nprobe: the same on every rank, or nobody searches
+            if (st.h_c[s * RW + W + RH_K] != (uint32_t)st.k || st.h_c[s * RW + W + RH_NP] != (uint32_t)st.np)
+                fail(MSVS_ERR_INVALID_ARGUMENT, "routed search: rank %zu was called with k = %u, nprobe = %u, this rank with %d, %zu", s,
+                     st.h_c[s * RW + W + RH_K], st.h_c[s * RW + W + RH_NP], st.k, st.np);
+        pp.peers_filtered = any_filtered;
+        std::shared_ptr<msvs_index::Global> g;
+        {
+            std::lock_guard<std::mutex> lk(ix->meta_mu);
+            g = ix->global;
+        }
+        const bool stale = need || !g || g->instances != inst; // (`need` and the instances are the same words on every rank; a rank whose
+                                                               // Global is missing or older said so itself through `need` / its instance)
+        const bool unsafe = any_filtered && any_pruned;
+        if (!stale && !unsafe)
+        {
+            for (size_t s = 0; s < W; s++)
+                for (size_t t = 0; t < W; t++)
+                    h_c[s * W + t] = st.h_c[s * RW + t];
+            break;
+        }
+        if (attempt >= 2)
+            fail(MSVS_ERR_DEVICE, "routed search: the ranks did not agree on the index state after two refreshes");
+        if (stale)
+            route_global(ix, comm, inst, xs);
+        routed_front(pp, st, comm, !unsafe, cs, xs);
+    }
+    const size_t nq = st.k ? st.nq : 0, np = st.np, d = ix->dim, k = (size_t)st.k;
+    if (!k)
+        return;
+    // ---- the tables of the step
+    const size_t ent = 4 * (1 + 2 * np + d);          // bytes of one routed entry
+    auto blk = [&](size_t c) { return round_up(c * k * 12, (size_t)16); }; // a result block {ids | dis} of c entries
+    std::vector<size_t> mat1(W * W), mat2(W * W);
+    for (size_t s = 0; s < W; s++)
+        for (size_t t = 0; t < W; t++)
+        {
+            mat1[s * W + t] = (size_t)h_c[s * W + t] * ent;
+            mat2[t * W + s] = blk(h_c[s * W + t]); // the results travel the other way
+        }
+    RouteTab to{}, from{}, res_of{}, home{};
+    size_t sbytes = 0, rbytes = 0, bbytes = 0, res_bytes = 0, n_out = 0, n_in = 0, cmax = 0;
+    for (size_t t = 0; t < W; t++)
+    {
+        to.region[t] = sbytes;
+        to.cnt[t] = h_c[r * W + t];
+        to.first[t] = (uint32_t)n_out;
+        home.region[t] = bbytes;
+        home.cnt[t] = h_c[r * W + t];
+        home.first[t] = (uint32_t)n_out;
+        sbytes += mat1[r * W + t];
+        bbytes += blk(h_c[r * W + t]);
+        n_out += h_c[r * W + t];
+        cmax = std::max<size_t>(cmax, h_c[r * W + t]);
+        from.region[t] = rbytes;
+        from.cnt[t] = h_c[t * W + r];
+        from.first[t] = (uint32_t)n_in;
+        res_of.region[t] = res_bytes;
+        res_of.cnt[t] = h_c[t * W + r];
+        res_of.first[t] = (uint32_t)n_in;
+        rbytes += mat1[t * W + r];
+        res_bytes += blk(h_c[t * W + r]);
+        n_in += h_c[t * W + r];
+    }
+    if (st.routed_pairs)
+        *st.routed_pairs = n_in;
+    // ---- 3. pack and exchange
+    Scratch & sx = pp.back;
+    reserve_two(sx, sbytes + rbytes + comm->exchange_tmp_bytes(mat1) + n_out * 4 + n_in * (np * 8 + d * 4 + k * 12) + res_bytes + bbytes
+                        + comm->exchange_tmp_bytes(mat2) + W * nq * k * 12 + 65536,
+                cs, xs);
+    unsigned char * send = sx.take<unsigned char>(std::max<size_t>(sbytes, 16));
+    unsigned char * recv = sx.take<unsigned char>(std::max<size_t>(rbytes, 16));
+    unsigned char * tmp1 = sx.take<unsigned char>(std::max<size_t>(comm->exchange_tmp_bytes(mat1), 16));
+    uint32_t * sent_q = sx.take<uint32_t>(std::max<size_t>(n_out, 1));
+    if (nq)
+    {
+        RoutePack pk{};
+        pk.Q = st.d_queries;
+        pk.probes = st.alive_probes;
+        pk.words = st.words;
+        pk.mask = st.mask;
+        pk.nq = (uint32_t)nq;
+        pk.np = (uint32_t)np;
+        pk.d = (uint32_t)d;
+        pk.W = (uint32_t)W;
+        pk.cursor = st.cursor;
+        pk.send = send;
+        pk.sent_q = sent_q;
+        pk.to = to;
+        hipLaunchKernelGGL(route_pack_kernel, dim3((unsigned)nq), dim3(64), 0, cs, pk);
+        MSVS_HIP(hipGetLastError());
+    }
+    hand_over(pp, 0, cs, xs);
+    {
+        ProfileScope prof("shard_exchange", xs);
+        comm->exchange(send, recv, mat1, tmp1, xs);
+    }
+    hand_over(pp, 1, xs, cs);
+    // ---- 4. what arrived, searched over this rank's lists under this rank's filter
+    unsigned char * res = sx.take<unsigned char>(std::max<size_t>(res_bytes, 16));
+    if (n_in)
+    {
+        int32_t * rp = sx.take<int32_t>(n_in * np);
+        uint32_t * rw = sx.take<uint32_t>(n_in * np);
+        float * rq = sx.take<float>(n_in * d);
+        int64_t * r_ids = sx.take<int64_t>(n_in * k);
+        float * r_dis = sx.take<float>(n_in * k);
+        RouteUnpack un{};
+        un.recv = recv;
+        un.from = from;
+        un.W = (uint32_t)W;
+        un.np = (uint32_t)np;
+        un.d = (uint32_t)d;
+        un.probes = rp;
+        un.words = rw;
+        un.Q = rq;
+        hipLaunchKernelGGL(route_unpack_kernel, dim3((unsigned)n_in), dim3(64), 0, cs, un, (uint32_t)n_in);
+        MSVS_HIP(hipGetLastError());
+        const auto meta = ix->get_meta();
+        size_t eff_bits = st.nbits;
+        const uint64_t * eff = effective_filter(*ix, meta.get(), st.d_alive, st.nbits, &eff_bits, cs);
+        ProbeWords gw{};
+        gw.given = rw;
+        index_search_device(*ix, rq, n_in, (uint32_t)k, np, eff, eff_bits, r_ids, r_dis, cs, rp, nullptr, nullptr, gw);
+        hipLaunchKernelGGL(route_result_kernel, dim3((unsigned)ceil_div(n_in * k, (size_t)256)), dim3(256), 0, cs, r_ids, r_dis, (uint32_t)n_in,
+                           (uint32_t)k, (uint32_t)W, res_of, res);
+        MSVS_HIP(hipGetLastError());
+    }
+    // ---- 5. results back to their home ranks, merged there
+    unsigned char * back = sx.take<unsigned char>(std::max<size_t>(bbytes, 16));
+    unsigned char * tmp2 = sx.take<unsigned char>(std::max<size_t>(comm->exchange_tmp_bytes(mat2), 16));
+    hand_over(pp, 0, cs, xs);
+    {
+        ProfileScope prof("shard_exchange", xs);
+        comm->exchange(res, back, mat2, tmp2, xs);
+    }
+    hand_over(pp, 1, xs, cs);
+    if (!nq)
+        return;
+    int64_t * m_ids = sx.take<int64_t>(W * nq * k);
+    float * m_dis = sx.take<float>(W * nq * k);
+    MSVS_HIP(hipMemsetAsync(m_ids, 0xFF, W * nq * k * 8, cs)); // -1: no hit
+    MSVS_HIP(hipMemsetAsync(m_dis, 0, W * nq * k * 4, cs));
+    if (cmax)
+    {
+        hipLaunchKernelGGL(route_scatter_kernel, dim3((unsigned)ceil_div(cmax * k, (size_t)256), (unsigned)W), dim3(256), 0, cs, back, home, sent_q,
+                           (uint32_t)nq, (uint32_t)k, m_ids, m_dis);
+        MSVS_HIP(hipGetLastError());
+    }
+    const int order = ix->metric == MSVS_METRIC_IP ? MSVS_METRIC_IP : MSVS_METRIC_L2; // (cosine distances leave the search as 1 - ip)
+    merge_topk_device(m_ids, nq * k, m_dis, nq * k, W, nq, k, order, st.d_ids, st.d_dis, cs);
+    apply_row_ids_map(ix->get_meta().get(), st.d_ids, nq * k, cs);
+}
+
+void routed_fill(RoutedStep & st, const msvs_index_t * ix, const float * d_queries, size_t nq, int k, int nprobe, const uint64_t * d_alive,
+                 size_t nbits, int64_t * d_ids, float * d_dis, uint64_t * routed_pairs)
+{
+    st.ix = ix;
+    st.d_queries = d_queries;
+    st.nq = nq;
+    st.k = k;
+    st.nprobe = nprobe;
+    st.d_alive = d_alive;
+    st.nbits = nbits;
+    st.d_ids = d_ids;
+    st.d_dis = d_dis;
+    st.routed_pairs = routed_pairs;
+    st.cursor = nullptr;
+}
+
+void routed_args_check(const msvs_index_t * ix, const msvs_comm_t * comm)
+{
+    // (what cannot be published: without a communicator there is nobody to tell)
+    if (!ix || !comm)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "null index / communicator");
+    if (comm->nranks > (int)ROUTE_MAX_RANKS)
+        fail(MSVS_ERR_INVALID_ARGUMENT, "the routed search serves up to %u ranks", ROUTE_MAX_RANKS);
+}
+}
+
+extern "C" int msvs_shard_search_routed_filtered_device(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq,
+                                                        int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
+                                                        float * d_dis, void * hip_stream, uint64_t * routed_pairs)
+{
+    return guarded([&] {
+        routed_args_check(ix, comm);
+        RoutePipe & pp = *route_pipe_of(comm, true);
+        std::lock_guard<std::mutex> lk(pp.mu);
+        if (pp.step[0].pending || pp.step[1].pending)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "a pipelined routed step is still in flight on this communicator: msvs_shard_search_drain first");
+        hipStream_t cs = as_stream(hip_stream);
+        RoutedStep & st = pp.step[0];
+        routed_fill(st, ix, d_queries, nq, k, nprobe, d_alive_bits, nbits, d_ids, d_dis, routed_pairs);
+        routed_front(pp, st, comm, true, cs, cs);
+        routed_back(pp, st, comm, cs, cs);
+    });
 }
 
 extern "C" int msvs_shard_search_routed_device(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq, int k,
                                                int nprobe, int64_t * d_ids, float * d_dis, void * hip_stream, uint64_t * routed_pairs)
 {
+    return msvs_shard_search_routed_filtered_device(ix, comm, d_queries, nq, k, nprobe, nullptr, 0, d_ids, d_dis, hip_stream, routed_pairs);
+}
+
+extern "C" int msvs_shard_search_routed_device_async(const msvs_index_t * ix, const msvs_comm_t * comm, const float * d_queries, size_t nq, int k,
+                                                     int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids, float * d_dis,
+                                                     void * hip_stream, uint64_t * routed_pairs, void ** prev_done_event)
+{
     return guarded([&] {
-        shard_check(ix, comm, d_queries, nq, k, d_ids, d_dis);
-        if (ix->type != MSVS_INDEX_IVFFLAT)
-            fail(MSVS_ERR_NOT_IMPLEMENTED, "the routed search serves IVFFLAT shards (a FLAT index has no lists to route by: msvs_shard_search_device)");
-        if (comm->nranks > (int)ROUTE_MAX_RANKS)
-            fail(MSVS_ERR_INVALID_ARGUMENT, "the routed search serves up to %u ranks", ROUTE_MAX_RANKS);
-        if (k == 0)
-            return; // (nq = 0 is a valid contribution: the rank still serves the others' queries)
-        check_k((size_t)k);
-        hipStream_t cs = as_stream(hip_stream);
-        const auto meta = ix->get_meta();
-        if (meta && (meta->delete_nbits || meta->row_ids_n))
-            fail(MSVS_ERR_NOT_IMPLEMENTED, "the routed search does not take delete bitmaps / row id maps yet (msvs_shard_search_device does)");
-        const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank, d = ix->dim;
-        const size_t np = std::min<size_t>(std::max(nprobe, 1), ix->nlist);
-        const auto g = route_global(ix, comm, cs);
-        Scratch & sh = shard_for(cs);
-        // ---- 1. own queries: probes, words, survivors; destination masks and counts
-        sh.reserve(nq * np * 12 + nq * 4 + W * W * 4 + 4096 + 64 * W, cs);
-        int32_t * probes = sh.take<int32_t>(std::max<size_t>(nq * np, 1));
-        uint32_t * words = sh.take<uint32_t>(std::max<size_t>(nq * np, 1));
-        int32_t * alive_probes = sh.take<int32_t>(std::max<size_t>(nq * np, 1));
-        uint32_t * mask = sh.take<uint32_t>(std::max<size_t>(nq, 1));
-        uint32_t * cmat = sh.take<uint32_t>(W * W);
-        uint32_t * cursor = sh.take<uint32_t>(W);
-        MSVS_HIP(hipMemsetAsync(cmat + r * W, 0, W * 4, cs));
-        MSVS_HIP(hipMemsetAsync(cursor, 0, W * 4, cs));
-        if (nq)
+        routed_args_check(ix, comm);
+        RoutePipe & pp = *route_pipe_of(comm, true);
+        std::lock_guard<std::mutex> lk(pp.mu);
+        const int p = (int)(pp.calls++ & 1);
+        RoutedStep & st = pp.step[p];
+        RoutedStep & prev = pp.step[1 - p];
+        if (st.pending)
+            fail(MSVS_ERR_DEVICE, "internal: routed slot still pending");
+        if (prev_done_event)
+            *prev_done_event = nullptr;
+        // inputs: whatever the caller's stream has enqueued so far
+        MSVS_HIP(hipEventRecord(st.in_ev, as_stream(hip_stream)));
+        MSVS_HIP(hipStreamWaitEvent(pp.compute, st.in_ev, 0));
+        routed_fill(st, ix, d_queries, nq, k, nprobe, d_alive_bits, nbits, d_ids, d_dis, routed_pairs);
+        routed_front(pp, st, comm, true, pp.compute, pp.xchg);
+        st.pending = true;
+        if (prev.pending)
         {
-            ProbeWords pw{};
-            pw.out = words;
-            pw.g_radius = g->radius.p;
-            pw.g_list_off = g->list_off.p;
-            pw.g_xmax = g->xmax;
-            pw.g_xmin = g->xmin;
-            pw.pruned_out = alive_probes;
-            index_search_device(*ix, d_queries, nq, (uint32_t)k, np, nullptr, 0, nullptr, nullptr, cs, nullptr, probes, nullptr, pw);
-            hipLaunchKernelGGL(route_mask_kernel, dim3((unsigned)ceil_div(nq, (size_t)256)), dim3(256), 0, cs, alive_probes, (uint32_t)nq, (uint32_t)np,
-                               (uint32_t)W, mask, cmat + r * W);
-            MSVS_HIP(hipGetLastError());
+            prev.pending = false; // (whatever happens below, the step is over)
+            routed_back(pp, prev, comm, pp.compute, pp.xchg);
+            MSVS_HIP(hipEventRecord(prev.done_ev, pp.compute));
+            if (prev_done_event)
+                *prev_done_event = prev.done_ev;
         }
-        // ---- 2. the count matrix on every host
-        comm->all_gather(reinterpret_cast<unsigned char *>(cmat), W * 4, cs);
-        std::vector<uint32_t> h_c(W * W);
-        MSVS_HIP(hipMemcpyAsync(h_c.data(), cmat, W * W * 4, hipMemcpyDeviceToHost, cs));
-        MSVS_HIP(hipStreamSynchronize(cs));
-        const size_t ent = 4 * (1 + 2 * np + d); // bytes of one routed entry
-        std::vector<size_t> mat1(W * W), mat2(W * W);
-        size_t n_out = 0, n_in = 0;
-        for (size_t s = 0; s < W; s++)
-            for (size_t t = 0; t < W; t++)
-            {
-                mat1[s * W + t] = (size_t)h_c[s * W + t] * ent;
-                mat2[t * W + s] = (size_t)h_c[s * W + t] * (size_t)k * 12; // the results travel the other way
-            }
-        std::vector<uint64_t> h_sreg(W), h_rreg(W), h_breg(W);
-        std::vector<uint32_t> h_soff(W), h_scnt(W);
-        size_t sbytes = 0, rbytes = 0, bbytes = 0;
-        RouteUnpack un{};
-        for (size_t t = 0; t < W; t++)
-        {
-            h_sreg[t] = sbytes;
-            h_breg[t] = bbytes;
-            h_soff[t] = (uint32_t)n_out;
-            h_scnt[t] = h_c[r * W + t];
-            sbytes += mat1[r * W + t];
-            bbytes += (size_t)h_c[r * W + t] * (size_t)k * 12;
-            n_out += h_c[r * W + t];
-            un.region[t] = rbytes;
-            un.cnt[t] = h_c[t * W + r];
-            un.first[t] = (uint32_t)n_in;
-            rbytes += mat1[t * W + r];
-            n_in += h_c[t * W + r];
-        }
-        if (routed_pairs)
-            *routed_pairs = n_in;
-        // ---- 3. pack and exchange
-        Scratch & sx = route_for(cs);
-        const size_t res_bytes = n_in * (size_t)k * 12;
-        sx.reserve(sbytes + rbytes + 2 * comm->exchange_tmp_bytes(mat1) + n_out * 4 + 5 * W * 8 + n_in * (np * 8 + d * 4) + 2 * res_bytes + bbytes
-                       + comm->exchange_tmp_bytes(mat2) + W * nq * (size_t)k * 12 + 65536,
-                   cs);
-        unsigned char * send = sx.take<unsigned char>(std::max<size_t>(sbytes, 16));
-        unsigned char * recv = sx.take<unsigned char>(std::max<size_t>(rbytes, 16));
-        unsigned char * tmp1 = sx.take<unsigned char>(std::max<size_t>(comm->exchange_tmp_bytes(mat1), 16));
-        uint32_t * sent_q = sx.take<uint32_t>(std::max<size_t>(n_out, 1));
-        uint64_t * d_sreg = sx.take<uint64_t>(W);
-        uint64_t * d_breg = sx.take<uint64_t>(W);
-        uint32_t * d_soff = sx.take<uint32_t>(W);
-        uint32_t * d_scnt = sx.take<uint32_t>(W);
-        MSVS_HIP(hipMemcpyAsync(d_sreg, h_sreg.data(), W * 8, hipMemcpyHostToDevice, cs));
-        MSVS_HIP(hipMemcpyAsync(d_breg, h_breg.data(), W * 8, hipMemcpyHostToDevice, cs));
-        MSVS_HIP(hipMemcpyAsync(d_soff, h_soff.data(), W * 4, hipMemcpyHostToDevice, cs));
-        MSVS_HIP(hipMemcpyAsync(d_scnt, h_scnt.data(), W * 4, hipMemcpyHostToDevice, cs));
-        if (nq)
-        {
-            RoutePack pk{};
-            pk.Q = d_queries;
-            pk.probes = alive_probes;
-            pk.words = words;
-            pk.mask = mask;
-            pk.nq = (uint32_t)nq;
-            pk.np = (uint32_t)np;
-            pk.d = (uint32_t)d;
-            pk.W = (uint32_t)W;
-            pk.cursor = cursor;
-            pk.region = d_sreg;
-            pk.cnt = d_scnt;
-            pk.send = send;
-            pk.sent_q = sent_q;
-            pk.sent_off = d_soff;
-            hipLaunchKernelGGL(route_pack_kernel, dim3((unsigned)nq), dim3(64), 0, cs, pk);
-            MSVS_HIP(hipGetLastError());
-        }
-        {
-            ProfileScope prof("shard_exchange", cs);
-            comm->exchange(send, recv, mat1, tmp1, cs);
-        }
-        // ---- 4. what arrived, searched over this rank's lists
-        unsigned char * res = sx.take<unsigned char>(std::max<size_t>(res_bytes, 16)); // source s's block: ids[cnt][k] | dis[cnt][k]
-        if (n_in)
-        {
-            int32_t * rp = sx.take<int32_t>(n_in * np);
-            uint32_t * rw = sx.take<uint32_t>(n_in * np);
-            float * rq = sx.take<float>(n_in * d);
-            int64_t * r_ids = sx.take<int64_t>(n_in * (size_t)k);
-            float * r_dis = sx.take<float>(n_in * (size_t)k);
-            un.recv = recv;
-            un.W = (uint32_t)W;
-            un.np = (uint32_t)np;
-            un.d = (uint32_t)d;
-            un.probes = rp;
-            un.words = rw;
-            un.Q = rq;
-            hipLaunchKernelGGL(route_unpack_kernel, dim3((unsigned)n_in), dim3(64), 0, cs, un, (uint32_t)n_in);
-            MSVS_HIP(hipGetLastError());
-            ProbeWords gw{};
-            gw.given = rw;
-            index_search_device(*ix, rq, n_in, (uint32_t)k, np, nullptr, 0, r_ids, r_dis, cs, rp, nullptr, nullptr, gw);
-            // per source: {ids | dis} blocks, the layout of the way back
-            size_t off = 0;
-            for (size_t s = 0; s < W; s++)
-            {
-                const size_t c = un.cnt[s];
-                if (!c)
-                    continue;
-                MSVS_HIP(hipMemcpyAsync(res + off, r_ids + (size_t)un.first[s] * k, c * (size_t)k * 8, hipMemcpyDeviceToDevice, cs));
-                MSVS_HIP(hipMemcpyAsync(res + off + c * (size_t)k * 8, r_dis + (size_t)un.first[s] * k, c * (size_t)k * 4, hipMemcpyDeviceToDevice, cs));
-                off += c * (size_t)k * 12;
-            }
-        }
-        // ---- 5. results back to their home ranks, merged there
-        unsigned char * back = sx.take<unsigned char>(std::max<size_t>(bbytes, 16));
-        unsigned char * tmp2 = sx.take<unsigned char>(std::max<size_t>(comm->exchange_tmp_bytes(mat2), 16));
-        {
-            ProfileScope prof("shard_exchange", cs);
-            comm->exchange(res, back, mat2, tmp2, cs);
-        }
-        if (!nq)
-            return;
-        int64_t * m_ids = sx.take<int64_t>(W * nq * (size_t)k);
-        float * m_dis = sx.take<float>(W * nq * (size_t)k);
-        MSVS_HIP(hipMemsetAsync(m_ids, 0xFF, W * nq * (size_t)k * 8, cs)); // -1: no hit
-        MSVS_HIP(hipMemsetAsync(m_dis, 0, W * nq * (size_t)k * 4, cs));
-        size_t cmax = 0;
-        for (size_t t = 0; t < W; t++)
-            cmax = std::max<size_t>(cmax, h_scnt[t]);
-        if (cmax)
-        {
-            hipLaunchKernelGGL(route_scatter_kernel, dim3((unsigned)ceil_div(cmax * (size_t)k, (size_t)256), (unsigned)W), dim3(256), 0, cs, back, d_breg,
-                               d_scnt, sent_q, d_soff, (uint32_t)W, (uint32_t)nq, (uint32_t)k, m_ids, m_dis);
-            MSVS_HIP(hipGetLastError());
-        }
-        const int order = ix->metric == MSVS_METRIC_IP ? MSVS_METRIC_IP : MSVS_METRIC_L2; // (cosine distances leave the search as 1 - ip)
-        merge_topk_device(m_ids, nq * (size_t)k, m_dis, nq * (size_t)k, W, nq, (size_t)k, order, d_ids, d_dis, cs);
     });
+}
+
+/// `hip_stream` waits for every batch still in flight on the communicator.  With a pipelined routed step pending this is COLLECTIVE:
+/// its back phase (two exchanges) runs here.
+extern "C" int msvs_shard_search_drain(const msvs_comm_t * comm, void * hip_stream)
+{
+    return guarded([&] {
+        if (!comm)
+            fail(MSVS_ERR_INVALID_ARGUMENT, "null communicator");
+        if (ShardPipe * pp = pipe_of(comm, false))
+        {
+            std::lock_guard<std::mutex> lk(pp->mu);
+            for (int p = 0; p < 2; p++)
+                if (pp->used[p])
+                    MSVS_HIP(hipStreamWaitEvent(as_stream(hip_stream), pp->done_ev[p], 0));
+        }
+        RoutePipe * rpp = route_pipe_of(comm, false);
+        if (!rpp)
+            return;
+        RoutePipe & rp = *rpp;
+        std::lock_guard<std::mutex> lk(rp.mu);
+        for (int i = 0; i < 2; i++)
+        {
+            RoutedStep & st = rp.step[(rp.calls + i) & 1]; // oldest first
+            if (!st.pending)
+                continue;
+            st.pending = false;
+            routed_back(rp, st, comm, rp.compute, rp.xchg);
+            MSVS_HIP(hipEventRecord(st.done_ev, rp.compute));
+        }
+        if (rp.calls)
+        {
+            MSVS_HIP(hipEventRecord(rp.hand[1], rp.compute));
+            MSVS_HIP(hipStreamWaitEvent(as_stream(hip_stream), rp.hand[1], 0));
+        }
+    });
+}
+
+/// msvs_comm_free: the pipelined forms' state of a communicator goes with it (device synchronised first: nothing of it may be in flight).
+static void forget_pipes(const msvs_comm_t * c)
+{
+    bool any = false;
+    {
+        std::lock_guard<std::mutex> lk(g_pipes_mu);
+        any |= g_pipes.count(c) != 0;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_route_pipes_mu);
+        any |= g_route_pipes.count(c) != 0;
+    }
+    if (!any)
+        return;
+    (void)hipDeviceSynchronize();
+    {
+        std::lock_guard<std::mutex> lk(g_pipes_mu);
+        auto it = g_pipes.find(c);
+        if (it != g_pipes.end())
+        {
+            ShardPipe & p = *it->second;
+            (void)hipStreamDestroy(p.compute);
+            (void)hipStreamDestroy(p.xchg);
+            for (int i = 0; i < 2; i++)
+                for (hipEvent_t e : {p.in_ev[i], p.ab_ev[i], p.x1_ev[i], p.b_ev[i], p.done_ev[i]})
+                    (void)hipEventDestroy(e);
+            g_pipes.erase(it);
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_route_pipes_mu);
+    auto it = g_route_pipes.find(c);
+    if (it != g_route_pipes.end())
+    {
+        RoutePipe & p = *it->second;
+        (void)hipStreamDestroy(p.compute);
+        (void)hipStreamDestroy(p.xchg);
+        for (hipEvent_t e : {p.hand[0], p.hand[1]})
+            (void)hipEventDestroy(e);
+        for (RoutedStep & st : p.step)
+        {
+            (void)hipFree(st.cmat);
+            (void)hipHostFree(st.h_c);
+            for (hipEvent_t e : {st.in_ev, st.a_ev, st.done_ev})
+                (void)hipEventDestroy(e);
+        }
+        g_route_pipes.erase(it);
+    }
 }

@@ -466,6 +466,33 @@ def test_rccl_transport_single_rank_roundtrip():
             torch.cuda.synchronize()
             fi, fd = ix.search(q, k, "nprobe=5" if typ == capi.INDEX_IVFFLAT else "")
             assert (oi.cpu().numpy() == fi).all() and (od.cpu().numpy() == fd).all()
+            if typ != capi.INDEX_IVFFLAT:
+                continue
+            # the ROUTED form through the real ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd path: with route_self_rccl the
+            # rank's own piece travels to itself through the group instead of a device copy (both exchanges of the step)
+            capi.set_option("route_self_rccl", "1")
+            try:
+                oi.fill_(-7)
+                served = ix.shard_search_routed_device(comm, dq.data_ptr(), nq, k, 5, oi.data_ptr(), od.data_ptr())
+                torch.cuda.synchronize()
+                assert served == nq and (oi.cpu().numpy() == fi).all() and (od.cpu().numpy() == fd).all()
+                alive = rng.random(n) < 0.5
+                bits = torch.from_numpy(capi.pack_bits(alive).view(np.int64)).cuda()
+                ix.shard_search_routed_device(comm, dq.data_ptr(), nq, k, 5, oi.data_ptr(), od.data_ptr(), 0, bits.data_ptr(), n)
+                torch.cuda.synchronize()
+                ai, ad = ix.search(q, k, "nprobe=5", alive=alive)
+                assert (oi.cpu().numpy() == ai).all() and (od.cpu().numpy() == ad).all()
+                # two steps in flight
+                o2 = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+                d2 = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+                assert ix.shard_search_routed_device_async(comm, dq.data_ptr(), nq, k, 5, oi.data_ptr(), od.data_ptr()) is None
+                assert ix.shard_search_routed_device_async(comm, dq.data_ptr(), nq, k, 5, o2.data_ptr(), d2.data_ptr()) is not None
+                comm.drain()
+                torch.cuda.synchronize()
+                for a, b in ((oi, od), (o2, d2)):
+                    assert (a.cpu().numpy() == fi).all() and (b.cpu().numpy() == fd).all()
+            finally:
+                capi.set_option("route_self_rccl", None)
     comm.close()
 
 
@@ -530,9 +557,13 @@ def test_bench_n_gt_1_code_path_runs_on_one_gpu():
     line = [ln for ln in r.stdout.split("\n") if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"].startswith("lists % 2")
-    mg = out["multi_gpu"]  # the routed form is the headline of N > 1 (its own batch per rank), the replicated one timed beside it
+    assert len(line) < 8000  # (the compact driver line; the full object is bench_detail.json)
+    mg = out["legs"]["multi_gpu"]  # the routed form is the headline of N > 1 (its own batch per rank), the replicated one timed beside it
     assert mg["mode"] == "routed" and out["scaling"] == "weak" and len(mg["routed"]["routed_pairs_per_step_by_rank"]) == 2
     assert all(512 <= p_ <= 2 * 512 for p_ in mg["routed"]["routed_pairs_per_step_by_rank"]), mg
     assert mg["replicated"]["qps"] > 0 and mg["routed"]["stage_ms_rank0"]["shard_exchange"] > 0
-    c4 = out["c4_sharded"]
+    c4 = out["legs"]["c4_sharded"]
     assert "error" not in c4 and c4["batches"]["4096"]["qps"] > 0 and 0 < c4["rows_on_rank0"] < 120000, c4
+    with open(os.path.join(root, "bench_detail.json")) as f:
+        full = json.load(f)
+    assert full["value"] == out["value"] and full["multi_gpu"]["routed"]["stage_ms_rank0"] == mg["routed"]["stage_ms_rank0"]
