@@ -7,9 +7,12 @@ Workload : BASELINE.json configs[1] -- IVFFLAT nlist=1024, nprobe=32, on synthet
 A "step" : one batch of `--batch` queries through the search entry point (coarse quantiser + list scan + exact re-rank /
            top-k merge), queries / index / outputs resident in HBM, enqueued on torch's current stream.
 N = 1    : msvs_index_search_device.
-N > 1    : msvs_shard_search_device (one process per GPU; libmsvs owns the RCCL communicator): lists sharded
-           list_id % N, the coarse quantiser sharded BY QUERY, one all-gather of the probe lists, local list scans, one
-           all-gather of the packed partial top-k, canonical merge.  Total work is fixed => "strong".
+N > 1    : one process per GPU, libmsvs owns the RCCL communicator, lists sharded list_id % N over the SAME 1M-row index.  `value`
+           switches to the ROUTED form (msvs_shard_search_routed_device_async, two steps in flight): every rank brings its OWN batch
+           of `--batch` queries per step, so `value` = N x batch queries per step / max-over-ranks time and "scaling" = "weak" -- weak
+           in QUERIES over a FIXED index (a reader of SCALE: the ratio value(N) / value(1) is the gain in served queries per second
+           when N servers share one index, not a larger table).  The replicated form (msvs_shard_search_device_async: every rank works
+           through the same batch; strong scaling of one batch) is timed beside it under legs.multi_gpu.replicated.
            `python bench.py --gpus N` without a launcher spawns its N ranks itself (torch.distributed.run on 127.0.0.1).
 
 Data: there is no network, so vectors are synthetic.  The headline (`value`) runs on SURVEY 8d's clustered model -- 1024 gaussian
@@ -47,6 +50,7 @@ Every leg but the headline is skipped by --headline-only (profiler runs); --only
 the headline and the sharded C4 family (12.5M rows, 2048 lists, 8 probes PER RANK: at N = 8 that is BASELINE configs[3]).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -298,12 +302,15 @@ def timed(fn, steps, warmup=3):
     return (time.perf_counter() - t) / steps
 
 
-def profiled(fn, steps, families):
-    """HIP-event time per step of the named kernel families (msvs_profile_*), on the launch stream."""
+def profiled(fn, steps, families, drain=None):
+    """HIP-event time per step of the named kernel families (msvs_profile_*), on the launch stream.  drain: completes steps a
+    pipelined entry point still holds (collective)."""
     capi.profile_reset()
     capi.profile_enable(True)
     for i in range(steps):
         fn(i)
+    if drain:
+        drain()
     torch.cuda.synchronize()
     capi.profile_enable(False)
     out = {}
@@ -476,14 +483,21 @@ def main():
 
     routed = world > 1 and args.shard_mode == "routed"
     routed_served = []
+    routed_live = []
+    routed_slots = [(torch.empty((B, k), device=dev, dtype=torch.int64), torch.empty((B, k), device=dev, dtype=torch.float32), ctypes.c_uint64(0))
+                    for _ in range(3)] if routed else []
 
     def step(i):
         if routed:
             # every rank brings its OWN batch (the queries that arrived at its server); a query visits the ranks that own lists it still
             # needs after the pre-pruning at its home rank (msvs_shard_search_routed_device)
+            # two steps in flight (msvs_shard_search_routed_device_async): call i enqueues the front phase of batch i and the back phase
+            # of batch i - 1, whose count matrix was gathered one call ago; fence() drains (collective) and synchronises
             j = (i * world + rank) % n_pool
-            routed_served.append(ix.shard_search_routed_device(comm, q_all[j * B:(j + 1) * B].data_ptr(), B, k, nprobe, out_ids.data_ptr(),
-                                                               out_dis.data_ptr(), stream))
+            slot = routed_slots[i % 3]  # (batch i - 1 is still in flight and batch i - 2's event has just been handed out)
+            ix.shard_search_routed_device_async(comm, q_all[j * B:(j + 1) * B].data_ptr(), B, k, nprobe, slot[0].data_ptr(), slot[1].data_ptr(),
+                                                stream, served=slot[2])
+            routed_live.append(slot[2])
             return
         q = q_all[(i % n_pool) * B:(i % n_pool + 1) * B]
         if world > 1:
@@ -496,7 +510,12 @@ def main():
             ix.search_device(q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
 
     def fence():
+        if world > 1:
+            comm.drain(stream)  # (a pending routed step's back phase runs here: collective)
         torch.cuda.synchronize()
+        if routed_live:
+            routed_served.extend(c.value for c in routed_live[-3:])  # (the pairs counters of the last steps, complete after the drain)
+            routed_live.clear()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -508,7 +527,7 @@ def main():
         ok_r = 1
         try:
             step(0)
-            torch.cuda.synchronize()
+            fence()  # (the back phase of the step runs in the drain: a failure on ANY rank's front phase is raised there on EVERY rank)
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("rank %d: routed search failed (%r): replicated form\n" % (rank, e))
             ok_r = 0
@@ -561,7 +580,8 @@ def main():
             allv = [a.cpu() for a in av]
         fam_r = None
         if routed:
-            fam_r = profiled(step, min(args.steps, 4), ("shard_exchange", "coarse_pass", "ivf_plan", "ivf_scan", "ivf_sample_scan", "rerank", "merge"))
+            fam_r = profiled(step, min(args.steps, 4), ("shard_exchange", "coarse_pass", "ivf_plan", "ivf_scan", "ivf_sample_scan", "rerank", "merge"),
+                             drain=fence)
         routed_now = routed
         routed = False
         for i in range(2):
@@ -1455,7 +1475,7 @@ def main():
                        "rows": n, "dim": d, "nlist": nlist, "nprobe": nprobe, "k": k, "batch": B,
                        "parallelism": (("lists %% %d, ROUTED: a batch of %d queries per rank and step, coarse quantiser + pre-pruning at the home rank, "
                                         "point-to-point exchange of the surviving (query, rank) pairs, local search, results back, merge at home "
-                                        "(msvs_shard_search_routed_device); transport: %s" % (world, B, comm_kind)) if routed else
+                                        "(msvs_shard_search_routed_device_async: two steps in flight); transport: %s" % (world, B, comm_kind)) if routed else
                                        ("lists %% %d, coarse quantiser by query, probe (+ coarse distance word) and packed top-k all-gathers, "
                                         "two batches in flight (msvs_shard_search_device_async); transport: %s"
                                         % (world, comm_kind))) if world > 1 else
