@@ -368,6 +368,20 @@ inline size_t h16_lds_bytes(uint32_t ncb, uint32_t nch)
 /// NRB = 2 (exhaustive batches: h16_flat_kernel): a wavefront walks TWO consecutive blocks at a time, so every A fragment read
 /// from LDS feeds two MFMAs -- with hundreds of queries per row the pass is bound by the LDS reads of the A operands (1 KiB per
 /// MFMA against 128 B/clk per CU: exactly the matrix pipe's rate), not by the row stream, which then comes out of L2.
+/// The cut of a query as the stream's epilogue tests it.  The pass keeps a row when the ordered word of its key is below the cut
+/// word: word(make_key(v)) < cut.  L2: make_key admits v < FLT_MAX (never NaN) and f2ord is monotone on the floats, so that is
+/// v < c with c = the float whose ordered word is the cut, capped at FLT_MAX -- as a FLOAT comparison, provided the two orders
+/// agree on the values that occur: they differ only on (-0, +0), and v = fl(fma(..) + qn) with qn = |q|^2 >= +0 is never -0 (a
+/// sum rounds to -0 only from two -0 addends).  Cut words below f2ord(-inf) (0: "nothing passes", the padding queries of a short
+/// tile) map to negative NaN patterns: every comparison false, as before.  IP keeps the integer test on the word itself.
+template <int METRIC>
+__device__ __forceinline__ uint32_t h16_stream_cut(const uint32_t cut)
+{
+    if (METRIC != M_L2)
+        return cut;
+    return cut > f2ord(3.402823466e+38f) ? __float_as_uint(3.402823466e+38f) : __float_as_uint(ord2f(cut));
+}
+
 template <int METRIC, int NCBI, int RING = H_RING, int NRB = 1>
 __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned char * qt /* tile */,
                                            const uint32_t chunk_stride, const float * m2_s, const float * qn_s,
@@ -526,8 +540,16 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
         // buffers in ONE parallel round of global atomics per <= 64 records, at the end of every block (a returning atomic
         // per passing register serialises one L2 round trip each; carrying the stage from block to block and flushing only
         // when it is full -- fewer, fuller rounds -- measured SLOWER: 0.545 against 0.476 ms on the bench step, round 4).
+        // Round 6: the TEST of a register is three instructions -- fma, add, compare against the query's cut as a FLOAT (thr_s holds
+        // h16_stream_cut: see there why that is the same decision as `ordered word of make_key < cut word`), a row that is not
+        // offered carries a NaN norm -- and the key is made only for the (rare) registers that pass.  The exhaustive batches spent
+        // 5 VALU instructions per MFMA here (SQ_INSTS_VALU 1153 M against 192 M MFMAs per 4096-query pass: 12 per register), exactly
+        // what the matrix pipe's shadow can hide and no more.
 #pragma unroll
         for (int rb = 0; rb < NRB; rb++)
+        {
+            const float xq = METRIC == M_L2 ? (ok[rb] ? xn[rb] : __builtin_nanf("")) : 0.f;
+            const uint64_t okb = METRIC == M_L2 ? ~0ull : __ballot(ok[rb]);
 #pragma unroll
         for (int cb = 0; cb < NCBI; cb++)
         {
@@ -543,30 +565,39 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                 {
-                    const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2v[e], acc[rb][cb][4 * g4 + e], xn[rb]), qnv[e])
-                                                   : __fmul_rn(m2v[e], acc[rb][cb][4 * g4 + e]);
-                    const uint64_t key = ok[rb] ? make_key<METRIC>(v, (uint32_t)row[rb]) : KEY_NONE;
-                    const uint32_t word = (uint32_t)(key >> 32);
-                    const bool pass = word < cutv[e]; // KEY_NONE has word 0xFFFFFFFF: never below a cut
-                    const uint64_t mask = __ballot(pass);
+                    bool pass;
+                    float v;
+                    if (METRIC == M_L2)
+                    {
+                        v = __fadd_rn(fmaf(m2v[e], acc[rb][cb][4 * g4 + e], xq), qnv[e]);
+                        pass = v < __uint_as_float(cutv[e]);
+                    }
+                    else
+                    {
+                        v = __fmul_rn(m2v[e], acc[rb][cb][4 * g4 + e]);
+                        pass = v > -3.402823466e+38f && ~f2ord(v) < cutv[e];
+                    }
+                    const uint64_t mask = __ballot(pass) & okb;
                     if (mask)
                     {
                         const uint32_t np = __popcll(mask);
                         if (cnt + np > (uint32_t)H_STAGE)
                             flush();
-                        if (pass)
+                        if (pass && ok[rb])
                         {
+                            const uint64_t key = make_key<METRIC>(v, (uint32_t)row[rb]);
                             const uint32_t at = cnt
                                 + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                             stage[at] = (uint32_t)key;
-                            stage[H_STAGE + at] = word;
+                            stage[H_STAGE + at] = (uint32_t)(key >> 32);
                             stage[2 * H_STAGE + at] = qrow_s[q0 + e];
                         }
                         cnt += np;
                     }
                 }
             }
+        }
         }
         flush();
     }
@@ -666,7 +697,7 @@ __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
             const float2 qi = a.qinfo[q];
             m2_s[tid] = qi.x;
             qn_s[tid] = qi.y;
-            thr_s[tid] = v ? a.qthr[q] : 0u; // padding queries of a short tile never pass
+            thr_s[tid] = h16_stream_cut<METRIC>(v ? a.qthr[q] : 0u); // padding queries of a short tile never pass
         }
         __syncthreads();
         // the tile: piece p = (chunk, query < tq_e, slot) holds piece slot ^ swizzle(query) of the query's chunk; LDS keeps the
@@ -1399,7 +1430,7 @@ __global__ __launch_bounds__(64 * H_NW) void h16_flat_kernel(const H16Params a, 
             const float2 qi = a.qinfo[q];
             m2_s[tid] = qi.x;
             qn_s[tid] = qi.y;
-            thr_s[tid] = v ? a.qthr[q] : 0u; // padding queries of a short tile never pass
+            thr_s[tid] = h16_stream_cut<METRIC>(v ? a.qthr[q] : 0u); // padding queries of a short tile never pass
         }
         __syncthreads();
         {
