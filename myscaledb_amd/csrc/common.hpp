@@ -175,6 +175,8 @@ struct Options
     double h16_rho = 1;       // fp16 shadow passes: error bound from the MEASURED rounding error of the stored rows and of each query image; 0: the worst case per element
     double flat_h16 = 1;      // FLAT batches through the index's fp16 shadow (h16_flat_kernel); 0: the split-bf16 pass over the f32 rows; 3: one row block per wavefront
     double flat_ncb = 0;      // FLAT shadow pass: column blocks per tile (0: by batch size)
+    double flat_lazy_flush = 1; // FLAT shadow pass, several tiles: a wavefront's survivors leave its LDS stage when it is full or the item ends (0: after every block)
+    double flat_rot = 0;      // FLAT shadow pass, several tiles: tile t starts flat_rot * t rounds into its segment and wraps around (0: all tiles in step)
     double flat_segb = 0;     // FLAT shadow pass: blocks per segment (0: 64 / 128 / 256 for one / several / many tiles)
     double h16_stamps = 0;    // experiments: the main launch records per-item wall-clock stamps (msvs_debug_h16_stamps)
     double lat_path = 1;      // few-query IVFFLAT searches in two self-merging launches (latency_kernels.hpp): 0 off,

@@ -72,6 +72,7 @@ struct H16Params
     // sample launch
     uint32_t * sample_out;    // [nq * nprobe][32] ordered distance word of row r of block 0 (0xFFFFFFFF = no row)
     uint32_t * sched;         // [8] work-queue cursors of this launch (zeroed by the caller)
+    uint32_t lazy_flush;      // 1: survivors stay in the wavefront's LDS stage from block to block and leave when it is full / at the end of the item
     uint64_t * stamps;        // nullable (option h16_stamps): [grid][H_STAMP_ITEMS][4] {item popped, tile resident, rows done, l << 32 | nvalid << 8}
                               // in wall_clock64 ticks (100 MHz), [grid][0][0] = items of the workgroup
 };
@@ -437,6 +438,13 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
         }
         cnt = 0;
     };
+    half8 afp[2][NCBI]; // NRB >= 2: the A fragments of the step in flight and of the next one (see `step`)
+    if (NRB >= 2)
+    {
+#pragma unroll
+        for (int cb = 0; cb < NCBI; cb++)
+            afp[0][cb] = *reinterpret_cast<const half8 *>(qt + cb * 4096 + aoff[0]);
+    }
     for (; blk < nblk; blk += stride)
     {
         const uint32_t nxt = blk + stride;
@@ -474,6 +482,32 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
                     acc[rb][cb][r] = 0.f;
         auto step = [&](const int u, const uint32_t c) {
             const unsigned char * qb = qt + (size_t)c * chunk_stride;
+            if (NRB >= 2)
+            {
+                // exhaustive batches (two row blocks per wavefront): the A fragments of the NEXT reduction step (of the next chunk after
+                // the last step of this one; of chunk 0 after the last chunk -- the tile is the same for every block) are requested
+                // BEFORE the MFMAs of this step issue: two register sets, the order pinned with sched_group_barrier (left to itself
+                // hipcc reads each step's fragments just in time into one set and every step opens on the LDS latency)
+                const unsigned char * qn_ = qt + (size_t)(c + 1 < nch ? c + 1 : 0) * chunk_stride;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+#pragma unroll
+                    for (int cb = 0; cb < NCBI; cb++)
+                        afp[(j + 1) & 1][cb] = *reinterpret_cast<const half8 *>((j < 3 ? qb : qn_) + cb * 4096 + aoff[(j + 1) & 3]);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; rb++)
+                    {
+                        const half8 bf = __builtin_bit_cast(half8, ring[rb][u][j]);
+#pragma unroll
+                        for (int cb = 0; cb < NCBI; cb++)
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afp[j & 1][cb], bf, acc[rb][cb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, NCBI, 0);       // the next step's LDS reads ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, NRB * NCBI, 0); // ... then this step's MFMAs
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
@@ -599,8 +633,11 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
             }
         }
         }
-        flush();
+        if (!a.lazy_flush)
+            flush();
     }
+    if (a.lazy_flush && cnt) // (exhaustive batches: the stage is emptied when it is full and at the end of the item's share)
+        flush();
 }
 
 /// Next work item of this workgroup: per-XCD queues (a.sched[x] = cursor of the x-th eighth of the items), own XCD
@@ -1362,6 +1399,7 @@ struct H16FlatParams
 {
     uint32_t nq, nblk, n_rows; // queries of the batch; blocks and rows of the table
     uint32_t nseg, ntiles, segb; // segments of segb blocks each; tiles
+    uint32_t rot;                // tile t starts rot * t rounds into its segment (0: every tile at the segment's first block)
 };
 
 /// One wavefront per query: the m-th smallest of its n_pad <= 2048 sample words becomes the cut; no candidate is appended here
@@ -1458,9 +1496,23 @@ __global__ __launch_bounds__(64 * H_NW) void h16_flat_kernel(const H16Params a, 
         }
         uint32_t * const stage = stage_s + wave * 3 * H_STAGE;
         const uint32_t b0 = seg * f.segb, b1 = b0 + f.segb < f.nblk ? b0 + f.segb : f.nblk;
+        // ROTATION (round 6, option flat_rot, OFF): the tiles of a segment run at the same time on the CUs of one XCD and ask for the
+        // same lines at the same moment; starting tile t `rot * t` rounds (of NW * NRB blocks) into the segment, wrapping around,
+        // was meant to turn the requests queued behind one fill into hits.  MEASURED SLOWER (6.23 -> 7.14 ms per 4096-query pass
+        // over 1M x 768): walking the segment in step is what keeps its working set inside the XCD's L2 -- the knob stays for the
+        // record (profiles/r06_flat_notes.txt).
+        const uint32_t round_blk = NW * NRB, rounds = (b1 - b0 + round_blk - 1) / round_blk;
+        const uint32_t r0 = f.rot ? (tidx * f.rot) % rounds : 0;
+        const uint32_t bs = b0 + r0 * round_blk;
 #define MSVS_H16_FLAT_STREAM(N)                                                                                                    \
-    h16_stream<METRIC, N, RING, NRB>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, 0, b0 + wave * NRB, NW * NRB, \
-                                     b1, 0, (int64_t)f.n_rows)
+    do                                                                                                                             \
+    {                                                                                                                              \
+        h16_stream<METRIC, N, RING, NRB>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, 0, bs + wave * NRB,       \
+                                         NW * NRB, b1, 0, (int64_t)f.n_rows);                                                      \
+        if (r0)                                                                                                                    \
+            h16_stream<METRIC, N, RING, NRB>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, 0, b0 + wave * NRB,   \
+                                             NW * NRB, bs, 0, (int64_t)f.n_rows);                                                  \
+    } while (0)
         if constexpr (NCB == 1)
             MSVS_H16_FLAT_STREAM(1);
         else if (ncb_e == 1)

@@ -910,6 +910,8 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         if (options().flat_segb >= 1)
             f.segb = (uint32_t)options().flat_segb;
         f.nseg = (uint32_t)ceil_div((size_t)nblk, (size_t)f.segb);
+        f.rot = f.ntiles >= 2 ? (uint32_t)options().flat_rot : 0;
+        h.lazy_flush = options().flat_lazy_flush != 0 && f.ntiles >= 2 ? 1 : 0;
         const size_t lds = h16_lds_bytes(ncb, ix.h_nch);
         const uint32_t per_cu = (uint32_t)std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
         const uint32_t fgrid = options().h16_grid >= 1 ? (uint32_t)options().h16_grid : device_cu_count() * per_cu;

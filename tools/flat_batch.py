@@ -17,6 +17,8 @@ def main():
     dev = torch.device("cuda", 0)
     capi.set_device(0)
     x = torch.randn((n, d), device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(1234))
+    if os.environ.get("FLAT_ZERO"):
+        x.zero_()
     q = torch.randn((2 * B, d), device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(4321))
     fl = capi.Index(capi.INDEX_FLAT, capi.METRIC_L2, d)
     fl.add(x.data_ptr(), n=n, mem=capi.MEM_DEVICE)
