@@ -186,6 +186,8 @@ struct Options
                                        // profiles/r02_filter.txt)
     double lat_prune = 1;     // few-query path (L2, no filter): probed lists the list radius rules out get no work items (0: off)
     double h16_preprune = 1;  // shadow list scan (L2, no filter): pairs the list radius alone rules out leave before the sample launch (0: off)
+    double h16_feedback = 1;  // shadow list scan: the second pruning stage is skipped while the last search of the index (same batch shape) came out of the
+                              // pre-pruning with too few pairs for it to pay (0: decided from nq * nprobe alone, as before round 6)
     double h16_prune = 1;     // shadow list scan (L2): drop (query, list) pairs that provably cannot hold one of the query's k nearest rows when the lists are probed by more than a tile of queries (0: off, 2: always)
     double coarse_band = 1;   // coarse quantiser of batches: only the candidates near the top-nprobe boundary are evaluated canonically (0: all 64)
     double rerank_hint = 1;   // second-chance re-rank: skip rows that cannot beat the first stage's k-th exact distance (0: evaluate the whole buffer)

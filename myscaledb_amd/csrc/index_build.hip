@@ -198,6 +198,11 @@ namespace msvs
 /// Row norms for the approximate pass and its error bound; called once the final storage is in place.
 void index_finalize_norms(msvs_index & ix, hipStream_t stream)
 {
+    if (!ix.plan_fb.pairs)
+    {
+        MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&ix.plan_fb.pairs), 64, hipHostMallocDefault));
+        *ix.plan_fb.pairs = 0xFFFFFFFFu;
+    }
     ix.xnorm.alloc(std::max<size_t>(ix.n, 1));
     ix.xnorm_max = 0.f;
     DevBuf<uint32_t> mx(1);

@@ -100,6 +100,20 @@ struct msvs_index
         std::vector<uint64_t> instances; // [W]: the shard objects (msvs_index::instance of every rank) this was gathered from
     };
     mutable std::shared_ptr<Global> global;
+    /// What the plan of the LAST shadow list scan of this index held after the pre-pruning (a pinned word the plan kernel writes, read
+    /// by the next search without synchronisation) and the batch shape it belongs to: a performance hint only -- whether the second
+    /// pruning stage can still pay (h16_list_scan) -- never a correctness input; racing searches may see each other's value.
+    struct PlanFeedback
+    {
+        uint32_t * pairs = nullptr; // pinned host memory, 0xFFFFFFFF: nothing yet
+        mutable uint32_t nq = 0, nprobe = 0;
+        ~PlanFeedback()
+        {
+            if (pairs)
+                (void)hipHostFree(pairs);
+        }
+    };
+    PlanFeedback plan_fb;
     /// Identity of this object among the shard objects a rank has held (an index is immutable once built; a reloaded shard is a new
     /// object): the routed search compares it with the instance its Global was gathered from.
     const uint64_t instance = next_instance();

@@ -448,6 +448,7 @@ struct H16Queries
     const uint32_t * probe_words = nullptr;  // or, a sharded search: the words of the given probes, [nq][nprobe] (ProbeWords::given)
     const float * probe_dis = nullptr;       // or, a small batch: canonical distances of the probes from the canonical coarse scan
     float * upre = nullptr;                  // the pre-pruning's bound per query (h16_preprune_kernel), for the list scan's second stage
+    bool prepruned = false;                  // the probe lists went through the pre-pruning (h16_preprune_kernel)
 };
 
 struct TablePass
@@ -1157,7 +1158,23 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     // ... or when the lists are LONG (a pair of >= 2.5 MB: a second plan's 18 us are a fraction of one list's scan -- batches of 64
     // over 10M+ rows; on the 1.5 MB lists of the 1M-row config the pre-pruning has done what can be done by then)
     const double pair_bytes = (double)ix.n / (double)std::max<size_t>(ix.nlist, 1) * (2.0 * (double)ix.dim + 8.0);
-    const bool prune_pays = options().h16_prune == 2 || (double)nq * (double)nprobe > (double)ix.nlist * (double)pp.T || pair_bytes >= 2.5e6;
+    // Round 6: the pairs that MATTER are those the pre-pruning left, and the host does not know their number -- but the last search of
+    // this index over the same batch shape does: its plan kernel left the count in a pinned word (msvs_index::PlanFeedback; no
+    // synchronisation, stale by one search, a hint only).  On SURVEY 8d's sigma-0.3 blobs 31 of 32 probes are gone before the sample
+    // launch: ~1.05 pairs per query, nothing left for a second stage to find -- its plan (three launches, ~17 us of the 4096-query
+    // step) and the bound arithmetic of the cut kernel are skipped until a batch comes back with more pairs.
+    double eff_pairs = (double)nq * (double)nprobe;
+    uint32_t * fb_out = nullptr;
+    if (prepared.prepruned && ix.plan_fb.pairs && options().h16_prune != 2 && options().h16_feedback != 0)
+    {
+        const uint32_t seen = *reinterpret_cast<volatile uint32_t *>(ix.plan_fb.pairs);
+        if (seen != 0xFFFFFFFFu && ix.plan_fb.nq == (uint32_t)nq && ix.plan_fb.nprobe == (uint32_t)nprobe)
+            eff_pairs = std::min(eff_pairs, 1.25 * (double)seen + 64.0);
+        ix.plan_fb.nq = (uint32_t)nq;
+        ix.plan_fb.nprobe = (uint32_t)nprobe;
+        fb_out = ix.plan_fb.pairs;
+    }
+    const bool prune_pays = options().h16_prune == 2 || eff_pairs > (double)ix.nlist * (double)pp.T || pair_bytes >= 2.5e6;
     const bool prune2 = options().h16_prune != 0 && prune_pays && (prepared.coarse_words || prepared.probe_words || prepared.probe_dis)
         && ix.list_radius.p && k <= 128 && nprobe <= 64 && options().wave_select != 0
         && (!prepared.probe_dis || ((ix.metric == MSVS_METRIC_L2 || ix.metric == MSVS_METRIC_COSINE) && !d_alive));
@@ -1166,8 +1183,10 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         pp.stat_rows = prefilter_fail_counter() + 10;
         pp.stat_first = prune2 ? 0 : 1;
     }
+    pp.pairs_out = fb_out;
     launch_ivf_plan(pp, stream);
     pp.stat_rows = nullptr;
+    pp.pairs_out = nullptr;
     IvfPlanParams pa = pp;
     pa.work_off = pp.work_off2;
     // the queries' fp16 images: the coarse pass over the centroid shadow left them behind, or they are made here
@@ -1590,7 +1609,10 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
                            (uint32_t)nq, (uint32_t)nprobe, out_probes);
         MSVS_HIP(hipGetLastError());
         if (keep_upre)
+        {
             prepared.upre = pr0.upre;
+            prepared.prepruned = true;
+        }
         return true;
     };
     if (probes_only)

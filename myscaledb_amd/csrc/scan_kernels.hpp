@@ -593,6 +593,8 @@ struct IvfPlanParams
     // pruning -- a batch of 64 queries keeps ~64 lists, one item per list would leave three quarters of the CUs idle (plan_nseg)
     uint32_t * seg_out = nullptr;
     uint32_t seg_target_items = 0;
+    uint32_t * pairs_out = nullptr; // nullable, HOST-visible (pinned): the scan launch leaves the number of pairs in the plan here (a hint for the
+                                    // next search's choice of stages: read by the host without any synchronisation, stale by design)
 };
 
 /// Segments of a list of `blocks` 32-row blocks at a segment size of sb blocks (rounded to the nearest count, at least one;
@@ -768,6 +770,8 @@ static __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const IvfPla
     {
         p.pair_off[p.nlist] = carry[0];
         p.work_off[p.nlist] = carry[1];
+        if (p.pairs_out)
+            *p.pairs_out = carry[0];
         if (p.work_off2)
             p.work_off2[p.nlist] = carry[2];
         if (p.stat_rows)
