@@ -634,6 +634,18 @@ def main():
     # (HBM traffic from the PMC counters is NOT measured inside this run: the FETCH_SIZE / WRITE_SIZE passes of the same step are
     # kept under profiles/ -- traffic.json, rNN_pmc_*.txt -- and the line says null rather than quoting another run's number)
     traffic = None
+    traffic_src = None
+    try:
+        # the FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of THIS step (same data model, batch, nprobe), run under rocprofv3 in their own
+        # processes (tools/r6_pmc_traffic.sh) and committed with the tree: quoted only when the run's shape is the one they measured
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)
+        leg_ = {"blobs03": "headline", "mid": "mid", "iid": "iid"}.get(args.data)
+        if world == 1 and cand_pass and leg_ in tj.get("legs", {}) and (n, d, B, nprobe, nlist) == (1_000_000, 768, 4096, 32, 1024):
+            traffic = int(tj["legs"][leg_]["hbm_bytes_per_step"])
+            traffic_src = "profiles/traffic.json (%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same step)" % tj.get("round")
+    except (OSError, ValueError, KeyError):
+        pass
     # matrix-core work of the same launches: fp16 MFMA, 2 flop per (query, probed row, element padded to 64)
     mfma_tf = rows_model * 2 * ((d + 63) // 64 * 64) / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 and cand_pass else 0.0
     if world > 1:
@@ -643,7 +655,7 @@ def main():
     step_ms = elapsed / args.steps * 1e3
     roof = {
         "bound": "hbm", "achieved": round(moved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(moved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "frac": round(moved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": "h16_scan_kernel + h16_sample_kernel (fp16-shadow MFMA candidate pass of the list scan; exact f32 re-rank + "
                   "certificate follow)" if cand_pass else "ivf_batched_scan_kernel / ivf_scan_kernel (canonical f32 scan)",
         "launch_ms": round(scan_ms, 4), "launches_per_step": 2 if fam["ivf_sample_scan"] else 1,
@@ -658,8 +670,8 @@ def main():
         "step_kernels_ms": {f: round(v, 4) for f, v in fam.items() if v},
         "note": "achieved / frac = the bytes the two launches READ -- the rows of the lists their plans hold (counted on the device: the probe pruning keeps lists out of them; rows_probed_union_per_step is what the reference's scan would visit) x (2d + 8) B: the fp16 "
                 "shadow row, its f32 norm and its id -- / (sample + main launch time, HIP events on the launch stream); "
-                "whole_step_* = the same bytes over the whole step; traffic: null here -- the FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of "
-                "this step live in profiles/ (traffic.json: 1.045 x the rows read); prefilter = (queries through the candidate pass, queries that needed "
+                "whole_step_* = the same bytes over the whole step; traffic: HBM bytes of the two launches per step from the FETCH_SIZE (x2, gfx950) + "
+                "WRITE_SIZE passes of this step kept in profiles/traffic.json (null when the run's shape is not the measured one); prefilter = (queries through the candidate pass, queries that needed "
                 "the canonical fallback) during the profiled steps; per_query_model_gbs exceeds HBM speed because one pass over "
                 "a list serves every query of the step that probes it",
     }

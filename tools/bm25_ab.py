@@ -1,5 +1,5 @@
 """Round 5: BM25 scorer variants side by side in ONE process (the 10M-document corpus is built once):
-    python tools/r5_bm25_ab.py [--docs 10000000] [--batches 16,64,256,1024] [--check 6]
+    python tools/bm25_ab.py [--docs 10000000] [--batches 16,64,256,1024] [--check 6]
 Every variant's first batch is compared with the default variant's results (ids and score bits) -- the variants are all exact."""
 import argparse
 import os
