@@ -365,7 +365,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     bool lean = recs && options().bm25_lean != 0;
     for (size_t q = 0; q < nq && lean; q++)
         lean = qoff[q + 1] < qoff[q] || qoff[q + 1] - qoff[q] <= BL_NT;
-    const uint32_t bpc = recs ? br_blocks_per_cu(big_slots) : BP_BLOCKS_PER_CU; // resident workgroups per CU of the posting scorer
+    const uint32_t bpc = lean ? BL_WAVES_PER_SIMD : recs ? br_blocks_per_cu(big_slots) : BP_BLOCKS_PER_CU; // resident workgroups per CU of the posting scorer
     // items per resident wavefront of the EMIT pass: an item costs ~7 us of dependent loads before its first window, a wavefront with
     // one long item cannot even out the others' tails -- measured: 1 item at 64 queries (0.163 -> 0.146 ms), 2 at 256, 4 at 1024
     // (0.749 -> 0.698 ms): ~4600 postings per item, between 1 and 4 items

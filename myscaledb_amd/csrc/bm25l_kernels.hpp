@@ -26,6 +26,10 @@ namespace msvs
 {
 
 constexpr uint32_t BL_SLOTS2 = 4096; // hash slots of the second look (a few dozen records per window reach it)
+#ifndef MSVS_BL_WPS
+#define MSVS_BL_WPS 4
+#endif
+constexpr uint32_t BL_WAVES_PER_SIMD = MSVS_BL_WPS; // resident wavefronts per SIMD the register budget is cut for (= workgroups per CU)
 constexpr uint32_t BL_NT = 4; // terms per query this kernel takes (the look-ahead is 64 lanes = 16 steps x 4 terms)
 
 typedef const __attribute__((address_space(1))) uint2 * bl_gptr_u2;
@@ -37,7 +41,7 @@ __device__ __forceinline__ T bl_sel4(const T & a0, const T & a1, const T & a2, c
 }
 
 template <int MODE, int R, int SLOTS>
-__global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25l_kernel(const Bm25RParams ar)
+__global__ __launch_bounds__(64 * BP_WAVES, BL_WAVES_PER_SIMD) void bm25l_kernel(const Bm25RParams ar)
 {
     constexpr uint32_t BMW = 2 * SLOTS / 32;
     __shared__ __attribute__((aligned(16))) uint32_t bm_s[BP_WAVES][BMW]; // word pairs: seen | dup bits of 32 hash slots
