@@ -201,6 +201,14 @@ struct HostSignal
     uint32_t * nfail = nullptr;
     uint32_t seq = 0;
     bool armed = false, used = false;
+    /// Before a call arms the signal: the completion word reads "not yet" (seq is never 0) and the failure count "unknown" -- the slot
+    /// lives inside a reused pinned block at an offset that depends on (nq, k, dim), so it may hold ids of an earlier call.  No
+    /// kernel of an earlier call can still write there: host-pointer calls return after their stream has run dry.
+    void reset() const
+    {
+        __atomic_store_n(flag, 0u, __ATOMIC_RELAXED);
+        __atomic_store_n(nfail, 0xFFFFFFFFu, __ATOMIC_RELEASE);
+    }
 };
 HostSignal & host_signal();
 

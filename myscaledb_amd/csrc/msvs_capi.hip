@@ -559,8 +559,14 @@ static bool host_signal_round(HostSignal & hs, const uint32_t * nfail, hipStream
         }
     }
     if (__atomic_load_n(hs.flag, __ATOMIC_ACQUIRE) != hs.seq)
+    {
+        // the stream ran dry without the word: the signal kernel did not run (its launch failed after hipGetLastError looked) -- the
+        // failure count in pinned memory is not this call's: the results cannot be trusted
         MSVS_HIP(hipStreamSynchronize(stream));
-    return *hs.nfail == 0;
+        if (__atomic_load_n(hs.flag, __ATOMIC_ACQUIRE) != hs.seq)
+            fail(MSVS_ERR_DEVICE, "host-pointer search: the completion word was never written (signal launch lost)");
+    }
+    return __atomic_load_n(hs.nfail, __ATOMIC_ACQUIRE) == 0;
 }
 
 /// Second half of a table pass, whatever produced the candidates: canonical re-rank + certificate, then the canonical scan

@@ -363,6 +363,7 @@ void flat_few_search_host(const msvs_index & ix, const float * queries, size_t n
     HostSignal & hs = host_signal();
     hs.flag = flag;
     hs.nfail = flag + 16;
+    hs.reset(); // (the slot's position depends on the call's shape: whatever an earlier, larger call left there must not read as this call's word)
     hs.seq = ++c.seq ? c.seq : ++c.seq; // never 0: the word starts at 0
     hs.armed = true;
     hs.used = false;
@@ -483,6 +484,7 @@ int index_search_host_call(const msvs_index_t * ix, const float * queries, size_
             uint32_t * flag = reinterpret_cast<uint32_t *>(c.batch_pinned + o_flag);
             hs.flag = flag;
             hs.nfail = flag + 16;
+            hs.reset(); // (see flat_few_search_host: the slot may hold an earlier call's ids)
             hs.seq = ++c.seq ? c.seq : ++c.seq; // never 0: the word starts at 0
             hs.armed = options().host_signal_batch != 0 && nq <= 256; // (one pass of the device-level search: index_search_device splits beyond)
             hs.used = false;
