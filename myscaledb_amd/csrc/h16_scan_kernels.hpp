@@ -1648,6 +1648,141 @@ __global__ __launch_bounds__(BLOCK, 1) void coarse_h16_kernel(const uint4 * H, u
     }
 }
 
+/// The same table pass as a workgroup-tiled product (round 6): 128 queries x 128 centroids per workgroup of four wavefronts (2 x 2, each
+/// 64 x 64 = four accumulators), BOTH operands staged once per 64-element chunk in LDS (double-buffered, one barrier per chunk).
+/// coarse_h16_kernel's wavefront tile of 64 x 64 fetches 192 KB of operands for 6.3 MFLOP -- 196 MB out of L2 per 4096 x 1024 x 768
+/// pass, and the pass runs at what L2 delivers (31.6 us; a 32 x 64 tile with three wavefronts per SIMD, 295 MB, ran 42 us: the
+/// traffic, not the latency, is the limit).  A 128 x 128 tile moves 384 KB for 25 MFLOP: 98 MB.  Query chunks arrive with coalesced
+/// loads (thread = (query, piece)) and take the list scan's XOR swizzle in LDS; the shadow's blocks are already in operand order and
+/// are copied as they are.  Same words, same output layout as coarse_h16_kernel (every word of sample_out[q][32 G] written).
+constexpr uint32_t CG_TQ = 128, CG_TC = 128; // queries / centroids per workgroup
+template <int METRIC>
+__global__ __launch_bounds__(256, 2) void coarse_gemm_kernel(const uint4 * H, uint32_t nch, const uint4 * Qh, const float2 * qinfo,
+                                                             const float * xnorm, uint32_t n_rows, uint32_t nq, uint32_t * sample_out)
+{
+    __shared__ __attribute__((aligned(16))) uint4 a_s[2][CG_TQ * 8];      // [buffer][query][8 pieces, swizzled]
+    __shared__ __attribute__((aligned(16))) uint4 b_s[2][(CG_TC / 32) * 256]; // [buffer][block][step][lane]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
+    const uint32_t G = (n_rows + H_ROWS - 1) / H_ROWS, n_pad = G * H_ROWS;
+    const uint32_t q_base = blockIdx.x * CG_TQ, g_base = blockIdx.y * (CG_TC / 32);
+    const uint32_t wq = wave >> 1, wc = wave & 1; // this wavefront: query blocks 2 wq, 2 wq + 1; centroid blocks 2 wc, 2 wc + 1 of the tile
+    // load side: A -- thread = (query tid / 8 + 32 i, piece tid % 8); B -- thread = u32x4 tid of block i's chunk
+    const uint32_t lq = tid >> 3, lp = tid & 7;
+    const u32x4 * asrc[4];
+    const u32x4 * bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const uint32_t q = q_base + lq + 32 * i < nq ? q_base + lq + 32 * i : nq - 1;
+        asrc[i] = reinterpret_cast<const u32x4 *>(Qh) + (size_t)q * nch * 8 + lp;
+        const uint32_t g = g_base + i < G ? g_base + i : G - 1;
+        bsrc[i] = reinterpret_cast<const u32x4 *>(H) + (size_t)g * nch * 256 + tid;
+    }
+    u32x4 ar[2][4], br[2][4]; // two chunks in flight: chunk c + 2 is requested before chunk c is multiplied
+    auto fetch = [&](const int r, const uint32_t c) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            ar[r][i] = asrc[i][(size_t)c * 8];
+            br[r][i] = bsrc[i][(size_t)c * 256];
+        }
+    };
+    auto put = [&](const int b, const int r) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const uint32_t qq = lq + 32 * i;
+            reinterpret_cast<u32x4 *>(a_s[b])[qq * 8 + (lp ^ ((qq >> 1) & 7))] = ar[r][i];
+            reinterpret_cast<u32x4 *>(b_s[b])[i * 256 + tid] = br[r][i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                acc[t][s2][r] = 0.f;
+    const uint32_t sw = (r32 >> 1) & 7;
+    auto mul = [&](const int b) {
+        const u32x4 * const al = reinterpret_cast<const u32x4 *>(a_s[b]);
+        const u32x4 * const bl = reinterpret_cast<const u32x4 *>(b_s[b]);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            half8 af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+            {
+                af[t] = __builtin_bit_cast(half8, al[(64 * wq + 32 * t + r32) * 8 + ((2 * j + h) ^ sw)]);
+                bf[t] = __builtin_bit_cast(half8, bl[(2 * wc + t) * 256 + j * 64 + lane]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
+                    acc[t][s2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[s2], acc[t][s2], 0, 0, 0);
+        }
+    };
+    const uint32_t last = nch - 1;
+    fetch(0, 0);
+    fetch(1, 1 < last ? 1 : last);
+    put(0, 0);
+    __syncthreads();
+    // chunk c lives in LDS buffer c & 1; register set c & 1 holds chunk c + 1 at the top of iteration c (set (c + 1) & 1 ... c + 2)
+    for (uint32_t c = 0; c < nch; c += 2)
+    {
+        fetch(0, c + 2 < last ? c + 2 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(0);
+        if (c + 1 < nch)
+            put(1, 1); // chunk c + 1 (the other buffer: its last readers passed the barrier that ended chunk c - 1)
+        __syncthreads();
+        if (c + 1 >= nch)
+            break;
+        fetch(1, c + 3 < last ? c + 3 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(1);
+        if (c + 2 < nch)
+            put(0, 0); // chunk c + 2
+        __syncthreads();
+    }
+    float2 qi[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+    {
+        const uint32_t q = q_base + 64 * wq + 32 * t + r32;
+        qi[t] = qinfo[q < nq ? q : nq - 1];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+    {
+        const uint32_t g = g_base + 2 * wc + s2;
+        if (g >= G)
+            break;
+        const uint32_t row = g * H_ROWS + r32;
+        const bool ok = row < n_rows;
+        const float xn = ok && METRIC == M_L2 ? xnorm[row] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+        {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+            {
+                // accumulator register i = query (i & 3) + 8 (i >> 2) + 4 h of the block, row r32 (as in coarse_h16_kernel)
+                const int qidx = (i & 3) + 8 * (i >> 2) + 4 * (int)h;
+                const float m2 = __shfl(qi[t].x, qidx), qn = __shfl(qi[t].y, qidx);
+                const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2, acc[t][s2][i], xn), qn) : __fmul_rn(m2, acc[t][s2][i]);
+                const uint64_t key = ok ? make_key<METRIC>(v, row) : KEY_NONE;
+                const uint32_t q = q_base + 64 * wq + 32 * t + (uint32_t)qidx;
+                if (q < nq)
+                    sample_out[(size_t)q * n_pad + row] = (uint32_t)(key >> 32);
+            }
+        }
+    }
+}
+
 /// The sample of a FLAT table for ONE query tile (<= 32 queries: the few-query path), with the cut: a workgroup per sample block,
 /// its four wavefronts take every fourth 64-element chunk of the reduction (coarse_h16_kernel walks all of them in one wavefront: 12
 /// dependent steps, 15 us for a launch of 32 wavefronts), the partial tiles meet in LDS; the last workgroup to finish selects every

@@ -786,7 +786,18 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
             // dedicated kernel: 2 x 2 blocks per wavefront, every word of `sample` written
             const uint32_t items = (uint32_t)(ceil_div((size_t)G, (size_t)2) * ceil_div(ceil_div(nq, (size_t)32), (size_t)2));
             const uint32_t cgrid = (uint32_t)std::min<size_t>(ceil_div((size_t)items, (size_t)4), (size_t)device_cu_count() * 2);
-            if (scan_metric(m) == M_IP)
+            if (options().coarse_h16 != 3 && nq >= 256)
+            {
+                // round 6: 128 x 128 workgroup tiles, both operands through LDS (coarse_gemm_kernel)
+                const dim3 ggrid((unsigned)ceil_div(nq, (size_t)CG_TQ), (unsigned)ceil_div((size_t)G, (size_t)(CG_TC / 32)));
+                if (scan_metric(m) == M_IP)
+                    hipLaunchKernelGGL((coarse_gemm_kernel<M_IP>), ggrid, dim3(256), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo, t.norms,
+                                       (uint32_t)t.n, (uint32_t)nq, sample);
+                else
+                    hipLaunchKernelGGL((coarse_gemm_kernel<M_L2>), ggrid, dim3(256), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo, t.norms,
+                                       (uint32_t)t.n, (uint32_t)nq, sample);
+            }
+            else if (scan_metric(m) == M_IP)
                 hipLaunchKernelGGL((coarse_h16_kernel<M_IP>), dim3(cgrid), dim3(BLOCK), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo,
                                    t.norms, (uint32_t)t.n, (uint32_t)nq, sample);
             else
