@@ -170,6 +170,7 @@ struct Options
     double fb_cap = 0;        // queries per round of the canonical fallback (0 = by memory; small values: many rounds)
     double h16_nocut = 0;     // shadow pass: no sample cut, every probed row becomes a candidate (tests)
     double h16_ncb = 0;       // shadow pass: column blocks (32 queries each) per tile, 0 = planned
+    double rerank_fused = 1;  // shadow list scan: the second chance runs inside the re-rank launch, by the block of the query that failed (0: a launch of its own)
     double rerank_second = 1; // queries whose first certificate fails get their whole candidate buffer re-ranked before the canonical scan
     double h16_segs = 1;      // shadow list scan: lists cut into row segments on the device so that a launch has ~4 items per workgroup; 0: one item per (list, tile)
     double h16_rho = 1;       // fp16 shadow passes: error bound from the MEASURED rounding error of the stored rows and of each query image; 0: the worst case per element

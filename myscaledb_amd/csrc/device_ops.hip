@@ -499,7 +499,8 @@ void launch_ivf_rerank(int metric, RerankParams a, uint32_t nq, hipStream_t stre
         return;
     if (a.kc > 256 || a.k > a.kc)
         fail(MSVS_ERR_INVALID_ARGUMENT, "re-rank of %u candidates for k = %u", a.kc, a.k);
-    const size_t lds = (size_t)a.ld4 * 16 + (a.kc <= 64 ? 64 : 256) * 8;
+    const size_t lds = (size_t)a.ld4 * 16 + (a.kc <= 64 ? 64 : 256) * 8
+        + (a.fuse_second ? (2 * RA_KMAX + RA_CHUNK) * 8 + RA_CHUNK * 4 + 16 : 0); // (+ the second chance's arrays: rerank_all_query)
     if (lds > 64 * 1024)
         fail(MSVS_ERR_INVALID_ARGUMENT, "dimension %u too large for the re-rank block", a.ld4 * 4);
     ProfileScope prof("rerank", stream);
@@ -629,7 +630,7 @@ const OptionField g_option_fields[] = {
     {"cand_cap", &Options::cand_cap},       {"ivf_eps_scale", &Options::ivf_eps_scale},
                {"h16_grid", &Options::h16_grid},
     {"h16_min_pairs", &Options::h16_min_pairs}, {"h16_ncb", &Options::h16_ncb},
-    {"h16_nocut", &Options::h16_nocut},     {"fb_cap", &Options::fb_cap},           {"rerank_second", &Options::rerank_second},
+    {"h16_nocut", &Options::h16_nocut},     {"fb_cap", &Options::fb_cap},           {"rerank_second", &Options::rerank_second}, {"rerank_fused", &Options::rerank_fused},
     {"lat_path", &Options::lat_path},         {"filter_compact_below", &Options::filter_compact_below},
     {"bm25_wave", &Options::bm25_wave},     {"rerank_hint", &Options::rerank_hint}, {"coarse_band", &Options::coarse_band}, {"h16_prune", &Options::h16_prune}, {"h16_feedback", &Options::h16_feedback}, {"h16_preprune", &Options::h16_preprune}, {"lat_prune", &Options::lat_prune},     {"bm25_posting", &Options::bm25_posting}, {"bm25_sub_docs", &Options::bm25_sub_docs}, {"bm25_dbg", &Options::bm25_dbg},
     {"h16_rho", &Options::h16_rho}, {"h16_segs", &Options::h16_segs}, {"h16_stamps", &Options::h16_stamps},   {"flat_h16", &Options::flat_h16},     {"flat_segb", &Options::flat_segb}, {"flat_rot", &Options::flat_rot}, {"flat_lazy_flush", &Options::flat_lazy_flush},   {"flat_ncb", &Options::flat_ncb},

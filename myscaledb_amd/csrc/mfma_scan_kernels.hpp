@@ -934,6 +934,22 @@ static __global__ __launch_bounds__(BLOCK) void cand_select_block_kernel(const u
         bound[q] = qcnt[q] > cap ? 0 : (qthr[q] == 0xFFFFFFFFu ? KEY_NONE : (uint64_t)qthr[q] << 32);
 }
 
+/// (second chance: ivf_rerank_all_kernel below)
+constexpr uint32_t RA_KMAX = 128, RA_CHUNK = 256;
+struct RerankAllParams
+{
+    const uint64_t * partial; // [nq][cap] candidate keys (approximate word << 32 | row position)
+    const uint32_t * qcnt;    // [nq] candidates appended (may exceed cap: overflow)
+    const uint32_t * qthr;    // [nq] the cut (0xFFFFFFFF = none: every probed row is a candidate)
+    uint32_t cap;
+    const uint32_t * failq_in;
+    const uint32_t * nfail_in;
+    uint32_t * failq_out;
+    uint32_t * nfail_out; // zeroed by the caller
+    unsigned long long * stat_fail;
+    const uint64_t * ek_in; // nullable [nq]: RerankParams::ek_out of the first stage
+};
+
 struct RerankParams
 {
     const float4 * Y;      // rows, ld4 float4 each
@@ -962,7 +978,12 @@ struct RerankParams
     int band; // probe lists (out_probes) only: candidates that are certainly inside / outside the exact top-k by their approximate
               // values alone are not evaluated (see ivf_rerank_kernel)
     uint64_t * ek_out; // nullable [nq]: a query WITHOUT a certificate leaves the k-th exact key of the candidates it evaluated here
-                       // (KEY_NONE: fewer than k) -- an upper bound of its true k-th distance for the second chance
+                       // (KEY_NONE: fewer than k) -- an upper bound of its true k-th distance for the second chance    // Round 6: the SECOND CHANCE in the same launch (result passes, 256-thread blocks): a query whose certificate fails has its whole
+    // candidate buffer re-ranked by its own block right away (rerank_all_query) instead of being queued for ivf_rerank_all_kernel --
+    // one launch less, and the second chances (a sixth of the queries on SURVEY 8d's sigma-0.3 blobs) run beside the other queries'
+    // first stage.  fuse_second != 0: `ra` is the second chance's view; what still fails goes to ra.failq_out / ra.nfail_out.
+    int fuse_second = 0;
+    RerankAllParams ra{};
 };
 
 /// |approximate value - canonical value| <= eps for every row of the table and this query (sx, sq: upper bounds of |x|, |q|).
@@ -975,6 +996,10 @@ __device__ __forceinline__ double rerank_eps(const RerankParams & a, double sx, 
                            : (c_dot + a.c_canon) * sx * sq)
         + 1e-30;
 }
+
+template <int METRIC>
+__device__ __forceinline__ bool rerank_all_query(const RerankParams & a, const RerankAllParams & b, const uint32_t q, float4 * qs,
+                                                 const bool qs_ready, unsigned char * lds, const uint64_t hint);
 
 /// One block of 16 G threads per query: G groups of 16 lanes, a group per candidate row and round.  G = 16; 32 (all
 /// candidates of a k <= 12 search in flight at once) measured SLOWER: 70 against 47 us per 4096 queries -- kept as a knob.
@@ -1188,8 +1213,12 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
         }
     }
     __syncthreads();
-    if (wave != 0 || band) // (a band that could be formed IS the certificate)
+    const bool fuse = a.fuse_second != 0 && G == 16 && !a.out_probes; // the second chance in this launch (uniform)
+    if (band || (wave != 0 && !fuse)) // (a band that could be formed IS the certificate)
         return;
+    __shared__ int s_failed;
+    if (wave == 0)
+    {
     // certificate (see the header comment): `last` = the smallest approximate key a non-candidate row can have; a
     // candidate list that is not full (and no truncated slice) holds every probed row
     uint64_t last = a.cand[(size_t)q * kc + kc - 1];
@@ -1222,13 +1251,30 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
             }
         }
     }
-    if (!ok && lane == 0)
+    if (!ok && lane == 0 && !fuse)
     {
         a.failq[atomicAdd(a.nfail, 1u)] = q;
         if (a.ek_out)
             a.ek_out[q] = s_ek;
         if (a.stat_fail)
             atomicAdd(a.stat_fail, 1ull);
+    }
+    if (fuse && lane == 0)
+        s_failed = ok ? 0 : 1;
+    }
+    if (!fuse)
+        return;
+    __syncthreads();
+    if (!s_failed)
+        return;
+    // the second chance, here and now: every row of the query's candidate buffer, certified against the cut (rerank_all_query); the
+    // query is in LDS already, the first stage's k-th exact key is the hint
+    const bool ok2 = rerank_all_query<METRIC>(a, a.ra, q, qs, true, msvs_smem + (size_t)ld4 * 16 + (size_t)64 * R * 8, s_ek);
+    if (!ok2 && tid == 0)
+    {
+        a.ra.failq_out[atomicAdd(a.ra.nfail_out, 1u)] = q;
+        if (a.ra.stat_fail)
+            atomicAdd(a.ra.stat_fail, 1ull);
     }
 }
 
@@ -1244,176 +1290,173 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
 /// cannot enter the result and its 3 KB are not read (on the sigma-0.3 blobs at nprobe 2 most of the ~250 rows of a buffer).
 /// One block of 256 threads per failed query (grid-stride over *nfail_in), 16 lanes per candidate row as in ivf_rerank_kernel.
 /// dynamic LDS: ld4 * 16 + (2 * RA_KMAX + RA_CHUNK) * 8 + RA_CHUNK * 4 + 16 bytes.
-constexpr uint32_t RA_KMAX = 128, RA_CHUNK = 256;
-struct RerankAllParams
+
+/// The second chance of ONE query by a block of 256 threads (see above).  qs: the query in LDS (loaded here unless qs_ready); lds: (2 *
+/// RA_KMAX + RA_CHUNK) * 8 + RA_CHUNK * 4 + 16 bytes of scratch; hint: the first stage's k-th exact key (KEY_NONE: none).  -> true: the
+/// query has its certificate and its results are written.  Uniform over the block (barriers inside).
+template <int METRIC>
+__device__ __forceinline__ bool rerank_all_query(const RerankParams & a, const RerankAllParams & b, const uint32_t q, float4 * qs,
+                                                 const bool qs_ready, unsigned char * lds, const uint64_t hint)
 {
-    const uint64_t * partial; // [nq][cap] candidate keys (approximate word << 32 | row position)
-    const uint32_t * qcnt;    // [nq] candidates appended (may exceed cap: overflow)
-    const uint32_t * qthr;    // [nq] the cut (0xFFFFFFFF = none: every probed row is a candidate)
-    uint32_t cap;
-    const uint32_t * failq_in;
-    const uint32_t * nfail_in;
-    uint32_t * failq_out;
-    uint32_t * nfail_out; // zeroed by the caller
-    unsigned long long * stat_fail;
-    const uint64_t * ek_in; // nullable [nq]: RerankParams::ek_out of the first stage
-};
+    uint64_t * best = reinterpret_cast<uint64_t *>(lds);          // [RA_KMAX] running exact top-k, ascending
+    uint64_t * chunk = best + RA_KMAX;                            // [RA_CHUNK] this round's exact keys
+    uint64_t * tmp = chunk + RA_CHUNK;                            // [RA_KMAX]
+    uint32_t * sel = reinterpret_cast<uint32_t *>(tmp + RA_KMAX); // [RA_CHUNK] row positions to evaluate this round
+    uint32_t * wcnt = sel + RA_CHUNK;                             // [4] of them per wavefront
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, g = tid & 15;
+    const uint32_t ld4 = a.ld4, k = a.k;
+    const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
+    const uint32_t cnt = b.qcnt[q];
+    bool ok = cnt <= b.cap; // an overflowed buffer dropped rows below the cut: nothing to certify
+    __syncthreads();        // whoever used the LDS arrays before is done with them
+    if (!ok)
+        return false;
+    // rows that cannot beat the first stage's k-th exact distance are skipped
+    const float qn0 = a.qnorm[q];
+    const bool have_hint = hint != KEY_NONE && qn0 < 1e30f && a.xmax < 1e30f;
+    double e0 = 0.0, eps0 = 0.0;
+    if (have_hint)
+    {
+        e0 = (double)key_value<METRIC>(hint);
+        eps0 = rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn0 * 1.001), q);
+    }
+    if (!qs_ready)
+        for (uint32_t c = tid; c < ld4; c += 256)
+            qs[c] = a.Q[(size_t)q * ld4 + c];
+    for (uint32_t c = tid; c < RA_KMAX; c += 256)
+        best[c] = tmp[c] = KEY_NONE;
+    __syncthreads();
+    for (uint32_t base = 0; base < cnt; base += RA_CHUNK)
+    {
+        // which of this chunk's candidates have to be evaluated: compacted, so that the 16 row groups share them evenly
+        // (most are skipped by the hint; a group per candidate slot left most groups idle round after round, and one
+        // failing query of a small batch costs the whole step its ~16 rounds)
+        {
+            bool take = base + tid < cnt;
+            uint64_t pk = 0;
+            if (take)
+            {
+                pk = b.partial[(size_t)q * b.cap + base + tid];
+                if (have_hint)
+                {
+                    const double aj = (double)key_value<METRIC>(pk & 0xFFFFFFFF00000000ull);
+                    take = METRIC == M_L2 ? !(aj - eps0 > e0) : !(aj + eps0 < e0);
+                }
+            }
+            const uint64_t m = __ballot(take);
+            if (lane == 0)
+                wcnt[wave] = (uint32_t)__popcll(m);
+            chunk[tid] = KEY_NONE;
+            __syncthreads();
+            uint32_t off = 0;
+            for (uint32_t w2 = 0; w2 < wave; w2++)
+                off += wcnt[w2];
+            if (take)
+                sel[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)pk;
+            __syncthreads();
+        }
+        const uint32_t ntake = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        for (uint32_t c = grp; c < ntake; c += 16)
+        {
+            const uint32_t pos = sel[c];
+            const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
+            const float4 * qrow = qs + g;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t j = 0;
+            for (; j + 8 <= jfull; j += 8) // 8 row pieces in flight per lane (the arithmetic stays in column order)
+            {
+                float4 y[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    y[u] = yrow[(j + u) * 16];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    canonical_update<METRIC>(acc, qrow[(j + u) * 16], y[u]);
+            }
+            for (; j + 4 <= jfull; j += 4)
+            {
+                const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16], y3 = yrow[(j + 3) * 16];
+                canonical_update<METRIC>(acc, qrow[j * 16], y0);
+                canonical_update<METRIC>(acc, qrow[(j + 1) * 16], y1);
+                canonical_update<METRIC>(acc, qrow[(j + 2) * 16], y2);
+                canonical_update<METRIC>(acc, qrow[(j + 3) * 16], y3);
+            }
+            for (; j < jfull; j++)
+                canonical_update<METRIC>(acc, qrow[j * 16], yrow[j * 16]);
+            if (g < jtail)
+                canonical_update<METRIC>(acc, qrow[jfull * 16], yrow[jfull * 16]);
+            float s = __fadd_rn(__fadd_rn(acc.x, acc.y), __fadd_rn(acc.z, acc.w));
+            s = row16_tree_sum(s);
+            if (g == 0)
+                chunk[c] = make_key<METRIC>(s, a.ids ? a.ids[pos] : pos);
+        }
+        __syncthreads();
+        // the k best of (running k, this chunk): every key ranks itself among the RA_KMAX + RA_CHUNK slots
+        for (uint32_t i = tid; i < RA_KMAX + RA_CHUNK; i += 256)
+        {
+            const uint64_t mine = best[i]; // best and chunk are contiguous
+            if (mine == KEY_NONE)
+                continue;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < RA_KMAX + RA_CHUNK; j++)
+                rank += best[j] < mine || (best[j] == mine && j < i) ? 1u : 0u;
+            if (rank < RA_KMAX)
+                tmp[rank] = mine;
+        }
+        __syncthreads();
+        for (uint32_t c = tid; c < RA_KMAX; c += 256) // ranks nobody took stay KEY_NONE
+        {
+            best[c] = tmp[c];
+            tmp[c] = KEY_NONE;
+        }
+        __syncthreads();
+    }
+    // certificate against the cut
+    if (tid == 0)
+    {
+        const uint32_t cutw = b.qthr[q];
+        bool good = true;
+        if (cutw != 0xFFFFFFFFu)
+        {
+            const uint64_t ek = best[k - 1];
+            const float qn = a.qnorm[q];
+            if (ek == KEY_NONE || !(qn < 1e30f) || !(a.xmax < 1e30f))
+                good = false;
+            else
+            {
+                const double al = (double)key_value<METRIC>((uint64_t)cutw << 32), e = (double)key_value<METRIC>(ek);
+                const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
+                const double eps = rerank_eps<METRIC>(a, sx, sq, q);
+                good = METRIC == M_L2 ? (al - eps > e) : (al + eps < e);
+            }
+        }
+        *reinterpret_cast<volatile uint32_t *>(tmp) = good ? 1u : 0u;
+    }
+    __syncthreads();
+    ok = *reinterpret_cast<volatile uint32_t *>(tmp) != 0;
+    if (ok)
+        for (uint32_t r = tid; r < k; r += 256)
+        {
+            const uint64_t mine = best[r];
+            const size_t o = (size_t)q * k + r;
+            a.out_ids[o] = mine == KEY_NONE ? -1 : (int64_t)(uint32_t)mine;
+            const float v = key_value<METRIC>(mine);
+            a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
+        }
+    return ok;
+}
 
 template <int METRIC>
 __global__ __launch_bounds__(256) void ivf_rerank_all_kernel(const RerankParams a, const RerankAllParams b)
 {
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
-    uint64_t * best = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16); // [RA_KMAX] running exact top-k, ascending
-    uint64_t * chunk = best + RA_KMAX;                                              // [RA_CHUNK] this round's exact keys
-    uint64_t * tmp = chunk + RA_CHUNK;                                              // [RA_KMAX]
-    uint32_t * sel = reinterpret_cast<uint32_t *>(tmp + RA_KMAX);                   // [RA_CHUNK] row positions to evaluate this round
-    uint32_t * wcnt = sel + RA_CHUNK;                                               // [4] of them per wavefront
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, g = tid & 15;
-    const uint32_t ld4 = a.ld4, k = a.k;
-    const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
+    unsigned char * lds = msvs_smem + (size_t)a.ld4 * 16;
     const uint32_t nf = *b.nfail_in;
     for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x)
     {
         const uint32_t q = b.failq_in[f];
-        const uint32_t cnt = b.qcnt[q];
-        bool ok = cnt <= b.cap; // an overflowed buffer dropped rows below the cut: nothing to certify
-        __syncthreads();        // the previous query is done with the LDS arrays
-        if (ok)
-        {
-            // rows that cannot beat the first stage's k-th exact distance are skipped
-            const uint64_t hint = b.ek_in ? b.ek_in[q] : KEY_NONE;
-            const float qn0 = a.qnorm[q];
-            const bool have_hint = hint != KEY_NONE && qn0 < 1e30f && a.xmax < 1e30f;
-            double e0 = 0.0, eps0 = 0.0;
-            if (have_hint)
-            {
-                e0 = (double)key_value<METRIC>(hint);
-                eps0 = rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn0 * 1.001), q);
-            }
-            for (uint32_t c = tid; c < ld4; c += 256)
-                qs[c] = a.Q[(size_t)q * ld4 + c];
-            for (uint32_t c = tid; c < RA_KMAX; c += 256)
-                best[c] = tmp[c] = KEY_NONE;
-            __syncthreads();
-            for (uint32_t base = 0; base < cnt; base += RA_CHUNK)
-            {
-                // which of this chunk's candidates have to be evaluated: compacted, so that the 16 row groups share them evenly
-                // (most are skipped by the hint; a group per candidate slot left most groups idle round after round, and one
-                // failing query of a small batch costs the whole step its ~16 rounds)
-                {
-                    bool take = base + tid < cnt;
-                    uint64_t pk = 0;
-                    if (take)
-                    {
-                        pk = b.partial[(size_t)q * b.cap + base + tid];
-                        if (have_hint)
-                        {
-                            const double aj = (double)key_value<METRIC>(pk & 0xFFFFFFFF00000000ull);
-                            take = METRIC == M_L2 ? !(aj - eps0 > e0) : !(aj + eps0 < e0);
-                        }
-                    }
-                    const uint64_t m = __ballot(take);
-                    if (lane == 0)
-                        wcnt[wave] = (uint32_t)__popcll(m);
-                    chunk[tid] = KEY_NONE;
-                    __syncthreads();
-                    uint32_t off = 0;
-                    for (uint32_t w2 = 0; w2 < wave; w2++)
-                        off += wcnt[w2];
-                    if (take)
-                        sel[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)pk;
-                    __syncthreads();
-                }
-                const uint32_t ntake = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-                for (uint32_t c = grp; c < ntake; c += 16)
-                {
-                    const uint32_t pos = sel[c];
-                    const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
-                    const float4 * qrow = qs + g;
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    uint32_t j = 0;
-                    for (; j + 8 <= jfull; j += 8) // 8 row pieces in flight per lane (the arithmetic stays in column order)
-                    {
-                        float4 y[8];
-#pragma unroll
-                        for (int u = 0; u < 8; u++)
-                            y[u] = yrow[(j + u) * 16];
-#pragma unroll
-                        for (int u = 0; u < 8; u++)
-                            canonical_update<METRIC>(acc, qrow[(j + u) * 16], y[u]);
-                    }
-                    for (; j + 4 <= jfull; j += 4)
-                    {
-                        const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16], y3 = yrow[(j + 3) * 16];
-                        canonical_update<METRIC>(acc, qrow[j * 16], y0);
-                        canonical_update<METRIC>(acc, qrow[(j + 1) * 16], y1);
-                        canonical_update<METRIC>(acc, qrow[(j + 2) * 16], y2);
-                        canonical_update<METRIC>(acc, qrow[(j + 3) * 16], y3);
-                    }
-                    for (; j < jfull; j++)
-                        canonical_update<METRIC>(acc, qrow[j * 16], yrow[j * 16]);
-                    if (g < jtail)
-                        canonical_update<METRIC>(acc, qrow[jfull * 16], yrow[jfull * 16]);
-                    float s = __fadd_rn(__fadd_rn(acc.x, acc.y), __fadd_rn(acc.z, acc.w));
-                    s = row16_tree_sum(s);
-                    if (g == 0)
-                        chunk[c] = make_key<METRIC>(s, a.ids ? a.ids[pos] : pos);
-                }
-                __syncthreads();
-                // the k best of (running k, this chunk): every key ranks itself among the RA_KMAX + RA_CHUNK slots
-                for (uint32_t i = tid; i < RA_KMAX + RA_CHUNK; i += 256)
-                {
-                    const uint64_t mine = best[i]; // best and chunk are contiguous
-                    if (mine == KEY_NONE)
-                        continue;
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < RA_KMAX + RA_CHUNK; j++)
-                        rank += best[j] < mine || (best[j] == mine && j < i) ? 1u : 0u;
-                    if (rank < RA_KMAX)
-                        tmp[rank] = mine;
-                }
-                __syncthreads();
-                for (uint32_t c = tid; c < RA_KMAX; c += 256) // ranks nobody took stay KEY_NONE
-                {
-                    best[c] = tmp[c];
-                    tmp[c] = KEY_NONE;
-                }
-                __syncthreads();
-            }
-            // certificate against the cut
-            if (tid == 0)
-            {
-                const uint32_t cutw = b.qthr[q];
-                bool good = true;
-                if (cutw != 0xFFFFFFFFu)
-                {
-                    const uint64_t ek = best[k - 1];
-                    const float qn = a.qnorm[q];
-                    if (ek == KEY_NONE || !(qn < 1e30f) || !(a.xmax < 1e30f))
-                        good = false;
-                    else
-                    {
-                        const double al = (double)key_value<METRIC>((uint64_t)cutw << 32), e = (double)key_value<METRIC>(ek);
-                        const double sx = sqrt((double)a.xmax * 1.001), sq = sqrt((double)qn * 1.001);
-                        const double eps = rerank_eps<METRIC>(a, sx, sq, q);
-                        good = METRIC == M_L2 ? (al - eps > e) : (al + eps < e);
-                    }
-                }
-                *reinterpret_cast<volatile uint32_t *>(tmp) = good ? 1u : 0u;
-            }
-            __syncthreads();
-            ok = *reinterpret_cast<volatile uint32_t *>(tmp) != 0;
-            if (ok)
-                for (uint32_t r = tid; r < k; r += 256)
-                {
-                    const uint64_t mine = best[r];
-                    const size_t o = (size_t)q * k + r;
-                    a.out_ids[o] = mine == KEY_NONE ? -1 : (int64_t)(uint32_t)mine;
-                    const float v = key_value<METRIC>(mine);
-                    a.out_dis[o] = a.cosine ? __fsub_rn(1.0f, v) : v;
-                }
-        }
-        if (!ok && tid == 0)
+        const bool ok = rerank_all_query<METRIC>(a, b, q, qs, false, lds, b.ek_in ? b.ek_in[q] : KEY_NONE);
+        if (!ok && threadIdx.x == 0)
         {
             b.failq_out[atomicAdd(b.nfail_out, 1u)] = q;
             if (b.stat_fail)

@@ -1374,23 +1374,15 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     rp.ek_out = ek_hint;
     rp.stat_fail = second ? nullptr : prefilter_fail_counter(); // the statistic counts queries that reach the canonical scan
     rp.stat_skip = options().rerank_stats != 0 ? prefilter_fail_counter() + 2 : nullptr;
-    launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
-    g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
-    // a small batch through msvs_index_search (search_entry.hip: the pinned form): the host learns how many queries are without a
-    // certificate and enqueues the second chance and the fallback rounds -- three launches that normally find nothing to do, ~14 of
-    // the batch's ~138 us -- only when somebody is; the results are in pinned memory at its return either way
-    HostSignal & hs = host_signal();
-    const bool signalled = hs.armed;
-    if (signalled && host_signal_round(hs, nfail, stream))
-        return;
-    // second chance of the queries without a certificate: every row of their candidate buffers, certified against the cut
+    // the second chance inside the re-rank launch (256-thread blocks: every shape but the rerank_groups = 32 experiment)
+    const bool fused = second && options().rerank_fused != 0 && (pl.kc > 64 || options().rerank_groups != 32);
     uint32_t * failq2 = failq;
     uint32_t * nfail_final = nfail;
+    RerankAllParams ra{};
     if (second)
     {
         failq2 = scr.take<uint32_t>(nq);
         nfail_final = nfail2;
-        RerankAllParams ra{};
         ra.partial = partial;
         ra.qcnt = qstate + nq;
         ra.qthr = qstate;
@@ -1401,8 +1393,25 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
         ra.nfail_out = nfail2;
         ra.stat_fail = prefilter_fail_counter();
         ra.ek_in = ek_hint;
-        launch_ivf_rerank_all(scan_metric(m), rp, ra, (uint32_t)nq, stream);
+        if (fused)
+        {
+            rp.fuse_second = 1;
+            rp.ra = ra;
+        }
     }
+    launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
+    rp.fuse_second = 0;
+    g_prefilter_queries.fetch_add(nq, std::memory_order_relaxed);
+    // a small batch through msvs_index_search (search_entry.hip: the pinned form): the host learns how many queries are without a
+    // certificate and enqueues the second chance and the fallback rounds -- three launches that normally find nothing to do, ~14 of
+    // the batch's ~138 us -- only when somebody is; the results are in pinned memory at its return either way
+    HostSignal & hs = host_signal();
+    const bool signalled = hs.armed;
+    if (signalled && host_signal_round(hs, fused ? nfail2 : nfail, stream))
+        return;
+    // second chance of the queries without a certificate: every row of their candidate buffers, certified against the cut
+    if (second && !fused)
+        launch_ivf_rerank_all(scan_metric(m), rp, ra, (uint32_t)nq, stream);
     // queries without a certificate: canonical scan, one query per block (normally zero of them)
     const size_t fb_cap = fallback_cap(nq, nprobe, pl.seg_max1, k);
     uint64_t * partial1 = scr.take<uint64_t>(fb_cap * nprobe * (size_t)pl.seg_max1 * k);
