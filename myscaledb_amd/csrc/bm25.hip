@@ -505,7 +505,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     int64_t * d_bounds_hi = scr.take<int64_t>(nf1 * (n_blocks + 1));
     uint64_t * partial = scr.take<uint64_t>(nq * (size_t)n_chunks * k);
     memcpy(blob_pinned, blob, blob_bytes);
-    MSVS_HIP(hipMemcpyAsync(d_blob, blob_pinned, blob_bytes, hipMemcpyHostToDevice, stream));
+    fetch_from_pinned(d_blob, blob_pinned, blob_bytes, stream); // (a copy kernel: no barrier packets around it)
     MSVS_HIP(hipEventRecord(ring.ev[slot], stream)); // the slot is free again once the copy has run
     a.post_off = ps.post_off.p;
     a.doc_ids = ps.doc_ids.p;

@@ -214,6 +214,8 @@ struct Options
     double bm25_select2 = 1;  // BM25 top-k of the candidates by selection (bm25_select2_kernel; 0: rank every candidate against every other)
     double bm25_skip = 1;     // BM25 posting sets carry a skip table of their frequent terms (read at msvs_postings_create)
     double bm25_bounds8 = 1;  // BM25 sub-range bounds by an 8-ary search (0: binary)
+    double pinned_fetch = 1;     // small host -> device hand-overs out of pinned memory by a copy kernel instead of hipMemcpyAsync (device_ops.hpp: fetch_from_pinned)
+    double pinned_fetch_max = 1048576; // ... up to this many bytes
     double route_self_rccl = 0; // routed sharded search over an RCCL communicator: a rank's OWN piece also travels through ncclSend / ncclRecv (to itself, grouped)
                                 // instead of a device copy -- lets one rank on a 1-GPU box execute the point-to-point group path (tests)
 };

@@ -88,6 +88,29 @@ size_t release_thread_arenas()
     return freed;
 }
 
+typedef uint32_t fetch_u32x4 __attribute__((ext_vector_type(4)));
+static __global__ void fetch_pinned_kernel(fetch_u32x4 * dst, const fetch_u32x4 * src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = __builtin_nontemporal_load(&src[i]);
+}
+
+void fetch_from_pinned(void * d_dst, const void * h_pinned_src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0)
+        return;
+    const size_t n16 = ceil_div(bytes, (size_t)16);
+    if (options().pinned_fetch == 0 || bytes > (size_t)options().pinned_fetch_max || ((uintptr_t)d_dst & 15) || ((uintptr_t)h_pinned_src & 15))
+    {
+        MSVS_HIP(hipMemcpyAsync(d_dst, h_pinned_src, bytes, hipMemcpyHostToDevice, stream));
+        return;
+    }
+    const unsigned grid = (unsigned)std::min<size_t>(64, ceil_div(n16, (size_t)256));
+    hipLaunchKernelGGL(fetch_pinned_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<fetch_u32x4 *>(d_dst),
+                       reinterpret_cast<const fetch_u32x4 *>(h_pinned_src), n16);
+    MSVS_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ profiling
 
 namespace
@@ -637,7 +660,7 @@ const OptionField g_option_fields[] = {
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},
     {"flat_few", &Options::flat_few},
     {"bm25_rec", &Options::bm25_rec},       {"bm25_slots", &Options::bm25_slots},
-    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8}, {"bm25_lean", &Options::bm25_lean}, {"bm25_skip", &Options::bm25_skip}, {"bm25_select2", &Options::bm25_select2}, {"bm25_items_per_wave", &Options::bm25_items_per_wave}, {"flat_host_signal", &Options::flat_host_signal}, {"flat_sample_few", &Options::flat_sample_few}, {"plan_fused", &Options::plan_fused}, {"coarse_dense", &Options::coarse_dense}, {"host_signal_batch", &Options::host_signal_batch}, {"combine_spin", &Options::combine_spin}, {"host_pinned", &Options::host_pinned}, {"coarse_few", &Options::coarse_few},
+    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8}, {"bm25_lean", &Options::bm25_lean}, {"bm25_skip", &Options::bm25_skip}, {"bm25_select2", &Options::bm25_select2}, {"bm25_items_per_wave", &Options::bm25_items_per_wave}, {"flat_host_signal", &Options::flat_host_signal}, {"flat_sample_few", &Options::flat_sample_few}, {"plan_fused", &Options::plan_fused}, {"coarse_dense", &Options::coarse_dense}, {"host_signal_batch", &Options::host_signal_batch}, {"combine_spin", &Options::combine_spin}, {"host_pinned", &Options::host_pinned}, {"coarse_few", &Options::coarse_few}, {"pinned_fetch", &Options::pinned_fetch}, {"pinned_fetch_max", &Options::pinned_fetch_max},
     {"route_self_rccl", &Options::route_self_rccl},
 };
 Options g_options;

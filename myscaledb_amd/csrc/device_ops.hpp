@@ -47,6 +47,14 @@ Scratch & shard_for(hipStream_t stream);
 Scratch & route_for(hipStream_t stream); // the routed sharded search's exchange buffers (shard.hip)
 /// ... and one for the compacted view of a filtered search and small per-filter counters.
 Scratch & view_for(hipStream_t stream);
+/// Host -> device hand-over of a SMALL block that already sits in pinned host memory (query batches of the host-pointer calls, a BM25
+/// batch's tables): a copy KERNEL that streams it over the link (nontemporal 16-byte loads) instead of hipMemcpyAsync.  The runtime's
+/// copy is a blit surrounded by barrier packets: ~10 us of idle device before and after it in the kernel trace
+/// (profiles/r05_bm25_64_kernel_trace_timeline.txt: 12.2 + 10.4 us around a 3 us copy); a kernel follows the previous kernel with no gap.
+/// bytes is rounded up to 16: both buffers must be 16-byte aligned and hold the rounded size.  Larger blocks (option pinned_fetch_max,
+/// default 1 MB) and option pinned_fetch = 0 take hipMemcpyAsync.
+void fetch_from_pinned(void * d_dst, const void * h_pinned_src, size_t bytes, hipStream_t stream);
+
 /// Free every arena of the calling host thread (after a device synchronisation); returns the bytes released.
 size_t release_thread_arenas();
 

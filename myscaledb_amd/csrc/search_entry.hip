@@ -478,7 +478,7 @@ int index_search_host_call(const msvs_index_t * ix, const float * queries, size_
             memcpy(c.batch_pinned, queries, nq * ix->dim * 4);
             int64_t * h_ids = reinterpret_cast<int64_t *>(c.batch_pinned + o_ids);
             float * h_dis = reinterpret_cast<float *>(c.batch_pinned + o_dis);
-            MSVS_HIP(hipMemcpyAsync(dq.p, c.batch_pinned, nq * ix->dim * 4, hipMemcpyHostToDevice, stream));
+            fetch_from_pinned(dq.p, c.batch_pinned, nq * ix->dim * 4, stream); // (a copy kernel: no barrier packets around it)
             // the shadow list scan ends with a completion word instead of its normally-empty fallback launches (HostSignal)
             HostSignal & hs = host_signal();
             uint32_t * flag = reinterpret_cast<uint32_t *>(c.batch_pinned + o_flag);
