@@ -83,16 +83,32 @@ struct PinnedRing
 {
     void * buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t cap[4] = {0, 0, 0, 0};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // a slot is free again when the device has written want[slot] to done[slot] (pinned): the first launch behind the copy does it
+    // (Bm25Params::slot_done: the first scorer launch) -- round 5 recorded an event per batch: a barrier packet, ~10 us of idle device
+    uint32_t * done = nullptr;
+    uint32_t want[4] = {0, 0, 0, 0};
+    uint32_t seq = 0;
     int next = 0;
-    void * take(size_t bytes, int & slot)
+    void * take(size_t bytes, int & slot, hipStream_t stream)
     {
         slot = next;
         next = (next + 1) & 3;
-        if (ev[slot])
-            MSVS_HIP(hipEventSynchronize(ev[slot]));
-        else
-            MSVS_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        if (!done)
+        {
+            MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&done), 64, hipHostMallocCoherent));
+            for (int i = 0; i < 4; i++)
+                done[i] = 0;
+        }
+        if (want[slot])
+        {
+            for (uint64_t spins = 1; __atomic_load_n(&done[slot], __ATOMIC_ACQUIRE) != want[slot]; spins++)
+            {
+                __builtin_ia32_pause();
+                if ((spins & 0xfff) == 0 && hipStreamQuery(stream) != hipErrorNotReady)
+                    break; // the stream ran dry (or failed: the next call reports it): nothing can still read the slot
+            }
+            want[slot] = 0;
+        }
         if (cap[slot] < bytes)
         {
             if (buf[slot])
@@ -103,6 +119,13 @@ struct PinnedRing
             cap[slot] = bytes + bytes / 2 + 4096;
         }
         return buf[slot];
+    }
+    /// The sequence number the launch behind this slot's copy must write to done[slot].
+    uint32_t arm(int slot)
+    {
+        seq = seq + 1 ? seq + 1 : 1;
+        want[slot] = seq;
+        return seq;
     }
 };
 PinnedRing & pinned_ring(hipStream_t stream)
@@ -431,7 +454,7 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     static thread_local std::vector<unsigned char> blob_heap;
     blob_heap.resize(blob_bytes);
     unsigned char * const blob = blob_heap.data();
-    unsigned char * const blob_pinned = static_cast<unsigned char *>(ring.take(blob_bytes, slot));
+    unsigned char * const blob_pinned = static_cast<unsigned char *>(ring.take(blob_bytes, slot, stream));
     uint32_t * h_qoff = reinterpret_cast<uint32_t *>(blob + o_qoff);
     uint32_t * h_terms = reinterpret_cast<uint32_t *>(blob + o_terms);
     float * weight = reinterpret_cast<float *>(blob + o_w);
@@ -505,8 +528,13 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
     int64_t * d_bounds_hi = scr.take<int64_t>(nf1 * (n_blocks + 1));
     uint64_t * partial = scr.take<uint64_t>(nq * (size_t)n_chunks * k);
     memcpy(blob_pinned, blob, blob_bytes);
-    fetch_from_pinned(d_blob, blob_pinned, blob_bytes, stream); // (a copy kernel: no barrier packets around it)
-    MSVS_HIP(hipEventRecord(ring.ev[slot], stream)); // the slot is free again once the copy has run
+    // the tables go to the device with the bounds launch (bm25_bounds8_kernel) when there is one, else with a copy kernel of their own;
+    // the first scorer launch behind them tells the host that the pinned slot is free again (Bm25Params::slot_done)
+    const bool tables_ride = n_flat != 0 && options().bm25_bounds8 != 0 && options().bm25_tables_ride != 0;
+    if (!tables_ride)
+        fetch_from_pinned(d_blob, blob_pinned, blob_bytes, stream);
+    a.slot_done = ring.done + slot;
+    a.slot_seq = ring.arm(slot);
     a.post_off = ps.post_off.p;
     a.doc_ids = ps.doc_ids.p;
     a.tfs = ps.tfs.p;
@@ -624,12 +652,17 @@ void bm25_chunk_device(const msvs_postings & ps, size_t nq, const uint32_t * qof
         if ((uint32_t)options().bm25_dbg & 32u) // experiment: does the first launch of a batch wait for the blob copy?
             hipLaunchKernelGGL(bm25_nop_kernel, dim3(1), dim3(64), 0, stream);
         const dim3 bgrid((unsigned)ceil_div(n_flat * (size_t)(n_blocks + 1), (size_t)256));
+        Bm25Params ab = a;
+        if (tables_ride) // (the launch that copies the tables reads its own input, the flat terms, from the pinned slot)
+            ab.qterms = reinterpret_cast<const uint32_t *>(blob_pinned + o_terms);
         if (options().bm25_bounds8 != 0)
             hipLaunchKernelGGL(bm25_bounds8_kernel,
-                               dim3((unsigned)ceil_div((size_t)n_blocks + 1, (size_t)256), (unsigned)std::min<size_t>(n_flat, 65535)), dim3(256), 0, stream, a, d_bounds,
+                               dim3((unsigned)ceil_div((size_t)n_blocks + 1, (size_t)256), (unsigned)std::min<size_t>(n_flat, 65535)), dim3(256), 0, stream, ab, d_bounds,
                                recs ? (int64_t *)nullptr : d_bounds_hi /* only bm25p_kernel reads the shifted copy */, (uint32_t)n_flat, docs_per_block,
                                counters, fills_ride ? nq + 1 : (size_t)0, sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0,
-                               ps.skip_n ? ps.skip_row.p : (const int32_t *)nullptr, ps.skip_tab.p, ps.skip_n);
+                               ps.skip_n ? ps.skip_row.p : (const int32_t *)nullptr, ps.skip_tab.p, ps.skip_n,
+                               tables_ride ? reinterpret_cast<bm25_u32x4 *>(d_blob) : (bm25_u32x4 *)nullptr,
+                               reinterpret_cast<const bm25_u32x4 *>(blob_pinned), tables_ride ? blob_bytes / 16 : (size_t)0);
         else
             hipLaunchKernelGGL(bm25_bounds_kernel, bgrid, dim3(256), 0, stream, a, d_bounds, d_bounds_hi, (uint32_t)n_flat, docs_per_block,
                                counters, fills_ride ? nq + 1 : (size_t)0, sample, fills_ride && n_items_s ? nq * (size_t)n_sb * cut_m : (size_t)0);

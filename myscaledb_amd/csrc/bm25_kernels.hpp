@@ -81,7 +81,17 @@ struct Bm25Params
     uint64_t * cand;             // [nq][BM25_CAND_CAP], the first cand_cap slots in use
     uint32_t cand_cap;
     uint32_t * ccnt;             // [nq], zeroed by the caller
+    // the first scorer launch behind the batch's tables tells the host that their pinned slot is free again (a word in pinned memory;
+    // nullable): the tables are copied by the bounds launch in front of it (bm25_bounds8_kernel), complete when this launch starts
+    uint32_t * slot_done = nullptr;
+    uint32_t slot_seq = 0;
 };
+
+__device__ __forceinline__ void bm25_slot_signal(const Bm25Params & p)
+{
+    if (p.slot_done && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p.slot_done, p.slot_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 /// The fills of the batch ride along (nullable): `zero` = the candidate counters + fail counter, `ones` = the sample's
 /// per-query lists (KEY_NONE = all bits set) -- two launches less in front of the sample pass.
@@ -143,6 +153,7 @@ enum
 template <int MODE, int R>
 __global__ __launch_bounds__(BLOCK) void bm25_score_kernel(const Bm25Params a)
 {
+    bm25_slot_signal(a);
     __shared__ float score[BM25_DOCS];
     __shared__ uint16_t mask[BM25_DOCS];
     __shared__ uint16_t touched[BM25_DOCS];
@@ -481,6 +492,7 @@ struct Bm25WParams
 template <int MODE, int R, int NF>
 __global__ __launch_bounds__(64 * BW_WAVES) void bm25w_kernel(const Bm25WParams a)
 {
+    bm25_slot_signal(a.p);
     __shared__ float score[BW_WAVES][BW_DOCS];
     __shared__ uint16_t mask[BW_WAVES][BW_DOCS];
     __shared__ uint16_t touched[BW_WAVES][BW_DOCS];

@@ -43,6 +43,7 @@ __device__ __forceinline__ T bl_sel4(const T & a0, const T & a1, const T & a2, c
 template <int MODE, int R, int SLOTS>
 __global__ __launch_bounds__(64 * BP_WAVES, BL_WAVES_PER_SIMD) void bm25l_kernel(const Bm25RParams ar)
 {
+    bm25_slot_signal(ar.w.p);
     constexpr uint32_t BMW = 2 * SLOTS / 32;
     __shared__ __attribute__((aligned(16))) uint32_t bm_s[BP_WAVES][BMW]; // word pairs: seen | dup bits of 32 hash slots
     __shared__ __attribute__((aligned(16))) uint32_t bm2_s[BP_WAVES][2 * BL_SLOTS2 / 32]; // the second look's seen | dup

@@ -64,6 +64,7 @@ __device__ __forceinline__ uint64_t bp_wave_sum(uint64_t v)
 template <int MODE, int R>
 __global__ __launch_bounds__(64 * BP_WAVES, BP_BLOCKS_PER_CU) void bm25p_kernel(const Bm25WParams a)
 {
+    bm25_slot_signal(a.p);
     __shared__ uint32_t rdoc_s[BP_WAVES][BP_CAP];
     __shared__ float rsc_s[BP_WAVES][BP_CAP];
     __shared__ uint32_t bm_s[BP_WAVES][2 * BP_SLOTS / 32];   // word pairs: seen | dup bits of 32 hash slots

@@ -87,6 +87,7 @@ __device__ __forceinline__ uint32_t br_wave_sum_sat(int64_t len)
 template <int MODE, int R, int SLOTS>
 __global__ __launch_bounds__(64 * BP_WAVES, 4) void bm25r_kernel(const Bm25RParams ar)
 {
+    bm25_slot_signal(ar.w.p);
     constexpr uint32_t BMW = 2 * SLOTS / 32;
     __shared__ __attribute__((aligned(16))) uint32_t bm_s[BP_WAVES][BMW]; // word pairs: seen | dup bits of 32 hash slots
     __shared__ uint32_t fdoc_s[BP_WAVES][BP_CAP];     // the flagged records of a window, in flat (= term) order: document ...
@@ -799,10 +800,20 @@ static __global__ void bm25_skip_build_kernel(const int64_t * post_off, const ui
 
 /// bm25_bounds_kernel with an 8-ary search: the chain of dependent loads is what the launch costs (21 steps for a list of 2M
 /// postings); seven independent probes per step cut it to 7.
+typedef uint32_t bm25_u32x4 __attribute__((ext_vector_type(4)));
 static __global__ void bm25_bounds8_kernel(const Bm25Params a, int64_t * bounds, int64_t * bounds_hi, uint32_t n_flat,
                                            uint32_t docs_per_block, uint32_t * zero, size_t n_zero, uint64_t * ones, size_t n_ones,
-                                           const int32_t * skip_row, const uint32_t * skip_tab, uint32_t skip_n)
+                                           const int32_t * skip_row, const uint32_t * skip_tab, uint32_t skip_n,
+                                           bm25_u32x4 * tables_dst = nullptr, const bm25_u32x4 * tables_pinned = nullptr, size_t tables_n16 = 0)
 {
+    // Round 6: the batch's tables ride along too -- this launch copies them from their pinned slot to the device (every thread a
+    // grid-stride share; the scorers behind it read the device copy) and reads the ONE table it needs itself, the flat terms, straight
+    // from pinned memory (a.qterms points there for this launch).  A copy of its own in front cost a launch and the gap behind it.
+    {
+        const size_t gsz = (size_t)gridDim.x * gridDim.y * blockDim.x;
+        for (size_t i = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < tables_n16; i += gsz)
+            tables_dst[i] = __builtin_nontemporal_load(&tables_pinned[i]);
+    }
     // grid: x over the boundaries of a term, y over the flat terms (the term and its list ends are uniform: scalar loads, and no
     // 64-bit division per thread -- the flat index form spent more on `i / nb1` than on its search)
     {

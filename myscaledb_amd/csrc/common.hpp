@@ -213,6 +213,8 @@ struct Options
     double bm25_items_per_wave = 0; // BM25 emit pass: equal-postings items per resident wavefront (0 = 2)
     double bm25_select2 = 1;  // BM25 top-k of the candidates by selection (bm25_select2_kernel; 0: rank every candidate against every other)
     double bm25_skip = 1;     // BM25 posting sets carry a skip table of their frequent terms (read at msvs_postings_create)
+    double bm25_tables_ride = 0; // BM25: the batch's tables are copied to the device by the bounds launch instead of a copy kernel of their own in front
+                                 // of it (measured: 1.97 -> 1.96-1.99 us/query at 64, 0.66 -> 0.68 at 1024 -- the bounds launch reads its terms over the link: off)
     double bm25_bounds8 = 1;  // BM25 sub-range bounds by an 8-ary search (0: binary)
     double pinned_fetch = 1;     // small host -> device hand-overs out of pinned memory by a copy kernel instead of hipMemcpyAsync (device_ops.hpp: fetch_from_pinned)
     double pinned_fetch_max = 1048576; // ... up to this many bytes

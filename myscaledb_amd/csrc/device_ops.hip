@@ -660,7 +660,7 @@ const OptionField g_option_fields[] = {
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},
     {"flat_few", &Options::flat_few},
     {"bm25_rec", &Options::bm25_rec},       {"bm25_slots", &Options::bm25_slots},
-    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8}, {"bm25_lean", &Options::bm25_lean}, {"bm25_skip", &Options::bm25_skip}, {"bm25_select2", &Options::bm25_select2}, {"bm25_items_per_wave", &Options::bm25_items_per_wave}, {"flat_host_signal", &Options::flat_host_signal}, {"flat_sample_few", &Options::flat_sample_few}, {"plan_fused", &Options::plan_fused}, {"coarse_dense", &Options::coarse_dense}, {"host_signal_batch", &Options::host_signal_batch}, {"combine_spin", &Options::combine_spin}, {"host_pinned", &Options::host_pinned}, {"coarse_few", &Options::coarse_few}, {"pinned_fetch", &Options::pinned_fetch}, {"pinned_fetch_max", &Options::pinned_fetch_max},
+    {"bm25_cutk", &Options::bm25_cutk},     {"bm25_bounds8", &Options::bm25_bounds8}, {"bm25_tables_ride", &Options::bm25_tables_ride}, {"bm25_lean", &Options::bm25_lean}, {"bm25_skip", &Options::bm25_skip}, {"bm25_select2", &Options::bm25_select2}, {"bm25_items_per_wave", &Options::bm25_items_per_wave}, {"flat_host_signal", &Options::flat_host_signal}, {"flat_sample_few", &Options::flat_sample_few}, {"plan_fused", &Options::plan_fused}, {"coarse_dense", &Options::coarse_dense}, {"host_signal_batch", &Options::host_signal_batch}, {"combine_spin", &Options::combine_spin}, {"host_pinned", &Options::host_pinned}, {"coarse_few", &Options::coarse_few}, {"pinned_fetch", &Options::pinned_fetch}, {"pinned_fetch_max", &Options::pinned_fetch_max},
     {"route_self_rccl", &Options::route_self_rccl},
 };
 Options g_options;
