@@ -562,6 +562,19 @@ __global__ void route_init_kernel(uint32_t * row, uint32_t W, uint32_t * cursor,
         row[W + t] = h.w[t];
 }
 
+/// The gathered count matrix to the host: a kernel that writes pinned memory and then a completion word (system-scope release), instead
+/// of hipMemcpyAsync + an event -- two barrier packets, ~10 us of idle device each (what the BM25 batch's hand-over measured); the host
+/// spins on the word.  n <= 32 * 40 words: one block.
+__global__ void route_matrix_out_kernel(const uint32_t * cmat, uint32_t * h_c, uint32_t n, uint32_t * h_flag, uint32_t seq)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        h_c[i] = cmat[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /// mask[q] = ranks that own a surviving probe of query q; cnt[t] += queries that go to rank t.
 __global__ void route_mask_kernel(const int32_t * probes, uint32_t nq, uint32_t np, uint32_t W, uint32_t * mask, uint32_t * cnt)
 {
@@ -801,6 +814,8 @@ struct RoutedStep
     Scratch front;
     uint32_t * cmat = nullptr; // device [W][W + ROUTE_HDR]
     uint32_t * h_c = nullptr;  // pinned, the same
+    uint32_t a_seq = 0;            // the completion word's value for the front phase in flight (h_c[W * RW])
+    hipStream_t a_stream = nullptr; // ... and the stream it was enqueued on
     hipEvent_t in_ev = nullptr, a_ev = nullptr, done_ev = nullptr;
 };
 
@@ -841,7 +856,8 @@ RoutePipe * route_pipe_of(const msvs_comm_t * comm, bool create)
         for (RoutedStep & st : p->step)
         {
             MSVS_HIP(hipMalloc(reinterpret_cast<void **>(&st.cmat), bytes));
-            MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&st.h_c), bytes, hipHostMallocDefault));
+            MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&st.h_c), bytes + 64, hipHostMallocCoherent)); // (+ the completion word)
+            memset(st.h_c, 0, bytes + 64);
             for (hipEvent_t * e : {&st.in_ev, &st.a_ev, &st.done_ev})
                 MSVS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
@@ -951,8 +967,10 @@ void routed_front(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, boo
     }
     hand_over(pp, 0, cs, xs);
     comm->all_gather(reinterpret_cast<unsigned char *>(st.cmat), RW * 4, xs);
-    MSVS_HIP(hipMemcpyAsync(st.h_c, st.cmat, W * RW * 4, hipMemcpyDeviceToHost, xs));
-    MSVS_HIP(hipEventRecord(st.a_ev, xs));
+    st.a_seq = st.a_seq + 1 ? st.a_seq + 1 : 1; // never 0
+    hipLaunchKernelGGL(route_matrix_out_kernel, dim3(1), dim3(256), 0, xs, st.cmat, st.h_c, (uint32_t)(W * RW), st.h_c + W * RW, st.a_seq);
+    MSVS_HIP(hipGetLastError());
+    st.a_stream = xs;
 }
 
 /// BACK: see the banner.  Returns after everything is enqueued; the results are complete when `cs` has run dry (st.done_ev).
@@ -963,7 +981,25 @@ void routed_back(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, hipS
     std::vector<uint32_t> h_c(W * W);
     for (int attempt = 0;; attempt++)
     {
-        MSVS_HIP(hipEventSynchronize(st.a_ev));
+        // the matrix of this step (front phase): wait for its completion word
+        for (uint64_t spins = 1; __atomic_load_n(st.h_c + W * RW, __ATOMIC_ACQUIRE) != st.a_seq; spins++)
+        {
+            __builtin_ia32_pause();
+            if ((spins & 0xfff) == 0)
+            {
+                const hipError_t e = hipStreamQuery(st.a_stream);
+                if (e == hipSuccess)
+                    break;
+                if (e != hipErrorNotReady)
+                    fail(MSVS_ERR_DEVICE, "routed search: %s", hipGetErrorString(e));
+            }
+        }
+        if (__atomic_load_n(st.h_c + W * RW, __ATOMIC_ACQUIRE) != st.a_seq)
+        {
+            MSVS_HIP(hipStreamSynchronize(st.a_stream));
+            if (__atomic_load_n(st.h_c + W * RW, __ATOMIC_ACQUIRE) != st.a_seq)
+                fail(MSVS_ERR_DEVICE, "routed search: the count matrix never arrived (launch lost)");
+        }
         // ---- the decision every rank takes alike
         int peer_status = MSVS_OK;
         size_t peer = 0;
