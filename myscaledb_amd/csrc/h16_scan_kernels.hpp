@@ -72,6 +72,7 @@ struct H16Params
     // sample launch
     uint32_t * sample_out;    // [nq * nprobe][32] ordered distance word of row r of block 0 (0xFFFFFFFF = no row)
     uint32_t * sched;         // [8] work-queue cursors of this launch (zeroed by the caller)
+    uint32_t group_appends;   // 1: tiles of <= H_GROUP_MAX_Q queries append their survivors with one atomic per (wavefront, query)
     uint32_t lazy_flush;      // 1: survivors stay in the wavefront's LDS stage from block to block and leave when it is full / at the end of the item
     uint64_t * stamps;        // nullable (option h16_stamps): [grid][H_STAMP_ITEMS][4] {item popped, tile resident, rows done, l << 32 | nvalid << 8}
                               // in wall_clock64 ticks (100 MHz), [grid][0][0] = items of the workgroup
@@ -350,6 +351,7 @@ static __global__ void h16_prep_queries_kernel(const float * Q, uint32_t nq, uin
 constexpr int H_NW = 8;      // wavefronts per workgroup of the main launch
 constexpr int H_RING = 4;    // row chunks per wavefront in registers (H_RING - 1 in flight + the one being multiplied)
 constexpr int H_STAGE = 64;  // survivor records a wavefront stages in LDS before one round of atomics
+constexpr uint32_t H_GROUP_MAX_Q = 8; // tiles of at most this many queries group their appends by query (h16_stream: flush)
 constexpr uint32_t H_NONE = 0xFFFFFFFFu;
 
 /// LDS bytes of the scan kernel for a tile of 32 * ncb queries.
@@ -389,10 +391,11 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
                                            const uint32_t * thr_s, const uint32_t * qrow_s, uint32_t * stage, const uint32_t lane,
                                            const uint32_t nch, const uint32_t hb_list /* first shadow block of the list */,
                                            const uint32_t blk0, const uint32_t stride, const uint32_t nblk,
-                                           const int64_t lbeg, const int64_t lend)
+                                           const int64_t lbeg, const int64_t lend, const uint32_t tile_queries = 0xFFFFFFFFu)
 {
     if (blk0 >= nblk)
         return;
+    const bool grouped = a.group_appends != 0 && tile_queries <= H_GROUP_MAX_Q; // (uniform: see flush)
     uint32_t blk = blk0;
     const uint32_t r32 = lane & 31, h = lane >> 5;
     // operand read offsets of this lane inside a 128-byte query row: piece (2 j + h) ^ swizzle
@@ -429,13 +432,41 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
 
     uint32_t cnt = 0; // records staged, wave-uniform (0 again after every block)
     auto flush = [&]() {
-        if (lane < cnt)
+        // Round 6: the records of a tile that holds FEW probing queries (most tiles of a small batch; many once the probe pruning has
+        // thinned the pairs) are grouped by query first -- one round of ballots per distinct query -- and every group takes ONE atomic:
+        // its leader adds the group's count (the leaders of all groups in one instruction), the members take consecutive slots.
+        // A returning atomic per record on one address serialises in L2: ~250 of them per query of a 32-query batch, from every
+        // wavefront that scans the query's one list (the per-item stamps showed 17 us of "rows" for 48 KB per wavefront; the list
+        // scan of a 16-query batch 45 -> 33 us).  Tiles of many queries keep one atomic per record: their addresses differ.
+        const bool have = lane < cnt;
+        const uint32_t q = have ? stage[2 * H_STAGE + lane] : 0u;
+        uint32_t pos = 0;
+        if (grouped)
         {
-            const uint32_t q = stage[2 * H_STAGE + lane];
-            const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
-            if (pos < a.cand_cap)
-                a.partial[(size_t)q * a.cand_cap + pos] = (uint64_t)stage[H_STAGE + lane] << 32 | stage[lane];
+            uint64_t rem = __ballot(have);
+            uint32_t leader = lane, rank = 0, count = 0;
+            while (rem)
+            {
+                const int lead = __builtin_ctzll(rem);
+                const uint32_t ql = (uint32_t)__builtin_amdgcn_readlane((int)q, lead);
+                const uint64_t m = __ballot(have && q == ql);
+                if (have && q == ql)
+                {
+                    leader = (uint32_t)lead;
+                    rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    count = (uint32_t)__popcll(m);
+                }
+                rem &= ~m;
+            }
+            uint32_t base = 0;
+            if (have && leader == lane)
+                base = atomicAdd(&a.qcnt[q], count);
+            pos = (uint32_t)__shfl((int)base, (int)leader) + rank;
         }
+        else if (have)
+            pos = atomicAdd(&a.qcnt[q], 1u);
+        if (have && pos < a.cand_cap)
+            a.partial[(size_t)q * a.cand_cap + pos] = (uint64_t)stage[H_STAGE + lane] << 32 | stage[lane];
         cnt = 0;
     };
     half8 afp[2][NCBI]; // NRB >= 2: the A fragments of the step in flight and of the next one (see `step`)
@@ -768,7 +799,7 @@ __global__ __launch_bounds__(64 * H_NW) void h16_scan_kernel(const H16Params a)
         }
         uint32_t * const stage = stage_s + wave * 3 * H_STAGE;
 #define MSVS_H16_STREAM(N)                                                                                                         \
-    h16_stream<METRIC, N>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, a.hoff[l], b_first + wave, NW, b_end, lbeg, lend)
+    h16_stream<METRIC, N>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, a.hoff[l], b_first + wave, NW, b_end, lbeg, lend, nvalid)
         if constexpr (NCB == 1)
             MSVS_H16_STREAM(1);
         else if (ncb_e == 1)
@@ -1508,10 +1539,10 @@ __global__ __launch_bounds__(64 * H_NW) void h16_flat_kernel(const H16Params a, 
     do                                                                                                                             \
     {                                                                                                                              \
         h16_stream<METRIC, N, RING, NRB>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, 0, bs + wave * NRB,       \
-                                         NW * NRB, b1, 0, (int64_t)f.n_rows);                                                      \
+                                         NW * NRB, b1, 0, (int64_t)f.n_rows, nvalid);                                              \
         if (r0)                                                                                                                    \
             h16_stream<METRIC, N, RING, NRB>(a, tile, TQ * 128, m2_s, qn_s, thr_s, qrow_s, stage, lane, nch, 0, b0 + wave * NRB,   \
-                                             NW * NRB, bs, 0, (int64_t)f.n_rows);                                                  \
+                                             NW * NRB, bs, 0, (int64_t)f.n_rows, nvalid);                                          \
     } while (0)
         if constexpr (NCB == 1)
             MSVS_H16_FLAT_STREAM(1);
