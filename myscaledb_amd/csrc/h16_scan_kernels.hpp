@@ -395,7 +395,9 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
 {
     if (blk0 >= nblk)
         return;
-    const bool grouped = a.group_appends != 0 && tile_queries <= H_GROUP_MAX_Q; // (uniform: see flush)
+    // (uniform: see flush.  Not in the two-row-block form -- exhaustive batches, tiles of 64+ queries: the extra code cost the kernel
+    // its last free registers, 54 scratch instructions around the MFMA loops, 5.9 -> 6.6 ms per 4096-query pass)
+    const bool grouped = NRB == 1 && a.group_appends != 0 && tile_queries <= H_GROUP_MAX_Q;
     uint32_t blk = blk0;
     const uint32_t r32 = lane & 31, h = lane >> 5;
     // operand read offsets of this lane inside a 128-byte query row: piece (2 j + h) ^ swizzle
