@@ -575,6 +575,15 @@ __global__ void route_matrix_out_kernel(const uint32_t * cmat, uint32_t * h_c, u
         __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__global__ void route_fill_kernel(int64_t * ids, float * dis, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        ids[i] = -1;
+        dis[i] = 0.f;
+    }
+}
+
 /// mask[q] = ranks that own a surviving probe of query q; cnt[t] += queries that go to rank t.
 __global__ void route_mask_kernel(const int32_t * probes, uint32_t nq, uint32_t np, uint32_t W, uint32_t * mask, uint32_t * cnt)
 {
@@ -1163,8 +1172,11 @@ void routed_back(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, hipS
         return;
     int64_t * m_ids = sx.take<int64_t>(W * nq * k);
     float * m_dis = sx.take<float>(W * nq * k);
-    MSVS_HIP(hipMemsetAsync(m_ids, 0xFF, W * nq * k * 8, cs)); // -1: no hit
-    MSVS_HIP(hipMemsetAsync(m_dis, 0, W * nq * k * 4, cs));
+    // -1 / 0: "no hit" in the parts a query did not visit -- one fill kernel (two hipMemsetAsync cost ~7.6 us each between kernels,
+    // tools/micro/copy_gap.hip)
+    hipLaunchKernelGGL(route_fill_kernel, dim3((unsigned)std::min<size_t>(256, ceil_div(W * nq * k, (size_t)256))), dim3(256), 0, cs, m_ids, m_dis,
+                       W * nq * k);
+    MSVS_HIP(hipGetLastError());
     if (cmax)
     {
         hipLaunchKernelGGL(route_scatter_kernel, dim3((unsigned)ceil_div(cmax * k, (size_t)256), (unsigned)W), dim3(256), 0, cs, back, home, sent_q,
