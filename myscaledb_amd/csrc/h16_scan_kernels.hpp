@@ -44,6 +44,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int H_ROWS = 32;  // rows per shadow block (one wavefront's B operand)
+
+/// LDS traffic of ONE wavefront: its ds operations execute in order, a wait + a compiler barrier is all a write -> read-by-another-lane
+/// hand-over needs (bm25p_kernels.hpp has the same helper).
+__device__ __forceinline__ void bp_wave_lds_fence_h16()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 constexpr int H_CHUNK = 64; // reduction elements per LDS stage = 4 MFMA steps = 128 B per query
 
 struct H16Params
@@ -2010,6 +2018,145 @@ static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint3
             top.offer(key[u], kc, lane);
     }
     top.store(dst, kc, lane);
+}
+
+/// Round 6 -- the coarse quantiser's selection AND band re-rank in one launch, one WAVEFRONT per query, no workgroup barrier:
+/// coarse_select_kernel (15 us per 4096 queries) + ivf_rerank_kernel in band mode (33 us: a 256-thread block per query, eight
+/// barriers around three or four canonical rows) were two launches whose cost is the latency chain of a block, not work.
+///   1. the kc <= 64 smallest of the query's approximate centroid words (coarse_select_wave, wave-private LDS), one per lane;
+///   2. ivf_rerank_kernel's band rule on them: with a_(k), a_(k+1) the k-th / (k+1)-th smallest approximate values and eps the error
+///      bound, a candidate with a + 2 eps < a_(k+1) is certainly IN (it takes the slot of its approximate rank), one with
+///      a - 2 eps > a_(k) certainly OUT, and so is every centroid that is not a candidate when the largest candidate value
+///      - 2 eps > a_(k); the band in between is evaluated canonically -- 16 lanes per row, four rows at a time, the arithmetic and
+///      order of scan_rows -- and fills the remaining slots in exact order;
+///   3. a query whose band cannot be formed (fewer than k + 1 candidates, non-finite norms, the margin test fails) leaves its
+///      candidates in cand / bound and its number on slowq: ivf_rerank_kernel serves that list (RerankParams::qmap) as before.
+/// Same probes as the two-launch form, slot by slot (test_small_batches... / the coarse parity tests compare both).
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) void coarse_tail_kernel(const uint32_t * sample, uint32_t nq, uint32_t n_pad, const RerankParams a,
+                                                            uint64_t * cand, uint64_t * bound, uint32_t * slowq, uint32_t * nslow)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
+    __shared__ uint64_t s_stage[BLOCK / WAVE][WAVE];
+    __shared__ uint64_t s_cand[BLOCK / WAVE][WAVE];
+    __shared__ uint64_t s_keys[BLOCK / WAVE][WAVE];
+    __shared__ uint32_t s_band[BLOCK / WAVE][WAVE];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * (BLOCK / WAVE) + wave;
+    if (q >= nq)
+        return;
+    const uint32_t kc = a.kc, k = a.k, ld4 = a.ld4;
+    uint64_t * const cd = s_cand[wave];
+    cd[lane] = KEY_NONE;
+    bp_wave_lds_fence_h16();
+    const uint32_t * src = sample + (size_t)q * n_pad;
+    if (n_pad <= 4 * WAVE)
+        coarse_select_wave<4>(src, n_pad, kc, cd, lane, s_hist[wave], s_stage[wave]);
+    else if (n_pad <= 8 * WAVE)
+        coarse_select_wave<8>(src, n_pad, kc, cd, lane, s_hist[wave], s_stage[wave]);
+    else if (n_pad <= 16 * WAVE)
+        coarse_select_wave<16>(src, n_pad, kc, cd, lane, s_hist[wave], s_stage[wave]);
+    else
+        coarse_select_wave<32>(src, n_pad, kc, cd, lane, s_hist[wave], s_stage[wave]);
+    bp_wave_lds_fence_h16();
+    const uint64_t mine = lane < kc ? cd[lane] : KEY_NONE;
+    uint32_t rank = 0; // of this candidate among all of them by approximate key (ties by slot)
+    for (uint32_t j = 0; j < kc; j++)
+    {
+        const uint64_t kj = cd[j];
+        rank += kj < mine || (kj == mine && j < lane) ? 1u : 0u;
+    }
+    const uint64_t m_k = __ballot(mine != KEY_NONE && rank == k - 1), m_k1 = __ballot(mine != KEY_NONE && rank == k);
+    const uint64_t key_k = m_k ? readlane64(mine, __builtin_ctzll(m_k)) : KEY_NONE;
+    const uint64_t key_k1 = m_k1 ? readlane64(mine, __builtin_ctzll(m_k1)) : KEY_NONE;
+    const float qn = a.qnorm[q];
+    bool band_ok = key_k != KEY_NONE && key_k1 != KEY_NONE && qn < 1e30f && a.xmax < 1e30f && kc > k;
+    double eps2 = 0.0, ak = 0.0, ak1 = 0.0;
+    if (band_ok)
+    {
+        eps2 = 2.0 * rerank_eps<METRIC>(a, sqrt((double)a.xmax * 1.001), sqrt((double)qn * 1.001), q);
+        ak = (double)key_value<METRIC>(key_k);
+        ak1 = (double)key_value<METRIC>(key_k1);
+        const uint64_t last = cd[kc - 1]; // the candidates' largest approximate value comes last; KEY_NONE: every centroid is a candidate
+        if (last != KEY_NONE)
+        {
+            const double al = (double)key_value<METRIC>(last);
+            band_ok = METRIC == M_L2 ? (al - eps2 > ak) : (al + eps2 < ak);
+        }
+    }
+    if (!band_ok) // (uniform over the wavefront)
+    {
+        if (lane < kc)
+            cand[(size_t)q * kc + lane] = mine;
+        if (lane == 0)
+        {
+            bound[q] = KEY_NONE;
+            slowq[atomicAdd(nslow, 1u)] = q;
+        }
+        return;
+    }
+    bool in = false, mid = false;
+    if (mine != KEY_NONE)
+    {
+        const double aj = (double)key_value<METRIC>(mine);
+        in = METRIC == M_L2 ? (aj + eps2 < ak1) : (aj - eps2 > ak1);
+        const bool out = METRIC == M_L2 ? (aj - eps2 > ak) : (aj + eps2 < ak);
+        mid = !in && !out;
+        if (in) // "in" is monotone in the approximate value: the certainly-in rows are the ranks 0 .. n_in - 1
+            a.out_probes[(size_t)q * k + rank] = (int32_t)(a.ids ? a.ids[(uint32_t)mine] : (uint32_t)mine);
+    }
+    const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+    const uint64_t mb = __ballot(mid);
+    const uint32_t nb = (uint32_t)__popcll(mb);
+    if (mid)
+        s_band[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u))] = (uint32_t)mine;
+    s_keys[wave][lane] = KEY_NONE;
+    bp_wave_lds_fence_h16();
+    // the band's rows, canonically: 16 lanes per row (scan_rows' arithmetic and order), four rows per round
+    const uint32_t grp = lane >> 4, g = lane & 15;
+    const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
+    const float4 * const qrow = a.Q + (size_t)q * ld4 + g;
+    for (uint32_t c0 = 0; c0 < nb; c0 += 4)
+    {
+        const uint32_t c = c0 + grp;
+        if (c < nb)
+        {
+            const uint32_t pos = s_band[wave][c];
+            const float4 * yrow = a.Y + (size_t)pos * ld4 + g;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t j = 0;
+            for (; j + 4 <= jfull; j += 4)
+            {
+                const float4 y0 = yrow[j * 16], y1 = yrow[(j + 1) * 16], y2 = yrow[(j + 2) * 16], y3 = yrow[(j + 3) * 16];
+                canonical_update<METRIC>(acc, qrow[j * 16], y0);
+                canonical_update<METRIC>(acc, qrow[(j + 1) * 16], y1);
+                canonical_update<METRIC>(acc, qrow[(j + 2) * 16], y2);
+                canonical_update<METRIC>(acc, qrow[(j + 3) * 16], y3);
+            }
+            for (; j < jfull; j++)
+                canonical_update<METRIC>(acc, qrow[j * 16], yrow[j * 16]);
+            if (g < jtail)
+                canonical_update<METRIC>(acc, qrow[jfull * 16], yrow[jfull * 16]);
+            float sum = __fadd_rn(__fadd_rn(acc.x, acc.y), __fadd_rn(acc.z, acc.w));
+            sum = row16_tree_sum(sum);
+            if (g == 0)
+                s_keys[wave][c] = make_key<METRIC>(sum, a.ids ? a.ids[pos] : pos);
+        }
+    }
+    bp_wave_lds_fence_h16();
+    // the band's rows fill the slots the certainly-in rows left, in exact order (ties by their slot among the candidates)
+    const uint64_t kb = lane < nb ? s_keys[wave][lane] : KEY_NONE;
+    if (kb != KEY_NONE)
+    {
+        uint32_t rb = 0;
+        for (uint32_t j = 0; j < nb; j++)
+        {
+            const uint64_t kj = s_keys[wave][j];
+            rb += kj < kb || (kj == kb && j < lane) ? 1u : 0u;
+        }
+        if (n_in + rb < k)
+            a.out_probes[(size_t)q * k + n_in + rb] = (int32_t)(uint32_t)kb;
+    }
 }
 
 }

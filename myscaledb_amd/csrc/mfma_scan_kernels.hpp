@@ -984,6 +984,9 @@ struct RerankParams
     // first stage.  fuse_second != 0: `ra` is the second chance's view; what still fails goes to ra.failq_out / ra.nfail_out.
     int fuse_second = 0;
     RerankAllParams ra{};
+    // Round 6 (probe lists): only the queries qmap[0 .. *qcount) -- those coarse_tail_kernel could not serve with a band (block b = entry b)
+    const uint32_t * qmap = nullptr;
+    const uint32_t * qcount = nullptr;
 };
 
 /// |approximate value - canonical value| <= eps for every row of the table and this query (sx, sq: upper bounds of |x|, |q|).
@@ -1010,7 +1013,9 @@ __global__ __launch_bounds__(16 * G) void ivf_rerank_kernel(const RerankParams a
     float4 * qs = reinterpret_cast<float4 *>(msvs_smem);
     uint64_t * keys = reinterpret_cast<uint64_t *>(msvs_smem + (size_t)a.ld4 * 16);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, g = tid & 15;
-    const uint32_t q = blockIdx.x, ld4 = a.ld4, kc = a.kc;
+    if (a.qmap && blockIdx.x >= *a.qcount)
+        return;
+    const uint32_t q = a.qmap ? a.qmap[blockIdx.x] : blockIdx.x, ld4 = a.ld4, kc = a.kc;
     for (uint32_t c = tid; c < ld4; c += 16 * G)
         qs[c] = a.Q[(size_t)q * ld4 + c];
     for (uint32_t c = tid; c < 64 * R; c += 16 * G)

@@ -478,7 +478,7 @@ static size_t table_pass_scratch(size_t n, size_t nq, uint32_t k)
 {
     const size_t nslices = ceil_div(std::max<size_t>(n, 1), (size_t)BG_ROWS);
     const size_t segs = ceil_div(std::max<size_t>(n, 1), (size_t)table_fallback_rpb(n));
-    return nq * (big_cand_cap(1, nslices) * 8 + 64 * 8 + 96) + fallback_cap(nq, 1, segs, k) * segs * k * 8 + 65536;
+    return nq * (big_cand_cap(1, nslices) * 8 + 64 * 8 + 96 + 4 /* the coarse tail's slow queue */) + fallback_cap(nq, 1, segs, k) * segs * k * 8 + 65536;
 }
 
 /// Worth it once the (query tile) x (128-row slice) grid can occupy the chip (64 work items measured no better than
@@ -571,10 +571,33 @@ static bool host_signal_round(HostSignal & hs, const uint32_t * nfail, hipStream
 
 /// Second half of a table pass, whatever produced the candidates: canonical re-rank + certificate, then the canonical scan
 /// of the table for the queries on the fail list.
+static RerankParams table_rerank_params(const msvs_index & ix, const TablePass & t, const ScanParams & a, const float * qnorm,
+                                        const uint64_t * cand, const uint64_t * bound, uint32_t kc, uint32_t * failq, uint32_t * nfail,
+                                        bool h16, const float * qrho);
+static void table_pass_fallback(int m, const TablePass & t, const ScanParams & a, size_t nq, uint32_t * failq, uint32_t * nfail,
+                                uint64_t * partial1, size_t fb_cap, uint32_t rpb1, uint32_t seg_max1, const int32_t * probes0,
+                                const int64_t * list_off, hipStream_t stream);
+
+/// slowq / nslow (nullable): the coarse quantiser's selection + band ran in coarse_tail_kernel; the re-rank launch serves only the
+/// queries it queued.
 static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, const ScanParams & a, size_t nq, const float * qnorm,
                             const uint64_t * cand, const uint64_t * bound, uint32_t kc, uint32_t * failq, uint32_t * nfail,
                             uint64_t * partial1, size_t fb_cap, uint32_t rpb1, uint32_t seg_max1, const int32_t * probes0,
-                            const int64_t * list_off, bool h16, const float * qrho, hipStream_t stream)
+                            const int64_t * list_off, bool h16, const float * qrho, hipStream_t stream, const uint32_t * slowq = nullptr,
+                            const uint32_t * nslow = nullptr)
+{
+    RerankParams rp = table_rerank_params(ix, t, a, qnorm, cand, bound, kc, failq, nfail, h16, qrho);
+    rp.qmap = slowq;
+    rp.qcount = nslow;
+    if (t.out_probes)
+        g_coarse_queries.fetch_add(nq, std::memory_order_relaxed);
+    launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
+    table_pass_fallback(m, t, a, nq, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, stream);
+}
+
+static RerankParams table_rerank_params(const msvs_index & ix, const TablePass & t, const ScanParams & a, const float * qnorm,
+                                        const uint64_t * cand, const uint64_t * bound, uint32_t kc, uint32_t * failq, uint32_t * nfail,
+                                        bool h16, const float * qrho)
 {
     RerankParams rp{};
     rp.Y = a.Y;
@@ -601,9 +624,13 @@ static void table_pass_tail(const msvs_index & ix, int m, const TablePass & t, c
     rp.band = t.out_probes && h16 && options().coarse_band != 0 ? 1 : 0;
     rp.stat_fail = prefilter_fail_counter() + (t.out_probes ? 1 : 0); // msvs_prefilter_stats / msvs_coarse_stats
     rp.stat_skip = options().rerank_stats != 0 ? prefilter_fail_counter() + (t.out_probes ? 4 : 2) : nullptr;
-    if (t.out_probes)
-        g_coarse_queries.fetch_add(nq, std::memory_order_relaxed);
-    launch_ivf_rerank(scan_metric(m), rp, (uint32_t)nq, stream);
+    return rp;
+}
+
+static void table_pass_fallback(int m, const TablePass & t, const ScanParams & a, size_t nq, uint32_t * failq, uint32_t * nfail,
+                                uint64_t * partial1, size_t fb_cap, uint32_t rpb1, uint32_t seg_max1, const int32_t * probes0,
+                                const int64_t * list_off, hipStream_t stream)
+{
     // queries without a certificate: canonical scan of the table
     ScanParams c = a;
     c.k = t.k;
@@ -749,6 +776,8 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         uint32_t * cpairs = scr.take<uint32_t>(nq * (size_t)G);
         uint32_t * cpoff = scr.take<uint32_t>(G + 1);
         uint32_t * cwoff = scr.take<uint32_t>(G + 1);
+        uint32_t * failq2c = t.out_probes ? scr.take<uint32_t>(nq) : nullptr; // queries coarse_tail_kernel leaves to the block-per-query re-rank ...
+        uint32_t * nslow = t.out_probes ? scr.take<uint32_t>(1) : nullptr;    // ... and their count (cleared by the preparation kernel)
         // one launch: norms, fp16 images, the one-list plan of this pass (what its fallback scans), its fail counter, and the
         // zeroed counters of the list scan that follows
         H16PrepAux aux{};
@@ -765,6 +794,11 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         {
             aux.zero[0] = t.h16_out->counters;
             aux.nzero[0] = t.h16_out->n_counters;
+        }
+        if (nslow)
+        {
+            aux.zero[1] = nslow;
+            aux.nzero[1] = 1;
         }
         hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq, (uint32_t)nq, ld,
                            ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qn16, 1, aux, qrho);
@@ -831,11 +865,25 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
             else
                 hipLaunchKernelGGL((h16_sample_kernel<M_L2, 1>), dim3(sgrid), dim3(BLOCK), 0, stream, h);
         }
-        hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
-                           n_pad, kc, cand, bound, (int)options().wave_select);
+        // round 6: selection + band re-rank of the probe lists in ONE launch, a wavefront per query (coarse_tail_kernel); the block-per-query
+        // re-rank then serves only the queries whose band could not be formed
+        const bool tail = t.out_probes && options().coarse_tail != 0 && options().coarse_band != 0 && options().wave_select == 1
+            && options().rerank_stats == 0 && n_pad <= 32 * WAVE && kc <= WAVE && kc > t.k && nslow != nullptr;
+        if (tail)
+        {
+            const RerankParams rp = table_rerank_params(ix, t, a, qn16, cand, bound, kc, failq, nfail, true, qrho);
+            const dim3 tgrid((unsigned)ceil_div(nq, (size_t)(BLOCK / WAVE)));
+            if (scan_metric(m) == M_IP)
+                hipLaunchKernelGGL((coarse_tail_kernel<M_IP>), tgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, rp, cand, bound, failq2c, nslow);
+            else
+                hipLaunchKernelGGL((coarse_tail_kernel<M_L2>), tgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, rp, cand, bound, failq2c, nslow);
+        }
+        else
+            hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
+                               n_pad, kc, cand, bound, (int)options().wave_select);
         MSVS_HIP(hipGetLastError());
         table_pass_tail(ix, m, t, a, nq, qn16, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true, qrho,
-                        stream);
+                        stream, tail ? failq2c : nullptr, tail ? nslow : nullptr);
         return;
     }
     if (t.flat_h16)
