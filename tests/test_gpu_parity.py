@@ -664,6 +664,58 @@ def test_small_batches_one_launch_coarse_and_plan_match_oracle(metric, knobs, op
         ix.close()
 
 
+@pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE])
+def test_round6_batch_forms_match_the_oracle_and_their_round5_forms(metric, opt):
+    """Round 6's launch-level changes of a batched search (>= 256 queries: the coarse pass through the centroid shadow), each against
+    the form it replaces AND the oracle: coarse_tail_kernel (selection + band in one launch, a wavefront per query; queries whose band
+    cannot be formed take the block-per-query re-rank through RerankParams::qmap) vs coarse_select_kernel + ivf_rerank_kernel;
+    coarse_gemm_kernel vs coarse_h16_kernel; the second chance inside the re-rank launch vs a launch of its own; grouped appends vs
+    one atomic per record; the plan feedback on / off.  Ties in the centroid distances (every centroid twice), lists that are not a
+    multiple of 32, more than 1024 lists.  The queries that reach the canonical fallback are the same whichever form runs (the same
+    probes and bounds reach the list scan); with the error bound blown up every query's band fails and all of them take the queue."""
+    rng = np.random.default_rng(606)
+    for n, d, nlist, nprobe, k, nq in ((60000, 96, 300, 16, 10, 700), (50000, 64, 1100, 32, 10, 400), (30000, 768, 256, 24, 10, 300)):
+        half = nlist // 2
+        centers = rng.standard_normal((half, d), dtype=np.float32) * 2
+        centers = np.concatenate([centers, centers[: nlist - half]])  # duplicate centroids: ties at every rank of the probe selection
+        x = (centers[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+        ix = capi.Index(capi.INDEX_IVFFLAT, metric, d, "ncentroids=%d" % nlist)
+        ix.set_centroids(centers)
+        ix.add(x)
+        ix.build()
+        q = (centers[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+        oi, od, _ = oracle_on_exported(ix, q, nprobe, k, metric)
+        counts = {}
+        for name, knobs in (("round6", {}), ("select+rerank", {"coarse_tail": "0"}), ("wave tiles", {"coarse_h16": "3"}),
+                            ("second chance launch", {"rerank_fused": "0"}), ("atomic per record", {"h16_group_appends": "0"}),
+                            ("no feedback", {"h16_feedback": "0"}), ("round5", {"coarse_tail": "0", "coarse_h16": "3", "rerank_fused": "0",
+                                                                                 "h16_group_appends": "0", "h16_feedback": "0", "pinned_fetch": "0"})):
+            for kn, v in knobs.items():
+                opt(kn, v)
+            for rep in range(2):  # (the second search of a shape runs with the first one's plan feedback)
+                c0, f0 = capi.coarse_stats(), capi.prefilter_stats()
+                ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+                same(ids, dis, oi, od)
+                c1, f1 = capi.coarse_stats(), capi.prefilter_stats()
+                counts.setdefault(rep, {})[name] = (c1[0] - c0[0], c1[1] - c0[1], f1[1] - f0[1])
+            for kn in knobs:
+                opt(kn, None)
+        for rep in (0, 1):
+            assert len(set(counts[rep].values())) == 1, counts[rep]
+            if metric != capi.METRIC_COSINE:  # (a cosine index ranks its centroids canonically: no shadow coarse pass to compare)
+                assert counts[rep]["round6"][0] == nq  # the shadow coarse pass is the one that ran
+        # nobody's band can be formed: every query goes through the queue to the block-per-query re-rank and on to the canonical fallback
+        opt("ivf_eps_scale", "1e12")
+        c0 = capi.coarse_stats()
+        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+        same(ids, dis, oi, od)
+        c1 = capi.coarse_stats()
+        if metric != capi.METRIC_COSINE:
+            assert c1[1] - c0[1] == nq
+        opt("ivf_eps_scale", None)
+        ix.close()
+
+
 @pytest.mark.parametrize("metric", [capi.METRIC_L2, capi.METRIC_COSINE])
 def test_shadow_pass_serves_k_up_to_128_with_256_candidates(metric, opt):
     """40 < k <= 128 (a hybrid search takes the vector top-100): the fp16-shadow pass with 256 candidates per query, the
