@@ -185,6 +185,8 @@ struct Options
     double filter_compact_below = -1;  // filtered searches run over a compacted view when less than this fraction of the
                                        // rows passes the filter (1: always, 0: never, < 0: by batch size,
                                        // profiles/r02_filter.txt)
+    double lat_hint = 1;      // few-query path: stage 2's grid sized by the rows the last call left after the radius pruning (0: always two blocks per CU)
+    double lat_items = 0;     // few-query path: work items of stage 2 per query (0 = planned: two blocks per CU over the call)
     double lat_prune = 1;     // few-query path (L2, no filter): probed lists the list radius rules out get no work items (0: off)
     double h16_preprune = 1;  // shadow list scan (L2, no filter): pairs the list radius alone rules out leave before the sample launch (0: off)
     double h16_group_appends = 1; // shadow passes: survivors of one query leave a wavefront's stage with ONE atomic (0: one per record)

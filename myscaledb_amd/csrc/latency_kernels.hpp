@@ -62,6 +62,8 @@ struct LatParams
     const uint64_t * alive;
     uint32_t nbits;
     uint32_t items;     // work items a query's probed rows are cut into (lat_cut); the grid has items + nprobe of them
+    uint32_t * hint_rows; // nullable, pinned host memory: stage 1 leaves the rows the query's surviving lists hold (the host sizes the
+                          // NEXT call's stage-2 grid by it: a hint, read without synchronisation)
     uint64_t * partial; // [nq][items + nprobe][k]
     int64_t * out_ids;  // [nq][k]
     float * out_dis;
@@ -293,6 +295,8 @@ __device__ __forceinline__ void lat_make_cut(const LatParams & p, uint32_t q, ui
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1)
         rows += (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)rows, o) | ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(rows >> 32), o) << 32);
+    if (p.hint_rows && lane == 0)
+        __hip_atomic_store(p.hint_rows, rows > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t rpb = (uint32_t)((rows + p.items - 1) / p.items);
     rpb = rpb < 16 ? 16 : (rpb + 15) / 16 * 16;
     const uint32_t mine = (len + rpb - 1) / rpb;

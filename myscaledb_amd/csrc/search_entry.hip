@@ -44,6 +44,10 @@ struct LatCtx
     // ... and of a small batch (index_search_host_call): its own block -- the few-query paths keep a completion word in theirs
     unsigned char * batch_pinned = nullptr;
     size_t batch_pinned_bytes = 0;
+    // the few-query path's feedback: rows of the probed lists that survived the radius pruning in the LAST call of this context (a
+    // pinned word stage 1 writes) and the index it was about -- sizes the next call's stage-2 grid (lat_launch)
+    uint32_t * hint_rows = nullptr;
+    const void * hint_ix = nullptr;
     static void grow(unsigned char *& p, size_t & have, size_t bytes)
     {
         if (bytes <= have)
@@ -85,6 +89,8 @@ LatShape lat_shape(const msvs_index & ix, size_t nq, size_t k, size_t nprobe)
     // work items per query: the grid (items + nprobe) is exactly 2 blocks per CU over the whole call -- a CU streams
     // ~22 KB/us whatever runs on it, so one CU with a third block sets the time of the launch (27 us against 19)
     s.items = (uint32_t)std::max<size_t>(nprobe, 2 * (size_t)device_cu_count() / nq > nprobe ? 2 * (size_t)device_cu_count() / nq - nprobe : nprobe);
+    if (options().lat_items >= 1)
+        s.items = (uint32_t)std::max<double>((double)nprobe, options().lat_items);
     s.grid_x = s.items + (uint32_t)nprobe;
     s.lds1 = (size_t)ix.ld * 4 + std::max((size_t)5 * nprobe * 8, lat_merge_lds(s.c_blocks, (uint32_t)nprobe));
     s.lds2 = (size_t)ix.ld * 4 + std::max((size_t)5 * k * 8, lat_merge_lds(s.grid_x, (uint32_t)k));
@@ -119,7 +125,29 @@ void lat_launch(const msvs_index & ix, LatCtx & c, const float * Q, size_t nq, u
     p.nprobe = (uint32_t)nprobe;
     p.nlist = (uint32_t)ix.nlist;
     p.C = reinterpret_cast<const float4 *>(ix.centroids.p);
-    const LatShape sh = lat_shape(ix, nq, k, nprobe);
+    LatShape sh = lat_shape(ix, nq, k, nprobe);
+    // Round 6: stage 2's grid follows the rows the LAST query of this context left after the radius pruning (on clustered data 32
+    // probes become 1 - 3: ~100 items of 16 rows instead of 480 blocks that mostly have nothing to scan but still arrive on the
+    // merge's counter -- 42.8 -> 39.0 us per call).  A hint: the cut adapts to whatever grid it gets (lat_make_cut), a query that
+    // needs more than the hint foresaw scans longer items this once.
+    if (!c.hint_rows)
+    {
+        MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&c.hint_rows), 64, hipHostMallocCoherent));
+        *c.hint_rows = 0;
+    }
+    if (options().lat_hint != 0 && options().lat_items < 1 && c.hint_ix == &ix)
+    {
+        const uint32_t rows_seen = *reinterpret_cast<volatile uint32_t *>(c.hint_rows);
+        if (rows_seen)
+        {
+            const uint32_t want = (uint32_t)std::min<size_t>(sh.items, std::max<size_t>(64, round_up(ceil_div((size_t)rows_seen, (size_t)16), (size_t)32)));
+            sh.items = std::max<uint32_t>(want, (uint32_t)nprobe);
+            sh.grid_x = sh.items + (uint32_t)nprobe;
+            sh.lds2 = (size_t)ix.ld * 4 + std::max((size_t)5 * k * 8, lat_merge_lds(sh.grid_x, (uint32_t)k));
+        }
+    }
+    c.hint_ix = &ix;
+    p.hint_rows = c.hint_rows;
     p.c_rows = sh.c_rows;
     p.c_blocks = sh.c_blocks;
     p.items = sh.items;
