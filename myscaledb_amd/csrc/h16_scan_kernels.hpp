@@ -80,7 +80,7 @@ struct H16Params
     // sample launch
     uint32_t * sample_out;    // [nq * nprobe][32] ordered distance word of row r of block 0 (0xFFFFFFFF = no row)
     uint32_t * sched;         // [8] work-queue cursors of this launch (zeroed by the caller)
-    uint32_t group_appends;   // 1: tiles of <= H_GROUP_MAX_Q queries append their survivors with one atomic per (wavefront, query)
+    uint32_t group_appends;   // n: tiles of <= n queries append their survivors with one atomic per (wavefront, query) (0: one per record)
     uint32_t lazy_flush;      // 1: survivors stay in the wavefront's LDS stage from block to block and leave when it is full / at the end of the item
     uint64_t * stamps;        // nullable (option h16_stamps): [grid][H_STAMP_ITEMS][4] {item popped, tile resident, rows done, l << 32 | nvalid << 8}
                               // in wall_clock64 ticks (100 MHz), [grid][0][0] = items of the workgroup
@@ -359,7 +359,6 @@ static __global__ void h16_prep_queries_kernel(const float * Q, uint32_t nq, uin
 constexpr int H_NW = 8;      // wavefronts per workgroup of the main launch
 constexpr int H_RING = 4;    // row chunks per wavefront in registers (H_RING - 1 in flight + the one being multiplied)
 constexpr int H_STAGE = 64;  // survivor records a wavefront stages in LDS before one round of atomics
-constexpr uint32_t H_GROUP_MAX_Q = 8; // tiles of at most this many queries group their appends by query (h16_stream: flush)
 constexpr uint32_t H_NONE = 0xFFFFFFFFu;
 
 /// LDS bytes of the scan kernel for a tile of 32 * ncb queries.
@@ -405,7 +404,7 @@ __device__ __forceinline__ void h16_stream(const H16Params & a, const unsigned c
         return;
     // (uniform: see flush.  Not in the two-row-block form -- exhaustive batches, tiles of 64+ queries: the extra code cost the kernel
     // its last free registers, 54 scratch instructions around the MFMA loops, 5.9 -> 6.6 ms per 4096-query pass)
-    const bool grouped = NRB == 1 && a.group_appends != 0 && tile_queries <= H_GROUP_MAX_Q;
+    const bool grouped = NRB == 1 && a.group_appends != 0 && tile_queries <= a.group_appends;
     uint32_t blk = blk0;
     const uint32_t r32 = lane & 31, h = lane >> 5;
     // operand read offsets of this lane inside a 128-byte query row: piece (2 j + h) ^ swizzle

@@ -954,7 +954,7 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         h.partial = candbuf;
         h.cand_cap = cap;
         h.sched = sched;
-        h.group_appends = options().h16_group_appends != 0 ? 1 : 0;
+        h.group_appends = (uint32_t)options().h16_group_appends;
         uint32_t ncb = (uint32_t)std::min<size_t>(3, ceil_div(nq, (size_t)32));
         if (options().flat_ncb >= 1)
             ncb = (uint32_t)std::min(3.0, options().flat_ncb);
@@ -1290,7 +1290,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     a.nlist = (uint32_t)ix.nlist;
     a.nprobe = (uint32_t)nprobe;
     a.xcd_order = (uint32_t)options().ivf_xcd;
-    a.group_appends = options().h16_group_appends != 0 ? 1 : 0;
+    a.group_appends = (uint32_t)options().h16_group_appends;
     a.qthr = qstate;
     a.qcnt = qstate + nq;
     a.partial = partial;
