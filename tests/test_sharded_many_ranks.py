@@ -268,3 +268,74 @@ def test_sharded_forms_with_many_ranks_match_the_oracle(world, metric_name):
         served_f = sum(res[r][1]["routed_filtered"][step][3] for r in range(world))
         served_u = sum(res[r][1]["routed"][step][3] for r in range(world))
         assert served_f >= served_u and served_f >= total
+
+
+# ---------------------------------------------------------------------------------------- a routed batch beyond one sub-batch
+
+def _big_case():
+    rng = np.random.default_rng(99)
+    n, d, nlist = 20000, 16, 256
+    centres = 4.0 * rng.standard_normal((nlist, d), dtype=np.float32)
+    x = (centres[rng.integers(0, nlist, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    nq = 33000  # index_search_device cuts a batch into sub-batches of max(256, 2^21 / nprobe) = 32768 queries at nprobe 64
+    q = (centres[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    return x, q, centres
+
+
+def _big_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import myscaledb_amd.capi as capi
+        from myscaledb_amd import sharded
+        capi.set_device(0)
+        x, q, centres = _big_case()
+        ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, x.shape[1], "ncentroids=%d,shard_rank=%d,shard_world=%d" % (centres.shape[0], rank, world))
+        ix.set_centroids(centres)
+        ix.add(x)
+        ix.build()
+        comm = sharded.gloo_comm()
+        sel = np.arange(q.shape[0] - 10) if rank == 0 else np.arange(q.shape[0] - 10, q.shape[0])  # 32990 queries on rank 0, 10 on rank 1
+        dq = torch.from_numpy(q[sel]).cuda()
+        oi = torch.full((len(sel), K), -7, dtype=torch.int64, device="cuda")
+        od = torch.empty((len(sel), K), dtype=torch.float32, device="cuda")
+        served = ix.shard_search_routed_device(comm, dq.data_ptr(), len(sel), K, 64, oi.data_ptr(), od.data_ptr())
+        torch.cuda.synchronize()
+        out.put((rank, sel, oi.cpu().numpy(), od.cpu().numpy(), served))
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_routed_batch_beyond_one_sub_batch_matches_the_oracle():
+    """a per-rank batch above the device-level search's sub-batch size (32768 queries at nprobe 64) -- the sub-batch
+    loop must carry the routed front phase's index-wide ProbeWords fields and offset its per-pair outputs (the survivors' array the
+    route mask reads): every query's result == the oracle's on the unsharded structure."""
+    import myscaledb_amd.capi as capi
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_big_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    x, q, centres = _big_case()
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, x.shape[1], "ncentroids=%d" % centres.shape[0])
+    ix.set_centroids(centres)
+    ix.add(x)
+    ix.build()
+    cent, off, vecs, lids = ix.export()
+    ix.close()
+    ei, ed, _ = o.ivf_search(cent, off, vecs, lids, q, 64, K, o.METRIC_L2, threads=8)
+    total = 0
+    for rank, sel, gi, gd, served in res:
+        _same(gi, gd, ei[sel], ed[sel], ("big", rank))
+        total += served
+    assert q.shape[0] <= total <= world * q.shape[0]
