@@ -22,6 +22,7 @@ struct msvs_postings
     std::vector<int64_t> h_post_off;
     std::vector<uint8_t> h_term_field; // empty: field 0
     size_t num_terms = 0, num_docs = 0, num_postings = 0, num_fields = 1;
+    int device = 0; // where the postings live: the host-pointer entries run there whichever thread calls (DeviceGuard)
     // resident alive bitmap (lightweight deletes of the part): swapped under `mu`, a search keeps its own reference
     mutable std::mutex mu;
     std::shared_ptr<DevBuf<uint64_t>> alive;
@@ -184,6 +185,7 @@ extern "C" int msvs_postings_create_fields(const int64_t * post_off, size_t num_
                     fail(MSVS_ERR_INVALID_ARGUMENT, "doc ids must ascend inside a posting list and stay below num_docs");
         }
         std::unique_ptr<msvs_postings> p(new msvs_postings);
+        MSVS_HIP(hipGetDevice(&p->device));
         p->num_terms = num_terms;
         p->num_docs = num_docs;
         p->num_postings = np;
@@ -255,6 +257,7 @@ extern "C" int msvs_postings_set_alive(msvs_postings_t * ps, const uint64_t * al
     return guarded([&] {
         if (!ps)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null postings");
+        DeviceGuard on_device(ps->device);
         std::shared_ptr<DevBuf<uint64_t>> next;
         if (alive_bits)
         {
@@ -915,6 +918,7 @@ extern "C" int msvs_bm25_search_batch(const msvs_postings_t * ps, size_t nq, con
             fail(MSVS_ERR_INVALID_ARGUMENT, "null buffer");
         for (size_t q = 0; q < nq; q++)
             n_out[q] = 0;
+        DeviceGuard on_device(ps->device);
         if (nq == 0 || k == 0 || ps->num_docs == 0)
             return;
         hipStream_t stream = thread_stream();

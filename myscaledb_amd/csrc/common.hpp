@@ -45,6 +45,31 @@ void set_last_error(const std::string & m);
                          #expr, hipGetErrorString(e_), __FILE__, __LINE__);                                         \
     } while (0)
 
+/// The host-pointer entry points take an index from ANY host thread (the reference searches from a pool of scan threads:
+/// MergeTreeVSManager.cpp:973), and a fresh thread's current device is 0: on a multi-GPU host the call runs on the device the index
+/// lives on, and the caller's device is what it was when the call returns.  (Device-pointer entries take the caller's stream: the
+/// caller's device is the right one by construction.)
+struct DeviceGuard
+{
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        int cur = -1;
+        if (dev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != dev)
+        {
+            MSVS_HIP(hipSetDevice(dev));
+            prev = cur;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard & operator=(const DeviceGuard &) = delete;
+};
+
 /// Runs a C-ABI body, translating exceptions into status codes + msvs_last_error().
 template <typename F>
 inline int guarded(F && f)

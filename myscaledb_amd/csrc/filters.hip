@@ -265,6 +265,7 @@ extern "C" int msvs_index_search_filter(const msvs_index_t * ix, const float * q
                                         const msvs_filter_t * filter, int64_t * ids, float * dis)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || !filter || (nq && (!queries || !ids || !dis)) || k < 0)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index/filter/buffer or negative k");
         if (nq == 0 || k == 0)
@@ -298,6 +299,7 @@ extern "C" int msvs_index_search_filter(const msvs_index_t * ix, const float * q
 extern "C" int msvs_index_set_delete_bitmap(msvs_index_t * ix, const uint64_t * alive_bits, size_t nbits)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
         auto cur = ix->get_meta();

@@ -317,6 +317,7 @@ extern "C" void msvs_index_free(msvs_index_t * index)
 extern "C" int msvs_index_set_centroids(msvs_index_t * ix, const float * centroids, size_t nlist, int mem)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || !centroids || nlist == 0)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index/centroids");
         if (ix->type != MSVS_INDEX_IVFFLAT)
@@ -333,6 +334,7 @@ extern "C" int msvs_index_set_centroids(msvs_index_t * ix, const float * centroi
 extern "C" int msvs_index_train(msvs_index_t * ix, const float * x, size_t n, int mem)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || (n && !x))
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index/data");
         if (ix->type != MSVS_INDEX_IVFFLAT)
@@ -550,6 +552,7 @@ extern "C" int msvs_index_set_cancel(msvs_index_t * ix, int (*is_cancelled)(void
 extern "C" int msvs_index_add(msvs_index_t * ix, const float * x, const int64_t * ids, size_t n, int mem)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || (n && !x))
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index/data");
         if (ix->ready)
@@ -645,6 +648,7 @@ extern "C" int msvs_index_add(msvs_index_t * ix, const float * x, const int64_t 
 extern "C" int msvs_index_build(msvs_index_t * ix)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix)
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index");
         if (ix->ready)

@@ -16,6 +16,7 @@ extern "C" int msvs_index_export(const msvs_index_t * ix, float * centroids, int
                                  int64_t * ids)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || !ix->ready)
             fail(MSVS_ERR_NOT_READY, "index is not ready");
         const size_t d = ix->dim, ld = ix->ld;
@@ -38,6 +39,7 @@ extern "C" int msvs_index_export(const msvs_index_t * ix, float * centroids, int
 extern "C" int msvs_index_export_list(const msvs_index_t * ix, size_t list, float * vecs, int64_t * ids)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || !ix->ready || ix->type != MSVS_INDEX_IVFFLAT)
             fail(MSVS_ERR_NOT_READY, "not a built IVFFLAT index");
         if (list >= ix->nlist)
@@ -128,6 +130,7 @@ msvs_io_t stdio_io(StdioCtx * c) { return msvs_io_t{c, stdio_open, stdio_write, 
 extern "C" int msvs_index_serialize_io(const msvs_index_t * ix, const msvs_io_t * io)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || !ix->ready)
             fail(MSVS_ERR_NOT_READY, "index is not ready");
         const size_t nlist = msvs_index_num_lists(ix), d = ix->dim, ld = ix->ld;

@@ -1934,6 +1934,7 @@ extern "C" int msvs_index_set_merged_maps(msvs_index_t * ix, const uint64_t * ro
                                           size_t n_new, uint32_t own_id)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || (n_old && !row_ids_map) || (n_new && (!inverted_row_ids_map || !inverted_row_sources_map)))
             fail(MSVS_ERR_INVALID_ARGUMENT, "null index / map");
         auto cur = ix->get_meta();
@@ -1968,6 +1969,7 @@ extern "C" int msvs_index_scanned_rows(const msvs_index_t * ix, const float * qu
                                        uint64_t * rows, uint64_t * rows_streamed, uint64_t * rows_unique)
 {
     return guarded([&] {
+        DeviceGuard on_device(ix ? ix->device : -1);
         if (!ix || !rows || (nq && !queries))
             fail(MSVS_ERR_INVALID_ARGUMENT, "null argument");
         if (!ix->ready)

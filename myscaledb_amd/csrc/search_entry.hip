@@ -446,6 +446,7 @@ int index_search_host_call(const msvs_index_t * ix, const float * queries, size_
             fail(MSVS_ERR_NOT_READY, "index is not ready");
         if (nq == 0 || k == 0)
             return;
+        DeviceGuard on_device(ix->device);
         if ((size_t)k > MSVS_MAX_K_ROUNDS)
             fail(MSVS_ERR_UNSUPPORTED_K, "k = %d exceeds the limit %d", k, MSVS_MAX_K_ROUNDS);
         auto p = parse_params(params);
