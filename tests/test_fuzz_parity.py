@@ -272,3 +272,50 @@ def test_fuzz_binary_vectors_against_the_oracle():
             check(tag + " [index]", bx.search(x, k, alive=alive), exp)
         finally:
             bx.close()
+
+
+def test_fuzz_concurrent_mixed_searches_on_one_index():
+    """Host threads searching ONE index at once with different shapes (single queries next to batches, with and without filters):
+    per-thread streams and scratch, the combiner, the stale-by-one hints an index keeps between searches (plan feedback, stage-2
+    grid hint) must never leak into another caller's answer."""
+    import threading
+
+    for it in range(max(1, ITERS // 8)):
+        seed = SEED + 400000 + it
+        rng = np.random.default_rng(seed)
+        metric = int(rng.choice([capi.METRIC_L2, capi.METRIC_IP, capi.METRIC_COSINE]))
+        d = int(rng.choice([32, 96, 128, 768]))
+        n, nlist = 40000 if d <= 128 else 15000, int(rng.choice([32, 200, 600]))
+        x, _ = make_rows(rng, n, d, nlist, str(rng.choice(["blobs", "iid", "dup"])))
+        ix = capi.Index(capi.INDEX_IVFFLAT, metric, d, "ncentroids=%d,kmeans_iters=3" % nlist)
+        ix.train(x)
+        ix.add(x)
+        ix.build()
+        jobs = []
+        for j in range(24):
+            nq = int(rng.choice([1, 1, 1, 2, 4, 16, 40, 300]))
+            k = int(rng.choice([1, 10, 10, 40, 100]))
+            nprobe = int(rng.choice([1, 4, 16, min(32, nlist)]))
+            q = make_queries(rng, x, nq, d)
+            alive = (rng.random(n) < 0.3) if rng.random() < 0.25 else None
+            jobs.append((q, k, nprobe, alive, oracle_ivf(ix, q, nprobe, k, metric, alive)))
+        errors = []
+
+        def worker(t):
+            order = np.random.default_rng(seed * 100 + t).permutation(len(jobs))
+            try:
+                for rep in range(3):
+                    for j in order:
+                        q, k, nprobe, alive, exp = jobs[j]
+                        check("seed %d thread %d job %d (nq %d k %d nprobe %d filter %s)" % (seed, t, j, len(q), k, nprobe, alive is not None),
+                              ix.search(q, k, "nprobe=%d" % nprobe, alive=alive), exp)
+            except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        ix.close()
+        assert not errors, errors[0]
