@@ -1695,52 +1695,65 @@ __global__ __launch_bounds__(BLOCK, 1) void coarse_h16_kernel(const uint4 * H, u
 /// traffic, not the latency, is the limit).  A 128 x 128 tile moves 384 KB for 25 MFLOP: 98 MB.  Query chunks arrive with coalesced
 /// loads (thread = (query, piece)) and take the list scan's XOR swizzle in LDS; the shadow's blocks are already in operand order and
 /// are copied as they are.  Same words, same output layout as coarse_h16_kernel (every word of sample_out[q][32 G] written).
-constexpr uint32_t CG_TQ = 128, CG_TC = 128; // queries / centroids per workgroup
-template <int METRIC>
+// (queries per workgroup: 64 NT, centroids per workgroup: 64 NS -- NT x NS blocks of 32 x 32 per wavefront)
+template <int METRIC, int NT, int NS>
 __global__ __launch_bounds__(256, 2) void coarse_gemm_kernel(const uint4 * H, uint32_t nch, const uint4 * Qh, const float2 * qinfo,
                                                              const float * xnorm, uint32_t n_rows, uint32_t nq, uint32_t * sample_out)
 {
+    constexpr uint32_t CG_TQ = 64 * NT, CG_TC = 64 * NS;
     __shared__ __attribute__((aligned(16))) uint4 a_s[2][CG_TQ * 8];      // [buffer][query][8 pieces, swizzled]
     __shared__ __attribute__((aligned(16))) uint4 b_s[2][(CG_TC / 32) * 256]; // [buffer][block][step][lane]
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, h = lane >> 5;
     const uint32_t G = (n_rows + H_ROWS - 1) / H_ROWS, n_pad = G * H_ROWS;
     const uint32_t q_base = blockIdx.x * CG_TQ, g_base = blockIdx.y * (CG_TC / 32);
-    const uint32_t wq = wave >> 1, wc = wave & 1; // this wavefront: query blocks 2 wq, 2 wq + 1; centroid blocks 2 wc, 2 wc + 1 of the tile
+    const uint32_t wq = wave >> 1, wc = wave & 1; // this wavefront: query blocks NT wq ..; centroid blocks NS wc .. of the tile
     // load side: A -- thread = (query tid / 8 + 32 i, piece tid % 8); B -- thread = u32x4 tid of block i's chunk
     const uint32_t lq = tid >> 3, lp = tid & 7;
-    const u32x4 * asrc[4];
-    const u32x4 * bsrc[4];
+    const u32x4 * asrc[2 * NT];
+    const u32x4 * bsrc[2 * NS];
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
-        const uint32_t q = q_base + lq + 32 * i < nq ? q_base + lq + 32 * i : nq - 1;
-        asrc[i] = reinterpret_cast<const u32x4 *>(Qh) + (size_t)q * nch * 8 + lp;
-        const uint32_t g = g_base + i < G ? g_base + i : G - 1;
-        bsrc[i] = reinterpret_cast<const u32x4 *>(H) + (size_t)g * nch * 256 + tid;
+        if (i < 2 * NT)
+        {
+            const uint32_t q = q_base + lq + 32 * i < nq ? q_base + lq + 32 * i : nq - 1;
+            asrc[i] = reinterpret_cast<const u32x4 *>(Qh) + (size_t)q * nch * 8 + lp;
+        }
+        if (i < 2 * NS)
+        {
+            const uint32_t g = g_base + i < G ? g_base + i : G - 1;
+            bsrc[i] = reinterpret_cast<const u32x4 *>(H) + (size_t)g * nch * 256 + tid;
+        }
     }
-    u32x4 ar[2][4], br[2][4]; // two chunks in flight: chunk c + 2 is requested before chunk c is multiplied
+    u32x4 ar[2][2 * NT], br[2][2 * NS]; // two chunks in flight: chunk c + 2 is requested before chunk c is multiplied
     auto fetch = [&](const int r, const uint32_t c) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            ar[r][i] = asrc[i][(size_t)c * 8];
-            br[r][i] = bsrc[i][(size_t)c * 256];
+            if (i < 2 * NT)
+                ar[r][i] = asrc[i][(size_t)c * 8];
+            if (i < 2 * NS)
+                br[r][i] = bsrc[i][(size_t)c * 256];
         }
     };
     auto put = [&](const int b, const int r) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            const uint32_t qq = lq + 32 * i;
-            reinterpret_cast<u32x4 *>(a_s[b])[qq * 8 + (lp ^ ((qq >> 1) & 7))] = ar[r][i];
-            reinterpret_cast<u32x4 *>(b_s[b])[i * 256 + tid] = br[r][i];
+            if (i < 2 * NT)
+            {
+                const uint32_t qq = lq + 32 * i;
+                reinterpret_cast<u32x4 *>(a_s[b])[qq * 8 + (lp ^ ((qq >> 1) & 7))] = ar[r][i];
+            }
+            if (i < 2 * NS)
+                reinterpret_cast<u32x4 *>(b_s[b])[i * 256 + tid] = br[r][i];
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[NT][NS];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++)
+        for (int s2 = 0; s2 < NS; s2++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 acc[t][s2][r] = 0.f;
@@ -1751,17 +1764,19 @@ __global__ __launch_bounds__(256, 2) void coarse_gemm_kernel(const uint4 * H, ui
 #pragma unroll
         for (int j = 0; j < 4; j++)
         {
-            half8 af[2], bf[2];
+            half8 af[NT], bf[NS];
 #pragma unroll
             for (int t = 0; t < 2; t++)
             {
-                af[t] = __builtin_bit_cast(half8, al[(64 * wq + 32 * t + r32) * 8 + ((2 * j + h) ^ sw)]);
-                bf[t] = __builtin_bit_cast(half8, bl[(2 * wc + t) * 256 + j * 64 + lane]);
+                if (t < NT)
+                    af[t] = __builtin_bit_cast(half8, al[(32 * NT * wq + 32 * t + r32) * 8 + ((2 * j + h) ^ sw)]);
+                if (t < NS)
+                    bf[t] = __builtin_bit_cast(half8, bl[(NS * wc + t) * 256 + j * 64 + lane]);
             }
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+            for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++)
+                for (int s2 = 0; s2 < NS; s2++)
                     acc[t][s2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[s2], acc[t][s2], 0, 0, 0);
         }
     };
@@ -1788,24 +1803,24 @@ __global__ __launch_bounds__(256, 2) void coarse_gemm_kernel(const uint4 * H, ui
             put(0, 0); // chunk c + 2
         __syncthreads();
     }
-    float2 qi[2];
+    float2 qi[NT];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < NT; t++)
     {
-        const uint32_t q = q_base + 64 * wq + 32 * t + r32;
+        const uint32_t q = q_base + 32 * NT * wq + 32 * t + r32;
         qi[t] = qinfo[q < nq ? q : nq - 1];
     }
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++)
+    for (int s2 = 0; s2 < NS; s2++)
     {
-        const uint32_t g = g_base + 2 * wc + s2;
+        const uint32_t g = g_base + NS * wc + s2;
         if (g >= G)
             break;
         const uint32_t row = g * H_ROWS + r32;
         const bool ok = row < n_rows;
         const float xn = ok && METRIC == M_L2 ? xnorm[row] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < NT; t++)
         {
 #pragma unroll
             for (int i = 0; i < 16; i++)
@@ -1815,7 +1830,7 @@ __global__ __launch_bounds__(256, 2) void coarse_gemm_kernel(const uint4 * H, ui
                 const float m2 = __shfl(qi[t].x, qidx), qn = __shfl(qi[t].y, qidx);
                 const float v = METRIC == M_L2 ? __fadd_rn(fmaf(m2, acc[t][s2][i], xn), qn) : __fmul_rn(m2, acc[t][s2][i]);
                 const uint64_t key = ok ? make_key<METRIC>(v, row) : KEY_NONE;
-                const uint32_t q = q_base + 64 * wq + 32 * t + (uint32_t)qidx;
+                const uint32_t q = q_base + 32 * NT * wq + 32 * t + (uint32_t)qidx;
                 if (q < nq)
                     sample_out[(size_t)q * n_pad + row] = (uint32_t)(key >> 32);
             }

@@ -823,13 +823,20 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
             if (options().coarse_h16 != 3 && nq >= 256)
             {
                 // round 6: 128 x 128 workgroup tiles, both operands through LDS (coarse_gemm_kernel)
-                const dim3 ggrid((unsigned)ceil_div(nq, (size_t)CG_TQ), (unsigned)ceil_div((size_t)G, (size_t)(CG_TC / 32)));
+                // (smaller tiles than 128 x 128: several workgroups per CU in different phases -- the launch is its prologue, epilogue
+                // and stores, not its loop)
+                const int nt = options().coarse_gemm_tq == 128 ? 2 : 1, ns = options().coarse_gemm_tc == 128 ? 2 : 1;
+                const dim3 ggrid((unsigned)ceil_div(nq, (size_t)(64 * nt)), (unsigned)ceil_div((size_t)G, (size_t)(2 * ns)));
+                auto go = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, ggrid, dim3(256), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo, t.norms, (uint32_t)t.n, (uint32_t)nq,
+                                       sample);
+                };
                 if (scan_metric(m) == M_IP)
-                    hipLaunchKernelGGL((coarse_gemm_kernel<M_IP>), ggrid, dim3(256), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo, t.norms,
-                                       (uint32_t)t.n, (uint32_t)nq, sample);
+                    nt == 2 ? (ns == 2 ? go(coarse_gemm_kernel<M_IP, 2, 2>) : go(coarse_gemm_kernel<M_IP, 2, 1>))
+                            : (ns == 2 ? go(coarse_gemm_kernel<M_IP, 1, 2>) : go(coarse_gemm_kernel<M_IP, 1, 1>));
                 else
-                    hipLaunchKernelGGL((coarse_gemm_kernel<M_L2>), ggrid, dim3(256), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo, t.norms,
-                                       (uint32_t)t.n, (uint32_t)nq, sample);
+                    nt == 2 ? (ns == 2 ? go(coarse_gemm_kernel<M_L2, 2, 2>) : go(coarse_gemm_kernel<M_L2, 2, 1>))
+                            : (ns == 2 ? go(coarse_gemm_kernel<M_L2, 1, 2>) : go(coarse_gemm_kernel<M_L2, 1, 1>));
             }
             else if (scan_metric(m) == M_IP)
                 hipLaunchKernelGGL((coarse_h16_kernel<M_IP>), dim3(cgrid), dim3(BLOCK), 0, stream, ix.c_shadow.p, ix.h_nch, qh, qinfo,
