@@ -2034,6 +2034,53 @@ static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint3
     top.store(dst, kc, lane);
 }
 
+/// coarse_tail_kernel, a query whose band cannot be formed, served by its own wavefront (`slow_inline`): the canonical distance of EVERY
+/// centroid -- 16 lanes per row, four rows per step, the arithmetic and order of scan_rows -- replaces the approximate word of that
+/// centroid in the query's row of `words` (an exact word is inside every error bound its later readers assume), and the selection
+/// that picked the candidates picks the k probes out of them: smallest (distance, id) first, the oracle's order of keys (ties inside
+/// wave_select_words go by ascending slot = id).  ~0.25 ms for that one wavefront over 1024 centroids of 768 dimensions -- the host
+/// takes this form only while the index has not queued a query for a while (the stamp in pinned memory: coarse_tail_kernel); it saves
+/// the three launches of the queue's chain on every search that has none.
+template <int METRIC>
+__device__ inline void coarse_exact_rows(const RerankParams & a, const uint32_t q, uint32_t * words /* [n_pad] of this query */,
+                                         const uint32_t n_rows, const uint32_t lane)
+{
+    const uint32_t grp = lane >> 4, g = lane & 15, ld4 = a.ld4;
+    const uint32_t jfull = ld4 >> 4, jtail = ld4 & 15;
+    const float4 * const qrow = a.Q + (size_t)q * ld4 + g;
+#pragma unroll 1
+    for (uint32_t r0 = 0; r0 < n_rows; r0 += 4)
+    {
+        const uint32_t row = r0 + grp;
+        const bool rv = row < n_rows;
+        const float4 * yrow = a.Y + (size_t)(rv ? row : n_rows - 1) * ld4 + g;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t j = 0;
+        for (; j + 6 <= jfull; j += 6)
+        {
+            float4 y[6];
+#pragma unroll
+            for (int v = 0; v < 6; v++)
+                y[v] = yrow[(j + v) * 16];
+#pragma unroll
+            for (int v = 0; v < 6; v++)
+                canonical_update<METRIC>(acc, qrow[(j + v) * 16], y[v]);
+        }
+        for (; j < jfull; j++)
+            canonical_update<METRIC>(acc, qrow[j * 16], yrow[j * 16]);
+        if (g < jtail)
+            canonical_update<METRIC>(acc, qrow[jfull * 16], yrow[jfull * 16]);
+        float sum = __fadd_rn(__fadd_rn(acc.x, acc.y), __fadd_rn(acc.z, acc.w));
+        sum = row16_tree_sum(sum);
+        if (g == 0 && rv)
+            words[row] = (uint32_t)(make_key<METRIC>(sum, row) >> 32);
+    }
+    // the words go back in through the same loads that read their approximate versions a moment ago: written back, the CU's vector
+    // cache dropped
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 /// Round 6 -- the coarse quantiser's selection AND band re-rank in one launch, one WAVEFRONT per query, no workgroup barrier:
 /// coarse_select_kernel (15 us per 4096 queries) + ivf_rerank_kernel in band mode (33 us: a 256-thread block per query, eight
 /// barriers around three or four canonical rows) were two launches whose cost is the latency chain of a block, not work.
@@ -2048,7 +2095,8 @@ static __global__ __launch_bounds__(BLOCK) void coarse_select_kernel(const uint3
 /// Same probes as the two-launch form, slot by slot (test_small_batches... / the coarse parity tests compare both).
 template <int METRIC>
 __global__ __launch_bounds__(BLOCK) void coarse_tail_kernel(const uint32_t * sample, uint32_t nq, uint32_t n_pad, const RerankParams a,
-                                                            uint64_t * cand, uint64_t * bound, uint32_t * slowq, uint32_t * nslow)
+                                                            uint64_t * cand, uint64_t * bound, uint32_t * slowq, uint32_t * nslow,
+                                                            uint32_t n_rows, uint32_t * slow_stamp, uint32_t seq, int slow_inline)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[BLOCK / WAVE][256];
     __shared__ uint64_t s_stage[BLOCK / WAVE][WAVE];
@@ -2100,6 +2148,36 @@ __global__ __launch_bounds__(BLOCK) void coarse_tail_kernel(const uint32_t * sam
     }
     if (!band_ok) // (uniform over the wavefront)
     {
+        // the host reads the stamp without synchronisation before its NEXT searches of this index: which form of the queue they take
+        if (slow_stamp && lane == 0)
+        {
+            __hip_atomic_store(slow_stamp, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(slow_stamp + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (slow_inline)
+        {
+            if (lane == 0 && a.stat_fail)
+                atomicAdd(a.stat_fail, 1ull);
+            uint32_t * const words = const_cast<uint32_t *>(src);
+            coarse_exact_rows<METRIC>(a, q, words, n_rows, lane);
+            cd[lane] = KEY_NONE;
+            bp_wave_lds_fence_h16();
+            if (n_pad <= 4 * WAVE)
+                coarse_select_wave<4>(src, n_pad, k, cd, lane, s_hist[wave], s_stage[wave]);
+            else if (n_pad <= 8 * WAVE)
+                coarse_select_wave<8>(src, n_pad, k, cd, lane, s_hist[wave], s_stage[wave]);
+            else if (n_pad <= 16 * WAVE)
+                coarse_select_wave<16>(src, n_pad, k, cd, lane, s_hist[wave], s_stage[wave]);
+            else
+                coarse_select_wave<32>(src, n_pad, k, cd, lane, s_hist[wave], s_stage[wave]);
+            bp_wave_lds_fence_h16();
+            if (lane < k)
+            {
+                const uint64_t key = cd[lane];
+                a.out_probes[(size_t)q * k + lane] = key == KEY_NONE ? -1 : (int32_t)(a.ids ? a.ids[(uint32_t)key] : (uint32_t)key);
+            }
+            return;
+        }
         if (lane < kc)
             cand[(size_t)q * kc + lane] = mine;
         if (lane == 0)

@@ -202,6 +202,7 @@ void index_finalize_norms(msvs_index & ix, hipStream_t stream)
     {
         MSVS_HIP(hipHostMalloc(reinterpret_cast<void **>(&ix.plan_fb.pairs), 64, hipHostMallocDefault));
         *ix.plan_fb.pairs = 0xFFFFFFFFu;
+        ix.plan_fb.pairs[1] = ix.plan_fb.pairs[2] = 0;
     }
     ix.xnorm.alloc(std::max<size_t>(ix.n, 1));
     ix.xnorm_max = 0.f;

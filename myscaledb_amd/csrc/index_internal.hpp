@@ -107,6 +107,11 @@ struct msvs_index
     {
         uint32_t * pairs = nullptr; // pinned host memory, 0xFFFFFFFF: nothing yet
         mutable uint32_t nq = 0, nprobe = 0;
+        // pairs[1], pairs[2]: the sequence number (`seq`) of the last batched search whose coarse stage met a query without a band, and
+        // whether there has been one at all (coarse_tail_kernel writes them; table_candidate_pass picks the form of the queue by them)
+        mutable std::atomic<uint32_t> seq{0};
+        // the inline form is retried after `window` searches without such a query; a retry that meets one again quadruples the window
+        mutable std::atomic<uint32_t> window{0}, last_inline{0}, bumped{0};
         ~PlanFeedback()
         {
             if (pairs)

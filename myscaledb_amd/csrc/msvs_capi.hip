@@ -876,19 +876,52 @@ static void table_candidate_pass(const msvs_index & ix, Scratch & scr, int m, co
         // re-rank then serves only the queries whose band could not be formed
         const bool tail = t.out_probes && options().coarse_tail != 0 && options().coarse_band != 0 && options().wave_select == 1
             && options().rerank_stats == 0 && n_pad <= 32 * WAVE && kc <= WAVE && kc > t.k && nslow != nullptr;
+        // ... and those, too, by their own wavefront while the index has not had one for a while (coarse_exact_wave): the queue's chain is
+        // three launches that find nothing to do on every other search (~15 us of the 4096-query step).  Which form runs is decided on
+        // a stamp the kernel leaves in pinned memory (the sequence number of the last search of this index that met such a query; read
+        // without synchronisation: a hint -- both forms are exact, the inline one is slow when MANY queries need it)
+        bool slow_inline = false;
+        uint32_t * slow_stamp = nullptr;
+        uint32_t seq = 0;
+        if (tail && ix.plan_fb.pairs)
+        {
+            slow_stamp = ix.plan_fb.pairs + 1;
+            seq = ix.plan_fb.seq.fetch_add(1, std::memory_order_relaxed) + 1;
+            const uint32_t last = *reinterpret_cast<volatile uint32_t *>(slow_stamp), seen = *reinterpret_cast<volatile uint32_t *>(slow_stamp + 1);
+            const uint32_t base = (uint32_t)options().coarse_slow_window;
+            uint32_t window = std::max(ix.plan_fb.window.load(std::memory_order_relaxed), base);
+            if (seen && base != 0 && last != 0 && last == ix.plan_fb.last_inline.load(std::memory_order_relaxed)
+                && ix.plan_fb.bumped.exchange(last, std::memory_order_relaxed) != last)
+            {
+                // the last inline attempt met such a query again: this index has them for good -- try less often (data whose centroid
+                // distances sit closer together than the error bound keeps a few hundred of them per batch)
+                window = (uint32_t)std::min<uint64_t>((uint64_t)window * 4, 1u << 20);
+                ix.plan_fb.window.store(window, std::memory_order_relaxed);
+            }
+            slow_inline = options().coarse_slow_inline != 0 && (seen == 0 || (uint32_t)(seq - last) > window);
+            if (slow_inline && seen) // (a retry: the first search of an index is not one)
+                ix.plan_fb.last_inline.store(seq, std::memory_order_relaxed);
+        }
         if (tail)
         {
             const RerankParams rp = table_rerank_params(ix, t, a, qn16, cand, bound, kc, failq, nfail, true, qrho);
             const dim3 tgrid((unsigned)ceil_div(nq, (size_t)(BLOCK / WAVE)));
             if (scan_metric(m) == M_IP)
-                hipLaunchKernelGGL((coarse_tail_kernel<M_IP>), tgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, rp, cand, bound, failq2c, nslow);
+                hipLaunchKernelGGL((coarse_tail_kernel<M_IP>), tgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, rp, cand, bound, failq2c, nslow,
+                                   (uint32_t)t.n, slow_stamp, seq, slow_inline ? 1 : 0);
             else
-                hipLaunchKernelGGL((coarse_tail_kernel<M_L2>), tgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, rp, cand, bound, failq2c, nslow);
+                hipLaunchKernelGGL((coarse_tail_kernel<M_L2>), tgrid, dim3(BLOCK), 0, stream, sample, (uint32_t)nq, n_pad, rp, cand, bound, failq2c, nslow,
+                                   (uint32_t)t.n, slow_stamp, seq, slow_inline ? 1 : 0);
         }
         else
             hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream, sample, (uint32_t)nq,
                                n_pad, kc, cand, bound, (int)options().wave_select);
         MSVS_HIP(hipGetLastError());
+        if (slow_inline) // (every query left the tail launch with its probes)
+        {
+            g_coarse_queries.fetch_add(nq, std::memory_order_relaxed);
+            return;
+        }
         table_pass_tail(ix, m, t, a, nq, qn16, cand, bound, kc, failq, nfail, partial1, fb_cap, rpb1, seg_max1, probes0, list_off, true, qrho,
                         stream, tail ? failq2c : nullptr, tail ? nslow : nullptr);
         return;

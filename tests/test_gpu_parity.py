@@ -704,14 +704,21 @@ def test_round6_batch_forms_match_the_oracle_and_their_round5_forms(metric, opt)
             assert len(set(counts[rep].values())) == 1, counts[rep]
             if metric != capi.METRIC_COSINE:  # (a cosine index ranks its centroids canonically: no shadow coarse pass to compare)
                 assert counts[rep]["round6"][0] == nq  # the shadow coarse pass is the one that ran
-        # nobody's band can be formed: every query goes through the queue to the block-per-query re-rank and on to the canonical fallback
+        # nobody's band can be formed: every query is computed exactly -- by its own wavefront inside the tail launch while the index has
+        # not met such a query for `coarse_slow_window` searches (window 0: always), through the queue to the block-per-query re-rank
+        # and on to the canonical fallback otherwise (coarse_slow_inline = 0: always); the default takes the first form once, then the second
         opt("ivf_eps_scale", "1e12")
-        c0 = capi.coarse_stats()
-        ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
-        same(ids, dis, oi, od)
-        c1 = capi.coarse_stats()
-        if metric != capi.METRIC_COSINE:
-            assert c1[1] - c0[1] == nq
+        for knobs in ({"coarse_slow_window": "0"}, {"coarse_slow_inline": "0"}, {}, {}):
+            for kn, v in knobs.items():
+                opt(kn, v)
+            c0 = capi.coarse_stats()
+            ids, dis = ix.search(q, k, "nprobe=%d" % nprobe)
+            same(ids, dis, oi, od)
+            c1 = capi.coarse_stats()
+            if metric != capi.METRIC_COSINE:
+                assert c1[1] - c0[1] == nq, knobs
+            for kn in knobs:
+                opt(kn, None)
         opt("ivf_eps_scale", None)
         ix.close()
 
