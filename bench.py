@@ -1549,8 +1549,7 @@ def compact_line(out):
     line["recall_at_10"] = out.get("recall_at_10")
     line["p50_ms_batch1"] = out.get("p50_ms_batch1")
     line["roofline"] = {k_: roof.get(k_) for k_ in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "launches_per_step",
-                                                     "bytes_per_launch", "whole_step_frac", "non_scan_ms_per_step", "pruned_pair_fraction",
-                                                     "launches_all_per_step")}
+                                                     "bytes_per_launch", "whole_step_frac", "non_scan_ms_per_step", "pruned_pair_fraction")}
     line["roofline"]["kernel"] = (roof.get("kernel") or "").split(" (")[0]
     line["cpu_baseline"] = {"value": cpu.get("value"), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
                             "sample": (cpu.get("sample") or "")[:60],
