@@ -106,6 +106,26 @@ static void index_build_shadow(msvs_index & ix, hipStream_t stream)
     memcpy(&maxabs, &bits, 4);
     if (!(maxabs < 3.0e38f))
         return;
+    // The centroid table shares the rows' scale (one set of query images serves the coarse pass and the list scan).  The centroids of
+    // an index's OWN rows never exceed them -- but a shard of a sharded index holds every centroid and only its own lists' rows: a
+    // component of somebody else's centroid beyond this shard's largest row cost the shard its centroid shadow, and with it the
+    // approximate centroid distances the routed search's pre-pruning reads (W = 8 over the bench data: 3 of 8 ranks pruned nothing,
+    // 4.5 instead of 1.0 ranks visited per query).  So the scale covers the centroids too, as long as that costs the rows at most two
+    // bits (centroids far beyond every row -- user-supplied ones -- still go without a shadow).
+    float cmax_tab = 0.f;
+    if (ix.type == MSVS_INDEX_IVFFLAT && ix.nlist && ix.centroids.p && ix.cnorm_max < 1e30f)
+    {
+        MSVS_HIP(hipMemsetAsync(mx.p, 0, 4, stream));
+        const size_t c4 = ix.nlist * (size_t)(ix.ld / 4);
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<size_t>(ceil_div(c4, (size_t)256), 4096)), dim3(256), 0, stream,
+                           reinterpret_cast<const float4 *>(ix.centroids.p), c4, mx.p);
+        MSVS_HIP(hipGetLastError());
+        MSVS_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, stream));
+        MSVS_HIP(hipStreamSynchronize(stream));
+        memcpy(&cmax_tab, &bits, 4);
+        if (cmax_tab > maxabs && cmax_tab <= 4.f * maxabs)
+            maxabs = cmax_tab;
+    }
     int ex = 0;
     if (maxabs > 0.f)
         (void)frexpf(maxabs, &ex); // maxabs < 2^ex  =>  |x| * 2^(14 - ex) < 2^14: no fp16 overflow

@@ -339,3 +339,84 @@ def test_routed_batch_beyond_one_sub_batch_matches_the_oracle():
         _same(gi, gd, ei[sel], ed[sel], ("big", rank))
         total += served
     assert q.shape[0] <= total <= world * q.shape[0]
+
+
+# ---------------------------------------------------------------------------------------- a shard whose rows are smaller than other shards' centroids
+
+def _small_case():
+    """Rank 0's lists (l % 4 == 0) hold rows around small centres, the other ranks' lists around centres four times as far out: every
+    shard holds EVERY centroid, and the centroid table shares the rows' fp16 scale."""
+    rng = np.random.default_rng(4242)
+    n, d, nlist = 60000, 48, 1024  # (1024 lists x >= 1024 queries: the batched coarse stage, with or without a centroid shadow)
+    centres = rng.standard_normal((nlist, d), dtype=np.float32)
+    centres[0::4] *= 1.0
+    centres[1::4] *= 4.0
+    centres[2::4] *= 4.0
+    centres[3::4] *= 4.0
+    x = (centres[rng.integers(0, nlist, n)] + 0.1 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    q = (centres[rng.integers(0, nlist, 4400)] + 0.1 * rng.standard_normal((4400, d), dtype=np.float32)).astype(np.float32)
+    return x, q, centres
+
+
+def _small_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import myscaledb_amd.capi as capi
+        from myscaledb_amd import sharded
+        capi.set_device(0)
+        x, q, centres = _small_case()
+        ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, x.shape[1], "ncentroids=%d,shard_rank=%d,shard_world=%d" % (centres.shape[0], rank, world))
+        ix.set_centroids(centres)
+        ix.add(x)
+        ix.build()
+        comm = sharded.gloo_comm()
+        sel = np.arange(rank * 1100, (rank + 1) * 1100)  # 1100 queries per rank: the batched coarse stage
+        dq = torch.from_numpy(q[sel]).cuda()
+        oi = torch.full((len(sel), K), -7, dtype=torch.int64, device="cuda")
+        od = torch.empty((len(sel), K), dtype=torch.float32, device="cuda")
+        served = 0
+        for _ in range(2):  # (the first step gathers the lists' radii; the second routes by them from the start)
+            served = ix.shard_search_routed_device(comm, dq.data_ptr(), len(sel), K, NPROBE, oi.data_ptr(), od.data_ptr())
+            torch.cuda.synchronize()
+        out.put((rank, sel, oi.cpu().numpy(), od.cpu().numpy(), served))
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_routed_pruning_on_a_shard_whose_rows_are_smaller_than_the_other_shards_centroids():
+    """Round 6, found by running bench.py --gpus 8 on one GPU: a shard keeps every centroid but only its own lists' rows, and the centroid
+    shadow shares the rows' fp16 scale -- a shard whose largest row component was below the largest centroid component had no centroid
+    shadow, hence no approximate centroid distances, hence no pre-pruning of ITS queries: they visited every rank that owned a probe
+    (3.6 ranks per query at W = 8 on the bench data instead of 1.0).  The scale now covers the centroids.  Results == the oracle's, and
+    the routed pairs stay near one per query on well separated blobs."""
+    import myscaledb_amd.capi as capi
+    world = 4
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_small_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    x, q, centres = _small_case()
+    ix = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_L2, x.shape[1], "ncentroids=%d" % centres.shape[0])
+    ix.set_centroids(centres)
+    ix.add(x)
+    ix.build()
+    cent, off, vecs, lids = ix.export()
+    ix.close()
+    ei, ed, _ = o.ivf_search(cent, off, vecs, lids, q, NPROBE, K, o.METRIC_L2)
+    total = served = 0
+    for rank, sel, gi, gd, sv in res:
+        _same(gi, gd, ei[sel], ed[sel], ("small rows", rank))
+        total += len(sel)
+        served += sv
+    assert total <= served <= 1.3 * total, "pre-pruning did not route: %d pairs for %d queries over %d ranks" % (served, total, world)
