@@ -655,7 +655,7 @@ const OptionField g_option_fields[] = {
     {"h16_min_pairs", &Options::h16_min_pairs}, {"h16_ncb", &Options::h16_ncb},
     {"h16_nocut", &Options::h16_nocut},     {"fb_cap", &Options::fb_cap},           {"rerank_second", &Options::rerank_second}, {"rerank_fused", &Options::rerank_fused},
     {"lat_path", &Options::lat_path},         {"filter_compact_below", &Options::filter_compact_below},
-    {"bm25_wave", &Options::bm25_wave},     {"rerank_hint", &Options::rerank_hint}, {"coarse_band", &Options::coarse_band}, {"coarse_tail", &Options::coarse_tail}, {"coarse_slow_inline", &Options::coarse_slow_inline}, {"coarse_slow_window", &Options::coarse_slow_window}, {"coarse_gemm_tq", &Options::coarse_gemm_tq}, {"coarse_gemm_tc", &Options::coarse_gemm_tc}, {"h16_prune", &Options::h16_prune}, {"h16_feedback", &Options::h16_feedback}, {"h16_group_appends", &Options::h16_group_appends}, {"h16_preprune", &Options::h16_preprune}, {"lat_prune", &Options::lat_prune}, {"lat_items", &Options::lat_items}, {"lat_hint", &Options::lat_hint},     {"bm25_posting", &Options::bm25_posting}, {"bm25_sub_docs", &Options::bm25_sub_docs}, {"bm25_dbg", &Options::bm25_dbg},
+    {"bm25_wave", &Options::bm25_wave},     {"rerank_hint", &Options::rerank_hint}, {"coarse_band", &Options::coarse_band}, {"coarse_tail", &Options::coarse_tail}, {"merge_small", &Options::merge_small}, {"route_streams", &Options::route_streams}, {"coarse_slow_inline", &Options::coarse_slow_inline}, {"coarse_slow_window", &Options::coarse_slow_window}, {"coarse_gemm_tq", &Options::coarse_gemm_tq}, {"coarse_gemm_tc", &Options::coarse_gemm_tc}, {"h16_prune", &Options::h16_prune}, {"h16_feedback", &Options::h16_feedback}, {"h16_group_appends", &Options::h16_group_appends}, {"h16_preprune", &Options::h16_preprune}, {"lat_prune", &Options::lat_prune}, {"lat_items", &Options::lat_items}, {"lat_hint", &Options::lat_hint},     {"bm25_posting", &Options::bm25_posting}, {"bm25_sub_docs", &Options::bm25_sub_docs}, {"bm25_dbg", &Options::bm25_dbg},
     {"h16_rho", &Options::h16_rho}, {"h16_segs", &Options::h16_segs}, {"h16_stamps", &Options::h16_stamps},   {"flat_h16", &Options::flat_h16},     {"flat_segb", &Options::flat_segb}, {"flat_rot", &Options::flat_rot}, {"flat_lazy_flush", &Options::flat_lazy_flush},   {"flat_ncb", &Options::flat_ncb},
     {"bm25_emit", &Options::bm25_emit},     {"bm25_cand_cap", &Options::bm25_cand_cap},
     {"flat_few", &Options::flat_few},

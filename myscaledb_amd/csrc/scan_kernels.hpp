@@ -1267,6 +1267,69 @@ __global__ __launch_bounds__(BLOCK) void merge_kernel(const MergeParams a)
     }
 }
 
+/// The merge of a FEW short lists (nparts * k <= 256: the result exchange of a sharded search, the per-part lists of a multi-part
+/// search) straight from the (ids, dis) arrays, one WAVEFRONT per query: every key ranks itself among the others through a
+/// wave-private LDS slab and writes itself to its output slot -- no packing pass, no block per query (the general pair of launches costs
+/// ~40 us per 4096 queries whatever the lists hold: eight barriers around eighty keys).  Same keys, same order, same outputs as
+/// pack_keys_kernel + merge_kernel (mode 0): ascending (distance | descending for IP, id); an id < 0 or a distance that is not
+/// strictly better than the neutral value is no entry; unfilled slots are id -1, distance +-FLT_MAX.
+template <int METRIC>
+__global__ __launch_bounds__(BLOCK) void merge_small_kernel(const int64_t * ids, size_t ids_stride, const float * dis, size_t dis_stride,
+                                                            uint32_t nparts, uint32_t nq, uint32_t k, int64_t * out_ids, float * out_dis)
+{
+    __shared__ uint64_t s_keys[BLOCK / WAVE][256];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * (BLOCK / WAVE) + wave;
+    if (q >= nq)
+        return;
+    const uint32_t n = nparts * k;
+    uint64_t mine[4];
+    uint32_t valid = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+        const uint32_t i = (uint32_t)u * WAVE + lane;
+        uint64_t key = KEY_NONE;
+        if (i < n)
+        {
+            const uint32_t p = i / k, j = i - p * k;
+            const size_t rem = (size_t)q * k + j;
+            const int64_t id = ids[p * ids_stride + rem];
+            const float d = dis[p * dis_stride + rem];
+            key = id < 0 ? KEY_NONE : make_key<METRIC>(d, (uint32_t)id);
+        }
+        mine[u] = key;
+        s_keys[wave][i] = key;
+        valid += (uint32_t)__popcll(__ballot(key != KEY_NONE));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-private LDS: the wavefront's own writes, in order
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+        const uint32_t i = (uint32_t)u * WAVE + lane;
+        if ((uint32_t)u * WAVE >= n) // (uniform)
+            break;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++)
+        {
+            const uint64_t kj = s_keys[wave][j];
+            rank += kj < mine[u] || (kj == mine[u] && j < i) ? 1u : 0u;
+        }
+        if (mine[u] != KEY_NONE && rank < k)
+        {
+            const size_t o = (size_t)q * k + rank;
+            out_ids[o] = (int64_t)(uint32_t)mine[u];
+            out_dis[o] = key_value<METRIC>(mine[u]);
+        }
+    }
+    for (uint32_t r = valid + lane; r < k; r += WAVE)
+    {
+        out_ids[(size_t)q * k + r] = -1;
+        out_dis[(size_t)q * k + r] = key_value<METRIC>(KEY_NONE);
+    }
+}
+
 /// (ids, dis) lists of `nparts` shards -> keys in the merge kernel's layout [nq][nparts][k].
 /// Shard p's lists start at ids + p * ids_stride / dis + p * dis_stride (element strides), each [nq][k].
 template <int METRIC>

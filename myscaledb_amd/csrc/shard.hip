@@ -22,6 +22,19 @@ void merge_topk_device(const int64_t * d_ids, size_t ids_stride, const float * d
     if (nq == 0 || k == 0)
         return;
     check_k(k);
+    if (nparts * k <= 256 && nq <= 0xfffffff0ull && options().merge_small != 0)
+    {
+        // a few short lists per query: one wavefront ranks them (merge_small_kernel)
+        const dim3 grid((unsigned)ceil_div(nq, (size_t)(BLOCK / WAVE)));
+        if (metric == MSVS_METRIC_IP)
+            hipLaunchKernelGGL((merge_small_kernel<M_IP>), grid, dim3(BLOCK), 0, stream, d_ids, ids_stride, d_dis, dis_stride, (uint32_t)nparts,
+                               (uint32_t)nq, (uint32_t)k, d_out_ids, d_out_dis);
+        else
+            hipLaunchKernelGGL((merge_small_kernel<M_L2>), grid, dim3(BLOCK), 0, stream, d_ids, ids_stride, d_dis, dis_stride, (uint32_t)nparts,
+                               (uint32_t)nq, (uint32_t)k, d_out_ids, d_out_dis);
+        MSVS_HIP(hipGetLastError());
+        return;
+    }
     Scratch & scr = scratch_for(stream);
     const size_t total = nparts * nq * k;
     scr.reserve(total * 8 + 8192, stream);
@@ -616,40 +629,66 @@ struct RoutePack
     RouteTab to;             // region / cnt / first of every destination
 };
 
-/// One wavefront per query: an entry in the region of every destination in its mask.  Region of cnt entries:
+/// An entry in the region of every destination in a query's mask.  Region of cnt entries:
 /// qidx u32[cnt] | probes i32[cnt][np] (the destination's lists only) | words u32[cnt][np] | vectors f32[cnt][d].
-__global__ __launch_bounds__(64) void route_pack_kernel(const RoutePack a)
+/// A workgroup takes 16 queries: their slots in the regions are reserved with ONE atomic per destination and workgroup (a returning
+/// atomic per query and destination on the same word serialises in L2: 54 us for 4096 queries going to one rank, 25 to two), then each
+/// of the four wavefronts copies four queries.
+constexpr uint32_t ROUTE_PACK_Q = 16;
+__global__ __launch_bounds__(256) void route_pack_kernel(const RoutePack a)
 {
-    const uint32_t q = blockIdx.x, lane = threadIdx.x;
-    uint32_t m = a.mask[q];
-    while (m)
+    __shared__ uint32_t s_slot[ROUTE_PACK_Q][ROUTE_MAX_RANKS];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q0 = blockIdx.x * ROUTE_PACK_Q;
+    if (wave == 0)
     {
-        const uint32_t t = (uint32_t)__builtin_ctz(m);
-        m &= m - 1;
-        uint32_t slot = 0;
-        if (lane == 0)
-            slot = atomicAdd(&a.cursor[t], 1u);
-        slot = (uint32_t)__shfl((int)slot, 0);
-        const uint32_t cnt = a.to.cnt[t];
-        unsigned char * const reg = a.send + a.to.region[t];
-        uint32_t * const qidx = reinterpret_cast<uint32_t *>(reg);
-        int32_t * const pr = reinterpret_cast<int32_t *>(reg + (size_t)cnt * 4) + (size_t)slot * a.np;
-        uint32_t * const wd = reinterpret_cast<uint32_t *>(reg + (size_t)cnt * 4 * (1 + a.np)) + (size_t)slot * a.np;
-        float * const vec = reinterpret_cast<float *>(reg + (size_t)cnt * 4 * (1 + 2 * (size_t)a.np)) + (size_t)slot * a.d;
-        if (lane == 0)
+        const uint32_t mq = lane < ROUTE_PACK_Q && q0 + lane < a.nq ? a.mask[q0 + lane] : 0u;
+        for (uint32_t t = 0; t < a.W; t++)
         {
-            qidx[slot] = q;
-            a.sent_q[a.to.first[t] + slot] = q;
+            const bool has = (mq >> t) & 1u;
+            const uint64_t b = __ballot(has);
+            if (!b)
+                continue;
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&a.cursor[t], (uint32_t)__popcll(b));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (has)
+                s_slot[lane][t] = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
         }
-        for (uint32_t j = lane; j < a.np; j += 64)
+    }
+    __syncthreads();
+    for (uint32_t i = 0; i < ROUTE_PACK_Q / 4; i++)
+    {
+        const uint32_t qi = wave * (ROUTE_PACK_Q / 4) + i, q = q0 + qi;
+        if (q >= a.nq)
+            break;
+        uint32_t m = a.mask[q];
+        while (m)
         {
-            const int32_t l = a.probes[(size_t)q * a.np + j];
-            const bool here = l >= 0 && (uint32_t)l % a.W == t;
-            pr[j] = here ? l : -1;
-            wd[j] = here ? a.words[(size_t)q * a.np + j] : 0xFFFFFFFFu;
+            const uint32_t t = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            const uint32_t slot = s_slot[qi][t];
+            const uint32_t cnt = a.to.cnt[t];
+            unsigned char * const reg = a.send + a.to.region[t];
+            uint32_t * const qidx = reinterpret_cast<uint32_t *>(reg);
+            int32_t * const pr = reinterpret_cast<int32_t *>(reg + (size_t)cnt * 4) + (size_t)slot * a.np;
+            uint32_t * const wd = reinterpret_cast<uint32_t *>(reg + (size_t)cnt * 4 * (1 + a.np)) + (size_t)slot * a.np;
+            float * const vec = reinterpret_cast<float *>(reg + (size_t)cnt * 4 * (1 + 2 * (size_t)a.np)) + (size_t)slot * a.d;
+            if (lane == 0)
+            {
+                qidx[slot] = q;
+                a.sent_q[a.to.first[t] + slot] = q;
+            }
+            for (uint32_t j = lane; j < a.np; j += 64)
+            {
+                const int32_t l = a.probes[(size_t)q * a.np + j];
+                const bool here = l >= 0 && (uint32_t)l % a.W == t;
+                pr[j] = here ? l : -1;
+                wd[j] = here ? a.words[(size_t)q * a.np + j] : 0xFFFFFFFFu;
+            }
+            for (uint32_t c = lane; c < a.d; c += 64)
+                vec[c] = a.Q[(size_t)q * a.d + c];
         }
-        for (uint32_t c = lane; c < a.d; c += 64)
-            vec[c] = a.Q[(size_t)q * a.d + c];
     }
 }
 
@@ -1120,7 +1159,7 @@ void routed_back(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, hipS
         pk.send = send;
         pk.sent_q = sent_q;
         pk.to = to;
-        hipLaunchKernelGGL(route_pack_kernel, dim3((unsigned)nq), dim3(64), 0, cs, pk);
+        hipLaunchKernelGGL(route_pack_kernel, dim3((unsigned)ceil_div(nq, (size_t)ROUTE_PACK_Q)), dim3(256), 0, cs, pk);
         MSVS_HIP(hipGetLastError());
     }
     hand_over(pp, 0, cs, xs);
@@ -1257,12 +1296,14 @@ extern "C" int msvs_shard_search_routed_device_async(const msvs_index_t * ix, co
         MSVS_HIP(hipEventRecord(st.in_ev, as_stream(hip_stream)));
         MSVS_HIP(hipStreamWaitEvent(pp.compute, st.in_ev, 0));
         routed_fill(st, ix, d_queries, nq, k, nprobe, d_alive_bits, nbits, d_ids, d_dis, routed_pairs);
-        routed_front(pp, st, comm, true, pp.compute, pp.xchg);
+        // (route_streams = 1: the exchange runs in the compute stream's order -- no hand-over events, no overlap of the exchange with compute)
+        hipStream_t const xs = options().route_streams == 1 ? pp.compute : pp.xchg;
+        routed_front(pp, st, comm, true, pp.compute, xs);
         st.pending = true;
         if (prev.pending)
         {
             prev.pending = false; // (whatever happens below, the step is over)
-            routed_back(pp, prev, comm, pp.compute, pp.xchg);
+            routed_back(pp, prev, comm, pp.compute, xs);
             MSVS_HIP(hipEventRecord(prev.done_ev, pp.compute));
             if (prev_done_event)
                 *prev_done_event = prev.done_ev;
@@ -1295,7 +1336,7 @@ extern "C" int msvs_shard_search_drain(const msvs_comm_t * comm, void * hip_stre
             if (!st.pending)
                 continue;
             st.pending = false;
-            routed_back(rp, st, comm, rp.compute, rp.xchg);
+            routed_back(rp, st, comm, rp.compute, options().route_streams == 1 ? rp.compute : rp.xchg);
             MSVS_HIP(hipEventRecord(st.done_ev, rp.compute));
         }
         if (rp.calls)
