@@ -1244,12 +1244,33 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     uint32_t * seg_words = want_segs ? scr.take<uint32_t>(2) : nullptr;
     pp.seg_out = seg_words;
     pp.seg_target_items = 4 * device_cu_count();
+    // the queries' fp16 images: the coarse pass over the centroid shadow left them behind, or they are made here -- in FRONT of the plan
+    // when that launch can clear the counters on its way (a search with given probes: the searching side of a routed step; a memset
+    // between two kernels is a barrier packet, ~8 us of idle device)
+    float * qnorm = prepared.qh ? prepared.qnorm : scr.take<float>(nq);
+    uint4 * qh = prepared.qh ? prepared.qh : scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + 64); // + what the register kernel may read past the last image
+    float2 * qinfo = prepared.qh ? prepared.qinfo : scr.take<float2>(nq);
+    float * qrho = prepared.qh ? prepared.qrho : scr.take<float>(nq);
+    bool prep_done = prepared.qh != nullptr;
+    auto prep = [&](const H16PrepAux & aux) {
+        ProfileScope prof("ivf_prep", stream);
+        hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq,
+                           (uint32_t)nq, ld, ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, aux, qrho);
+        prep_done = true;
+    };
     if (!zeroed)
     {
         if (ivf_plan_fused(pp)) // (a small batch: the one-launch plan needs no zeroed counts and clears nfail / the cursors / nfail2 itself)
         {
             pp.zero = nfail;
             pp.nzero = 18;
+        }
+        else if (!prep_done)
+        {
+            H16PrepAux aux{};
+            aux.zero[0] = counters;
+            aux.nzero[0] = (uint32_t)n_counters;
+            prep(aux);
         }
         else
             MSVS_HIP(hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), stream));
@@ -1274,8 +1295,10 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     if (prepared.prepruned && ix.plan_fb.pairs && options().h16_prune != 2 && options().h16_feedback != 0)
     {
         const uint32_t seen = *reinterpret_cast<volatile uint32_t *>(ix.plan_fb.pairs);
-        if (seen != 0xFFFFFFFFu && ix.plan_fb.nq == (uint32_t)nq && ix.plan_fb.nprobe == (uint32_t)nprobe)
-            eff_pairs = std::min(eff_pairs, 1.25 * (double)seen + 64.0);
+        // (the same nprobe; another batch size scales the count: the searching side of a routed step sees a few queries more or less
+        // every time)
+        if (seen != 0xFFFFFFFFu && ix.plan_fb.nq != 0 && ix.plan_fb.nprobe == (uint32_t)nprobe)
+            eff_pairs = std::min(eff_pairs, 1.25 * (double)seen * ((double)nq / (double)ix.plan_fb.nq) + 64.0);
         ix.plan_fb.nq = (uint32_t)nq;
         ix.plan_fb.nprobe = (uint32_t)nprobe;
         fb_out = ix.plan_fb.pairs;
@@ -1295,22 +1318,13 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
     pp.pairs_out = nullptr;
     IvfPlanParams pa = pp;
     pa.work_off = pp.work_off2;
-    // the queries' fp16 images: the coarse pass over the centroid shadow left them behind, or they are made here
-    float * qnorm = prepared.qh ? prepared.qnorm : scr.take<float>(nq);
-    uint4 * qh = prepared.qh ? prepared.qh : scr.take<uint4>(nq * (size_t)ix.h_nch * 8 + 64); // + what the register kernel may read past the last image
-    float2 * qinfo = prepared.qh ? prepared.qinfo : scr.take<float2>(nq);
-    float * qrho = prepared.qh ? prepared.qrho : scr.take<float>(nq);
     uint32_t * sample = scr.take<uint32_t>(nq * nprobe * H_ROWS);
     uint32_t * qstate = scr.take<uint32_t>(2 * nq);
     uint64_t * cand = scr.take<uint64_t>(nq * (size_t)pl.kc);
     uint64_t * bound = scr.take<uint64_t>(nq);
     uint32_t * failq = scr.take<uint32_t>(nq);
-    if (!prepared.qh)
-    {
-        ProfileScope prof("ivf_prep", stream);
-        hipLaunchKernelGGL(h16_prep_queries_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(256), 0, stream, dq,
-                           (uint32_t)nq, ld, ix.h_nch, ix.h_inv_scale, m == MSVS_METRIC_L2 ? 0 : 1, qh, qinfo, qnorm, 1, H16PrepAux{}, qrho);
-    }
+    if (!prep_done)
+        prep(H16PrepAux{});
     // (no fill of `sample`: the sample launch writes all 32 words of every pair whose list has rows, and the cut kernels
     // take a pair whose list is empty as 32 missing rows)
     H16Params a{};
@@ -1752,7 +1766,10 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
         return;
     }
     if (given_probes)
+    {
         prepared.probe_words = words.given;
+        prepared.prepruned = true; // (a routed search: the sending rank dropped what it could; the plan's own count tells the next search)
+    }
     const int32_t * all_probes = d_probes;
     (void)all_probes;
     {
