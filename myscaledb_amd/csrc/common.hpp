@@ -222,7 +222,8 @@ struct Options
     double coarse_gemm_tc = 128; // ... and centroids (64 or 128)
     double coarse_slow_inline = 1; // coarse_tail_kernel: a query without a band computed exactly by its own wavefront while such queries are rare (0: always the queue + its three launches)
     double coarse_slow_window = 64; // ... rare = none in this many batched searches of the index
-    double route_streams = 2; // msvs_shard_search_routed_device_async: 2 = exchange on its own stream (hand-over events, overlap), 1 = in the compute stream's order
+    double route_streams = 1; // msvs_shard_search_routed_device_async: 1 = the exchanges in the compute stream's order; 2 = on their own stream (four event hand-overs
+                              // per step, and -- FRONT(i) being enqueued ahead of BACK(i - 1) -- nothing they could overlap with: 0.70 against 0.63 ms on one rank)
     double merge_small = 1;   // msvs_merge_topk_device: nparts * k <= 256 keys per query merged by one wavefront (0: pack + block merge)
     double coarse_tail = 1;   // coarse quantiser of batches: selection + band re-rank in one launch, a wavefront per query (0: coarse_select_kernel + ivf_rerank_kernel)
     double coarse_band = 1;   // coarse quantiser of batches: only the candidates near the top-nprobe boundary are evaluated canonically (0: all 64)

@@ -1296,7 +1296,8 @@ extern "C" int msvs_shard_search_routed_device_async(const msvs_index_t * ix, co
         MSVS_HIP(hipEventRecord(st.in_ev, as_stream(hip_stream)));
         MSVS_HIP(hipStreamWaitEvent(pp.compute, st.in_ev, 0));
         routed_fill(st, ix, d_queries, nq, k, nprobe, d_alive_bits, nbits, d_ids, d_dis, routed_pairs);
-        // (route_streams = 1: the exchange runs in the compute stream's order -- no hand-over events, no overlap of the exchange with compute)
+        // (route_streams = 1, the default: the exchanges run in the compute stream's order -- no hand-over events; with FRONT(i) enqueued ahead of
+        // BACK(i - 1) a second stream has nothing to overlap them with)
         hipStream_t const xs = options().route_streams == 1 ? pp.compute : pp.xchg;
         routed_front(pp, st, comm, true, pp.compute, xs);
         st.pending = true;
