@@ -496,7 +496,7 @@ def main():
             j = (i * world + rank) % n_pool
             slot = routed_slots[i % 3]  # (batch i - 1 is still in flight and batch i - 2's event has just been handed out)
             ix.shard_search_routed_device_async(comm, q_all[j * B:(j + 1) * B].data_ptr(), B, k, nprobe, slot[0].data_ptr(), slot[1].data_ptr(),
-                                                stream, served=slot[2])
+                                                stream, served=slot[2], want_event=False)
             routed_live.append(slot[2])
             return
         q = q_all[(i % n_pool) * B:(i % n_pool + 1) * B]

@@ -555,15 +555,18 @@ class Index:
             _check(lib().msvs_shard_search_routed_device(self._h, comm._h, q, C.c_size_t(nq), int(k), int(nprobe), oi, od, st, C.byref(served)))
         return served.value
 
-    def shard_search_routed_device_async(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0, served=None):
+    def shard_search_routed_device_async(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0, served=None,
+                                         want_event=True):
         """msvs_shard_search_routed_device_async: two routed steps in flight.  Returns the done event of the PREVIOUS call's batch (None at
-        the first call); `served` (a ctypes c_uint64 the caller keeps alive) receives this batch's routed pairs when ITS back phase runs."""
+        the first call; never asked for with want_event=False: a caller that stays on one stream and drains at the end needs none, and an
+        event record between two kernels is ~8 us of idle device); `served` (a ctypes c_uint64 the caller keeps alive) receives this
+        batch's routed pairs when ITS back phase runs."""
         ev = C.c_void_p()
         _check(lib().msvs_shard_search_routed_device_async(self._h, comm._h, C.c_void_p(int(d_queries)) if d_queries else None, C.c_size_t(nq), int(k),
                                                            int(nprobe), C.c_void_p(int(d_alive)) if d_alive else None, C.c_size_t(nbits),
                                                            C.c_void_p(int(d_ids)) if d_ids else None, C.c_void_p(int(d_dis)) if d_dis else None,
                                                            C.c_void_p(int(stream)) if stream else None,
-                                                           C.byref(served) if served is not None else None, C.byref(ev)))
+                                                           C.byref(served) if served is not None else None, C.byref(ev) if want_event else None))
         return ev.value
 
     def shard_search_device_async(self, comm, d_queries, nq, k, nprobe, d_ids, d_dis, stream=0, d_alive=0, nbits=0):

@@ -878,6 +878,10 @@ struct RoutePipe
     Scratch back;
     uint64_t calls = 0;
     bool peers_filtered = false;
+    // route_streams = 1: the pipelined steps run on the CALLER's stream (no internal stream, no events while the caller stays on one
+    // stream); `last` = the stream the step in flight was enqueued on
+    hipStream_t last = nullptr;
+    bool has_last = false;
     std::mutex mu;
 };
 
@@ -1292,22 +1296,48 @@ extern "C" int msvs_shard_search_routed_device_async(const msvs_index_t * ix, co
             fail(MSVS_ERR_DEVICE, "internal: routed slot still pending");
         if (prev_done_event)
             *prev_done_event = nullptr;
-        // inputs: whatever the caller's stream has enqueued so far
-        MSVS_HIP(hipEventRecord(st.in_ev, as_stream(hip_stream)));
-        MSVS_HIP(hipStreamWaitEvent(pp.compute, st.in_ev, 0));
+        hipStream_t const caller = as_stream(hip_stream);
+        // route_streams = 1 (the default): everything in the caller's stream's order -- FRONT(i), then BACK(i - 1): no internal stream, no
+        // event while the caller stays on one stream (an event record between two kernels is a barrier packet: ~8 us of idle device; the
+        // two-stream form had five hand-overs per step and -- FRONT(i) being enqueued ahead of BACK(i - 1) -- nothing to overlap the
+        // exchanges with).  What the pipelined form buys is that the host never waits for the count matrix.
+        const bool own = options().route_streams == 1;
+        hipStream_t const cs = own ? caller : pp.compute, xs = own ? caller : pp.xchg;
+        if (own)
+        {
+            if (pp.has_last && pp.last != caller) // the step in flight was enqueued elsewhere: this stream continues behind it
+            {
+                MSVS_HIP(hipEventRecord(pp.hand[1], pp.last));
+                MSVS_HIP(hipStreamWaitEvent(caller, pp.hand[1], 0));
+            }
+            pp.last = caller;
+            pp.has_last = true;
+        }
+        else
+        {
+            if (pp.has_last) // (the option changed while a step was in flight on a caller's stream: the internal stream continues behind it)
+            {
+                MSVS_HIP(hipEventRecord(pp.hand[1], pp.last));
+                MSVS_HIP(hipStreamWaitEvent(pp.compute, pp.hand[1], 0));
+                pp.has_last = false;
+            }
+            // inputs: whatever the caller's stream has enqueued so far
+            MSVS_HIP(hipEventRecord(st.in_ev, caller));
+            MSVS_HIP(hipStreamWaitEvent(pp.compute, st.in_ev, 0));
+        }
         routed_fill(st, ix, d_queries, nq, k, nprobe, d_alive_bits, nbits, d_ids, d_dis, routed_pairs);
-        // (route_streams = 1, the default: the exchanges run in the compute stream's order -- no hand-over events; with FRONT(i) enqueued ahead of
-        // BACK(i - 1) a second stream has nothing to overlap them with)
-        hipStream_t const xs = options().route_streams == 1 ? pp.compute : pp.xchg;
-        routed_front(pp, st, comm, true, pp.compute, xs);
+        routed_front(pp, st, comm, true, cs, xs);
         st.pending = true;
         if (prev.pending)
         {
             prev.pending = false; // (whatever happens below, the step is over)
-            routed_back(pp, prev, comm, pp.compute, xs);
-            MSVS_HIP(hipEventRecord(prev.done_ev, pp.compute));
-            if (prev_done_event)
-                *prev_done_event = prev.done_ev;
+            routed_back(pp, prev, comm, cs, xs);
+            if (!own || prev_done_event)
+            {
+                MSVS_HIP(hipEventRecord(prev.done_ev, cs));
+                if (prev_done_event)
+                    *prev_done_event = prev.done_ev;
+            }
         }
     });
 }
@@ -1331,18 +1361,21 @@ extern "C" int msvs_shard_search_drain(const msvs_comm_t * comm, void * hip_stre
             return;
         RoutePipe & rp = *rpp;
         std::lock_guard<std::mutex> lk(rp.mu);
+        // (route_streams = 1: the steps live on the stream of the call that enqueued them -- rp.last)
+        const bool own = rp.has_last;
+        hipStream_t const cs = own ? rp.last : rp.compute, xs = own ? rp.last : rp.xchg;
         for (int i = 0; i < 2; i++)
         {
             RoutedStep & st = rp.step[(rp.calls + i) & 1]; // oldest first
             if (!st.pending)
                 continue;
             st.pending = false;
-            routed_back(rp, st, comm, rp.compute, options().route_streams == 1 ? rp.compute : rp.xchg);
-            MSVS_HIP(hipEventRecord(st.done_ev, rp.compute));
+            routed_back(rp, st, comm, cs, xs);
+            MSVS_HIP(hipEventRecord(st.done_ev, cs));
         }
-        if (rp.calls)
+        if (rp.calls && cs != as_stream(hip_stream))
         {
-            MSVS_HIP(hipEventRecord(rp.hand[1], rp.compute));
+            MSVS_HIP(hipEventRecord(rp.hand[1], cs));
             MSVS_HIP(hipStreamWaitEvent(as_stream(hip_stream), rp.hand[1], 0));
         }
     });

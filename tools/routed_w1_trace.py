@@ -30,7 +30,7 @@ def step(i):
     s = slots[i % 3]
     qp = q_all[(i % 8) * B:(i % 8 + 1) * B].data_ptr()
     if use_async:
-        ix.shard_search_routed_device_async(comm, qp, B, k, nprobe, s[0].data_ptr(), s[1].data_ptr(), st, served=s[2])
+        ix.shard_search_routed_device_async(comm, qp, B, k, nprobe, s[0].data_ptr(), s[1].data_ptr(), st, served=s[2], want_event=False)
     else:
         ix.shard_search_routed_device(comm, qp, B, k, nprobe, s[0].data_ptr(), s[1].data_ptr(), st)
 
