@@ -332,12 +332,14 @@ MSVS_API int msvs_shard_search_routed_device(const msvs_index_t * shard, const m
 MSVS_API int msvs_shard_search_routed_filtered_device(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries,
                                                       size_t nq, int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits,
                                                       int64_t * d_ids, float * d_dis, void * hip_stream, uint64_t * routed_pairs);
-/* The routed search with TWO STEPS IN FLIGHT: call i enqueues the FRONT phase of its batch (communicator's compute + exchange
- * streams; `hip_stream` orders the inputs only) and then the BACK phase of batch i - 1, whose count matrix was gathered one call
- * ago -- the host does not wait for the device while the list scan of step i - 1 and the coarse stage of step i are still to run.
- * The results (and *routed_pairs) of batch i are complete when the event handed out by call i + 1 in *prev_done_event has fired
- * (nullptr at the first call), or after msvs_shard_search_drain -- which is COLLECTIVE while a routed step is pending (it runs that
- * step's back phase).  Buffers of a batch stay untouched until then; every rank issues the same sequence of calls. */
+/* The routed search with TWO STEPS IN FLIGHT: call i enqueues the FRONT phase of its batch and then the BACK phase of batch i - 1,
+ * whose count matrix was gathered one call ago -- the host does not wait for the device while the list scan of step i - 1 and the
+ * coarse stage of step i are still to run.  Both phases run in `hip_stream`'s order (option route_streams = 2: on the communicator's
+ * own compute + exchange streams, `hip_stream` ordering the inputs only); a call on another stream than the previous one continues
+ * behind it.  The results (and *routed_pairs) of batch i are complete when call i + 1's work on its stream is -- or when the event
+ * handed out by call i + 1 in *prev_done_event has fired (prev_done_event may be NULL: no event is recorded then; nullptr at the
+ * first call) -- or after msvs_shard_search_drain, which is COLLECTIVE while a routed step is pending (it runs that step's back
+ * phase).  Buffers of a batch stay untouched until then; every rank issues the same sequence of calls. */
 MSVS_API int msvs_shard_search_routed_device_async(const msvs_index_t * shard, const msvs_comm_t * comm, const float * d_queries, size_t nq,
                                                    int k, int nprobe, const uint64_t * d_alive_bits, size_t nbits, int64_t * d_ids,
                                                    float * d_dis, void * hip_stream, uint64_t * routed_pairs, void ** prev_done_event);
