@@ -993,6 +993,7 @@ struct H16Prune
                                // slack included, rounded up (+inf: none); the second stage takes the smaller of its own bound and this
     int32_t * out_probes;      // [nq][nprobe]: the probes that survive (-1: dropped or absent)
     unsigned long long * stat; // nullable: [0] += pairs dropped, [1] += pairs
+    int stat_all = 1;          // the second stage: 0 = a pre-pruning (here or on the rank the probes came from) has counted the pairs
 };
 
 /// PRE-PRUNING (round 4; L2 indexes, no filter): before a single sample row is scored, the list radius alone rules most pairs
@@ -1150,12 +1151,13 @@ static __global__ __launch_bounds__(BLOCK) void h16_preprune_kernel(const int32_
     }
     if (pr.stat)
     {
-        // [0] pairs dropped, [1] pairs looked at: the second stage counts the pairs it still sees, this one the pairs it takes away
-        const uint64_t dropped = __ballot(l >= 0 && !keep);
-        if (lane == 0 && dropped)
+        // [0] pairs dropped, [1] pairs looked at: every probe of the query here; a second stage behind this one adds what IT drops only
+        // (H16Prune::stat_all = 0)
+        const uint64_t dropped = __ballot(l >= 0 && !keep), all = __ballot(l >= 0);
+        if (lane == 0 && all)
         {
             atomicAdd(pr.stat, (unsigned long long)__popcll(dropped));
-            atomicAdd(pr.stat + 1, (unsigned long long)__popcll(dropped));
+            atomicAdd(pr.stat + 1, (unsigned long long)__popcll(all));
         }
     }
 }
@@ -1292,7 +1294,8 @@ __device__ inline void h16_sample_thr_wave(const uint32_t * src, const int32_t *
             if (lane == 0)
             {
                 atomicAdd(pr.stat, (unsigned long long)__popcll(dropped));
-                atomicAdd(pr.stat + 1, (unsigned long long)__popcll(all));
+                if (pr.stat_all)
+                    atomicAdd(pr.stat + 1, (unsigned long long)__popcll(all));
             }
         }
     }

@@ -191,6 +191,7 @@ struct ProbeWords
     const int64_t * g_list_off = nullptr;
     float g_xmax = 0.f, g_xmin = 0.f; // max / min |x|^2 over the rows of every rank (the bounds' error terms)
     int32_t * pruned_out = nullptr;
+    bool given_pruned = false; // with given_probes: they are what a pre-pruning on the rank they came from left (the routed search's back phase)
 };
 /// search_entry.hip: the canonical coarse quantiser of a small batch in one launch (-> false: not for this shape).
 bool coarse_few_launch(const msvs_index & ix, const float * dq, size_t nq, size_t nprobe, int32_t * d_probes, float * d_probe_dis,

@@ -1386,6 +1386,7 @@ static void h16_list_scan(const msvs_index & ix, Scratch & scr, int m, const flo
                 pr.out_probes = scr.take<int32_t>(nq * nprobe);
                 pr.upre = prepared.upre; // (null without the pre-pruning)
                 pr.stat = options().rerank_stats != 0 ? prefilter_fail_counter() + 8 : nullptr;
+                pr.stat_all = prepared.prepruned ? 0 : 1;
             }
             hipLaunchKernelGGL(h16_sample_thr_wave_kernel, dim3((unsigned)ceil_div(nq, (size_t)4)), dim3(BLOCK), 0, stream,
                                sample, plan_probes, ix.list_off.p, (uint32_t)nq, (uint32_t)nprobe, pl.h_mth, qstate,
@@ -1768,7 +1769,7 @@ static void index_search_device_one(const msvs_index & ix, const float * d_queri
     if (given_probes)
     {
         prepared.probe_words = words.given;
-        prepared.prepruned = true; // (a routed search: the sending rank dropped what it could; the plan's own count tells the next search)
+        prepared.prepruned = words.given_pruned; // (a routed search: the sending rank dropped what it could; the plan's own count tells the next search)
     }
     const int32_t * all_probes = d_probes;
     (void)all_probes;

@@ -1031,6 +1031,7 @@ void routed_back(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, hipS
     const msvs_index_t * ix = st.ix;
     const size_t W = (size_t)comm->nranks, r = (size_t)comm->rank, RW = W + ROUTE_HDR;
     std::vector<uint32_t> h_c(W * W);
+    bool senders_pruned = false; // (some rank's front phase pre-pruned what it sends)
     for (int attempt = 0;; attempt++)
     {
         // the matrix of this step (front phase): wait for its completion word
@@ -1089,6 +1090,7 @@ void routed_back(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, hipS
         const bool unsafe = any_filtered && any_pruned;
         if (!stale && !unsafe)
         {
+            senders_pruned = any_pruned;
             for (size_t s = 0; s < W; s++)
                 for (size_t t = 0; t < W; t++)
                     h_c[s * W + t] = st.h_c[s * RW + t];
@@ -1197,6 +1199,7 @@ void routed_back(RoutePipe & pp, RoutedStep & st, const msvs_comm_t * comm, hipS
         const uint64_t * eff = effective_filter(*ix, meta.get(), st.d_alive, st.nbits, &eff_bits, cs);
         ProbeWords gw{};
         gw.given = rw;
+        gw.given_pruned = senders_pruned;
         index_search_device(*ix, rq, n_in, (uint32_t)k, np, eff, eff_bits, r_ids, r_dis, cs, rp, nullptr, nullptr, gw);
         hipLaunchKernelGGL(route_result_kernel, dim3((unsigned)ceil_div(n_in * k, (size_t)256)), dim3(256), 0, cs, r_ids, r_dis, (uint32_t)n_in,
                            (uint32_t)k, (uint32_t)W, res_of, res);
