@@ -11,7 +11,7 @@ N > 1    : one process per GPU, libmsvs owns the RCCL communicator, lists sharde
            switches to the ROUTED form (msvs_shard_search_routed_device_async, two steps in flight): every rank brings its OWN batch
            of `--batch` queries per step, so `value` = N x batch queries per step / max-over-ranks time and "scaling" = "weak" -- weak
            in QUERIES over a FIXED index (a reader of SCALE: the ratio value(N) / value(1) is the gain in served queries per second
-           when N servers share one index, not a larger table).  The replicated form (msvs_shard_search_device_async: every rank works
+           when N servers share one index, not a larger table).  The replicated form (msvs_shard_search_device: every rank works
            through the same batch; strong scaling of one batch) is timed beside it under legs.multi_gpu.replicated.
            `python bench.py --gpus N` without a launcher spawns its N ranks itself (torch.distributed.run on 127.0.0.1).
 
@@ -382,7 +382,7 @@ def main():
     ap.add_argument("--skip", default="", help="comma list of legs to skip: other_batches,latency,iid,blobs03,latent32,mid,target,c1,c3,c4,c5,cpu")
     ap.add_argument("--shard-mode", default="routed", choices=("routed", "replicated"),
                     help="N > 1: every rank brings its own batch and queries are routed to the ranks that own their lists (default), or "
-                         "every rank works through the same batch (msvs_shard_search_device_async)")
+                         "every rank works through the same batch (msvs_shard_search_device)")
     ap.add_argument("--only", default="", help="comma list of legs to run (the others are skipped; the headline always runs)")
     ap.add_argument("--c4-rows", type=int, default=12_500_000, help="rows per GPU of the C4 leg (100M / 8)")
     ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the C3 / C5 legs")
@@ -501,8 +501,10 @@ def main():
             return
         q = q_all[(i % n_pool) * B:(i % n_pool + 1) * B]
         if world > 1:
-            # two batches in flight: batch i's top-k exchange + merge under batch i + 1's scan; fence() drains (device sync)
-            ix.shard_search_device_async(comm, q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
+            # the whole sharded search as ONE stream-ordered call (no host synchronisation).  (The two-batches-in-flight form,
+            # msvs_shard_search_device_async, hands over between two streams five times per batch: 0.70 against 0.51 ms per step on one
+            # rank -- more than the top-k exchange it could hide costs.)
+            ix.shard_search_device(comm, q.data_ptr(), B, k, nprobe, out_ids.data_ptr(), out_dis.data_ptr(), stream)
         elif multi["on"]:
             s_ = i % multi["n"]
             ix.search_device(q.data_ptr(), B, k, nprobe, xs_out[s_][0].data_ptr(), xs_out[s_][1].data_ptr(), xs[s_].cuda_stream)
@@ -600,7 +602,7 @@ def main():
                                 "qps": round(qps, 1) if routed_now else None, "stage_ms_rank0": fam_r,
                                 "note": "routed_pairs = (query, rank) pairs a rank served: its share of the list-scan work; W x batch when nothing can be pruned"},
                      "replicated": {"qps": round(args.steps * B / float(t.item()), 1), "ms_per_step": round(float(t.item()) / args.steps * 1e3, 4),
-                                    "note": "msvs_shard_search_device_async: every rank works through the SAME batch (strong scaling of one batch's latency)"}}
+                                    "note": "msvs_shard_search_device: every rank works through the SAME batch (strong scaling of one batch's latency)"}}
 
     # ---- roofline of the dominant kernel: the list scan = h16_sample_kernel + h16_scan_kernel (HIP events on the launch
     # stream, separate pass over the same steps)
@@ -1489,7 +1491,7 @@ def main():
                                         "point-to-point exchange of the surviving (query, rank) pairs, local search, results back, merge at home "
                                         "(msvs_shard_search_routed_device_async: two steps in flight); transport: %s" % (world, B, comm_kind)) if routed else
                                        ("lists %% %d, coarse quantiser by query, probe (+ coarse distance word) and packed top-k all-gathers, "
-                                        "two batches in flight (msvs_shard_search_device_async); transport: %s"
+                                        "one stream-ordered call per batch (msvs_shard_search_device); transport: %s"
                                         % (world, comm_kind))) if world > 1 else
                                       ("single GPU" if n_streams == 1 else "single GPU, %d independent batches in flight on %d HIP streams" % (n_streams, n_streams)),
                        "streams": n_streams, "data_model": data_desc},
