@@ -387,6 +387,8 @@ def main():
     ap.add_argument("--c4-rows", type=int, default=12_500_000, help="rows per GPU of the C4 leg (100M / 8)")
     ap.add_argument("--big-rows", type=int, default=10_000_000, help="rows of the C3 / C5 legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--leg-timeout", type=int, default=480, help="N > 1: seconds the collective c4_sharded leg may take before the headline "
+                                                                   "line is printed without it")
     ap.add_argument("--test-single-device", action="store_true",
                     help="N > 1 ranks all on cuda:0 with a gloo transport under msvs_shard_search_device: exercises the N > 1 "
                          "code path of this script on a one-GPU box (not a measurement)")
@@ -685,9 +687,8 @@ def main():
     # IVFFLAT index (N = 8: 100M x 1536, nlist 16384, nprobe 64, lists list_id % 8).  Every rank is shown every row of the
     # index (generated on its device, chunk by chunk) and keeps the rows of its lists; the coarse centroids are the blob centres
     # of the data model (identical on every rank: nothing to train or broadcast).
-    def c4_sharded():
-        d4, nl_g, npb = 1536, 2048 * world, 8 * world
-        total_rows = args.c4_rows * world
+    def c4_sharded_build():
+        d4, nl_g = 1536, 2048 * world
         mdl = _latent_model(d4, 99, dev, nl_g)
         cent = (mdl[0] @ mdl[1]).contiguous()
         six = capi.Index(capi.INDEX_IVFFLAT, capi.METRIC_IP, d4, "ncentroids=%d,shard_rank=%d,shard_world=%d" % (nl_g, rank, world))
@@ -709,6 +710,24 @@ def main():
         six.build()
         torch.cuda.synchronize()
         build_s = time.time() - t1
+        return six, mdl, build_s
+
+    def c4_sharded():
+        # every rank builds; the ranks agree that ALL of them did before the first collective search
+        built, err = None, None
+        try:
+            built = c4_sharded_build()
+        except Exception as e:  # noqa: BLE001 -- reported below, on every rank alike
+            err = e
+        okt = torch.tensor([1 if built is not None else 0], device="cpu" if args.test_single_device else dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            if built is not None:
+                built[0].close()
+            raise RuntimeError("c4_sharded: a rank could not build its shard (%r)" % (err,))
+        six, mdl, build_s = built
+        d4, nl_g, npb = 1536, 2048 * world, 8 * world
+        total_rows = args.c4_rows * world
         res = {"workload": "IVFFLAT %d x %d f32 inner product, nlist %d, nprobe %d, lists list_id %% %d, top-%d; weak scaling family "
                            "(12.5M rows generated on each rank's device, 2048 lists, 8 probes per rank; every rank searches the same "
                            "batch, so qps stays ~constant while the table grows with N)" % (total_rows, d4, nl_g, npb, world, k),
@@ -736,7 +755,33 @@ def main():
         return res
 
     if world > 1 and not args.headline_only and "c4" not in skip:
+        # The leg is COLLECTIVE: a rank that fails in it (out of memory while it builds 12.5M x 1536 rows, a lost peer) leaves the others
+        # waiting in an all-gather, and the run would end without its line.  The headline is measured by now: a watchdog prints it
+        # (with the leg marked as timed out) and ends the process if the leg has not come back in --leg-timeout seconds.
+        import threading
+
+        def bail():
+            if rank == 0:
+                emit({"metric": "QPS at recall@10>=0.95, 1Mx768-d L2 top-10 (IVFFLAT nlist=1024 nprobe=%d)" % nprobe,
+                      "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                      "scaling": "weak" if routed else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "IVFFLAT nlist=%d, %dx%d f32, L2, nprobe=%d, top-%d, batch %d queries/step "
+                                             "(BASELINE.json configs[1])" % (nlist, n, d, nprobe, k, B),
+                                 "rows": n, "dim": d, "nlist": nlist, "nprobe": nprobe, "k": k, "batch": B,
+                                 "parallelism": "lists %% %d, %s; transport: %s" % (world, "routed" if routed else "replicated", comm_kind),
+                                 "streams": 1, "data_model": data_desc},
+                      "recall_at_10": None, "p50_ms_batch1": None, "roofline": roof, "multi_gpu": multi_gpu, "cpu_baseline": None,
+                      "c4_sharded": {"error": "the collective leg did not return within %d s: line printed by the watchdog" % args.leg_timeout},
+                      "setup_s": round(setup_s, 1)})
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+        wd = threading.Timer(args.leg_timeout, bail)
+        wd.daemon = True
+        wd.start()
         leg("c4_sharded", c4_sharded, extra)
+        wd.cancel()
 
     # ---- the same index at other step sizes (20 timed steps each)
     def other_batches():
