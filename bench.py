@@ -14,6 +14,9 @@ N > 1    : one process per GPU, libmsvs owns the RCCL communicator, lists sharde
            when N servers share one index, not a larger table).  The replicated form (msvs_shard_search_device: every rank works
            through the same batch; strong scaling of one batch) is timed beside it under legs.multi_gpu.replicated.
            `python bench.py --gpus N` without a launcher spawns its N ranks itself (torch.distributed.run on 127.0.0.1).
+           The collective C4 leg that follows the headline at N > 1 (12.5M x 1536 rows per rank) is guarded: the ranks agree on their
+           builds before the first collective search, and if the leg has not returned after --leg-timeout seconds (a rank lost) the
+           measured headline line is printed without it.
 
 Data: there is no network, so vectors are synthetic.  The headline (`value`) runs on SURVEY 8d's clustered model -- 1024 gaussian
 blobs, sigma 0.3, in R^768 (`blobs03`) -- at the configuration's nprobe = 32 (recall@10 measured against the exact scan of the
