@@ -214,7 +214,7 @@ struct Options
     double lat_items = 0;     // few-query path: work items of stage 2 per query (0 = planned: two blocks per CU over the call)
     double lat_prune = 1;     // few-query path (L2, no filter): probed lists the list radius rules out get no work items (0: off)
     double h16_preprune = 1;  // shadow list scan (L2, no filter): pairs the list radius alone rules out leave before the sample launch (0: off)
-    double h16_group_appends = 8; // shadow passes: tiles of at most this many queries append their survivors with one atomic per (wavefront, query) (0: one per record)
+    double h16_group_appends = 32; // shadow passes: tiles of at most this many queries append their survivors with one atomic per (wavefront, query) (0: one per record)
     double h16_feedback = 1;  // shadow list scan: the second pruning stage is skipped while the last search of the index (same batch shape) came out of the
                               // pre-pruning with too few pairs for it to pay (0: decided from nq * nprobe alone, as before round 6)
     double h16_prune = 1;     // shadow list scan (L2): drop (query, list) pairs that provably cannot hold one of the query's k nearest rows when the lists are probed by more than a tile of queries (0: off, 2: always)
